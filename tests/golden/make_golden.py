@@ -1,0 +1,395 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference (h3jia/bayesfast).
+
+Runs only in the build container, where /root/reference exists.  It copies the reference package to a
+scratch directory, builds its four Cython extensions with a plain setuptools script, installs two
+environment shims (removed NumPy aliases; a stub numdifftools) and then records inputs/outputs of the
+reference's own functions on the hot path.  Nothing of the reference's source enters this repository:
+the .npz files hold data only (inputs, coefficients the reference fitted, outputs, logged random draws).
+
+Usage:  python tests/golden/make_golden.py [--ref /root/reference] [--work /tmp/bfref]
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from specio import flatten_spec, flatten_poly  # noqa: E402
+
+BUILD_EXT = r'''
+import numpy as np
+from setuptools import setup, Extension
+from Cython.Build import cythonize
+names = ['bayesfast/modules/_poly', 'bayesfast/transforms/_constraint', 'bayesfast/utils/_sobol',
+         'bayesfast/utils/_cubic']
+exts = [Extension(n.replace('/', '.'), [n + '.pyx'], include_dirs=[np.get_include()],
+                  extra_compile_args=['-fopenmp', '-O3'], extra_link_args=['-fopenmp']) for n in names]
+setup(ext_modules=cythonize(exts, language_level='3'))
+'''
+
+
+def prepare_reference(ref, work):
+    pkg = os.path.join(work, 'bayesfast')
+    if not os.path.exists(os.path.join(pkg, 'modules')) or not any(
+            f.endswith('.so') for f in os.listdir(os.path.join(pkg, 'modules'))):
+        os.makedirs(work, exist_ok=True)
+        if os.path.exists(pkg):
+            shutil.rmtree(pkg)
+        shutil.copytree(os.path.join(ref, 'bayesfast'), pkg)
+        with open(os.path.join(work, 'build_ext.py'), 'w') as f:
+            f.write(BUILD_EXT)
+        subprocess.check_call([sys.executable, 'build_ext.py', 'build_ext', '--inplace'], cwd=work,
+                              stdout=subprocess.DEVNULL)
+    # shim 1: NumPy aliases removed in 1.24 that the reference still uses
+    for n, t in (('int', int), ('float', float)):
+        if not hasattr(np, n):
+            setattr(np, n, t)
+    # shim 2: numdifftools is not installed; only Laplace (OptimizeStep) and the reference's tests use it
+    nd = types.ModuleType('numdifftools')
+
+    def _central(f, x, h=1e-6):
+        x = np.atleast_1d(np.asarray(x, dtype=float))
+        f0 = np.atleast_1d(f(x))
+        J = np.empty((f0.size, x.size))
+        for i in range(x.size):
+            e = np.zeros_like(x)
+            e[i] = h
+            J[:, i] = (np.atleast_1d(f(x + e)) - np.atleast_1d(f(x - e))) / (2 * h)
+        return J
+
+    class Gradient:
+        def __init__(self, f, *a, **k):
+            self.f = f
+
+        def __call__(self, x):
+            return _central(self.f, x)[0]
+
+    class Jacobian(Gradient):
+        def __call__(self, x):
+            return _central(self.f, x)
+
+    class Hessian(Gradient):
+        def __call__(self, x):
+            return _central(lambda y: _central(self.f, y)[0], x, 1e-4)
+
+    class Hessdiag(Gradient):
+        def __call__(self, x):
+            return np.diag(Hessian(self.f)(x))
+
+    nd.Gradient, nd.Jacobian, nd.Hessian, nd.Hessdiag = Gradient, Jacobian, Hessian, Hessdiag
+    sys.modules['numdifftools'] = nd
+    sys.path.insert(0, work)
+    import bayesfast  # noqa: F401
+    return bayesfast
+
+
+# ---------------------------------------------------------------------------------------------------
+
+def poly_spec_from_reference(pm):
+    """PolyModel -> spec dict (data only)."""
+    cfgs = [dict(order=c.order, input_mask=np.array(c.input_mask), output_mask=np.array(c.output_mask),
+                 coef=np.array(c._coef)) for c in pm.configs]
+    poly = dict(input_size=pm._input_size, output_size=pm._output_size, configs=cfgs,
+                use_bound=bool(pm._use_bound and not pm._all_linear))
+    if poly['use_bound']:
+        poly.update(mu=np.array(pm._mu), hess=np.array(pm._hess), alpha=float(pm._alpha),
+                    f_mu=np.array(pm._f_mu))
+    return poly
+
+
+def density_spec_from_reference(den):
+    su = den._surrogate_list[0]
+    d = int(den.input_size)
+    spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None,
+                poly=poly_spec_from_reference(su), use_decay=bool(den._use_decay))
+    if den._input_scales is not None:
+        spec['ranges'] = np.array(den._input_scales)
+        hb = den._hard_bounds
+        if isinstance(hb, bool):
+            hb = hb * np.ones((d, 2), np.uint8)
+        spec['hard_bounds'] = np.array(hb, dtype=np.uint8)
+    if su._input_scales is not None:
+        spec['su_lo'] = np.array(su._input_scales[:, 0])
+        spec['su_diff'] = np.array(su._input_scales_diff)
+    if den._use_decay:
+        spec.update(decay_mu=np.array(den._mu), decay_hess=np.array(den._hess),
+                    decay_alpha2=float(den._alpha_2), decay_gamma=float(den._gamma))
+    return spec
+
+
+class LoggingGenerator:
+    """Wraps a np.random.Generator and records the draws the samplers consume."""
+
+    def __init__(self, g):
+        self._g = g
+        self.normals = []
+        self.uniforms = []
+
+    def normal(self, size=None):
+        v = self._g.normal(size=size)
+        self.normals.extend(np.atleast_1d(v).tolist())
+        return v
+
+    def uniform(self):
+        v = self._g.uniform()
+        self.uniforms.append(float(v))
+        return v
+
+    def integers(self, *a, **k):
+        return self._g.integers(*a, **k)
+
+    @property
+    def bit_generator(self):
+        return self._g.bit_generator
+
+
+def make_density(bf, d, seed, scales=False, decay=False, cubic=0.1, n_fit_mult=3, surrogate='quadratic',
+                 su_scales=False):
+    """A reference Density whose single module is replaced by a fitted PolyModel logp surrogate."""
+    from bayesfast.modules import PolyModel
+    rng = np.random.default_rng(seed)
+    Pm = np.eye(d) + 0.3 * rng.normal(size=(d, d)) / np.sqrt(d)
+    Pm = Pm @ Pm.T
+
+    def f(x):
+        return -0.5 * x @ Pm @ x - cubic * np.sum(x**3) / d
+
+    def j(x):
+        return (-(Pm @ x) - 3 * cubic * x**2 / d)[None]
+
+    kw = {}
+    if scales:
+        lo, hi = -6. - rng.uniform(size=d), 7. + rng.uniform(size=d)
+        kw['input_scales'] = np.stack([lo, hi], 1)
+        hb = np.zeros((d, 2), int)
+        hb[0] = (1, 1)
+        hb[1 % d] = (1, 0)
+        hb[2 % d] = (0, 1)
+        kw['hard_bounds'] = hb
+    skw = {}
+    if su_scales:
+        skw['input_scales'] = np.stack([-2. - rng.uniform(size=d), 3. + rng.uniform(size=d)], 1)
+    su = PolyModel(surrogate, input_size=d, output_size=1, input_vars='x', output_vars='logp', **skw)
+    den = bf.Density(density_name='logp', module_list=[bf.Module(fun=f, jac=j, input_vars='x', output_vars='logp')],
+                     surrogate_list=[su], input_vars='x', input_shapes=d,
+                     decay_options=dict(use_decay=bool(decay)), **kw)
+    xs = rng.normal(size=(n_fit_mult * int(su.n_param), d))
+    vds = [den.fun(x, original_space=True, use_surrogate=False) for x in xs]
+    den.fit(vds)
+    return den, rng
+
+
+def gen_poly_kernels(bf, out):
+    from bayesfast.modules import _poly
+    rng = np.random.default_rng(11)
+    z = {}
+    for n in (2, 3, 5, 8):  # n = 1 would overflow the reference's size_t loop bound n - 2 (_poly.pyx:98)
+        m = 2
+        x = rng.normal(size=n)
+        z['n%d.x' % n] = x
+        xs = rng.normal(size=(4, n))
+        z['n%d.xs' % n] = xs
+        for order, npk, shape in (('quadratic', n * (n + 1) // 2, (n, n)), ('cubic_2', n * n, (n, n)),
+                                  ('cubic_3', n * (n - 1) * (n - 2) // 6, (n, n, n))):
+            a = rng.normal(size=(m, npk))
+            coef = np.zeros((m,) + shape)
+            for i in range(m):
+                getattr(_poly, '_set_' + order)(np.ascontiguousarray(a[i]), coef[i], n)
+            f = np.empty(m)
+            jj = np.empty((m, n))
+            getattr(_poly, '_' + order + '_f')(x, coef, f, m, n)
+            getattr(_poly, '_' + order + '_j')(x, coef, jj, m, n)
+            A = np.empty((4, npk))
+            getattr(_poly, '_lsq_' + order)(xs, A, 4, n)
+            k = 'n%d.%s.' % (n, order)
+            z[k + 'a'], z[k + 'coef'], z[k + 'f'], z[k + 'j'], z[k + 'lsq'] = a, coef, f, jj, A
+    np.savez_compressed(os.path.join(out, 'poly_kernels.npz'), **z)
+
+
+def gen_constraint(bf, out):
+    from bayesfast.transforms import _constraint as cs
+    rng = np.random.default_rng(12)
+    n = 8
+    ranges = np.stack([-1 - rng.uniform(size=n), 2 + rng.uniform(size=n)], 1)
+    hb = np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * 2, dtype=np.uint8)
+    xt = rng.normal(size=(6, n)) * 2
+    z = dict(ranges=ranges, hard_bounds=hb, x_trans=xt)
+    for nm in ('f', 'j', 'jj'):
+        o = np.empty_like(xt)
+        getattr(cs, '_to_original_%s2' % nm)(xt, ranges, o, hb, n, xt.shape[0])
+        z['to_' + nm] = o
+    xo = z['to_f']
+    for nm in ('f', 'j', 'jj'):
+        o = np.empty_like(xo)
+        getattr(cs, '_from_original_%s2' % nm)(np.ascontiguousarray(xo), ranges, o, hb, n, xo.shape[0])
+        z['from_' + nm] = o
+    np.savez_compressed(os.path.join(out, 'constraint.npz'), **z)
+
+
+def gen_polymodel(bf, out):
+    """Masked multi-output PolyModel: fit + fun/jac inside and outside the bound (poly.py:440-589)."""
+    from bayesfast.modules import PolyModel, PolyConfig
+    rng = np.random.default_rng(13)
+    d, m = 6, 3
+    configs = [PolyConfig('linear'), PolyConfig('quadratic', input_mask=[0, 2, 3, 5], output_mask=[0, 2]),
+               PolyConfig('cubic-2', input_mask=[1, 2, 4], output_mask=[1]),
+               PolyConfig('cubic-3', input_mask=[0, 1, 2, 3, 4], output_mask=[0, 1, 2])]
+    pm = PolyModel(configs, input_size=d, output_size=m, bound_options=dict(alpha_p=90.))
+    npts = 120
+    x = rng.normal(size=(npts, d))
+    W = rng.normal(size=(d, m))
+    y = np.tanh(x @ W) + 0.1 * (x**2) @ np.abs(W) + 0.05 * rng.normal(size=(npts, m))
+    logp = -0.5 * np.sum(x**2, 1)
+    pm.fit(x, y, logp)
+    xe = np.concatenate([rng.normal(size=(6, d)) * 0.5, rng.normal(size=(6, d)) * 4.0])
+    f = np.array([pm._fun(xx) for xx in xe])
+    j = np.array([pm._jac(xx) for xx in xe])
+    beta = np.array([np.dot(np.dot(xx - pm._mu, pm._hess), xx - pm._mu)**0.5 for xx in xe])
+    assert (beta > pm._alpha).any() and (beta < pm._alpha).any()
+    z = dict(x_fit=x, y_fit=y, logp_fit=logp, x_eval=xe, f=f, j=j, beta=beta, n_param=int(pm.n_param),
+             alpha_p=90.)
+    z.update(flatten_poly(poly_spec_from_reference(pm)))
+    # weighted fit of a single-output quadratic model
+    pm2 = PolyModel('quadratic', input_size=4, output_size=1)
+    x2 = rng.normal(size=(40, 4))
+    y2 = np.sum(x2**2, 1, keepdims=True) + x2[:, :1] * x2[:, 1:2] + 0.01 * rng.normal(size=(40, 1))
+    w2 = rng.uniform(0.5, 1.5, size=40)
+    pm2.fit(x2, y2, logp=y2[:, 0], w=w2)
+    z.update(flatten_poly(poly_spec_from_reference(pm2), 'w.poly.'))
+    z.update({'w.x_fit': x2, 'w.y_fit': y2, 'w.w': w2})
+    np.savez_compressed(os.path.join(out, 'polymodel.npz'), **z)
+
+
+def gen_density(bf, out):
+    """Density.logp_and_grad with every feature combination (density.py:724-754)."""
+    z = {}
+    cases = dict(plain=dict(), decay=dict(decay=True), scales=dict(scales=True), su=dict(su_scales=True),
+                 full=dict(scales=True, decay=True, su_scales=True))
+    for name, kw in cases.items():
+        den, rng = make_density(bf, 5, 21, **kw)
+        spec = density_spec_from_reference(den)
+        # points near and far (far ones leave the surrogate bound and the decay radius)
+        xt = np.concatenate([rng.normal(size=(5, 5)) * 0.3, rng.normal(size=(5, 5)) * (1.5 if kw.get('scales') else 4.)])
+        lt, gt = zip(*[den.logp_and_grad(x, original_space=False, use_surrogate=True) for x in xt])
+        xo = den.to_original(xt)
+        lo, go = zip(*[den.logp_and_grad(x, original_space=True, use_surrogate=True) for x in xo])
+        z.update(flatten_spec(spec, name + '.'))
+        z.update({name + '.x_trans': xt, name + '.logp_trans': np.array(lt), name + '.grad_trans': np.array(gt),
+                  name + '.x_orig': xo, name + '.logp_orig': np.array(lo), name + '.grad_orig': np.array(go)})
+    # headline-shaped case: d = 64 quadratic logp surrogate, bound on, no scales
+    den, rng = make_density(bf, 64, 22, n_fit_mult=2)
+    spec = density_spec_from_reference(den)
+    xt = np.concatenate([rng.normal(size=(6, 64)), rng.normal(size=(2, 64)) * 3.])
+    lt, gt = zip(*[den.logp_and_grad(x, original_space=False, use_surrogate=True) for x in xt])
+    z.update(flatten_spec(spec, 'd64.'))
+    z.update({'d64.x_trans': xt, 'd64.logp_trans': np.array(lt), 'd64.grad_trans': np.array(gt)})
+    np.savez_compressed(os.path.join(out, 'density.npz'), **z)
+
+
+def gen_sampler(bf, out):
+    """Leapfrog states and logged-RNG NUTS/HMC trajectories (integration.py, nuts.py, hmc.py, base_hmc.py)."""
+    from bayesfast.samplers import NUTS, HMC, NTrace, HTrace
+    from bayesfast.samplers.hmc_utils.integration import CpuLeapfrogIntegrator
+    from bayesfast.samplers.hmc_utils.metrics import QuadMetricDiag
+    z = {}
+    for name, d, kw, n_iter, n_warmup, n_chain in (('full5', 5, dict(scales=True, decay=True, su_scales=True), 40, 25, 3),
+                                                   ('plain16', 16, dict(), 40, 25, 2),
+                                                   ('d64', 64, dict(n_fit_mult=2), 30, 20, 2)):
+        den, rng = make_density(bf, d, 31 + d, **kw)
+        spec = density_spec_from_reference(den)
+        z.update(flatten_spec(spec, name + '.'))
+
+        def lg(x):
+            return den.logp_and_grad(x, original_space=False, use_surrogate=True)
+
+        # (iv) single leapfrog steps
+        var = rng.uniform(0.5, 2., size=d)
+        integ = CpuLeapfrogIntegrator(QuadMetricDiag(var), lg)
+        q0 = rng.normal(size=d) * 0.5
+        p0 = rng.normal(size=d)
+        s0 = integ.compute_state(q0, p0)
+        s1 = integ.step(0.13, s0)
+        s2 = integ.step(-0.07, s1)
+        for tag, s in (('s0', s0), ('s1', s1), ('s2', s2)):
+            for fld in ('q', 'p', 'velocity', 'q_grad', 'energy', 'logp'):
+                z['%s.lf.%s.%s' % (name, tag, fld)] = np.asarray(getattr(s, fld))
+        z[name + '.lf.var'] = var
+        z[name + '.lf.eps'] = np.array([0.13, -0.07])
+
+        # (v) NUTS trajectories with logged draws
+        x0 = rng.normal(size=(n_chain, d)) * 0.5
+        z[name + '.x0'] = x0
+        z[name + '.n_iter'], z[name + '.n_warmup'] = np.asarray(n_iter), np.asarray(n_warmup)
+        for c in range(n_chain):
+            t = NTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, x_0=x0.copy(), random_generator=1234)
+            t._init_chain(c)
+            log = LoggingGenerator(t._random_generator)
+            t._random_generator = log
+            NUTS(logp_and_grad=lg, sample_trace=t).run(verbose=False)
+            k = '%s.nuts%d.' % (name, c)
+            z[k + 'samples'] = t.samples
+            z[k + 'normals'] = np.array(log.normals)
+            z[k + 'uniforms'] = np.array(log.uniforms)
+            for si in t.stats.stats_items:
+                z[k + si] = np.array(getattr(t.stats, '_' + si), dtype=float)
+            z[k + 'final_var'] = np.array(t.metric._var)
+            z[k + 'n_call'] = np.asarray(t.n_call)
+        # HMC
+        for c in range(2):
+            t = HTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, n_int_step=8, x_0=x0.copy(),
+                       random_generator=4321)
+            t._init_chain(c)
+            log = LoggingGenerator(t._random_generator)
+            t._random_generator = log
+            HMC(logp_and_grad=lg, sample_trace=t).run(verbose=False)
+            k = '%s.hmc%d.' % (name, c)
+            z[k + 'samples'] = t.samples
+            z[k + 'normals'] = np.array(log.normals)
+            z[k + 'uniforms'] = np.array(log.uniforms)
+            for si in t.stats.stats_items:
+                z[k + si] = np.array(getattr(t.stats, '_' + si), dtype=float)
+    # a deliberately hard case: huge step size => divergences and early U-turns
+    den, rng = make_density(bf, 5, 77)
+    spec = density_spec_from_reference(den)
+    z.update(flatten_spec(spec, 'div5.'))
+    x0 = rng.normal(size=(1, 5))
+    t = NTrace(n_chain=1, n_iter=30, n_warmup=10, x_0=x0.copy(), random_generator=99, step_size=40.,
+               max_change=50.)
+    t._init_chain(0)
+    log = LoggingGenerator(t._random_generator)
+    t._random_generator = log
+    NUTS(logp_and_grad=lambda x: den.logp_and_grad(x, original_space=False, use_surrogate=True),
+         sample_trace=t).run(verbose=False)
+    z['div5.x0'] = x0
+    z['div5.nuts0.samples'] = t.samples
+    z['div5.nuts0.normals'] = np.array(log.normals)
+    z['div5.nuts0.uniforms'] = np.array(log.uniforms)
+    for si in t.stats.stats_items:
+        z['div5.nuts0.' + si] = np.array(getattr(t.stats, '_' + si), dtype=float)
+    np.savez_compressed(os.path.join(out, 'sampler.npz'), **z)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--work', default='/tmp/bfref')
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    bf = prepare_reference(a.ref, a.work)
+    gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
+                density=gen_density, sampler=gen_sampler)
+    for k, g in gens.items():
+        if a.only and k != a.only:
+            continue
+        g(bf, HERE)
+        print('wrote', k)
+
+
+if __name__ == '__main__':
+    main()

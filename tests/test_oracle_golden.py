@@ -1,0 +1,212 @@
+"""Pins the CPU oracle (oracle/bf_oracle.c + oracle/oracle.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from specio import rebuild_spec, rebuild_poly
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+@pytest.fixture(scope='module')
+def kern():
+    return np.load(os.path.join(G, 'poly_kernels.npz'))
+
+
+@pytest.mark.parametrize('n', [2, 3, 5, 8])
+@pytest.mark.parametrize('order', ['quadratic', 'cubic_2', 'cubic_3'])
+def test_poly_kernels(kern, n, order):
+    """_poly.pyx value / Jacobian / design block / coefficient scatter, bitwise or to 1 ulp."""
+    L = orc.lib()
+    k = 'n%d.%s.' % (n, order)
+    x = np.ascontiguousarray(kern['n%d.x' % n])
+    xs = np.ascontiguousarray(kern['n%d.xs' % n])
+    a, coef = kern[k + 'a'], np.ascontiguousarray(kern[k + 'coef'])
+    m = a.shape[0]
+    # scatter
+    shape = coef.shape[1:]
+    for i in range(m):
+        c = np.zeros(shape)
+        getattr(L, 'bfo_set_' + order)(_p(np.ascontiguousarray(a[i])), _p(c), n)
+        assert np.array_equal(c, coef[i])
+    f = np.empty(m)
+    j = np.empty((m, n))
+    getattr(L, 'bfo_%s_f' % order)(_p(x), _p(coef), _p(f), m, n)
+    getattr(L, 'bfo_%s_j' % order)(_p(x), _p(coef), _p(j), m, n)
+    np.testing.assert_allclose(f, kern[k + 'f'], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(j, kern[k + 'j'], rtol=1e-14, atol=1e-15)
+    A = np.empty_like(kern[k + 'lsq'])
+    if A.size:
+        getattr(L, 'bfo_lsq_' + order)(_p(xs), _p(A), xs.shape[0], n)
+    assert np.array_equal(A, kern[k + 'lsq'])
+
+
+def test_constraint():
+    z = np.load(os.path.join(G, 'constraint.npz'))
+    L = orc.lib()
+    ranges, hb = np.ascontiguousarray(z['ranges']), np.ascontiguousarray(z['hard_bounds'])
+    n = ranges.shape[0]
+    hbp = hb.ctypes.data_as(C.POINTER(C.c_uint8))
+    for i, xt in enumerate(z['x_trans']):
+        xt = np.ascontiguousarray(xt)
+        for nm in ('f', 'j', 'jj'):
+            o = np.empty(n)
+            getattr(L, 'bfo_to_original_' + nm)(_p(xt), _p(ranges), _p(o), hbp, n)
+            np.testing.assert_allclose(o, z['to_' + nm][i], rtol=1e-14, atol=0)
+        xo = np.ascontiguousarray(z['to_f'][i])
+        for nm in ('f', 'j', 'jj'):
+            o = np.empty(n)
+            assert getattr(L, 'bfo_from_original_' + nm)(_p(xo), _p(ranges), _p(o), hbp, n) == 0
+            np.testing.assert_allclose(o, z['from_' + nm][i], rtol=1e-13, atol=0)
+    # out of bound is reported (the reference raises ValueError, _constraint.pyx:27-28)
+    bad = np.ascontiguousarray(z['to_f'][0]).copy()
+    bad[0] = ranges[0, 1] + 1.
+    assert L.bfo_from_original_f(_p(bad), _p(ranges), _p(np.empty(n)), hbp, n) == 1
+
+
+def _independent(order, coef):
+    """The entries the kernels read.  PolyConfig._set fills an np.empty block (modules/poly.py:146), so the
+    other entries of the reference's dense coefficient arrays are uninitialised memory."""
+    n = coef.shape[-1]
+    if order == 'quadratic':
+        return coef[..., np.triu(np.ones((n, n), bool))]
+    if order == 'cubic-3':
+        i, j, k = np.meshgrid(*[np.arange(n)] * 3, indexing='ij')
+        return coef[..., (i < j) & (j < k)]
+    return coef
+
+
+def test_polymodel_eval_and_fit():
+    z = np.load(os.path.join(G, 'polymodel.npz'))
+    poly = rebuild_poly(z)
+    f, j = orc.poly_fun_and_jac(poly, z['x_eval'])
+    np.testing.assert_allclose(f, z['f'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(j, z['j'], rtol=1e-11, atol=1e-12)
+    # fit restatement: same lstsq, same scatter, same bound statistics
+    fit = orc.poly_fit(poly, z['x_fit'], z['y_fit'], z['logp_fit'], bound_options=dict(alpha_p=float(z['alpha_p'])))
+    for c0, c1 in zip(poly['configs'], fit['configs']):
+        np.testing.assert_allclose(_independent(c0['order'], c1['coef']), _independent(c0['order'], c0['coef']),
+                                   rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(fit['mu'], poly['mu'], rtol=1e-13)
+    np.testing.assert_allclose(fit['hess'], poly['hess'], rtol=1e-10)
+    np.testing.assert_allclose(fit['alpha'], poly['alpha'], rtol=1e-12)
+    np.testing.assert_allclose(fit['f_mu'], poly['f_mu'], rtol=1e-9)
+    assert sum(orc.a_size(c['order'], len(c['input_mask'])) for c in poly['configs']) == int(z['n_param'])
+    # weighted single-output fit
+    pw = rebuild_poly(z, 'w.poly.')
+    fw = orc.poly_fit(pw, z['w.x_fit'], z['w.y_fit'], z['w.y_fit'][:, 0], w=z['w.w'])
+    for c0, c1 in zip(pw['configs'], fw['configs']):
+        np.testing.assert_allclose(_independent(c0['order'], c1['coef']), _independent(c0['order'], c0['coef']),
+                                   rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(fw['alpha'], pw['alpha'], rtol=1e-12)
+    with pytest.raises(ValueError):
+        orc.poly_fit(pw, z['w.x_fit'][:5], z['w.y_fit'][:5])
+
+
+@pytest.mark.parametrize('case', ['plain', 'decay', 'scales', 'su', 'full', 'd64'])
+def test_density_logp_and_grad(case):
+    z = np.load(os.path.join(G, 'density.npz'))
+    spec = rebuild_spec(z, case + '.')
+    lp, g = orc.logp_and_grad(spec, z[case + '.x_trans'])
+    np.testing.assert_allclose(lp, z[case + '.logp_trans'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g, z[case + '.grad_trans'], rtol=1e-11, atol=1e-11)
+    if case + '.x_orig' in z.files:
+        lp, g = orc.logp_and_grad(spec, z[case + '.x_orig'], original_space=True)
+        np.testing.assert_allclose(lp, z[case + '.logp_orig'], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(g, z[case + '.grad_orig'], rtol=1e-11, atol=1e-11)
+
+
+@pytest.fixture(scope='module')
+def samp():
+    return np.load(os.path.join(G, 'sampler.npz'))
+
+
+@pytest.mark.parametrize('name', ['full5', 'plain16', 'd64'])
+def test_leapfrog(samp, name):
+    spec = rebuild_spec(samp, name + '.')
+    var, eps = samp[name + '.lf.var'], samp[name + '.lf.eps']
+    for a, b, e in (('s0', 's1', eps[0]), ('s1', 's2', eps[1])):
+        s = {f: samp['%s.lf.%s.%s' % (name, a, f)] for f in ('q', 'p', 'q_grad')}
+        r = orc.leapfrog(spec, var, e, s['q'], s['p'], s['q_grad'])
+        for f, k in (('q', 'q'), ('p', 'p'), ('velocity', 'v'), ('q_grad', 'grad'), ('energy', 'energy'), ('logp', 'logp')):
+            np.testing.assert_allclose(r[k], samp['%s.lf.%s.%s' % (name, b, f)], rtol=1e-11, atol=1e-12)
+
+
+def _replay_nuts(samp, name, c, **kw):
+    spec = rebuild_spec(samp, name + '.')
+    k = '%s.nuts%d.' % (name, c)
+    x0 = samp[name + '.x0'][c]
+    n_iter = samp[k + 'samples'].shape[0]
+    n_warmup = int(np.sum(samp[k + 'warmup']))
+    chain = orc.Chain(x0, **kw)
+    rng = orc.make_rng('replay', normals=samp[k + 'normals'], uniforms=samp[k + 'uniforms'])
+    mc = kw.pop('max_change', None)
+    return orc.nuts_run(spec, chain, rng, n_iter, n_warmup), chain, rng, k
+
+
+@pytest.mark.parametrize('name,c', [('plain16', 0), ('plain16', 1), ('d64', 0), ('d64', 1), ('full5', 0),
+                                     ('full5', 1), ('full5', 2)])
+def test_nuts_replay(samp, name, c):
+    """T1: feeding the reference's logged draws to the restatement reproduces its trajectory."""
+    (samples, st), chain, rng, k = _replay_nuts(samp, name, c)
+    for f in ('tree_depth', 'tree_size', 'diverging', 'warmup'):
+        assert np.array_equal(st[f], samp[k + f]), f
+    # every logged draw consumed, none missing: the draw ORDER of the recursion is reproduced
+    assert rng[0].i_uniform == samp[k + 'uniforms'].size and rng[0].i_normal == samp[k + 'normals'].size
+    np.testing.assert_allclose(samples, samp[k + 'samples'], rtol=1e-9, atol=1e-9)
+    for f in ('logp', 'energy', 'mean_tree_accept', 'step_size', 'step_size_bar', 'energy_change', 'max_energy_change'):
+        np.testing.assert_allclose(st[f], samp[k + f], rtol=1e-7, atol=1e-7, err_msg=f)
+    np.testing.assert_allclose(chain.vec('var'), samp[k + 'final_var'], rtol=1e-9)
+    # n_call accounting of NTrace (samplers/sample_trace.py:529-530)
+    assert int(st['tree_size'][1:].sum()) + samples.shape[0] + 1 == int(samp[k + 'n_call'])
+
+
+def test_nuts_replay_divergent(samp):
+    """Huge step size: divergences (|dE| >= max_change) and immediate U-turns, nuts.py:119-132."""
+    spec = rebuild_spec(samp, 'div5.')
+    k = 'div5.nuts0.'
+    chain = orc.Chain(samp['div5.x0'][0], step_size=40.)
+    rng = orc.make_rng('replay', normals=samp[k + 'normals'], uniforms=samp[k + 'uniforms'])
+    samples, st = orc.nuts_run(spec, chain, rng, 30, 10, max_change=50.)
+    assert st['diverging'].sum() >= 1
+    for f in ('tree_depth', 'tree_size', 'diverging'):
+        assert np.array_equal(st[f], samp[k + f]), f
+    np.testing.assert_allclose(samples, samp[k + 'samples'], rtol=1e-9, atol=1e-9)
+    assert rng[0].i_uniform == samp[k + 'uniforms'].size
+
+
+@pytest.mark.parametrize('name,c', [('plain16', 0), ('d64', 1), ('full5', 0)])
+def test_hmc_replay(samp, name, c):
+    spec = rebuild_spec(samp, name + '.')
+    k = '%s.hmc%d.' % (name, c)
+    chain = orc.Chain(samp[name + '.x0'][c])
+    rng = orc.make_rng('replay', normals=samp[k + 'normals'], uniforms=samp[k + 'uniforms'])
+    n_iter = samp[k + 'samples'].shape[0]
+    samples, st = orc.hmc_run(spec, chain, rng, n_iter, int(samp[k + 'warmup'].sum()), n_int_step=8)
+    for f in ('accepted', 'diverging', 'n_int_step'):
+        assert np.array_equal(st[f], samp[k + f]), f
+    assert rng[0].i_uniform == samp[k + 'uniforms'].size
+    # Early warm-up runs 8-step trajectories at step sizes far beyond the leapfrog stability limit, so
+    # summation-order differences (1e-14 at iteration 2) grow exponentially: tight on the head, loose overall.
+    np.testing.assert_allclose(samples[:8], samp[k + 'samples'][:8], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(samples, samp[k + 'samples'], rtol=1e-4, atol=1e-4)
+    for f in ('logp', 'energy', 'accept_stat', 'step_size', 'step_size_bar', 'energy_change'):
+        np.testing.assert_allclose(st[f][:8], samp[k + f][:8], rtol=1e-8, atol=1e-8, err_msg=f)
+        np.testing.assert_allclose(st[f], samp[k + f], rtol=1e-3, atol=1e-3, err_msg=f)
+
+
+def test_xoshiro_reference_vectors():
+    """xoshiro256++ known answers: state {1,2,3,4} (first outputs of the public reference implementation)."""
+    L = orc.lib()
+    s = (C.c_uint64 * 4)(1, 2, 3, 4)
+    got = [L.bfo_xoshiro_next(s) for _ in range(3)]
+    assert got == [41943041, 58720359, 3588806011781223]
