@@ -1,0 +1,100 @@
+"""ctypes binding of libbfhip.so (include/bfhip.h).  The HIP extension is mandatory: there is no CPU
+fallback, and every compute entry point fails loudly when the library is missing."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbfhip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+SC_FIELDS = ('log_step', 'log_bar', 'hbar', 'mu', 'count', 'fg_n', 'bg_n', 'n_samples', 'prev_update',
+             'adapt_window', 'i_iter', 'error')
+SC_N = len(SC_FIELDS)
+VEC_FIELDS = ('q', 'var', 'fg_mean', 'fg_raw', 'bg_mean', 'bg_raw')
+VEC_N = len(VEC_FIELDS)
+STAT_STRIDE = 11
+NSTATS = ('logp', 'energy', 'tree_depth', 'tree_size', 'mean_tree_accept', 'step_size', 'step_size_bar',
+          'warmup', 'energy_change', 'max_energy_change', 'diverging')
+HSTATS = ('logp', 'energy', 'n_int_step', 'accept_stat', 'accepted', 'step_size', 'step_size_bar', 'warmup',
+          'energy_change', 'diverging')
+MAX_DIM = 128
+MAX_TREEDEPTH = 12
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class DensityDesc(C.Structure):
+    _fields_ = [('d', C.c_int), ('ranges', _dp), ('hard_bounds', _u8p), ('su_lo', _dp), ('su_diff', _dp),
+                ('c0', C.c_double), ('lin', _dp), ('quad', _dp), ('cubic2', _dp), ('cubic3', _dp),
+                ('use_bound', C.c_int), ('mu', _dp), ('hess', _dp), ('alpha', C.c_double), ('f_mu', C.c_double),
+                ('use_decay', C.c_int), ('decay_mu', _dp), ('decay_hess', _dp), ('decay_alpha2', C.c_double),
+                ('decay_gamma', C.c_double)]
+
+
+class SamplerConfig(C.Structure):
+    _fields_ = [('sampler', C.c_int), ('n_warmup', C.c_int), ('max_treedepth', C.c_int), ('n_int_step', C.c_int),
+                ('max_change', C.c_double), ('target_accept', C.c_double), ('gamma', C.c_double), ('k', C.c_double),
+                ('t_0', C.c_double), ('adapt_step_size', C.c_int), ('adapt_metric', C.c_int),
+                ('update_window', C.c_int), ('doubling', C.c_int)]
+
+
+# every symbol include/bfhip.h declares: (restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = {
+    'bfhip_version': (C.c_int, []),
+    'bfhip_last_error': (C.c_char_p, []),
+    'bfhip_ctx_create': (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    'bfhip_ctx_destroy': (None, [_vp]),
+    'bfhip_ctx_set_stream': (C.c_int, [_vp, _vp]),
+    'bfhip_ctx_synchronize': (C.c_int, [_vp]),
+    'bfhip_density_upload': (C.c_int, [_vp, C.POINTER(DensityDesc)]),
+    'bfhip_logp_grad': (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    'bfhip_leapfrog': (C.c_int, [_vp, C.c_int] + [_vp] * 8),
+    'bfhip_sampler_run': (C.c_int, [_vp, C.POINTER(SamplerConfig), C.c_int, C.c_int, _vp, _vp, _vp, C.c_int,
+                                    C.c_int, _vp, _vp, _vp]),
+    'bfhip_rng_seed': (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, _vp]),
+    'bfhip_chain_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp, C.c_double, C.c_int, _vp, _vp]),
+    'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
+    'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
+    'bfhip_solve_spd': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libbfhip.so for gfx950 in tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(['make', '-C', CSRC, '-j4'], stdout=out)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'bayesfast_amd: the HIP extension %s is missing; build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or `make -C bayesfast_amd/csrc`. '
+                'There is no CPU fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class BfhipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().bfhip_last_error().decode()
+        exc = {-1: ValueError, -2: RuntimeError, -4: NotImplementedError}.get(rc, BfhipError)
+        raise exc('bfhip error %d: %s' % (rc, msg))

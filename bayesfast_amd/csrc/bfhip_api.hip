@@ -1,0 +1,225 @@
+// bfhip_api.hip -- context, error reporting, density upload, RNG seeding, chain initialisation.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "bfhip_common.h"
+
+static thread_local char g_err[512] = "";
+
+int bf_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int bfhip_version(void) { return 100; }
+extern "C" const char *bfhip_last_error(void) { return g_err; }
+
+extern "C" int bfhip_ctx_create(bfhip_ctx **out, int device, void *stream) {
+    if (!out) return bf_set_error(BFHIP_ERR_ARG, "bfhip_ctx_create: out is NULL");
+    int n_dev = 0;
+    BF_HIP_CHECK(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return bf_set_error(BFHIP_ERR_ARG, "bfhip_ctx_create: device %d of %d", device, n_dev);
+    BF_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip is built for gfx950 only, found %s", prop.gcnArchName);
+    bfhip_ctx *c = (bfhip_ctx *)calloc(1, sizeof(bfhip_ctx));
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+extern "C" void bfhip_ctx_destroy(bfhip_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->model_buf) (void)hipFree(ctx->model_buf);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    free(ctx);
+}
+
+extern "C" int bfhip_ctx_set_stream(bfhip_ctx *ctx, void *stream) {
+    if (!ctx) return bf_set_error(BFHIP_ERR_ARG, "ctx is NULL");
+    ctx->stream = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" int bfhip_ctx_synchronize(bfhip_ctx *ctx) {
+    if (!ctx) return bf_set_error(BFHIP_ERR_ARG, "ctx is NULL");
+    BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int padded_tiles(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : 8; }
+
+// M (d,d) row-major (optionally transposed) -> A-fragments of the DP x DP zero-padded matrix
+static void to_fragments(const double *M, int d, int DP, bool transpose, double *frag) {
+    const int T = DP / 16, NS = DP / 4;
+    for (int t = 0; t < T; ++t)
+        for (int s = 0; s < NS; ++s)
+            for (int l = 0; l < 64; ++l) {
+                int row = 16 * t + (l & 15), col = 4 * s + (l >> 4);
+                double v = 0.;
+                if (row < d && col < d) v = transpose ? M[(size_t)col * d + row] : M[(size_t)row * d + col];
+                frag[((size_t)t * NS + s) * 64 + l] = v;
+            }
+}
+
+extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds) {
+    if (!ctx || !ds) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: NULL argument");
+    const int d = ds->d;
+    if (d < 1 || d > BFHIP_MAX_DIM) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: d = %d out of [1, %d]", d, BFHIP_MAX_DIM);
+    if (ds->cubic2 || ds->cubic3)
+        return bf_set_error(BFHIP_ERR_UNSUPPORTED, "cubic PolyConfig terms are not implemented on device yet");
+    if (ds->use_bound && (!ds->mu || !ds->hess || !(ds->alpha > 0.)))
+        return bf_set_error(BFHIP_ERR_ARG, "use_bound needs mu, hess and alpha > 0");
+    if (ds->use_decay && (!ds->decay_mu || !ds->decay_hess))
+        return bf_set_error(BFHIP_ERR_ARG, "use_decay needs decay_mu and decay_hess");
+    if ((ds->su_lo == NULL) != (ds->su_diff == NULL)) return bf_set_error(BFHIP_ERR_ARG, "su_lo and su_diff go together");
+    const int T = padded_tiles(d), DP = 16 * T;
+    const size_t MAT = (size_t)DP * DP;
+    const size_t n_dbl = (size_t)PD_N * DP + 3 * MAT;
+    std::vector<double> h(n_dbl, 0.);
+    double *pd = h.data(), *Sf = pd + (size_t)PD_N * DP, *Hf = Sf + MAT, *Hdf = Hf + MAT;
+    for (int i = 0; i < DP; ++i) {
+        pd[PD_RG * DP + i] = 1.;
+        pd[PD_SU_DIFF * DP + i] = 1.;
+    }
+    for (int i = 0; i < d; ++i) {
+        if (ds->ranges) {
+            int lo = ds->hard_bounds ? ds->hard_bounds[2 * i] : 0, hi = ds->hard_bounds ? ds->hard_bounds[2 * i + 1] : 0;
+            pd[PD_KIND * DP + i] = (lo && hi) ? 1. : (lo ? 2. : (hi ? 3. : 0.));
+            pd[PD_LO * DP + i] = ds->ranges[2 * i];
+            pd[PD_RG * DP + i] = ds->ranges[2 * i + 1] - ds->ranges[2 * i];
+        }
+        if (ds->su_lo) {
+            pd[PD_SU_LO * DP + i] = ds->su_lo[i];
+            pd[PD_SU_DIFF * DP + i] = ds->su_diff[i];
+        }
+        if (ds->lin) pd[PD_LIN * DP + i] = ds->lin[i];
+        if (ds->use_bound) pd[PD_MU * DP + i] = ds->mu[i];
+        if (ds->use_decay) pd[PD_DMU * DP + i] = ds->decay_mu[i];
+    }
+    if (ds->quad) {
+        // S = A + A^T from the upper triangle the reference reads (modules/_poly.pyx:13-43)
+        std::vector<double> S((size_t)d * d, 0.);
+        for (int j = 0; j < d; ++j)
+            for (int k = j; k < d; ++k) {
+                double a = ds->quad[(size_t)j * d + k];
+                if (j == k) S[(size_t)j * d + j] = 2. * a;
+                else { S[(size_t)j * d + k] = a; S[(size_t)k * d + j] = a; }
+            }
+        to_fragments(S.data(), d, DP, false, Sf);
+    }
+    if (ds->use_bound) to_fragments(ds->hess, d, DP, false, Hf);
+    // decay gradient is (x - mu) H, i.e. H^T (x - mu): core/density.py:745
+    if (ds->use_decay) to_fragments(ds->decay_hess, d, DP, true, Hdf);
+
+    BF_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = n_dbl * sizeof(double);
+    if (ctx->model_bytes < bytes) {
+        if (ctx->model_buf) BF_HIP_CHECK(hipFree(ctx->model_buf));
+        ctx->model_buf = NULL;
+        ctx->model_bytes = 0;
+        BF_HIP_CHECK(hipMalloc(&ctx->model_buf, bytes));
+        ctx->model_bytes = bytes;
+    }
+    BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // nobody may still read the old model
+    BF_HIP_CHECK(hipMemcpy(ctx->model_buf, h.data(), bytes, hipMemcpyHostToDevice));
+    DevModel &m = ctx->model;
+    memset(&m, 0, sizeof(m));
+    m.d = d;
+    m.DP = DP;
+    m.has_transform = ds->ranges != NULL;
+    m.has_su = ds->su_lo != NULL;
+    m.has_quad = ds->quad != NULL;
+    m.use_bound = ds->use_bound != 0;
+    m.use_decay = ds->use_decay != 0;
+    const double *base = (const double *)ctx->model_buf;
+    m.pd = base;
+    m.Sf = base + (size_t)PD_N * DP;
+    m.Hf = m.Sf + MAT;
+    m.Hdf = m.Hf + MAT;
+    m.c0 = ds->c0;
+    m.alpha = ds->alpha;
+    m.f_mu = ds->f_mu;
+    m.decay_alpha2 = ds->decay_alpha2;
+    m.decay_gamma = ds->decay_gamma;
+    ctx->has_model = 1;
+    return 0;
+}
+
+// stream = global chain index, so results do not depend on how chains are sharded over GPUs
+static void seed_state(uint64_t seed, uint64_t stream, uint64_t s[4]) {
+    uint64_t x = seed ^ (0xD1B54A32D192ED03ULL * (stream + 1));
+    for (int i = 0; i < 4; ++i) {
+        x += BF_GOLDEN;
+        s[i] = bf_mix64(x);
+    }
+}
+
+extern "C" int bfhip_rng_seed(bfhip_ctx *ctx, int n_chain, uint64_t seed, uint64_t first_stream, uint64_t *rng) {
+    if (!ctx || n_chain < 0 || !rng) return bf_set_error(BFHIP_ERR_ARG, "bfhip_rng_seed: invalid argument");
+    std::vector<uint64_t> h((size_t)n_chain * 4);
+    for (int c = 0; c < n_chain; ++c) seed_state(seed, first_stream + (uint64_t)c, &h[(size_t)c * 4]);
+    BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BF_HIP_CHECK(hipMemcpy(rng, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// _HTrace._init_chain: samplers/sample_trace.py:178-202, :365-373 (step size), :424-455 (metric)
+__global__ void bf_chain_init_kernel(int n_chain, int d, const double *__restrict__ x0, double log_step0, double mu0,
+                                     const double *__restrict__ metric_var, const double *__restrict__ initial_mean,
+                                     double initial_weight, int adapt_window, double *__restrict__ sc,
+                                     double *__restrict__ vec) {
+    const int c = blockIdx.x;
+    if (c >= n_chain) return;
+    double *s = sc + (size_t)c * BFHIP_SC_N;
+    if (threadIdx.x == 0) {
+        s[BFHIP_SC_LOG_STEP] = log_step0;   // step_size.py:13
+        s[BFHIP_SC_LOG_BAR] = log_step0;    // :14
+        s[BFHIP_SC_HBAR] = 0.;
+        s[BFHIP_SC_MU] = mu0;               // :20
+        s[BFHIP_SC_COUNT] = 1.;             // :19
+        s[BFHIP_SC_FG_N] = initial_weight;  // metrics.py:337
+        s[BFHIP_SC_BG_N] = 10.;             // _WeightedVariance(n) default initial_weight, metrics.py:335
+        s[BFHIP_SC_N_SAMPLES] = 0.;
+        s[BFHIP_SC_PREV_UPDATE] = 0.;
+        s[BFHIP_SC_ADAPT_WINDOW] = (double)adapt_window;
+        s[BFHIP_SC_I_ITER] = 0.;
+        s[BFHIP_SC_ERROR] = 0.;
+    }
+    double *v = vec + (size_t)c * BFHIP_VEC_N * d;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        const double x = x0[(size_t)c * d + i];
+        const double var = metric_var ? metric_var[i] : 1.;
+        v[BFHIP_VEC_Q * d + i] = x;
+        v[BFHIP_VEC_VAR * d + i] = var;
+        v[BFHIP_VEC_FG_MEAN * d + i] = initial_mean ? initial_mean[i] : x;  // sample_trace.py:436-437
+        v[BFHIP_VEC_FG_RAW * d + i] = var * initial_weight;                 // metrics.py:347
+        v[BFHIP_VEC_BG_MEAN * d + i] = 0.;
+        v[BFHIP_VEC_BG_RAW * d + i] = 0.;
+    }
+}
+
+extern "C" int bfhip_chain_init(bfhip_ctx *ctx, int n_chain, int d, const double *x0, double step_size,
+                                const double *metric_var, const double *initial_mean, double initial_weight,
+                                int adapt_window, double *sc, double *vec) {
+    if (!ctx || n_chain < 0 || d < 1 || d > BFHIP_MAX_DIM || !x0 || !sc || !vec || !(step_size > 0.) ||
+        !(initial_weight > 0.) || adapt_window < 1)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_chain_init: invalid argument");
+    if (n_chain == 0) return 0;
+    const double initial_step = step_size / pow((double)d, 0.25);  // sample_trace.py:371-373
+    hipLaunchKernelGGL(bf_chain_init_kernel, dim3(n_chain), dim3(64), 0, ctx->stream, n_chain, d, x0,
+                       log(initial_step), log(10. * initial_step), metric_var, initial_mean, initial_weight,
+                       adapt_window, sc, vec);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}

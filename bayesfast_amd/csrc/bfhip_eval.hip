@@ -1,0 +1,202 @@
+// bfhip_eval.hip -- batched surrogate logp+grad and batched leapfrog step (wave-local MFMA layout).
+#include "bfhip_eval.h"
+
+// Stages the model's fragments and per-dimension table into LDS (coefficient matrices are read by
+// every MFMA of every wave; 32 KB each at DP = 64).  Returns pointers valid after __syncthreads().
+struct StagedModel {
+    const double *Sf, *Hf, *Hdf, *pd;
+};
+
+template <int T, bool STAGE>
+__device__ inline StagedModel bf_stage_model(const DevModel &m, double *lds) {
+    constexpr int DP = 16 * T;
+    constexpr int MAT = DP * DP;
+    StagedModel s;
+    if constexpr (!STAGE) {
+        s.Sf = m.Sf; s.Hf = m.Hf; s.Hdf = m.Hdf; s.pd = m.pd;
+        return s;
+    } else {
+        double *p = lds;
+        double *pdl = p; p += PD_N * DP;
+        double *S = p; if (m.has_quad) p += MAT;
+        double *H = p; if (m.use_bound) p += MAT;
+        double *Hd = p;
+        const int tid = threadIdx.x, nt = blockDim.x;
+        for (int i = tid; i < PD_N * DP; i += nt) pdl[i] = m.pd[i];
+        // 16-byte copies, coalesced
+        const d2_t *src; d2_t *dst;
+        if (m.has_quad) { src = (const d2_t *)m.Sf; dst = (d2_t *)S; for (int i = tid; i < MAT / 2; i += nt) dst[i] = src[i]; }
+        if (m.use_bound) { src = (const d2_t *)m.Hf; dst = (d2_t *)H; for (int i = tid; i < MAT / 2; i += nt) dst[i] = src[i]; }
+        if (m.use_decay) { src = (const d2_t *)m.Hdf; dst = (d2_t *)Hd; for (int i = tid; i < MAT / 2; i += nt) dst[i] = src[i]; }
+        __syncthreads();
+        s.Sf = S; s.Hf = H; s.Hdf = Hd; s.pd = pdl;
+        return s;
+    }
+}
+
+static size_t bf_stage_bytes(const DevModel &m) {
+    size_t mat = (size_t)m.DP * m.DP * sizeof(double);
+    return (size_t)PD_N * m.DP * sizeof(double) + mat * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
+}
+
+// Density.logp_and_grad over n points; replaces the per-row Python recursion of core/density.py:523-525.
+template <int T, bool STAGE>
+__global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int n, const double *__restrict__ x,
+                                                           int original_space, double *__restrict__ logp,
+                                                           double *__restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int E = 4 * T;
+    StagedModel sm = bf_stage_model<T, STAGE>(m, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n_tiles = (n + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int pt = tile * 16 + c;
+        double xv[E], gv[E], lp;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int dim = 4 * e + g;
+            xv[e] = (pt < n && dim < m.d) ? x[(size_t)pt * m.d + dim] : 0.;
+        }
+        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, original_space, xv, lp, gv, lane);
+        if (pt < n) {
+            if (g == 0) logp[pt] = lp;
+            if (grad) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int dim = 4 * e + g;
+                    if (dim < m.d) grad[(size_t)pt * m.d + dim] = gv[e];
+                }
+            }
+        }
+    }
+}
+
+// CpuLeapfrogIntegrator._step (samplers/hmc_utils/integration.py:68-95), diagonal metric, n chains.
+template <int T, bool STAGE>
+__global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int n, const double *__restrict__ eps,
+                                                          const double *__restrict__ var, double *__restrict__ q,
+                                                          double *__restrict__ p, double *__restrict__ grad,
+                                                          double *__restrict__ logp, double *__restrict__ energy,
+                                                          double *__restrict__ vel) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int E = 4 * T;
+    StagedModel sm = bf_stage_model<T, STAGE>(m, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n_tiles = (n + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int ch = tile * 16 + c;
+        const bool live = ch < n;
+        const double ep = live ? eps[ch] : 0.;
+        const double dt = 0.5 * ep;
+        double qn[E], pn[E], vr[E], gn[E], lp;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int dim = 4 * e + g;
+            const bool ok = live && dim < m.d;
+            const size_t idx = (size_t)ch * m.d + dim;
+            vr[e] = ok ? var[idx] : 1.;
+            const double pp = ok ? p[idx] : 0., gg = ok ? grad[idx] : 0., qq = ok ? q[idx] : 0.;
+            pn[e] = pp + dt * gg;              // integration.py:80
+            qn[e] = qq + ep * (vr[e] * pn[e]); // :82-85
+        }
+        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, 0, qn, lp, gn, lane);  // :87
+        double kin = 0.;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            pn[e] = pn[e] + dt * gn[e];  // :90
+            const double v = vr[e] * pn[e];
+            kin += pn[e] * v;            // metrics.py:88-91
+            vr[e] = v;
+        }
+        kin = bf_sum_g(kin);
+        if (live) {
+            if (g == 0) {
+                logp[ch] = lp;
+                energy[ch] = 0.5 * kin - lp;  // :92-93
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int dim = 4 * e + g;
+                if (dim < m.d) {
+                    const size_t idx = (size_t)ch * m.d + dim;
+                    q[idx] = qn[e];
+                    p[idx] = pn[e];
+                    grad[idx] = gn[e];
+                    if (vel) vel[idx] = vr[e];
+                }
+            }
+        }
+    }
+}
+
+template <typename K>
+static int bf_set_lds(K kern, size_t bytes) {
+    if (bytes > 64 * 1024)
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+template <int T, bool STAGE>
+static int launch_logp_grad(bfhip_ctx *ctx, int grid, size_t lds, int n, const double *x, int original_space,
+                            double *logp, double *grad) {
+    auto k = bf_logp_grad_kernel<T, STAGE>;
+    if (STAGE) {
+        if (int rc = bf_set_lds(k, lds)) return rc;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), STAGE ? lds : 0, ctx->stream, ctx->model, n, x, original_space, logp, grad);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int T, bool STAGE>
+static int launch_leapfrog(bfhip_ctx *ctx, int grid, size_t lds, int n, const double *eps, const double *var, double *q,
+                           double *p, double *grad, double *logp, double *energy, double *vel) {
+    auto k = bf_leapfrog_kernel<T, STAGE>;
+    if (STAGE) {
+        if (int rc = bf_set_lds(k, lds)) return rc;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), STAGE ? lds : 0, ctx->stream, ctx->model, n, eps, var, q, p, grad, logp, energy, vel);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int eval_grid(const bfhip_ctx *ctx, int n) {
+    const int n_tiles = (n + 15) / 16;
+    int grid = (n_tiles + 3) / 4;
+    if (grid > ctx->n_cu * 2) grid = ctx->n_cu * 2;
+    return grid;
+}
+
+extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad) {
+    if (!ctx || n < 0 || (n > 0 && (!x || !logp))) return bf_set_error(BFHIP_ERR_ARG, "bfhip_logp_grad: invalid argument");
+    if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_logp_grad: no density uploaded");
+    if (n == 0) return 0;
+    const int grid = eval_grid(ctx, n);
+    const size_t lds = bf_stage_bytes(ctx->model);
+    switch (ctx->model.DP / 16) {
+    case 1: return launch_logp_grad<1, true>(ctx, grid, lds, n, x, original_space, logp, grad);
+    case 2: return launch_logp_grad<2, true>(ctx, grid, lds, n, x, original_space, logp, grad);
+    case 4: return launch_logp_grad<4, true>(ctx, grid, lds, n, x, original_space, logp, grad);
+    case 8: return launch_logp_grad<8, false>(ctx, grid, lds, n, x, original_space, logp, grad);
+    }
+    return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->model.DP);
+}
+
+extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const double *var, double *q, double *p,
+                              double *grad, double *logp, double *energy, double *velocity_out) {
+    if (!ctx || n < 0 || (n > 0 && (!eps || !var || !q || !p || !grad || !logp || !energy)))
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_leapfrog: invalid argument");
+    if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_leapfrog: no density uploaded");
+    if (n == 0) return 0;
+    const int grid = eval_grid(ctx, n);
+    const size_t lds = bf_stage_bytes(ctx->model);
+    switch (ctx->model.DP / 16) {
+    case 1: return launch_leapfrog<1, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
+    case 2: return launch_leapfrog<2, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
+    case 4: return launch_leapfrog<4, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
+    case 8: return launch_leapfrog<8, false>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
+    }
+    return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->model.DP);
+}

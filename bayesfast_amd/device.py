@@ -1,0 +1,223 @@
+"""Device context and device-resident surrogate density (host side of include/bfhip.h).
+
+PyTorch-ROCm is used for device memory and streams only; all arithmetic happens in libbfhip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ['DeviceContext', 'DeviceDensity', 'density_desc_from_spec', 'get_context']
+
+_ORDERS = ('linear', 'quadratic', 'cubic-2', 'cubic-3')
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DeviceContext:
+    """One bfhip_ctx bound to a HIP device and stream (include/bfhip.h: bfhip_ctx_create)."""
+
+    def __init__(self, device=0, stream=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError('bayesfast_amd needs a ROCm GPU (gfx950); none is visible.')
+        self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
+        self._lib = _lib.lib()
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            s = stream if stream is not None else torch.cuda.current_stream(self.device)
+            self.stream = s
+            _lib.check(self._lib.bfhip_ctx_create(C.byref(self._ctx), self.device.index, C.c_void_p(s.cuda_stream)))
+
+    def close(self):
+        if self._ctx:
+            self._lib.bfhip_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def set_stream(self, stream):
+        self.stream = stream
+        _lib.check(self._lib.bfhip_ctx_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)))
+
+    def synchronize(self):
+        _lib.check(self._lib.bfhip_ctx_synchronize(self._ctx))
+
+    def tensor(self, a, dtype=None):
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.device)
+            if dtype is not None:
+                t = t.to(dtype)
+            return t.contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device).contiguous()
+
+    def empty(self, shape, dtype=None):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype or torch.float64, device=self.device)
+
+    def zeros(self, shape, dtype=None):
+        torch = _torch()
+        return torch.zeros(shape, dtype=dtype or torch.float64, device=self.device)
+
+
+_contexts = {}
+
+
+def get_context(device=0):
+    """Process-wide default context of a device."""
+    if device not in _contexts:
+        _contexts[device] = DeviceContext(device)
+    return _contexts[device]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def density_desc_from_spec(spec):
+    """Flatten a density spec (dict, see below) into a bfhip_density_desc + the arrays it points to.
+
+    spec = {'d', 'ranges', 'hard_bounds', 'su_lo', 'su_diff',
+            'poly': {'input_size', 'output_size' (=1), 'configs': [{'order', 'input_mask', 'output_mask', 'coef'}],
+                     'use_bound', 'mu', 'hess', 'alpha', 'f_mu'},
+            'use_decay', 'decay_mu', 'decay_hess', 'decay_alpha2', 'decay_gamma'}
+
+    The PolyConfig masks are scattered to the full input here, which is what PolyModel._fun_and_jac does
+    on every call (modules/poly.py:474-477)."""
+    d = int(spec['d'])
+    poly = spec['poly']
+    if int(poly['output_size']) != 1 or int(poly['input_size']) != d:
+        raise ValueError('the device density needs a surrogate with output_size 1 and input_size d.')
+    keep = []
+
+    def f64(a, shape=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if shape is not None and a.shape != shape:
+            raise ValueError('expected shape {}, got {}.'.format(shape, a.shape))
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    ds = _lib.DensityDesc()
+    ds.d = d
+    if spec.get('ranges') is not None:
+        ds.ranges = f64(spec['ranges'], (d, 2))
+        hb = spec.get('hard_bounds')
+        if hb is not None:
+            hb = np.ascontiguousarray(hb, dtype=np.uint8)
+            if hb.shape != (d, 2):
+                raise ValueError('hard_bounds should have shape (d, 2).')
+            keep.append(hb)
+            ds.hard_bounds = hb.ctypes.data_as(C.POINTER(C.c_uint8))
+    if spec.get('su_lo') is not None:
+        ds.su_lo = f64(spec['su_lo'], (d,))
+        ds.su_diff = f64(spec['su_diff'], (d,))
+    c0 = 0.
+    lin = np.zeros(d)
+    quad = np.zeros((d, d))
+    cubic2 = np.zeros((d, d))
+    cubic3 = None
+    has = dict.fromkeys(_ORDERS, False)
+    for cf in poly['configs']:
+        order = cf['order']
+        if order not in _ORDERS:
+            raise ValueError('unexpected PolyConfig order "{}".'.format(order))
+        im = np.asarray(cf['input_mask'], dtype=np.int64)
+        coef = np.asarray(cf['coef'], dtype=np.float64)
+        if has[order]:
+            raise ValueError('multiple {} PolyConfig(s) share the output variable.'.format(order))
+        has[order] = True
+        n = im.size
+        if order == 'linear':
+            c0 += coef[0, 0]
+            lin[im] += coef[0, 1:]
+        elif order == 'quadratic':
+            iu = np.triu_indices(n)  # only j <= k is defined in the reference's blocks (modules/poly.py:146)
+            quad[im[iu[0]], im[iu[1]]] += coef[0][iu]
+        elif order == 'cubic-2':
+            cubic2[np.ix_(im, im)] += coef[0]
+        else:
+            if cubic3 is None:
+                cubic3 = np.zeros((d, d, d))
+            j, k, l = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing='ij')
+            sel = (j < k) & (k < l)
+            cubic3[im[j[sel]], im[k[sel]], im[l[sel]]] += coef[0][sel]
+    ds.c0 = c0
+    ds.lin = f64(lin)
+    if has['quadratic']:
+        ds.quad = f64(quad)
+    if has['cubic-2']:
+        ds.cubic2 = f64(cubic2)
+    if has['cubic-3']:
+        ds.cubic3 = f64(cubic3)
+    all_linear = not (has['quadratic'] or has['cubic-2'] or has['cubic-3'])
+    if poly.get('use_bound', False) and not all_linear:
+        ds.use_bound = 1
+        ds.mu = f64(poly['mu'], (d,))
+        ds.hess = f64(poly['hess'], (d, d))
+        ds.alpha = float(poly['alpha'])
+        ds.f_mu = float(np.asarray(poly['f_mu']).reshape(-1)[0])
+    if spec.get('use_decay', False):
+        ds.use_decay = 1
+        ds.decay_mu = f64(spec['decay_mu'], (d,))
+        ds.decay_hess = f64(spec['decay_hess'], (d, d))
+        ds.decay_alpha2 = float(spec['decay_alpha2'])
+        ds.decay_gamma = float(spec['decay_gamma'])
+    return ds, keep
+
+
+class DeviceDensity:
+    """A surrogate log density resident on one GPU.
+
+    Counterpart of ``Density.logp_and_grad(x, original_space, use_surrogate=True)`` (core/density.py:724-754)
+    for a pipeline whose density variable is a single PolyModel output."""
+
+    def __init__(self, spec, ctx=None):
+        self.ctx = ctx if ctx is not None else get_context()
+        self.d = int(spec['d'])
+        self.spec = spec
+        ds, keep = density_desc_from_spec(spec)
+        _lib.check(self.ctx._lib.bfhip_density_upload(self.ctx.handle, C.byref(ds)))
+
+    def upload(self):
+        """Make this density the context's current one again (a context holds one density at a time)."""
+        ds, keep = density_desc_from_spec(self.spec)
+        _lib.check(self.ctx._lib.bfhip_density_upload(self.ctx.handle, C.byref(ds)))
+
+    def logp_and_grad(self, x, original_space=False):
+        """x: (n, d) or (d,) array/tensor -> (logp (n,), grad (n, d)) float64 device tensors."""
+        torch = _torch()
+        xt = self.ctx.tensor(x, torch.float64)
+        single = xt.dim() == 1
+        xt = xt.reshape(-1, self.d)
+        n = xt.shape[0]
+        logp = self.ctx.empty((n,))
+        grad = self.ctx.empty((n, self.d))
+        _lib.check(self.ctx._lib.bfhip_logp_grad(self.ctx.handle, n, _ptr(xt), int(bool(original_space)),
+                                                 _ptr(logp), _ptr(grad)))
+        return (logp[0], grad[0]) if single else (logp, grad)
+
+    def leapfrog(self, eps, var, q, p, grad, logp=None, energy=None, velocity=None):
+        """In-place batched CpuLeapfrogIntegrator._step; all arguments float64 device tensors, (n,) or (n,d)."""
+        n = q.shape[0]
+        if logp is None:
+            logp = self.ctx.empty((n,))
+        if energy is None:
+            energy = self.ctx.empty((n,))
+        for t in (eps, var, q, p, grad, logp, energy):
+            assert t.is_contiguous() and t.device == self.ctx.device
+        _lib.check(self.ctx._lib.bfhip_leapfrog(self.ctx.handle, n, _ptr(eps), _ptr(var), _ptr(q), _ptr(p), _ptr(grad),
+                                                _ptr(logp), _ptr(energy), _ptr(velocity)))
+        return logp, energy

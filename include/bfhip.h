@@ -1,0 +1,204 @@
+/*
+ * bfhip.h -- C ABI of libbfhip.so: the MI355X (gfx950) implementation of BayesFast's data-parallel hot
+ * path (polynomial-surrogate logp/grad, leapfrog, NUTS/HMC transitions over many chains, surrogate fit).
+ *
+ * The reference (h3jia/bayesfast) has no FFI boundary on this path: the seam is Python duck typing
+ * (SURVEY.md section 8b).  Each entry point below therefore names the reference *Python/Cython interface*
+ * it replaces (file:line relative to the reference root); INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C, no exceptions: every function returns 0 on success, <0 on error; bfhip_last_error()
+ *     returns a message for the calling thread's last failure.
+ *   - all array arguments of compute calls are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm
+ *     tensor.data_ptr()), row-major float64 unless stated; model descriptions are HOST pointers
+ *     and are copied during the upload call.
+ *   - one bfhip_ctx per (device, stream); calls on one ctx are not thread-safe, different ctxs are
+ *     independent.  Kernels are launched asynchronously on the ctx's stream; nothing synchronises
+ *     unless documented.
+ */
+#ifndef BFHIP_H
+#define BFHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bfhip_ctx bfhip_ctx;
+
+#define BFHIP_OK 0
+#define BFHIP_ERR_ARG (-1)        /* invalid argument (the reference raises ValueError) */
+#define BFHIP_ERR_STATE (-2)      /* bad state, e.g. no density uploaded (RuntimeError) */
+#define BFHIP_ERR_HIP (-3)        /* HIP runtime failure */
+#define BFHIP_ERR_UNSUPPORTED (-4)/* valid in the reference, not implemented on device yet (NotImplementedError) */
+
+#define BFHIP_MAX_DIM 128         /* input_size limit of the device path */
+#define BFHIP_MAX_TREEDEPTH 12
+
+int bfhip_version(void);
+const char *bfhip_last_error(void);
+
+/* stream: a hipStream_t (as void*), NULL for the default stream.  device: HIP ordinal. */
+int bfhip_ctx_create(bfhip_ctx **out, int device, void *stream);
+void bfhip_ctx_destroy(bfhip_ctx *ctx);
+int bfhip_ctx_set_stream(bfhip_ctx *ctx, void *stream);
+int bfhip_ctx_synchronize(bfhip_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Surrogate density description.  Replaces, as one flattened record, the objects walked per call by
+ * Density.logp_and_grad (core/density.py:724-754): the Density's constraint transform
+ * (core/density.py:92-140 -> transforms/_constraint.pyx:133-215), the Surrogate input scaling
+ * (core/module.py:76-83,226), the PolyModel configs with their masks scattered to full input size
+ * (modules/poly.py:466-478, modules/_poly.pyx:13-137), the linear-extrapolation bound
+ * (modules/poly.py:480-503) and the decay penalty (core/density.py:740-746).
+ * output_size of the surrogate is 1: the surrogate IS the log density.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int d;                        /* input_size, 1..BFHIP_MAX_DIM */
+    /* Density.input_scales (d,2) and hard_bounds (d,2) uint8; NULL => identity transform */
+    const double *ranges;
+    const uint8_t *hard_bounds;   /* may be NULL with ranges set => no hard bound */
+    /* Surrogate.input_scales: lower edge (d,) and width (d,); NULL => none */
+    const double *su_lo;
+    const double *su_diff;
+    /* polynomial in surrogate space, masks already scattered to the full input:
+     *   f(x) = c0 + lin.x + sum_{j<=k} quad[j,k] x_j x_k + sum_{j,k} cubic2[j,k] x_j^2 x_k
+     *          + sum_{j<k<l} cubic3[j,k,l] x_j x_k x_l                                              */
+    double c0;
+    const double *lin;            /* (d,)   or NULL */
+    const double *quad;           /* (d,d)  only j<=k is read (the reference leaves the rest unset) */
+    const double *cubic2;         /* (d,d)  or NULL */
+    const double *cubic3;         /* (d,d,d) only j<k<l is read, or NULL */
+    /* PolyModel bound, modules/poly.py:262-292 */
+    int use_bound;
+    const double *mu;             /* (d,) */
+    const double *hess;           /* (d,d) */
+    double alpha;
+    double f_mu;
+    /* Density decay, core/density.py:761-811 */
+    int use_decay;
+    const double *decay_mu;       /* (d,) */
+    const double *decay_hess;     /* (d,d) */
+    double decay_alpha2;
+    double decay_gamma;
+} bfhip_density_desc;
+
+/* Copies and re-lays-out the description into device memory (MFMA A-operand fragments). Synchronous. */
+int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *desc);
+
+/* Density.logp_and_grad(x, original_space, use_surrogate=True) for n points.
+ * x (n,d) -> logp (n,), grad (n,d).  Replaces core/density.py:724-754 (which loops rows in Python,
+ * core/density.py:523-525).  grad may be NULL. */
+int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad);
+
+/* CpuLeapfrogIntegrator._step for n chains at once (samplers/hmc_utils/integration.py:68-95) with a
+ * diagonal metric (QuadMetricDiag, samplers/hmc_utils/metrics.py:51-91).
+ * eps (n,), var (n,d); q,p,grad (n,d) and logp,energy (n,) are updated in place; velocity_out (n,d) may be NULL. */
+int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const double *var, double *q, double *p,
+                   double *grad, double *logp, double *energy, double *velocity_out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler.  Per-chain state lives in caller-owned device arrays so that a later run() continues the
+ * chains (SURVEY.md section 5 "checkpoint/resume"; samplers/hmc_utils/base_hmc.py:98-111).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    /* _HTrace / NTrace / HTrace hyper-parameters, samplers/sample_trace.py:159-172,460-512 */
+    int sampler;                  /* 0 = NUTS (samplers/nuts.py), 1 = HMC (samplers/hmc.py) */
+    int n_warmup;
+    int max_treedepth;            /* NUTS, <= BFHIP_MAX_TREEDEPTH */
+    int n_int_step;               /* HMC */
+    double max_change;
+    double target_accept, gamma, k, t_0;
+    int adapt_step_size;
+    int adapt_metric;
+    int update_window;
+    int doubling;
+} bfhip_sampler_config;
+
+/* Layout of the per-chain scalar state array `sc` (C, BFHIP_SC_N) float64 */
+enum {
+    BFHIP_SC_LOG_STEP = 0,   /* DualAverageAdaptation._log_step, samplers/hmc_utils/step_size.py:13 */
+    BFHIP_SC_LOG_BAR,        /* _log_bar */
+    BFHIP_SC_HBAR,           /* _hbar */
+    BFHIP_SC_MU,             /* _mu = log(10 * initial_step) */
+    BFHIP_SC_COUNT,          /* _count */
+    BFHIP_SC_FG_N,           /* _WeightedVariance.n_samples of the foreground window, metrics.py:337 */
+    BFHIP_SC_BG_N,           /* same, background window */
+    BFHIP_SC_N_SAMPLES,      /* QuadMetricDiagAdapt._n_samples */
+    BFHIP_SC_PREV_UPDATE,    /* _previous_update */
+    BFHIP_SC_ADAPT_WINDOW,   /* _adapt_window (doubles when `doubling`) */
+    BFHIP_SC_I_ITER,         /* iterations done (len(trace._samples)) */
+    BFHIP_SC_ERROR,          /* 0 ok; 1 bad initial energy (base_hmc.py:72-76); 2 logbern(NaN) (nuts.py:201-202) */
+    BFHIP_SC_N
+};
+
+/* Layout of the per-chain vector state array `vec` (C, BFHIP_VEC_N, d) float64 */
+enum {
+    BFHIP_VEC_Q = 0,         /* current position: last sample, or x_0 (transformed space) */
+    BFHIP_VEC_VAR,           /* QuadMetricDiag._var */
+    BFHIP_VEC_FG_MEAN, BFHIP_VEC_FG_RAW, BFHIP_VEC_BG_MEAN, BFHIP_VEC_BG_RAW, /* metrics.py:333-371 */
+    BFHIP_VEC_N
+};
+
+/* NUTS statistics per iteration, order of samplers/hmc_utils/stats.py:12-14 */
+enum {
+    BFHIP_NS_LOGP = 0, BFHIP_NS_ENERGY, BFHIP_NS_TREE_DEPTH, BFHIP_NS_TREE_SIZE, BFHIP_NS_MEAN_TREE_ACCEPT,
+    BFHIP_NS_STEP_SIZE, BFHIP_NS_STEP_SIZE_BAR, BFHIP_NS_WARMUP, BFHIP_NS_ENERGY_CHANGE,
+    BFHIP_NS_MAX_ENERGY_CHANGE, BFHIP_NS_DIVERGING, BFHIP_NS_N
+};
+/* HMC statistics, order of samplers/hmc_utils/stats.py:7-9 (one slot left unused to share the stride) */
+enum {
+    BFHIP_HS_LOGP = 0, BFHIP_HS_ENERGY, BFHIP_HS_N_INT_STEP, BFHIP_HS_ACCEPT_STAT, BFHIP_HS_ACCEPTED,
+    BFHIP_HS_STEP_SIZE, BFHIP_HS_STEP_SIZE_BAR, BFHIP_HS_WARMUP, BFHIP_HS_ENERGY_CHANGE, BFHIP_HS_DIVERGING,
+    BFHIP_HS_N
+};
+#define BFHIP_STAT_STRIDE 11
+
+/* Runs every chain from its own i_iter up to (excluding) iter_end: BaseHMC.run/astep
+ * (samplers/hmc_utils/base_hmc.py:62-85,155-156) with NUTS._hamiltonian_step (samplers/nuts.py:205-217,
+ * Tree :21-189) or HMC._hamiltonian_step (samplers/hmc.py:16-49), for n_chain chains in one launch.
+ *   rng     (C,4) uint64  per-chain xoshiro256++ state (bfhip_rng_seed)
+ *   sc      (C,BFHIP_SC_N) float64, vec (C,BFHIP_VEC_N,d) float64: state above, updated in place
+ *   samples (C,n_out,d): iteration i of a chain is written to row i - iter_out0
+ *   stats   (C,n_out,BFHIP_STAT_STRIDE)
+ *   n_leapfrog (1,) uint64 device counter, incremented by the number of leapfrog steps taken (may be NULL)
+ * Asynchronous. */
+int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_chain, int iter_end,
+                      uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
+                      double *stats, unsigned long long *n_leapfrog);
+
+/* Fills rng (C,4) with xoshiro256++ states for streams first_stream .. first_stream+C-1 of `seed`
+ * (counterpart of utils/random.py:20-32 spawn_generator: one independent stream per GLOBAL chain index). */
+int bfhip_rng_seed(bfhip_ctx *ctx, int n_chain, uint64_t seed, uint64_t first_stream, uint64_t *rng);
+
+/* Initialises sc/vec for fresh chains: _HTrace._init_chain (samplers/sample_trace.py:178-202),
+ * _set_step_size_2 (:365-373) and _set_metric_2 (:424-455).
+ * x0 (C,d); metric_var (d,) or NULL (ones); initial_mean (d,) or NULL (x0 of each chain). */
+int bfhip_chain_init(bfhip_ctx *ctx, int n_chain, int d, const double *x0, double step_size,
+                     const double *metric_var, const double *initial_mean, double initial_weight,
+                     int adapt_window, double *sc, double *vec);
+
+/* ------------------------------------------------------------------------------------------------
+ * Surrogate fit, PolyModel.fit (modules/poly.py:505-589).
+ * ---------------------------------------------------------------------------------------------- */
+/* Design-matrix block for one PolyConfig: x (n, n_in) gathered inputs -> A[:, col0 : col0+width] of the
+ * row-major (n, lda) matrix A.  order: 0 linear (1 | x), 1 quadratic, 2 cubic-2, 3 cubic-3.
+ * Replaces modules/poly.py:537-564 -> modules/_poly.pyx:143-177.  Optional row weights w (n,) scale the
+ * block (modules/poly.py:566-568). */
+int bfhip_design_block(bfhip_ctx *ctx, int order, int n, int n_in, const double *x, const double *w,
+                       double *A, int lda, int col0);
+
+/* Normal equations with FP64 MFMA: G (P,P) = A^T A, r (P,m) = A^T B for A (n,P), B (n,m), row-major.
+ * Stands in for the factorisation inside scipy.linalg.lstsq (modules/poly.py:570). */
+int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, const double *B, double *G, double *r);
+
+/* Solves G c = r for SPD G (P,P) in place by blocked Cholesky on device: G is overwritten by its factor,
+ * r (P,m) by the solution.  info (1,) int32 device flag: 0 ok, k>0 pivot k not positive. */
+int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

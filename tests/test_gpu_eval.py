@@ -1,0 +1,104 @@
+"""GPU parity (through the C ABI): batched surrogate logp+grad and batched leapfrog vs the CPU oracle and
+vs the golden vectors the reference produced.  Tolerance: float64, relative 1e-11 (summation order only)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from bayesfast_amd.device import get_context
+    return get_context(0)
+
+
+def _spec(z, prefix):
+    from specio import rebuild_spec
+    return rebuild_spec(z, prefix)
+
+
+@pytest.mark.parametrize('case', ['plain', 'decay', 'scales', 'su', 'full', 'd64'])
+def test_logp_grad_golden(ctx, case):
+    """Density.logp_and_grad fixtures of the reference (core/density.py:724-754), both spaces."""
+    from bayesfast_amd.device import DeviceDensity
+    z = np.load(os.path.join(G, 'density.npz'))
+    dd = DeviceDensity(_spec(z, case + '.'), ctx)
+    lp, g = dd.logp_and_grad(z[case + '.x_trans'])
+    np.testing.assert_allclose(lp.cpu().numpy(), z[case + '.logp_trans'], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(g.cpu().numpy(), z[case + '.grad_trans'], rtol=1e-10, atol=1e-10)
+    if case + '.x_orig' in z.files:
+        lp, g = dd.logp_and_grad(z[case + '.x_orig'], original_space=True)
+        np.testing.assert_allclose(lp.cpu().numpy(), z[case + '.logp_orig'], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(g.cpu().numpy(), z[case + '.grad_orig'], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize('case,n,scale', [('full', 1000, 1.0), ('d64', 4096, 1.0), ('d64', 333, 2.5), ('plain', 17, 3.0)])
+def test_logp_grad_vs_oracle(ctx, case, n, scale):
+    """Seeded random batches, ragged sizes, points inside and outside the bound, vs the C oracle."""
+    from bayesfast_amd.device import DeviceDensity
+    from oracle import oracle as orc
+    z = np.load(os.path.join(G, 'density.npz'))
+    spec = _spec(z, case + '.')
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n, spec['d'])) * scale
+    lp0, g0 = orc.logp_and_grad(spec, x)
+    lp, g = DeviceDensity(spec, ctx).logp_and_grad(x)
+    lp, g = lp.cpu().numpy(), g.cpu().numpy()
+    if spec['poly']['use_bound']:
+        beta = np.sqrt(np.einsum('ij,jk,ik->i', x - spec['poly']['mu'], spec['poly']['hess'], x - spec['poly']['mu'])) \
+            if spec.get('su_lo') is None and spec.get('ranges') is None else None
+        if beta is not None and scale > 1.:
+            assert (beta > spec['poly']['alpha']).any(), 'test should exercise the extrapolation branch'
+    np.testing.assert_allclose(lp, lp0, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(g, g0, rtol=1e-10, atol=1e-9)
+
+
+def test_logp_grad_empty_and_errors(ctx):
+    import torch
+    from bayesfast_amd.device import DeviceDensity
+    z = np.load(os.path.join(G, 'density.npz'))
+    dd = DeviceDensity(_spec(z, 'plain.'), ctx)
+    lp, g = dd.logp_and_grad(np.zeros((0, 5)))
+    assert lp.shape == (0,) and g.shape == (0, 5)
+    lp1, g1 = dd.logp_and_grad(np.zeros(5))
+    assert lp1.dim() == 0 and g1.shape == (5,)
+    assert torch.isfinite(lp1)
+
+
+@pytest.mark.parametrize('name', ['full5', 'plain16', 'd64'])
+def test_leapfrog_golden_and_oracle(ctx, name):
+    """CpuLeapfrogIntegrator._step fixtures (integration.py:68-95), then a random batch vs the oracle."""
+    import torch
+    from bayesfast_amd.device import DeviceDensity
+    from oracle import oracle as orc
+    samp = np.load(os.path.join(G, 'sampler.npz'))
+    spec = _spec(samp, name + '.')
+    dd = DeviceDensity(spec, ctx)
+    var, eps = samp[name + '.lf.var'], samp[name + '.lf.eps']
+    T = lambda a: ctx.tensor(np.atleast_2d(a).copy(), torch.float64)
+    for a, b, e in (('s0', 's1', eps[0]), ('s1', 's2', eps[1])):
+        q, p, g = (T(samp['%s.lf.%s.%s' % (name, a, f)]) for f in ('q', 'p', 'q_grad'))
+        v = ctx.empty(q.shape)
+        logp, energy = dd.leapfrog(ctx.tensor(np.array([e])), T(var), q, p, g, velocity=v)
+        for f, t in (('q', q), ('p', p), ('velocity', v), ('q_grad', g)):
+            np.testing.assert_allclose(t.cpu().numpy()[0], samp['%s.lf.%s.%s' % (name, b, f)], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(logp.item(), samp['%s.lf.%s.logp' % (name, b)], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(energy.item(), samp['%s.lf.%s.energy' % (name, b)], rtol=1e-11, atol=1e-11)
+    # batch of 77 chains with per-chain eps and var
+    rng = np.random.default_rng(8)
+    n, d = 77, spec['d']
+    q, p = rng.normal(size=(n, d)) * 0.4, rng.normal(size=(n, d))
+    var_b, eps_b = rng.uniform(0.5, 2., size=(n, d)), rng.uniform(-0.2, 0.2, size=n)
+    _, g = orc.logp_and_grad(spec, q)
+    tq, tp, tg = T(q), T(p), T(g)
+    logp, energy = dd.leapfrog(ctx.tensor(eps_b), T(var_b), tq, tp, tg)
+    for i in range(0, n, 7):
+        r = orc.leapfrog(spec, var_b[i], eps_b[i], q[i], p[i], g[i])
+        np.testing.assert_allclose(tq[i].cpu().numpy(), r['q'], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(tp[i].cpu().numpy(), r['p'], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(tg[i].cpu().numpy(), r['grad'], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(energy[i].item(), r['energy'], rtol=1e-11, atol=1e-10)
