@@ -1,0 +1,106 @@
+"""Batched chain state on one GPU and the fused NUTS/HMC launch (bfhip_sampler_run)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceDensity, _ptr
+
+__all__ = ['DeviceChains']
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DeviceChains:
+    """All chains of one GPU shard: positions, per-chain step-size and metric adaptation state, RNG streams.
+
+    The per-chain arithmetic is the reference's (``BaseHMC.astep``, samplers/hmc_utils/base_hmc.py:62-85);
+    the state that the reference keeps in one ``NTrace``/``HTrace`` object per chain
+    (samplers/sample_trace.py:157-455) lives here in three device tensors, so a later ``run`` continues the
+    chains exactly where they stopped.
+
+    Parameters
+    ----------
+    density : DeviceDensity
+    x_0 : (n_chain, d) array_like, starting points in the sampler's (transformed) space
+    seed, first_stream : the xoshiro256++ stream of chain i is (seed, first_stream + i); with
+        first_stream = global index of this shard's first chain, results do not depend on the sharding.
+    """
+
+    def __init__(self, density, x_0, seed=0, first_stream=0, step_size=1., metric=None, initial_mean=None,
+                 initial_weight=10., adapt_window=60):
+        torch = _torch()
+        if not isinstance(density, DeviceDensity):
+            raise ValueError('density should be a DeviceDensity.')
+        self.density = density
+        self.ctx = density.ctx
+        x_0 = self.ctx.tensor(x_0, torch.float64)
+        if x_0.dim() != 2 or x_0.shape[1] != density.d:
+            raise ValueError('x_0 should have shape (n_chain, {}).'.format(density.d))
+        self.n_chain, self.d = x_0.shape
+        lib, h = self.ctx._lib, self.ctx.handle
+        self.rng = torch.empty((self.n_chain, 4), dtype=torch.int64, device=self.ctx.device)
+        self.sc = self.ctx.empty((self.n_chain, _lib.SC_N))
+        self.vec = self.ctx.empty((self.n_chain, _lib.VEC_N, self.d))
+        self.n_leapfrog = torch.zeros((1,), dtype=torch.int64, device=self.ctx.device)
+        mv = None if metric is None else self.ctx.tensor(np.asarray(metric, dtype=np.float64).reshape(self.d))
+        im = None if initial_mean is None else self.ctx.tensor(np.asarray(initial_mean, dtype=np.float64).reshape(self.d))
+        _lib.check(lib.bfhip_rng_seed(h, self.n_chain, int(seed) & (2**64 - 1), int(first_stream), _ptr(self.rng)))
+        _lib.check(lib.bfhip_chain_init(h, self.n_chain, self.d, _ptr(x_0), float(step_size), _ptr(mv), _ptr(im),
+                                        float(initial_weight), int(adapt_window), _ptr(self.sc), _ptr(self.vec)))
+        self.i_iter = 0
+
+    def run(self, n_run, sampler='NUTS', n_warmup=500, max_treedepth=10, n_int_step=32, max_change=1000.,
+            target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,
+            update_window=1, doubling=True, samples=None, stats=None, check=True):
+        """Advance every chain by ``n_run`` iterations in ONE kernel launch.
+
+        Returns (samples (n_chain, n_run, d), stats (n_chain, n_run, 11)) device tensors; the stats columns
+        follow ``_lib.NSTATS`` / ``_lib.HSTATS`` (samplers/hmc_utils/stats.py:7-14)."""
+        torch = _torch()
+        self.density.upload_if_needed()
+        cfg = _lib.SamplerConfig()
+        cfg.sampler = {'NUTS': 0, 'HMC': 1}[sampler]
+        cfg.n_warmup = int(n_warmup)
+        cfg.max_treedepth = int(max_treedepth)
+        cfg.n_int_step = int(n_int_step)
+        cfg.max_change = float(max_change)
+        cfg.target_accept, cfg.gamma, cfg.k, cfg.t_0 = float(target_accept), float(gamma), float(k), float(t_0)
+        cfg.adapt_step_size, cfg.adapt_metric = int(bool(adapt_step_size)), int(bool(adapt_metric))
+        cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
+        n_run = int(n_run)
+        if samples is None:
+            samples = self.ctx.empty((self.n_chain, n_run, self.d))
+        if stats is None:
+            stats = self.ctx.empty((self.n_chain, n_run, _lib.STAT_STRIDE))
+        _lib.check(self.ctx._lib.bfhip_sampler_run(
+            self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + n_run, _ptr(self.rng), _ptr(self.sc),
+            _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
+        self.i_iter += n_run
+        if check:
+            self.raise_on_error()
+        return samples, stats
+
+    def raise_on_error(self):
+        """Synchronises; raises like the reference does for a chain that hit a fatal condition."""
+        err = self.sc[:, _lib.SC_FIELDS.index('error')]
+        bad = (err != 0).nonzero()
+        if bad.numel():
+            i = int(bad[0, 0])
+            code = int(err[i])
+            if code == 1:  # base_hmc.py:72-76
+                raise RuntimeError('Bad initial energy for chain #{}, please check the Hamiltonian.'.format(i))
+            raise FloatingPointError("logp can't be nan (chain #{}).".format(i))  # nuts.py:201-202
+
+    def field(self, name):
+        """One per-chain quantity by its reference name (device tensor view)."""
+        if name in _lib.SC_FIELDS:
+            return self.sc[:, _lib.SC_FIELDS.index(name)]
+        return self.vec[:, _lib.VEC_FIELDS.index(name)]
+
+    @property
+    def total_leapfrog(self):
+        return int(self.n_leapfrog.item())

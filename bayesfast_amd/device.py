@@ -188,17 +188,22 @@ class DeviceDensity:
         self.ctx = ctx if ctx is not None else get_context()
         self.d = int(spec['d'])
         self.spec = spec
-        ds, keep = density_desc_from_spec(spec)
-        _lib.check(self.ctx._lib.bfhip_density_upload(self.ctx.handle, C.byref(ds)))
+        self.upload()
 
     def upload(self):
-        """Make this density the context's current one again (a context holds one density at a time)."""
+        """Make this density the context's current one (a context holds one density at a time)."""
         ds, keep = density_desc_from_spec(self.spec)
         _lib.check(self.ctx._lib.bfhip_density_upload(self.ctx.handle, C.byref(ds)))
+        self.ctx._current_density = self
+
+    def upload_if_needed(self):
+        if getattr(self.ctx, '_current_density', None) is not self:
+            self.upload()
 
     def logp_and_grad(self, x, original_space=False):
         """x: (n, d) or (d,) array/tensor -> (logp (n,), grad (n, d)) float64 device tensors."""
         torch = _torch()
+        self.upload_if_needed()
         xt = self.ctx.tensor(x, torch.float64)
         single = xt.dim() == 1
         xt = xt.reshape(-1, self.d)
@@ -211,6 +216,7 @@ class DeviceDensity:
 
     def leapfrog(self, eps, var, q, p, grad, logp=None, energy=None, velocity=None):
         """In-place batched CpuLeapfrogIntegrator._step; all arguments float64 device tensors, (n,) or (n,d)."""
+        self.upload_if_needed()
         n = q.shape[0]
         if logp is None:
             logp = self.ctx.empty((n,))

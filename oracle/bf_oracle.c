@@ -403,7 +403,7 @@ void bfo_logp_and_grad(const bfo_density *dn, const double *x, int original_spac
     if (dn->use_decay) { /* density.py:740-746 */
         double beta2 = mahalanobis2(xo, dn->decay_mu, dn->decay_hess, d, hv);
         double ex = beta2 - dn->decay_alpha2;
-        f -= dn->decay_gamma * (ex > 0. ? ex : 0.);
+        f -= dn->decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.)); /* np.clip keeps NaN */
         if (beta2 > dn->decay_alpha2)
             for (int i = 0; i < d; ++i) g[i] -= 2 * dn->decay_gamma * hv[i];
     }
@@ -465,7 +465,15 @@ double bfo_rng_uniform(bfo_rng *r) {
     return (double)(bfo_xoshiro_next(r->s) >> 11) * TWO_M53; /* [0,1) */
 }
 
-/* n standard normals; xoshiro mode: Box-Muller on consecutive draw pairs (cos -> even, sin -> odd index) */
+static uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+/* n standard normals.  xoshiro mode (the device kernels' definition): ONE xoshiro draw K keys a SplitMix64
+ * counter stream u_i = mix64(K + (i+1) GOLDEN); pair P = (u_2P, u_2P+1) gives elements 2P (cos) and 2P+1
+ * (sin) by Box-Muller, so any lane can produce its own dimensions without walking the stream. */
 void bfo_rng_normal(bfo_rng *r, double *out, int n) {
     if (r->kind == 1) {
         for (int i = 0; i < n; ++i) {
@@ -474,9 +482,11 @@ void bfo_rng_normal(bfo_rng *r, double *out, int n) {
         }
         return;
     }
+    const uint64_t K = bfo_xoshiro_next(r->s);
     for (int i = 0; i < n; i += 2) {
-        double u1 = (double)((bfo_xoshiro_next(r->s) >> 11) + 1) * TWO_M53; /* (0,1] */
-        double u2 = (double)(bfo_xoshiro_next(r->s) >> 11) * TWO_M53;       /* [0,1) */
+        const uint64_t P = (uint64_t)(i / 2);
+        double u1 = (double)((mix64(K + (2 * P + 1) * 0x9E3779B97F4A7C15ULL) >> 11) + 1) * TWO_M53; /* (0,1] */
+        double u2 = (double)(mix64(K + (2 * P + 2) * 0x9E3779B97F4A7C15ULL) >> 11) * TWO_M53;       /* [0,1) */
         double rad = sqrt(-2. * log(u1));
         double th = TWO_PI * u2;
         out[i] = rad * cos(th);
@@ -664,6 +674,11 @@ static double dot(const double *a, const double *b, int d) {
     return s;
 }
 
+/* optional diagnostics: energies of every leaf, in integration order */
+double *bfo_trace_buf = NULL;
+long bfo_trace_cap = 0, bfo_trace_n = 0;
+void bfo_set_trace(double *buf, long cap) { bfo_trace_buf = buf; bfo_trace_cap = cap; bfo_trace_n = 0; }
+
 /* nuts.py:105-132 */
 static subtree single_step(tree_ctx *cx, const lf_state *left, double eps, int *diverging) {
     int d = cx->d;
@@ -673,6 +688,11 @@ static subtree single_step(tree_ctx *cx, const lf_state *left, double eps, int *
     bfo_leapfrog(cx->dn, cx->ch->var, eps, left->q, left->p, left->grad, right.q, right.p, right.v, right.grad,
                  &right.energy, &right.logp);
     cx->n_leapfrog += 1;
+    if (bfo_trace_buf && bfo_trace_n + 8 <= bfo_trace_cap) {
+        double *t = bfo_trace_buf + bfo_trace_n;
+        bfo_trace_n += 8;
+        t[0] = 0.; t[1] = right.energy; t[2] = eps; t[3] = t[4] = t[5] = t[6] = t[7] = 0.;
+    }
     double energy_change = right.energy - cx->start_energy;
     if (isnan(energy_change)) energy_change = INFINITY;
     if (fabs(energy_change) > fabs(cx->max_energy_change)) cx->max_energy_change = energy_change;
@@ -718,6 +738,12 @@ static subtree build_subtree(tree_ctx *cx, const lf_state *left, int depth, doub
     if (!(*diverging || *turning)) {
         for (int i = 0; i < d; ++i) t.p_sum[i] = t1.p_sum[i] + t2.p_sum[i];
         int turn = (dot(t.p_sum, t.left.v, d) <= 0) || (dot(t.p_sum, t.right.v, d) <= 0);
+        if (bfo_trace_buf && bfo_trace_n + 8 <= bfo_trace_cap) {
+            double *tt = bfo_trace_buf + bfo_trace_n;
+            bfo_trace_n += 8;
+            tt[0] = 1.; tt[1] = depth; tt[2] = dot(t.p_sum, t.left.v, d); tt[3] = dot(t.p_sum, t.right.v, d);
+            tt[4] = tt[5] = tt[6] = tt[7] = 0.;
+        }
         if (depth > 1) { /* nuts.py:154-161 */
             double *ps = (double *)malloc(sizeof(double) * (size_t)d);
             for (int i = 0; i < d; ++i) ps[i] = t1.p_sum[i] + t2.left.p[i];

@@ -1,0 +1,198 @@
+"""GPU parity of the fused NUTS/HMC kernel (through the C ABI) against the CPU oracle.
+
+T1 (trajectory): same xoshiro256++ stream => the device chain reproduces the oracle chain: tree depth,
+tree size and divergence flags exactly, positions to 1e-8 over the compared horizon (float64; the only
+differences are summation order and libm rounding, which chaotic warm-up trajectories amplify).
+T2 (statistical): posterior moments of an exactly-quadratic target vs the analytic values."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SEED = 20240917
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from bayesfast_amd.device import get_context
+    return get_context(0)
+
+
+@pytest.fixture(scope='module')
+def samp():
+    return np.load(os.path.join(G, 'sampler.npz'))
+
+
+def _spec(z, prefix):
+    from specio import rebuild_spec
+    return rebuild_spec(z, prefix)
+
+
+def _oracle_chains(spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, **kw):
+    from oracle import oracle as orc
+    out = []
+    for i in range(x0.shape[0]):
+        ch = orc.Chain(x0[i], **{k: v for k, v in kw.items() if k in ('step_size', 'target_accept')})
+        rng = orc.make_rng('xoshiro', seed=SEED, stream=first_stream + i)
+        if sampler == 'NUTS':
+            out.append(orc.nuts_run(spec, ch, rng, n_iter, n_warmup, max_treedepth=kw.get('max_treedepth', 10),
+                                    max_change=kw.get('max_change', 1000.)) + (ch,))
+        else:
+            out.append(orc.hmc_run(spec, ch, rng, n_iter, n_warmup, n_int_step=kw.get('n_int_step', 32),
+                                   max_change=kw.get('max_change', 1000.)) + (ch,))
+    return out
+
+
+def _device_chains(ctx, spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, split=None, **kw):
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd import _lib
+    dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=SEED, first_stream=first_stream,
+                      step_size=kw.get('step_size', 1.))
+    run_kw = {k: v for k, v in kw.items() if k in ('max_treedepth', 'max_change', 'n_int_step', 'target_accept')}
+    if split is None:
+        s, st = dc.run(n_iter, sampler, n_warmup=n_warmup, **run_kw)
+    else:  # two launches: the state arrays carry the chains across (resume)
+        s1, st1 = dc.run(split, sampler, n_warmup=n_warmup, **run_kw)
+        s2, st2 = dc.run(n_iter - split, sampler, n_warmup=n_warmup, **run_kw)
+        import torch
+        s, st = torch.cat([s1, s2], 1), torch.cat([st1, st2], 1)
+    names = _lib.NSTATS if sampler == 'NUTS' else _lib.HSTATS
+    st = st.cpu().numpy()
+    return s.cpu().numpy(), {k: st[:, :, i] for i, k in enumerate(names)}, dc
+
+
+def _compare_nuts(dev, orc_runs, n_exact, rtol_q=1e-5, n_head=8):
+    """Discrete fields exactly over the whole horizon; positions to 1e-9 on the first n_head iterations and
+    to rtol_q overall (warm-up trajectories at step sizes near the stability limit amplify the 1e-16
+    summation-order differences by orders of magnitude per iteration)."""
+    s, st, dc = dev
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        for f in ('tree_depth', 'tree_size', 'diverging', 'warmup'):
+            assert np.array_equal(st[f][i][:n_exact], sto[f][:n_exact]), (i, f, st[f][i][:n_exact], sto[f][:n_exact])
+        np.testing.assert_allclose(s[i][:n_head], so[:n_head], rtol=1e-9, atol=1e-9, err_msg='chain %d' % i)
+        np.testing.assert_allclose(s[i][:n_exact], so[:n_exact], rtol=rtol_q, atol=rtol_q, err_msg='chain %d' % i)
+        for f in ('logp', 'energy', 'mean_tree_accept', 'step_size', 'step_size_bar', 'energy_change', 'max_energy_change'):
+            np.testing.assert_allclose(st[f][i][:n_head], sto[f][:n_head], rtol=1e-8, atol=1e-8, err_msg=f)
+            np.testing.assert_allclose(st[f][i][:n_exact], sto[f][:n_exact], rtol=1e-4, atol=1e-4, err_msg=f)
+
+
+@pytest.mark.parametrize('name,n_chain,n_iter,n_warmup', [('plain16', 5, 40, 25), ('d64', 19, 30, 20), ('full5', 3, 25, 15)])
+def test_nuts_trajectories_match_oracle(ctx, samp, name, n_chain, n_iter, n_warmup):
+    spec = _spec(samp, name + '.')
+    rng = np.random.default_rng(3)
+    x0 = rng.normal(size=(n_chain, spec['d'])) * 0.5
+    dev = _device_chains(ctx, spec, x0, n_iter, n_warmup)
+    orc_runs = _oracle_chains(spec, x0, n_iter, n_warmup)
+    _compare_nuts(dev, orc_runs, n_iter)
+    # adapted metric and n_leapfrog accounting
+    s, st, dc = dev
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        np.testing.assert_allclose(dc.field('var')[i].cpu().numpy(), ch.vec('var'), rtol=1e-5)
+    assert dc.total_leapfrog == int(sum(r[1]['tree_size'].sum() for r in orc_runs))
+
+
+def test_nuts_resume_and_shard_invariance(ctx, samp):
+    """Two launches == one launch; a chain's result depends on its GLOBAL stream index only."""
+    spec = _spec(samp, 'plain16.')
+    rng = np.random.default_rng(4)
+    x0 = rng.normal(size=(20, 16)) * 0.5
+    s_all, st_all, _ = _device_chains(ctx, spec, x0, 30, 20)
+    s_split, st_split, _ = _device_chains(ctx, spec, x0, 30, 20, split=13)
+    assert np.array_equal(s_all, s_split)
+    assert np.array_equal(st_all['tree_size'], st_split['tree_size'])
+    s_tail, st_tail, _ = _device_chains(ctx, spec, x0[7:], 30, 20, first_stream=7)
+    assert np.array_equal(s_all[7:], s_tail)
+
+
+def test_nuts_divergences_and_max_treedepth(ctx, samp):
+    """Huge step size => divergent leaves and immediate U-turns; tiny max_treedepth => depth cap."""
+    spec = _spec(samp, 'div5.')
+    x0 = np.repeat(samp['div5.x0'], 4, 0) + np.arange(4)[:, None] * 0.1
+    kw = dict(step_size=40., max_change=50.)
+    dev = _device_chains(ctx, spec, x0, 30, 10, **kw)
+    orc_runs = _oracle_chains(spec, x0, 30, 10, **kw)
+    assert sum(r[1]['diverging'].sum() for r in orc_runs) >= 1
+    _compare_nuts(dev, orc_runs, 30)
+    spec = _spec(samp, 'plain16.')
+    x0 = np.random.default_rng(5).normal(size=(4, 16))
+    kw = dict(step_size=0.05, max_treedepth=3)
+    dev = _device_chains(ctx, spec, x0, 12, 0, **kw)
+    orc_runs = _oracle_chains(spec, x0, 12, 0, **kw)
+    assert dev[1]['tree_depth'].max() == 3 and dev[1]['tree_size'].max() == 7
+    _compare_nuts(dev, orc_runs, 12)
+
+
+def test_nuts_far_start_extrapolation_branch(ctx, samp):
+    """Start 6 sigma out: the chains begin outside the surrogate's alpha-ellipsoid (poly.py:480-503) and
+    the first trees see energy changes of hundreds (weights over a huge dynamic range)."""
+    spec = _spec(samp, 'd64.')
+    rng = np.random.default_rng(6)
+    x0 = rng.normal(size=(6, 64)) * 6.
+    from oracle import oracle as orc
+    mu, H = spec['poly']['mu'], spec['poly']['hess']
+    assert (np.sqrt(np.einsum('ij,jk,ik->i', x0 - mu, H, x0 - mu)) > spec['poly']['alpha']).all()
+    dev = _device_chains(ctx, spec, x0, 12, 8)
+    orc_runs = _oracle_chains(spec, x0, 12, 8)
+    _compare_nuts(dev, orc_runs, 12)
+
+
+@pytest.mark.parametrize('name', ['plain16', 'full5'])
+def test_hmc_trajectories_match_oracle(ctx, samp, name):
+    spec = _spec(samp, name + '.')
+    rng = np.random.default_rng(7)
+    x0 = rng.normal(size=(6, spec['d'])) * 0.5
+    s, st, dc = _device_chains(ctx, spec, x0, 30, 20, sampler='HMC', n_int_step=8)
+    orc_runs = _oracle_chains(spec, x0, 30, 20, sampler='HMC', n_int_step=8)
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        for f in ('accepted', 'diverging', 'n_int_step'):
+            assert np.array_equal(st[f][i], sto[f]), (i, f)
+        np.testing.assert_allclose(s[i][:8], so[:8], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(st['accept_stat'][i], sto['accept_stat'], rtol=1e-3, atol=1e-3)
+    assert dc.total_leapfrog == 6 * 30 * 8
+
+
+def test_bad_initial_energy_raises(ctx, samp):
+    """Non-finite initial energy is an error, not a divergence (base_hmc.py:72-76)."""
+    spec = _spec(samp, 'plain16.')
+    x0 = np.zeros((3, 16))
+    x0[1, 0] = np.inf
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=1)
+    with pytest.raises(RuntimeError):
+        dc.run(3, n_warmup=1)
+
+
+def test_nuts_posterior_moments_quadratic_target(ctx):
+    """T2: an exactly quadratic log density; 2048 chains x (150 warm-up + 100) draws vs N(0, P^-1)."""
+    d = 32
+    rng = np.random.default_rng(123)
+    L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
+    P = L @ L.T
+    cov = np.linalg.inv(P)
+    quad = np.zeros((d, d))
+    iu = np.triu_indices(d)
+    A = -0.5 * P
+    quad[iu] = A[iu] * np.where(iu[0] == iu[1], 1., 2.)
+    spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, use_decay=False,
+                poly=dict(input_size=d, output_size=1, use_bound=False, configs=[
+                    dict(order='linear', input_mask=np.arange(d), output_mask=[0], coef=np.zeros((1, d + 1))),
+                    dict(order='quadratic', input_mask=np.arange(d), output_mask=[0], coef=quad[None])]))
+    n_chain = 2048
+    x0 = rng.normal(size=(n_chain, d))
+    s, st, dc = _device_chains(ctx, spec, x0, 250, 150)
+    draws = s[:, 150:].reshape(-1, d)
+    assert st['diverging'][:, 150:].sum() == 0
+    acc = st['mean_tree_accept'][:, 150:].mean()
+    assert 0.7 < acc < 0.92, acc
+    sd = np.sqrt(np.diag(cov))
+    n_eff = n_chain * 100 / 4.  # conservative
+    assert np.all(np.abs(draws.mean(0)) < 5 * sd / np.sqrt(n_eff))
+    np.testing.assert_allclose(draws.var(0), np.diag(cov), rtol=0.05)
+    emp = np.cov(draws, rowvar=False)
+    assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.03
