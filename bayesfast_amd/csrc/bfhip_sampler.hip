@@ -1,14 +1,15 @@
 // bfhip_sampler.hip -- fused NUTS / HMC transitions for many chains (gfx950).
 //
 // Work decomposition ("tile phase / chain phase"):
-//   * A workgroup of W = DP/16 wavefronts owns a GROUP of 16 chains for the whole launch.
-//   * Tile phase (gradient): the batched matvecs G^T = S X^T and (H (X-mu)^T) for the 16 chains run on
-//     v_mfma_f64_16x16x4_f64.  Wave w computes output rows 16w..16w+15 for all 16 chains; its A operands
-//     (one 16 x DP row tile of S and of H) stay in registers for the whole launch.
-//   * Chain phase (everything O(d)): wave w owns chains w*CPW .. w*CPW+CPW-1 (CPW = 16/W); a chain is a
-//     ROW of RW = 4W consecutive lanes, lane j of the row holds dimensions 4j..4j+3 of every state vector.
-//     Dot products are row reductions (no LDS, no barrier); per-chain scalars are replicated over the row.
-//   * The two layouts meet in LDS: XB (B operands, written by the chain phase) and GB (matvec results).
+//   * A workgroup of 16 wavefronts owns a GROUP of 16 chains for the whole launch: 4 waves per SIMD, so the
+//     latency-bound per-chain logic of one wave hides behind the other three.
+//   * Chain phase (everything O(d)): ONE WAVE PER CHAIN.  Lane l holds dimensions l*E .. l*E+E-1 of every
+//     state vector (E = DP/64, 1 at d <= 64).  All tree control flow is wave-uniform: no cross-chain
+//     divergence, dot products are wave reductions, per-chain scalars live once per wave.
+//   * Tile phase (gradient): the batched matvecs G^T = S X^T and H (X - mu)^T of the 16 chains run on
+//     v_mfma_f64_16x16x4_f64 in the first W = DP/16 waves (wave w: output rows 16w..16w+15 for all 16 chains).
+//     The coefficient matrices S, H (, H_decay) are staged once per launch in LDS as A-operand fragments.
+//   * The two layouts meet in LDS: XB (B operands, written by the chain waves) and GB (matvec results).
 //     Two workgroup barriers per trip, none inside the tree logic.
 //
 // Every chain is an independent state machine (INIT -> LEAF ... -> iteration end -> INIT ...); one loop
@@ -18,7 +19,9 @@
 //
 // The recursion of Tree._build_subtree (samplers/nuts.py:134-178) is flattened: leaf i of a 2^depth
 // subtree is merged upwards while bit `level` of i is set; completed sub-subtrees wait on a per-chain
-// stack (vectors in global scratch, scalars in LDS).  Random draws are consumed in the recursion's
+// stack (vectors in global scratch, scalars in LDS).  The per-chain logic is time-sliced into UNITS (finish
+// an evaluation / one merge level / end of a doubling / three pieces of the iteration end), one unit per
+// chain per trip, so the workgroup barrier never waits for a long bookkeeping path of one chain.  Random draws are consumed in the recursion's
 // post-order, so a chain reproduces the CPU oracle's trajectory for the same xoshiro stream.
 #include "bfhip_eval.h"
 
@@ -29,94 +32,141 @@ struct SamplerArgs {
     double *sc, *vec, *samples, *stats;
     unsigned long long *n_leapfrog;
     double *scratch;
-    double *dbg;      // optional trace of one chain: [dbg_cap][32] doubles (diagnostics only)
-    int dbg_chain, dbg_cap;
+    unsigned long long *stamps;  // diagnostics only: [groups][16 waves][8] cycle counters per phase, or NULL
 };
 
 enum { M_INIT = 0, M_LEAF = 1, M_OOB = 2, M_DONE = 3 };
+// units of per-chain work; a chain runs one per trip (U_EVAL needs this trip's gradient)
+enum { U_EVAL = 0, U_MERGE_RUN, U_DBL_END, U_END1, U_END2, U_END3, U_DONE, U_MERGE, U_ABORT };
 enum { SL_LEFT_Q = 0, SL_LEFT_P, SL_LEFT_G, SL_RIGHT_Q, SL_RIGHT_P, SL_RIGHT_G, SL_PROP_Q, SL_PSUM, SL_STACK };
 enum { LS_LS = 0, LS_E, LS_LOGP, LS_ACC, LS_N };
+// cold per-chain scalars parked in LDS (one writer: lane 0 of the chain's wave; broadcast reads)
+enum { CS_LOG_STEP = 0, CS_LOG_BAR, CS_HBAR, CS_SMU, CS_COUNT, CS_PROP_E, CS_PROP_LOGP, CS_MAX_DE, CS_HACC, CS_HDE,
+       CS_W_OFF, CS_TREE_W, CS_BETA, CS_T_E, CS_T_LOGP, CS_N };
 
-__device__ inline void ld4(const double *p, double (&v)[4]) {
-    const d2_t a = ((const d2_t *)p)[0], b = ((const d2_t *)p)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+// one DPP move of a double (both halves)
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ inline void st4(double *p, const double (&v)[4]) {
-    d2_t a, b;
-    a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
-    ((d2_t *)p)[0] = a;
-    ((d2_t *)p)[1] = b;
+__device__ inline double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// sum over the 64 lanes, wave-uniform result: DPP butterflies inside each row of 16 lanes (no LDS
+// crossbar), then the four row totals are read to scalar registers and added in a fixed order
+__device__ inline double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror
+    return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 
-template <int RW>
-__device__ inline double row_sum(double v) {
-#pragma unroll
-    for (int msk = RW / 2; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk, 64);
-    return v;
-}
+template <int W>
+struct SamplerGeo {
+    static constexpr int DP = 16 * W, NS = 4 * W;
+    static constexpr int E = DP >= 64 ? DP / 64 : 1;  // state elements per lane
+    static constexpr int XS = 65;                     // XB row stride (doubles)
+    static constexpr int GS = DP + 1;                 // GB row stride
+    static constexpr int MAT = DP * DP;
+    static constexpr bool STAGE = DP <= 64;           // coefficient fragments fit in LDS
+};
 
 template <int W, bool NUTS>
-__global__ __launch_bounds__(64 * W) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
-    constexpr int DP = 16 * W, NS = 4 * W, RW = 4 * W, CPW = 16 / W;
-    constexpr int XS = 65;       // XB row stride (doubles): odd => conflict-free column writes
-    constexpr int GS = DP + 1;   // GB row stride
+__global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
+    using G = SamplerGeo<W>;
+    constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
     constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *XB = lds;                        // [3][NS][XS]
-    double *GB = XB + 3 * NS * XS;           // [3][16][GS]
-    double *PDL = GB + 3 * 16 * GS;          // [PD_N][DP]
-    double *LS = PDL + PD_N * DP;            // [MAXL][LS_N][16]
-    int *alive = (int *)(LS + MAXL * LS_N * 16);  // [2]
+    double *XB = lds;                         // [3][NS][XS]   B operands
+    double *GB = XB + 3 * NS * XS;            // [3][16][GS]   matvec results
+    double *LS = GB + 3 * 16 * GS;            // [16][MAXL][LS_N] per-chain stack scalars
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] (+ pad)
+    double *CS = LS + 16 * MAXL * LS_N + 2;   // [16][CS_N]    cold per-chain scalars (kept out of the VGPR budget)
+    double *PDL = CS + 16 * CS_N;             // [PD_N][DP]    per-dimension table (rarely used rows are read from here)
+    double *FR = PDL + PD_N * DP;             // staged A fragments: S | H | H_decay
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // tile-phase identity
-    const int mc = lane & 15, mg = lane >> 4;
-    // chain-phase identity
-    const int row = lane / RW, j = lane % RW;
-    const int cl = w * CPW + row;
-    const int chain = blockIdx.x * 16 + cl;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
+    const int chain = blockIdx.x * 16 + w;
     const bool real = chain < a.n_chain;
     const int d = m.d;
 
-    for (int i = tid; i < PD_N * DP; i += 64 * W) PDL[i] = m.pd[i];
-    if (tid < 2) alive[tid] = 0;
-
-    // A operands of this wave's row tile, resident in registers for the whole launch
-    double Sreg[NS], Hreg[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        Sreg[s] = m.has_quad ? m.Sf[(w * NS + s) * 64 + lane] : 0.;
-        Hreg[s] = m.use_bound ? m.Hf[(w * NS + s) * 64 + lane] : 0.;
+    // ---- stage the coefficient matrices (A-operand fragments) in LDS ----
+    const double *Sf = m.Sf, *Hf = m.Hf, *Hdf = m.Hdf;
+    if constexpr (G::STAGE) {
+        double *pS = FR, *pH = pS + (m.has_quad ? MAT : 0), *pD = pH + (m.use_bound ? MAT : 0);
+        if (m.has_quad)
+            for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pS)[i] = ((const d2_t *)m.Sf)[i];
+        if (m.use_bound)
+            for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pH)[i] = ((const d2_t *)m.Hf)[i];
+        if (m.use_decay)
+            for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pD)[i] = ((const d2_t *)m.Hdf)[i];
+        Sf = pS; Hf = pH; Hdf = pD;
     }
+    if (tid < 2) alive[tid] = 0;
+    for (int i = tid; i < PD_N * DP; i += 1024) PDL[i] = m.pd[i];
 
-    // ---- per-chain state ----
-    double q[4], p[4] = {0., 0., 0., 0.}, g[4] = {0., 0., 0., 0.}, var[4];
-    double TLp[4], TPs[4], TPq[4];
+    // ---- per-lane constants: the per-dimension table rows of this lane's dimensions ----
+    double c_lin[E], c_mu[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int dim = lane * E + e;
+        const bool in = dim < DP;
+        c_lin[e] = in ? m.pd[PD_LIN * DP + dim] : 0.;
+        c_mu[e] = in ? m.pd[PD_MU * DP + dim] : 0.;
+    }
+    // rows of the per-dimension table that only optional features read (from LDS, in their branches)
+    auto pdl = [&](int rowi, int e) -> double {
+        const int dim = lane * E + e;
+        return dim < DP ? PDL[rowi * DP + dim] : ((rowi == PD_RG || rowi == PD_SU_DIFF) ? 1. : 0.);
+    };
+
+    // ---- per-chain state (scalars are wave-uniform) ----
+    double q[E], p[E], g[E], var[E], TLp[E], TPs[E], TPq[E];
     uint64_t rs[4] = {0, 0, 0, 0};
-    double log_step = 0., log_bar = 0., hbar = 0., smu = 0., count = 1.;
     int i_iter = 0, mode = M_DONE, prev_mode = M_INIT, err = 0;
-    double eps = 0., eps_t = 0., beta_saved = 0.;
+    double eps = 0., eps_t = 0.;
     int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0;
-    double start_energy = 0., tree_ls = 0., acc_sum = 0., max_dE = 0., prop_E = 0., prop_logp = 0.;
-    double T_ls = 0., T_E = 0., T_logp = 0., T_acc = 0.;
+    double start_energy = 0., acc_sum = 0.;
+    double T_W = 0., T_acc = 0.;
+    int unit = U_DONE, lev = 0, h_accepted = 0;
+    double *csw = CS + w * CS_N;
+    auto cs_set = [&](int i, double v) { if (lane == 0) csw[i] = v; };
     unsigned long long nlf = 0;
-    double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + 4 * j;
+    const bool lane_ok = lane * E < DP;  // lanes beyond the padded dimension idle (DP < 64)
+    double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + lane * E;
     double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
     double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
+    double *lsw = LS + w * (MAXL * LS_N);
     const int nw = a.cfg.n_warmup;
 
-    auto load_vec = [&](int field, double (&v)[4], double pad) {
+    auto load_vec = [&](int field, double (&v)[E], double pad) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int dim = 4 * j + e;
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
             v[e] = (dim < d) ? vecp[field * d + dim] : pad;
         }
     };
-    auto store_vec = [&](int field, const double (&v)[4]) {
+    auto store_vec = [&](int field, const double (&v)[E]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int dim = 4 * j + e;
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
             if (dim < d) vecp[field * d + dim] = v[e];
+        }
+    };
+    auto ldv = [&](int slot, double (&v)[E]) {  // scratch vector slot -> registers (coalesced, 512 B per wave at E = 1)
+        if (lane_ok) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = sbase[(size_t)slot * DP + e];
+        }
+    };
+    auto stv = [&](int slot, const double (&v)[E]) {
+        if (lane_ok) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) sbase[(size_t)slot * DP + e] = v[e];
         }
     };
     // metric.random: samplers/hmc_utils/metrics.py:83-86.  One xoshiro draw K keys a SplitMix64 counter
@@ -124,580 +174,590 @@ __global__ __launch_bounds__(64 * W) void bf_sampler_kernel(DevModel m, SamplerA
     auto draw_momentum = [&]() {
         const uint64_t K = bf_xoshiro_next(rs);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint64_t P = (uint64_t)(2 * j + h);
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
+            const uint64_t P = (uint64_t)(dim >> 1);
             const double u1 = bf_u01_open0(bf_mix64(K + (2 * P + 1) * BF_GOLDEN));
             const double u2 = bf_u01(bf_mix64(K + (2 * P + 2) * BF_GOLDEN));
             const double rad = sqrt(-2. * log(u1));
-            const double th = BF_TWO_PI * u2;
-            const double z0 = rad * cos(th), z1 = rad * sin(th);
-            const int d0 = 4 * j + 2 * h;
-            p[2 * h] = (d0 < d) ? (1. / sqrt(var[2 * h])) * z0 : 0.;
-            p[2 * h + 1] = (d0 + 1 < d) ? (1. / sqrt(var[2 * h + 1])) * z1 : 0.;
+            double sn, cs;
+            sincospi(2. * u2, &sn, &cs);  // angle 2 pi u2 without a large-argument reduction
+            const double z = (dim & 1) ? rad * sn : rad * cs;
+            p[e] = (dim < d) ? (1. / sqrt(var[e])) * z : 0.;
+            g[e] = 0.;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] = 0.;
     };
-
+#pragma unroll
+    for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; }
     if (real) {
         for (int k = 0; k < 4; ++k) rs[k] = a.rng[(size_t)chain * 4 + k];
-        log_step = scp[BFHIP_SC_LOG_STEP];
-        log_bar = scp[BFHIP_SC_LOG_BAR];
-        hbar = scp[BFHIP_SC_HBAR];
-        smu = scp[BFHIP_SC_MU];
-        count = scp[BFHIP_SC_COUNT];
+        cs_set(CS_LOG_STEP, scp[BFHIP_SC_LOG_STEP]);
+        cs_set(CS_LOG_BAR, scp[BFHIP_SC_LOG_BAR]);
+        cs_set(CS_HBAR, scp[BFHIP_SC_HBAR]);
+        cs_set(CS_SMU, scp[BFHIP_SC_MU]);
+        cs_set(CS_COUNT, scp[BFHIP_SC_COUNT]);
         i_iter = (int)scp[BFHIP_SC_I_ITER];
         err = (int)scp[BFHIP_SC_ERROR];
         load_vec(BFHIP_VEC_Q, q, 0.);
         load_vec(BFHIP_VEC_VAR, var, 1.);
         if (i_iter < a.iter_end && err == 0) {
             mode = M_INIT;
+            unit = U_EVAL;
             draw_momentum();
         }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; }
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; }
     __syncthreads();
 
-    // uniform draw of this chain's stream; logbern(l) = log(U) < l (samplers/nuts.py:200-203)
-    auto logbern = [&](double l) -> bool {
-        if (l != l) err = 2;
-        return log(bf_u01(bf_xoshiro_next(rs))) < l;
-    };
-
-    for (int trip = 0;; ++trip) {
-        // ================= phase A: first half of the leapfrog, B operands =================
-        double xs[4], jac[4], gj[4], xo[4];
-        double logdet = 0.;
-        const bool evaluating = mode != M_DONE;
-        if (evaluating) {
-            if (mode != M_OOB) {
-                eps_t = (mode == M_LEAF) ? eps * (double)dir : 0.;
-                const double dt = 0.5 * eps_t;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    p[e] = p[e] + dt * g[e];               // integration.py:80
-                    q[e] = q[e] + eps_t * (var[e] * p[e]); // :82-85
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int dim = 4 * j + e;
-                xo[e] = q[e];
-                jac[e] = 1.;
-                gj[e] = 0.;
-                if (m.has_transform) {
-                    double J, J2;
-                    bf_to_original(q[e], (int)PDL[PD_KIND * DP + dim], PDL[PD_LO * DP + dim], PDL[PD_RG * DP + dim],
-                                   xo[e], J, J2);
-                    logdet += log(fabs(J));
-                    jac[e] = J;
-                    gj[e] = J2 / J;
-                }
-                xs[e] = m.has_su ? (xo[e] - PDL[PD_SU_LO * DP + dim]) / PDL[PD_SU_DIFF * DP + dim] : xo[e];
-                const double mu = PDL[PD_MU * DP + dim];
-                double x_eval = xs[e];
-                if (mode == M_OOB)  // modules/poly.py:482
-                    x_eval = (m.alpha * xs[e] + (beta_saved - m.alpha) * mu) / beta_saved;
-                XB[(0 * NS + j) * XS + cl + 16 * e] = x_eval;
-                if (m.use_bound) XB[(1 * NS + j) * XS + cl + 16 * e] = xs[e] - mu;
-                if (m.use_decay) XB[(2 * NS + j) * XS + cl + 16 * e] = xo[e] - PDL[PD_DMU * DP + dim];
-            }
-            alive[trip & 1] = 1;
-        }
-        __syncthreads();  // B1
-        if (alive[trip & 1] == 0) break;  // every chain of the group is done (uniform)
-        if (tid == 0) alive[(trip + 1) & 1] = 0;
-
-        // ================= phase B: gradient tile on MFMA =================
-        {
-            d4_t accS = {0., 0., 0., 0.}, accH = {0., 0., 0., 0.}, accD = {0., 0., 0., 0.};
-            if (m.has_quad) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    accS = __builtin_amdgcn_mfma_f64_16x16x4f64(Sreg[s], XB[(0 * NS + s) * XS + lane], accS, 0, 0, 0);
-            }
-            if (m.use_bound) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    accH = __builtin_amdgcn_mfma_f64_16x16x4f64(Hreg[s], XB[(1 * NS + s) * XS + lane], accH, 0, 0, 0);
-            }
-            if (m.use_decay) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    accD = __builtin_amdgcn_mfma_f64_16x16x4f64(m.Hdf[(w * NS + s) * 64 + lane],
-                                                                XB[(2 * NS + s) * XS + lane], accD, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int dim = 16 * w + 4 * r4 + mg;
-                GB[(0 * 16 + mc) * GS + dim] = accS[r4];
-                if (m.use_bound) GB[(1 * 16 + mc) * GS + dim] = accH[r4];
-                if (m.use_decay) GB[(2 * 16 + mc) * GS + dim] = accD[r4];
-            }
-        }
-        __syncthreads();  // B2
-
-        // ================= phase C: finish the evaluation =================
-        double gn[4], hv[4], dgr[4], xm[4];
-        double logp_new = 0., E_new = 0.;
-        bool have_eval = false;
-        if (evaluating) {
-            double red[5] = {0., 0., 0., 0., 0.};  // quad (quad_0), lin (lin_0), beta^2, dot(jj_0, x-mu), decay beta^2
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int dim = 4 * j + e;
-                const double c = PDL[PD_LIN * DP + dim];
-                const double mu = PDL[PD_MU * DP + dim];
-                double sx = GB[(0 * 16 + cl) * GS + dim];
-                hv[e] = m.use_bound ? GB[(1 * 16 + cl) * GS + dim] : 0.;
-                dgr[e] = m.use_decay ? GB[(2 * 16 + cl) * GS + dim] : 0.;
-                xm[e] = xs[e] - mu;
-                double x_eval = xs[e];
-                if (mode == M_OOB) x_eval = (m.alpha * xs[e] + (beta_saved - m.alpha) * mu) / beta_saved;
-                red[0] += x_eval * sx;
-                red[1] += c * x_eval;
-                gn[e] = sx + c;
-                red[2] += xm[e] * hv[e];
-                if (mode == M_OOB) red[3] += gn[e] * xm[e];  // dot(jj_0, x - mu), poly.py:496
-                red[4] += (xo[e] - PDL[PD_DMU * DP + dim]) * dgr[e];
-            }
-            red[0] = row_sum<RW>(red[0]);
-            red[1] = row_sum<RW>(red[1]);
-            if (m.use_bound) red[2] = row_sum<RW>(red[2]);
-            if (m.use_bound) red[3] = row_sum<RW>(red[3]);
-            if (m.use_decay) red[4] = row_sum<RW>(red[4]);
-            if (m.has_transform) logdet = row_sum<RW>(logdet);
-
-            double f = (m.c0 + red[1]) + 0.5 * red[0];
-            const double beta = sqrt(red[2]);
-            bool oob_now = false;
-            if (m.use_bound) {
-                if (mode == M_OOB) {  // second pass: f, gn currently hold f_0 and jj_0 (poly.py:484-496)
-                    const double f0 = f;
-                    f = (beta_saved * f0 - (beta_saved - m.alpha) * m.f_mu) / m.alpha;
-                    const double coef = (f0 - m.f_mu) / m.alpha - red[3] / beta_saved;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gn[e] = gn[e] + coef * (hv[e] / beta_saved);
-                } else if (beta > m.alpha) {
-                    oob_now = true;
-                }
-            }
-            if (oob_now) {
-                // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
-                beta_saved = beta;
-                prev_mode = mode;
-                mode = M_OOB;
-            } else {
-                if (mode == M_OOB) mode = prev_mode;
-                // chain rule (module.py:226, density.py:558), decay (:740-746), transform (:747-750)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (m.has_su) gn[e] = gn[e] / PDL[PD_SU_DIFF * DP + 4 * j + e];
-                    gn[e] = gn[e] * jac[e];
-                }
-                if (m.use_decay) {
-                    f -= m.decay_gamma * bf_clip0(red[4] - m.decay_alpha2);
-                    if (red[4] > m.decay_alpha2) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
-                    }
-                }
-                if (m.has_transform) {
-                    f += logdet;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gn[e] += gj[e];
-                }
-                logp_new = f;
-                have_eval = true;
-            }
-        }
-        // second half of the leapfrog and the kinetic energy
-        {
-            const bool need_kin = have_eval;
-            double kin = 0.;
-            const double dt = 0.5 * eps_t;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double pe = p[e] + dt * gn[e];  // integration.py:90
-                kin += pe * (var[e] * pe);            // metrics.py:88-91
-                if (need_kin) p[e] = pe;
-            }
-            if (__any(need_kin)) kin = row_sum<RW>(kin);
-            E_new = 0.5 * kin - logp_new;            // integration.py:92-93
-        }
-
-        // ================= per-chain state machine =================
-        double dbgv[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-        bool it_end = false;   // this chain finished an iteration in this trip
-        bool complete = false; // NUTS: subtree of this doubling is complete
-        const bool is_leaf = have_eval && mode == M_LEAF;  // (an INIT trip becomes M_LEAF below; it is not a leaf)
-        if (have_eval) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = gn[e];
-            if (mode == M_INIT) {
+    // ---- the per-chain state machine: ONE unit of work per call (wave-uniform control flow) ----
+    auto run_unit = [&](bool have_ev, double E_new, double logp_new) {
+        // ================= per-chain state machine: ONE unit of work per trip =================
+        // (wave-uniform control flow; the barrier-to-barrier critical path is the longest single unit)
+        if (unit == U_EVAL) {
+            if (have_ev && mode == M_INIT) {
                 // BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43
                 if (!(fabs(E_new) <= 1.7976931348623157e308)) {
                     err = 1;
-                    mode = M_DONE;
                 } else {
                     start_energy = E_new;
-                    st4(sbase + SL_LEFT_Q * DP, q);
-                    st4(sbase + SL_LEFT_P * DP, p);
-                    st4(sbase + SL_LEFT_G * DP, g);
-                    st4(sbase + SL_RIGHT_Q * DP, q);
-                    st4(sbase + SL_RIGHT_P * DP, p);
-                    st4(sbase + SL_RIGHT_G * DP, g);
-                    st4(sbase + SL_PROP_Q * DP, q);
-                    st4(sbase + SL_PSUM * DP, p);
-                    prop_E = E_new;
-                    prop_logp = logp_new;
-                    depth = 0;
-                    tree_ls = 0.;
-                    acc_sum = 0.;
-                    n_prop = 0;
-                    max_dE = 0.;
-                    diverged = 0;
-                    i_leaf = 0;
-                    eps = exp(i_iter < nw ? log_step : log_bar);  // step_size.py:25-29
+                    stv(SL_LEFT_Q, q); stv(SL_LEFT_P, p); stv(SL_LEFT_G, g);
+                    stv(SL_RIGHT_Q, q); stv(SL_RIGHT_P, p); stv(SL_RIGHT_G, g);
+                    stv(SL_PROP_Q, q); stv(SL_PSUM, p);
+                    cs_set(CS_PROP_E, E_new);
+                    cs_set(CS_PROP_LOGP, logp_new);
+                    cs_set(CS_TREE_W, 1.);
+                    cs_set(CS_W_OFF, 0.);
+                    cs_set(CS_MAX_DE, 0.);
+                    depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
+                    eps = exp(i_iter < nw ? csw[CS_LOG_STEP] : csw[CS_LOG_BAR]);  // step_size.py:25-29
                     dir = 1;
-                    if (NUTS) dir = logbern(-0.6931471805599453094) ? 1 : -1;  // nuts.py:210
+                    if (NUTS) dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
                     mode = M_LEAF;
                 }
-            } else if (mode == M_LEAF) {
+            } else if (have_ev && mode == M_LEAF) {
                 nlf += 1;
                 if (NUTS) {
                     // ---- Tree._single_step: nuts.py:105-132 ----
                     n_prop += 1;
                     double dE = E_new - start_energy;
                     if (dE != dE) dE = INFINITY;
-                    if (fabs(dE) > fabs(max_dE)) max_dE = dE;
+                    if (fabs(dE) > fabs(csw[CS_MAX_DE])) cs_set(CS_MAX_DE, dE);
+                    cs_set(CS_T_E, E_new);
+                    cs_set(CS_T_LOGP, logp_new);
+                    T_acc = 0.; lev = 0;
                     if (fabs(dE) < a.cfg.max_change) {
-                        const double pacc = exp(-dE);
+                        // multinomial weight exp(log_size) = exp(-dE), kept in the linear domain relative to
+                        // a running offset w_off (exact streaming log-sum-exp; rescales are rare)
+                        const double w_off = csw[CS_W_OFF];
+                        double aw = -dE - w_off;
+                        if (aw > 600.) {
+                            const double sc_ = exp(-aw);
+                            cs_set(CS_TREE_W, csw[CS_TREE_W] * sc_);
+                            if (lane == 0)
+                                for (int l2 = 0; l2 < depth; ++l2) lsw[l2 * LS_N + LS_LS] *= sc_;
+                            cs_set(CS_W_OFF, w_off + aw);
+                            aw = 0.;
+                        }
+                        T_W = exp(aw);
+                        const double pacc = (csw[CS_W_OFF] == 0.) ? T_W : exp(-dE);
                         T_acc = pacc > 1. ? 1. : pacc;
-                        T_ls = -dE;
-                        T_E = E_new;
-                        T_logp = logp_new;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
+                        for (int e = 0; e < E; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
+                        unit = U_MERGE;  // resolved below (push / complete need no further trip)
                     } else {
                         diverged = 1;
-                        T_acc = 0.;
+                        unit = U_ABORT;
                     }
                 } else {
+                    // ---- HMC._hamiltonian_step: samplers/hmc.py:16-49 ----
                     i_leaf += 1;
-                }
-            }
-        }
-
-        if (NUTS) {
-            // ---- Tree._build_subtree merges (nuts.py:134-178), iteratively ----
-            const bool leaf_ok = is_leaf && !diverged;
-            int lev = 0;
-            bool turned = false;
-            while (true) {
-                const bool do_m = leaf_ok && !turned && lev < depth && ((i_leaf >> lev) & 1);
-                if (!__any(do_m)) break;
-                double A[4], B[4], S1[4], dts[6] = {0., 0., 0., 0., 0., 0.};
-                double *slot = sbase + (SL_STACK + 4 * lev) * DP;
-                if (do_m) {
-                    ld4(slot + 0 * DP, A);
-                    ld4(slot + 1 * DP, B);
-                    ld4(slot + 2 * DP, S1);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { A[e] = 0.; B[e] = 0.; S1[e] = 0.; }
-                }
-                double psum[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    psum[e] = S1[e] + TPs[e];
-                    const double vA = var[e] * A[e], vB = var[e] * B[e], vC = var[e] * TLp[e], vD = var[e] * p[e];
-                    dts[0] += psum[e] * vA;  // nuts.py:150-151
-                    dts[1] += psum[e] * vD;
-                    const double ps1 = S1[e] + TLp[e];  // :155-157
-                    dts[2] += ps1 * vA;
-                    dts[3] += ps1 * vC;
-                    const double ps2 = B[e] + TPs[e];   // :158-160
-                    dts[4] += ps2 * vB;
-                    dts[5] += ps2 * vD;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) dts[k] = row_sum<RW>(dts[k]);
-                if (do_m) {
-                    bool turning = (dts[0] <= 0.) || (dts[1] <= 0.);
-                    if (lev >= 1) turning = turning || (dts[2] <= 0.) || (dts[3] <= 0.) || (dts[4] <= 0.) || (dts[5] <= 0.);
-                    const double *lsp = LS + (lev * LS_N) * 16 + cl;
-                    for (int k = 0; k < 6; ++k) dbgv[k] = dts[k];
-                    dbgv[6] = lev; dbgv[7] = turning;
-                    T_acc = lsp[LS_ACC * 16] + T_acc;  // :173
-                    // nuts.py:163-167 run even when THIS merge's check says turning: the draw is consumed
-                    const double ls1 = lsp[LS_LS * 16];
-                    const double ls = bf_logaddexp(ls1, T_ls);
-                    const bool keep_t2 = logbern(T_ls - ls);
-                    if (turning) {
-                        turned = true;
-                    } else {
-                        if (!keep_t2) {
-                            ld4(slot + 3 * DP, TPq);
-                            T_E = lsp[LS_E * 16];
-                            T_logp = lsp[LS_LOGP * 16];
-                        }
-                        T_ls = ls;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { TLp[e] = A[e]; TPs[e] = psum[e]; }
-                        lev += 1;
+                    if (i_leaf >= a.cfg.n_int_step) {
+                        const bool fin = fabs(E_new) <= 1.7976931348623157e308;
+                        const double h_dE = fin ? (start_energy - E_new) : -INFINITY;
+                        diverged = (!fin || fabs(h_dE) > a.cfg.max_change) ? 1 : 0;
+                        double h_accept_stat = exp(h_dE);
+                        if (h_accept_stat > 1.) h_accept_stat = 1.;
+                        h_accepted = 0;
+                        if (!diverged) h_accepted = !(bf_u01(bf_xoshiro_next(rs)) >= h_accept_stat);
+                        if (h_accepted) stv(SL_PROP_Q, q);
+                        cs_set(CS_HDE, h_dE);
+                        cs_set(CS_HACC, h_accept_stat);
+                        cs_set(CS_PROP_E, E_new);
+                        cs_set(CS_PROP_LOGP, logp_new);
+                        unit = U_END1;
                     }
                 }
             }
-            if (is_leaf) {
-                if (diverged || turned) {
-                    // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
-                    for (int al = (diverged ? 0 : lev + 1); al < depth; ++al)
-                        if ((i_leaf >> al) & 1) T_acc = LS[(al * LS_N + LS_ACC) * 16 + cl] + T_acc;
-                    depth += 1;          // nuts.py:71-73
-                    acc_sum += T_acc;
-                    it_end = true;
-                } else if (lev == depth) {
-                    complete = true;
-                } else {
-                    double *slot = sbase + (SL_STACK + 4 * lev) * DP;
-                    st4(slot + 0 * DP, TLp);
-                    st4(slot + 1 * DP, p);
-                    st4(slot + 2 * DP, TPs);
-                    st4(slot + 3 * DP, TPq);
-                    double *lsp = LS + (lev * LS_N) * 16 + cl;
-                    lsp[LS_LS * 16] = T_ls;
-                    lsp[LS_E * 16] = T_E;
-                    lsp[LS_LOGP * 16] = T_logp;
-                    lsp[LS_ACC * 16] = T_acc;
-                    i_leaf += 1;
-                }
+        } else if (unit == U_MERGE_RUN) {
+            // ---- one level of Tree._build_subtree's merge (nuts.py:146-178) ----
+            double A[E], B[E], S1[E], psum[E];
+            const int slot = SL_STACK + 4 * lev;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { A[e] = 0.; B[e] = 0.; S1[e] = 0.; }
+            ldv(slot + 0, A);
+            ldv(slot + 1, B);
+            ldv(slot + 2, S1);
+            double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                psum[e] = S1[e] + TPs[e];
+                const double vA = var[e] * A[e], vB = var[e] * B[e], vC = var[e] * TLp[e], vD = var[e] * p[e];
+                d0 += psum[e] * vA;  // nuts.py:150-151
+                d1 += psum[e] * vD;
+                const double ps1 = S1[e] + TLp[e];  // :155-157
+                d2 += ps1 * vA;
+                d3 += ps1 * vC;
+                const double ps2 = B[e] + TPs[e];   // :158-160
+                d4 += ps2 * vB;
+                d5 += ps2 * vD;
             }
+            d0 = wave_sum(d0);
+            d1 = wave_sum(d1);
+            bool turning = (d0 <= 0.) || (d1 <= 0.);
+            if (lev >= 1) {
+                d2 = wave_sum(d2); d3 = wave_sum(d3); d4 = wave_sum(d4); d5 = wave_sum(d5);
+                turning = turning || (d2 <= 0.) || (d3 <= 0.) || (d4 <= 0.) || (d5 <= 0.);
+            }
+            const double *lsp = lsw + lev * LS_N;
+            T_acc = lsp[LS_ACC] + T_acc;  // :173
+            // nuts.py:163-167 run even when THIS merge's check says turning: the draw is consumed.
+            // logbern(ls2 - logaddexp(ls1, ls2))  <=>  U * (W1 + W2) < W2
+            const double Wsum = lsp[LS_LS] + T_W;
+            if (Wsum != Wsum) err = 2;
+            const double u = bf_u01(bf_xoshiro_next(rs));
+            const bool keep_t2 = (u * Wsum < T_W) || (u == 0.);
+            if (turning) {
+                unit = U_ABORT;
+                lev += 1;  // ancestors above this level still add their accept sums
+            } else {
+                if (!keep_t2) {
+                    ldv(slot + 3, TPq);
+                    cs_set(CS_T_E, lsp[LS_E]);
+                    cs_set(CS_T_LOGP, lsp[LS_LOGP]);
+                }
+                T_W = Wsum;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { TLp[e] = A[e]; TPs[e] = psum[e]; }
+                lev += 1;
+                unit = U_MERGE;
+            }
+        } else if (unit == U_DBL_END) {
             // ---- Tree.extend after a complete subtree: nuts.py:71-103 ----
-            if (__any(complete)) {
-                double oldL[4], oldR[4], ps[4], dts[6] = {0., 0., 0., 0., 0., 0.};
-                bool swap = false;
-                if (complete) {
-                    depth += 1;
-                    acc_sum += T_acc;
-                    swap = logbern(T_ls - tree_ls);  // :81-83
-                    tree_ls = bf_logaddexp(tree_ls, T_ls);  // :85
-                    ld4(sbase + SL_PSUM * DP, ps);
-                    ld4(sbase + SL_LEFT_P * DP, oldL);
-                    ld4(sbase + SL_RIGHT_P * DP, oldR);
-                    if (swap) {
-                        st4(sbase + SL_PROP_Q * DP, TPq);
-                        prop_E = T_E;
-                        prop_logp = T_logp;
-                    }
+            double oldL[E], oldR[E], ps[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { oldL[e] = 0.; oldR[e] = 0.; ps[e] = 0.; }
+            depth += 1;
+            acc_sum += T_acc;
+            ldv(SL_PSUM, ps);
+            ldv(SL_LEFT_P, oldL);
+            ldv(SL_RIGHT_P, oldR);
+            {   // :81-83  logbern(ls_new - ls_old)  <=>  U * W_old < W_new
+                const double tree_W = csw[CS_TREE_W];
+                if (T_W != T_W || tree_W != tree_W) err = 2;
+                const double u = bf_u01(bf_xoshiro_next(rs));
+                if ((u * tree_W < T_W) || (u == 0.)) {
+                    stv(SL_PROP_Q, TPq);
+                    cs_set(CS_PROP_E, csw[CS_T_E]);
+                    cs_set(CS_PROP_LOGP, csw[CS_T_LOGP]);
+                }
+                cs_set(CS_TREE_W, tree_W + T_W);  // :85
+            }
+            double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ps[e] += TPs[e];  // :86 (in place)
+                const double vN = var[e] * p[e], vT = var[e] * TLp[e], vL = var[e] * oldL[e], vR = var[e] * oldR[e];
+                // NOTE (reference behaviour, kept on purpose): leftmost_p_sum (dir > 0) / rightmost_p_sum
+                // (dir < 0) alias self.p_sum, which line 86 has just updated in place.
+                if (dir > 0) {
+                    d0 += ps[e] * vL;                     // left = old left
+                    d1 += ps[e] * vN;                     // right = new end
+                    const double ps1 = ps[e] + TLp[e];    // (aliased) leftmost_p_sum + rightmost_begin.p
+                    d2 += ps1 * vL;                       // leftmost_begin = old left
+                    d3 += ps1 * vT;                       // rightmost_begin = tree.left
+                    const double ps2 = oldR[e] + TPs[e];  // leftmost_end.p + rightmost_p_sum
+                    d4 += ps2 * vR;                       // leftmost_end = old right
+                    d5 += ps2 * vN;                       // rightmost_end = tree.right
                 } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { oldL[e] = 0.; oldR[e] = 0.; ps[e] = 0.; }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ps[e] += TPs[e];  // :86 (in place)
-                    const double vN = var[e] * p[e], vT = var[e] * TLp[e], vL = var[e] * oldL[e], vR = var[e] * oldR[e];
-                    // NOTE (reference behaviour, kept on purpose): leftmost_p_sum (dir > 0) / rightmost_p_sum
-                    // (dir < 0) alias self.p_sum, which line 86 has just updated in place.
-                    if (dir > 0) {
-                        dts[0] += ps[e] * vL;  // left = old left
-                        dts[1] += ps[e] * vN;  // right = new end
-                        const double ps1 = ps[e] + TLp[e];    // (aliased) leftmost_p_sum + rightmost_begin.p
-                        dts[2] += ps1 * vL;                   // leftmost_begin = old left
-                        dts[3] += ps1 * vT;                   // rightmost_begin = tree.left
-                        const double ps2 = oldR[e] + TPs[e];  // leftmost_end.p + rightmost_p_sum
-                        dts[4] += ps2 * vR;                   // leftmost_end = old right
-                        dts[5] += ps2 * vN;                   // rightmost_end = tree.right
-                    } else {
-                        dts[0] += ps[e] * vN;  // left = new end
-                        dts[1] += ps[e] * vR;  // right = old right
-                        const double ps1 = TPs[e] + oldL[e];  // leftmost_p_sum + rightmost_begin.p
-                        dts[2] += ps1 * vN;                   // leftmost_begin = tree.right
-                        dts[3] += ps1 * vL;                   // rightmost_begin = old left
-                        const double ps2 = TLp[e] + ps[e];    // leftmost_end.p + (aliased) rightmost_p_sum
-                        dts[4] += ps2 * vT;                   // leftmost_end = tree.left
-                        dts[5] += ps2 * vR;                   // rightmost_end = old right
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) dts[k] = row_sum<RW>(dts[k]);
-                if (complete) {
-                    st4(sbase + SL_PSUM * DP, ps);
-                    const int eo = (dir > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
-                    st4(sbase + (eo + 0) * DP, q);
-                    st4(sbase + (eo + 1) * DP, p);
-                    st4(sbase + (eo + 2) * DP, g);
-                    bool turning = false;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) turning = turning || (dts[k] <= 0.);
-                    if (turning || depth >= a.cfg.max_treedepth) {
-                        it_end = true;
-                    } else {
-                        const int nd = logbern(-0.6931471805599453094) ? 1 : -1;  // nuts.py:210
-                        if (nd != dir) {
-                            const int eo2 = (nd > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
-                            ld4(sbase + (eo2 + 0) * DP, q);
-                            ld4(sbase + (eo2 + 1) * DP, p);
-                            ld4(sbase + (eo2 + 2) * DP, g);
-                        }
-                        dir = nd;
-                        i_leaf = 0;
-                    }
+                    d0 += ps[e] * vN;                     // left = new end
+                    d1 += ps[e] * vR;                     // right = old right
+                    const double ps1 = TPs[e] + oldL[e];  // leftmost_p_sum + rightmost_begin.p
+                    d2 += ps1 * vN;                       // leftmost_begin = tree.right
+                    d3 += ps1 * vL;                       // rightmost_begin = old left
+                    const double ps2 = TLp[e] + ps[e];    // leftmost_end.p + (aliased) rightmost_p_sum
+                    d4 += ps2 * vT;                       // leftmost_end = tree.left
+                    d5 += ps2 * vR;                       // rightmost_end = old right
                 }
             }
+            d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+            d3 = wave_sum(d3); d4 = wave_sum(d4); d5 = wave_sum(d5);
+            stv(SL_PSUM, ps);
+            const int eo = (dir > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
+            stv(eo + 0, q); stv(eo + 1, p); stv(eo + 2, g);
+            const bool turning = (d0 <= 0.) || (d1 <= 0.) || (d2 <= 0.) || (d3 <= 0.) || (d4 <= 0.) || (d5 <= 0.);
+            if (turning || depth >= a.cfg.max_treedepth) {
+                unit = U_END1;
+            } else {
+                const int nd = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
+                if (nd != dir) {
+                    const int eo2 = (nd > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
+                    ldv(eo2 + 0, q); ldv(eo2 + 1, p); ldv(eo2 + 2, g);
+                }
+                dir = nd;
+                i_leaf = 0;
+                unit = U_EVAL;
+            }
+        } else if (unit == U_END1) {
+            // ================= iteration end, part 1: step size + stats (base_hmc.py:80-85) =================
+            const bool warm = i_iter < nw;
+            const double accept_stat = NUTS ? acc_sum / (double)n_prop : csw[CS_HACC];  // nuts.py:186
+            double log_step = csw[CS_LOG_STEP], log_bar = csw[CS_LOG_BAR];
+            if (warm && a.cfg.adapt_step_size) {  // step_size.py:31-45
+                const double count = csw[CS_COUNT];
+                const double wgt = 1. / (count + a.cfg.t_0);
+                const double hbar = ((1. - wgt) * csw[CS_HBAR] + wgt * (a.cfg.target_accept - accept_stat));
+                log_step = csw[CS_SMU] - hbar * sqrt(count) / a.cfg.gamma;
+                const double mk = exp(-a.cfg.k * log(count));  // count ** -k
+                log_bar = mk * log_step + (1. - mk) * log_bar;
+                cs_set(CS_HBAR, hbar);
+                cs_set(CS_LOG_STEP, log_step);
+                cs_set(CS_LOG_BAR, log_bar);
+                cs_set(CS_COUNT, count + 1.);
+            }
+            const double prop_E = csw[CS_PROP_E], prop_logp = csw[CS_PROP_LOGP];
+            const int orow = i_iter - a.iter_out0;
+            if (orow >= 0 && orow < a.n_out && lane == 0) {
+                double *st = a.stats + ((size_t)chain * a.n_out + orow) * BFHIP_STAT_STRIDE;
+                if (NUTS) {
+                    st[BFHIP_NS_LOGP] = prop_logp;
+                    st[BFHIP_NS_ENERGY] = prop_E;
+                    st[BFHIP_NS_TREE_DEPTH] = (double)depth;
+                    st[BFHIP_NS_TREE_SIZE] = (double)n_prop;
+                    st[BFHIP_NS_MEAN_TREE_ACCEPT] = accept_stat;
+                    st[BFHIP_NS_STEP_SIZE] = exp(log_step);
+                    st[BFHIP_NS_STEP_SIZE_BAR] = exp(log_bar);
+                    st[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
+                    st[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
+                    st[BFHIP_NS_MAX_ENERGY_CHANGE] = csw[CS_MAX_DE];
+                    st[BFHIP_NS_DIVERGING] = (double)diverged;
+                } else {
+                    st[BFHIP_HS_LOGP] = prop_logp;
+                    st[BFHIP_HS_ENERGY] = prop_E;
+                    st[BFHIP_HS_N_INT_STEP] = (double)a.cfg.n_int_step;
+                    st[BFHIP_HS_ACCEPT_STAT] = accept_stat;
+                    st[BFHIP_HS_ACCEPTED] = (double)h_accepted;
+                    st[BFHIP_HS_STEP_SIZE] = exp(log_step);
+                    st[BFHIP_HS_STEP_SIZE_BAR] = exp(log_bar);
+                    st[BFHIP_HS_WARMUP] = warm ? 1. : 0.;
+                    st[BFHIP_HS_ENERGY_CHANGE] = csw[CS_HDE];
+                    st[BFHIP_HS_DIVERGING] = (double)diverged;
+                    st[10] = 0.;
+                }
+            }
+            unit = U_END2;
+        } else if (unit == U_END2) {
+            // ================= iteration end, part 2: the new sample + metric adaptation =================
+            const bool warm = i_iter < nw;
+            const int orow = i_iter - a.iter_out0;
+            ldv(SL_PROP_Q, q);
+            if (orow >= 0 && orow < a.n_out) {
+                double *sp = a.samples + ((size_t)chain * a.n_out + orow) * d;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (lane * E + e < d) sp[lane * E + e] = q[e];
+            }
+            // QuadMetricDiagAdapt.update: metrics.py:186-211, _WeightedVariance.add_sample :354-360
+            if (warm && a.cfg.adapt_metric) {
+                double fg_n = scp[BFHIP_SC_FG_N], bg_n = scp[BFHIP_SC_BG_N];
+                double n_samples = scp[BFHIP_SC_N_SAMPLES], prev_upd = scp[BFHIP_SC_PREV_UPDATE];
+                double adapt_window = scp[BFHIP_SC_ADAPT_WINDOW];
+                const long delta = (long)(n_samples - prev_upd);
+                double fm[E], fr[E], bm[E], br[E];
+                load_vec(BFHIP_VEC_FG_MEAN, fm, 0.);
+                load_vec(BFHIP_VEC_FG_RAW, fr, 0.);
+                load_vec(BFHIP_VEC_BG_MEAN, bm, 0.);
+                load_vec(BFHIP_VEC_BG_RAW, br, 0.);
+                fg_n += 1.;
+                bg_n += 1.;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double od = q[e] - fm[e];
+                    fm[e] += od / fg_n;
+                    fr[e] += 1. * od * (q[e] - fm[e]);
+                    od = q[e] - bm[e];
+                    bm[e] += od / bg_n;
+                    br[e] += 1. * od * (q[e] - bm[e]);
+                }
+                if ((delta + 1) % (long)a.cfg.update_window == 0) {  // metrics.py:181-184
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (lane * E + e < d) var[e] = fr[e] / fg_n;
+                    store_vec(BFHIP_VEC_VAR, var);
+                }
+                if ((double)delta >= adapt_window) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { fm[e] = bm[e]; fr[e] = br[e]; bm[e] = 0.; br[e] = 0.; }
+                    fg_n = bg_n;
+                    bg_n = 10.;
+                    prev_upd = n_samples;
+                    if (a.cfg.doubling) adapt_window *= 2.;
+                }
+                n_samples += 1.;
+                store_vec(BFHIP_VEC_FG_MEAN, fm);
+                store_vec(BFHIP_VEC_FG_RAW, fr);
+                store_vec(BFHIP_VEC_BG_MEAN, bm);
+                store_vec(BFHIP_VEC_BG_RAW, br);
+                if (lane == 0) {
+                    scp[BFHIP_SC_FG_N] = fg_n;
+                    scp[BFHIP_SC_BG_N] = bg_n;
+                    scp[BFHIP_SC_N_SAMPLES] = n_samples;
+                    scp[BFHIP_SC_PREV_UPDATE] = prev_upd;
+                    scp[BFHIP_SC_ADAPT_WINDOW] = adapt_window;
+                }
+            }
+            i_iter += 1;
+            unit = U_END3;
+        } else if (unit == U_END3) {
+            // ================= iteration end, part 3: next momentum =================
+            if (i_iter < a.iter_end && err == 0) {
+                mode = M_INIT;
+                draw_momentum();
+                unit = U_EVAL;
+            } else {
+                mode = M_DONE;
+                unit = U_DONE;
+            }
+        }
+        // ---- cheap follow-ups that need no trip of their own ----
+        if (unit == U_ABORT) {
+            // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
+            for (int al = (diverged ? 0 : lev); al < depth; ++al)
+                if ((i_leaf >> al) & 1) T_acc = lsw[al * LS_N + LS_ACC] + T_acc;
+            depth += 1;  // nuts.py:71-73
+            acc_sum += T_acc;
+            unit = U_END1;
+        } else if (unit == U_MERGE) {
+            if (lev < depth && ((i_leaf >> lev) & 1)) {
+                unit = U_MERGE_RUN;  // next trip: merge with the waiting left sibling at this level
+            } else if (lev < depth) {
+                // the subtree waits for its right sibling
+                const int slot = SL_STACK + 4 * lev;
+                stv(slot + 0, TLp); stv(slot + 1, p); stv(slot + 2, TPs); stv(slot + 3, TPq);
+                if (lane == 0) {
+                    double *lsp = lsw + lev * LS_N;
+                    lsp[LS_LS] = T_W; lsp[LS_E] = csw[CS_T_E]; lsp[LS_LOGP] = csw[CS_T_LOGP]; lsp[LS_ACC] = T_acc;
+                }
+                i_leaf += 1;
+                unit = U_EVAL;
+            } else {
+                unit = U_DBL_END;
+            }
+        }
+        if (err != 0) { mode = M_DONE; unit = U_DONE; }
+    };
+
+    int mat_id[3] = {0, 0, 0};
+    int n_mat = 0;
+    if (m.has_quad) mat_id[n_mat++] = 0;
+    if (m.use_bound) mat_id[n_mat++] = 1;
+    if (m.use_decay) mat_id[n_mat++] = 2;
+
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = a.stamps ? clock64() : 0;
+    auto stamp = [&](int k) {
+        if (a.stamps) {
+            const unsigned long long t = clock64();
+            st_acc[k] += t - st_prev;
+            st_prev = t;
+        }
+    };
+
+    for (int trip = 0;; ++trip) {
+        // ================= phase A: first half of the leapfrog, B operands =================
+        double xs[E], jac[E], gj[E], xo[E];
+        double logdet = 0.;
+        const bool evaluating = unit == U_EVAL;
+        if (evaluating) {
+            if (mode != M_OOB) {
+                eps_t = (mode == M_LEAF) ? eps * (double)dir : 0.;
+                const double dt = 0.5 * eps_t;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    p[e] = p[e] + dt * g[e];               // integration.py:80
+                    q[e] = q[e] + eps_t * (var[e] * p[e]); // :82-85
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int dim = lane * E + e;
+                xo[e] = q[e];
+                jac[e] = 1.;
+                gj[e] = 0.;
+                if (m.has_transform) {
+                    double J, J2;
+                    bf_to_original(q[e], (int)pdl(PD_KIND, e), pdl(PD_LO, e), pdl(PD_RG, e), xo[e], J, J2);
+                    logdet += log(fabs(J));
+                    jac[e] = J;
+                    gj[e] = J2 / J;
+                }
+                xs[e] = m.has_su ? (xo[e] - pdl(PD_SU_LO, e)) / pdl(PD_SU_DIFF, e) : xo[e];
+                double x_eval = xs[e];
+                if (mode == M_OOB)  // modules/poly.py:482
+                    x_eval = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
+                if (dim < DP) {
+                    const int xi = (dim >> 2) * XS + w + 16 * (dim & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
+                    XB[0 * NS * XS + xi] = x_eval;
+                    if (m.use_bound) XB[1 * NS * XS + xi] = xs[e] - c_mu[e];
+                    if (m.use_decay) XB[2 * NS * XS + xi] = xo[e] - pdl(PD_DMU, e);
+                }
+            }
+        }
+        if (unit != U_DONE && lane == 0) alive[trip & 1] = 1;
+        stamp(0);
+        __syncthreads();  // B1
+        stamp(1);
+        if (alive[trip & 1] == 0) break;  // every chain of the group is done (uniform)
+        if (tid == 0) alive[(trip + 1) & 1] = 0;
+
+        // ================= phase B: gradient tiles on MFMA =================
+        // job j = (matrix j / W, row tile j % W); jobs are dealt over the 16 waves so that the S and H tiles of
+        // one row range run on different waves (the MFMA pipe of each SIMD sees the same total work)
+        {
+            const int mc = lane & 15, mg = lane >> 4;
+            const int n_job = n_mat * W;
+            for (int job = w; job < n_job; job += 16) {
+                const int slot_m = job / W, t = job % W;       // slot_m-th enabled matrix
+                const int b = mat_id[slot_m];                   // 0 S, 1 H, 2 H_decay
+                const double *Af = b == 0 ? Sf : (b == 1 ? Hf : Hdf);
+                d4_t acc = {0., 0., 0., 0.};
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[(t * NS + s) * 64 + lane], XB[(b * NS + s) * XS + lane], acc, 0, 0, 0);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) GB[(b * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
+            }
+        }
+        // ---- chains that do not need this trip's gradient run their unit here, under the MFMA pipe ----
+        const int unit_in = unit;
+        if (unit_in != U_EVAL) run_unit(false, 0., 0.);
+        stamp(2);
+        __syncthreads();  // B2
+        stamp(3);
+
+        // ================= phase C: finish the evaluation =================
+        double gn[E], hv[E], dgr[E];
+        double logp_new = 0., E_new = 0.;
+        bool have_eval = false, kin_ready = false;
+        double kin_fast = 0.;
+        if (evaluating) {
+            double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
+            const bool fast_kin = !m.use_decay && mode != M_OOB;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int dim = lane * E + e;
+                const double sx = (m.has_quad && lane_ok) ? GB[(0 * 16 + w) * GS + dim] : 0.;
+                hv[e] = (m.use_bound && lane_ok) ? GB[(1 * 16 + w) * GS + dim] : 0.;
+                dgr[e] = (m.use_decay && lane_ok) ? GB[(2 * 16 + w) * GS + dim] : 0.;
+                const double xm = xs[e] - c_mu[e];
+                double x_eval = xs[e];
+                if (mode == M_OOB) x_eval = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
+                r_quad += x_eval * sx;
+                r_lin += c_lin[e] * x_eval;
+                gn[e] = sx + c_lin[e];
+                r_b2 += xm * hv[e];
+                r_dotj += gn[e] * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
+                if (m.use_decay) r_bd2 += (xo[e] - pdl(PD_DMU, e)) * dgr[e];
+                if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
+                    double ge = gn[e];
+                    if (m.has_su) ge = ge / pdl(PD_SU_DIFF, e);
+                    ge = ge * jac[e];
+                    if (m.has_transform) ge += gj[e];
+                    const double pe = p[e] + (0.5 * eps_t) * ge;
+                    r_kin += pe * (var[e] * pe);
+                }
+            }
+            if (fast_kin) r_kin = wave_sum(r_kin);
+            r_quad = wave_sum(r_quad);
+            r_lin = wave_sum(r_lin);
+            if (m.use_bound) r_b2 = wave_sum(r_b2);
+            if (m.use_bound && mode == M_OOB) r_dotj = wave_sum(r_dotj);
+            if (m.use_decay) r_bd2 = wave_sum(r_bd2);
+            if (m.has_transform) logdet = wave_sum(logdet);
+
+            double f = (m.c0 + r_lin) + 0.5 * r_quad;
+            const double beta = sqrt(r_b2);
+            bool oob_now = false;
+            if (m.use_bound) {
+                if (mode == M_OOB) {  // second pass: f, gn currently hold f_0 and jj_0 (poly.py:484-496)
+                    const double f0 = f, beta_saved = csw[CS_BETA];
+                    f = (beta_saved * f0 - (beta_saved - m.alpha) * m.f_mu) / m.alpha;
+                    const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta_saved;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gn[e] = gn[e] + coef * (hv[e] / beta_saved);
+                } else if (beta > m.alpha) {
+                    oob_now = true;
+                }
+            }
+            kin_ready = fast_kin && !oob_now;
+            kin_fast = r_kin;
+            if (oob_now) {
+                // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
+                cs_set(CS_BETA, beta);
+                prev_mode = mode;
+                mode = M_OOB;
+            } else {
+                if (mode == M_OOB) mode = prev_mode;
+                // chain rule (module.py:226, density.py:558), decay (:740-746), transform (:747-750)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (m.has_su) gn[e] = gn[e] / pdl(PD_SU_DIFF, e);
+                    gn[e] = gn[e] * jac[e];
+                }
+                if (m.use_decay) {
+                    f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
+                    if (r_bd2 > m.decay_alpha2) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
+                    }
+                }
+                if (m.has_transform) {
+                    f += logdet;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gn[e] += gj[e];
+                }
+                logp_new = f;
+                have_eval = true;
+            }
+        }
+        if (have_eval) {
+            // second half of the leapfrog and the kinetic energy
+            double kin = 0.;
+            const double dt = 0.5 * eps_t;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                p[e] = p[e] + dt * gn[e];        // integration.py:90
+                kin += p[e] * (var[e] * p[e]);   // metrics.py:88-91
+                g[e] = gn[e];
+            }
+            kin = kin_ready ? kin_fast : wave_sum(kin);
+            E_new = 0.5 * kin - logp_new;        // integration.py:92-93
         }
 
-        // ---- HMC._hamiltonian_step end of trajectory: samplers/hmc.py:21-49 ----
-        double h_accept_stat = 0., h_dE = 0.;
-        int h_accepted = 0;
-        if (!NUTS) {
-            if (is_leaf && i_leaf >= a.cfg.n_int_step) {
-                const bool fin = fabs(E_new) <= 1.7976931348623157e308;
-                h_dE = fin ? (start_energy - E_new) : -INFINITY;
-                diverged = (!fin || fabs(h_dE) > a.cfg.max_change) ? 1 : 0;
-                h_accept_stat = exp(h_dE);
-                if (h_accept_stat > 1.) h_accept_stat = 1.;
-                if (!diverged) h_accepted = !(bf_u01(bf_xoshiro_next(rs)) >= h_accept_stat);
-                if (h_accepted) st4(sbase + SL_PROP_Q * DP, q);
-                prop_E = E_new;
-                prop_logp = logp_new;
-                it_end = true;
-            }
-        }
-
-        // ================= iteration end: base_hmc.py:80-85 =================
-        if (__any(it_end)) {
-            if (it_end) {
-                const bool warm = i_iter < nw;
-                const double accept_stat = NUTS ? acc_sum / (double)n_prop : h_accept_stat;  // nuts.py:186
-                if (warm && a.cfg.adapt_step_size) {  // step_size.py:31-45
-                    const double wgt = 1. / (count + a.cfg.t_0);
-                    hbar = ((1. - wgt) * hbar + wgt * (a.cfg.target_accept - accept_stat));
-                    log_step = smu - hbar * sqrt(count) / a.cfg.gamma;
-                    const double mk = pow(count, -a.cfg.k);
-                    log_bar = mk * log_step + (1. - mk) * log_bar;
-                    count += 1.;
-                }
-                const int orow = i_iter - a.iter_out0;
-                const bool wr = orow >= 0 && orow < a.n_out;
-                if (wr && j == 0) {
-                    double *st = a.stats + ((size_t)chain * a.n_out + orow) * BFHIP_STAT_STRIDE;
-                    if (NUTS) {
-                        st[BFHIP_NS_LOGP] = prop_logp;
-                        st[BFHIP_NS_ENERGY] = prop_E;
-                        st[BFHIP_NS_TREE_DEPTH] = (double)depth;
-                        st[BFHIP_NS_TREE_SIZE] = (double)n_prop;
-                        st[BFHIP_NS_MEAN_TREE_ACCEPT] = accept_stat;
-                        st[BFHIP_NS_STEP_SIZE] = exp(log_step);
-                        st[BFHIP_NS_STEP_SIZE_BAR] = exp(log_bar);
-                        st[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
-                        st[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
-                        st[BFHIP_NS_MAX_ENERGY_CHANGE] = max_dE;
-                        st[BFHIP_NS_DIVERGING] = (double)diverged;
-                    } else {
-                        st[BFHIP_HS_LOGP] = prop_logp;
-                        st[BFHIP_HS_ENERGY] = prop_E;
-                        st[BFHIP_HS_N_INT_STEP] = (double)a.cfg.n_int_step;
-                        st[BFHIP_HS_ACCEPT_STAT] = accept_stat;
-                        st[BFHIP_HS_ACCEPTED] = (double)h_accepted;
-                        st[BFHIP_HS_STEP_SIZE] = exp(log_step);
-                        st[BFHIP_HS_STEP_SIZE_BAR] = exp(log_bar);
-                        st[BFHIP_HS_WARMUP] = warm ? 1. : 0.;
-                        st[BFHIP_HS_ENERGY_CHANGE] = h_dE;
-                        st[BFHIP_HS_DIVERGING] = (double)diverged;
-                        st[10] = 0.;
-                    }
-                }
-                // the new sample
-                ld4(sbase + SL_PROP_Q * DP, q);
-                if (wr) {
-                    double *sp = a.samples + ((size_t)chain * a.n_out + orow) * d;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * j + e < d) sp[4 * j + e] = q[e];
-                }
-                // QuadMetricDiagAdapt.update: metrics.py:186-211, _WeightedVariance.add_sample :354-360
-                if (warm && a.cfg.adapt_metric) {
-                    double fg_n = scp[BFHIP_SC_FG_N], bg_n = scp[BFHIP_SC_BG_N];
-                    double n_samples = scp[BFHIP_SC_N_SAMPLES], prev_upd = scp[BFHIP_SC_PREV_UPDATE];
-                    double adapt_window = scp[BFHIP_SC_ADAPT_WINDOW];
-                    const long delta = (long)(n_samples - prev_upd);
-                    double fm[4], fr[4], bm[4], br[4];
-                    load_vec(BFHIP_VEC_FG_MEAN, fm, 0.);
-                    load_vec(BFHIP_VEC_FG_RAW, fr, 0.);
-                    load_vec(BFHIP_VEC_BG_MEAN, bm, 0.);
-                    load_vec(BFHIP_VEC_BG_RAW, br, 0.);
-                    fg_n += 1.;
-                    bg_n += 1.;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        double od = q[e] - fm[e];
-                        fm[e] += od / fg_n;
-                        fr[e] += 1. * od * (q[e] - fm[e]);
-                        od = q[e] - bm[e];
-                        bm[e] += od / bg_n;
-                        br[e] += 1. * od * (q[e] - bm[e]);
-                    }
-                    if ((delta + 1) % (long)a.cfg.update_window == 0) {  // metrics.py:181-184
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (4 * j + e < d) var[e] = fr[e] / fg_n;
-                        store_vec(BFHIP_VEC_VAR, var);
-                    }
-                    if ((double)delta >= adapt_window) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { fm[e] = bm[e]; fr[e] = br[e]; bm[e] = 0.; br[e] = 0.; }
-                        fg_n = bg_n;
-                        bg_n = 10.;
-                        prev_upd = n_samples;
-                        if (a.cfg.doubling) adapt_window *= 2.;
-                    }
-                    n_samples += 1.;
-                    store_vec(BFHIP_VEC_FG_MEAN, fm);
-                    store_vec(BFHIP_VEC_FG_RAW, fr);
-                    store_vec(BFHIP_VEC_BG_MEAN, bm);
-                    store_vec(BFHIP_VEC_BG_RAW, br);
-                    if (j == 0) {
-                        scp[BFHIP_SC_FG_N] = fg_n;
-                        scp[BFHIP_SC_BG_N] = bg_n;
-                        scp[BFHIP_SC_N_SAMPLES] = n_samples;
-                        scp[BFHIP_SC_PREV_UPDATE] = prev_upd;
-                        scp[BFHIP_SC_ADAPT_WINDOW] = adapt_window;
-                    }
-                }
-                i_iter += 1;
-                if (i_iter < a.iter_end && err == 0) {
-                    mode = M_INIT;
-                    draw_momentum();
-                } else {
-                    mode = M_DONE;
-                }
-            }
-        }
-        if (err != 0 && mode != M_DONE) mode = M_DONE;
-        if (a.dbg && real && chain == a.dbg_chain && j == 0 && trip < a.dbg_cap) {
-            double *t = a.dbg + (size_t)trip * 32;
-            t[0] = have_eval; t[1] = is_leaf; t[2] = i_leaf; t[3] = depth; t[4] = dir; t[5] = E_new; t[6] = logp_new;
-            t[7] = it_end; t[8] = complete; t[9] = T_acc; t[10] = acc_sum; t[11] = tree_ls; t[12] = T_ls; t[13] = i_iter;
-            t[14] = q[0]; t[15] = p[0];
-            for (int k = 0; k < 8; ++k) t[16 + k] = dbgv[k];
-        }
+        stamp(4);
+        if (a.stamps) st_acc[7] += 1;
+        if (unit_in == U_EVAL) run_unit(have_eval, E_new, logp_new);
+        stamp(unit_in == U_EVAL ? 5 : 6);
     }
 
+    if (a.stamps && lane == 0)
+        for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * 16 + w) * 8 + k] = st_acc[k];
     // ---- write the chain state back ----
     if (real) {
         store_vec(BFHIP_VEC_Q, q);
-        if (j == 0) {
+        if (lane == 0) {
             for (int k = 0; k < 4; ++k) a.rng[(size_t)chain * 4 + k] = rs[k];
-            scp[BFHIP_SC_LOG_STEP] = log_step;
-            scp[BFHIP_SC_LOG_BAR] = log_bar;
-            scp[BFHIP_SC_HBAR] = hbar;
-            scp[BFHIP_SC_COUNT] = count;
+            scp[BFHIP_SC_LOG_STEP] = csw[CS_LOG_STEP];
+            scp[BFHIP_SC_LOG_BAR] = csw[CS_LOG_BAR];
+            scp[BFHIP_SC_HBAR] = csw[CS_HBAR];
+            scp[BFHIP_SC_COUNT] = csw[CS_COUNT];
             scp[BFHIP_SC_I_ITER] = (double)i_iter;
             scp[BFHIP_SC_ERROR] = (double)err;
             if (a.n_leapfrog && nlf) atomicAdd(a.n_leapfrog, nlf);
@@ -705,28 +765,28 @@ __global__ __launch_bounds__(64 * W) void bf_sampler_kernel(DevModel m, SamplerA
     }
 }
 
-static size_t sampler_lds_bytes(int W) {
-    const int DP = 16 * W, NS = 4 * W;
-    size_t dbl = (size_t)3 * NS * 65 + (size_t)3 * 16 * (DP + 1) + (size_t)PD_N * DP + (size_t)BFHIP_MAX_TREEDEPTH * LS_N * 16;
-    return dbl * sizeof(double) + 16;
+static size_t sampler_lds_bytes(const DevModel &m) {
+    const int W = m.DP / 16, DP = m.DP, NS = 4 * W;
+    size_t dbl = (size_t)3 * NS * 65 + (size_t)3 * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 + (size_t)16 * CS_N + (size_t)PD_N * DP;
+    if (DP <= 64) dbl += (size_t)DP * DP * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
+    return dbl * sizeof(double);
 }
 
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     auto k = bf_sampler_kernel<W, NUTS>;
-    const size_t lds = sampler_lds_bytes(W);
+    const size_t lds = sampler_lds_bytes(ctx->model);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + 15) / 16;
-    hipLaunchKernelGGL(k, dim3(groups), dim3(64 * W), lds, ctx->stream, ctx->model, args);
+    hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-static double *g_dbg_buf = NULL;
-static int g_dbg_chain = 0, g_dbg_cap = 0;
-// diagnostics hook (not part of include/bfhip.h): trace one chain's trips into a device buffer
-extern "C" void bfhip_debug_trace(double *buf, int chain, int cap) { g_dbg_buf = buf; g_dbg_chain = chain; g_dbg_cap = cap; }
+static unsigned long long *g_stamps = NULL;
+// diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
+extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 
 extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_chain, int iter_end,
                                  uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
@@ -757,9 +817,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.samples = samples;
     args.stats = stats;
     args.n_leapfrog = n_leapfrog;
-    args.dbg = g_dbg_buf;
-    args.dbg_chain = g_dbg_chain;
-    args.dbg_cap = g_dbg_cap;
+    args.stamps = g_stamps;
     const size_t need = (size_t)((n_chain + 15) / 16 * 16) * args.nslot * m.DP * sizeof(double);
     if (ctx->scratch_bytes < need) {  // grow-only workspace; allocation is outside any timed region after the first call
         BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));

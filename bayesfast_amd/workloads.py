@@ -1,0 +1,52 @@
+"""Synthetic workloads of BASELINE.json (shapes, distributions and seeds fixed in SURVEY.md section 8d).
+
+Only NumPy: these build the density *spec* (plain dict) that both the device path and the test oracle consume.
+"""
+import numpy as np
+
+__all__ = ['correlated_gaussian_spec', 'B_STEP_BYTES', 'flops_per_leapfrog']
+
+
+def B_STEP_BYTES(d):
+    """Algorithmic HBM bytes of one leapfrog step of one chain: read q, p, grad and write them back
+    (48 d) plus logp/energy in and out (32).  SURVEY.md section 8(d)."""
+    return 48 * d + 32
+
+
+def flops_per_leapfrog(d, use_bound=True):
+    """Algorithmic flops of one leapfrog step of one chain: S x (2 d^2) for value+gradient of the
+    quadratic form and H (x - mu) (2 d^2) for the bound test; the O(d) tail is ignored."""
+    return (4 if use_bound else 2) * d * d
+
+
+def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7):
+    """Config-2 family of SURVEY.md section 8(d) at dimension d: target logp = -x^T P x / 2 with P = L L^T,
+    L = I + 0.3 tril(G, -1) / sqrt(d), G ~ N(0, 1) from default_rng(seed).
+
+    The surrogate is ``PolyModel('quadratic')`` (configs linear + quadratic, bound on with alpha_p = 100,
+    modules/poly.py:185-186,232-260).  The target is exactly quadratic, so the least-squares solution is
+    known in closed form (linear part 0, upper-triangular a[j,k] from -P/2); the bound statistics
+    mu, H = inv(cov), alpha = max Mahalanobis radius (modules/poly.py:268-276) are those of the
+    n_fit_mult * P fit points x ~ N(0, I) from default_rng(fit_seed), and f_mu is the surrogate at the
+    fit point of largest logp (center_max)."""
+    rng = np.random.default_rng(seed)
+    L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
+    P = L @ L.T
+    A = -0.5 * P
+    quad = np.zeros((d, d))
+    iu = np.triu_indices(d)
+    quad[iu] = A[iu] * np.where(iu[0] == iu[1], 1., 2.)
+    n_param = 1 + d + d * (d + 1) // 2
+    x = np.random.default_rng(fit_seed).normal(size=(n_fit_mult * n_param, d))
+    mu = np.mean(x, axis=0)
+    hess = np.linalg.inv(np.cov(x, rowvar=False))
+    beta = np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5
+    alpha = float(np.max(beta))
+    logp_fit = -0.5 * np.einsum('ij,jk,ik->i', x, P, x)
+    xm = x[np.argmax(logp_fit)]
+    f_mu = float(-0.5 * xm @ P @ xm)
+    poly = dict(input_size=d, output_size=1, use_bound=True, mu=mu, hess=hess, alpha=alpha, f_mu=np.array([f_mu]),
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.array([0]), coef=np.zeros((1, d + 1))),
+                         dict(order='quadratic', input_mask=np.arange(d), output_mask=np.array([0]), coef=quad[None])])
+    spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=poly, use_decay=False)
+    return spec, np.linalg.inv(P)

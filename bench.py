@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog steps/sec (all chains), 4096 chains x 64-d quadratic surrogate, NUTS.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE launch of the fused NUTS kernel that advances every chain of the rank by --iters NUTS
+iterations (reference loop: BaseHMC.run/astep, samplers/hmc_utils/base_hmc.py:62-85,155-156).  The W
+untimed steps are the NUTS warm-up (step-size and metric adaptation, n_warmup = W * iters); the K timed steps
+are post-warm-up sampling.  Leapfrog steps are counted as the reference counts them: sum of tree_size
+(samplers/sample_trace.py:529-530); the extra gradient evaluation that opens every iteration is not a
+leapfrog step.  Chains shard over ranks with no data-path collective (weak scaling: 4096 chains per GPU,
+RNG stream = global chain index).
+
+The CPU baseline is the repository's C restatement of the reference path (oracle/, "port"), run on the
+host cores on a bounded sample of the same workload; it is a reported baseline, never the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(spec, d, n_warm_iter, seed, target_seconds=15.):
+    """Leapfrog steps/sec of the CPU oracle on all host cores, post-warm-up, on a bounded sample."""
+    from oracle import oracle as orc  # the checker, timed as a baseline only
+    n_thr = orc.max_threads()
+    n_chain = 4 * n_thr
+    x0 = np.random.default_rng(seed).normal(size=(n_chain, d))
+    cs = orc.ChainSet(spec, x0, seed)
+    cs.run(n_warm_iter, n_warm_iter, n_threads=n_thr)  # untimed adaptation, same as the GPU path
+    t0 = time.perf_counter()
+    _, _, nl = cs.run(5, n_warm_iter, n_threads=n_thr)
+    dt = time.perf_counter() - t0
+    n_it = int(max(5, min(2000, target_seconds / max(dt / 5, 1e-6))))
+    t0 = time.perf_counter()
+    _, st, nl = cs.run(n_it, n_warm_iter, n_threads=n_thr)
+    dt = time.perf_counter() - t0
+    try:
+        model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+    except Exception:
+        model = 'unknown'
+    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': n_thr, 'kind': 'port',
+            'sample': '%d chains x %d post-warm-up NUTS iterations (%d leapfrogs in %.1f s) of the same 64-d workload, '
+                      'one chain per OpenMP thread, %s' % (n_chain, n_it, nl, dt, model)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--iters', type=int, default=100, help='NUTS iterations per step (per launch)')
+    ap.add_argument('--seed', type=int, default=2024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    import torch
+    from bayesfast_amd.device import DeviceContext, DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec, B_STEP_BYTES, flops_per_leapfrog
+    from bayesfast_amd import _lib
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if a.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
+
+    d, C = a.dim, a.chains
+    spec, cov = correlated_gaussian_spec(d)
+    ctx = DeviceContext(local_rank)
+    with torch.cuda.device(ctx.device):
+        dens = DeviceDensity(spec, ctx)
+        # chain starts: N(0, I) rows (core/sample.py:111-112), one global array sliced per rank
+        x0 = np.random.default_rng(a.seed).normal(size=(world * C, d))[rank * C:(rank + 1) * C]
+        chains = DeviceChains(dens, x0, seed=a.seed, first_stream=rank * C)
+        n_warm_iter = a.warmup * a.iters
+        kw = dict(n_warmup=n_warm_iter, check=False)
+        samples = ctx.empty((C, a.iters, d))
+        stats = ctx.empty((C, a.iters, _lib.STAT_STRIDE))
+
+        for _ in range(a.warmup):
+            chains.run(a.iters, 'NUTS', samples=samples, stats=stats, **kw)
+        chains.raise_on_error()
+        lf0 = chains.total_leapfrog
+
+        def sync():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        sync()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            ev[k][0].record(ctx.stream)  # HIP events on the stream the kernel is launched on
+            chains.run(a.iters, 'NUTS', samples=samples, stats=stats, **kw)
+            ev[k][1].record(ctx.stream)
+        sync()
+        elapsed = time.perf_counter() - t0
+        chains.raise_on_error()
+        n_lf = chains.total_leapfrog - lf0
+        kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if a.steps else 0.
+        st_last = stats.cpu().numpy()
+
+        tot = torch.tensor([float(n_lf)], dtype=torch.float64, device=ctx.device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        if dist is not None:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_lf, elapsed_max = float(tot.item()), float(tmax.item())
+
+    if rank == 0:
+        value = total_lf / elapsed_max
+        lf_per_launch = n_lf / max(a.steps, 1)
+        use_bound = bool(spec['poly']['use_bound'])
+        flops = flops_per_leapfrog(d, use_bound) * lf_per_launch
+        bytes_alg = B_STEP_BYTES(d) * lf_per_launch
+        ach_tf = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else 0.
+        peak_tf = 78.6  # FP64 MFMA, 256 CUs x 4 SIMDs x 2.4 GHz x 2048 flop / 64 cyc; 77.7 measured (profiles/r01_probe_mfma_f64.log)
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get('dim') == d:
+                    traffic = tj['hbm_bytes_per_leapfrog'] * lf_per_launch
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'leapfrog steps/sec (all chains), 4096 chains x 64-d quadratic surrogate',
+            'value': value, 'unit': 'leapfrog steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': elapsed_max / max(a.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%d chains/GPU x %d-d correlated Gaussian (SURVEY 8d config-2 family), '
+                                   "PolyModel('quadratic') surrogate = linear+quadratic, bound on; NUTS defaults "
+                                   '(diag-adapt metric, target_accept 0.8, max_treedepth 10)' % (C, d),
+                       'chains_per_gpu': C, 'dim': d, 'nuts_iterations_per_step': a.iters,
+                       'nuts_warmup_iterations': n_warm_iter,
+                       'mean_tree_size': float(st_last[:, :, _lib.NSTATS.index('tree_size')].mean()),
+                       'parallelism': 'chains sharded over %d rank(s), no data-path collective' % world},
+            'roofline': {'bound': 'mfma', 'achieved': ach_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
+                         'frac': ach_tf / peak_tf, 'traffic': traffic,
+                         'kernel': 'bf_sampler_kernel<4,true>', 'kernel_ms_per_launch': kernel_ms,
+                         'flops_per_leapfrog': flops_per_leapfrog(d, use_bound)},
+            'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
+                                         'peak': 8000., 'unit': 'GB/s',
+                                         'frac': (bytes_alg / (kernel_ms * 1e-3) / 1e9 / 8000.) if kernel_ms else 0.,
+                                         'bytes_per_leapfrog': B_STEP_BYTES(d)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(spec, d, n_warm_iter, a.seed)
+        elif not a.no_cpu_baseline:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

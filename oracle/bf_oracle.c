@@ -994,3 +994,36 @@ long bfo_nuts_run_many(const bfo_density *dn, int n_chain, const double *x0, uin
     }
     return err ? (long)err : total;
 }
+
+/* Persistent-chain variant for the CPU baseline: chains[i] continue from their state; returns leapfrogs. */
+long bfo_nuts_run_chains(const bfo_density *dn, int n_chain, bfo_chain **chains, bfo_rng *rngs, long n_run,
+                         long n_warmup, int max_treedepth, double max_change, int n_threads, double *samples,
+                         double *stats) {
+    int d = dn->d;
+    long total = 0;
+    int err = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int ci = 0; ci < n_chain; ++ci) {
+        double *smp = samples + (size_t)ci * n_run * d;
+        double *st = stats + (size_t)ci * n_run * BFO_N_NSTATS;
+        int rc = bfo_nuts_run(dn, chains[ci], &rngs[ci], n_run, n_warmup, max_treedepth, max_change, smp, st);
+        if (rc) {
+#pragma omp atomic write
+            err = rc;
+        } else {
+            for (long i = 0; i < n_run; ++i) total += (long)st[(size_t)i * BFO_N_NSTATS + BFO_ST_TREE_SIZE];
+        }
+    }
+    return err ? (long)err : total;
+}
+
+int bfo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

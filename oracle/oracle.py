@@ -101,6 +101,10 @@ def lib():
         L.bfo_nuts_run_many.restype = C.c_long
         L.bfo_nuts_run_many.argtypes = [C.POINTER(_Density), C.c_int, _dp, C.c_uint64, C.c_uint64, C.c_long,
                                         C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp]
+        L.bfo_nuts_run_chains.restype = C.c_long
+        L.bfo_nuts_run_chains.argtypes = [C.POINTER(_Density), C.c_int, C.POINTER(C.POINTER(_Chain)), C.POINTER(_Rng),
+                                          C.c_long, C.c_long, C.c_int, C.c_double, C.c_int, _dp, _dp]
+        L.bfo_max_threads.restype = C.c_int
         L.bfo_xoshiro_seed.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.bfo_xoshiro_next.restype = C.c_uint64
         L.bfo_xoshiro_next.argtypes = [C.POINTER(C.c_uint64)]
@@ -453,3 +457,34 @@ def set_decay(x, alpha=None, alpha_p=150., gamma=0.1):
     mu, hess, alpha = _mu_hess_alpha(_f64(x), alpha, alpha_p)
     return dict(use_decay=True, decay_mu=mu, decay_hess=hess, decay_alpha2=float(alpha)**2,
                 decay_gamma=float(gamma))
+
+
+class ChainSet:
+    """Persistent chains + xoshiro streams for timing phases separately (bench.py cpu_baseline)."""
+
+    def __init__(self, spec, x0, seed, first_stream=0, **chain_kw):
+        self.dn, self._keep = density_struct(spec)
+        x0 = _f64(x0)
+        self.n_chain, self.d = x0.shape
+        self.chains = [Chain(x0[i], **chain_kw) for i in range(self.n_chain)]
+        self._cptr = (C.POINTER(_Chain) * self.n_chain)(*[c._c for c in self.chains])
+        self._rngs = (_Rng * self.n_chain)()
+        for i in range(self.n_chain):
+            self._rngs[i].kind = 0
+            s = xoshiro_seed(seed, first_stream + i)
+            for k in range(4):
+                self._rngs[i].s[k] = int(s[k])
+
+    def run(self, n_run, n_warmup, max_treedepth=10, max_change=1000., n_threads=0):
+        samples = np.empty((self.n_chain, n_run, self.d))
+        stats = np.empty((self.n_chain, n_run, len(NSTATS)))
+        total = lib().bfo_nuts_run_chains(C.byref(self.dn), self.n_chain, self._cptr, self._rngs, int(n_run),
+                                          int(n_warmup), int(max_treedepth), float(max_change), int(n_threads),
+                                          _p(samples), _p(stats))
+        if total < 0:
+            raise RuntimeError('oracle chain failed with code %d' % total)
+        return samples, {k: stats[:, :, i].copy() for i, k in enumerate(NSTATS)}, int(total)
+
+
+def max_threads():
+    return int(lib().bfo_max_threads())
