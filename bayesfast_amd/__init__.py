@@ -2,8 +2,13 @@
 
 Polynomial-surrogate logp/grad, leapfrog, NUTS/HMC over many chains and the surrogate's least-squares fit
 run as hand-written gfx950 HIP kernels behind a C ABI (include/bfhip.h); this package is the thin Python
-host side that mirrors the reference's ``modules``/``samplers`` interfaces for that path.
+host side that mirrors the reference's ``modules`` / ``samplers`` / ``core.sample`` interfaces for that path.
 """
 from . import _lib  # noqa: F401
+from .modules import PolyConfig, PolyModel
+from .core.module import Surrogate
+from .core.density import SurrogateDensity
+from .core.sample import sample
+from .samplers import NTrace, HTrace, TraceTuple
 
-__all__ = ['_lib']
+__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'sample', 'NTrace', 'HTrace', 'TraceTuple']

@@ -1,0 +1,173 @@
+"""Surrogate density: the part of ``bayesfast.core.density.Density`` that the sampler path touches, for a
+pipeline whose log density is one PolyModel output.
+
+Host state is NumPy; every ``logp``/``grad``/``logp_and_grad`` call is one batched device launch
+(``bfhip_logp_grad``), replacing the per-row Python recursion of core/density.py:523-525."""
+import numpy as np
+
+from ..modules.poly import PolyModel
+
+__all__ = ['SurrogateDensity']
+
+
+class SurrogateDensity:
+    """log density = PolyModel surrogate (+ decay penalty) in a constrained parameter space.
+
+    surrogate : PolyModel with output_size 1
+    input_scales : None or (d, 2) array, ``Density(input_scales=...)`` (core/density.py:33-58)
+    hard_bounds : bool or (d,) / (d, 2) array_like (core/density.py:60-76)
+    decay_options : dict for ``set_decay_options`` (core/density.py:761-794)
+    """
+
+    def __init__(self, surrogate, input_scales=None, hard_bounds=False, decay_options=None):
+        if not isinstance(surrogate, PolyModel) or surrogate.output_size != 1:
+            raise ValueError('surrogate should be a PolyModel with output_size 1.')
+        self.surrogate = surrogate
+        self._d = surrogate.input_size
+        if input_scales is None:
+            self._input_scales = None
+        else:
+            sc = np.ascontiguousarray(input_scales, dtype=np.float64)
+            if sc.ndim == 1:
+                sc = np.array((np.zeros_like(sc), sc)).T.copy()
+            if sc.shape != (self._d, 2) or not np.all(sc[:, 1] > sc[:, 0]):
+                raise ValueError('invalid value for input_scales.')
+            self._input_scales = sc
+        try:
+            hb = np.atleast_1d(hard_bounds).astype(bool).astype(np.uint8)
+            if hb.ndim == 1:
+                hb = np.array((hb, hb)).T.copy()
+            if hb.shape[0] == 1:
+                hb = np.repeat(hb, self._d, 0)
+            assert hb.shape == (self._d, 2)
+        except Exception:
+            raise ValueError('Invalid value for hard_bounds')
+        self._hard_bounds = np.ascontiguousarray(hb)
+        self.set_decay_options(**(decay_options or {}))
+        self._mu = self._hess = None
+        self._device = None
+
+    input_size = property(lambda self: self._d)
+
+    def set_decay_options(self, use_decay=False, alpha=None, alpha_p=150., gamma=0.1):
+        """core/density.py:761-794."""
+        self._use_decay = bool(use_decay)
+        self._alpha = None if alpha is None else float(alpha)
+        self._alpha_2 = None if alpha is None else float(alpha)**2
+        if alpha_p is None and alpha is None:
+            raise ValueError('alpha and alpha_p cannot both be None.')
+        self._alpha_p = None if alpha_p is None else float(alpha_p)
+        gamma = float(gamma)
+        if not gamma > 0:
+            raise ValueError('invalid value for gamma.')
+        self._gamma = gamma
+        self._device = None
+
+    # ---- constraint transforms (core/density.py:92-140 -> transforms/_constraint.pyx); host glue that
+    # ``sample`` uses once per call to convert x_0 and the returned samples (core/sample.py:114-116,175-177) ----
+    def _kinds(self):
+        lo, hi = self._hard_bounds[:, 0].astype(bool), self._hard_bounds[:, 1].astype(bool)
+        return lo & hi, lo & ~hi, ~lo & hi
+
+    def from_original(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self._input_scales is None:
+            return x.copy()
+        lo, rg = self._input_scales[:, 0], self._input_scales[:, 1] - self._input_scales[:, 0]
+        t = (x - lo) / rg
+        both, lower, upper = self._kinds()
+        if np.any((t <= 0.)[..., both | lower]) or np.any((t >= 1.)[..., both | upper]):
+            raise ValueError('variable out of bound.')
+        out = t.copy()
+        out[..., both] = np.log(t[..., both] / (1. - t[..., both]))
+        out[..., lower] = np.log(t[..., lower])
+        out[..., upper] = np.log(1. - t[..., upper])
+        return out
+
+    def to_original(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self._input_scales is None:
+            return x.copy()
+        lo, rg = self._input_scales[:, 0], self._input_scales[:, 1] - self._input_scales[:, 0]
+        both, lower, upper = self._kinds()
+        t = x.copy()
+        t[..., both] = 1. / (1. + np.exp(-x[..., both]))
+        t[..., lower] = np.exp(x[..., lower])
+        t[..., upper] = 1. - np.exp(x[..., upper])
+        return lo + t * rg
+
+    def to_original_grad(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self._input_scales is None:
+            return np.ones_like(x)
+        rg = self._input_scales[:, 1] - self._input_scales[:, 0]
+        both, lower, upper = self._kinds()
+        t = np.ones_like(x)
+        s = 1. / (1. + np.exp(-x[..., both]))
+        t[..., both] = s * (1. - s)
+        t[..., lower] = np.exp(x[..., lower])
+        t[..., upper] = -np.exp(x[..., upper])
+        return t * rg
+
+    def to_original_density(self, density, x_trans):
+        """core/density.py:188-195: density in the original space from the transformed-space value."""
+        diff = np.sum(np.log(np.abs(self.to_original_grad(x_trans))), axis=-1)
+        return np.asarray(density) - diff
+
+    # ---- fit ----
+    def fit(self, x, logp):
+        """``Density.fit`` (core/density.py:813-830) for x (n, d) original-space points with true logp (n,)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        logp = np.asarray(logp, dtype=np.float64).reshape(-1)
+        if x.ndim != 2 or x.shape != (logp.size, self._d):
+            raise ValueError('x should have shape (n, d) and logp shape (n,).')
+        if self._use_decay:
+            self._set_decay(x)
+        su = self.surrogate
+        xs = x if su._input_scales is None else (x - su._input_scales[:, 0]) / su._input_scales_diff
+        su.fit(xs, logp[:, None], logp)
+        self._device = None
+
+    def _set_decay(self, x):
+        """core/density.py:796-811."""
+        self._mu = np.mean(x, axis=0)
+        self._hess = np.linalg.inv(np.cov(x, rowvar=False))
+        if self._alpha_p is not None:
+            beta = np.einsum('ij,jk,ik->i', x - self._mu, self._hess, x - self._mu)**0.5
+            self._alpha = float(np.percentile(beta, self._alpha_p) if self._alpha_p < 100 else
+                                np.max(beta) * self._alpha_p / 100)
+            self._alpha_2 = self._alpha**2
+
+    # ---- device ----
+    def spec(self):
+        su = self.surrogate
+        spec = dict(d=self._d, ranges=self._input_scales,
+                    hard_bounds=self._hard_bounds if self._input_scales is not None else None,
+                    su_lo=None if su._input_scales is None else su._input_scales[:, 0],
+                    su_diff=None if su._input_scales is None else su._input_scales_diff,
+                    poly=su.poly_spec(), use_decay=self._use_decay)
+        if self._use_decay:
+            if self._mu is None:
+                raise RuntimeError('the decay statistics have not been set; call fit first.')
+            spec.update(decay_mu=self._mu, decay_hess=self._hess, decay_alpha2=self._alpha_2, decay_gamma=self._gamma)
+        return spec
+
+    def device(self, ctx=None):
+        from ..device import DeviceDensity
+        if self._device is None or (ctx is not None and self._device.ctx is not ctx):
+            self._device = DeviceDensity(self.spec(), ctx)
+        return self._device
+
+    def logp_and_grad(self, x, original_space=True):
+        """``Density.logp_and_grad(x, original_space, use_surrogate=True)`` (core/density.py:724-754)."""
+        x = np.asarray(x, dtype=np.float64)
+        lp, g = self.device().logp_and_grad(x, original_space)
+        return lp.cpu().numpy(), g.cpu().numpy()
+
+    def logp(self, x, original_space=True):
+        return self.logp_and_grad(x, original_space)[0]
+
+    __call__ = logp
+
+    def grad(self, x, original_space=True):
+        return self.logp_and_grad(x, original_space)[1]

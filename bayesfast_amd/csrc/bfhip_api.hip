@@ -42,6 +42,7 @@ extern "C" void bfhip_ctx_destroy(bfhip_ctx *ctx) {
     if (!ctx) return;
     if (ctx->model_buf) (void)hipFree(ctx->model_buf);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->cubic_buf) (void)hipFree(ctx->cubic_buf);
     free(ctx);
 }
 
@@ -76,8 +77,6 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     if (!ctx || !ds) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: NULL argument");
     const int d = ds->d;
     if (d < 1 || d > BFHIP_MAX_DIM) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: d = %d out of [1, %d]", d, BFHIP_MAX_DIM);
-    if (ds->cubic2 || ds->cubic3)
-        return bf_set_error(BFHIP_ERR_UNSUPPORTED, "cubic PolyConfig terms are not implemented on device yet");
     if (ds->use_bound && (!ds->mu || !ds->hess || !(ds->alpha > 0.)))
         return bf_set_error(BFHIP_ERR_ARG, "use_bound needs mu, hess and alpha > 0");
     if (ds->use_decay && (!ds->decay_mu || !ds->decay_hess))
@@ -152,6 +151,68 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     m.f_mu = ds->f_mu;
     m.decay_alpha2 = ds->decay_alpha2;
     m.decay_gamma = ds->decay_gamma;
+    // ---- cubic terms, compact over the dimensions they touch (modules/_poly.pyx:49-137) ----
+    m.has_cubic = (ds->cubic2 || ds->cubic3) ? 1 : 0;
+    if (m.has_cubic) {
+        std::vector<int> mask2, mask3, pos2(DP, -1), pos3(DP, -1);
+        if (ds->cubic2) {
+            for (int i = 0; i < d; ++i) {
+                bool used = false;
+                for (int k = 0; k < d && !used; ++k) used = ds->cubic2[(size_t)i * d + k] != 0. || ds->cubic2[(size_t)k * d + i] != 0.;
+                if (used) { pos2[i] = (int)mask2.size(); mask2.push_back(i); }
+            }
+        }
+        if (ds->cubic3) {
+            std::vector<char> used(d, 0);
+            for (int j = 0; j < d; ++j)
+                for (int k = j + 1; k < d; ++k)
+                    for (int l = k + 1; l < d; ++l)
+                        if (ds->cubic3[((size_t)j * d + k) * d + l] != 0.) used[j] = used[k] = used[l] = 1;
+            for (int i = 0; i < d; ++i)
+                if (used[i]) { pos3[i] = (int)mask3.size(); mask3.push_back(i); }
+        }
+        const int n2 = (int)mask2.size(), n3 = (int)mask3.size();
+        std::vector<double> A2((size_t)n2 * n2), A2t((size_t)n2 * n2), T3((size_t)n3 * n3 * n3, 0.);
+        for (int a = 0; a < n2; ++a)
+            for (int b = 0; b < n2; ++b) {
+                A2[(size_t)a * n2 + b] = ds->cubic2[(size_t)mask2[a] * d + mask2[b]];
+                A2t[(size_t)b * n2 + a] = A2[(size_t)a * n2 + b];
+            }
+        for (int a = 0; a < n3; ++a)
+            for (int b = a + 1; b < n3; ++b)
+                for (int c = b + 1; c < n3; ++c) {
+                    const double v = ds->cubic3[((size_t)mask3[a] * d + mask3[b]) * d + mask3[c]];
+                    const int p[3] = {a, b, c};
+                    static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+                    for (int q = 0; q < 6; ++q)  // T3t[k][l][j]
+                        T3[((size_t)p[perm[q][0]] * n3 + p[perm[q][1]]) * n3 + p[perm[q][2]]] = v;
+                }
+        const size_t ib = (size_t)(n2 + n3 + 2 * DP) * sizeof(int), ibp = (ib + 7) / 8 * 8;
+        const size_t cbytes = ibp + (A2.size() * 2 + T3.size()) * sizeof(double) + 8;
+        if (ctx->cubic_bytes < cbytes) {
+            if (ctx->cubic_buf) BF_HIP_CHECK(hipFree(ctx->cubic_buf));
+            ctx->cubic_buf = NULL;
+            ctx->cubic_bytes = 0;
+            BF_HIP_CHECK(hipMalloc(&ctx->cubic_buf, cbytes));
+            ctx->cubic_bytes = cbytes;
+        }
+        std::vector<char> hb(cbytes, 0);
+        int *ip = (int *)hb.data();
+        memcpy(ip, mask2.data(), n2 * sizeof(int));
+        memcpy(ip + n2, pos2.data(), DP * sizeof(int));
+        memcpy(ip + n2 + DP, mask3.data(), n3 * sizeof(int));
+        memcpy(ip + n2 + DP + n3, pos3.data(), DP * sizeof(int));
+        double *dp = (double *)(hb.data() + ibp);
+        memcpy(dp, A2.data(), A2.size() * sizeof(double));
+        memcpy(dp + A2.size(), A2t.data(), A2t.size() * sizeof(double));
+        memcpy(dp + 2 * A2.size(), T3.data(), T3.size() * sizeof(double));
+        BF_HIP_CHECK(hipMemcpy(ctx->cubic_buf, hb.data(), cbytes, hipMemcpyHostToDevice));
+        const int *dip = (const int *)ctx->cubic_buf;
+        const double *ddp = (const double *)((const char *)ctx->cubic_buf + ibp);
+        m.n2 = n2; m.n3 = n3;
+        m.mask2 = dip; m.pos2 = dip + n2; m.mask3 = dip + n2 + DP; m.pos3 = dip + n2 + DP + n3;
+        m.A2 = ddp; m.A2t = ddp + A2.size(); m.T3t = ddp + 2 * A2.size();
+    }
     ctx->has_model = 1;
     return 0;
 }

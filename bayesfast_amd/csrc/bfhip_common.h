@@ -31,6 +31,13 @@ struct DevModel {
     const double *Hf;   // bound Hessian
     const double *Hdf;  // decay Hessian
     double c0, alpha, f_mu, decay_alpha2, decay_gamma;
+    // cubic terms in compact (masked) form; pos2/pos3 map a dimension to its index in the mask or -1
+    int n2, n3;
+    const int *mask2, *pos2, *mask3, *pos3;  // mask: [n], pos: [DP]
+    const double *A2;    // [n2][n2] cubic-2 coefficients a[j][k]  (f = sum_j x_j^2 sum_k a[j][k] x_k)
+    const double *A2t;   // [n2][n2] its transpose
+    const double *T3t;   // [n3][n3][n3] symmetric fill of the j<k<l coefficients, zero where indices repeat,
+                         // stored [k][l][j] so that consecutive lanes (j) read consecutive words
 };
 
 // ---- xoshiro256++ / splitmix64 --------------------------------------------------------------------
@@ -88,6 +95,8 @@ struct bfhip_ctx {
     DevModel model;
     void *model_buf;      // one device allocation holding pd + fragments
     size_t model_bytes;
+    void *cubic_buf;      // cubic-term tables
+    size_t cubic_bytes;
     void *scratch;        // sampler tree scratch (grow-only)
     size_t scratch_bytes;
     int n_cu;

@@ -35,6 +35,40 @@ __device__ inline void bf_to_original(double x, int kind, double lo, double rg, 
     J2 = j2t * rg;
 }
 
+// Cubic-2 and cubic-3 contributions to gradient component `dim` of one point (modules/_poly.pyx:49-137),
+// compact masked tables (DevModel).  X(k) returns x_k of the point; xj = x_dim.
+//   cubic-2: f = sum_j x_j^2 v1_j, v1 = A x ;  df/dx_j = 2 x_j v1_j + (A^T x^2)_j
+//   cubic-3: f = sum_{j<k<l} a x_j x_k x_l ;   df/dx_j = 1/2 sum_{k,l} T[j,k,l] x_k x_l (T symmetric fill),
+//            and x . grad = 3 f (Euler), so the value needs no second pass.
+template <typename XF>
+__device__ inline void bf_cubic_grad(const DevModel &m, int dim, double xj, XF X, double &gc, double &fc) {
+    gc = 0.;
+    fc = 0.;
+    if (dim >= m.DP) return;
+    const int p2 = m.n2 > 0 ? m.pos2[dim] : -1;
+    if (p2 >= 0) {
+        double v1 = 0., v2 = 0.;
+        for (int k = 0; k < m.n2; ++k) {
+            const double xk = X(m.mask2[k]);
+            v1 += m.A2t[k * m.n2 + p2] * xk;       // a[dim][k]
+            v2 += m.A2[k * m.n2 + p2] * (xk * xk); // a[k][dim]
+        }
+        gc += 2. * xj * v1 + v2;
+        fc += xj * xj * v1;
+    }
+    const int p3 = m.n3 > 0 ? m.pos3[dim] : -1;
+    if (p3 >= 0) {
+        double s = 0.;
+        for (int k = 0; k < m.n3; ++k) {
+            double t = 0.;
+            for (int l = 0; l < m.n3; ++l) t += m.T3t[((size_t)k * m.n3 + l) * m.n3 + p3] * X(m.mask3[l]);
+            s += t * X(m.mask3[k]);
+        }
+        gc += 0.5 * s;
+        fc += xj * (0.5 * s) * (1. / 3.);
+    }
+}
+
 // np.clip(x, 0, inf) keeps NaN
 __device__ inline double bf_clip0(double x) { return x > 0. ? x : (x != x ? x : 0.); }
 
@@ -67,7 +101,7 @@ __device__ inline double bf_sum_g(double v) {
 template <int T>
 __device__ inline void bf_eval_w1(const DevModel &m, const double *Sf, const double *Hf, const double *Hdf,
                                   const double *pd, int original_space, const double (&x)[4 * T], double &logp,
-                                  double (&grad)[4 * T], int lane) {
+                                  double (&grad)[4 * T], int lane, double *xst /* wave-private LDS [16][DP], cubic only */) {
     constexpr int E = 4 * T;
     const int DP = 16 * T;
     const int g = lane >> 4;
@@ -118,6 +152,26 @@ __device__ inline void bf_eval_w1(const DevModel &m, const double *Sf, const dou
         lin += c * xs[e];
         grad[e] += c;
     }
+    // cubic configs: the point's coordinates go through the wave-private LDS stage
+    const int pc = lane & 15;
+    auto add_cubic = [&](const double (&xe)[E], double (&ge)[E]) -> double {
+        double fsum = 0.;
+#pragma unroll
+        for (int e = 0; e < E; ++e) xst[pc * DP + 4 * e + g] = xe[e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            double gc, fc;
+            bf_cubic_grad(m, 4 * e + g, xe[e], [&](int k) { return xst[pc * DP + k]; }, gc, fc);
+            ge[e] += gc;
+            fsum += fc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        return bf_sum_g(fsum);
+    };
+    double fcub = 0.;
+    if (m.has_cubic) fcub = add_cubic(xs, grad);
     if (m.use_bound) {
 #pragma unroll
         for (int e = 0; e < E; ++e) xm[e] = xs[e] - pd[PD_MU * DP + 4 * e + g];
@@ -130,7 +184,7 @@ __device__ inline void bf_eval_w1(const DevModel &m, const double *Sf, const dou
     if (m.use_bound) b2 = bf_sum_g(b2);
     if (m.use_decay) bd2 = bf_sum_g(bd2);
     if (tr) logdet = bf_sum_g(logdet);
-    double f = (m.c0 + lin) + 0.5 * quad;
+    double f = ((m.c0 + lin) + 0.5 * quad) + fcub;
     // ---- linear extrapolation outside the alpha-ellipsoid (modules/poly.py:480-503) ----
     if (m.use_bound) {
         const double beta = sqrt(b2);
@@ -146,20 +200,22 @@ __device__ inline void bf_eval_w1(const DevModel &m, const double *Sf, const dou
 #pragma unroll
                 for (int e = 0; e < E; ++e) j0[e] = 0.;
             }
-            double quad0 = 0., lin0 = 0., dotj = 0.;
+            double quad0 = 0., lin0 = 0., dotj = 0., fcub0 = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const double c = pd[PD_LIN * DP + 4 * e + g];
                 quad0 += x0[e] * j0[e];
                 lin0 += c * x0[e];
                 j0[e] += c;
-                dotj += j0[e] * xm[e];
             }
+            if (m.has_cubic) fcub0 = add_cubic(x0, j0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) dotj += j0[e] * xm[e];
             quad0 = bf_sum_g(quad0);
             lin0 = bf_sum_g(lin0);
             dotj = bf_sum_g(dotj);
             if (oob) {
-                const double f0 = (m.c0 + lin0) + 0.5 * quad0;
+                const double f0 = ((m.c0 + lin0) + 0.5 * quad0) + fcub0;
                 f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
                 const double coef = (f0 - m.f_mu) / m.alpha - dotj / beta;
 #pragma unroll

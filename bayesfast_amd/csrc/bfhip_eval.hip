@@ -34,14 +34,18 @@ __device__ inline StagedModel bf_stage_model(const DevModel &m, double *lds) {
     }
 }
 
-static size_t bf_stage_bytes(const DevModel &m) {
+static size_t bf_stage_bytes(const DevModel &m) {  // bytes of the staged model (0 when it is not staged)
+    if (m.DP > 64) return 0;
     size_t mat = (size_t)m.DP * m.DP * sizeof(double);
     return (size_t)PD_N * m.DP * sizeof(double) + mat * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
+}
+static size_t bf_eval_lds_bytes(const DevModel &m) {  // + the wave-private coordinate stage of the cubic terms
+    return bf_stage_bytes(m) + (m.has_cubic ? (size_t)4 * 16 * m.DP * sizeof(double) : 0);
 }
 
 // Density.logp_and_grad over n points; replaces the per-row Python recursion of core/density.py:523-525.
 template <int T, bool STAGE>
-__global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int n, const double *__restrict__ x,
+__global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int stage_dbl, int n, const double *__restrict__ x,
                                                            int original_space, double *__restrict__ logp,
                                                            double *__restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int n, co
     StagedModel sm = bf_stage_model<T, STAGE>(m, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
+    double *xst = lds + stage_dbl + wave * 16 * 16 * T;
     const int n_tiles = (n + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int pt = tile * 16 + c;
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int n, co
             const int dim = 4 * e + g;
             xv[e] = (pt < n && dim < m.d) ? x[(size_t)pt * m.d + dim] : 0.;
         }
-        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, original_space, xv, lp, gv, lane);
+        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, original_space, xv, lp, gv, lane, xst);
         if (pt < n) {
             if (g == 0) logp[pt] = lp;
             if (grad) {
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int n, co
 
 // CpuLeapfrogIntegrator._step (samplers/hmc_utils/integration.py:68-95), diagonal metric, n chains.
 template <int T, bool STAGE>
-__global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int n, const double *__restrict__ eps,
+__global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int stage_dbl, int n, const double *__restrict__ eps,
                                                           const double *__restrict__ var, double *__restrict__ q,
                                                           double *__restrict__ p, double *__restrict__ grad,
                                                           double *__restrict__ logp, double *__restrict__ energy,
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int n, con
     StagedModel sm = bf_stage_model<T, STAGE>(m, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
+    double *xst = lds + stage_dbl + wave * 16 * 16 * T;
     const int n_tiles = (n + 15) / 16;
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int ch = tile * 16 + c;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int n, con
             pn[e] = pp + dt * gg;              // integration.py:80
             qn[e] = qq + ep * (vr[e] * pn[e]); // :82-85
         }
-        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, 0, qn, lp, gn, lane);  // :87
+        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, 0, qn, lp, gn, lane, xst);  // :87
         double kin = 0.;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -142,10 +148,9 @@ template <int T, bool STAGE>
 static int launch_logp_grad(bfhip_ctx *ctx, int grid, size_t lds, int n, const double *x, int original_space,
                             double *logp, double *grad) {
     auto k = bf_logp_grad_kernel<T, STAGE>;
-    if (STAGE) {
-        if (int rc = bf_set_lds(k, lds)) return rc;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), STAGE ? lds : 0, ctx->stream, ctx->model, n, x, original_space, logp, grad);
+    if (int rc = bf_set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, (int)(bf_stage_bytes(ctx->model) / sizeof(double)),
+                       n, x, original_space, logp, grad);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -154,10 +159,9 @@ template <int T, bool STAGE>
 static int launch_leapfrog(bfhip_ctx *ctx, int grid, size_t lds, int n, const double *eps, const double *var, double *q,
                            double *p, double *grad, double *logp, double *energy, double *vel) {
     auto k = bf_leapfrog_kernel<T, STAGE>;
-    if (STAGE) {
-        if (int rc = bf_set_lds(k, lds)) return rc;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), STAGE ? lds : 0, ctx->stream, ctx->model, n, eps, var, q, p, grad, logp, energy, vel);
+    if (int rc = bf_set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, (int)(bf_stage_bytes(ctx->model) / sizeof(double)),
+                       n, eps, var, q, p, grad, logp, energy, vel);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -174,7 +178,7 @@ extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int origi
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_logp_grad: no density uploaded");
     if (n == 0) return 0;
     const int grid = eval_grid(ctx, n);
-    const size_t lds = bf_stage_bytes(ctx->model);
+    const size_t lds = bf_eval_lds_bytes(ctx->model);
     switch (ctx->model.DP / 16) {
     case 1: return launch_logp_grad<1, true>(ctx, grid, lds, n, x, original_space, logp, grad);
     case 2: return launch_logp_grad<2, true>(ctx, grid, lds, n, x, original_space, logp, grad);
@@ -191,7 +195,7 @@ extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const do
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_leapfrog: no density uploaded");
     if (n == 0) return 0;
     const int grid = eval_grid(ctx, n);
-    const size_t lds = bf_stage_bytes(ctx->model);
+    const size_t lds = bf_eval_lds_bytes(ctx->model);
     switch (ctx->model.DP / 16) {
     case 1: return launch_leapfrog<1, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
     case 2: return launch_leapfrog<2, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);

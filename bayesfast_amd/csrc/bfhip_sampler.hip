@@ -650,18 +650,33 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
             const bool fast_kin = !m.use_decay && mode != M_OOB;
+            double xev[E], r_cub = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int dim = lane * E + e;
                 const double sx = (m.has_quad && lane_ok) ? GB[(0 * 16 + w) * GS + dim] : 0.;
                 hv[e] = (m.use_bound && lane_ok) ? GB[(1 * 16 + w) * GS + dim] : 0.;
                 dgr[e] = (m.use_decay && lane_ok) ? GB[(2 * 16 + w) * GS + dim] : 0.;
-                const double xm = xs[e] - c_mu[e];
-                double x_eval = xs[e];
-                if (mode == M_OOB) x_eval = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
-                r_quad += x_eval * sx;
-                r_lin += c_lin[e] * x_eval;
+                xev[e] = xs[e];
+                if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
+                r_quad += xev[e] * sx;
+                r_lin += c_lin[e] * xev[e];
                 gn[e] = sx + c_lin[e];
+            }
+            if (m.has_cubic) {  // cubic configs: x_k of this chain is lane k / E, element k % E
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double gc, fc;
+                    bf_cubic_grad(m, lane * E + e, xev[e],
+                                  [&](int k) { return readlane_f64((E > 1 && (k % E)) ? xev[E - 1] : xev[0], k / E); }, gc, fc);
+                    gn[e] += gc;
+                    r_cub += fc;
+                }
+                r_cub = wave_sum(r_cub);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double xm = xs[e] - c_mu[e];
                 r_b2 += xm * hv[e];
                 r_dotj += gn[e] * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
                 if (m.use_decay) r_bd2 += (xo[e] - pdl(PD_DMU, e)) * dgr[e];
@@ -682,7 +697,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             if (m.use_decay) r_bd2 = wave_sum(r_bd2);
             if (m.has_transform) logdet = wave_sum(logdet);
 
-            double f = (m.c0 + r_lin) + 0.5 * r_quad;
+            double f = ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
             const double beta = sqrt(r_b2);
             bool oob_now = false;
             if (m.use_bound) {

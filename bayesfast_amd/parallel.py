@@ -1,0 +1,48 @@
+"""Chain sharding over the GPUs of one node and the one exchange step of the path.
+
+Chains are independent between refits (core/sample.py:211-213 is a pure map), so each rank owns a contiguous
+block of chains and runs them with no data-path collective; the per-chain RNG stream is keyed by the GLOBAL
+chain index, so results do not depend on the number of ranks.  The refit needs every rank to see all samples
+(the reference's resampler indexes the flattened all-chain array, core/recipe.py:1024-1025,1074,1082): that is
+ONE all-gather per sampling round (RCCL over xGMI with backend "nccl"; gloo in the CPU tests)."""
+import numpy as np
+
+__all__ = ['world', 'shard_range', 'all_gather_chains']
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) without one."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
+def shard_range(n_chain, rank, world_size):
+    """Contiguous block [begin, end) of chains owned by ``rank`` (sizes differ by at most one)."""
+    base, extra = divmod(int(n_chain), int(world_size))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def all_gather_chains(t, n_chain):
+    """All-gather along the chain axis of a tensor whose first dimension is this rank's shard.
+
+    Shards may differ by one chain: every rank pads to the largest shard, one ``all_gather`` moves the padded
+    blocks, and the pads are cut away.  Works on CUDA tensors (nccl = RCCL) and CPU tensors (gloo)."""
+    import torch
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return t
+    sizes = [shard_range(n_chain, r, ws)[1] - shard_range(n_chain, r, ws)[0] for r in range(ws)]
+    mx = max(sizes)
+    pad = t
+    if t.shape[0] < mx:
+        pad = torch.cat([t, t.new_zeros((mx - t.shape[0],) + tuple(t.shape[1:]))], 0)
+    out = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(out, pad.contiguous())
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], 0)

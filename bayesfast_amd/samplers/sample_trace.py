@@ -1,0 +1,290 @@
+"""Sampler configuration and result containers with the reference's names and semantics
+(bayesfast/samplers/sample_trace.py).  In the reference one ``NTrace``/``HTrace`` object per chain holds the
+configuration AND that chain's adaptive state and samples; here the configuration object is shared and the
+state of all chains lives in device tensors (``bayesfast_amd.chains.DeviceChains``), while ``TraceTuple``
+exposes the per-chain views the callers (``Recipe``, users) read."""
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib
+
+__all__ = ['NTrace', 'HTrace', 'TraceTuple', 'ChainView', '_get_step_size', '_get_metric']
+
+
+class _HTrace:
+    """Options shared by HTrace and NTrace (samplers/sample_trace.py:157-172, defaults identical)."""
+
+    _sampler = None
+
+    def __init__(self, n_chain=4, n_iter=1500, n_warmup=500, x_0=None, random_generator=None, step_size=1.,
+                 adapt_step_size=True, metric='diag', adapt_metric=True, max_change=1000., target_accept=0.8,
+                 gamma=0.05, k=0.75, t_0=10., initial_mean=None, initial_weight=10., adapt_window=60,
+                 update_window=1, doubling=True):
+        def _pos_int(v, name):
+            try:
+                v = int(v)
+                assert v > 0
+            except Exception:
+                raise ValueError('{} should be a positive int, instead of {}.'.format(name, v))
+            return v
+        self.n_chain = _pos_int(n_chain, 'n_chain')
+        self.n_iter = _pos_int(n_iter, 'n_iter')
+        self.n_warmup = _pos_int(n_warmup, 'n_warmup')
+        if self.n_warmup >= self.n_iter:
+            raise ValueError('n_iter is {}, so n_warmup should be smaller than this number.'.format(self.n_iter))
+        self.x_0 = None if x_0 is None else np.atleast_1d(x_0).copy()
+        self._x_0_transformed = False
+        self.random_generator = random_generator
+        if step_size is None:
+            step_size = 1.
+        try:
+            step_size = float(step_size)
+            assert step_size > 0
+        except Exception:
+            raise ValueError('invalid value for step_size.')
+        self._step_size = step_size
+        self._adapt_step_size = bool(adapt_step_size)
+        if isinstance(metric, str):
+            if metric == 'full':
+                raise NotImplementedError('the full-rank metric is not implemented on device yet.')
+            if metric != 'diag':
+                raise ValueError('invalid value for metric.')
+            self._metric = None
+        else:
+            metric = np.asarray(metric, dtype=np.float64)
+            if metric.ndim == 2:
+                raise NotImplementedError('the full-rank metric is not implemented on device yet.')
+            if metric.ndim != 1 or not np.all(metric > 0):
+                raise ValueError('invalid value for metric.')
+            self._metric = metric
+        self._adapt_metric = bool(adapt_metric)
+        try:
+            self.max_change = float(max_change)
+            assert self.max_change > 0
+        except Exception:
+            raise ValueError('max_change should be a positive float, instead of {}.'.format(max_change))
+        try:
+            self._target_accept = float(target_accept)
+            assert 0 < self._target_accept < 1
+        except Exception:
+            raise ValueError('invalid value for target_accept.')
+        self._gamma, self._k, self._t_0 = float(gamma), float(k), float(t_0)
+        if self._gamma == 0 or self._t_0 < 0:
+            raise ValueError('invalid value for gamma or t_0.')
+        self._initial_mean = None if initial_mean is None else np.atleast_1d(initial_mean).astype(np.float64)
+        self._initial_weight = float(initial_weight)
+        self._adapt_window = _pos_int(adapt_window, 'adapt_window')
+        self._update_window = _pos_int(update_window, 'update_window')
+        self._doubling = bool(doubling)
+
+    x_0_transformed = property(lambda self: self._x_0_transformed)
+
+    @property
+    def input_size(self):
+        try:
+            return self.x_0.shape[-1]
+        except Exception:
+            return None
+
+    def seed(self):
+        """Integer seed of the per-chain xoshiro streams, from ``random_generator`` (None: OS entropy)."""
+        g = self.random_generator
+        if g is None:
+            return int(np.random.SeedSequence().generate_state(1, np.uint64)[0])
+        if isinstance(g, (int, np.integer)):
+            return int(g)
+        return int(np.random.default_rng(g).integers(0, 2**63 - 1))
+
+    def run_kwargs(self):
+        kw = dict(n_warmup=self.n_warmup, max_change=self.max_change, target_accept=self._target_accept,
+                  gamma=self._gamma, k=self._k, t_0=self._t_0, adapt_step_size=self._adapt_step_size,
+                  adapt_metric=self._adapt_metric, update_window=self._update_window, doubling=self._doubling)
+        return kw
+
+
+class NTrace(_HTrace):
+    """Trace options of the NUTS sampler (samplers/sample_trace.py:499-537)."""
+    _sampler = 'NUTS'
+
+    def __init__(self, n_chain=4, n_iter=1500, n_warmup=500, x_0=None, random_generator=None, step_size=1.,
+                 adapt_step_size=True, metric='diag', adapt_metric=True, max_change=1000., max_treedepth=10,
+                 target_accept=0.8, gamma=0.05, k=0.75, t_0=10., initial_mean=None, initial_weight=10.,
+                 adapt_window=60, update_window=1, doubling=True):
+        super().__init__(n_chain, n_iter, n_warmup, x_0, random_generator, step_size, adapt_step_size, metric,
+                         adapt_metric, max_change, target_accept, gamma, k, t_0, initial_mean, initial_weight,
+                         adapt_window, update_window, doubling)
+        try:
+            self.max_treedepth = int(max_treedepth)
+            assert 0 < self.max_treedepth <= _lib.MAX_TREEDEPTH
+        except Exception:
+            raise ValueError('max_treedepth should be a positive int not larger than {}, instead of '
+                             '{}.'.format(_lib.MAX_TREEDEPTH, max_treedepth))
+
+    def run_kwargs(self):
+        return dict(super().run_kwargs(), max_treedepth=self.max_treedepth)
+
+
+class HTrace(_HTrace):
+    """Trace options of the static HMC sampler (samplers/sample_trace.py:458-497)."""
+    _sampler = 'HMC'
+
+    def __init__(self, n_chain=4, n_iter=1500, n_warmup=500, n_int_step=32, x_0=None, random_generator=None,
+                 step_size=1., adapt_step_size=True, metric='diag', adapt_metric=True, max_change=1000.,
+                 target_accept=0.8, gamma=0.05, k=0.75, t_0=10., initial_mean=None, initial_weight=10.,
+                 adapt_window=60, update_window=1, doubling=True):
+        super().__init__(n_chain, n_iter, n_warmup, x_0, random_generator, step_size, adapt_step_size, metric,
+                         adapt_metric, max_change, target_accept, gamma, k, t_0, initial_mean, initial_weight,
+                         adapt_window, update_window, doubling)
+        try:
+            self.n_int_step = int(n_int_step)
+            assert self.n_int_step > 0
+        except Exception:
+            raise ValueError('n_int_step should be a positive int, instead of {}.'.format(n_int_step))
+
+    def run_kwargs(self):
+        return dict(super().run_kwargs(), n_int_step=self.n_int_step)
+
+
+class _Stats:
+    """``NStats``/``HStats`` look-alike of one chain (samplers/hmc_utils/stats.py:39-94)."""
+
+    def __init__(self, items, table, n_warmup):
+        self.stats_items = items
+        self._n_warmup = n_warmup
+        for i, k in enumerate(items):
+            col = table[:, i]
+            if k in ('tree_depth', 'tree_size', 'n_int_step'):
+                col = col.astype(int)
+            elif k in ('warmup', 'diverging', 'accepted'):
+                col = col.astype(bool)
+            setattr(self, '_' + k, list(col))
+
+    n_iter = property(lambda self: len(self._logp))
+    n_warmup = property(lambda self: self._n_warmup)
+
+    def get(self, since_iter=None, include_warmup=False):
+        if since_iter is None:
+            since_iter = 0 if include_warmup else self._n_warmup
+        return OrderedDict((k, getattr(self, '_' + k)[int(since_iter):]) for k in self.stats_items)
+
+    __call__ = get
+
+
+class ChainView:
+    """What one element of the reference's ``TraceTuple`` offers to its readers."""
+
+    def __init__(self, tt, i):
+        self._tt, self.chain_id = tt, i
+
+    n_iter = property(lambda self: self._tt.n_iter)
+    n_warmup = property(lambda self: self._tt.n_warmup)
+    i_iter = property(lambda self: self._tt.i_iter)
+    input_size = property(lambda self: self._tt.input_size)
+    samples = property(lambda self: self._tt.samples[self.chain_id])
+    samples_original = property(lambda self: self._tt.samples_original[self.chain_id])
+    logp = property(lambda self: self._tt.logp[self.chain_id])
+    logp_original = property(lambda self: self._tt.logp_original[self.chain_id])
+
+    @property
+    def stats(self):
+        t = self._tt
+        return _Stats(t._stat_items, t._stats[self.chain_id], t.n_warmup)
+
+    @property
+    def n_call(self):
+        t = self._tt
+        if t.sampler == 'NUTS':  # samplers/sample_trace.py:529-530
+            return int(t._stats[self.chain_id, 1:, t._stat_items.index('tree_size')].sum()) + t.i_iter + 1
+        return t.i_iter * (t._trace.n_int_step + 1) + 1  # :487-489
+
+    def get(self, since_iter=None, include_warmup=False, original_space=True, return_type='samples', flatten=True):
+        return self._tt.get(since_iter, include_warmup, original_space, return_type, flatten=False)[self.chain_id]
+
+    __call__ = get
+
+
+class TraceTuple:
+    """All chains of one ``sample`` call (samplers/sample_trace.py:631-801)."""
+
+    def __init__(self, trace, samples, stats, samples_original, logp_original, chains=None):
+        self._trace = trace
+        self.sampler = trace._sampler
+        self._samples = np.asarray(samples)
+        self._stats = np.asarray(stats)
+        self._stat_items = _lib.NSTATS if self.sampler == 'NUTS' else _lib.HSTATS
+        self._samples_original = np.asarray(samples_original)
+        self._logp_original = np.asarray(logp_original)
+        self._chains = chains  # DeviceChains of this rank (None for a gathered result on another rank)
+
+    sample_traces = property(lambda self: tuple(ChainView(self, i) for i in range(self.n_chain)))
+    n_chain = property(lambda self: self._samples.shape[0])
+    n_iter = property(lambda self: self._trace.n_iter)
+    i_iter = property(lambda self: self._samples.shape[1])
+    n_warmup = property(lambda self: self._trace.n_warmup)
+    input_size = property(lambda self: self._samples.shape[-1])
+    finished = property(lambda self: self.i_iter >= self.n_iter)
+    samples = property(lambda self: self._samples)
+    samples_original = property(lambda self: self._samples_original)
+    logp = property(lambda self: self._stats[:, :, 0])
+    logp_original = property(lambda self: self._logp_original)
+    stats = property(lambda self: [t.stats for t in self.sample_traces])
+    n_call = property(lambda self: sum(t.n_call for t in self.sample_traces))
+
+    def stat(self, name):
+        """(n_chain, i_iter) array of one statistic by its reference name."""
+        return self._stats[:, :, self._stat_items.index(name)]
+
+    def get(self, since_iter=None, include_warmup=False, original_space=True, return_type='samples', flatten=True):
+        if return_type == 'all':
+            return [self.get(since_iter, include_warmup, original_space, r, flatten) for r in ('samples', 'logp')]
+        if since_iter is None:
+            since_iter = 0 if include_warmup else self.n_warmup
+        since_iter = int(since_iter)
+        if since_iter >= self.i_iter - 1:
+            raise ValueError('since_iter is too large. Nothing to return.')
+        if return_type == 'samples':
+            s = (self._samples_original if original_space else self._samples)[:, since_iter:]
+            return s.reshape((-1, self.input_size)) if flatten else s
+        if return_type == 'logp':
+            l = (self._logp_original if original_space else self.logp)[:, since_iter:]
+            return l.flatten() if flatten else l
+        raise ValueError('invalid value for return_type.')
+
+    __call__ = get
+
+    def __getitem__(self, key):
+        return self.sample_traces[key]
+
+    def __len__(self):
+        return self.n_chain
+
+    def __iter__(self):
+        return iter(self.sample_traces)
+
+
+def _get_step_size(sample_trace):
+    """Warm-start step size for the next round (samplers/sample_trace.py:804-817): exp(log_bar) * d^(1/4),
+    averaged over chains."""
+    if not isinstance(sample_trace, TraceTuple) or sample_trace._chains is None:
+        raise ValueError('invalid value for sample_trace.')
+    lb = sample_trace._chains.field('log_bar').cpu().numpy()
+    return float(np.mean(np.exp(lb) * sample_trace.input_size**0.25))
+
+
+def _get_metric(sample_trace, target, from_samples=True):
+    """Warm-start metric (samplers/sample_trace.py:820-847)."""
+    if not isinstance(sample_trace, TraceTuple):
+        raise ValueError('invalid value for sample_trace.')
+    if from_samples:
+        cov = np.cov(sample_trace.get(original_space=False, flatten=True), rowvar=False)
+    else:
+        if sample_trace._chains is None:
+            raise ValueError('invalid value for sample_trace.')
+        cov = np.diag(sample_trace._chains.field('var').cpu().numpy().mean(0))
+    if target == 'diag':
+        return np.diag(cov)
+    if target == 'full':
+        return cov
+    raise ValueError('unexpected value for target.')

@@ -196,3 +196,46 @@ def test_nuts_posterior_moments_quadratic_target(ctx):
     np.testing.assert_allclose(draws.var(0), np.diag(cov), rtol=0.05)
     emp = np.cov(draws, rowvar=False)
     assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.03
+
+
+def _cubic_spec(d=6, seed=3):
+    """Negative-definite quadratic + small masked cubic-2 / cubic-3 terms, bound on."""
+    rng = np.random.default_rng(seed)
+    L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
+    A = -0.5 * (L @ L.T)
+    quad = np.zeros((d, d))
+    iu = np.triu_indices(d)
+    quad[iu] = A[iu] * np.where(iu[0] == iu[1], 1., 2.)
+    m2, m3 = np.array([1, 2, 4]), np.array([0, 1, 3, 5])
+    c2 = 0.02 * rng.normal(size=(1, 3, 3))
+    c3 = np.zeros((1, 4, 4, 4))
+    j, k, l = np.meshgrid(*[np.arange(4)] * 3, indexing='ij')
+    c3[0][(j < k) & (k < l)] = 0.03 * rng.normal(size=4)
+    x = rng.normal(size=(200, d))
+    mu = x.mean(0)
+    hess = np.linalg.inv(np.cov(x, rowvar=False))
+    alpha = float(np.sqrt(np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)).max())
+    poly = dict(input_size=d, output_size=1, use_bound=True, mu=mu, hess=hess, alpha=alpha, f_mu=np.array([0.3]),
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.array([0]), coef=0.1 * rng.normal(size=(1, d + 1))),
+                         dict(order='quadratic', input_mask=np.arange(d), output_mask=np.array([0]), coef=quad[None]),
+                         dict(order='cubic-2', input_mask=m2, output_mask=np.array([0]), coef=c2),
+                         dict(order='cubic-3', input_mask=m3, output_mask=np.array([0]), coef=c3)])
+    return dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=poly, use_decay=False)
+
+
+def test_cubic_configs_eval_and_nuts(ctx):
+    """cubic-2 / cubic-3 PolyConfigs with masks (modules/_poly.pyx:49-137): batched logp+grad inside and
+    outside the bound, then NUTS trajectories, vs the oracle."""
+    from bayesfast_amd.device import DeviceDensity
+    from oracle import oracle as orc
+    spec = _cubic_spec()
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.normal(size=(40, 6)) * 0.7, rng.normal(size=(9, 6)) * 3.])
+    lp0, g0 = orc.logp_and_grad(spec, x)
+    lp, g = DeviceDensity(spec, ctx).logp_and_grad(x)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp0, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(g.cpu().numpy(), g0, rtol=1e-10, atol=1e-10)
+    x0 = rng.normal(size=(5, 6)) * 0.5
+    dev = _device_chains(ctx, spec, x0, 25, 15)
+    orc_runs = _oracle_chains(spec, x0, 25, 15)
+    _compare_nuts(dev, orc_runs, 25)

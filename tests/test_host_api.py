@@ -1,0 +1,159 @@
+"""CPU-only tests of the host side that mirrors the reference interface (no compute calls: no GPU here)."""
+import copy
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from bayesfast_amd import PolyConfig, PolyModel, NTrace, HTrace, TraceTuple, SurrogateDensity
+from bayesfast_amd import _lib, parallel
+from oracle import oracle as orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_polyconfig_shapes_and_errors():
+    with pytest.raises(ValueError):
+        PolyConfig('quartic')
+    c = PolyConfig('cubic-3', input_mask=[4, 1, 1, 2], output_mask=[0])
+    assert list(c.input_mask) == [1, 2, 4] and c.input_size == 3 and c.output_size == 1
+    assert c._A_shape == (1, 3, 3, 3) and c._a_shape == (1,)
+    assert PolyConfig('quadratic', [0, 1, 2], [0, 1])._a_shape == (6,)
+    with pytest.raises(RuntimeError):
+        PolyConfig('linear')._A_shape
+
+
+@pytest.mark.parametrize('order', ['linear', 'quadratic', 'cubic-2', 'cubic-3'])
+def test_polyconfig_set_matches_reference_scatter(order):
+    """PolyConfig._set packs like modules/_poly.pyx:183-214 (checked through the oracle's restatement)."""
+    n = 5
+    c = PolyConfig(order, input_mask=np.arange(n), output_mask=[0, 1])
+    a = np.random.default_rng(0).normal(size=c._a_shape)
+    c._set(a, 1)
+    assert np.array_equal(c._coef[1], orc.dense_coef(order, a, n))
+    assert not c._coef[0].any()
+    with pytest.raises(ValueError):
+        c._set(a[:-1], 0)
+    with pytest.raises(ValueError):
+        c._set(a, 2)
+
+
+def test_polymodel_construction_recipe_and_nparam():
+    m = PolyModel('quadratic', input_size=64, output_size=1)
+    assert [c.order for c in m.configs] == ['linear', 'quadratic'] and m.n_param == 2145
+    assert m.bound_options.use_bound and m.bound_options.alpha_p == 100.
+    assert PolyModel('cubic-3', input_size=4, output_size=1).n_param == 5 + 10 + 16 + 4
+    with pytest.raises(ValueError):  # two quadratic configs on the same output (modules/poly.py:308-313)
+        PolyModel([PolyConfig('quadratic'), PolyConfig('quadratic')], input_size=3, output_size=1)
+    with pytest.raises(ValueError):  # output 1 has no config (:334-337)
+        PolyModel([PolyConfig('linear', output_mask=[0])], input_size=3, output_size=2)
+    with pytest.raises(ValueError):
+        PolyModel('quintic', input_size=3, output_size=1)
+    with pytest.raises(ValueError):
+        m.set_bound_options(alpha=None, alpha_p=None)
+    with pytest.raises(ValueError):
+        m.fit(np.zeros((10, 64)), np.zeros((10, 1)))  # fewer points than parameters (:521-523)
+    with pytest.raises(ValueError):
+        m.fit(np.zeros((3000, 63)), np.zeros((3000, 1)))
+    with pytest.raises(RuntimeError):
+        m.poly_spec()  # not fitted
+
+
+def test_polymodel_survives_deepcopy_and_pickle():
+    """Recipe deep-copies and pickles surrogates (core/recipe.py:822,1163): no device handles in the state."""
+    m = PolyModel('quadratic', input_size=3, output_size=1, input_scales=np.array([[0., 2.]] * 3))
+    for c in m.configs:
+        c._set(np.arange(c._a_shape[0], dtype=float), 0)
+    m._mu, m._hess, m._alpha, m._f_mu = np.zeros(3), np.eye(3), 2., np.array([1.])
+    for m2 in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert np.array_equal(m2.configs[1]._coef, m.configs[1]._coef)
+        assert m2.poly_spec()['alpha'] == 2. and m2.scope == (0, 1)
+        assert np.array_equal(m2._input_scales_diff, [2., 2., 2.])
+
+
+def test_trace_options_validation_and_defaults():
+    t = NTrace()
+    assert (t.n_chain, t.n_iter, t.n_warmup, t.max_treedepth, t.max_change) == (4, 1500, 500, 10, 1000.)
+    assert t.run_kwargs()['target_accept'] == 0.8 and HTrace().n_int_step == 32
+    for bad in (dict(n_chain=0), dict(n_iter=10, n_warmup=10), dict(max_treedepth=0), dict(max_treedepth=99),
+                dict(step_size=-1.), dict(target_accept=1.5), dict(max_change=0.), dict(metric='banana')):
+        with pytest.raises(ValueError):
+            NTrace(**bad)
+    with pytest.raises(NotImplementedError):
+        NTrace(metric='full')
+    assert NTrace(random_generator=7).seed() == 7
+
+
+def test_tracetuple_get_semantics():
+    """get() drops the warm-up by default and flattens chains (samplers/sample_trace.py:277-303,753-785)."""
+    tr = NTrace(n_chain=3, n_iter=10, n_warmup=4)
+    C, n, d = 3, 10, 2
+    s = np.arange(C * n * d, dtype=float).reshape(C, n, d)
+    st = np.zeros((C, n, _lib.STAT_STRIDE))
+    st[:, :, _lib.NSTATS.index('tree_size')] = 3
+    st[:, :, 0] = np.arange(n)
+    tt = TraceTuple(tr, s, st, s * 10, st[:, :, 0] - 1.)
+    assert tt.get().shape == (C * 6, d) and np.array_equal(tt.get()[0], s[0, 4] * 10)
+    assert tt.get(original_space=False, flatten=False).shape == (C, 6, d)
+    assert tt.get(include_warmup=True, return_type='logp').shape == (C * n,)
+    assert len(tt) == 3 and tt[1].samples.shape == (n, d) and [t.chain_id for t in tt] == [0, 1, 2]
+    assert tt[0].n_call == 3 * (n - 1) + n + 1 and tt.n_call == 3 * tt[0].n_call
+    assert tt[2].stats.get()['tree_size'] == [3] * 6 and tt[0].stats.n_iter == n
+    with pytest.raises(ValueError):
+        tt.get(since_iter=9)
+    with pytest.raises(ValueError):
+        tt.get(return_type='weights')
+
+
+def test_surrogate_density_transforms_match_reference_fixture():
+    z = np.load(os.path.join(G, 'constraint.npz'))
+    n = z['ranges'].shape[0]
+    den = SurrogateDensity(PolyModel('quadratic', input_size=n, output_size=1), input_scales=z['ranges'],
+                           hard_bounds=z['hard_bounds'])
+    np.testing.assert_allclose(den.to_original(z['x_trans']), z['to_f'], rtol=1e-14)
+    np.testing.assert_allclose(den.to_original_grad(z['x_trans']), z['to_j'], rtol=1e-14)
+    np.testing.assert_allclose(den.from_original(z['to_f']), z['from_f'], rtol=1e-12)
+    bad = z['to_f'][0].copy()
+    bad[0] = z['ranges'][0, 1] + 1.
+    with pytest.raises(ValueError):
+        den.from_original(bad)
+    with pytest.raises(ValueError):
+        SurrogateDensity(PolyModel('quadratic', input_size=n, output_size=2))
+
+
+def test_shard_range_partitions_chains():
+    for n, ws in ((4096, 8), (10, 3), (5, 8), (1, 1)):
+        r = [parallel.shard_range(n, k, ws) for k in range(ws)]
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+        assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+
+
+def _gather_worker(rank, ws, port, n_chain, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    try:
+        b, e = parallel.shard_range(n_chain, rank, ws)
+        full = torch.arange(n_chain * 3 * 2, dtype=torch.float64).reshape(n_chain, 3, 2)
+        out = parallel.all_gather_chains(full[b:e].clone(), n_chain)
+        q.put((rank, bool(torch.equal(out, full)), parallel.world()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_chain', [8, 7])
+def test_all_gather_chains_gloo_world2(n_chain):
+    """The refit exchange step on 2 CPU processes (gloo): even and ragged shards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + n_chain) % 2000
+    ps = [ctx.Process(target=_gather_worker, args=(r, 2, port, n_chain, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    assert [r[1] for r in res] == [True, True]
+    assert [r[2] for r in res] == [(0, 2), (1, 2)]
