@@ -25,6 +25,19 @@
 // post-order, so a chain reproduces the CPU oracle's trajectory for the same xoshiro stream.
 #include "bfhip_eval.h"
 
+// The f64 libm expansions (exp, log, sincospi, sqrt) are long inline sequences whose constants get hoisted
+// out of the trip loop; inlined at every call site they push the kernel far over its 128-VGPR budget
+// (68 spilled VGPRs, 228 B of scratch per lane, reloaded inside the hot loop).  Out-of-line copies keep the
+// hot loop's register pressure down (32 spilled); the calls are rare (a few per chain per trip).
+__device__ __attribute__((noinline)) static double bf_exp_ni(double x) { return exp(x); }
+__device__ __attribute__((noinline)) static double bf_log_ni(double x) { return log(x); }
+__device__ __attribute__((noinline)) static double bf_sqrt_ni(double x) { return sqrt(x); }
+__device__ __attribute__((noinline)) static void bf_sincospi_ni(double x, double *s, double *c) { sincospi(x, s, c); }
+#define exp(x) bf_exp_ni(x)
+#define log(x) bf_log_ni(x)
+#define sqrt(x) bf_sqrt_ni(x)
+#define sincospi(x, s, c) bf_sincospi_ni(x, s, c)
+
 struct SamplerArgs {
     bfhip_sampler_config cfg;
     int n_chain, iter_end, iter_out0, n_out, nslot;
@@ -74,7 +87,7 @@ struct SamplerGeo {
     static constexpr bool STAGE = DP <= 64;           // coefficient fragments fit in LDS
 };
 
-template <int W, bool NUTS>
+template <int W, bool NUTS, bool STAMPS>
 __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
     using G = SamplerGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
@@ -126,6 +139,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 
     // ---- per-chain state (scalars are wave-uniform) ----
     double q[E], p[E], g[E], var[E], TLp[E], TPs[E], TPq[E];
+    double L0p[E], L0q[E];           // stack level 0 (a single waiting leaf): its p and q
+    double PF0[E], PF1[E], PF2[E];  // vectors the NEXT unit needs, loaded one trip ahead (latency hides in the barrier)
     uint64_t rs[4] = {0, 0, 0, 0};
     int i_iter = 0, mode = M_DONE, prev_mode = M_INIT, err = 0;
     double eps = 0., eps_t = 0.;
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
     };
 #pragma unroll
-    for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; }
+    for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; PF0[e] = 0.; PF1[e] = 0.; PF2[e] = 0.; L0p[e] = 0.; L0q[e] = 0.; }
     if (real) {
         for (int k = 0; k < 4; ++k) rs[k] = a.rng[(size_t)chain * 4 + k];
         cs_set(CS_LOG_STEP, scp[BFHIP_SC_LOG_STEP]);
@@ -263,6 +278,38 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #pragma unroll
                         for (int e = 0; e < E; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
                         unit = U_MERGE;  // resolved below (push / complete need no further trip)
+                        if ((i_leaf & 1) && depth > 0) {
+                            // ---- level-0 merge with the previous leaf, whose (p, q) wait in L0p / L0q ----
+                            // (single leaves: left.p = right.p = p_sum, and no extra checks at depth 1, nuts.py:154)
+                            double d0 = 0., d1 = 0.;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const double ps0 = L0p[e] + p[e];
+                                d0 += ps0 * (var[e] * L0p[e]);  // nuts.py:150-151
+                                d1 += ps0 * (var[e] * p[e]);
+                            }
+                            d0 = wave_sum(d0);
+                            d1 = wave_sum(d1);
+                            T_acc = lsw[LS_ACC] + T_acc;  // :173
+                            const double Wsum = lsw[LS_LS] + T_W;
+                            if (Wsum != Wsum) err = 2;
+                            const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
+                            if ((d0 <= 0.) || (d1 <= 0.)) {
+                                unit = U_ABORT;
+                                lev = 1;
+                            } else {
+                                if (!((u * Wsum < T_W) || (u == 0.))) {
+#pragma unroll
+                                    for (int e = 0; e < E; ++e) TPq[e] = L0q[e];
+                                    cs_set(CS_T_E, lsw[LS_E]);
+                                    cs_set(CS_T_LOGP, lsw[LS_LOGP]);
+                                }
+                                T_W = Wsum;
+#pragma unroll
+                                for (int e = 0; e < E; ++e) { TPs[e] = L0p[e] + p[e]; TLp[e] = L0p[e]; }
+                                lev = 1;
+                            }
+                        }
                     } else {
                         diverged = 1;
                         unit = U_ABORT;
@@ -292,10 +339,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             double A[E], B[E], S1[E], psum[E];
             const int slot = SL_STACK + 4 * lev;
 #pragma unroll
-            for (int e = 0; e < E; ++e) { A[e] = 0.; B[e] = 0.; S1[e] = 0.; }
-            ldv(slot + 0, A);
-            ldv(slot + 1, B);
-            ldv(slot + 2, S1);
+            for (int e = 0; e < E; ++e) { A[e] = PF0[e]; B[e] = PF1[e]; S1[e] = PF2[e]; }  // prefetched when this unit was scheduled
             double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -344,12 +388,9 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             // ---- Tree.extend after a complete subtree: nuts.py:71-103 ----
             double oldL[E], oldR[E], ps[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) { oldL[e] = 0.; oldR[e] = 0.; ps[e] = 0.; }
+            for (int e = 0; e < E; ++e) { ps[e] = PF0[e]; oldL[e] = PF1[e]; oldR[e] = PF2[e]; }  // prefetched
             depth += 1;
             acc_sum += T_acc;
-            ldv(SL_PSUM, ps);
-            ldv(SL_LEFT_P, oldL);
-            ldv(SL_RIGHT_P, oldR);
             {   // :81-83  logbern(ls_new - ls_old)  <=>  U * W_old < W_new
                 const double tree_W = csw[CS_TREE_W];
                 if (T_W != T_W || tree_W != tree_W) err = 2;
@@ -453,12 +494,14 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     st[10] = 0.;
                 }
             }
+            ldv(SL_PROP_Q, PF0);
             unit = U_END2;
         } else if (unit == U_END2) {
             // ================= iteration end, part 2: the new sample + metric adaptation =================
             const bool warm = i_iter < nw;
             const int orow = i_iter - a.iter_out0;
-            ldv(SL_PROP_Q, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) q[e] = PF0[e];  // the proposal, prefetched by part 1
             if (orow >= 0 && orow < a.n_out) {
                 double *sp = a.samples + ((size_t)chain * a.n_out + orow) * d;
 #pragma unroll
@@ -538,10 +581,18 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         } else if (unit == U_MERGE) {
             if (lev < depth && ((i_leaf >> lev) & 1)) {
                 unit = U_MERGE_RUN;  // next trip: merge with the waiting left sibling at this level
+                ldv(SL_STACK + 4 * lev + 0, PF0);
+                ldv(SL_STACK + 4 * lev + 1, PF1);
+                ldv(SL_STACK + 4 * lev + 2, PF2);
             } else if (lev < depth) {
                 // the subtree waits for its right sibling
-                const int slot = SL_STACK + 4 * lev;
-                stv(slot + 0, TLp); stv(slot + 1, p); stv(slot + 2, TPs); stv(slot + 3, TPq);
+                if (lev == 0) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { L0p[e] = p[e]; L0q[e] = q[e]; }  // stack level 0 lives in registers
+                } else {
+                    const int slot = SL_STACK + 4 * lev;
+                    stv(slot + 0, TLp); stv(slot + 1, p); stv(slot + 2, TPs); stv(slot + 3, TPq);
+                }
                 if (lane == 0) {
                     double *lsp = lsw + lev * LS_N;
                     lsp[LS_LS] = T_W; lsp[LS_E] = csw[CS_T_E]; lsp[LS_LOGP] = csw[CS_T_LOGP]; lsp[LS_ACC] = T_acc;
@@ -550,6 +601,9 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 unit = U_EVAL;
             } else {
                 unit = U_DBL_END;
+                ldv(SL_PSUM, PF0);
+                ldv(SL_LEFT_P, PF1);
+                ldv(SL_RIGHT_P, PF2);
             }
         }
         if (err != 0) { mode = M_DONE; unit = U_DONE; }
@@ -561,9 +615,10 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     if (m.use_bound) mat_id[n_mat++] = 1;
     if (m.use_decay) mat_id[n_mat++] = 2;
 
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = a.stamps ? clock64() : 0;
+    // phase stamps exist only in the diagnostic instantiation (they cost 18 always-live VGPRs)
+    unsigned long long st_acc[STAMPS ? 8 : 1] = {0}, st_prev = STAMPS ? clock64() : 0;
     auto stamp = [&](int k) {
-        if (a.stamps) {
+        if constexpr (STAMPS) {
             const unsigned long long t = clock64();
             st_acc[k] += t - st_prev;
             st_prev = t;
@@ -757,13 +812,15 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
 
         stamp(4);
-        if (a.stamps) st_acc[7] += 1;
+        if constexpr (STAMPS) st_acc[7] += 1;
         if (unit_in == U_EVAL) run_unit(have_eval, E_new, logp_new);
         stamp(unit_in == U_EVAL ? 5 : 6);
     }
 
-    if (a.stamps && lane == 0)
-        for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * 16 + w) * 8 + k] = st_acc[k];
+    if constexpr (STAMPS) {
+        if (a.stamps && lane == 0)
+            for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * 16 + w) * 8 + k] = st_acc[k];
+    }
     // ---- write the chain state back ----
     if (real) {
         store_vec(BFHIP_VEC_Q, q);
@@ -787,9 +844,9 @@ static size_t sampler_lds_bytes(const DevModel &m) {
     return dbl * sizeof(double);
 }
 
-template <int W, bool NUTS>
-static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
-    auto k = bf_sampler_kernel<W, NUTS>;
+template <int W, bool NUTS, bool STAMPS>
+static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
+    auto k = bf_sampler_kernel<W, NUTS, STAMPS>;
     const size_t lds = sampler_lds_bytes(ctx->model);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -802,6 +859,12 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
 static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
+
+template <int W, bool NUTS>
+static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
+    if (W == 4 && NUTS && args.stamps) return launch_sampler_t<W, NUTS, (W == 4 && NUTS)>(ctx, args);  // diagnostic build, d <= 64 NUTS only
+    return launch_sampler_t<W, NUTS, false>(ctx, args);
+}
 
 extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_chain, int iter_end,
                                  uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
