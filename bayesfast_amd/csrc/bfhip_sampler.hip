@@ -690,9 +690,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 for (int r4 = 0; r4 < 4; ++r4) GB[(b * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
             }
         }
-        // ---- chains that do not need this trip's gradient run their unit here, under the MFMA pipe ----
         const int unit_in = unit;
-        if (unit_in != U_EVAL) run_unit(false, 0., 0.);
         stamp(2);
         __syncthreads();  // B2
         stamp(3);
@@ -813,7 +811,10 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 
         stamp(4);
         if constexpr (STAMPS) st_acc[7] += 1;
+        // every chain runs ONE unit here, in parallel: chains that evaluated finish their leaf / init, the
+        // others do their pending merge level / doubling end / iteration-end piece
         if (unit_in == U_EVAL) run_unit(have_eval, E_new, logp_new);
+        else run_unit(false, 0., 0.);
         stamp(unit_in == U_EVAL ? 5 : 6);
     }
 
