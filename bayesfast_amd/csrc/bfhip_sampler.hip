@@ -45,7 +45,7 @@ struct SamplerArgs {
     double *sc, *vec, *samples, *stats;
     unsigned long long *n_leapfrog;
     double *scratch;
-    unsigned long long *stamps;  // diagnostics only: [groups][16 waves][8] cycle counters per phase, or NULL
+    unsigned long long *stamps;  // diagnostics only: [groups][16 waves][20]: 10 cycle counters + 10 event counts, or NULL
 };
 
 enum { M_INIT = 0, M_LEAF = 1, M_OOB = 2, M_DONE = 3 };
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     // ---- per-chain state (scalars are wave-uniform) ----
     double q[E], p[E], g[E], var[E], TLp[E], TPs[E], TPq[E];
     double L0p[E], L0q[E];           // stack level 0 (a single waiting leaf): its p and q
-    double PF0[E], PF1[E], PF2[E];  // vectors the NEXT unit needs, loaded one trip ahead (latency hides in the barrier)
+    double PF0[E], PF1[E], PF2[E], PF3[E];  // vectors the NEXT unit needs, loaded one trip ahead (latency hides in the barrier)
     uint64_t rs[4] = {0, 0, 0, 0};
     int i_iter = 0, mode = M_DONE, prev_mode = M_INIT, err = 0;
     double eps = 0., eps_t = 0.;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
     };
 #pragma unroll
-    for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; PF0[e] = 0.; PF1[e] = 0.; PF2[e] = 0.; L0p[e] = 0.; L0q[e] = 0.; }
+    for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; PF0[e] = 0.; PF1[e] = 0.; PF2[e] = 0.; PF3[e] = 0.; L0p[e] = 0.; L0q[e] = 0.; }
     if (real) {
         for (int k = 0; k < 4; ++k) rs[k] = a.rng[(size_t)chain * 4 + k];
         cs_set(CS_LOG_STEP, scp[BFHIP_SC_LOG_STEP]);
@@ -337,7 +337,6 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         } else if (unit == U_MERGE_RUN) {
             // ---- one level of Tree._build_subtree's merge (nuts.py:146-178) ----
             double A[E], B[E], S1[E], psum[E];
-            const int slot = SL_STACK + 4 * lev;
 #pragma unroll
             for (int e = 0; e < E; ++e) { A[e] = PF0[e]; B[e] = PF1[e]; S1[e] = PF2[e]; }  // prefetched when this unit was scheduled
             double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
@@ -374,7 +373,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 lev += 1;  // ancestors above this level still add their accept sums
             } else {
                 if (!keep_t2) {
-                    ldv(slot + 3, TPq);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) TPq[e] = PF3[e];  // the sibling's proposal, prefetched
                     cs_set(CS_T_E, lsp[LS_E]);
                     cs_set(CS_T_LOGP, lsp[LS_LOGP]);
                 }
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 ldv(SL_STACK + 4 * lev + 0, PF0);
                 ldv(SL_STACK + 4 * lev + 1, PF1);
                 ldv(SL_STACK + 4 * lev + 2, PF2);
+                ldv(SL_STACK + 4 * lev + 3, PF3);
             } else if (lev < depth) {
                 // the subtree waits for its right sibling
                 if (lev == 0) {
@@ -616,11 +617,12 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     if (m.use_decay) mat_id[n_mat++] = 2;
 
     // phase stamps exist only in the diagnostic instantiation (they cost 18 always-live VGPRs)
-    unsigned long long st_acc[STAMPS ? 8 : 1] = {0}, st_prev = STAMPS ? clock64() : 0;
+    unsigned long long st_acc[STAMPS ? 10 : 1] = {0}, st_cnt[STAMPS ? 10 : 1] = {0}, st_prev = STAMPS ? clock64() : 0;
     auto stamp = [&](int k) {
         if constexpr (STAMPS) {
             const unsigned long long t = clock64();
             st_acc[k] += t - st_prev;
+            st_cnt[k] += 1;
             st_prev = t;
         }
     };
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         const int unit_in = unit;
         stamp(2);
         __syncthreads();  // B2
-        stamp(3);
+        stamp(1);
 
         // ================= phase C: finish the evaluation =================
         double gn[E], hv[E], dgr[E];
@@ -809,18 +811,21 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             E_new = 0.5 * kin - logp_new;        // integration.py:92-93
         }
 
-        stamp(4);
-        if constexpr (STAMPS) st_acc[7] += 1;
+        stamp(3);
+        const int mode_in = mode;
         // every chain runs ONE unit here, in parallel: chains that evaluated finish their leaf / init, the
         // others do their pending merge level / doubling end / iteration-end piece
         if (unit_in == U_EVAL) run_unit(have_eval, E_new, logp_new);
         else run_unit(false, 0., 0.);
-        stamp(unit_in == U_EVAL ? 5 : 6);
+        stamp(unit_in == U_EVAL ? (mode_in == M_INIT ? 4 : 5) : (unit_in == U_MERGE_RUN ? 6 : (unit_in == U_DBL_END ? 7 : (unit_in == U_DONE ? 9 : 8))));
     }
 
     if constexpr (STAMPS) {
         if (a.stamps && lane == 0)
-            for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * 16 + w) * 8 + k] = st_acc[k];
+            for (int k = 0; k < 10; ++k) {
+                a.stamps[((size_t)blockIdx.x * 16 + w) * 20 + k] = st_acc[k];
+                a.stamps[((size_t)blockIdx.x * 16 + w) * 20 + 10 + k] = st_cnt[k];
+            }
     }
     // ---- write the chain state back ----
     if (real) {

@@ -13,7 +13,7 @@ C_ = 4096
 x0 = np.random.default_rng(1).normal(size=(C_, 64))
 dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=1)
 dc.run(200, n_warmup=200)
-buf = torch.zeros((C_ // 16, 16, 8), dtype=torch.int64, device='cuda')
+buf = torch.zeros((C_ // 16, 16, 20), dtype=torch.int64, device='cuda')
 L = _lib.lib()
 L.bfhip_debug_stamps.argtypes = [C.c_void_p]
 L.bfhip_debug_stamps(C.c_void_p(buf.data_ptr()))
@@ -22,10 +22,10 @@ s, st = dc.run(50, n_warmup=200)
 torch.cuda.synchronize(); dt = time.time() - t0
 L.bfhip_debug_stamps(None)
 b = buf.cpu().numpy().astype(float)
-names = ['A(pre-B1)', 'wait B1', 'B(mfma)', 'wait B2', 'C(eval)', 'unit: eval-post', 'unit: other', 'trips']
-tot = b[:, :, :7].sum(-1)
-print('launch %.1f ms; leapfrogs %d; trips per wave mean %.0f' % (dt * 1e3, st[:, :, 3].sum().item(), b[:, :, 7].mean()))
-print('cycles per wave total (clock64 ticks): mean %.3g' % tot.mean())
-for k in range(7):
-    print('%-18s %6.1f%%  per trip %8.1f' % (names[k], 100 * b[:, :, k].sum() / tot.sum(), b[:, :, k].sum() / b[:, :, 7].sum()))
-print('MFMA waves (0-3) vs others, B phase per trip:', b[:, :4, 2].sum() / b[:, :4, 7].sum(), b[:, 4:, 2].sum() / b[:, 4:, 7].sum())
+acc, cnt = b[:, :, :10], b[:, :, 10:]
+names = ['A (post x)', 'barrier waits', 'MFMA window', 'C (finish eval)', 'unit INIT', 'unit LEAF', 'unit MERGE_RUN', 'unit DBL_END', 'unit END1-3', 'idle (done)']
+tot = acc.sum()
+trips = cnt[:, :, 0].mean()
+print('launch %.1f ms; leapfrogs %d; trips per wave %.0f; ticks per trip %.0f' % (dt * 1e3, st[:, :, 3].sum().item(), trips, acc.sum(-1).mean() / trips))
+for k in range(10):
+    print('%-18s %5.1f%% of time | %8.0f events/wave | %7.0f ticks/event (mean) ' % (names[k], 100 * acc[:, :, k].sum() / tot, cnt[:, :, k].mean(), acc[:, :, k].sum() / max(cnt[:, :, k].sum(), 1)))
