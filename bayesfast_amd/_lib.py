@@ -51,6 +51,7 @@ SYMBOLS = {
     'bfhip_ctx_synchronize': (C.c_int, [_vp]),
     'bfhip_density_upload': (C.c_int, [_vp, C.POINTER(DensityDesc)]),
     'bfhip_logp_grad': (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    'bfhip_constraint': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     'bfhip_leapfrog': (C.c_int, [_vp, C.c_int] + [_vp] * 8),
     'bfhip_sampler_run': (C.c_int, [_vp, C.POINTER(SamplerConfig), C.c_int, C.c_int, _vp, _vp, _vp, C.c_int,
                                     C.c_int, _vp, _vp, _vp]),

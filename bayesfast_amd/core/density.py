@@ -63,51 +63,41 @@ class SurrogateDensity:
         self._gamma = gamma
         self._device = None
 
-    # ---- constraint transforms (core/density.py:92-140 -> transforms/_constraint.pyx); host glue that
-    # ``sample`` uses once per call to convert x_0 and the returned samples (core/sample.py:114-116,175-177) ----
-    def _kinds(self):
-        lo, hi = self._hard_bounds[:, 0].astype(bool), self._hard_bounds[:, 1].astype(bool)
-        return lo & hi, lo & ~hi, ~lo & hi
+    # ---- constraint transforms (core/density.py:142-163 -> transforms/_constraint.pyx), on device ----
+    def _transform_device(self):
+        """A device density that carries only the transform (usable before the surrogate is fitted)."""
+        from ..device import DeviceDensity
+        if getattr(self, '_tdev', None) is None:
+            d = self._d
+            spec = dict(d=d, ranges=self._input_scales,
+                        hard_bounds=self._hard_bounds if self._input_scales is not None else None, su_lo=None,
+                        su_diff=None, use_decay=False,
+                        poly=dict(input_size=d, output_size=1, use_bound=False,
+                                  configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.array([0]),
+                                                coef=np.zeros((1, d + 1)))]))
+            self._tdev = DeviceDensity(spec)
+        return self._tdev
+
+    def _constraint(self, which, x):
+        return self._transform_device().constraint(which, np.asarray(x, dtype=np.float64)).cpu().numpy()
 
     def from_original(self, x):
-        x = np.asarray(x, dtype=np.float64)
-        if self._input_scales is None:
-            return x.copy()
-        lo, rg = self._input_scales[:, 0], self._input_scales[:, 1] - self._input_scales[:, 0]
-        t = (x - lo) / rg
-        both, lower, upper = self._kinds()
-        if np.any((t <= 0.)[..., both | lower]) or np.any((t >= 1.)[..., both | upper]):
-            raise ValueError('variable out of bound.')
-        out = t.copy()
-        out[..., both] = np.log(t[..., both] / (1. - t[..., both]))
-        out[..., lower] = np.log(t[..., lower])
-        out[..., upper] = np.log(1. - t[..., upper])
-        return out
+        return self._constraint('from_original', x)
+
+    def from_original_grad(self, x):
+        return self._constraint('from_original_grad', x)
+
+    def from_original_grad2(self, x):
+        return self._constraint('from_original_grad2', x)
 
     def to_original(self, x):
-        x = np.asarray(x, dtype=np.float64)
-        if self._input_scales is None:
-            return x.copy()
-        lo, rg = self._input_scales[:, 0], self._input_scales[:, 1] - self._input_scales[:, 0]
-        both, lower, upper = self._kinds()
-        t = x.copy()
-        t[..., both] = 1. / (1. + np.exp(-x[..., both]))
-        t[..., lower] = np.exp(x[..., lower])
-        t[..., upper] = 1. - np.exp(x[..., upper])
-        return lo + t * rg
+        return self._constraint('to_original', x)
 
     def to_original_grad(self, x):
-        x = np.asarray(x, dtype=np.float64)
-        if self._input_scales is None:
-            return np.ones_like(x)
-        rg = self._input_scales[:, 1] - self._input_scales[:, 0]
-        both, lower, upper = self._kinds()
-        t = np.ones_like(x)
-        s = 1. / (1. + np.exp(-x[..., both]))
-        t[..., both] = s * (1. - s)
-        t[..., lower] = np.exp(x[..., lower])
-        t[..., upper] = -np.exp(x[..., upper])
-        return t * rg
+        return self._constraint('to_original_grad', x)
+
+    def to_original_grad2(self, x):
+        return self._constraint('to_original_grad2', x)
 
     def to_original_density(self, density, x_trans):
         """core/density.py:188-195: density in the original space from the transformed-space value."""

@@ -204,3 +204,52 @@ extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const do
     }
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->model.DP);
 }
+
+// transforms/_constraint.pyx:19-215, one thread per coordinate
+__global__ void bf_constraint_kernel(DevModel m, int which, long total, const double *__restrict__ x,
+                                     double *__restrict__ out, int *__restrict__ bad) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int i = (int)(idx % m.d);
+    const double xv = x[idx];
+    if (!m.has_transform) {  // core/density.py:93-111
+        out[idx] = (which == 0 || which == 3) ? xv : ((which == 1 || which == 4) ? 1. : 0.);
+        return;
+    }
+    const int kind = (int)m.pd[PD_KIND * m.DP + i];
+    const double lo = m.pd[PD_LO * m.DP + i], rg = m.pd[PD_RG * m.DP + i];
+    double r;
+    if (which >= 3) {
+        double xo, J, J2;
+        bf_to_original(xv, kind, lo, rg, xo, J, J2);
+        r = which == 3 ? xo : (which == 4 ? J : J2);
+    } else {
+        double t = (xv - lo) / rg;
+        const bool oob = (kind == 1 && (t <= 0. || t >= 1.)) || (kind == 2 && t <= 0.) || (kind == 3 && t >= 1.);
+        if (oob) atomicCAS(bad, 0, i + 1);
+        if (which == 0) {
+            r = kind == 1 ? log(t / (1. - t)) : (kind == 2 ? log(t) : (kind == 3 ? log(1. - t) : t));
+        } else if (which == 1) {
+            r = kind == 1 ? 1. / t / (1. - t) : (kind == 2 ? 1. / t : (kind == 3 ? 1. / (t - 1.) : 1.));
+            r /= rg;
+        } else {
+            r = kind == 1 ? (2. * t - 1.) / t / t / (1. - t) / (1. - t)
+                          : (kind == 2 ? -1. / t / t : (kind == 3 ? 1. / (t - 1.) / (1. - t) : 0.));
+            r /= rg * rg;
+        }
+    }
+    out[idx] = r;
+}
+
+extern "C" int bfhip_constraint(bfhip_ctx *ctx, int which, int n, const double *x, double *out, int *bad) {
+    if (!ctx || which < 0 || which > 5 || n < 0 || (n > 0 && (!x || !out)) || (which < 3 && !bad))
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_constraint: invalid argument");
+    if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_constraint: no density uploaded");
+    if (which < 3) BF_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    if (n == 0) return 0;
+    const long total = (long)n * ctx->model.d;
+    hipLaunchKernelGGL(bf_constraint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->model,
+                       which, total, x, out, bad);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -214,6 +214,25 @@ class DeviceDensity:
                                                  _ptr(logp), _ptr(grad)))
         return (logp[0], grad[0]) if single else (logp, grad)
 
+    _WHICH = {'from_original': 0, 'from_original_grad': 1, 'from_original_grad2': 2, 'to_original': 3,
+              'to_original_grad': 4, 'to_original_grad2': 5}
+
+    def constraint(self, which, x):
+        """Constraint transform of this density on device (core/density.py:142-163): (..., d) -> (..., d) tensor.
+        Raises ValueError when a variable is out of bound in a ``from_original*`` call."""
+        torch = _torch()
+        self.upload_if_needed()
+        xt = self.ctx.tensor(x, torch.float64)
+        shape = xt.shape
+        xt = xt.reshape(-1, self.d)
+        out = self.ctx.empty(xt.shape)
+        bad = torch.zeros((1,), dtype=torch.int32, device=self.ctx.device)
+        _lib.check(self.ctx._lib.bfhip_constraint(self.ctx.handle, self._WHICH[which], xt.shape[0], _ptr(xt), _ptr(out),
+                                                  _ptr(bad)))
+        if which.startswith('from') and int(bad.item()):
+            raise ValueError('variable #{} out of bound.'.format(int(bad.item()) - 1))
+        return out.reshape(shape)
+
     def leapfrog(self, eps, var, q, p, grad, logp=None, energy=None, velocity=None):
         """In-place batched CpuLeapfrogIntegrator._step; all arguments float64 device tensors, (n,) or (n,d)."""
         self.upload_if_needed()

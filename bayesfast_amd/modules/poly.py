@@ -311,8 +311,18 @@ class PolyModel(Surrogate):
             _lib.check(lib.bfhip_gram(h, n, P, len(outs), _ptr(A), P, _ptr(B), _ptr(G), _ptr(r)))
             _lib.check(lib.bfhip_solve_spd(h, P, len(outs), _ptr(G), _ptr(r), _ptr(info)))
             if int(info.item()) != 0:
-                raise np.linalg.LinAlgError('the normal equations of the polynomial fit are not positive definite '
-                                            '(pivot {}); the design matrix is rank deficient.'.format(int(info.item())))
+                # numerically rank-deficient design matrix: LAPACK gelsd (modules/poly.py:570) would return the
+                # minimum-norm solution; here the normal equations get a relative ridge of 1e-9 on the diagonal
+                # (Tikhonov) and are solved again.  Loud, because the two answers differ in the null directions.
+                warnings.warn('the design matrix of the polynomial fit is numerically rank deficient (pivot {}); '
+                              'solving ridge-regularised normal equations instead.'.format(int(info.item())),
+                              RuntimeWarning)
+                _lib.check(lib.bfhip_gram(h, n, P, len(outs), _ptr(A), P, _ptr(B), _ptr(G), _ptr(r)))
+                G.diagonal().mul_(1. + 1e-9)
+                _lib.check(lib.bfhip_solve_spd(h, P, len(outs), _ptr(G), _ptr(r), _ptr(info)))
+                if int(info.item()) != 0:
+                    raise np.linalg.LinAlgError('the normal equations of the polynomial fit are singular (pivot '
+                                                '{}).'.format(int(info.item())))
             sol = r.cpu().numpy()
             for jo, ii in enumerate(outs):
                 k = 0

@@ -93,6 +93,14 @@ int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *desc);
  * core/density.py:523-525).  grad may be NULL. */
 int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad);
 
+/* Constraint transforms of the uploaded density for n points, x (n,d) -> out (n,d):
+ * which = 0 from_original, 1 from_original_grad, 2 from_original_grad2, 3 to_original, 4 to_original_grad,
+ * 5 to_original_grad2  (Density.from_original/to_original/..., core/density.py:142-163 ->
+ * transforms/_constraint.pyx:19-215; identity / ones / zeros when the density has no input_scales,
+ * core/density.py:93-111).  bad (1,) int32 device flag: set to 1+i when variable i of some point is out of
+ * bound in a from_original* call (the reference raises ValueError, _constraint.pyx:27-28). */
+int bfhip_constraint(bfhip_ctx *ctx, int which, int n, const double *x, double *out, int *bad);
+
 /* CpuLeapfrogIntegrator._step for n chains at once (samplers/hmc_utils/integration.py:68-95) with a
  * diagonal metric (QuadMetricDiag, samplers/hmc_utils/metrics.py:51-91).
  * eps (n,), var (n,d); q,p,grad (n,d) and logp,energy (n,) are updated in place; velocity_out (n,d) may be NULL. */

@@ -102,3 +102,25 @@ def test_leapfrog_golden_and_oracle(ctx, name):
         np.testing.assert_allclose(tp[i].cpu().numpy(), r['p'], rtol=1e-10, atol=1e-11)
         np.testing.assert_allclose(tg[i].cpu().numpy(), r['grad'], rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(energy[i].item(), r['energy'], rtol=1e-11, atol=1e-10)
+
+
+def test_constraint_transforms_golden(ctx):
+    """from_original / to_original and their first and second derivatives vs the reference fixture
+    (transforms/_constraint.pyx:19-215), through SurrogateDensity; out-of-bound inputs raise ValueError."""
+    from bayesfast_amd import PolyModel, SurrogateDensity
+    z = np.load(os.path.join(G, 'constraint.npz'))
+    n = z['ranges'].shape[0]
+    den = SurrogateDensity(PolyModel('quadratic', input_size=n, output_size=1), input_scales=z['ranges'],
+                           hard_bounds=z['hard_bounds'])
+    for nm, f in (('f', den.to_original), ('j', den.to_original_grad), ('jj', den.to_original_grad2)):
+        np.testing.assert_allclose(f(z['x_trans']), z['to_' + nm], rtol=1e-14, atol=0)
+    xo = z['to_f']
+    for nm, f in (('f', den.from_original), ('j', den.from_original_grad), ('jj', den.from_original_grad2)):
+        np.testing.assert_allclose(f(xo), z['from_' + nm], rtol=1e-12, atol=0)
+    bad = xo[0].copy()
+    bad[0] = z['ranges'][0, 1] + 1.
+    with pytest.raises(ValueError):
+        den.from_original(bad)
+    plain = SurrogateDensity(PolyModel('quadratic', input_size=n, output_size=1))
+    assert np.array_equal(plain.to_original(z['x_trans']), z['x_trans'])
+    assert np.array_equal(plain.to_original_grad(z['x_trans']), np.ones_like(z['x_trans']))

@@ -170,3 +170,98 @@ def test_sample_end_to_end_matches_oracle_and_resumes():
     with pytest.raises(ValueError):  # non-finite logp at x_0 (base_hmc.py:42-46)
         bad = den.to_original(np.full((6, d), 40.))
         sample(den, NTrace(n_chain=6, n_iter=5, n_warmup=2, x_0=np.full((6, d), np.nan)), verbose=False)
+
+
+def _compare_chains_with_oracle(tt, den, seed, chains, n_iter, n_warmup, **orc_kw):
+    from oracle import oracle as orc
+    spec = den.spec()
+    x0_t = den.from_original(tt._trace.x_0) if not tt._trace.x_0_transformed else tt._trace.x_0
+    for i in chains:
+        ch = orc.Chain(x0_t[i], **{k: v for k, v in orc_kw.items() if k in ('target_accept', 'step_size')})
+        so, sto = orc.nuts_run(spec, ch, orc.make_rng('xoshiro', seed=seed, stream=i), n_iter, n_warmup)
+        assert np.array_equal(tt[i].stats._tree_size, sto['tree_size'].astype(int)), i
+        assert np.array_equal(tt[i].stats._tree_depth, sto['tree_depth'].astype(int)), i
+        assert np.array_equal(np.array(tt[i].stats._diverging, dtype=float), sto['diverging']), i
+        np.testing.assert_allclose(tt[i].samples[:6], so[:6], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(tt[i].samples, so, rtol=1e-3, atol=1e-3)
+
+
+def test_config3_banana_quadratic_surrogate_with_refit_cycle():
+    """BASELINE config 3: 64-d rotated banana (examples/banana-gbs.ipynb cell 3 at D = 64, Q = 0.01), quadratic
+    PolyModel fitted on 2 P points, NUTS, then ONE refit cycle on points drawn from the first round.  The
+    first-round quadratic surrogate is indefinite, so chains live on the extrapolation bound with deep trees:
+    a stress case for the fit, the out-of-bound branch and the tree logic (checked against the oracle)."""
+    from scipy.stats import special_ortho_group
+    from bayesfast_amd import PolyModel, SurrogateDensity, sample, NTrace
+    D, Q = 64, 0.01
+    np.random.seed(0)
+    A = special_ortho_group.rvs(D)
+
+    def logp(x):
+        x = x @ A.T
+        return -np.sum((x[..., ::2]**2 - x[..., 1::2])**2 / Q + (x[..., ::2] - 1)**2, axis=-1)
+
+    su = PolyModel('quadratic', input_size=D, output_size=1)
+    den = SurrogateDensity(su)
+    P = su.n_param
+    assert P == 2145
+    rng = np.random.default_rng(1)
+    x_fit = rng.normal(size=(2 * P, D))
+    den.fit(x_fit, logp(x_fit))
+    # the device fit solves the same least-squares problem as the reference's lstsq
+    resid = su.fun(x_fit[0])[0][0] - logp(x_fit[0])
+    from oracle import oracle as orc
+    ref = orc.poly_fit(su.poly_spec(use_bound=False), x_fit, logp(x_fit)[:, None], logp(x_fit))
+    np.testing.assert_allclose(su.configs[1]._coef[0][np.triu_indices(D)], ref['configs'][1]['coef'][0][np.triu_indices(D)],
+                               rtol=0, atol=1e-7 * np.abs(ref['configs'][1]['coef']).max())
+    tr = NTrace(n_chain=256, n_iter=24, n_warmup=12, x_0=x_fit[:256], random_generator=3)
+    tt = sample(den, tr, verbose=False)
+    assert tt.stat('tree_depth').max() >= 6
+    _compare_chains_with_oracle(tt, den, 3, (0, 100, 255), 24, 12)
+    # refit cycle: 2 P points spread evenly over the first-round samples, true logp, refit, sample again
+    pool = np.unique(tt.get(include_warmup=True).reshape(-1, D), axis=0)  # rejected iterations repeat a sample
+    pool = pool[np.all(np.abs(pool) < 50., axis=1)]
+    n_new = min(P, pool.shape[0])
+    x_new = np.concatenate([pool[np.linspace(0, pool.shape[0] - 1, n_new).astype(int)], x_fit[:2 * P - n_new]])
+    den.fit(x_new, logp(x_new))
+    tr2 = NTrace(n_chain=64, n_iter=16, n_warmup=8, x_0=x_new[:64], random_generator=4)
+    tt2 = sample(den, tr2, verbose=False)
+    _compare_chains_with_oracle(tt2, den, 4, (0, 63), 16, 8)
+    assert abs(resid) < 1e6
+
+
+def test_config4_funnel_target_accept_095():
+    """BASELINE config 4 (one shard): 64-d funnel (examples/funnel-gbs.ipynb cell 3: a = 1, b = 0.5), quadratic
+    surrogate, target_accept = 0.95; chain results depend on the GLOBAL chain index only (first_stream)."""
+    from bayesfast_amd import PolyModel, SurrogateDensity, sample, NTrace
+    D, a, b = 64, 1., 0.5
+
+    def logp(x):
+        return (-x[..., 0]**2 / (2 * a**2) - np.sum(x[..., 1:]**2, axis=-1) / (2 * np.exp(2 * b * x[..., 0])) -
+                (D - 1) * b * x[..., 0])
+
+    su = PolyModel('quadratic', input_size=D, output_size=1)
+    den = SurrogateDensity(su, decay_options=dict(use_decay=True))
+    rng = np.random.default_rng(2)
+    x_fit = rng.normal(size=(2 * su.n_param, D))
+    den.fit(x_fit, logp(x_fit))
+    tr = NTrace(n_chain=96, n_iter=30, n_warmup=20, x_0=x_fit[:96] * 0.5, random_generator=9, target_accept=0.95)
+    tt = sample(den, tr, verbose=False)
+    _compare_chains_with_oracle(tt, den, 9, (0, 50, 95), 30, 20, target_accept=0.95)
+    acc = tt.stat('mean_tree_accept')[:, 20:].mean()
+    assert acc > 0.85, acc
+
+
+def test_fit_rank_deficient_design_warns_and_regularises():
+    """Duplicate columns: gelsd would return a min-norm solution; the device fit warns and solves ridge-regularised
+    normal equations (predictions on the fit points still match the data)."""
+    from bayesfast_amd import PolyModel
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(60, 3))
+    x[:, 2] = x[:, 1]  # x_2 == x_1: the columns x_1, x_2 (and their products) are collinear
+    y = 1. + x[:, 0] - 2. * x[:, 1] + 0.5 * x[:, 0] * x[:, 1]
+    pm = PolyModel('quadratic', input_size=3, output_size=1, bound_options=dict(use_bound=False))
+    with pytest.warns(RuntimeWarning):
+        pm.fit(x, y[:, None])
+    pred = np.array([pm.fun(xx)[0][0] for xx in x[:10]])
+    np.testing.assert_allclose(pred, y[:10], rtol=1e-5, atol=1e-5)
