@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbfhip.so')
+# BFHIP_LIBRARY overrides the in-tree library (tuning builds of tools/variant.sh)
+LIB_PATH = os.environ.get('BFHIP_LIBRARY') or os.path.join(_HERE, 'libbfhip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 SC_FIELDS = ('log_step', 'log_bar', 'hbar', 'mu', 'count', 'fg_n', 'bg_n', 'n_samples', 'prev_update',

@@ -23,7 +23,6 @@
 // an evaluation / one merge level / end of a doubling / three pieces of the iteration end), one unit per
 // chain per trip, so the workgroup barrier never waits for a long bookkeeping path of one chain.  Random draws are consumed in the recursion's
 // post-order, so a chain reproduces the CPU oracle's trajectory for the same xoshiro stream.
-#include <type_traits>
 #include "bfhip_eval.h"
 
 // The f64 libm expansions (exp, log, sincospi, sqrt) are long inline sequences whose constants get hoisted
@@ -42,7 +41,6 @@ __device__ __attribute__((noinline)) static void bf_sincospi_ni(double x, double
 struct SamplerArgs {
     bfhip_sampler_config cfg;
     int n_chain, iter_end, iter_out0, n_out, nslot;
-    int ks, gbn;  // K-split of the matvec jobs (so that all 16 waves get one) and the number of result slots
     uint64_t *rng;
     double *sc, *vec, *samples, *stats;
     unsigned long long *n_leapfrog;
@@ -69,66 +67,14 @@ __device__ inline double dpp_f64(double v) {
 __device__ inline double readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-// gfx950 row swaps: every lane ends with (its row) + (the neighbouring row), then (its half) + (the other half)
-__device__ inline double swap16_add_f64(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-__device__ inline double swap32_add_f64(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-}
-// Sums over the 64 lanes of N independent values, wave-uniform results in a fixed order: DPP butterflies
-// inside each row of 16 lanes, then two row swaps (no LDS crossbar).  The N reductions advance step by
-// step together so that the latency of each f64 add is covered by the other values' instructions.
-#ifndef BF_WSUM_MODE
-#define BF_WSUM_MODE 2
-#endif
-template <int N>
-__device__ inline void wave_sum_n(double (&v)[N]) {
-#if BF_WSUM_MODE == 0
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double t = v[i];
-        t += dpp_f64<0xB1>(t);
-        t += dpp_f64<0x4E>(t);
-        t += dpp_f64<0x141>(t);
-        t += dpp_f64<0x140>(t);
-        v[i] = ((readlane_f64(t, 0) + readlane_f64(t, 16)) + readlane_f64(t, 32)) + readlane_f64(t, 48);
-    }
-#else
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x4E>(v[i]);   // quad_perm [2,3,0,1]
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x141>(v[i]);  // row_half_mirror
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x140>(v[i]);  // row_mirror
-#if BF_WSUM_MODE == 1
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        v[i] = ((readlane_f64(v[i], 0) + readlane_f64(v[i], 16)) + readlane_f64(v[i], 32)) + readlane_f64(v[i], 48);
-#else
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = swap16_add_f64(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = swap32_add_f64(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        v[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v[i])),
-                                __builtin_amdgcn_readfirstlane(__double2loint(v[i])));
-#endif
-#endif
-}
+// sum over the 64 lanes, wave-uniform result: DPP butterflies inside each row of 16 lanes (no LDS
+// crossbar), then the four row totals are read to scalar registers and added in a fixed order
 __device__ inline double wave_sum(double v) {
-    double t[1] = {v};
-    wave_sum_n<1>(t);
-    return t[0];
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror
+    return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 
 template <int W>
@@ -141,28 +87,19 @@ struct SamplerGeo {
     static constexpr bool STAGE = DP <= 64;           // coefficient fragments fit in LDS
 };
 
-// PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
-// extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
-// and the state of the optional features disappear from the instantiation.
-template <int W, bool NUTS, bool STAMPS, bool PLAIN>
+template <int W, bool NUTS, bool STAMPS>
 __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
-    const bool f_quad = PLAIN ? true : (bool)m.has_quad, f_bound = PLAIN ? true : (bool)m.use_bound;
-    const bool f_decay = PLAIN ? false : (bool)m.use_decay, f_tr = PLAIN ? false : (bool)m.has_transform;
-    const bool f_su = PLAIN ? false : (bool)m.has_su, f_cubic = PLAIN ? false : (bool)m.has_cubic;
-    const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
     using G = SamplerGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
     constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XB = lds;                         // [3][NS][XS]   B operands
-    double *LS = XB + 3 * NS * XS;            // [16][MAXL][LS_N] per-chain stack scalars
+    double *GB = XB + 3 * NS * XS;            // [3][16][GS]   matvec results
+    double *LS = GB + 3 * 16 * GS;            // [16][MAXL][LS_N] per-chain stack scalars
     int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] (+ pad)
     double *CS = LS + 16 * MAXL * LS_N + 2;   // [16][CS_N]    cold per-chain scalars (kept out of the VGPR budget)
     double *PDL = CS + 16 * CS_N;             // [PD_N][DP]    per-dimension table (rarely used rows are read from here)
     double *FR = PDL + PD_N * DP;             // staged A fragments: S | H | H_decay
-    // the matvec results [gbn][16][GS] (slot = enabled matrix x K part) come last: every region above keeps a
-    // compile-time LDS offset
-    double *GB = FR + (G::STAGE ? MAT * ((f_quad ? 1 : 0) + (f_bound ? 1 : 0) + (f_decay ? 1 : 0)) : 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
@@ -173,12 +110,12 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     // ---- stage the coefficient matrices (A-operand fragments) in LDS ----
     const double *Sf = m.Sf, *Hf = m.Hf, *Hdf = m.Hdf;
     if constexpr (G::STAGE) {
-        double *pS = FR, *pH = pS + (f_quad ? MAT : 0), *pD = pH + (f_bound ? MAT : 0);
-        if (f_quad)
+        double *pS = FR, *pH = pS + (m.has_quad ? MAT : 0), *pD = pH + (m.use_bound ? MAT : 0);
+        if (m.has_quad)
             for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pS)[i] = ((const d2_t *)m.Sf)[i];
-        if (f_bound)
+        if (m.use_bound)
             for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pH)[i] = ((const d2_t *)m.Hf)[i];
-        if (f_decay)
+        if (m.use_decay)
             for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pD)[i] = ((const d2_t *)m.Hdf)[i];
         Sf = pS; Hf = pH; Hdf = pD;
     }
@@ -351,7 +288,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                                 d0 += ps0 * (var[e] * L0p[e]);  // nuts.py:150-151
                                 d1 += ps0 * (var[e] * p[e]);
                             }
-                            { double r2[2] = {d0, d1}; wave_sum_n<2>(r2); d0 = r2[0]; d1 = r2[1]; }
+                            d0 = wave_sum(d0);
+                            d1 = wave_sum(d1);
                             T_acc = lsw[LS_ACC] + T_acc;  // :173
                             const double Wsum = lsw[LS_LS] + T_W;
                             if (Wsum != Wsum) err = 2;
@@ -415,13 +353,13 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 d4 += ps2 * vB;
                 d5 += ps2 * vD;
             }
-            {   // this unit only runs for lev >= 1 (level-0 merges are inline in the leaf), so all six checks apply
-                double r6[6] = {d0, d1, d2, d3, d4, d5};
-                wave_sum_n<6>(r6);
-                d0 = r6[0]; d1 = r6[1]; d2 = r6[2]; d3 = r6[3]; d4 = r6[4]; d5 = r6[5];
-            }
+            d0 = wave_sum(d0);
+            d1 = wave_sum(d1);
             bool turning = (d0 <= 0.) || (d1 <= 0.);
-            if (lev >= 1) turning = turning || (d2 <= 0.) || (d3 <= 0.) || (d4 <= 0.) || (d5 <= 0.);
+            if (lev >= 1) {
+                d2 = wave_sum(d2); d3 = wave_sum(d3); d4 = wave_sum(d4); d5 = wave_sum(d5);
+                turning = turning || (d2 <= 0.) || (d3 <= 0.) || (d4 <= 0.) || (d5 <= 0.);
+            }
             const double *lsp = lsw + lev * LS_N;
             T_acc = lsp[LS_ACC] + T_acc;  // :173
             // nuts.py:163-167 run even when THIS merge's check says turning: the draw is consumed.
@@ -491,11 +429,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     d5 += ps2 * vR;                       // rightmost_end = old right
                 }
             }
-            {
-                double r6[6] = {d0, d1, d2, d3, d4, d5};
-                wave_sum_n<6>(r6);
-                d0 = r6[0]; d1 = r6[1]; d2 = r6[2]; d3 = r6[3]; d4 = r6[4]; d5 = r6[5];
-            }
+            d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+            d3 = wave_sum(d3); d4 = wave_sum(d4); d5 = wave_sum(d5);
             stv(SL_PSUM, ps);
             const int eo = (dir > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
             stv(eo + 0, q); stv(eo + 1, p); stv(eo + 2, g);
@@ -675,20 +610,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         if (err != 0) { mode = M_DONE; unit = U_DONE; }
     };
 
-    // enabled coefficient matrices in slot order: mat0 = id of the first, mat1 = id of the second (the third is 2)
-    const int n_mat = (f_quad ? 1 : 0) + (f_bound ? 1 : 0) + (f_decay ? 1 : 0);
-    const int mat0 = f_quad ? 0 : (f_bound ? 1 : 2);
-    const int mat1 = f_quad ? (f_bound ? 1 : 2) : 2;
-
-    // result of enabled matrix slot_m for this chain: the K parts are added in a fixed order
-    const int slot_S = 0, slot_H = f_quad ? 1 : 0, slot_D = slot_H + (f_bound ? 1 : 0);
-    auto gb_read = [&](int slot_m, int dim) -> double {
-        const double *gp = GB + ((slot_m * ks_rt) * 16 + w) * GS + dim;
-        double r = gp[0];
-        if (ks_rt > 1) r += gp[16 * GS];
-        if (ks_rt > 2) { r += gp[2 * 16 * GS]; r += gp[3 * 16 * GS]; }
-        return r;
-    };
+    int mat_id[3] = {0, 0, 0};
+    int n_mat = 0;
+    if (m.has_quad) mat_id[n_mat++] = 0;
+    if (m.use_bound) mat_id[n_mat++] = 1;
+    if (m.use_decay) mat_id[n_mat++] = 2;
 
     // phase stamps exist only in the diagnostic instantiation (they cost 18 always-live VGPRs)
     unsigned long long st_acc[STAMPS ? 10 : 1] = {0}, st_cnt[STAMPS ? 10 : 1] = {0}, st_prev = STAMPS ? clock64() : 0;
@@ -722,22 +648,22 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 xo[e] = q[e];
                 jac[e] = 1.;
                 gj[e] = 0.;
-                if (f_tr) {
+                if (m.has_transform) {
                     double J, J2;
                     bf_to_original(q[e], (int)pdl(PD_KIND, e), pdl(PD_LO, e), pdl(PD_RG, e), xo[e], J, J2);
                     logdet += log(fabs(J));
                     jac[e] = J;
                     gj[e] = J2 / J;
                 }
-                xs[e] = f_su ? (xo[e] - pdl(PD_SU_LO, e)) / pdl(PD_SU_DIFF, e) : xo[e];
+                xs[e] = m.has_su ? (xo[e] - pdl(PD_SU_LO, e)) / pdl(PD_SU_DIFF, e) : xo[e];
                 double x_eval = xs[e];
                 if (mode == M_OOB)  // modules/poly.py:482
                     x_eval = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
                 if (dim < DP) {
                     const int xi = (dim >> 2) * XS + w + 16 * (dim & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
                     XB[0 * NS * XS + xi] = x_eval;
-                    if (f_bound) XB[1 * NS * XS + xi] = xs[e] - c_mu[e];
-                    if (f_decay) XB[2 * NS * XS + xi] = xo[e] - pdl(PD_DMU, e);
+                    if (m.use_bound) XB[1 * NS * XS + xi] = xs[e] - c_mu[e];
+                    if (m.use_decay) XB[2 * NS * XS + xi] = xo[e] - pdl(PD_DMU, e);
                 }
             }
         }
@@ -749,42 +675,23 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         if (tid == 0) alive[(trip + 1) & 1] = 0;
 
         // ================= phase B: gradient tiles on MFMA =================
-        // job = (enabled matrix, row tile t, K part): NS / KS k-steps of one 16-row tile for the 16 chains.
-        // KS is chosen on the host so that each of the 16 waves gets a job whenever n_mat * W <= 8; the KS
-        // partial results land in separate GB slots and are added by the chain's own wave in phase C.
-        // All operands of a job (at most 8 k-steps at a time) are fetched from LDS before the first MFMA so
-        // that the LDS latency is paid once per job, not once per k-step.
-        auto run_jobs = [&](auto ks_tag) {
-            constexpr int KS = decltype(ks_tag)::value;
-            constexpr int KPJ = NS / KS;                        // k-steps per job
-#ifndef BF_JOB_CH
-#define BF_JOB_CH 8
-#endif
-            constexpr int CH = KPJ < BF_JOB_CH ? KPJ : BF_JOB_CH;  // k-steps fetched together
+        // job j = (matrix j / W, row tile j % W); jobs are dealt over the 16 waves so that the S and H tiles of
+        // one row range run on different waves (the MFMA pipe of each SIMD sees the same total work)
+        {
             const int mc = lane & 15, mg = lane >> 4;
-            const int n_job = n_mat * (W * KS);
+            const int n_job = n_mat * W;
             for (int job = w; job < n_job; job += 16) {
-                const int slot_m = job / (W * KS), rem = job % (W * KS);
-                const int t = rem / KS, kp = rem % KS;
-                const int b = slot_m == 0 ? mat0 : (slot_m == 1 ? mat1 : 2);  // 0 S, 1 H, 2 H_decay
-                const double *Af = (b == 0 ? Sf : (b == 1 ? Hf : Hdf)) + (t * NS + kp * KPJ) * 64 + lane;
-                const double *Xf = XB + (b * NS + kp * KPJ) * XS + lane;
+                const int slot_m = job / W, t = job % W;       // slot_m-th enabled matrix
+                const int b = mat_id[slot_m];                   // 0 S, 1 H, 2 H_decay
+                const double *Af = b == 0 ? Sf : (b == 1 ? Hf : Hdf);
                 d4_t acc = {0., 0., 0., 0.};
 #pragma unroll
-                for (int c0 = 0; c0 < KPJ; c0 += CH) {
-                    double av[CH], xv[CH];
+                for (int s = 0; s < NS; ++s)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Af[(t * NS + s) * 64 + lane], XB[(b * NS + s) * XS + lane], acc, 0, 0, 0);
 #pragma unroll
-                    for (int s = 0; s < CH; ++s) { av[s] = Af[(c0 + s) * 64]; xv[s] = Xf[(c0 + s) * XS]; }
-#pragma unroll
-                    for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], xv[s], acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
+                for (int r4 = 0; r4 < 4; ++r4) GB[(b * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
             }
-        };
-        if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>());
-        else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>());
-        else run_jobs(std::integral_constant<int, 1>());
+        }
         const int unit_in = unit;
         stamp(2);
         __syncthreads();  // B2
@@ -797,21 +704,21 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         double kin_fast = 0.;
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
-            const bool fast_kin = !f_decay && mode != M_OOB;
+            const bool fast_kin = !m.use_decay && mode != M_OOB;
             double xev[E], r_cub = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int dim = lane * E + e;
-                const double sx = (f_quad && lane_ok) ? gb_read(slot_S, dim) : 0.;
-                hv[e] = (f_bound && lane_ok) ? gb_read(slot_H, dim) : 0.;
-                dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
+                const double sx = (m.has_quad && lane_ok) ? GB[(0 * 16 + w) * GS + dim] : 0.;
+                hv[e] = (m.use_bound && lane_ok) ? GB[(1 * 16 + w) * GS + dim] : 0.;
+                dgr[e] = (m.use_decay && lane_ok) ? GB[(2 * 16 + w) * GS + dim] : 0.;
                 xev[e] = xs[e];
                 if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
                 r_quad += xev[e] * sx;
                 r_lin += c_lin[e] * xev[e];
                 gn[e] = sx + c_lin[e];
             }
-            if (f_cubic) {  // cubic configs: x_k of this chain is lane k / E, element k % E
+            if (m.has_cubic) {  // cubic configs: x_k of this chain is lane k / E, element k % E
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     double gc, fc;
@@ -827,29 +734,28 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 const double xm = xs[e] - c_mu[e];
                 r_b2 += xm * hv[e];
                 r_dotj += gn[e] * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
-                if (f_decay) r_bd2 += (xo[e] - pdl(PD_DMU, e)) * dgr[e];
+                if (m.use_decay) r_bd2 += (xo[e] - pdl(PD_DMU, e)) * dgr[e];
                 if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
                     double ge = gn[e];
-                    if (f_su) ge = ge / pdl(PD_SU_DIFF, e);
+                    if (m.has_su) ge = ge / pdl(PD_SU_DIFF, e);
                     ge = ge * jac[e];
-                    if (f_tr) ge += gj[e];
+                    if (m.has_transform) ge += gj[e];
                     const double pe = p[e] + (0.5 * eps_t) * ge;
                     r_kin += pe * (var[e] * pe);
                 }
             }
-            {   // the four reductions every evaluation needs, advanced together
-                double r4[4] = {r_kin, r_quad, r_lin, r_b2};
-                wave_sum_n<4>(r4);
-                r_kin = r4[0]; r_quad = r4[1]; r_lin = r4[2]; r_b2 = r4[3];
-            }
-            if (f_bound && mode == M_OOB) r_dotj = wave_sum(r_dotj);
-            if (f_decay) r_bd2 = wave_sum(r_bd2);
-            if (f_tr) logdet = wave_sum(logdet);
+            if (fast_kin) r_kin = wave_sum(r_kin);
+            r_quad = wave_sum(r_quad);
+            r_lin = wave_sum(r_lin);
+            if (m.use_bound) r_b2 = wave_sum(r_b2);
+            if (m.use_bound && mode == M_OOB) r_dotj = wave_sum(r_dotj);
+            if (m.use_decay) r_bd2 = wave_sum(r_bd2);
+            if (m.has_transform) logdet = wave_sum(logdet);
 
             double f = ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
             const double beta = sqrt(r_b2);
             bool oob_now = false;
-            if (f_bound) {
+            if (m.use_bound) {
                 if (mode == M_OOB) {  // second pass: f, gn currently hold f_0 and jj_0 (poly.py:484-496)
                     const double f0 = f, beta_saved = csw[CS_BETA];
                     f = (beta_saved * f0 - (beta_saved - m.alpha) * m.f_mu) / m.alpha;
@@ -872,17 +778,17 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 // chain rule (module.py:226, density.py:558), decay (:740-746), transform (:747-750)
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    if (f_su) gn[e] = gn[e] / pdl(PD_SU_DIFF, e);
+                    if (m.has_su) gn[e] = gn[e] / pdl(PD_SU_DIFF, e);
                     gn[e] = gn[e] * jac[e];
                 }
-                if (f_decay) {
+                if (m.use_decay) {
                     f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
                     if (r_bd2 > m.decay_alpha2) {
 #pragma unroll
                         for (int e = 0; e < E; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
                     }
                 }
-                if (f_tr) {
+                if (m.has_transform) {
                     f += logdet;
 #pragma unroll
                     for (int e = 0; e < E; ++e) gn[e] += gj[e];
@@ -937,30 +843,16 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     }
 }
 
-// K-split of the matvec jobs: the largest power of two KS <= W with n_mat * W * KS <= 16
-static int sampler_ksplit(const DevModel &m) {
-    const int W = m.DP / 16;
-    const int n_mat = (m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0);
-    int ks = 1;
-    while (2 * ks <= W && n_mat * W * 2 * ks <= 16) ks *= 2;
-    return ks;
-}
-static int sampler_gb_slots(const DevModel &m) {
-    const int n_mat = (m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0);
-    return n_mat * sampler_ksplit(m) > 1 ? n_mat * sampler_ksplit(m) : 1;
-}
-
 static size_t sampler_lds_bytes(const DevModel &m) {
     const int W = m.DP / 16, DP = m.DP, NS = 4 * W;
-    size_t dbl = (size_t)3 * NS * 65 + (size_t)sampler_gb_slots(m) * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 +
-                 (size_t)16 * CS_N + (size_t)PD_N * DP;
+    size_t dbl = (size_t)3 * NS * 65 + (size_t)3 * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 + (size_t)16 * CS_N + (size_t)PD_N * DP;
     if (DP <= 64) dbl += (size_t)DP * DP * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
     return dbl * sizeof(double);
 }
 
-template <int W, bool NUTS, bool STAMPS, bool PLAIN>
+template <int W, bool NUTS, bool STAMPS>
 static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
-    auto k = bf_sampler_kernel<W, NUTS, STAMPS, PLAIN>;
+    auto k = bf_sampler_kernel<W, NUTS, STAMPS>;
     const size_t lds = sampler_lds_bytes(ctx->model);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -974,17 +866,10 @@ static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 
-static bool g_no_plain = false;  // tuning hook: force the generic instantiation
-extern "C" void bfhip_debug_no_plain(int v) { g_no_plain = v != 0; }
-
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
-    const DevModel &m = ctx->model;
-    const bool plain = m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !g_no_plain;
-    if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
-        return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS)>(ctx, args)
-                     : launch_sampler_t<W, NUTS, (W == 4 && NUTS), false>(ctx, args);
-    return plain ? launch_sampler_t<W, NUTS, false, true>(ctx, args) : launch_sampler_t<W, NUTS, false, false>(ctx, args);
+    if (W == 4 && NUTS && args.stamps) return launch_sampler_t<W, NUTS, (W == 4 && NUTS)>(ctx, args);  // diagnostic build, d <= 64 NUTS only
+    return launch_sampler_t<W, NUTS, false>(ctx, args);
 }
 
 extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_chain, int iter_end,
@@ -1010,8 +895,6 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.iter_out0 = iter_out0;
     args.n_out = n_out;
     args.nslot = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH;
-    args.ks = sampler_ksplit(m);
-    args.gbn = sampler_gb_slots(m);
     args.rng = rng;
     args.sc = sc;
     args.vec = vec;
@@ -1031,12 +914,10 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.scratch = (double *)ctx->scratch;
     const bool nuts = cfg->sampler == 0;
     switch (W) {
-#ifndef BF_ONLY_HEADLINE  // tuning builds (tools/variant.sh) compile the 64-d instantiations only
     case 1: return nuts ? launch_sampler<1, true>(ctx, args) : launch_sampler<1, false>(ctx, args);
     case 2: return nuts ? launch_sampler<2, true>(ctx, args) : launch_sampler<2, false>(ctx, args);
-    case 8: return nuts ? launch_sampler<8, true>(ctx, args) : launch_sampler<8, false>(ctx, args);
-#endif
     case 4: return nuts ? launch_sampler<4, true>(ctx, args) : launch_sampler<4, false>(ctx, args);
+    case 8: return nuts ? launch_sampler<8, true>(ctx, args) : launch_sampler<8, false>(ctx, args);
     }
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", m.DP);
 }

@@ -4,7 +4,7 @@ Only NumPy: these build the density *spec* (plain dict) that both the device pat
 """
 import numpy as np
 
-__all__ = ['correlated_gaussian_spec', 'B_STEP_BYTES', 'flops_per_leapfrog']
+__all__ = ['correlated_gaussian_spec', 'banana_logp', 'sobol_normal', 'B_STEP_BYTES', 'flops_per_leapfrog']
 
 
 def B_STEP_BYTES(d):
@@ -50,3 +50,26 @@ def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7):
                          dict(order='quadratic', input_mask=np.arange(d), output_mask=np.array([0]), coef=quad[None])])
     spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=poly, use_decay=False)
     return spec, np.linalg.inv(P)
+
+
+def banana_logp(d=64, q=0.01, seed=0):
+    """Config 3 (headline) target of SURVEY.md section 8(d): the banana of examples/banana-gbs.ipynb cell 3 at
+    D = d, Q = q, rotated by ``special_ortho_group.rvs(d)`` drawn after ``np.random.seed(seed)``.
+    Returns a vectorised ``logp(x (..., d)) -> (...)`` evaluated on the host (the "true model")."""
+    from scipy.stats import special_ortho_group
+    A = special_ortho_group.rvs(d, random_state=np.random.RandomState(seed))
+
+    def logp(x):
+        z = np.asarray(x, dtype=np.float64) @ A.T
+        return -np.sum((z[..., ::2]**2 - z[..., 1::2])**2 / q + (z[..., ::2] - 1)**2, axis=-1)
+
+    return logp
+
+
+def sobol_normal(n, d, seed=0):
+    """n rows of a scrambled Sobol sequence mapped to N(0, I_d) (the reference's fit points and chain starts,
+    core/sample.py:111-112, come from its own Sobol generator; any low-discrepancy normal set serves)."""
+    from scipy.stats import qmc, norm
+    m = int(np.ceil(np.log2(max(n, 2))))
+    u = qmc.Sobol(d, scramble=True, seed=seed).random_base2(m)[:n]
+    return norm.ppf(np.clip(u, 1e-12, 1 - 1e-12))
