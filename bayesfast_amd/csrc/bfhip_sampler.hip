@@ -38,10 +38,15 @@ __device__ __attribute__((noinline)) static void bf_sincospi_ni(double x, double
 #define log(x) bf_log_ni(x)
 #define sqrt(x) bf_sqrt_ni(x)
 #define sincospi(x, s, c) bf_sincospi_ni(x, s, c)
+// wave-uniform argument -> wave-uniform result (see rfl below)
+#define uexp(x) rfl(bf_exp_ni(x))
+#define ulog(x) rfl(bf_log_ni(x))
+#define usqrt(x) rfl(bf_sqrt_ni(x))
 
 struct SamplerArgs {
     bfhip_sampler_config cfg;
     int n_chain, iter_end, iter_out0, n_out, nslot;
+    int tail_max;  // plain kernel: at most this many evaluating chains of a group take the VALU matvec (0: never)
     int ks, gbn;  // K-split of the matvec jobs (so that all 16 waves get one) and the number of result slots
     uint64_t *rng;
     double *sc, *vec, *samples, *stats;
@@ -68,6 +73,26 @@ __device__ inline double dpp_f64(double v) {
 }
 __device__ inline double readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// Wave-uniform values that arrive through a vector load (LDS, global memory) or an out-of-line call look
+// divergent to the compiler, which then keeps the whole chain state machine in VGPRs and lowers its branches to
+// exec-mask manipulation.  rfl() states the uniformity: the value moves to scalar registers and everything
+// derived from it (unit, mode, depth, the branch conditions) stays scalar.
+#ifdef BF_NO_RFL  // tuning experiment: leave the uniformity undeclared
+__device__ inline int rfl(int v) { return v; }
+__device__ inline double rfl(double v) { return v; }
+__device__ inline uint64_t rfl(uint64_t v) { return v; }
+__device__ inline uint64_t rfl_unused(uint64_t v) {
+#else
+__device__ inline int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline double rfl(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ inline uint64_t rfl(uint64_t v) {
+#endif
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
 // gfx950 row swaps: every lane ends with (its row) + (the neighbouring row), then (its half) + (the other half)
 __device__ inline double swap16_add_f64(double v) {
@@ -101,6 +126,11 @@ __device__ inline void wave_sum_n(double (&v)[N]) {
         v[i] = ((readlane_f64(t, 0) + readlane_f64(t, 16)) + readlane_f64(t, 32)) + readlane_f64(t, 48);
     }
 #else
+#ifdef BF_X_NOSUM  // timing experiment only (wrong sums): what do the reductions cost on the critical path?
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = rfl(v[i]) * 64.;
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] += dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
 #pragma unroll
@@ -150,19 +180,39 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     const bool f_decay = PLAIN ? false : (bool)m.use_decay, f_tr = PLAIN ? false : (bool)m.has_transform;
     const bool f_su = PLAIN ? false : (bool)m.has_su, f_cubic = PLAIN ? false : (bool)m.has_cubic;
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
+    // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
+    // (matrix, row tile, K part) on every trip and keeps its A operands in registers for the whole launch:
+    // the coefficient matrices are not staged in LDS at all.
+#ifdef BF_NO_AREG
+    constexpr bool AREG = false;
+#else
+    constexpr bool AREG = PLAIN && W <= 4;
+#endif
+#ifdef BF_NO_TAIL
+    constexpr bool TAIL = false;
+#else
+    constexpr bool TAIL = AREG;
+#endif
+    constexpr int KS_P = (W == 2 || W == 4) ? 2 : 1, KPJ_P = (4 * W) / KS_P, NJOB_P = 2 * W * KS_P;
     using G = SamplerGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
     constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XB = lds;                         // [3][NS][XS]   B operands
     double *LS = XB + 3 * NS * XS;            // [16][MAXL][LS_N] per-chain stack scalars
-    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] (+ pad)
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity)
     double *CS = LS + 16 * MAXL * LS_N + 2;   // [16][CS_N]    cold per-chain scalars (kept out of the VGPR budget)
     double *PDL = CS + 16 * CS_N;             // [PD_N][DP]    per-dimension table (rarely used rows are read from here)
     double *FR = PDL + PD_N * DP;             // staged A fragments: S | H | H_decay
     // the matvec results [gbn][16][GS] (slot = enabled matrix x K part) come last: every region above keeps a
     // compile-time LDS offset
-    double *GB = FR + (G::STAGE ? MAT * ((f_quad ? 1 : 0) + (f_bound ? 1 : 0) + (f_decay ? 1 : 0)) : 0);
+    // plain kernel: row-major padded copies of S and H (RM) and the chains' x in plain layout (XP) feed the VALU
+    // matvec that replaces the MFMA jobs while only a few chains of the group are still evaluating
+    constexpr int RS = DP + 2;                // RM row stride (16-byte aligned rows, conflict-free b128 reads)
+    double *RM = FR;                          // [2][DP][RS]
+    double *XP = RM + 2 * DP * RS;            // [2][16][DP]
+    double *GB = AREG ? XP + 2 * 16 * DP
+                      : FR + (G::STAGE ? MAT * ((f_quad ? 1 : 0) + (f_bound ? 1 : 0) + (f_decay ? 1 : 0)) : 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
@@ -172,7 +222,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 
     // ---- stage the coefficient matrices (A-operand fragments) in LDS ----
     const double *Sf = m.Sf, *Hf = m.Hf, *Hdf = m.Hdf;
-    if constexpr (G::STAGE) {
+    if constexpr (G::STAGE && !AREG) {
         double *pS = FR, *pH = pS + (f_quad ? MAT : 0), *pD = pH + (f_bound ? MAT : 0);
         if (f_quad)
             for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pS)[i] = ((const d2_t *)m.Sf)[i];
@@ -182,7 +232,23 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pD)[i] = ((const d2_t *)m.Hdf)[i];
         Sf = pS; Hf = pH; Hdf = pD;
     }
-    if (tid < 2) alive[tid] = 0;
+    double afr[AREG ? KPJ_P : 1];
+    if constexpr (AREG) {
+        const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
+        const double *Af = (slot_m == 0 ? m.Sf : m.Hf) + (t * NS + kp * KPJ_P) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KPJ_P; ++s) afr[s] = (w < NJOB_P) ? Af[s * 64] : 0.;
+    }
+    if constexpr (TAIL) {
+        // frag[(t * NS + s) * 64 + l] = M[16 t + (l & 15)][4 s + (l >> 4)]  ->  RM[b][row][col]
+        for (int i = tid; i < MAT; i += 1024) {
+            const int l = i & 63, s = (i >> 6) % NS, t = (i >> 6) / NS;
+            const int row = 16 * t + (l & 15), col = 4 * s + (l >> 4);
+            RM[(0 * DP + row) * RS + col] = m.Sf[i];
+            RM[(1 * DP + row) * RS + col] = m.Hf[i];
+        }
+    }
+    if (tid < 4) alive[tid] = 0;
     for (int i = tid; i < PD_N * DP; i += 1024) PDL[i] = m.pd[i];
 
     // ---- per-lane constants: the per-dimension table rows of this lane's dimensions ----
@@ -213,6 +279,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     int unit = U_DONE, lev = 0, h_accepted = 0;
     double *csw = CS + w * CS_N;
     auto cs_set = [&](int i, double v) { if (lane == 0) csw[i] = v; };
+    auto cs_get = [&](int i) -> double { return rfl(csw[i]); };
     unsigned long long nlf = 0;
     const bool lane_ok = lane * E < DP;  // lanes beyond the padded dimension idle (DP < 64)
     double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + lane * E;
@@ -268,14 +335,14 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #pragma unroll
     for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; PF0[e] = 0.; PF1[e] = 0.; PF2[e] = 0.; PF3[e] = 0.; L0p[e] = 0.; L0q[e] = 0.; }
     if (real) {
-        for (int k = 0; k < 4; ++k) rs[k] = a.rng[(size_t)chain * 4 + k];
-        cs_set(CS_LOG_STEP, scp[BFHIP_SC_LOG_STEP]);
-        cs_set(CS_LOG_BAR, scp[BFHIP_SC_LOG_BAR]);
-        cs_set(CS_HBAR, scp[BFHIP_SC_HBAR]);
-        cs_set(CS_SMU, scp[BFHIP_SC_MU]);
-        cs_set(CS_COUNT, scp[BFHIP_SC_COUNT]);
-        i_iter = (int)scp[BFHIP_SC_I_ITER];
-        err = (int)scp[BFHIP_SC_ERROR];
+        for (int k = 0; k < 4; ++k) rs[k] = rfl((uint64_t)a.rng[(size_t)chain * 4 + k]);
+        cs_set(CS_LOG_STEP, rfl(scp[BFHIP_SC_LOG_STEP]));
+        cs_set(CS_LOG_BAR, rfl(scp[BFHIP_SC_LOG_BAR]));
+        cs_set(CS_HBAR, rfl(scp[BFHIP_SC_HBAR]));
+        cs_set(CS_SMU, rfl(scp[BFHIP_SC_MU]));
+        cs_set(CS_COUNT, rfl(scp[BFHIP_SC_COUNT]));
+        i_iter = rfl((int)scp[BFHIP_SC_I_ITER]);
+        err = rfl((int)scp[BFHIP_SC_ERROR]);
         load_vec(BFHIP_VEC_Q, q, 0.);
         load_vec(BFHIP_VEC_VAR, var, 1.);
         if (i_iter < a.iter_end && err == 0) {
@@ -287,9 +354,17 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     __syncthreads();
 
     // ---- the per-chain state machine: ONE unit of work per call (wave-uniform control flow) ----
+#ifndef BF_FUSE
+#define BF_FUSE 0
+#endif
     auto run_unit = [&](bool have_ev, double E_new, double logp_new) {
         // ================= per-chain state machine: ONE unit of work per trip =================
-        // (wave-uniform control flow; the barrier-to-barrier critical path is the longest single unit)
+        // (wave-uniform control flow; the barrier-to-barrier critical path is the longest single unit.)
+        // BF_FUSE >= 1 (tuning) runs the merge levels / doubling end that follow a leaf in the leaf's own trip.
+        // Measured slower while the subtree stack lives in global memory: the stack loads of a fused merge
+        // are consumed at once, and their latency is longer than the trip they save (1.7e8 against 2.2e8
+        // leapfrog steps/s on the headline workload); with one unit per trip they are prefetched a trip ahead.
+        for (;;) {
         if (unit == U_EVAL) {
             if (have_ev && mode == M_INIT) {
                 // BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43
@@ -306,7 +381,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     cs_set(CS_W_OFF, 0.);
                     cs_set(CS_MAX_DE, 0.);
                     depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
-                    eps = exp(i_iter < nw ? csw[CS_LOG_STEP] : csw[CS_LOG_BAR]);  // step_size.py:25-29
+                    eps = uexp(i_iter < nw ? cs_get(CS_LOG_STEP) : cs_get(CS_LOG_BAR));  // step_size.py:25-29
                     dir = 1;
                     if (NUTS) dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
                     mode = M_LEAF;
@@ -318,25 +393,25 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     n_prop += 1;
                     double dE = E_new - start_energy;
                     if (dE != dE) dE = INFINITY;
-                    if (fabs(dE) > fabs(csw[CS_MAX_DE])) cs_set(CS_MAX_DE, dE);
+                    if (fabs(dE) > fabs(cs_get(CS_MAX_DE))) cs_set(CS_MAX_DE, dE);
                     cs_set(CS_T_E, E_new);
                     cs_set(CS_T_LOGP, logp_new);
                     T_acc = 0.; lev = 0;
                     if (fabs(dE) < a.cfg.max_change) {
                         // multinomial weight exp(log_size) = exp(-dE), kept in the linear domain relative to
                         // a running offset w_off (exact streaming log-sum-exp; rescales are rare)
-                        const double w_off = csw[CS_W_OFF];
+                        const double w_off = cs_get(CS_W_OFF);
                         double aw = -dE - w_off;
                         if (aw > 600.) {
-                            const double sc_ = exp(-aw);
-                            cs_set(CS_TREE_W, csw[CS_TREE_W] * sc_);
+                            const double sc_ = uexp(-aw);
+                            cs_set(CS_TREE_W, cs_get(CS_TREE_W) * sc_);
                             if (lane == 0)
                                 for (int l2 = 0; l2 < depth; ++l2) lsw[l2 * LS_N + LS_LS] *= sc_;
                             cs_set(CS_W_OFF, w_off + aw);
                             aw = 0.;
                         }
-                        T_W = exp(aw);
-                        const double pacc = (csw[CS_W_OFF] == 0.) ? T_W : exp(-dE);
+                        T_W = uexp(aw);
+                        const double pacc = (cs_get(CS_W_OFF) == 0.) ? T_W : uexp(-dE);
                         T_acc = pacc > 1. ? 1. : pacc;
 #pragma unroll
                         for (int e = 0; e < E; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
@@ -352,8 +427,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                                 d1 += ps0 * (var[e] * p[e]);
                             }
                             { double r2[2] = {d0, d1}; wave_sum_n<2>(r2); d0 = r2[0]; d1 = r2[1]; }
-                            T_acc = lsw[LS_ACC] + T_acc;  // :173
-                            const double Wsum = lsw[LS_LS] + T_W;
+                            T_acc = rfl(lsw[LS_ACC]) + T_acc;  // :173
+                            const double Wsum = rfl(lsw[LS_LS]) + T_W;
                             if (Wsum != Wsum) err = 2;
                             const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
                             if ((d0 <= 0.) || (d1 <= 0.)) {
@@ -363,8 +438,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                                 if (!((u * Wsum < T_W) || (u == 0.))) {
 #pragma unroll
                                     for (int e = 0; e < E; ++e) TPq[e] = L0q[e];
-                                    cs_set(CS_T_E, lsw[LS_E]);
-                                    cs_set(CS_T_LOGP, lsw[LS_LOGP]);
+                                    cs_set(CS_T_E, rfl(lsw[LS_E]));
+                                    cs_set(CS_T_LOGP, rfl(lsw[LS_LOGP]));
                                 }
                                 T_W = Wsum;
 #pragma unroll
@@ -383,7 +458,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                         const bool fin = fabs(E_new) <= 1.7976931348623157e308;
                         const double h_dE = fin ? (start_energy - E_new) : -INFINITY;
                         diverged = (!fin || fabs(h_dE) > a.cfg.max_change) ? 1 : 0;
-                        double h_accept_stat = exp(h_dE);
+                        double h_accept_stat = uexp(h_dE);
                         if (h_accept_stat > 1.) h_accept_stat = 1.;
                         h_accepted = 0;
                         if (!diverged) h_accepted = !(bf_u01(bf_xoshiro_next(rs)) >= h_accept_stat);
@@ -423,10 +498,10 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             bool turning = (d0 <= 0.) || (d1 <= 0.);
             if (lev >= 1) turning = turning || (d2 <= 0.) || (d3 <= 0.) || (d4 <= 0.) || (d5 <= 0.);
             const double *lsp = lsw + lev * LS_N;
-            T_acc = lsp[LS_ACC] + T_acc;  // :173
+            T_acc = rfl(lsp[LS_ACC]) + T_acc;  // :173
             // nuts.py:163-167 run even when THIS merge's check says turning: the draw is consumed.
             // logbern(ls2 - logaddexp(ls1, ls2))  <=>  U * (W1 + W2) < W2
-            const double Wsum = lsp[LS_LS] + T_W;
+            const double Wsum = rfl(lsp[LS_LS]) + T_W;
             if (Wsum != Wsum) err = 2;
             const double u = bf_u01(bf_xoshiro_next(rs));
             const bool keep_t2 = (u * Wsum < T_W) || (u == 0.);
@@ -437,8 +512,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 if (!keep_t2) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) TPq[e] = PF3[e];  // the sibling's proposal, prefetched
-                    cs_set(CS_T_E, lsp[LS_E]);
-                    cs_set(CS_T_LOGP, lsp[LS_LOGP]);
+                    cs_set(CS_T_E, rfl(lsp[LS_E]));
+                    cs_set(CS_T_LOGP, rfl(lsp[LS_LOGP]));
                 }
                 T_W = Wsum;
 #pragma unroll
@@ -454,13 +529,13 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             depth += 1;
             acc_sum += T_acc;
             {   // :81-83  logbern(ls_new - ls_old)  <=>  U * W_old < W_new
-                const double tree_W = csw[CS_TREE_W];
+                const double tree_W = cs_get(CS_TREE_W);
                 if (T_W != T_W || tree_W != tree_W) err = 2;
                 const double u = bf_u01(bf_xoshiro_next(rs));
                 if ((u * tree_W < T_W) || (u == 0.)) {
                     stv(SL_PROP_Q, TPq);
-                    cs_set(CS_PROP_E, csw[CS_T_E]);
-                    cs_set(CS_PROP_LOGP, csw[CS_T_LOGP]);
+                    cs_set(CS_PROP_E, cs_get(CS_T_E));
+                    cs_set(CS_PROP_LOGP, cs_get(CS_T_LOGP));
                 }
                 cs_set(CS_TREE_W, tree_W + T_W);  // :85
             }
@@ -515,21 +590,21 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         } else if (unit == U_END1) {
             // ================= iteration end, part 1: step size + stats (base_hmc.py:80-85) =================
             const bool warm = i_iter < nw;
-            const double accept_stat = NUTS ? acc_sum / (double)n_prop : csw[CS_HACC];  // nuts.py:186
-            double log_step = csw[CS_LOG_STEP], log_bar = csw[CS_LOG_BAR];
+            const double accept_stat = NUTS ? acc_sum / (double)n_prop : cs_get(CS_HACC);  // nuts.py:186
+            double log_step = cs_get(CS_LOG_STEP), log_bar = cs_get(CS_LOG_BAR);
             if (warm && a.cfg.adapt_step_size) {  // step_size.py:31-45
-                const double count = csw[CS_COUNT];
+                const double count = cs_get(CS_COUNT);
                 const double wgt = 1. / (count + a.cfg.t_0);
-                const double hbar = ((1. - wgt) * csw[CS_HBAR] + wgt * (a.cfg.target_accept - accept_stat));
-                log_step = csw[CS_SMU] - hbar * sqrt(count) / a.cfg.gamma;
-                const double mk = exp(-a.cfg.k * log(count));  // count ** -k
+                const double hbar = ((1. - wgt) * cs_get(CS_HBAR) + wgt * (a.cfg.target_accept - accept_stat));
+                log_step = cs_get(CS_SMU) - hbar * usqrt(count) / a.cfg.gamma;
+                const double mk = uexp(-a.cfg.k * ulog(count));  // count ** -k
                 log_bar = mk * log_step + (1. - mk) * log_bar;
                 cs_set(CS_HBAR, hbar);
                 cs_set(CS_LOG_STEP, log_step);
                 cs_set(CS_LOG_BAR, log_bar);
                 cs_set(CS_COUNT, count + 1.);
             }
-            const double prop_E = csw[CS_PROP_E], prop_logp = csw[CS_PROP_LOGP];
+            const double prop_E = cs_get(CS_PROP_E), prop_logp = cs_get(CS_PROP_LOGP);
             const int orow = i_iter - a.iter_out0;
             if (orow >= 0 && orow < a.n_out && lane == 0) {
                 double *st = a.stats + ((size_t)chain * a.n_out + orow) * BFHIP_STAT_STRIDE;
@@ -543,7 +618,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     st[BFHIP_NS_STEP_SIZE_BAR] = exp(log_bar);
                     st[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
                     st[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
-                    st[BFHIP_NS_MAX_ENERGY_CHANGE] = csw[CS_MAX_DE];
+                    st[BFHIP_NS_MAX_ENERGY_CHANGE] = cs_get(CS_MAX_DE);
                     st[BFHIP_NS_DIVERGING] = (double)diverged;
                 } else {
                     st[BFHIP_HS_LOGP] = prop_logp;
@@ -554,7 +629,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     st[BFHIP_HS_STEP_SIZE] = exp(log_step);
                     st[BFHIP_HS_STEP_SIZE_BAR] = exp(log_bar);
                     st[BFHIP_HS_WARMUP] = warm ? 1. : 0.;
-                    st[BFHIP_HS_ENERGY_CHANGE] = csw[CS_HDE];
+                    st[BFHIP_HS_ENERGY_CHANGE] = cs_get(CS_HDE);
                     st[BFHIP_HS_DIVERGING] = (double)diverged;
                     st[10] = 0.;
                 }
@@ -575,9 +650,9 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             }
             // QuadMetricDiagAdapt.update: metrics.py:186-211, _WeightedVariance.add_sample :354-360
             if (warm && a.cfg.adapt_metric) {
-                double fg_n = scp[BFHIP_SC_FG_N], bg_n = scp[BFHIP_SC_BG_N];
-                double n_samples = scp[BFHIP_SC_N_SAMPLES], prev_upd = scp[BFHIP_SC_PREV_UPDATE];
-                double adapt_window = scp[BFHIP_SC_ADAPT_WINDOW];
+                double fg_n = rfl(scp[BFHIP_SC_FG_N]), bg_n = rfl(scp[BFHIP_SC_BG_N]);
+                double n_samples = rfl(scp[BFHIP_SC_N_SAMPLES]), prev_upd = rfl(scp[BFHIP_SC_PREV_UPDATE]);
+                double adapt_window = rfl(scp[BFHIP_SC_ADAPT_WINDOW]);
                 const long delta = (long)(n_samples - prev_upd);
                 double fm[E], fr[E], bm[E], br[E];
                 load_vec(BFHIP_VEC_FG_MEAN, fm, 0.);
@@ -639,7 +714,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         if (unit == U_ABORT) {
             // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
             for (int al = (diverged ? 0 : lev); al < depth; ++al)
-                if ((i_leaf >> al) & 1) T_acc = lsw[al * LS_N + LS_ACC] + T_acc;
+                if ((i_leaf >> al) & 1) T_acc = rfl(lsw[al * LS_N + LS_ACC]) + T_acc;
             depth += 1;  // nuts.py:71-73
             acc_sum += T_acc;
             unit = U_END1;
@@ -661,7 +736,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 }
                 if (lane == 0) {
                     double *lsp = lsw + lev * LS_N;
-                    lsp[LS_LS] = T_W; lsp[LS_E] = csw[CS_T_E]; lsp[LS_LOGP] = csw[CS_T_LOGP]; lsp[LS_ACC] = T_acc;
+                    lsp[LS_LS] = T_W; lsp[LS_E] = cs_get(CS_T_E); lsp[LS_LOGP] = cs_get(CS_T_LOGP); lsp[LS_ACC] = T_acc;
                 }
                 i_leaf += 1;
                 unit = U_EVAL;
@@ -673,6 +748,9 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             }
         }
         if (err != 0) { mode = M_DONE; unit = U_DONE; }
+        if (!((BF_FUSE >= 1 && unit == U_MERGE_RUN) || (BF_FUSE >= 2 && unit == U_DBL_END))) break;
+        have_ev = false;
+        }
     };
 
     // enabled coefficient matrices in slot order: mat0 = id of the first, mat1 = id of the second (the third is 2)
@@ -701,7 +779,17 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
     };
 
+    // BF_TRACE=<n> (tuning builds only): wave 0 of workgroup 0 records s_memtime at 12 points of its first n
+    // trips in LDS and dumps them to the stamps buffer
+#ifdef BF_TRACE
+    __shared__ unsigned long long TRC[BF_TRACE * 16];
+#define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip < BF_TRACE && lane == 0) TRC[trip * 16 + (k)] = clock64(); } while (0)
+#else
+#define TRACE(k) do { } while (0)
+#endif
+
     for (int trip = 0;; ++trip) {
+        TRACE(0);
         // ================= phase A: first half of the leapfrog, B operands =================
         double xs[E], jac[E], gj[E], xo[E];
         double logdet = 0.;
@@ -732,21 +820,32 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 xs[e] = f_su ? (xo[e] - pdl(PD_SU_LO, e)) / pdl(PD_SU_DIFF, e) : xo[e];
                 double x_eval = xs[e];
                 if (mode == M_OOB)  // modules/poly.py:482
-                    x_eval = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
+                    x_eval = (m.alpha * xs[e] + (cs_get(CS_BETA) - m.alpha) * c_mu[e]) / cs_get(CS_BETA);
                 if (dim < DP) {
                     const int xi = (dim >> 2) * XS + w + 16 * (dim & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
                     XB[0 * NS * XS + xi] = x_eval;
                     if (f_bound) XB[1 * NS * XS + xi] = xs[e] - c_mu[e];
                     if (f_decay) XB[2 * NS * XS + xi] = xo[e] - pdl(PD_DMU, e);
+                    if constexpr (TAIL) {
+                        XP[(0 * 16 + w) * DP + dim] = x_eval;
+                        XP[(1 * 16 + w) * DP + dim] = xs[e] - c_mu[e];
+                    }
                 }
             }
         }
-        if (unit != U_DONE && lane == 0) alive[trip & 1] = 1;
+        TRACE(1);
+        if (lane == 0) {
+            if (unit != U_DONE) alive[trip & 1] = 1;
+            if (TAIL && evaluating) atomicOr((unsigned *)&alive[2 + (trip & 1)], 1u << w);
+        }
         stamp(0);
         __syncthreads();  // B1
+        TRACE(2);
         stamp(1);
-        if (alive[trip & 1] == 0) break;  // every chain of the group is done (uniform)
-        if (tid == 0) alive[(trip + 1) & 1] = 0;
+        if (rfl(alive[trip & 1]) == 0) break;  // every chain of the group is done (uniform)
+        const unsigned ev_mask = TAIL ? (unsigned)rfl(alive[2 + (trip & 1)]) : 0u;
+        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; }
+        TRACE(3);
 
         // ================= phase B: gradient tiles on MFMA =================
         // job = (enabled matrix, row tile t, K part): NS / KS k-steps of one 16-row tile for the 16 chains.
@@ -782,12 +881,64 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
             }
         };
-        if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>());
+        // Tail of a launch: while at most tail_max chains of the group still evaluate, the 16-column MFMA tiles
+        // are mostly padding and their fixed cost (32 MFMAs per SIMD) is the longest piece of the trip.  The same
+        // numbers come from plain FMAs: v_mfma_f64_16x16x4_f64 accumulates each entry as ONE sequential fma chain
+        // over k (checked bit for bit, tools/probe/mfma_arith_probe.hip), so lane = output row running that chain
+        // over the K part reproduces the MFMA result exactly; wave w takes (chain w / WPC, matrix, K part).
+        constexpr int WPC = 2 * KS_P, VMAX = 16 / WPC, KP = 4 * KPJ_P;
+        const int n_ev = __builtin_popcount(ev_mask);
+        if (TAIL && n_ev <= (a.tail_max < VMAX ? a.tail_max : VMAX)) {
+            const int ci = w / WPC, b = (w / KS_P) & 1, kp = w % KS_P;
+            if (ci < n_ev && lane < DP) {
+                unsigned mm = ev_mask;
+                for (int i = 0; i < ci; ++i) mm &= mm - 1;
+                const int c = __builtin_ctz(mm);
+                const double *Mr = RM + (b * DP + lane) * RS + kp * KP;
+                const double *xc = XP + (b * 16 + c) * DP + kp * KP;
+                double acc = 0.;
+#pragma unroll
+                for (int k = 0; k < KP; k += 2) {
+                    const d2_t mv = *(const d2_t *)(Mr + k), xv2 = *(const d2_t *)(xc + k);
+                    acc = __builtin_fma(mv[0], xv2[0], acc);
+                    acc = __builtin_fma(mv[1], xv2[1], acc);
+                }
+                GB[((b * KS_P + kp) * 16 + c) * GS + lane] = acc;
+            }
+            TRACE(4);
+            TRACE(5);
+        } else if constexpr (AREG) {
+            if (w < NJOB_P) {
+                const int mc = lane & 15, mg = lane >> 4;
+                const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
+                const double *Xf = XB + (slot_m * NS + kp * KPJ_P) * XS + lane;  // PLAIN: matrix id == slot
+                d4_t acc = {0., 0., 0., 0.};
+#ifndef BF_X_NOMFMA  // (timing experiment: skip the matvec, results are zeros)
+                double xv[KPJ_P];
+#pragma unroll
+                for (int s = 0; s < KPJ_P; ++s) xv[s] = Xf[s * XS];
+#ifdef BF_X_MFMA_N  // timing experiment: BF_X_MFMA_N MFMAs per job instead of KPJ_P
+#pragma unroll
+                for (int s = 0; s < BF_X_MFMA_N; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s % KPJ_P], xv[s % KPJ_P], acc, 0, 0, 0);
+#else
+#pragma unroll
+                for (int s = 0; s < KPJ_P; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], xv[s], acc, 0, 0, 0);
+#endif
+#else
+                acc[0] = afr[0] * 1e-300 + Xf[0] * 1e-300;
+#endif
+                TRACE(4);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
+            }
+            TRACE(5);
+        } else if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>());
         else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>());
         else run_jobs(std::integral_constant<int, 1>());
         const int unit_in = unit;
         stamp(2);
         __syncthreads();  // B2
+        TRACE(6);
         stamp(1);
 
         // ================= phase C: finish the evaluation =================
@@ -806,7 +957,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 hv[e] = (f_bound && lane_ok) ? gb_read(slot_H, dim) : 0.;
                 dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
                 xev[e] = xs[e];
-                if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (csw[CS_BETA] - m.alpha) * c_mu[e]) / csw[CS_BETA];
+                if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (cs_get(CS_BETA) - m.alpha) * c_mu[e]) / cs_get(CS_BETA);
                 r_quad += xev[e] * sx;
                 r_lin += c_lin[e] * xev[e];
                 gn[e] = sx + c_lin[e];
@@ -837,21 +988,28 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     r_kin += pe * (var[e] * pe);
                 }
             }
+            TRACE(7);
             {   // the four reductions every evaluation needs, advanced together
                 double r4[4] = {r_kin, r_quad, r_lin, r_b2};
                 wave_sum_n<4>(r4);
                 r_kin = r4[0]; r_quad = r4[1]; r_lin = r4[2]; r_b2 = r4[3];
             }
+            TRACE(8);
             if (f_bound && mode == M_OOB) r_dotj = wave_sum(r_dotj);
             if (f_decay) r_bd2 = wave_sum(r_bd2);
             if (f_tr) logdet = wave_sum(logdet);
 
             double f = ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
-            const double beta = sqrt(r_b2);
+            // beta = sqrt(r_b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
+            // decided on the squares whenever r_b2 is not within rounding distance of alpha^2, so the common
+            // in-bound evaluation has no sqrt on its critical path and the decision is still the reference's
+            double beta = 0.;
             bool oob_now = false;
             if (f_bound) {
+                const double a2 = m.alpha * m.alpha;
+                if (mode != M_OOB && !(r_b2 < a2 * (1. - 1e-12))) beta = usqrt(r_b2);
                 if (mode == M_OOB) {  // second pass: f, gn currently hold f_0 and jj_0 (poly.py:484-496)
-                    const double f0 = f, beta_saved = csw[CS_BETA];
+                    const double f0 = f, beta_saved = cs_get(CS_BETA);
                     f = (beta_saved * f0 - (beta_saved - m.alpha) * m.f_mu) / m.alpha;
                     const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta_saved;
 #pragma unroll
@@ -906,14 +1064,20 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
 
         stamp(3);
+        TRACE(9);
         const int mode_in = mode;
         // every chain runs ONE unit here, in parallel: chains that evaluated finish their leaf / init, the
         // others do their pending merge level / doubling end / iteration-end piece
         if (unit_in == U_EVAL) run_unit(have_eval, E_new, logp_new);
         else run_unit(false, 0., 0.);
+        TRACE(10);
         stamp(unit_in == U_EVAL ? (mode_in == M_INIT ? 4 : 5) : (unit_in == U_MERGE_RUN ? 6 : (unit_in == U_DBL_END ? 7 : (unit_in == U_DONE ? 9 : 8))));
     }
 
+#ifdef BF_TRACE
+    if (a.stamps && w == 0 && blockIdx.x == 0)
+        for (int i = lane; i < BF_TRACE * 16; i += 64) a.stamps[i] = TRC[i];
+#endif
     if constexpr (STAMPS) {
         if (a.stamps && lane == 0)
             for (int k = 0; k < 10; ++k) {
@@ -926,15 +1090,24 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         store_vec(BFHIP_VEC_Q, q);
         if (lane == 0) {
             for (int k = 0; k < 4; ++k) a.rng[(size_t)chain * 4 + k] = rs[k];
-            scp[BFHIP_SC_LOG_STEP] = csw[CS_LOG_STEP];
-            scp[BFHIP_SC_LOG_BAR] = csw[CS_LOG_BAR];
-            scp[BFHIP_SC_HBAR] = csw[CS_HBAR];
-            scp[BFHIP_SC_COUNT] = csw[CS_COUNT];
+            scp[BFHIP_SC_LOG_STEP] = cs_get(CS_LOG_STEP);
+            scp[BFHIP_SC_LOG_BAR] = cs_get(CS_LOG_BAR);
+            scp[BFHIP_SC_HBAR] = cs_get(CS_HBAR);
+            scp[BFHIP_SC_COUNT] = cs_get(CS_COUNT);
             scp[BFHIP_SC_I_ITER] = (double)i_iter;
             scp[BFHIP_SC_ERROR] = (double)err;
             if (a.n_leapfrog && nlf) atomicAdd(a.n_leapfrog, nlf);
         }
     }
+}
+
+static int g_tail_max = 4;  // tuning / test hook: 0 disables the VALU matvec of the plain kernel
+extern "C" void bfhip_debug_tail_max(int v) { g_tail_max = v; }
+static bool g_no_plain = false;  // tuning hook: force the generic instantiation
+extern "C" void bfhip_debug_no_plain(int v) { g_no_plain = v != 0; }
+// the common surrogate: linear + quadratic configs with the extrapolation bound and nothing else
+static bool sampler_plain(const DevModel &m) {
+    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !g_no_plain;
 }
 
 // K-split of the matvec jobs: the largest power of two KS <= W with n_mat * W * KS <= 16
@@ -954,7 +1127,10 @@ static size_t sampler_lds_bytes(const DevModel &m) {
     const int W = m.DP / 16, DP = m.DP, NS = 4 * W;
     size_t dbl = (size_t)3 * NS * 65 + (size_t)sampler_gb_slots(m) * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 +
                  (size_t)16 * CS_N + (size_t)PD_N * DP;
-    if (DP <= 64) dbl += (size_t)DP * DP * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
+    if (DP <= 64 && sampler_plain(m))  // A operands in registers; row-major S, H and plain x for the VALU matvec
+        dbl += (size_t)2 * DP * (DP + 2) + (size_t)2 * 16 * DP;
+    else if (DP <= 64)
+        dbl += (size_t)DP * DP * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
     return dbl * sizeof(double);
 }
 
@@ -974,16 +1150,15 @@ static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 
-static bool g_no_plain = false;  // tuning hook: force the generic instantiation
-extern "C" void bfhip_debug_no_plain(int v) { g_no_plain = v != 0; }
-
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
-    const bool plain = m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !g_no_plain;
+    const bool plain = sampler_plain(m);
+#ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
         return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS)>(ctx, args)
                      : launch_sampler_t<W, NUTS, (W == 4 && NUTS), false>(ctx, args);
+#endif
     return plain ? launch_sampler_t<W, NUTS, false, true>(ctx, args) : launch_sampler_t<W, NUTS, false, false>(ctx, args);
 }
 
@@ -1010,6 +1185,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.iter_out0 = iter_out0;
     args.n_out = n_out;
     args.nslot = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH;
+    args.tail_max = g_tail_max;
     args.ks = sampler_ksplit(m);
     args.gbn = sampler_gb_slots(m);
     args.rng = rng;

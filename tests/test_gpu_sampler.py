@@ -108,6 +108,32 @@ def test_nuts_resume_and_shard_invariance(ctx, samp):
     assert np.array_equal(s_all[7:], s_tail)
 
 
+@pytest.mark.parametrize('d', [64, 32, 10])
+def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
+    """The plain kernel switches its matvec from MFMA tiles to per-row FMA chains while at most 4 chains of a
+    16-chain group are evaluating.  v_mfma_f64_16x16x4_f64 accumulates every entry as one sequential fma chain
+    over k, which the FMA path repeats, so samples and statistics must agree bit for bit with the MFMA-only
+    run (the hook bfhip_debug_tail_max(0) disables the switch)."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    spec, _ = correlated_gaussian_spec(d)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(1).normal(size=(150, d))  # 9 full groups and a ragged one
+    out = {}
+    try:
+        for tm in (0, 4):
+            _lib.lib().bfhip_debug_tail_max(tm)
+            dc = DeviceChains(dens, x0, seed=5)
+            s, st = dc.run(40, 'NUTS', n_warmup=20)
+            out[tm] = (s.cpu().numpy(), st.cpu().numpy())
+    finally:
+        _lib.lib().bfhip_debug_tail_max(4)
+    assert np.array_equal(out[0][0], out[4][0])
+    assert np.array_equal(out[0][1], out[4][1], equal_nan=True)
+
+
 def test_nuts_divergences_and_max_treedepth(ctx, samp):
     """Huge step size => divergent leaves and immediate U-turns; tiny max_treedepth => depth cap."""
     spec = _spec(samp, 'div5.')

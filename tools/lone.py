@@ -13,9 +13,10 @@ spec, cov = correlated_gaussian_spec(d)
 ctx = DeviceContext(0)
 dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(2024).normal(size=(C, d))
+SAMPLER = os.environ.get('SAMPLER', 'NUTS')
 for k_act in [int(v) for v in os.environ.get('K_ACTS', '1 4 16').split()]:
     ch = DeviceChains(dens, x0, seed=2024)
-    ch.run(300, 'NUTS', n_warmup=300, check=False)
+    ch.run(300, SAMPLER, n_warmup=300, check=False)
     if k_act < 16:
         parked = (torch.arange(C, device=ch.sc.device) % 16) >= k_act
         ch.sc[parked, _lib.SC_FIELDS.index('i_iter')] = 1e9
@@ -23,9 +24,9 @@ for k_act in [int(v) for v in os.environ.get('K_ACTS', '1 4 16').split()]:
     res = []
     for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        s, st = ch.run(100, 'NUTS', n_warmup=300, check=False)
+        s, st = ch.run(100, SAMPLER, n_warmup=300, check=False)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        ts = st[:, :, ts_i].cpu().numpy()
+        ts = st[:, :, ts_i].cpu().numpy() if SAMPLER == 'NUTS' else np.full((C, 100), 32.)
         act = (np.arange(C) % 16) < k_act
         tot = ts[act].sum(1)
         res.append((dt * 1e3, tot.sum() / dt, dt * 1e6 / tot.max(), tot.max(), tot.mean()))

@@ -12,7 +12,8 @@ spec, _ = correlated_gaussian_spec(64)
 C_ = 4096
 x0 = np.random.default_rng(1).normal(size=(C_, 64))
 dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=1)
-dc.run(200, n_warmup=200)
+SAMPLER = os.environ.get('SAMPLER', 'NUTS')
+dc.run(200, SAMPLER, n_warmup=200)
 K_ACT = int(os.environ.get('K_ACT', 16))  # chains active per 16-chain workgroup (the rest are parked)
 if K_ACT < 16:
     parked = (torch.arange(C_, device='cuda') % 16) >= K_ACT
@@ -22,7 +23,7 @@ L = _lib.lib()
 L.bfhip_debug_stamps.argtypes = [C.c_void_p]
 L.bfhip_debug_stamps(C.c_void_p(buf.data_ptr()))
 torch.cuda.synchronize(); import time; t0 = time.time()
-s, st = dc.run(50, n_warmup=200)
+s, st = dc.run(50, SAMPLER, n_warmup=200)
 torch.cuda.synchronize(); dt = time.time() - t0
 L.bfhip_debug_stamps(None)
 b = buf.cpu().numpy().astype(float)
