@@ -52,6 +52,30 @@ def cpu_baseline(spec, d, n_warm_iter, seed, target_seconds=15.):
                       'one chain per OpenMP thread, %s' % (n_chain, n_it, nl, dt, model)}
 
 
+def fit_timing(d, cov, seed=7):
+    """Device least-squares fit of the same surrogate family (PolyModel.fit, modules/poly.py:505-589): n = 2 P
+    points of the exactly quadratic target, timed on the second call (reported beside the headline, never in it)."""
+    import torch
+    from bayesfast_amd import PolyModel
+    su = PolyModel('quadratic', input_size=d, output_size=1)
+    n_param = su.n_param
+    x = np.random.default_rng(seed).normal(size=(2 * n_param, d))
+    prec = np.linalg.inv(cov)
+    y = -0.5 * np.einsum('ij,jk,ik->i', x, prec, x)
+    dts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        su.fit(x, y[:, None], logp=y)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = min(dts[1:])
+    err = float(max(abs(float(np.ravel(su.fun(x[i])[0])[0]) - y[i]) for i in range(8)))
+    return {'ms': dt * 1e3, 'n': int(x.shape[0]), 'n_param': int(n_param), 'gram_flops': 2. * x.shape[0] * n_param**2,
+            'max_abs_residual_on_fit_points': err,
+            'note': 'host arrays in, coefficients out: upload, design blocks, split-K MFMA Gram, blocked Cholesky solve, bound statistics'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -62,6 +86,7 @@ def main():
     ap.add_argument('--iters', type=int, default=100, help='NUTS iterations per step (per launch)')
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fit', action='store_true', help='skip the (untimed, separately reported) surrogate fit')
     a = ap.parse_args()
 
     import torch
@@ -156,13 +181,19 @@ def main():
                        'parallelism': 'chains sharded over %d rank(s), no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'achieved': ach_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': ach_tf / peak_tf, 'traffic': traffic,
-                         'kernel': 'bf_sampler_kernel<4, true, false>', 'kernel_ms_per_launch': kernel_ms,
+                         'kernel': 'bf_sampler_kernel<4, true, false, true>', 'kernel_ms_per_launch': kernel_ms,
                          'flops_per_leapfrog': flops_per_leapfrog(d, use_bound)},
             'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
                                          'peak': 8000., 'unit': 'GB/s',
                                          'frac': (bytes_alg / (kernel_ms * 1e-3) / 1e9 / 8000.) if kernel_ms else 0.,
                                          'bytes_per_leapfrog': B_STEP_BYTES(d)},
         }
+        if not a.no_fit and not a.no_cpu_baseline and world == 1:
+            try:
+                with torch.cuda.device(ctx.device):
+                    out['fit'] = fit_timing(d, cov)
+            except Exception as ex:  # the fit is a side measurement; the headline line must still print
+                out['fit'] = {'error': repr(ex)}
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, d, n_warm_iter, a.seed)
         elif not a.no_cpu_baseline:
