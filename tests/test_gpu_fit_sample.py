@@ -265,3 +265,46 @@ def test_fit_rank_deficient_design_warns_and_regularises():
         pm.fit(x, y[:, None])
     pred = np.array([pm.fun(xx)[0][0] for xx in x[:10]])
     np.testing.assert_allclose(pred, y[:10], rtol=1e-5, atol=1e-5)
+
+
+def test_config5_128d_cubic_cross_surrogate():
+    """BASELINE config 5 shapes (one shard): d = 128, N(0, Sigma) with cond(Sigma) = 1e4 (log-uniform spectrum, random
+    rotation, seed 18) plus a cubic perturbation on the first 16 coordinates; surrogate = linear + quadratic +
+    cubic-2 + cubic-3 ("cubic-cross") on input_mask range(16): P = 129 + 8256 + 256 + 560 = 9201, the largest fit
+    and the widest sampler instantiation (DP = 128, two dimensions per lane).  The target lies in the model
+    family, so the device fit must recover it (cf. the reference's tests/test_poly.py:18-26), and NUTS chains on
+    the fitted surrogate must follow the oracle."""
+    from scipy.stats import special_ortho_group
+    from bayesfast_amd import PolyModel, PolyConfig, SurrogateDensity, sample, NTrace
+    d, m16 = 128, np.arange(16)
+    rs = np.random.RandomState(18)
+    R = special_ortho_group.rvs(d, random_state=rs)
+    lam = np.exp(np.linspace(0., np.log(1e4), d))
+    prec = (R * (1. / lam)) @ R.T                        # Sigma^-1
+    c2 = rs.normal(size=(16, 16)) * 0.02
+    c3 = rs.normal(size=(16, 16, 16)) * 0.02
+
+    def logp(x):
+        x = np.atleast_2d(x)
+        z = x[:, :16]
+        cub = np.einsum('ni,ij,nj->n', z**2, c2, z)
+        for j in range(16):
+            for k in range(j + 1, 16):
+                for l in range(k + 1, 16):
+                    cub += c3[j, k, l] * z[:, j] * z[:, k] * z[:, l]
+        return -0.5 * np.einsum('ni,ij,nj->n', x, prec, x) + cub
+
+    su = PolyModel([PolyConfig('linear'), PolyConfig('quadratic'), PolyConfig('cubic-2', input_mask=m16),
+                    PolyConfig('cubic-3', input_mask=m16)], input_size=d, output_size=1)
+    assert su.n_param == 9201
+    den = SurrogateDensity(su)
+    rng = np.random.default_rng(5)
+    chol = np.linalg.cholesky((R * lam) @ R.T)
+    x_fit = rng.normal(size=(su.n_param + 600, d)) @ chol.T
+    den.fit(x_fit, logp(x_fit))
+    x_new = rng.normal(size=(32, d)) @ chol.T * 0.8
+    got = np.array([su.fun(x)[0][0] for x in x_new])
+    np.testing.assert_allclose(got, logp(x_new), rtol=1e-6, atol=1e-6 * np.abs(logp(x_new)).max())
+    tr = NTrace(n_chain=40, n_iter=12, n_warmup=8, x_0=x_fit[:40] * 0.3, random_generator=12)
+    tt = sample(den, tr, verbose=False)
+    _compare_chains_with_oracle(tt, den, 12, (0, 17, 39), 12, 8)
