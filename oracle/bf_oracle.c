@@ -540,7 +540,72 @@ bfo_chain *bfo_chain_new(int d, const double *x0, double step_size, int adapt_st
 void bfo_chain_free(bfo_chain *c) {
     if (!c) return;
     free(c->var);
+    free(c->cov);
     free(c);
+}
+
+/* scipy.linalg.cholesky(a, lower=True) (LAPACK dpotrf): reads the lower triangle of a, writes l (zeros above the
+ * diagonal).  Returns -1 if a pivot is not positive (LinAlgError). */
+static int chol_lower(const double *a, double *l, int d) {
+    for (int i = 0; i < d * d; ++i) l[i] = 0.;
+    for (int j = 0; j < d; ++j) {
+        double s = a[j * d + j];
+        for (int k = 0; k < j; ++k) s -= l[j * d + k] * l[j * d + k];
+        if (!(s > 0.)) return -1;
+        double ljj = sqrt(s);
+        l[j * d + j] = ljj;
+        for (int i = j + 1; i < d; ++i) {
+            double t = a[i * d + j];
+            for (int k = 0; k < j; ++k) t -= l[i * d + k] * l[j * d + k];
+            l[i * d + j] = t / ljj;
+        }
+    }
+    return 0;
+}
+
+int bfo_chain_set_full(bfo_chain *c, const double *cov0) {
+    int d = c->d;
+    size_t n = (size_t)d * d;
+    double *buf = (double *)calloc(n * 5, sizeof(double));
+    c->cov = buf; c->chol = buf + n; c->fg_cov = buf + 2 * n; c->bg_cov = buf + 3 * n; c->work = buf + 4 * n;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) c->cov[i * d + j] = cov0 ? cov0[i * d + j] : (i == j ? 1. : 0.);
+    if (chol_lower(c->cov, c->chol, d)) return -1;
+    /* _WeightedCovariance(n, initial_mean, initial_cov, initial_weight): raw_cov = cov * weight (metrics.py:382-395);
+     * background = _WeightedCovariance(n): weight 10, zero mean, raw_cov = 10 I */
+    for (size_t i = 0; i < n; ++i) c->fg_cov[i] = c->cov[i] * c->initial_weight;
+    for (int i = 0; i < d; ++i) c->bg_cov[i * d + i] = 10.;
+    c->full = 1;
+    return 0;
+}
+
+/* metric.velocity: metrics.py:66-71 (diag), :113-115 (full, np.dot(cov, x)) */
+static void metric_velocity(const bfo_chain *c, const double *p, double *v) {
+    int d = c->d;
+    if (!c->full) {
+        for (int i = 0; i < d; ++i) v[i] = c->var[i] * p[i];
+        return;
+    }
+    for (int i = 0; i < d; ++i) {
+        double s = 0.;
+        for (int k = 0; k < d; ++k) s += c->cov[i * d + k] * p[k];
+        v[i] = s;
+    }
+}
+
+/* metric.random: metrics.py:83-86 (diag), :123-127 (full: solve_triangular(chol.T, normals)) */
+static void metric_random(const bfo_chain *c, bfo_rng *rng, double *p) {
+    int d = c->d;
+    bfo_rng_normal(rng, p, d);
+    if (!c->full) {
+        for (int i = 0; i < d; ++i) p[i] = c->inv_std[i] * p[i];
+        return;
+    }
+    for (int i = d - 1; i >= 0; --i) {  /* L^T p = z, back substitution */
+        double s = p[i];
+        for (int j = i + 1; j < d; ++j) s -= c->chol[j * d + i] * p[j];
+        p[i] = s / c->chol[i * d + i];
+    }
 }
 
 /* metrics.py:354-360 */
@@ -554,9 +619,50 @@ static void welford_add(double *mean, double *raw, double *n, const double *x, i
     }
 }
 
+/* _WeightedCovariance.add_sample: metrics.py:401-407 */
+static void welford_cov_add(double *mean, double *raw, double *n, const double *x, int d, double *old_diff) {
+    *n += 1.;
+    for (int i = 0; i < d; ++i) {
+        old_diff[i] = x[i] - mean[i];
+        mean[i] += old_diff[i] / *n;
+    }
+    for (int i = 0; i < d; ++i) {
+        double new_diff = x[i] - mean[i];
+        for (int j = 0; j < d; ++j) raw[i * d + j] += 1. * new_diff * old_diff[j];
+    }
+}
+
+/* QuadMetricFullAdapt.update: metrics.py:294-324 */
+static void metric_update_full(bfo_chain *c, const double *sample) {
+    int d = c->d;
+    size_t n = (size_t)d * d;
+    long delta = c->n_samples - c->previous_update;
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)d);
+    welford_cov_add(c->fg_mean, c->fg_cov, &c->fg_n, sample, d, tmp);
+    welford_cov_add(c->bg_mean, c->bg_cov, &c->bg_n, sample, d, tmp);
+    free(tmp);
+    if ((delta + 1) % c->update_window == 0) { /* _update_from_weightvar: :287-292 */
+        for (size_t i = 0; i < n; ++i) c->cov[i] = c->fg_cov[i] / c->fg_n;
+        if (chol_lower(c->cov, c->work, d) == 0) memcpy(c->chol, c->work, sizeof(double) * n);
+    }
+    if (delta >= c->adapt_window) {
+        memcpy(c->fg_mean, c->bg_mean, sizeof(double) * (size_t)d);
+        memcpy(c->fg_cov, c->bg_cov, sizeof(double) * n);
+        c->fg_n = c->bg_n;
+        for (int i = 0; i < d; ++i) c->bg_mean[i] = 0.;
+        for (size_t i = 0; i < n; ++i) c->bg_cov[i] = 0.;
+        for (int i = 0; i < d; ++i) c->bg_cov[i * d + i] = 10.;
+        c->bg_n = 10.;
+        c->previous_update = c->n_samples;
+        if (c->doubling) c->adapt_window *= 2;
+    }
+    c->n_samples += 1;
+}
+
 /* metrics.py:186-211 */
 static void metric_update(bfo_chain *c, const double *sample, int warmup) {
     if (!warmup || !c->adapt_metric) return;
+    if (c->full) { metric_update_full(c, sample); return; }
     int d = c->d;
     long delta = c->n_samples - c->previous_update;
     welford_add(c->fg_mean, c->fg_raw, &c->fg_n, sample, d);
@@ -630,6 +736,33 @@ void bfo_leapfrog(const bfo_density *dn, const double *var, double eps, const do
     *energy_new = 0.5 * kin - *logp_new;                                 /* :93 */
 }
 
+void bfo_leapfrog_full(const bfo_density *dn, const double *cov, double eps, const double *q, const double *p,
+                       const double *grad, double *q_new, double *p_new, double *v_new, double *grad_new,
+                       double *energy_new, double *logp_new) {
+    bfo_chain c;
+    memset(&c, 0, sizeof(c));
+    c.d = dn->d; c.full = 1; c.cov = (double *)cov;
+    int d = dn->d;
+    double dt = 0.5 * eps;
+    for (int i = 0; i < d; ++i) p_new[i] = p[i] + dt * grad[i];
+    metric_velocity(&c, p_new, v_new);
+    for (int i = 0; i < d; ++i) q_new[i] = q[i] + eps * v_new[i];
+    bfo_logp_and_grad(dn, q_new, 0, logp_new, grad_new);
+    for (int i = 0; i < d; ++i) p_new[i] = p_new[i] + dt * grad_new[i];
+    metric_velocity(&c, p_new, v_new);
+    double kin = 0.;
+    for (int i = 0; i < d; ++i) kin += p_new[i] * v_new[i];
+    *energy_new = 0.5 * kin - *logp_new;
+}
+
+/* the integrator step with the chain's own metric */
+static void leapfrog_chain(const bfo_density *dn, const bfo_chain *c, double eps, const double *q, const double *p,
+                           const double *grad, double *q_new, double *p_new, double *v_new, double *grad_new,
+                           double *energy_new, double *logp_new) {
+    if (c->full) bfo_leapfrog_full(dn, c->cov, eps, q, p, grad, q_new, p_new, v_new, grad_new, energy_new, logp_new);
+    else bfo_leapfrog(dn, c->var, eps, q, p, grad, q_new, p_new, v_new, grad_new, energy_new, logp_new);
+}
+
 /* ================= NUTS tree: samplers/nuts.py ==================================================== */
 
 typedef struct {
@@ -685,7 +818,7 @@ static subtree single_step(tree_ctx *cx, const lf_state *left, double eps, int *
     subtree t;
     memset(&t, 0, sizeof(t));
     lf_state right = state_alloc(d);
-    bfo_leapfrog(cx->dn, cx->ch->var, eps, left->q, left->p, left->grad, right.q, right.p, right.v, right.grad,
+    leapfrog_chain(cx->dn, cx->ch, eps, left->q, left->p, left->grad, right.q, right.p, right.v, right.grad,
                  &right.energy, &right.logp);
     cx->n_leapfrog += 1;
     if (bfo_trace_buf && bfo_trace_n + 8 <= bfo_trace_cap) {
@@ -786,13 +919,13 @@ static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int
     cx.n_leapfrog = 0; cx.err = 0;
     /* p0 = metric.random(rng): metrics.py:83-86 */
     lf_state start = state_alloc(d);
-    bfo_rng_normal(rng, start.p, d);
-    for (int i = 0; i < d; ++i) start.p[i] = c->inv_std[i] * start.p[i];
+    metric_random(c, rng, start.p);
     memcpy(start.q, c->q, sizeof(double) * (size_t)d);
     /* integrator.compute_state: integration.py:28-34 */
     bfo_logp_and_grad(dn, start.q, 0, &start.logp, start.grad);
     double kin = 0.;
-    for (int i = 0; i < d; ++i) { start.v[i] = c->var[i] * start.p[i]; kin += start.p[i] * start.v[i]; }
+    metric_velocity(c, start.p, start.v);
+    for (int i = 0; i < d; ++i) kin += start.p[i] * start.v[i];
     start.energy = 0.5 * kin - start.logp;
     if (!isfinite(start.energy)) { state_free(&start); return -1; } /* base_hmc.py:72-76 */
     double step_size = exp(warmup ? c->log_step : c->log_bar);      /* step_size.py:25-29 */
@@ -909,12 +1042,12 @@ int bfo_hmc_run(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, long n_run, l
     for (long it = 0; it < n_run && !rc; ++it) {
         int warmup = c->i_iter < n_warmup;
         double *st = stats + (size_t)it * BFO_N_HSTATS;
-        bfo_rng_normal(rng, start.p, d);
-        for (int i = 0; i < d; ++i) start.p[i] = c->inv_std[i] * start.p[i];
+        metric_random(c, rng, start.p);
         memcpy(start.q, c->q, sizeof(double) * (size_t)d);
         bfo_logp_and_grad(dn, start.q, 0, &start.logp, start.grad);
         double kin = 0.;
-        for (int i = 0; i < d; ++i) { start.v[i] = c->var[i] * start.p[i]; kin += start.p[i] * start.v[i]; }
+        metric_velocity(c, start.p, start.v);
+        for (int i = 0; i < d; ++i) kin += start.p[i] * start.v[i];
         start.energy = 0.5 * kin - start.logp;
         if (!isfinite(start.energy)) { rc = -1; break; }
         double step_size = exp(warmup ? c->log_step : c->log_bar);
@@ -922,7 +1055,7 @@ int bfo_hmc_run(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, long n_run, l
         a.energy = start.energy; a.logp = start.logp;
         lf_state *cur = &a, *nxt = &b;
         for (int s = 0; s < n_int_step; ++s) { /* hmc.py:19-20 */
-            bfo_leapfrog(dn, c->var, step_size, cur->q, cur->p, cur->grad, nxt->q, nxt->p, nxt->v, nxt->grad,
+            leapfrog_chain(dn, c, step_size, cur->q, cur->p, cur->grad, nxt->q, nxt->p, nxt->v, nxt->grad,
                          &nxt->energy, &nxt->logp);
             lf_state *t = cur; cur = nxt; nxt = t;
         }

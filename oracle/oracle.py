@@ -68,7 +68,8 @@ class _Chain(C.Structure):
                 ('bg_raw', _dp), ('fg_n', C.c_double), ('bg_n', C.c_double), ('initial_weight', C.c_double),
                 ('n_samples', C.c_long), ('previous_update', C.c_long), ('adapt_window', C.c_long),
                 ('update_window', C.c_long), ('doubling', C.c_int), ('q', _dp), ('i_iter', C.c_long),
-                ('d', C.c_int)]
+                ('d', C.c_int), ('full', C.c_int), ('cov', _dp), ('chol', _dp), ('fg_cov', _dp), ('bg_cov', _dp),
+                ('work', _dp)]
 
 
 _lib = None
@@ -95,6 +96,9 @@ def lib():
                                     C.c_double, _dp, C.c_int, _dp, C.c_double, C.c_long, C.c_long, C.c_int]
         L.bfo_chain_free.argtypes = [C.POINTER(_Chain)]
         L.bfo_leapfrog.argtypes = [C.POINTER(_Density), _dp, C.c_double] + [_dp] * 9
+        L.bfo_leapfrog_full.argtypes = L.bfo_leapfrog.argtypes
+        L.bfo_chain_set_full.restype = C.c_int
+        L.bfo_chain_set_full.argtypes = [C.POINTER(_Chain), _dp]
         L.bfo_nuts_run.argtypes = [C.POINTER(_Density), C.POINTER(_Chain), C.POINTER(_Rng), C.c_long, C.c_long,
                                    C.c_int, C.c_double, _dp, _dp]
         L.bfo_hmc_run.argtypes = L.bfo_nuts_run.argtypes
@@ -249,6 +253,18 @@ def leapfrog(spec, var, eps, q, p, grad):
     return dict(q=out[0], p=out[1], v=out[2], grad=out[3], energy=e[0], logp=lp[0])
 
 
+def leapfrog_full(spec, cov, eps, q, p, grad):
+    """CpuLeapfrogIntegrator._step with QuadMetricFull(cov). Returns dict(q,p,v,grad,energy,logp)."""
+    dn, keep = density_struct(spec)
+    d = dn.d
+    out = [np.empty(d) for _ in range(4)]
+    e = np.empty(1)
+    lp = np.empty(1)
+    lib().bfo_leapfrog_full(C.byref(dn), _p(_f64(cov)), float(eps), _p(_f64(q)), _p(_f64(p)), _p(_f64(grad)),
+                            _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _p(e), _p(lp))
+    return dict(q=out[0], p=out[1], v=out[2], grad=out[3], energy=e[0], logp=lp[0])
+
+
 def xoshiro_seed(seed, stream):
     s = (C.c_uint64 * 4)()
     lib().bfo_xoshiro_seed(int(seed), int(stream), s)
@@ -263,6 +279,13 @@ class Chain:
                  adapt_window=60, update_window=1, doubling=True):
         x0 = _f64(x0)
         self.d = x0.size
+        # metric: None / 1-d variances (diagonal), or 'full' / 2-d covariance (QuadMetricFull(Adapt))
+        cov0 = None
+        full = isinstance(metric, str) and metric == 'full'
+        if isinstance(metric, str):
+            metric = None
+        elif metric is not None and np.ndim(metric) == 2:
+            cov0, metric, full = _f64(metric), None, True
         mv = None if metric is None else _f64(metric)
         im = None if initial_mean is None else _f64(initial_mean)
         self._c = lib().bfo_chain_new(self.d, _p(x0), float(step_size), int(adapt_step_size),
@@ -270,6 +293,12 @@ class Chain:
                                       _p(mv) if mv is not None else None, int(adapt_metric),
                                       _p(im) if im is not None else None, float(initial_weight),
                                       int(adapt_window), int(update_window), int(doubling))
+        if full:
+            if lib().bfo_chain_set_full(self._c, _p(cov0) if cov0 is not None else None):
+                raise ValueError('the input covariance is not positive definite.')
+
+    def mat(self, name):
+        return np.ctypeslib.as_array(getattr(self._c.contents, name), shape=(self.d, self.d)).copy()
 
     def __del__(self):
         try:

@@ -375,6 +375,74 @@ def gen_sampler(bf, out):
     np.savez_compressed(os.path.join(out, 'sampler.npz'), **z)
 
 
+def gen_sampler_fullmetric(bf, out):
+    """Full-rank metric (QuadMetricFull / QuadMetricFullAdapt, samplers/hmc_utils/metrics.py:94-132,240-330,
+    374-417): leapfrog states and logged-RNG NUTS / HMC trajectories."""
+    from bayesfast.samplers import NUTS, HMC, NTrace, HTrace
+    from bayesfast.samplers.hmc_utils.integration import CpuLeapfrogIntegrator
+    from bayesfast.samplers.hmc_utils.metrics import QuadMetricFull
+    z = {}
+    d = 8
+    den, rng = make_density(bf, d, 57)
+    spec = density_spec_from_reference(den)
+    z.update(flatten_spec(spec, 'fm8.'))
+
+    def lg(x):
+        return den.logp_and_grad(x, original_space=False, use_surrogate=True)
+
+    B = rng.normal(size=(d, d)) * 0.3
+    cov0 = np.eye(d) * 0.8 + B @ B.T
+    z['fm8.cov0'] = cov0
+    integ = CpuLeapfrogIntegrator(QuadMetricFull(cov0), lg)
+    q0 = rng.normal(size=d) * 0.5
+    p0 = rng.normal(size=d)
+    s0 = integ.compute_state(q0, p0)
+    s1 = integ.step(0.11, s0)
+    s2 = integ.step(-0.06, s1)
+    for tag, st in (('s0', s0), ('s1', s1), ('s2', s2)):
+        for fld in ('q', 'p', 'velocity', 'q_grad', 'energy', 'logp'):
+            z['fm8.lf.%s.%s' % (tag, fld)] = np.asarray(getattr(st, fld))
+    z['fm8.lf.eps'] = np.array([0.11, -0.06])
+    n_iter, n_warmup, n_chain = 40, 28, 2
+    x0 = rng.normal(size=(n_chain, d)) * 0.5
+    z['fm8.x0'] = x0
+    z['fm8.n_iter'], z['fm8.n_warmup'] = np.asarray(n_iter), np.asarray(n_warmup)
+
+    def record(t, sampler, key):
+        log = LoggingGenerator(t._random_generator)
+        t._random_generator = log
+        sampler(logp_and_grad=lg, sample_trace=t).run(verbose=False)
+        z[key + 'samples'] = t.samples
+        z[key + 'normals'] = np.array(log.normals)
+        z[key + 'uniforms'] = np.array(log.uniforms)
+        for si in t.stats.stats_items:
+            z[key + si] = np.array(getattr(t.stats, '_' + si), dtype=float)
+        z[key + 'final_cov'] = np.array(t.metric._cov)
+
+    # adaptive full metric from the identity (metric='full'), NUTS: small adapt_window so that the window switch
+    # and the doubling both happen inside the warm-up
+    for c in range(n_chain):
+        t = NTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, x_0=x0.copy(), random_generator=777,
+                   metric='full', adapt_window=8)
+        t._init_chain(c)
+        record(t, NUTS, 'fm8.nuts_adapt%d.' % c)
+    # fixed full metric (adapt_metric=False): NUTS and HMC
+    t = NTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, x_0=x0.copy(), random_generator=778,
+               metric=cov0.tolist(), adapt_metric=False)
+    t._init_chain(0)
+    record(t, NUTS, 'fm8.nuts_fixed0.')
+    t = HTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, n_int_step=8, x_0=x0.copy(),
+               random_generator=779, metric=cov0.tolist(), adapt_metric=False)
+    t._init_chain(1)
+    record(t, HMC, 'fm8.hmc_fixed1.')
+    # adaptive from a given covariance, HMC
+    t = HTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, n_int_step=8, x_0=x0.copy(),
+               random_generator=780, metric=cov0.tolist(), adapt_window=8)
+    t._init_chain(0)
+    record(t, HMC, 'fm8.hmc_adapt0.')
+    np.savez_compressed(os.path.join(out, 'sampler_fullmetric.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -383,7 +451,7 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler)
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue

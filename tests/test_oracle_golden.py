@@ -210,3 +210,79 @@ def test_xoshiro_reference_vectors():
     s = (C.c_uint64 * 4)(1, 2, 3, 4)
     got = [L.bfo_xoshiro_next(s) for _ in range(3)]
     assert got == [41943041, 58720359, 3588806011781223]
+
+
+# ---- full-rank metric (QuadMetricFull / QuadMetricFullAdapt): fixture sampler_fullmetric.npz ----------------
+
+@pytest.fixture(scope='module')
+def fullm():
+    return np.load(os.path.join(G, 'sampler_fullmetric.npz'))
+
+
+def test_full_metric_leapfrog(fullm):
+    """CpuLeapfrogIntegrator with QuadMetricFull: velocity = cov p (metrics.py:113-115)."""
+    spec = rebuild_spec(fullm, 'fm8.')
+    cov = fullm['fm8.cov0']
+    for a, b, eps in (('s0', 's1', fullm['fm8.lf.eps'][0]), ('s1', 's2', fullm['fm8.lf.eps'][1])):
+        r = orc.leapfrog_full(spec, cov, eps, fullm['fm8.lf.%s.q' % a], fullm['fm8.lf.%s.p' % a], fullm['fm8.lf.%s.q_grad' % a])
+        for f, g in (('q', 'q'), ('p', 'p'), ('v', 'velocity'), ('grad', 'q_grad'), ('energy', 'energy'), ('logp', 'logp')):
+            np.testing.assert_allclose(r[f], fullm['fm8.lf.%s.%s' % (b, g)], rtol=1e-11, atol=1e-11, err_msg=f)
+
+
+def _replay_full(fullm, key, chain_i, sampler, **chain_kw):
+    spec = rebuild_spec(fullm, 'fm8.')
+    chain = orc.Chain(fullm['fm8.x0'][chain_i], **chain_kw)
+    rng = orc.make_rng('replay', normals=fullm[key + 'normals'], uniforms=fullm[key + 'uniforms'])
+    n_iter, n_warmup = int(fullm['fm8.n_iter']), int(fullm['fm8.n_warmup'])
+    if sampler == 'NUTS':
+        out = orc.nuts_run(spec, chain, rng, n_iter, n_warmup)
+    else:
+        out = orc.hmc_run(spec, chain, rng, n_iter, n_warmup, n_int_step=8)
+    return out, chain, rng
+
+
+@pytest.mark.parametrize('c', [0, 1])
+def test_full_metric_adaptive_nuts_replay(fullm, c):
+    """NTrace(metric='full'): Welford covariance windows, per-iteration Cholesky, window switch and doubling
+    (metrics.py:240-330,374-417) under the reference's own logged draws."""
+    k = 'fm8.nuts_adapt%d.' % c
+    (samples, st), chain, rng = _replay_full(fullm, k, c, 'NUTS', metric='full', adapt_window=8)
+    for f in ('tree_depth', 'tree_size', 'diverging', 'warmup'):
+        assert np.array_equal(st[f], fullm[k + f]), f
+    assert rng[0].i_uniform == fullm[k + 'uniforms'].size and rng[0].i_normal == fullm[k + 'normals'].size
+    # BLAS / LAPACK summation orders (dgemv, dtrtrs, dpotrf) differ from the plain loops here at the 1e-16 level and
+    # the warm-up trajectories (up to 63 leapfrogs, covariance still rough) amplify that: tight on the head of the
+    # run, loose overall, discrete fields exact over the whole horizon (above)
+    np.testing.assert_allclose(samples[:7], fullm[k + 'samples'][:7], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(samples, fullm[k + 'samples'], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(chain.mat('cov'), fullm[k + 'final_cov'], rtol=1e-3, atol=1e-3)
+    for f in ('energy', 'step_size', 'mean_tree_accept'):
+        np.testing.assert_allclose(st[f][:7], fullm[k + f][:7], rtol=1e-8, atol=1e-8, err_msg=f)
+        np.testing.assert_allclose(st[f], fullm[k + f], rtol=5e-3, atol=5e-3, err_msg=f)
+
+
+def test_full_metric_fixed_nuts_and_hmc_replay(fullm):
+    cov0 = fullm['fm8.cov0']
+    k = 'fm8.nuts_fixed0.'
+    (samples, st), chain, rng = _replay_full(fullm, k, 0, 'NUTS', metric=cov0, adapt_metric=False)
+    for f in ('tree_depth', 'tree_size', 'diverging'):
+        assert np.array_equal(st[f], fullm[k + f]), f
+    np.testing.assert_allclose(samples, fullm[k + 'samples'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(chain.mat('cov'), cov0, rtol=0, atol=0)
+    # HMC at step sizes near the stability limit amplifies the rounding-level differences (cf. test_hmc_replay)
+    k = 'fm8.hmc_fixed1.'
+    (samples, st), chain, rng = _replay_full(fullm, k, 1, 'HMC', metric=cov0, adapt_metric=False)
+    assert np.array_equal(st['accepted'], fullm[k + 'accepted'])
+    np.testing.assert_allclose(samples[:10], fullm[k + 'samples'][:10], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(samples, fullm[k + 'samples'], rtol=1e-2, atol=1e-2)
+    k = 'fm8.hmc_adapt0.'
+    (samples, st), chain, rng = _replay_full(fullm, k, 0, 'HMC', metric=cov0, adapt_window=8)
+    assert np.array_equal(st['accepted'], fullm[k + 'accepted'])
+    np.testing.assert_allclose(samples[:10], fullm[k + 'samples'][:10], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(samples, fullm[k + 'samples'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(chain.mat('cov'), fullm[k + 'final_cov'], rtol=1e-4, atol=1e-4)
+
+
+def test_full_metric_rejects_indefinite_covariance():
+    with pytest.raises(ValueError):
+        orc.Chain(np.zeros(3), metric=np.diag([1., -1., 1.]))
