@@ -14,6 +14,7 @@ SC_FIELDS = ('log_step', 'log_bar', 'hbar', 'mu', 'count', 'fg_n', 'bg_n', 'n_sa
 SC_N = len(SC_FIELDS)
 VEC_FIELDS = ('q', 'var', 'fg_mean', 'fg_raw', 'bg_mean', 'bg_raw')
 VEC_N = len(VEC_FIELDS)
+MAT_N = 6  # BFHIP_MAT_N: per-chain matrices of the full-rank metric (slot 0 = covariance)
 STAT_STRIDE = 11
 NSTATS = ('logp', 'energy', 'tree_depth', 'tree_size', 'mean_tree_accept', 'step_size', 'step_size_bar',
           'warmup', 'energy_change', 'max_energy_change', 'diverging')
@@ -38,7 +39,7 @@ class SamplerConfig(C.Structure):
     _fields_ = [('sampler', C.c_int), ('n_warmup', C.c_int), ('max_treedepth', C.c_int), ('n_int_step', C.c_int),
                 ('max_change', C.c_double), ('target_accept', C.c_double), ('gamma', C.c_double), ('k', C.c_double),
                 ('t_0', C.c_double), ('adapt_step_size', C.c_int), ('adapt_metric', C.c_int),
-                ('update_window', C.c_int), ('doubling', C.c_int)]
+                ('update_window', C.c_int), ('doubling', C.c_int), ('full_metric', C.c_int), ('metric_mat', C.c_void_p)]
 
 
 # every symbol include/bfhip.h declares: (restype, argtypes)
@@ -58,6 +59,7 @@ SYMBOLS = {
                                     C.c_int, _vp, _vp, _vp]),
     'bfhip_rng_seed': (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, _vp]),
     'bfhip_chain_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp, C.c_double, C.c_int, _vp, _vp]),
+    'bfhip_metric_init_full': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp]),
     'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
     'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_solve_spd': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),

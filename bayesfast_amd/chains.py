@@ -46,11 +46,30 @@ class DeviceChains:
         self.sc = self.ctx.empty((self.n_chain, _lib.SC_N))
         self.vec = self.ctx.empty((self.n_chain, _lib.VEC_N, self.d))
         self.n_leapfrog = torch.zeros((1,), dtype=torch.int64, device=self.ctx.device)
+        # metric: None / 1-d variances -> QuadMetricDiag(Adapt); 'full' / 2-d covariance -> QuadMetricFull(Adapt)
+        cov0 = None
+        self.full_metric = isinstance(metric, str) and metric == 'full'
+        if isinstance(metric, str):
+            if metric not in ('diag', 'full'):
+                raise ValueError('invalid value for metric.')
+            metric = None
+        elif metric is not None and np.ndim(metric) == 2:
+            cov0 = np.asarray(metric, dtype=np.float64)
+            if cov0.shape != (self.d, self.d):
+                raise ValueError('invalid value for metric.')
+            metric, self.full_metric = None, True
         mv = None if metric is None else self.ctx.tensor(np.asarray(metric, dtype=np.float64).reshape(self.d))
         im = None if initial_mean is None else self.ctx.tensor(np.asarray(initial_mean, dtype=np.float64).reshape(self.d))
         _lib.check(lib.bfhip_rng_seed(h, self.n_chain, int(seed) & (2**64 - 1), int(first_stream), _ptr(self.rng)))
         _lib.check(lib.bfhip_chain_init(h, self.n_chain, self.d, _ptr(x_0), float(step_size), _ptr(mv), _ptr(im),
                                         float(initial_weight), int(adapt_window), _ptr(self.sc), _ptr(self.vec)))
+        self.mat = None
+        if self.full_metric:
+            self.mat = torch.zeros((self.n_chain, _lib.MAT_N, self.d, self.d), dtype=torch.float64, device=self.ctx.device)
+            c0 = None if cov0 is None else self.ctx.tensor(cov0, torch.float64)
+            _lib.check(lib.bfhip_metric_init_full(h, self.n_chain, self.d, _ptr(c0), float(initial_weight), _ptr(self.sc),
+                                                  _ptr(self.mat)))
+            self.raise_on_error()
         self.i_iter = 0
 
     def run(self, n_run, sampler='NUTS', n_warmup=500, max_treedepth=10, n_int_step=32, max_change=1000.,
@@ -71,6 +90,8 @@ class DeviceChains:
         cfg.target_accept, cfg.gamma, cfg.k, cfg.t_0 = float(target_accept), float(gamma), float(k), float(t_0)
         cfg.adapt_step_size, cfg.adapt_metric = int(bool(adapt_step_size)), int(bool(adapt_metric))
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
+        cfg.full_metric = int(self.full_metric)
+        cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
         n_run = int(n_run)
         if samples is None:
             samples = self.ctx.empty((self.n_chain, n_run, self.d))
@@ -91,9 +112,18 @@ class DeviceChains:
         if bad.numel():
             i = int(bad[0, 0])
             code = int(err[i])
+            if code == 3:  # metrics.py:107-108
+                raise ValueError('the input covariance is not positive definite.')
             if code == 1:  # base_hmc.py:72-76
                 raise RuntimeError('Bad initial energy for chain #{}, please check the Hamiltonian.'.format(i))
             raise FloatingPointError("logp can't be nan (chain #{}).".format(i))  # nuts.py:201-202
+
+    def covariance(self):
+        """Per-chain metric covariance (n_chain, d, d): QuadMetricFull._cov, or diag(var) for the diagonal metric."""
+        torch = _torch()
+        if self.full_metric:
+            return self.mat[:, 0].transpose(1, 2).contiguous()
+        return torch.diag_embed(self.field('var'))
 
     def field(self, name):
         """One per-chain quantity by its reference name (device tensor view)."""

@@ -1,0 +1,121 @@
+// bfhip_metric.h -- full-rank metric (QuadMetricFull / QuadMetricFullAdapt, samplers/hmc_utils/metrics.py:94-132,
+// 240-330, 374-417): per-chain d x d matrices and the wave-level routines on them.
+//
+// One wave owns one chain; lane l holds rows / dimensions l*E .. l*E+E-1 (E = 1 for d <= 64, 2 up to 128).
+// Every matrix M of a chain is stored TRANSPOSED, MT[k * d + i] = M[i][k], so that for a fixed column k the
+// rows of all lanes are one contiguous, coalesced segment and a lane only ever re-reads what it wrote itself;
+// values of other rows travel by v_readlane.  The Cholesky factor also has a row-major copy (for the back
+// substitution of metric.random, which walks rows).  Arithmetic is written with explicit non-fused multiplies and
+// adds in the order of the CPU restatement (oracle/bf_oracle.c), so both sides round identically.
+#pragma once
+#include "bfhip_common.h"
+
+enum { BF_MAT_COV = 0, BF_MAT_CHOL, BF_MAT_CHOL_ROWS, BF_MAT_FG, BF_MAT_BG, BF_MAT_WORK, BF_MAT_N };
+
+__device__ inline double bf_readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// element k of a vector held as x[e] of lane k / E (E <= 2)
+template <int E>
+__device__ inline double bf_pick(const double (&x)[E], int k) {
+    return bf_readlane_f64((E > 1 && (k % E)) ? x[E - 1] : x[0], k / E);
+}
+
+// scipy.linalg.cholesky(a, lower=True): aT (transposed storage, only the lower triangle of a is read) -> lT.
+// Returns false when a pivot is not positive (the reference keeps its previous factor then, metrics.py:287-292).
+template <int E>
+__device__ inline bool bf_chol_rows(const double *aT, double *lT, int d, int lane) {
+    for (int j = 0; j < d; ++j) {
+        double acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            acc[e] = (i < d) ? aT[(size_t)j * d + i] : 0.;  // a[i][j]
+        }
+        for (int k = 0; k < j; ++k) {
+            double lik[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                lik[e] = (i < d) ? lT[(size_t)k * d + i] : 0.;  // L[i][k], written by this lane at step k
+            }
+            const double ljk = bf_pick<E>(lik, j);              // L[j][k]
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = __dsub_rn(acc[e], __dmul_rn(lik[e], ljk));
+        }
+        const double s = bf_pick<E>(acc, j);
+        if (!(s > 0.)) return false;
+        const double ljj = __dsqrt_rn(s);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) lT[(size_t)j * d + i] = i > j ? __ddiv_rn(acc[e], ljj) : (i == j ? ljj : 0.);
+        }
+    }
+    return true;
+}
+
+// lT -> the two stored copies of the factor
+template <int E>
+__device__ inline void bf_chol_publish(const double *lT, double *cholT, double *cholR, int d, int lane) {
+    for (int j = 0; j < d; ++j) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) {
+                const double v = lT[(size_t)j * d + i];
+                cholT[(size_t)j * d + i] = v;
+                cholR[(size_t)i * d + j] = v;  // row-major: L[i][j]
+            }
+        }
+    }
+}
+
+// velocity = cov p (np.dot(cov, x), metrics.py:113-115): out_i = sum_k cov[i][k] p_k, k ascending
+template <int E>
+__device__ inline void bf_velocity_full(const double *covT, const double (&pv)[E], double (&out)[E], int d, int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] = 0.;
+    for (int k = 0; k < d; ++k) {
+        const double pk = bf_pick<E>(pv, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) out[e] = __dadd_rn(out[e], __dmul_rn(covT[(size_t)k * d + i], pk));
+        }
+    }
+}
+
+// metric.random for the full metric: solve L^T p = z (scipy.linalg.solve_triangular(chol.T, z), metrics.py:123-127)
+// by the column sweep of BLAS dtrsv: j = d-1 .. 0: p_j = z_j / L[j][j]; z_i -= L[j][i] p_j for i < j.
+template <int E>
+__device__ inline void bf_solve_lt(const double *cholR, double (&z)[E], int d, int lane) {
+    for (int j = d - 1; j >= 0; --j) {
+        double row[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            row[e] = (i <= j) ? cholR[(size_t)j * d + i] : 0.;  // L[j][i]
+        }
+        const double pj = __ddiv_rn(bf_pick<E>(z, j), bf_pick<E>(row, j));
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < j) z[e] = __dsub_rn(z[e], __dmul_rn(row[e], pj));
+            else if (i == j) z[e] = pj;
+        }
+    }
+}
+
+// _WeightedCovariance.add_sample (metrics.py:401-407) on the transposed accumulator: raw[i][j] += new_i * old_j
+template <int E>
+__device__ inline void bf_welford_cov(double *rawT, const double (&new_diff)[E], const double (&old_diff)[E], int d, int lane) {
+    for (int j = 0; j < d; ++j) {
+        const double oj = bf_pick<E>(old_diff, j);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) rawT[(size_t)j * d + i] = __dadd_rn(rawT[(size_t)j * d + i], __dmul_rn(__dmul_rn(1., new_diff[e]), oj));
+        }
+    }
+}

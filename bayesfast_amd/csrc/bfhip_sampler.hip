@@ -25,6 +25,7 @@
 // post-order, so a chain reproduces the CPU oracle's trajectory for the same xoshiro stream.
 #include <type_traits>
 #include "bfhip_eval.h"
+#include "bfhip_metric.h"
 
 // The f64 libm expansions (exp, log, sincospi, sqrt) are long inline sequences whose constants get hoisted
 // out of the trip loop; inlined at every call site they push the kernel far over its 128-VGPR budget
@@ -52,6 +53,7 @@ struct SamplerArgs {
     double *sc, *vec, *samples, *stats;
     unsigned long long *n_leapfrog;
     double *scratch;
+    double *mat;  // full-rank metric: [n_chain][BF_MAT_N][d][d] (transposed storage, bfhip_metric.h), or NULL
     unsigned long long *stamps;  // diagnostics only: [groups][16 waves][20]: 10 cycle counters + 10 event counts, or NULL
 };
 
@@ -174,7 +176,9 @@ struct SamplerGeo {
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
 // extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
 // and the state of the optional features disappear from the instantiation.
-template <int W, bool NUTS, bool STAMPS, bool PLAIN>
+// FULLM: full-rank metric (velocity = cov p with a per-chain covariance, adapted by Welford windows and refactorised
+// every update_window iterations); the diagonal metric is the default instantiation.
+template <int W, bool NUTS, bool STAMPS, bool PLAIN, bool FULLM>
 __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
     const bool f_quad = PLAIN ? true : (bool)m.has_quad, f_bound = PLAIN ? true : (bool)m.use_bound;
     const bool f_decay = PLAIN ? false : (bool)m.use_decay, f_tr = PLAIN ? false : (bool)m.has_transform;
@@ -287,6 +291,18 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
     double *lsw = LS + w * (MAXL * LS_N);
     const int nw = a.cfg.n_warmup;
+    // full-rank metric: this chain's matrices (bfhip_metric.h) and the velocity of a momentum
+    const size_t msz = (size_t)d * d;
+    double *matp = FULLM ? a.mat + (size_t)(real ? chain : 0) * BF_MAT_N * msz : nullptr;
+    double vcur[FULLM ? E : 1], L0v[FULLM ? E : 1];  // velocities of the current momentum and of the waiting level-0 leaf
+    auto velocity = [&](const double (&pv)[E], double (&out)[E]) {
+        if constexpr (FULLM) {
+            bf_velocity_full<E>(matp + BF_MAT_COV * msz, pv, out, d, lane);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) out[e] = var[e] * pv[e];
+        }
+    };
 
     auto load_vec = [&](int field, double (&v)[E], double pad) {
 #pragma unroll
@@ -328,9 +344,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             double sn, cs;
             sincospi(2. * u2, &sn, &cs);  // angle 2 pi u2 without a large-argument reduction
             const double z = (dim & 1) ? rad * sn : rad * cs;
-            p[e] = (dim < d) ? (1. / sqrt(var[e])) * z : 0.;
+            if constexpr (FULLM) p[e] = (dim < d) ? z : 0.;
+            else p[e] = (dim < d) ? (1. / sqrt(var[e])) * z : 0.;
             g[e] = 0.;
         }
+        if constexpr (FULLM) bf_solve_lt<E>(matp + BF_MAT_CHOL_ROWS * msz, p, d, lane);  // metrics.py:123-127
     };
 #pragma unroll
     for (int e = 0; e < E; ++e) { q[e] = 0.; p[e] = 0.; g[e] = 0.; var[e] = 1.; TLp[e] = 0.; TPs[e] = 0.; TPq[e] = 0.; PF0[e] = 0.; PF1[e] = 0.; PF2[e] = 0.; PF3[e] = 0.; L0p[e] = 0.; L0q[e] = 0.; }
@@ -423,8 +441,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #pragma unroll
                             for (int e = 0; e < E; ++e) {
                                 const double ps0 = L0p[e] + p[e];
-                                d0 += ps0 * (var[e] * L0p[e]);  // nuts.py:150-151
-                                d1 += ps0 * (var[e] * p[e]);
+                                d0 += ps0 * (FULLM ? L0v[FULLM ? e : 0] : var[e] * L0p[e]);  // nuts.py:150-151
+                                d1 += ps0 * (FULLM ? vcur[FULLM ? e : 0] : var[e] * p[e]);
                             }
                             { double r2[2] = {d0, d1}; wave_sum_n<2>(r2); d0 = r2[0]; d1 = r2[1]; }
                             T_acc = rfl(lsw[LS_ACC]) + T_acc;  // :173
@@ -477,10 +495,12 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #pragma unroll
             for (int e = 0; e < E; ++e) { A[e] = PF0[e]; B[e] = PF1[e]; S1[e] = PF2[e]; }  // prefetched when this unit was scheduled
             double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
+            double vAa[E], vBa[E], vCa[E];
+            velocity(A, vAa); velocity(B, vBa); velocity(TLp, vCa);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 psum[e] = S1[e] + TPs[e];
-                const double vA = var[e] * A[e], vB = var[e] * B[e], vC = var[e] * TLp[e], vD = var[e] * p[e];
+                const double vA = vAa[e], vB = vBa[e], vC = vCa[e], vD = FULLM ? vcur[FULLM ? e : 0] : var[e] * p[e];
                 d0 += psum[e] * vA;  // nuts.py:150-151
                 d1 += psum[e] * vD;
                 const double ps1 = S1[e] + TLp[e];  // :155-157
@@ -540,10 +560,12 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 cs_set(CS_TREE_W, tree_W + T_W);  // :85
             }
             double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
+            double vTa[E], vLa[E], vRa[E];
+            velocity(TLp, vTa); velocity(oldL, vLa); velocity(oldR, vRa);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 ps[e] += TPs[e];  // :86 (in place)
-                const double vN = var[e] * p[e], vT = var[e] * TLp[e], vL = var[e] * oldL[e], vR = var[e] * oldR[e];
+                const double vN = FULLM ? vcur[FULLM ? e : 0] : var[e] * p[e], vT = vTa[e], vL = vLa[e], vR = vRa[e];
                 // NOTE (reference behaviour, kept on purpose): leftmost_p_sum (dir > 0) / rightmost_p_sum
                 // (dir < 0) alias self.p_sum, which line 86 has just updated in place.
                 if (dir > 0) {
@@ -648,8 +670,67 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 for (int e = 0; e < E; ++e)
                     if (lane * E + e < d) sp[lane * E + e] = q[e];
             }
+            if (FULLM && warm && a.cfg.adapt_metric) {
+                // QuadMetricFullAdapt.update: metrics.py:294-324, _WeightedCovariance.add_sample :401-407
+                double fg_n = rfl(scp[BFHIP_SC_FG_N]), bg_n = rfl(scp[BFHIP_SC_BG_N]);
+                double n_samples = rfl(scp[BFHIP_SC_N_SAMPLES]), prev_upd = rfl(scp[BFHIP_SC_PREV_UPDATE]);
+                double adapt_window = rfl(scp[BFHIP_SC_ADAPT_WINDOW]);
+                const long delta = (long)(n_samples - prev_upd);
+                double fm[E], bm[E], od[E], nd[E];
+                load_vec(BFHIP_VEC_FG_MEAN, fm, 0.);
+                load_vec(BFHIP_VEC_BG_MEAN, bm, 0.);
+                double *fgT = matp + BF_MAT_FG * msz, *bgT = matp + BF_MAT_BG * msz, *covT = matp + BF_MAT_COV * msz;
+                fg_n += 1.;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { od[e] = q[e] - fm[e]; fm[e] += od[e] / fg_n; nd[e] = q[e] - fm[e]; }
+                bf_welford_cov<E>(fgT, nd, od, d, lane);
+                bg_n += 1.;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { od[e] = q[e] - bm[e]; bm[e] += od[e] / bg_n; nd[e] = q[e] - bm[e]; }
+                bf_welford_cov<E>(bgT, nd, od, d, lane);
+                if ((delta + 1) % (long)a.cfg.update_window == 0) {  // _update_from_weightvar: :287-292
+                    for (int j = 0; j < d; ++j) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int i = lane * E + e;
+                            if (i < d) covT[(size_t)j * d + i] = fgT[(size_t)j * d + i] / fg_n;
+                        }
+                    }
+                    double *wT = matp + BF_MAT_WORK * msz;
+                    if (bf_chol_rows<E>(covT, wT, d, lane))
+                        bf_chol_publish<E>(wT, matp + BF_MAT_CHOL * msz, matp + BF_MAT_CHOL_ROWS * msz, d, lane);
+                }
+                if ((double)delta >= adapt_window) {
+                    for (int j = 0; j < d; ++j) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int i = lane * E + e;
+                            if (i < d) {
+                                fgT[(size_t)j * d + i] = bgT[(size_t)j * d + i];
+                                bgT[(size_t)j * d + i] = (i == j) ? 10. : 0.;  // _WeightedCovariance(n): 10 I
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { fm[e] = bm[e]; bm[e] = 0.; }
+                    fg_n = bg_n;
+                    bg_n = 10.;
+                    prev_upd = n_samples;
+                    if (a.cfg.doubling) adapt_window *= 2.;
+                }
+                n_samples += 1.;
+                store_vec(BFHIP_VEC_FG_MEAN, fm);
+                store_vec(BFHIP_VEC_BG_MEAN, bm);
+                if (lane == 0) {
+                    scp[BFHIP_SC_FG_N] = fg_n;
+                    scp[BFHIP_SC_BG_N] = bg_n;
+                    scp[BFHIP_SC_N_SAMPLES] = n_samples;
+                    scp[BFHIP_SC_PREV_UPDATE] = prev_upd;
+                    scp[BFHIP_SC_ADAPT_WINDOW] = adapt_window;
+                }
+            }
             // QuadMetricDiagAdapt.update: metrics.py:186-211, _WeightedVariance.add_sample :354-360
-            if (warm && a.cfg.adapt_metric) {
+            if (!FULLM && warm && a.cfg.adapt_metric) {
                 double fg_n = rfl(scp[BFHIP_SC_FG_N]), bg_n = rfl(scp[BFHIP_SC_BG_N]);
                 double n_samples = rfl(scp[BFHIP_SC_N_SAMPLES]), prev_upd = rfl(scp[BFHIP_SC_PREV_UPDATE]);
                 double adapt_window = rfl(scp[BFHIP_SC_ADAPT_WINDOW]);
@@ -730,6 +811,10 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 if (lev == 0) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) { L0p[e] = p[e]; L0q[e] = q[e]; }  // stack level 0 lives in registers
+                    if constexpr (FULLM) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) L0v[e] = vcur[e];
+                    }
                 } else {
                     const int slot = SL_STACK + 4 * lev;
                     stv(slot + 0, TLp); stv(slot + 1, p); stv(slot + 2, TPs); stv(slot + 3, TPq);
@@ -799,10 +884,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 eps_t = (mode == M_LEAF) ? eps * (double)dir : 0.;
                 const double dt = 0.5 * eps_t;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    p[e] = p[e] + dt * g[e];               // integration.py:80
-                    q[e] = q[e] + eps_t * (var[e] * p[e]); // :82-85
-                }
+                for (int e = 0; e < E; ++e) p[e] = p[e] + dt * g[e];  // integration.py:80
+                double vh[E];
+                velocity(p, vh);                                       // :82
+#pragma unroll
+                for (int e = 0; e < E; ++e) q[e] = q[e] + eps_t * vh[e];  // :85
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -948,7 +1034,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         double kin_fast = 0.;
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
-            const bool fast_kin = !f_decay && mode != M_OOB;
+            const bool fast_kin = !FULLM && !f_decay && mode != M_OOB;
             double xev[E], r_cub = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1056,8 +1142,15 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 p[e] = p[e] + dt * gn[e];        // integration.py:90
-                kin += p[e] * (var[e] * p[e]);   // metrics.py:88-91
                 g[e] = gn[e];
+            }
+            if constexpr (FULLM) {
+                velocity(p, vcur);               // integration.py:92
+#pragma unroll
+                for (int e = 0; e < E; ++e) kin += p[e] * vcur[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) kin += p[e] * (var[e] * p[e]);   // metrics.py:88-91
             }
             kin = kin_ready ? kin_fast : wave_sum(kin);
             E_new = 0.5 * kin - logp_new;        // integration.py:92-93
@@ -1123,21 +1216,21 @@ static int sampler_gb_slots(const DevModel &m) {
     return n_mat * sampler_ksplit(m) > 1 ? n_mat * sampler_ksplit(m) : 1;
 }
 
-static size_t sampler_lds_bytes(const DevModel &m) {
+static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
     const int W = m.DP / 16, DP = m.DP, NS = 4 * W;
     size_t dbl = (size_t)3 * NS * 65 + (size_t)sampler_gb_slots(m) * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 +
                  (size_t)16 * CS_N + (size_t)PD_N * DP;
-    if (DP <= 64 && sampler_plain(m))  // A operands in registers; row-major S, H and plain x for the VALU matvec
+    if (DP <= 64 && plain)  // A operands in registers; row-major S, H and plain x for the VALU matvec
         dbl += (size_t)2 * DP * (DP + 2) + (size_t)2 * 16 * DP;
     else if (DP <= 64)
         dbl += (size_t)DP * DP * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
     return dbl * sizeof(double);
 }
 
-template <int W, bool NUTS, bool STAMPS, bool PLAIN>
+template <int W, bool NUTS, bool STAMPS, bool PLAIN, bool FULLM = false>
 static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
-    auto k = bf_sampler_kernel<W, NUTS, STAMPS, PLAIN>;
-    const size_t lds = sampler_lds_bytes(ctx->model);
+    auto k = bf_sampler_kernel<W, NUTS, STAMPS, PLAIN, FULLM>;
+    const size_t lds = sampler_lds_bytes(ctx->model, PLAIN);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + 15) / 16;
@@ -1153,7 +1246,8 @@ extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
-    const bool plain = sampler_plain(m);
+    const bool plain = sampler_plain(m) && !args.mat;
+    if (args.mat) return launch_sampler_t<W, NUTS, false, false, true>(ctx, args);
 #ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
         return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS)>(ctx, args)
@@ -1195,6 +1289,8 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.stats = stats;
     args.n_leapfrog = n_leapfrog;
     args.stamps = g_stamps;
+    args.mat = (cfg->full_metric && cfg->metric_mat) ? cfg->metric_mat : NULL;
+    if (cfg->full_metric && !cfg->metric_mat) return bf_set_error(BFHIP_ERR_ARG, "bfhip_sampler_run: full_metric without metric_mat");
     const size_t need = (size_t)((n_chain + 15) / 16 * 16) * args.nslot * m.DP * sizeof(double);
     if (ctx->scratch_bytes < need) {  // grow-only workspace; allocation is outside any timed region after the first call
         BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1215,4 +1311,46 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     case 4: return nuts ? launch_sampler<4, true>(ctx, args) : launch_sampler<4, false>(ctx, args);
     }
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", m.DP);
+}
+
+
+// ---- full-rank metric initialisation (one wave per chain) ------------------------------------------
+template <int E>
+__global__ __launch_bounds__(64) void bf_metric_init_full_kernel(int n_chain, int d, const double *cov0, double initial_weight,
+                                                               double *sc, double *mat) {
+    const int chain = blockIdx.x, lane = threadIdx.x;
+    if (chain >= n_chain) return;
+    const size_t msz = (size_t)d * d;
+    double *mp = mat + (size_t)chain * BF_MAT_N * msz;
+    double *covT = mp + BF_MAT_COV * msz, *fgT = mp + BF_MAT_FG * msz, *bgT = mp + BF_MAT_BG * msz, *wT = mp + BF_MAT_WORK * msz;
+    for (int j = 0; j < d; ++j) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) {
+                const double c = cov0 ? cov0[(size_t)i * d + j] : (i == j ? 1. : 0.);  // cov[i][j] -> covT[j][i]
+                covT[(size_t)j * d + i] = c;
+                fgT[(size_t)j * d + i] = c * initial_weight;   // _WeightedCovariance(n, mean, cov, weight): metrics.py:382-395
+                bgT[(size_t)j * d + i] = (i == j) ? 10. : 0.;  // _WeightedCovariance(n)
+            }
+        }
+    }
+    if (bf_chol_rows<E>(covT, wT, d, lane)) {
+        bf_chol_publish<E>(wT, mp + BF_MAT_CHOL * msz, mp + BF_MAT_CHOL_ROWS * msz, d, lane);
+    } else if (lane == 0) {
+        sc[(size_t)chain * BFHIP_SC_N + BFHIP_SC_ERROR] = 3.;
+    }
+}
+
+extern "C" int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const double *cov0, double initial_weight,
+                                      double *sc, double *mat) {
+    if (!ctx || n_chain < 0 || d <= 0 || d > BFHIP_MAX_DIM || (n_chain > 0 && (!sc || !mat)))
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_metric_init_full: invalid argument");
+    if (n_chain == 0) return 0;
+    if (d <= 64)
+        hipLaunchKernelGGL(bf_metric_init_full_kernel<1>, dim3(n_chain), dim3(64), 0, ctx->stream, n_chain, d, cov0, initial_weight, sc, mat);
+    else
+        hipLaunchKernelGGL(bf_metric_init_full_kernel<2>, dim3(n_chain), dim3(64), 0, ctx->stream, n_chain, d, cov0, initial_weight, sc, mat);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
 }

@@ -47,16 +47,15 @@ class _HTrace:
         self._step_size = step_size
         self._adapt_step_size = bool(adapt_step_size)
         if isinstance(metric, str):
-            if metric == 'full':
-                raise NotImplementedError('the full-rank metric is not implemented on device yet.')
-            if metric != 'diag':
+            if metric not in ('diag', 'full'):
                 raise ValueError('invalid value for metric.')
-            self._metric = None
+            self._metric = None if metric == 'diag' else 'full'  # 'full': QuadMetricFullAdapt from the identity
         else:
             metric = np.asarray(metric, dtype=np.float64)
-            if metric.ndim == 2:
-                raise NotImplementedError('the full-rank metric is not implemented on device yet.')
-            if metric.ndim != 1 or not np.all(metric > 0):
+            n = metric.shape[0] if metric.ndim else 0
+            if not (metric.shape == (n,) or metric.shape == (n, n)):  # samplers/sample_trace.py:382-388
+                raise ValueError('invalid value for metric.')
+            if metric.ndim == 1 and not np.all(metric > 0):
                 raise ValueError('invalid value for metric.')
             self._metric = metric
         self._adapt_metric = bool(adapt_metric)
@@ -282,7 +281,7 @@ def _get_metric(sample_trace, target, from_samples=True):
     else:
         if sample_trace._chains is None:
             raise ValueError('invalid value for sample_trace.')
-        cov = np.diag(sample_trace._chains.field('var').cpu().numpy().mean(0))
+        cov = sample_trace._chains.covariance().cpu().numpy().mean(0)
     if target == 'diag':
         return np.diag(cov)
     if target == 'full':

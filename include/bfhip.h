@@ -123,7 +123,18 @@ typedef struct {
     int adapt_metric;
     int update_window;
     int doubling;
+    /* Full-rank metric, QuadMetricFull / QuadMetricFullAdapt (samplers/hmc_utils/metrics.py:94-132,240-330).
+     * 0 / NULL: the diagonal metric of `vec`.  Otherwise metric_mat points to the per-chain matrices filled by
+     * bfhip_metric_init_full, (n_chain, BFHIP_MAT_N, d, d) doubles on the device; adapt_metric chooses between the
+     * fixed (QuadMetricFull) and the adaptive (QuadMetricFullAdapt) variant exactly as for the diagonal metric. */
+    int full_metric;
+    double *metric_mat;
 } bfhip_sampler_config;
+
+/* matrices per chain for the full-rank metric (layout documented in bayesfast_amd/csrc/bfhip_metric.h; slot
+ * BFHIP_MAT_COV holds the covariance transposed, i.e. as is for a symmetric matrix) */
+#define BFHIP_MAT_COV 0
+#define BFHIP_MAT_N 6
 
 /* Layout of the per-chain scalar state array `sc` (C, BFHIP_SC_N) float64 */
 enum {
@@ -138,7 +149,7 @@ enum {
     BFHIP_SC_PREV_UPDATE,    /* _previous_update */
     BFHIP_SC_ADAPT_WINDOW,   /* _adapt_window (doubles when `doubling`) */
     BFHIP_SC_I_ITER,         /* iterations done (len(trace._samples)) */
-    BFHIP_SC_ERROR,          /* 0 ok; 1 bad initial energy (base_hmc.py:72-76); 2 logbern(NaN) (nuts.py:201-202) */
+    BFHIP_SC_ERROR,          /* 0 ok; 1 bad initial energy (base_hmc.py:72-76); 2 logbern(NaN) (nuts.py:201-202); 3 metric covariance not positive definite (metrics.py:107-108) */
     BFHIP_SC_N
 };
 
@@ -187,6 +198,14 @@ int bfhip_rng_seed(bfhip_ctx *ctx, int n_chain, uint64_t seed, uint64_t first_st
 int bfhip_chain_init(bfhip_ctx *ctx, int n_chain, int d, const double *x0, double step_size,
                      const double *metric_var, const double *initial_mean, double initial_weight,
                      int adapt_window, double *sc, double *vec);
+
+/* Full-rank metric for fresh chains: _set_metric_2 with a 2-d metric (samplers/sample_trace.py:424-455),
+ * QuadMetricFull.__init__ / QuadMetricFullAdapt.__init__ (metrics.py:103-111,261-285).
+ * cov0 (d,d) row-major or NULL (identity), shared by all chains; mat (C, BFHIP_MAT_N, d, d).  Call after
+ * bfhip_chain_init (the Welford means and weights live in sc/vec).  A cov0 that is not positive definite sets
+ * sc[:, BFHIP_SC_ERROR] = 3 for every chain (the reference raises ValueError, metrics.py:107-108). */
+int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const double *cov0, double initial_weight,
+                           double *sc, double *mat);
 
 /* ------------------------------------------------------------------------------------------------
  * Surrogate fit, PolyModel.fit (modules/poly.py:505-589).

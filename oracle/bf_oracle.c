@@ -601,10 +601,9 @@ static void metric_random(const bfo_chain *c, bfo_rng *rng, double *p) {
         for (int i = 0; i < d; ++i) p[i] = c->inv_std[i] * p[i];
         return;
     }
-    for (int i = d - 1; i >= 0; --i) {  /* L^T p = z, back substitution */
-        double s = p[i];
-        for (int j = i + 1; j < d; ++j) s -= c->chol[j * d + i] * p[j];
-        p[i] = s / c->chol[i * d + i];
+    for (int j = d - 1; j >= 0; --j) {  /* L^T p = z: the column sweep of BLAS dtrsv (upper, no transpose) */
+        p[j] = p[j] / c->chol[j * d + j];
+        for (int i = 0; i < j; ++i) p[i] -= c->chol[j * d + i] * p[j];
     }
 }
 

@@ -308,3 +308,33 @@ def test_config5_128d_cubic_cross_surrogate():
     tr = NTrace(n_chain=40, n_iter=12, n_warmup=8, x_0=x_fit[:40] * 0.3, random_generator=12)
     tt = sample(den, tr, verbose=False)
     _compare_chains_with_oracle(tt, den, 12, (0, 17, 39), 12, 8)
+
+
+def test_sample_with_full_rank_metric_recovers_a_correlated_gaussian():
+    """T2 for the full-rank metric through the public entry point: sample(density, NTrace(metric='full')) on an
+    exactly quadratic, strongly correlated target; the adapted metric approaches the target covariance and the
+    posterior moments come out right (a diagonal metric would need far longer trees here)."""
+    from bayesfast_amd import PolyModel, SurrogateDensity, sample, NTrace
+    from bayesfast_amd.samplers.sample_trace import _get_metric
+    d = 12
+    rng = np.random.default_rng(77)
+    B = rng.normal(size=(d, d))
+    cov = B @ B.T / d + 0.05 * np.eye(d)          # condition number of a few hundred
+    prec = np.linalg.inv(cov)
+    su = PolyModel('quadratic', input_size=d, output_size=1, bound_options=dict(use_bound=False))
+    den = SurrogateDensity(su)
+    x_fit = rng.normal(size=(3 * su.n_param, d)) @ np.linalg.cholesky(cov).T
+    den.fit(x_fit, -0.5 * np.einsum('ni,ij,nj->n', x_fit, prec, x_fit))
+    tr = NTrace(n_chain=512, n_iter=260, n_warmup=160, x_0=x_fit[:512], random_generator=21, metric='full')
+    tt = sample(den, tr, verbose=False)
+    draws = tt.get().reshape(-1, d)
+    assert tt.stat('diverging')[:, 160:].sum() == 0
+    assert tt.stat('tree_size')[:, 160:].mean() < 12       # a well-adapted full metric needs short trajectories
+    sd = np.sqrt(np.diag(cov))
+    n_eff = 512 * 100 / 4.
+    assert np.all(np.abs(draws.mean(0)) < 5 * sd / np.sqrt(n_eff))
+    emp = np.cov(draws, rowvar=False)
+    assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.04
+    m = _get_metric(tt, 'full', from_samples=False)          # mean over chains of the adapted covariances
+    assert m.shape == (d, d)
+    assert np.max(np.abs(m - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.25

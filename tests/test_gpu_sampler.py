@@ -265,3 +265,58 @@ def test_cubic_configs_eval_and_nuts(ctx):
     dev = _device_chains(ctx, spec, x0, 25, 15)
     orc_runs = _oracle_chains(spec, x0, 25, 15)
     _compare_nuts(dev, orc_runs, 25)
+
+
+# ---- full-rank metric: QuadMetricFull / QuadMetricFullAdapt (samplers/hmc_utils/metrics.py:94-132,240-330) -----
+
+def _full_metric_compare(ctx, spec, x0, n_iter, n_warmup, sampler, chain_kw, n_head=6, tol=2e-3, n_exact=None):
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd import _lib
+    from oracle import oracle as orc
+    dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=SEED, **{k: v for k, v in chain_kw.items() if k != 'adapt_metric'})
+    s, st = dc.run(n_iter, sampler, n_warmup=n_warmup, n_int_step=8,
+                   **{k: v for k, v in chain_kw.items() if k in ('adapt_metric',)})
+    s, st = s.cpu().numpy(), st.cpu().numpy()
+    cov = dc.covariance().cpu().numpy()
+    names = _lib.NSTATS if sampler == 'NUTS' else _lib.HSTATS
+    for i in range(x0.shape[0]):
+        ch = orc.Chain(x0[i], **chain_kw)
+        rng = orc.make_rng('xoshiro', seed=SEED, stream=i)
+        if sampler == 'NUTS':
+            so, sto = orc.nuts_run(spec, ch, rng, n_iter, n_warmup)
+            for f in ('tree_depth', 'tree_size', 'diverging'):
+                assert np.array_equal(st[i, :n_exact, names.index(f)], sto[f][:n_exact]), (i, f)
+        else:
+            so, sto = orc.hmc_run(spec, ch, rng, n_iter, n_warmup, n_int_step=8)
+            assert np.array_equal(st[i, :, names.index('accepted')], sto['accepted']), i
+        np.testing.assert_allclose(s[i, :n_head], so[:n_head], rtol=1e-9, atol=1e-9)
+        if np.isfinite(tol):
+            np.testing.assert_allclose(s[i], so, rtol=tol, atol=tol)
+            np.testing.assert_allclose(cov[i], ch.mat('cov'), rtol=tol, atol=tol)
+
+
+def test_full_metric_adaptive_and_fixed_match_oracle(ctx):
+    """Device chains with the full-rank metric against the oracle (itself pinned to the reference's trajectories by
+    tests/golden/sampler_fullmetric.npz): adaptive from the identity (window switch and doubling inside the
+    warm-up), adaptive from a given covariance, and fixed; NUTS and HMC."""
+    from specio import rebuild_spec
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'sampler_fullmetric.npz'))
+    spec = rebuild_spec(z, 'fm8.')
+    cov0 = z['fm8.cov0']
+    x0 = np.random.default_rng(4).normal(size=(5, 8)) * 0.5
+    _full_metric_compare(ctx, spec, x0, 40, 28, 'NUTS', dict(metric='full', adapt_window=8))
+    _full_metric_compare(ctx, spec, x0, 30, 20, 'NUTS', dict(metric=cov0, adapt_metric=False))
+    _full_metric_compare(ctx, spec, x0, 30, 20, 'HMC', dict(metric=cov0, adapt_window=8), tol=1e-2)
+
+
+def test_full_metric_64d_and_bad_covariance(ctx, samp):
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    spec = _spec(samp, 'd64.')
+    x0 = np.random.default_rng(6).normal(size=(18, 64)) * 0.5
+    # 64-d trees are hundreds of leapfrogs long while the covariance estimate is still rough: the discrete fields
+    # are compared on the first iterations, the positions on the head (rounding differences amplify after that)
+    _full_metric_compare(ctx, spec, x0[:3], 14, 10, 'NUTS', dict(metric='full'), n_head=5, tol=np.inf, n_exact=8)
+    with pytest.raises(ValueError):
+        DeviceChains(DeviceDensity(spec, ctx), x0, metric=-np.eye(64))

@@ -80,8 +80,9 @@ def test_trace_options_validation_and_defaults():
                 dict(step_size=-1.), dict(target_accept=1.5), dict(max_change=0.), dict(metric='banana')):
         with pytest.raises(ValueError):
             NTrace(**bad)
-    with pytest.raises(NotImplementedError):
-        NTrace(metric='full')
+    assert NTrace(metric='full')._metric == 'full' and NTrace(metric=np.eye(3))._metric.shape == (3, 3)
+    with pytest.raises(ValueError):
+        NTrace(metric=np.ones((2, 3)))
     assert NTrace(random_generator=7).seed() == 7
 
 
