@@ -101,3 +101,8 @@ struct bfhip_ctx {
     size_t scratch_bytes;
     int n_cu;
 };
+
+// the common surrogate: linear + quadratic configs with the extrapolation bound and nothing else
+static inline bool bf_model_plain(const DevModel &m) {
+    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic;
+}

@@ -98,13 +98,23 @@ __device__ inline double bf_sum_g(double v) {
 
 // Density.logp_and_grad (core/density.py:724-754) for the 16 points of the wave.
 // x: own elements of the input (transformed space unless original_space); padded dims hold 0.
-template <int T>
-__device__ inline void bf_eval_w1(const DevModel &m, const double *Sf, const double *Hf, const double *Hdf,
+// PL fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the bound;
+// no transform, input scaling, decay or cubic configs: bf_model_plain), which removes the optional features'
+// register arrays -- at d = 128 the generic instantiation spills, the plain one does not.
+template <int T, bool PL = false>
+__device__ inline void bf_eval_w1(const DevModel &mm, const double *Sf, const double *Hf, const double *Hdf,
                                   const double *pd, int original_space, const double (&x)[4 * T], double &logp,
                                   double (&grad)[4 * T], int lane, double *xst /* wave-private LDS [16][DP], cubic only */) {
     constexpr int E = 4 * T;
     const int DP = 16 * T;
     const int g = lane >> 4;
+    struct Flags {  // the model's switches, constants when PL
+        bool has_transform, has_su, use_decay, has_cubic, has_quad, use_bound;
+        double c0, alpha, f_mu, decay_gamma, decay_alpha2;
+    };
+    const Flags m = {PL ? false : (bool)mm.has_transform, PL ? false : (bool)mm.has_su, PL ? false : (bool)mm.use_decay,
+                     PL ? false : (bool)mm.has_cubic, PL ? true : (bool)mm.has_quad, PL ? true : (bool)mm.use_bound,
+                     mm.c0, mm.alpha, mm.f_mu, mm.decay_gamma, mm.decay_alpha2};
     const bool tr = m.has_transform && !original_space;
     double xs[E], jac[E], gj[E], hv[E];
     double logdet = 0.;
@@ -163,7 +173,7 @@ __device__ inline void bf_eval_w1(const DevModel &m, const double *Sf, const dou
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             double gc, fc;
-            bf_cubic_grad(m, 4 * e + g, xe[e], [&](int k) { return xst[pc * DP + k]; }, gc, fc);
+            bf_cubic_grad(mm, 4 * e + g, xe[e], [&](int k) { return xst[pc * DP + k]; }, gc, fc);
             ge[e] += gc;
             fsum += fc;
         }

@@ -44,7 +44,7 @@ static size_t bf_eval_lds_bytes(const DevModel &m) {  // + the wave-private coor
 }
 
 // Density.logp_and_grad over n points; replaces the per-row Python recursion of core/density.py:523-525.
-template <int T, bool STAGE>
+template <int T, bool STAGE, bool PL>
 __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int stage_dbl, int n, const double *__restrict__ x,
                                                            int original_space, double *__restrict__ logp,
                                                            double *__restrict__ grad) {
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int stage
             const int dim = 4 * e + g;
             xv[e] = (pt < n && dim < m.d) ? x[(size_t)pt * m.d + dim] : 0.;
         }
-        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, original_space, xv, lp, gv, lane, xst);
+        bf_eval_w1<T, PL>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, original_space, xv, lp, gv, lane, xst);
         if (pt < n) {
             if (g == 0) logp[pt] = lp;
             if (grad) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int stage
 }
 
 // CpuLeapfrogIntegrator._step (samplers/hmc_utils/integration.py:68-95), diagonal metric, n chains.
-template <int T, bool STAGE>
+template <int T, bool STAGE, bool PL>
 __global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int stage_dbl, int n, const double *__restrict__ eps,
                                                           const double *__restrict__ var, double *__restrict__ q,
                                                           double *__restrict__ p, double *__restrict__ grad,
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int stage_
             pn[e] = pp + dt * gg;              // integration.py:80
             qn[e] = qq + ep * (vr[e] * pn[e]); // :82-85
         }
-        bf_eval_w1<T>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, 0, qn, lp, gn, lane, xst);  // :87
+        bf_eval_w1<T, PL>(m, sm.Sf, sm.Hf, sm.Hdf, sm.pd, 0, qn, lp, gn, lane, xst);  // :87
         double kin = 0.;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -147,10 +147,16 @@ static int bf_set_lds(K kern, size_t bytes) {
 template <int T, bool STAGE>
 static int launch_logp_grad(bfhip_ctx *ctx, int grid, size_t lds, int n, const double *x, int original_space,
                             double *logp, double *grad) {
-    auto k = bf_logp_grad_kernel<T, STAGE>;
-    if (int rc = bf_set_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, (int)(bf_stage_bytes(ctx->model) / sizeof(double)),
-                       n, x, original_space, logp, grad);
+    const int sd = (int)(bf_stage_bytes(ctx->model) / sizeof(double));
+    if (T <= 4 && bf_model_plain(ctx->model)) {  // at d = 128 the plain instantiation schedules worse (more spills)
+        auto k = bf_logp_grad_kernel<T, STAGE, (T <= 4)>;
+        if (int rc = bf_set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, sd, n, x, original_space, logp, grad);
+    } else {
+        auto k = bf_logp_grad_kernel<T, STAGE, false>;
+        if (int rc = bf_set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, sd, n, x, original_space, logp, grad);
+    }
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -158,10 +164,16 @@ static int launch_logp_grad(bfhip_ctx *ctx, int grid, size_t lds, int n, const d
 template <int T, bool STAGE>
 static int launch_leapfrog(bfhip_ctx *ctx, int grid, size_t lds, int n, const double *eps, const double *var, double *q,
                            double *p, double *grad, double *logp, double *energy, double *vel) {
-    auto k = bf_leapfrog_kernel<T, STAGE>;
-    if (int rc = bf_set_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, (int)(bf_stage_bytes(ctx->model) / sizeof(double)),
-                       n, eps, var, q, p, grad, logp, energy, vel);
+    const int sd = (int)(bf_stage_bytes(ctx->model) / sizeof(double));
+    if (T <= 4 && bf_model_plain(ctx->model)) {
+        auto k = bf_leapfrog_kernel<T, STAGE, (T <= 4)>;
+        if (int rc = bf_set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, sd, n, eps, var, q, p, grad, logp, energy, vel);
+    } else {
+        auto k = bf_leapfrog_kernel<T, STAGE, false>;
+        if (int rc = bf_set_lds(k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, ctx->stream, ctx->model, sd, n, eps, var, q, p, grad, logp, energy, vel);
+    }
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

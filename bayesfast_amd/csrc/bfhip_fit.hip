@@ -8,6 +8,10 @@
 #include <vector>
 #include "bfhip_common.h"
 
+__device__ inline double bf_readlane(double v, int l) {  // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // design blocks: modules/_poly.pyx:143-177 (+ the [1 | x] block of modules/poly.py:537-543)
 // ---------------------------------------------------------------------------------------------------
@@ -142,14 +146,26 @@ __global__ void bf_gram_reduce_kernel(int P, int nb, int split, const double *__
     }
 }
 
-// r = A^T B: one thread per column of A, rows in order (deterministic); B (n, m) row-major, m small
+// r = A^T B in two deterministic passes: partial sums over NSEG row segments (one thread per column and segment,
+// rows in order), then the segments in order.  B (n, m) row-major, m small.
+#define ATB_SEG_ 32
 __global__ void bf_atb_kernel(int n, int P, int m, const double *__restrict__ A, int lda, const double *__restrict__ B,
-                              double *__restrict__ r) {
+                              double *__restrict__ part) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, sg = blockIdx.z;
+    if (j >= P) return;
+    const int rows = (n + ATB_SEG_ - 1) / ATB_SEG_;
+    const int i0 = sg * rows, i1 = min(n, i0 + rows);
+    double s = 0.;
+    for (int i = i0; i < i1; ++i) s += A[(size_t)i * lda + j] * B[(size_t)i * m + c];
+    part[((size_t)sg * m + c) * P + j] = s;
+}
+__global__ void bf_atb_reduce_kernel(int P, int m, const double *__restrict__ part, double *__restrict__ r) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (j >= P) return;
     double s = 0.;
-    for (int i = 0; i < n; ++i) s += A[(size_t)i * lda + j] * B[(size_t)i * m + c];
+    for (int sg = 0; sg < ATB_SEG_; ++sg) s += part[((size_t)sg * m + c) * P + j];
     r[(size_t)j * m + c] = s;
 }
 
@@ -174,13 +190,18 @@ extern "C" int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, 
     if (split < 1) split = 1;
     if (split > 16) split = 16;
     if (split > (n + 63) / 64) split = (n + 63) / 64;
-    const size_t need = (size_t)split * n_blk * GB_ * GB_ * sizeof(double);
+    size_t need = (size_t)split * n_blk * GB_ * GB_ * sizeof(double);
+    const size_t need_atb = (size_t)ATB_SEG_ * (m > 0 ? m : 1) * P * sizeof(double);
+    if (need < need_atb) need = need_atb;
     if (int rc = ensure_scratch(ctx, need)) return rc;
     double *part = (double *)ctx->scratch;
     const int waves = n_blk * split;
     hipLaunchKernelGGL(bf_gram_kernel, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, n, P, A, lda, nb, split, part);
     hipLaunchKernelGGL(bf_gram_reduce_kernel, dim3(n_blk), dim3(256), 0, ctx->stream, P, nb, split, part, G);
-    if (m > 0) hipLaunchKernelGGL(bf_atb_kernel, dim3((P + 127) / 128, m), dim3(128), 0, ctx->stream, n, P, m, A, lda, B, r);
+    if (m > 0) {  // (the Gram partials have been consumed by the reduce kernel: the scratch is free again)
+        hipLaunchKernelGGL(bf_atb_kernel, dim3((P + 127) / 128, m, ATB_SEG_), dim3(128), 0, ctx->stream, n, P, m, A, lda, B, part);
+        hipLaunchKernelGGL(bf_atb_reduce_kernel, dim3((P + 127) / 128, m), dim3(128), 0, ctx->stream, P, m, part, r);
+    }
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -210,64 +231,89 @@ __global__ void bf_unscale_kernel(int P, int m, double *__restrict__ r, const do
         for (int c = 0; c < m; ++c) r[(size_t)i * m + c] *= dsc[i];
 }
 
-// Cholesky of the NB x NB diagonal block at (k0, k0), in LDS; info = first non-positive pivot (1-based)
-__global__ void bf_chol_diag_kernel(int P, int k0, double *__restrict__ G, int *__restrict__ info) {
+// Cholesky of the NB x NB diagonal block at (k0, k0) by ONE wave (lane = row, left-looking, block in LDS), followed
+// by the inverse of the factor (forward substitution on the identity, lane = column), which turns the panel solve
+// below into a small matrix product.  info = first pivot below the threshold (1-based).
+__global__ __launch_bounds__(64) void bf_chol_diag_kernel(int P, int k0, double *__restrict__ G, double *__restrict__ Linv,
+                                                         int *__restrict__ info) {
     __shared__ double L[NB_][NB_ + 1];
+    __shared__ double X[NB_][NB_ + 1];
     const int nbk = min(NB_, P - k0);
     const int t = threadIdx.x;
-    for (int e = t; e < NB_ * NB_; e += blockDim.x) {
-        const int i = e / NB_, j = e % NB_;
-        L[i][j] = (i < nbk && j < nbk) ? G[(size_t)(k0 + i) * P + k0 + j] : (i == j ? 1. : 0.);
-    }
-    __syncthreads();
+    for (int i = 0; i < NB_; ++i)  // row i: one coalesced 512-byte read
+        L[i][t] = (i < nbk && t < nbk) ? G[(size_t)(k0 + i) * P + k0 + t] : (i == t ? 1. : 0.);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < nbk; ++j) {
-        if (t == 0) {
-            const double djj = L[j][j];
-            // the matrix is equilibrated (unit diagonal): a pivot below 1e-13 means a numerically rank
-            // deficient design matrix (condition number of the normal equations beyond double precision)
-            if (!(djj > 1e-13)) {
-                if (*info == 0) *info = k0 + j + 1;
-                L[j][j] = 1.;
-            } else {
-                L[j][j] = sqrt(djj);
-            }
+        // lane i >= j: a[i][j] - sum_{k<j} L[i][k] L[j][k]
+        double acc = L[t][j];
+#pragma unroll 8
+        for (int k = 0; k < j; ++k) acc -= L[t][k] * L[j][k];
+        double djj = bf_readlane(acc, j);
+        // the matrix is equilibrated (unit diagonal): a pivot below 1e-13 means a numerically rank deficient design
+        // matrix (condition number of the normal equations beyond double precision)
+        if (!(djj > 1e-13)) {
+            if (t == 0 && *info == 0) *info = k0 + j + 1;
+            djj = 1.;
         }
-        __syncthreads();
-        const double ljj = L[j][j];
-        for (int i = j + 1 + t; i < nbk; i += blockDim.x) L[i][j] /= ljj;
-        __syncthreads();
-        // trailing update of the lower triangle
-        for (int e = t; e < (nbk - j - 1) * (nbk - j - 1); e += blockDim.x) {
-            const int i = j + 1 + e / (nbk - j - 1), c = j + 1 + e % (nbk - j - 1);
-            if (c <= i) L[i][c] -= L[i][j] * L[c][j];
+        const double ljj = sqrt(djj);
+        __builtin_amdgcn_wave_barrier();
+        if (t == j) L[t][j] = ljj;
+        else if (t > j) L[t][j] = acc / ljj;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = 0; i < NB_; ++i)
+        if (i < nbk && t < nbk) G[(size_t)(k0 + i) * P + k0 + t] = t <= i ? L[i][t] : 0.;
+    // X = L^-1: lane c solves L x = e_c
+    for (int j = 0; j < NB_; ++j) {
+        double sacc = (j == t) ? 1. : 0.;
+        if (j >= t) {
+#pragma unroll 8
+            for (int k = t; k < j; ++k) sacc -= L[j][k] * X[k][t];
+            sacc /= L[j][j];
+        } else {
+            sacc = 0.;
         }
-        __syncthreads();
+        X[j][t] = sacc;
     }
-    for (int e = t; e < NB_ * NB_; e += blockDim.x) {
-        const int i = e / NB_, j = e % NB_;
-        if (i < nbk && j < nbk) G[(size_t)(k0 + i) * P + k0 + j] = j <= i ? L[i][j] : 0.;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < NB_; ++i) Linv[i * NB_ + t] = X[i][t];
 }
 
-// panel: rows below the diagonal block, X L11^T = A21 (one thread per row, L11 in LDS)
-__global__ void bf_chol_trsm_kernel(int P, int k0, double *__restrict__ G) {
-    __shared__ double L[NB_][NB_ + 1];
+// panel: rows below the diagonal block, X = A21 L11^-T = A21 (L11^-1)^T: 64-row tiles, each thread 16 outputs
+__global__ __launch_bounds__(256) void bf_chol_trsm_kernel(int P, int k0, double *__restrict__ G, const double *__restrict__ Linv) {
+    __shared__ double Li[NB_][NB_ + 1];
+    __shared__ double At[NB_][NB_ + 1];
     const int nbk = min(NB_, P - k0);
-    for (int e = threadIdx.x; e < NB_ * NB_; e += blockDim.x) {
-        const int i = e / NB_, j = e % NB_;
-        L[i][j] = (i < nbk && j < nbk) ? G[(size_t)(k0 + i) * P + k0 + j] : 0.;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int r0 = k0 + nbk + blockIdx.x * NB_;
+    for (int i = wv; i < NB_; i += 4) {
+        Li[i][lane] = Linv[i * NB_ + lane];
+        const int row = r0 + i;
+        At[i][lane] = (row < P && lane < nbk) ? G[(size_t)row * P + k0 + lane] : 0.;
     }
     __syncthreads();
-    const int row = k0 + nbk + blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= P) return;
-    double *a = G + (size_t)row * P + k0;
-    double xr[NB_];
-    for (int j = 0; j < nbk; ++j) {
-        double s = a[j];
-        for (int c = 0; c < j; ++c) s -= xr[c] * L[j][c];
-        xr[j] = s / L[j][j];
+    // thread (row = lane, columns wv*16 .. wv*16+15):  X[row][j] = sum_{k <= j} A[row][k] Linv[j][k]
+    const int row = r0 + lane;
+    double out[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = wv * 16 + jj;
+        double sacc = 0.;
+        for (int k = 0; k <= j; ++k) sacc += At[lane][k] * Li[j][k];
+        out[jj] = sacc;
     }
-    for (int j = 0; j < nbk; ++j) a[j] = xr[j];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) At[lane][wv * 16 + jj] = out[jj];
+    __syncthreads();
+    for (int i = wv; i < NB_; i += 4) {
+        const int rr = r0 + i;
+        if (rr < P && lane < nbk) G[(size_t)rr * P + k0 + lane] = At[i][lane];
+    }
+    (void)row;
 }
 
 // trailing update A22 -= L21 L21^T on MFMA, lower-triangular 64 x 64 blocks, one wave per block
@@ -316,88 +362,120 @@ __global__ __launch_bounds__(256) void bf_chol_syrk_kernel(int P, int k0, double
             }
 }
 
-// forward substitution L y = r over one diagonal block + update of the rows below (one workgroup)
-__global__ void bf_trsv_fwd_kernel(int P, int m, int k0, const double *__restrict__ G, double *__restrict__ r) {
-    __shared__ double L[NB_][NB_ + 1];
-    __shared__ double y[NB_];
-    const int nbk = min(NB_, P - k0);
-    const int t = threadIdx.x;
-    for (int e = t; e < NB_ * NB_; e += blockDim.x) {
-        const int i = e / NB_, j = e % NB_;
-        L[i][j] = (i < nbk && j < nbk) ? G[(size_t)(k0 + i) * P + k0 + j] : 0.;
-    }
-    for (int c = 0; c < m; ++c) {
-        __syncthreads();
-        if (t < nbk) y[t] = r[(size_t)(k0 + t) * m + c];
-        __syncthreads();
-        for (int j = 0; j < nbk; ++j) {
-            if (t == 0) y[j] /= L[j][j];
-            __syncthreads();
-            if (t > j && t < nbk) y[t] -= L[t][j] * y[j];
-            __syncthreads();
-        }
-        if (t < nbk) r[(size_t)(k0 + t) * m + c] = y[t];
-        // rows below: r_i -= L[i, k0:k0+nbk] . y
-        for (int i = k0 + nbk + t; i < P; i += blockDim.x) {
-            const double *li = G + (size_t)i * P + k0;
-            double s = 0.;
-            for (int j = 0; j < nbk; ++j) s += li[j] * y[j];
-            r[(size_t)i * m + c] -= s;
-        }
-    }
+// L y = r then L^T x = y in ONE launch of one 1024-thread workgroup (the right-hand side lives in LDS); per 64-block
+// wave 0 solves the diagonal block by substitution, then all 16 waves sweep the rows below / above it with coalesced
+// 512-byte row reads.  Summation orders are fixed.
+template <int CTRL>
+__device__ inline double bf_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-
-// backward substitution L^T c = y, blocks from the bottom up
-__global__ void bf_trsv_bwd_kernel(int P, int m, int k0, const double *__restrict__ G, double *__restrict__ r) {
-    __shared__ double L[NB_][NB_ + 1];
-    __shared__ double y[NB_];
-    const int nbk = min(NB_, P - k0);
-    const int t = threadIdx.x;
-    for (int e = t; e < NB_ * NB_; e += blockDim.x) {
-        const int i = e / NB_, j = e % NB_;
-        L[i][j] = (i < nbk && j < nbk) ? G[(size_t)(k0 + i) * P + k0 + j] : 0.;
-    }
+// sums of N values over the 64 lanes, advanced together: DPP butterflies inside the rows of 16 lanes, then the four
+// row totals by v_readlane, in a fixed order (no LDS crossbar)
+template <int N>
+__device__ inline void bf_wave_sum_n(double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += bf_dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += bf_dpp_f64<0x4E>(v[i]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += bf_dpp_f64<0x141>(v[i]);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += bf_dpp_f64<0x140>(v[i]);  // row_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = ((bf_readlane(v[i], 0) + bf_readlane(v[i], 16)) + bf_readlane(v[i], 32)) + bf_readlane(v[i], 48);
+}
+__global__ __launch_bounds__(1024) void bf_trsv_kernel(int P, int m, const double *__restrict__ G, double *__restrict__ r) {
+    extern __shared__ double sm[];
+    double *y = sm;                 // [P]
+    double *Lb = y + P;             // [NB_][NB_ + 1]
+    double *part = Lb + NB_ * (NB_ + 1);  // [16][NB_]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (int c = 0; c < m; ++c) {
+        for (int i = t; i < P; i += 1024) y[i] = r[(size_t)i * m + c];
         __syncthreads();
-        // y_j = r_j - sum_{i >= k0 + nbk} L[i][k0 + j] x_i   (x below is final already)
-        if (t < nbk) {
-            double s = r[(size_t)(k0 + t) * m + c];
-            for (int i = k0 + nbk; i < P; ++i) s -= G[(size_t)i * P + k0 + t] * r[(size_t)i * m + c];
-            y[t] = s;
+        // ---- forward: L y = r ----
+        for (int k0 = 0; k0 < P; k0 += NB_) {
+            const int nbk = min(NB_, P - k0);
+            for (int i = wv; i < NB_; i += 16) Lb[i * (NB_ + 1) + lane] = (i < nbk && lane < nbk) ? G[(size_t)(k0 + i) * P + k0 + lane] : (i == lane ? 1. : 0.);
+            __syncthreads();
+            if (wv == 0) {
+                double yi = lane < nbk ? y[k0 + lane] : 0.;
+                for (int j = 0; j < nbk; ++j) {
+                    const double yj = bf_readlane(yi, j) / Lb[j * (NB_ + 1) + j];
+                    if (lane == j) yi = yj;
+                    else if (lane > j) yi -= Lb[lane * (NB_ + 1) + j] * yj;
+                }
+                if (lane < nbk) y[k0 + lane] = yi;
+            }
+            __syncthreads();
+            const double yl = lane < nbk ? y[k0 + lane] : 0.;
+            for (int i0 = k0 + nbk + 4 * wv; i0 < P; i0 += 64) {  // four rows per wave and pass: the reductions overlap
+                double v4[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int i = i0 + q4;
+                    v4[q4] = (i < P && lane < nbk) ? G[(size_t)i * P + k0 + lane] * yl : 0.;
+                }
+                bf_wave_sum_n<4>(v4);
+                if (lane < 4 && i0 + lane < P) y[i0 + lane] -= (lane == 0 ? v4[0] : (lane == 1 ? v4[1] : (lane == 2 ? v4[2] : v4[3])));
+            }
+            __syncthreads();
         }
+        // ---- backward: L^T x = y ----
+        for (int k0 = (P - 1) / NB_ * NB_; k0 >= 0; k0 -= NB_) {
+            const int nbk = min(NB_, P - k0);
+            for (int i = wv; i < NB_; i += 16) Lb[i * (NB_ + 1) + lane] = (i < nbk && lane < nbk) ? G[(size_t)(k0 + i) * P + k0 + lane] : (i == lane ? 1. : 0.);
+            // y_j -= sum_{i below the block} L[i][k0 + j] x_i : every wave takes rows i = k0 + nbk + wv, + 16, ...
+            double acc = 0.;
+            for (int i = k0 + nbk + wv; i < P; i += 16) acc += (lane < nbk ? G[(size_t)i * P + k0 + lane] : 0.) * y[i];
+            part[wv * NB_ + lane] = acc;
+            __syncthreads();
+            if (wv == 0) {
+                double yi = lane < nbk ? y[k0 + lane] : 0.;
+                for (int w2 = 0; w2 < 16; ++w2) yi -= part[w2 * NB_ + lane];
+                for (int j = nbk - 1; j >= 0; --j) {
+                    const double xj = bf_readlane(yi, j) / Lb[j * (NB_ + 1) + j];
+                    if (lane == j) yi = xj;
+                    else if (lane < j) yi -= Lb[j * (NB_ + 1) + lane] * xj;
+                }
+                if (lane < nbk) y[k0 + lane] = yi;
+            }
+            __syncthreads();
+        }
+        for (int i = t; i < P; i += 1024) r[(size_t)i * m + c] = y[i];
         __syncthreads();
-        for (int j = nbk - 1; j >= 0; --j) {
-            if (t == 0) y[j] /= L[j][j];
-            __syncthreads();
-            if (t < j) y[t] -= L[j][t] * y[j];
-            __syncthreads();
-        }
-        if (t < nbk) r[(size_t)(k0 + t) * m + c] = y[t];
     }
 }
 
 extern "C" int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info) {
     if (!ctx || P < 1 || m < 1 || !G || !r || !info) return bf_set_error(BFHIP_ERR_ARG, "bfhip_solve_spd: invalid argument");
-    if (int rc = ensure_scratch(ctx, (size_t)P * sizeof(double))) return rc;
+    if (int rc = ensure_scratch(ctx, (size_t)(P + NB_ * NB_) * sizeof(double))) return rc;
     double *dsc = (double *)ctx->scratch;
+    double *Linv = dsc + P;  // inverse of the current diagonal block's factor
     hipStream_t st = ctx->stream;
     BF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
     hipLaunchKernelGGL(bf_diag_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, G, dsc);
     hipLaunchKernelGGL(bf_scale_kernel, dim3(P), dim3(256), 0, st, P, m, G, r, dsc);
     for (int k0 = 0; k0 < P; k0 += NB_) {
         const int nbk = P - k0 < NB_ ? P - k0 : NB_;
-        hipLaunchKernelGGL(bf_chol_diag_kernel, dim3(1), dim3(256), 0, st, P, k0, G, info);
+        hipLaunchKernelGGL(bf_chol_diag_kernel, dim3(1), dim3(64), 0, st, P, k0, G, Linv, info);
         const int below = P - k0 - nbk;
         if (below > 0) {
-            hipLaunchKernelGGL(bf_chol_trsm_kernel, dim3((below + 63) / 64), dim3(64), 0, st, P, k0, G);
+            hipLaunchKernelGGL(bf_chol_trsm_kernel, dim3((below + NB_ - 1) / NB_), dim3(256), 0, st, P, k0, G, Linv);
             const int nb = (below + GB_ - 1) / GB_;
             const int n_blk = nb * (nb + 1) / 2;
             hipLaunchKernelGGL(bf_chol_syrk_kernel, dim3((n_blk + 3) / 4), dim3(256), 0, st, P, k0, G);
         }
     }
-    for (int k0 = 0; k0 < P; k0 += NB_) hipLaunchKernelGGL(bf_trsv_fwd_kernel, dim3(1), dim3(256), 0, st, P, m, k0, G, r);
-    for (int k0 = (P - 1) / NB_ * NB_; k0 >= 0; k0 -= NB_)
-        hipLaunchKernelGGL(bf_trsv_bwd_kernel, dim3(1), dim3(256), 0, st, P, m, k0, G, r);
+    {
+        const size_t lds = ((size_t)P + NB_ * (NB_ + 1) + 16 * NB_) * sizeof(double);
+        if (lds > 160 * 1024) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_solve_spd: P = %d is beyond the LDS-resident solve", P);
+        if (lds > 64 * 1024)
+            BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bf_trsv_kernel, dim3(1), dim3(1024), lds, st, P, m, G, r);
+    }
     hipLaunchKernelGGL(bf_unscale_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, m, r, dsc);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
