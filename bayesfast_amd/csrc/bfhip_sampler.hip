@@ -113,11 +113,25 @@ __device__ inline double swap32_add_f64(double v) {
 // inside each row of 16 lanes, then two row swaps (no LDS crossbar).  The N reductions advance step by
 // step together so that the latency of each f64 add is covered by the other values' instructions.
 #ifndef BF_WSUM_MODE
-#define BF_WSUM_MODE 2
+#define BF_WSUM_MODE 3
 #endif
 template <int N>
 __device__ inline void wave_sum_n(double (&v)[N]) {
-#if BF_WSUM_MODE == 0
+#if BF_WSUM_MODE == 3
+    // two v_mfma_f64_4x4x4 per value: with B = 1 the first leaves, in lane 16i + 4b + j, the sum of the four lanes
+    // 16k + 4b + i (k = 0..3); fed back as the B operand with A = 1 the second sums those over i: every lane of
+    // block b = (lane >> 2) & 3 holds the total of its block's 16 lanes; two row rotations add the four blocks.
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[i], 1., 0., 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(1., v[i], 0., 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x128>(v[i]);  // row_ror:8
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x124>(v[i]);  // row_ror:4
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = rfl(v[i]);
+#elif BF_WSUM_MODE == 0
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double t = v[i];

