@@ -294,6 +294,9 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0;
     double start_energy = 0., acc_sum = 0.;
     double T_W = 0., T_acc = 0.;
+    // hot tree scalars in registers: largest |dE| of the tree, the weight offset, and the waiting level-0 leaf's weight
+    // and accept sum (mirrors of lsw[LS_LS], lsw[LS_ACC] of level 0, which stay the backing store)
+    double max_de = 0., w_off = 0., L0_W = 0., L0_acc = 0.;
     int unit = U_DONE, lev = 0, h_accepted = 0;
     double *csw = CS + w * CS_N;
     auto cs_set = [&](int i, double v) { if (lane == 0) csw[i] = v; };
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     cs_set(CS_PROP_E, E_new);
                     cs_set(CS_PROP_LOGP, logp_new);
                     cs_set(CS_TREE_W, 1.);
-                    cs_set(CS_W_OFF, 0.);
-                    cs_set(CS_MAX_DE, 0.);
+                    w_off = 0.;
+                    max_de = 0.;
                     depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
                     eps = uexp(i_iter < nw ? cs_get(CS_LOG_STEP) : cs_get(CS_LOG_BAR));  // step_size.py:25-29
                     dir = 1;
@@ -425,25 +428,27 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     n_prop += 1;
                     double dE = E_new - start_energy;
                     if (dE != dE) dE = INFINITY;
-                    if (fabs(dE) > fabs(cs_get(CS_MAX_DE))) cs_set(CS_MAX_DE, dE);
+                    if (fabs(dE) > fabs(max_de)) max_de = dE;
                     cs_set(CS_T_E, E_new);
                     cs_set(CS_T_LOGP, logp_new);
                     T_acc = 0.; lev = 0;
                     if (fabs(dE) < a.cfg.max_change) {
                         // multinomial weight exp(log_size) = exp(-dE), kept in the linear domain relative to
                         // a running offset w_off (exact streaming log-sum-exp; rescales are rare)
-                        const double w_off = cs_get(CS_W_OFF);
                         double aw = -dE - w_off;
                         if (aw > 600.) {
                             const double sc_ = uexp(-aw);
                             cs_set(CS_TREE_W, cs_get(CS_TREE_W) * sc_);
                             if (lane == 0)
                                 for (int l2 = 0; l2 < depth; ++l2) lsw[l2 * LS_N + LS_LS] *= sc_;
-                            cs_set(CS_W_OFF, w_off + aw);
+                            L0_W *= sc_;
+                            w_off = w_off + aw;
                             aw = 0.;
                         }
+                        // (an inlined short-dependency exp was tried here: its constants and temporaries push the
+                        // kernel over the 128-VGPR budget and cost 11 %; the out-of-line libm call stays)
                         T_W = uexp(aw);
-                        const double pacc = (cs_get(CS_W_OFF) == 0.) ? T_W : uexp(-dE);
+                        const double pacc = (w_off == 0.) ? T_W : uexp(-dE);
                         T_acc = pacc > 1. ? 1. : pacc;
 #pragma unroll
                         for (int e = 0; e < E; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
@@ -459,8 +464,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                                 d1 += ps0 * (FULLM ? vcur[FULLM ? e : 0] : var[e] * p[e]);
                             }
                             { double r2[2] = {d0, d1}; wave_sum_n<2>(r2); d0 = r2[0]; d1 = r2[1]; }
-                            T_acc = rfl(lsw[LS_ACC]) + T_acc;  // :173
-                            const double Wsum = rfl(lsw[LS_LS]) + T_W;
+                            T_acc = L0_acc + T_acc;  // :173
+                            const double Wsum = L0_W + T_W;
                             if (Wsum != Wsum) err = 2;
                             const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
                             if ((d0 <= 0.) || (d1 <= 0.)) {
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     st[BFHIP_NS_STEP_SIZE_BAR] = exp(log_bar);
                     st[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
                     st[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
-                    st[BFHIP_NS_MAX_ENERGY_CHANGE] = cs_get(CS_MAX_DE);
+                    st[BFHIP_NS_MAX_ENERGY_CHANGE] = max_de;
                     st[BFHIP_NS_DIVERGING] = (double)diverged;
                 } else {
                     st[BFHIP_HS_LOGP] = prop_logp;
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     double *lsp = lsw + lev * LS_N;
                     lsp[LS_LS] = T_W; lsp[LS_E] = cs_get(CS_T_E); lsp[LS_LOGP] = cs_get(CS_T_LOGP); lsp[LS_ACC] = T_acc;
                 }
+                if (lev == 0) { L0_W = T_W; L0_acc = T_acc; }
                 i_leaf += 1;
                 unit = U_EVAL;
             } else {
