@@ -39,7 +39,7 @@ def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7):
     n_param = 1 + d + d * (d + 1) // 2
     x = np.random.default_rng(fit_seed).normal(size=(n_fit_mult * n_param, d))
     mu = np.mean(x, axis=0)
-    hess = np.linalg.inv(np.cov(x, rowvar=False))
+    hess = np.linalg.inv(np.atleast_2d(np.cov(x, rowvar=False)))
     beta = np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5
     alpha = float(np.max(beta))
     logp_fit = -0.5 * np.einsum('ij,jk,ik->i', x, P, x)

@@ -322,3 +322,32 @@ def test_full_metric_64d_and_bad_covariance(ctx, samp):
     _full_metric_compare(ctx, spec, x0[:3], 14, 10, 'NUTS', dict(metric='full'), n_head=5, tol=np.inf, n_exact=8)
     with pytest.raises(ValueError):
         DeviceChains(DeviceDensity(spec, ctx), x0, metric=-np.eye(64))
+
+
+@pytest.mark.parametrize('d', [1, 3, 17, 33, 65, 100])
+def test_odd_shapes_match_oracle(ctx, d):
+    """Dimensions that are not multiples of the 16-wide tiles, and chain counts that leave ragged workgroups (1, 17):
+    NUTS and HMC chains against the oracle (tree sizes / accept flags exactly, head positions to 1e-8)."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    from oracle import oracle as orc
+    spec, _ = correlated_gaussian_spec(d)
+    dens = DeviceDensity(spec, ctx)
+    for C in (1, 17):
+        x0 = np.random.default_rng(d * 1000 + C).normal(size=(C, d)) * 0.7
+        for smp in ('NUTS', 'HMC'):
+            dc = DeviceChains(dens, x0, seed=9)
+            s, st = dc.run(12, smp, n_warmup=8, n_int_step=6)
+            s, st = s.cpu().numpy(), st.cpu().numpy()
+            for i in sorted(set((0, C - 1))):
+                ch = orc.Chain(x0[i])
+                rng = orc.make_rng('xoshiro', seed=9, stream=i)
+                if smp == 'NUTS':
+                    so, sto = orc.nuts_run(spec, ch, rng, 12, 8)
+                    assert np.array_equal(st[i, :, _lib.NSTATS.index('tree_size')], sto['tree_size']), (d, C, i)
+                else:
+                    so, sto = orc.hmc_run(spec, ch, rng, 12, 8, n_int_step=6)
+                    assert np.array_equal(st[i, :, _lib.HSTATS.index('accepted')], sto['accepted']), (d, C, i)
+                np.testing.assert_allclose(s[i, :5], so[:5], rtol=1e-8, atol=1e-8)
