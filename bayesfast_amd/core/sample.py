@@ -46,6 +46,10 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
 
     d = density.input_size
     rank, ws = parallel.world()
+    if ws > 1:  # one process per GPU: bind this rank to its own device before anything touches device memory
+        dev = parallel.local_device(torch.cuda.device_count())
+        if dev is not None and torch.cuda.current_device() != dev:
+            torch.cuda.set_device(dev)
     b, e = parallel.shard_range(trace.n_chain, rank, ws)
     if prev is None:
         if trace.x_0 is None:  # core/sample.py:106-113 (N(0, I) starts; the reference draws them from a Sobol sequence)

@@ -74,6 +74,7 @@ static void to_fragments(const double *M, int d, int DP, bool transpose, double 
 }
 
 extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || !ds) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: NULL argument");
     const int d = ds->d;
     if (d < 1 || d > BFHIP_MAX_DIM) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: d = %d out of [1, %d]", d, BFHIP_MAX_DIM);
@@ -227,6 +228,7 @@ static void seed_state(uint64_t seed, uint64_t stream, uint64_t s[4]) {
 }
 
 extern "C" int bfhip_rng_seed(bfhip_ctx *ctx, int n_chain, uint64_t seed, uint64_t first_stream, uint64_t *rng) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || n_chain < 0 || !rng) return bf_set_error(BFHIP_ERR_ARG, "bfhip_rng_seed: invalid argument");
     std::vector<uint64_t> h((size_t)n_chain * 4);
     for (int c = 0; c < n_chain; ++c) seed_state(seed, first_stream + (uint64_t)c, &h[(size_t)c * 4]);
@@ -273,6 +275,7 @@ __global__ void bf_chain_init_kernel(int n_chain, int d, const double *__restric
 extern "C" int bfhip_chain_init(bfhip_ctx *ctx, int n_chain, int d, const double *x0, double step_size,
                                 const double *metric_var, const double *initial_mean, double initial_weight,
                                 int adapt_window, double *sc, double *vec) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || n_chain < 0 || d < 1 || d > BFHIP_MAX_DIM || !x0 || !sc || !vec || !(step_size > 0.) ||
         !(initial_weight > 0.) || adapt_window < 1)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_chain_init: invalid argument");

@@ -102,6 +102,17 @@ struct bfhip_ctx {
     int n_cu;
 };
 
+// Every entry point that launches or allocates runs on its context's device, whatever the caller's current device is
+// (one process may hold contexts of several GPUs); the previous device is restored on return.
+struct BfDeviceGuard {
+    int prev = -1;
+    explicit BfDeviceGuard(const bfhip_ctx *ctx) {
+        if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) (void)hipSetDevice(ctx->device);
+        else prev = -1;
+    }
+    ~BfDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // the common surrogate: linear + quadratic configs with the extrapolation bound and nothing else
 static inline bool bf_model_plain(const DevModel &m) {
     return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic;

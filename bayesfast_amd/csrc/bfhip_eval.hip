@@ -186,6 +186,7 @@ static int eval_grid(const bfhip_ctx *ctx, int n) {
 }
 
 extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || n < 0 || (n > 0 && (!x || !logp))) return bf_set_error(BFHIP_ERR_ARG, "bfhip_logp_grad: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_logp_grad: no density uploaded");
     if (n == 0) return 0;
@@ -202,6 +203,7 @@ extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int origi
 
 extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const double *var, double *q, double *p,
                               double *grad, double *logp, double *energy, double *velocity_out) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || n < 0 || (n > 0 && (!eps || !var || !q || !p || !grad || !logp || !energy)))
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_leapfrog: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_leapfrog: no density uploaded");
@@ -254,6 +256,7 @@ __global__ void bf_constraint_kernel(DevModel m, int which, long total, const do
 }
 
 extern "C" int bfhip_constraint(bfhip_ctx *ctx, int which, int n, const double *x, double *out, int *bad) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || which < 0 || which > 5 || n < 0 || (n > 0 && (!x || !out)) || (which < 3 && !bad))
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_constraint: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_constraint: no density uploaded");

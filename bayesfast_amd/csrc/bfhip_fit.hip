@@ -63,6 +63,7 @@ __global__ void bf_design_block_kernel(int order, int n, int n_in, const double 
 
 extern "C" int bfhip_design_block(bfhip_ctx *ctx, int order, int n, int n_in, const double *x, const double *w,
                                   double *A, int lda, int col0) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || order < 0 || order > 3 || n < 0 || n_in < 1 || n_in > 1024 || lda < 1 || col0 < 0)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_design_block: invalid argument");
     if (n == 0) return 0;
@@ -182,6 +183,7 @@ static int ensure_scratch(bfhip_ctx *ctx, size_t need) {
 }
 
 extern "C" int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, const double *B, double *G, double *r) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || n < 1 || P < 1 || m < 0 || !A || !G || lda < P || (m > 0 && (!B || !r)))
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_gram: invalid argument");
     const int nb = (P + GB_ - 1) / GB_;
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(1024) void bf_trsv_kernel(int P, int m, const doubl
 }
 
 extern "C" int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || P < 1 || m < 1 || !G || !r || !info) return bf_set_error(BFHIP_ERR_ARG, "bfhip_solve_spd: invalid argument");
     if (int rc = ensure_scratch(ctx, (size_t)(P + NB_ * NB_) * sizeof(double))) return rc;
     double *dsc = (double *)ctx->scratch;

@@ -1279,6 +1279,7 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
 extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_chain, int iter_end,
                                  uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
                                  double *stats, unsigned long long *n_leapfrog) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || !cfg || n_chain < 0) return bf_set_error(BFHIP_ERR_ARG, "bfhip_sampler_run: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_sampler_run: no density uploaded");
     if (n_chain == 0) return 0;
@@ -1364,6 +1365,7 @@ __global__ __launch_bounds__(64) void bf_metric_init_full_kernel(int n_chain, in
 
 extern "C" int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const double *cov0, double initial_weight,
                                       double *sc, double *mat) {
+    BfDeviceGuard dev_guard(ctx);
     if (!ctx || n_chain < 0 || d <= 0 || d > BFHIP_MAX_DIM || (n_chain > 0 && (!sc || !mat)))
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_metric_init_full: invalid argument");
     if (n_chain == 0) return 0;

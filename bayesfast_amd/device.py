@@ -76,8 +76,11 @@ class DeviceContext:
 _contexts = {}
 
 
-def get_context(device=0):
-    """Process-wide default context of a device."""
+def get_context(device=None):
+    """Process-wide default context of a device (default: torch's current device, i.e. the one a rank selected with
+    ``torch.cuda.set_device(local_rank)``)."""
+    if device is None:
+        device = _torch().cuda.current_device()
     if device not in _contexts:
         _contexts[device] = DeviceContext(device)
     return _contexts[device]

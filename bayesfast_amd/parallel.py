@@ -7,7 +7,7 @@ chain index, so results do not depend on the number of ranks.  The refit needs e
 ONE all-gather per sampling round (RCCL over xGMI with backend "nccl"; gloo in the CPU tests)."""
 import numpy as np
 
-__all__ = ['world', 'shard_range', 'all_gather_chains']
+__all__ = ['world', 'shard_range', 'all_gather_chains', 'local_device']
 
 
 def world():
@@ -19,6 +19,20 @@ def world():
     except Exception:
         pass
     return 0, 1
+
+
+def local_device(n_visible, env=None):
+    """Device index this rank should use on its node: one process per GPU (torchrun exports LOCAL_RANK).  Returns None
+    when there is nothing to decide (single process, or no LOCAL_RANK)."""
+    import os
+    env = os.environ if env is None else env
+    rank, ws = world()
+    if ws == 1 or 'LOCAL_RANK' not in env:
+        return None
+    lr = int(env['LOCAL_RANK'])
+    if not 0 <= lr < n_visible:
+        raise RuntimeError('LOCAL_RANK {} but only {} visible device(s).'.format(lr, n_visible))
+    return lr
 
 
 def shard_range(n_chain, rank, world_size):

@@ -134,7 +134,8 @@ def _gather_worker(rank, ws, port, n_chain, q):
         b, e = parallel.shard_range(n_chain, rank, ws)
         full = torch.arange(n_chain * 3 * 2, dtype=torch.float64).reshape(n_chain, 3, 2)
         out = parallel.all_gather_chains(full[b:e].clone(), n_chain)
-        q.put((rank, bool(torch.equal(out, full)), parallel.world()))
+        dev_ok = parallel.local_device(8, env={'LOCAL_RANK': str(rank)}) == rank  # one process per GPU
+        q.put((rank, bool(torch.equal(out, full)) and dev_ok, parallel.world()))
     finally:
         dist.destroy_process_group()
 
@@ -152,3 +153,10 @@ def test_all_gather_chains_gloo_world2(n_chain):
     [p.join(60) for p in ps]
     assert [r[1] for r in res] == [True, True]
     assert [r[2] for r in res] == [(0, 2), (1, 2)]
+
+
+def test_local_device_selection():
+    """One process per GPU: the rank's device comes from LOCAL_RANK when a process group exists (here: none -> None)."""
+    from bayesfast_amd import parallel
+    assert parallel.local_device(8, env={'LOCAL_RANK': '3'}) is None  # no process group: nothing to decide
+    assert parallel.shard_range(10, 3, 4) == (8, 10)
