@@ -42,6 +42,12 @@ class SamplerConfig(C.Structure):
                 ('update_window', C.c_int), ('doubling', C.c_int), ('full_metric', C.c_int), ('metric_mat', C.c_void_p)]
 
 
+class PolymodelDesc(C.Structure):  # bfhip_polymodel_desc
+    _fields_ = [('d', C.c_int), ('m', C.c_int), ('c0', C.POINTER(C.c_double)), ('lin', C.POINTER(C.c_double)),
+                ('quad', C.POINTER(C.c_double)), ('use_bound', C.c_int), ('mu', C.POINTER(C.c_double)),
+                ('hess', C.POINTER(C.c_double)), ('alpha', C.c_double), ('f_mu', C.POINTER(C.c_double))]
+
+
 # every symbol include/bfhip.h declares: (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -60,6 +66,8 @@ SYMBOLS = {
     'bfhip_rng_seed': (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, _vp]),
     'bfhip_chain_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp, C.c_double, C.c_int, _vp, _vp]),
     'bfhip_metric_init_full': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp]),
+    'bfhip_polymodel_upload': (C.c_int, [_vp, C.POINTER(PolymodelDesc)]),
+    'bfhip_polymodel_eval': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
     'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_solve_spd': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),

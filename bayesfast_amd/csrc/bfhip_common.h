@@ -97,6 +97,19 @@ struct bfhip_ctx {
     size_t model_bytes;
     void *cubic_buf;      // cubic-term tables
     size_t cubic_bytes;
+    void *pm_buf;         // multi-output polymodel (bfhip_polymodel_upload)
+    size_t pm_bytes;
+    int has_pm;
+    struct PolyDev {
+        int d, DP, m, use_bound, has_quad;
+        const double *Sf;    // [m][DP*DP] A fragments of S_o = A_o + A_o^T
+        const double *lin;   // [m][DP]
+        const double *c0;    // [m]
+        const double *f_mu;  // [m]
+        const double *mu;    // [DP]
+        const double *Hf;    // [DP*DP]
+        double alpha;
+    } pm;
     void *scratch;        // sampler tree scratch (grow-only)
     size_t scratch_bytes;
     int n_cu;

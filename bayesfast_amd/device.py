@@ -8,7 +8,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ['DeviceContext', 'DeviceDensity', 'density_desc_from_spec', 'get_context']
+__all__ = ['DeviceContext', 'DeviceDensity', 'DevicePolyModel', 'density_desc_from_spec', 'get_context']
 
 _ORDERS = ('linear', 'quadratic', 'cubic-2', 'cubic-3')
 
@@ -249,3 +249,73 @@ class DeviceDensity:
         _lib.check(self.ctx._lib.bfhip_leapfrog(self.ctx.handle, n, _ptr(eps), _ptr(var), _ptr(q), _ptr(p), _ptr(grad),
                                                 _ptr(logp), _ptr(energy), _ptr(velocity)))
         return logp, energy
+
+
+class DevicePolyModel:
+    """A multi-output PolyModel resident on one GPU: ``PolyModel.fun / jac / fun_and_jac`` over batches of points
+    (modules/poly.py:430-503) for linear and quadratic configs; masks are scattered to dense per-output
+    coefficients here, which is what ``_fun_and_jac`` does on every call (modules/poly.py:474-477).
+
+    poly : the dict ``PolyModel.poly_spec()`` returns."""
+
+    def __init__(self, poly, ctx=None):
+        self.ctx = ctx if ctx is not None else get_context()
+        d, m = int(poly['input_size']), int(poly['output_size'])
+        c0 = np.zeros(m)
+        lin = np.zeros((m, d))
+        quad = np.zeros((m, d, d))
+        has_quad = False
+        for cf in poly['configs']:
+            im = np.asarray(cf['input_mask'], dtype=np.int64)
+            om = np.asarray(cf['output_mask'], dtype=np.int64)
+            coef = np.asarray(cf['coef'], dtype=np.float64)
+            if cf['order'] == 'linear':
+                c0[om] += coef[:, 0]
+                lin[np.ix_(om, im)] += coef[:, 1:]
+            elif cf['order'] == 'quadratic':
+                has_quad = True
+                iu = np.triu_indices(im.size)
+                for q, o in enumerate(om):
+                    quad[o, im[iu[0]], im[iu[1]]] += coef[q][iu]
+            else:
+                raise NotImplementedError('cubic configs are evaluated per output through DeviceDensity.')
+        self.d, self.m = d, m
+        ds = _lib.PolymodelDesc()
+        keep = []
+
+        def f64(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+
+        ds.d, ds.m = d, m
+        ds.c0, ds.lin = f64(c0), f64(lin)
+        if has_quad:
+            ds.quad = f64(quad)
+        if poly.get('use_bound', False) and has_quad:
+            ds.use_bound = 1
+            ds.mu, ds.hess = f64(poly['mu']), f64(poly['hess'])
+            ds.alpha = float(poly['alpha'])
+            ds.f_mu = f64(np.asarray(poly['f_mu'], dtype=np.float64).reshape(m))
+        self._desc, self._keep = ds, keep
+        self._uploaded = None
+
+    def upload_if_needed(self):
+        if self.ctx.__dict__.get('_pm_owner') is not self:
+            _lib.check(self.ctx._lib.bfhip_polymodel_upload(self.ctx.handle, C.byref(self._desc)))
+            self.ctx._pm_owner = self
+
+    def fun_and_jac(self, x, jac=True):
+        """x (n, d) or (d,) -> f (n, m) and, if ``jac``, the Jacobians (n, m, d); float64 device tensors."""
+        torch = _torch()
+        self.upload_if_needed()
+        xt = self.ctx.tensor(x, torch.float64)
+        single = xt.dim() == 1
+        xt = xt.reshape(-1, self.d)
+        n = xt.shape[0]
+        f = self.ctx.empty((n, self.m))
+        j = self.ctx.empty((n, self.m, self.d)) if jac else None
+        _lib.check(self.ctx._lib.bfhip_polymodel_eval(self.ctx.handle, n, _ptr(xt), _ptr(f), _ptr(j)))
+        if single:
+            return f[0], (j[0] if jac else None)
+        return f, j

@@ -239,10 +239,27 @@ class PolyModel(Surrogate):
         return dict(d=self._input_size, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=one,
                     use_decay=False)
 
+    def device_model(self, use_bound=None):
+        """The multi-output module on the GPU (``DevicePolyModel``): batched ``fun_and_jac`` for linear + quadratic
+        configs in one launch.  Rebuilt after every fit."""
+        from ..device import DevicePolyModel
+        key = (id(self._configs[0]._coef), use_bound)
+        if getattr(self, '_dev_model_key', None) != key:
+            self._dev_model = DevicePolyModel(self.poly_spec(use_bound))
+            self._dev_model_key = key
+        return self._dev_model
+
+    def fun_and_jac_batch(self, x, jac=True):
+        """f (n, m) and Jacobians (n, m, d) of a batch of points x (n, d) as device tensors (one launch)."""
+        return self.device_model().fun_and_jac(x, jac=jac)
+
     def _device_eval(self, x, use_bound=None):
-        """f (m,), j (m, d) of one point, on device (one batched launch per output)."""
+        """f (m,), j (m, d) of one point, on device."""
         from ..device import DeviceDensity
         x = np.asarray(x, dtype=np.float64).reshape(1, -1)
+        if all(c.order in ('linear', 'quadratic') for c in self._configs):  # one launch for all outputs
+            f, j = self.device_model(use_bound).fun_and_jac(x)
+            return f[0].cpu().numpy(), j[0].cpu().numpy()
         f = np.empty(self._output_size)
         j = np.empty((self._output_size, self._input_size))
         for ii in range(self._output_size):
@@ -330,8 +347,10 @@ class PolyModel(Surrogate):
                     qq = int(np.argwhere(c._output_mask == ii)[0, 0])
                     c._set(sol[k:k + wd, jo], qq)
                     k += wd
+        self._dev_model_key = None  # the device copy of the module is stale now
         if self._use_bound and not self._all_linear:
             self._set_bound(x, logp)
+        self._dev_model_key = None
 
     def _set_bound(self, x, logp=None):
         """mu, H = inv(cov), alpha and f_mu of the extrapolation bound (modules/poly.py:262-292)."""

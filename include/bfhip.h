@@ -208,6 +208,28 @@ int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const double *cov
                            double *sc, double *mat);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-output surrogate module: PolyModel.fun / jac / fun_and_jac for output_size m > 1
+ * (modules/poly.py:430-503).  Linear and quadratic configs, masks already scattered by
+ * the caller: c0 (m), lin (m,d), quad (m,d,d) with the upper triangle j <= k as in bfhip_density_desc.
+ * The extrapolation bound (mu, hess, alpha) is shared by all outputs, f_mu (m) is per output.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bfhip_polymodel_desc {
+    int d, m;
+    const double *c0, *lin, *quad;  /* quad may be NULL (all-linear model) */
+    int use_bound;
+    const double *mu, *hess;        /* (d), (d,d) */
+    double alpha;
+    const double *f_mu;             /* (m) */
+} bfhip_polymodel_desc;
+
+/* Copies the module into device memory owned by the context (host pointers in the descriptor). */
+int bfhip_polymodel_upload(bfhip_ctx *ctx, const bfhip_polymodel_desc *desc);
+
+/* f (n,m) and, if jac != NULL, jac (n,m,d) for n points x (n,d); device pointers.  Outside the bound every output
+ * is extrapolated linearly from the projected point, PolyModel._fj_bound (modules/poly.py:480-503). */
+int bfhip_polymodel_eval(bfhip_ctx *ctx, int n, const double *x, double *f, double *jac);
+
+/* ------------------------------------------------------------------------------------------------
  * Surrogate fit, PolyModel.fit (modules/poly.py:505-589).
  * ---------------------------------------------------------------------------------------------- */
 /* Design-matrix block for one PolyConfig: x (n, n_in) gathered inputs -> A[:, col0 : col0+width] of the

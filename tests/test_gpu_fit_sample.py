@@ -338,3 +338,58 @@ def test_sample_with_full_rank_metric_recovers_a_correlated_gaussian():
     m = _get_metric(tt, 'full', from_samples=False)          # mean over chains of the adapted covariances
     assert m.shape == (d, d)
     assert np.max(np.abs(m - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.25
+
+
+@pytest.mark.parametrize('d,m', [(6, 5), (40, 9), (64, 33)])
+def test_multi_output_polymodel_batched_fun_and_jac(d, m):
+    """PolyModel.fun / jac / fun_and_jac for output_size > 1 in ONE launch (modules/poly.py:430-503; the masked
+    scatter of :474-477, the shared extrapolation bound of :480-503) against the oracle, inside and outside the
+    bound; then through the fitted module's own entry points."""
+    from bayesfast_amd import PolyModel, PolyConfig
+    from bayesfast_amd.device import DevicePolyModel
+    from oracle import oracle as orc
+    rng = np.random.default_rng(d * 10 + m)
+    im_q = np.sort(rng.choice(d, size=max(2, d // 2), replace=False))
+    om_q = np.sort(rng.choice(m, size=max(1, m // 2), replace=False))
+    om_q2 = np.setdiff1d(np.arange(m), om_q)[:max(1, m // 3)]
+    nq = im_q.size
+    cq = np.zeros((om_q.size, nq, nq))
+    iu = np.triu_indices(nq)
+    for q in range(om_q.size):
+        cq[q][iu] = rng.normal(size=iu[0].size) * 0.2
+    cq2 = np.zeros((om_q2.size, d, d))
+    iud = np.triu_indices(d)
+    for q in range(om_q2.size):
+        cq2[q][iud] = rng.normal(size=iud[0].size) * 0.1
+    xs = rng.normal(size=(200, d))
+    mu = xs.mean(0)
+    hess = np.linalg.inv(np.atleast_2d(np.cov(xs, rowvar=False)))
+    alpha = float(np.sqrt(np.einsum('ij,jk,ik->i', xs - mu, hess, xs - mu)).max()) * 0.8
+    poly = dict(input_size=d, output_size=m, use_bound=True, mu=mu, hess=hess, alpha=alpha, f_mu=rng.normal(size=m),
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(m), coef=rng.normal(size=(m, d + 1))),
+                         dict(order='quadratic', input_mask=im_q, output_mask=om_q, coef=cq),
+                         dict(order='quadratic', input_mask=np.arange(d), output_mask=om_q2, coef=cq2)])
+    x = np.concatenate([rng.normal(size=(70, d)) * 0.6, rng.normal(size=(19, d)) * 2.5])  # ragged tile, in and out of bound
+    beta = np.sqrt(np.einsum('ij,jk,ik->i', x - mu, hess, x - mu))
+    assert (beta > alpha).any() and (beta < alpha).any()
+    f0, j0 = orc.poly_fun_and_jac(poly, x)
+    f, j = DevicePolyModel(poly).fun_and_jac(x)
+    sc = np.abs(f0).max()
+    np.testing.assert_allclose(f.cpu().numpy(), f0, rtol=1e-11, atol=1e-11 * sc)
+    np.testing.assert_allclose(j.cpu().numpy(), j0, rtol=1e-10, atol=1e-10 * np.abs(j0).max())
+    f1, _ = DevicePolyModel(poly).fun_and_jac(x[3], jac=False)
+    np.testing.assert_allclose(f1.cpu().numpy(), f0[3], rtol=1e-11, atol=1e-11 * sc)
+    # a fitted multi-output module: fit (one factorisation per config group), then batched evaluation
+    pm = PolyModel([PolyConfig('linear'), PolyConfig('quadratic', input_mask=im_q, output_mask=om_q)], input_size=d,
+                   output_size=m)
+    xf = rng.normal(size=(2 * pm.n_param + 20, d))
+    yf = rng.normal(size=(xf.shape[0], m)) * 0.01 + xf[:, :1] * np.arange(1, m + 1)[None, :]
+    yf[:, om_q] += (xf[:, im_q[0]] * xf[:, im_q[1]])[:, None]
+    pm.fit(xf, yf, logp=yf[:, 0])
+    fb, jb = pm.fun_and_jac_batch(x[:40])
+    f_ref, j_ref = orc.poly_fun_and_jac(pm.poly_spec(), x[:40])
+    np.testing.assert_allclose(fb.cpu().numpy(), f_ref, rtol=1e-10, atol=1e-10 * np.abs(f_ref).max())
+    np.testing.assert_allclose(jb.cpu().numpy(), j_ref, rtol=1e-9, atol=1e-9 * np.abs(j_ref).max())
+    f_one, j_one = pm.fun_and_jac(x[5])
+    np.testing.assert_allclose(f_one[0], f_ref[5], rtol=1e-10, atol=1e-10 * np.abs(f_ref).max())
+    np.testing.assert_allclose(j_one[0], j_ref[5], rtol=1e-9, atol=1e-9 * np.abs(j_ref).max())

@@ -99,3 +99,27 @@ for _ in range(4):
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 out['fit_total_host_in_host_out'] = dict(ms=min(ts[1:]) * 1e3, n=n, P=P)
 print(json.dumps(out, indent=1))
+
+# multi-output module at a cosmology-like size (m = 457 outputs)
+try:
+    from bayesfast_amd.device import DevicePolyModel
+    d, m, n = 64, 457, 4096
+    rng = np.random.default_rng(5)
+    iu = np.triu_indices(d)
+    cq = np.zeros((m, d, d))
+    cq[:, iu[0], iu[1]] = rng.normal(size=(m, iu[0].size)) * 0.05
+    poly = dict(input_size=d, output_size=m, use_bound=False,
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(m), coef=rng.normal(size=(m, d + 1))),
+                         dict(order='quadratic', input_mask=np.arange(d), output_mask=np.arange(m), coef=cq)])
+    dm = DevicePolyModel(poly, ctx)
+    dm.upload_if_needed()
+    x = ctx.tensor(rng.normal(size=(n, d)), torch.float64)
+    f, j = ctx.empty((n, m)), ctx.empty((n, m, d))
+    t = timeit(lambda: _lib.check(L.bfhip_polymodel_eval(h, n, _ptr(x), _ptr(f), _ptr(j))), reps=5)
+    t2 = timeit(lambda: _lib.check(L.bfhip_polymodel_eval(h, n, _ptr(x), _ptr(f), None)), reps=5)
+    out2 = dict(points=n, outputs=m, ms_with_jacobian=t * 1e3, jac_GBps=n * m * d * 8 / t / 1e9, hbm_frac=n * m * d * 8 / t / 8e12,
+                TFLOPs=2. * n * m * d * d / t / 1e12, mfma_frac=2. * n * m * d * d / t / 78.6e12, ms_values_only=t2 * 1e3,
+                TFLOPs_values_only=2. * n * m * d * d / t2 / 1e12)
+    print(json.dumps({'polymodel_eval_m457_d64': out2}, indent=1))
+except Exception as ex:
+    print(json.dumps({'polymodel_eval_m457_d64': {'error': repr(ex)}}))
