@@ -389,6 +389,17 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     __syncthreads();
 
     // ---- the per-chain state machine: ONE unit of work per call (wave-uniform control flow) ----
+    // BF_TRACE=<n> (tuning builds only): wave 0 of workgroup 0 records s_memtime at up to 16 points of its first n
+    // trips in LDS and dumps them to the stamps buffer
+    int trip_no = 0;
+#ifdef BF_TRACE
+    __shared__ unsigned long long TRC[BF_TRACE * 16];
+#define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
+    for (int i = threadIdx.x; i < BF_TRACE * 16; i += 1024) TRC[i] = 0;
+#else
+#define TRACE(k) do { } while (0)
+#endif
+
 #ifndef BF_FUSE
 #define BF_FUSE 0
 #endif
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     double dE = E_new - start_energy;
                     if (dE != dE) dE = INFINITY;
                     if (fabs(dE) > fabs(max_de)) max_de = dE;
+                    TRACE(11);
                     cs_set(CS_T_E, E_new);
                     cs_set(CS_T_LOGP, logp_new);
                     T_acc = 0.; lev = 0;
@@ -445,11 +457,13 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                             w_off = w_off + aw;
                             aw = 0.;
                         }
-                        // (an inlined short-dependency exp was tried here: its constants and temporaries push the
-                        // kernel over the 128-VGPR budget and cost 11 %; the out-of-line libm call stays)
+                        // (inlined exps were tried here -- a degree-13 Estrin polynomial, then a 64-entry table with a
+                        // degree-5 polynomial, 2 ulp: both lose 4-11 % to the extra live registers of this kernel at its
+                        // 128-VGPR budget; the out-of-line libm call stays)
                         T_W = uexp(aw);
                         const double pacc = (w_off == 0.) ? T_W : uexp(-dE);
                         T_acc = pacc > 1. ? 1. : pacc;
+                        TRACE(12);
 #pragma unroll
                         for (int e = 0; e < E; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
                         unit = U_MERGE;  // resolved below (push / complete need no further trip)
@@ -463,11 +477,14 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                                 d0 += ps0 * (FULLM ? L0v[FULLM ? e : 0] : var[e] * L0p[e]);  // nuts.py:150-151
                                 d1 += ps0 * (FULLM ? vcur[FULLM ? e : 0] : var[e] * p[e]);
                             }
+                            TRACE(13);
                             { double r2[2] = {d0, d1}; wave_sum_n<2>(r2); d0 = r2[0]; d1 = r2[1]; }
+                            TRACE(14);
                             T_acc = L0_acc + T_acc;  // :173
                             const double Wsum = L0_W + T_W;
                             if (Wsum != Wsum) err = 2;
                             const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
+                            TRACE(15);
                             if ((d0 <= 0.) || (d1 <= 0.)) {
                                 unit = U_ABORT;
                                 lev = 1;
@@ -840,7 +857,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 }
                 if (lane == 0) {
                     double *lsp = lsw + lev * LS_N;
-                    lsp[LS_LS] = T_W; lsp[LS_E] = cs_get(CS_T_E); lsp[LS_LOGP] = cs_get(CS_T_LOGP); lsp[LS_ACC] = T_acc;
+                    // (a level-0 subtree is the fresh leaf itself: its energy and logp are this trip's evaluation,
+                    // no need to read back what the leaf just parked in LDS)
+                    lsp[LS_LS] = T_W; lsp[LS_ACC] = T_acc;
+                    lsp[LS_E] = (lev == 0 && have_ev) ? E_new : cs_get(CS_T_E);
+                    lsp[LS_LOGP] = (lev == 0 && have_ev) ? logp_new : cs_get(CS_T_LOGP);
                 }
                 if (lev == 0) { L0_W = T_W; L0_acc = T_acc; }
                 i_leaf += 1;
@@ -884,16 +905,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
     };
 
-    // BF_TRACE=<n> (tuning builds only): wave 0 of workgroup 0 records s_memtime at 12 points of its first n
-    // trips in LDS and dumps them to the stamps buffer
-#ifdef BF_TRACE
-    __shared__ unsigned long long TRC[BF_TRACE * 16];
-#define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip < BF_TRACE && lane == 0) TRC[trip * 16 + (k)] = clock64(); } while (0)
-#else
-#define TRACE(k) do { } while (0)
-#endif
-
     for (int trip = 0;; ++trip) {
+        trip_no = trip;
         TRACE(0);
         // ================= phase A: first half of the leapfrog, B operands =================
         double xs[E], jac[E], gj[E], xo[E];

@@ -26,6 +26,7 @@ L.bfhip_debug_stamps(None)
 t = buf.cpu().numpy().reshape(N, 16).astype(np.int64)
 names = ['0 loop top', '1 A done (x posted)', '2 after B1', '3 alive checked', '4 MFMAs done', '5 GB written', '6 after B2',
          '7 partials ready', '8 reductions done', '9 C done', '10 unit done']
+leaf_names = ['11 leaf: dE known', '12 leaf: weights (exp) done', '13 merge0: partial dots', '14 merge0: reduced', '15 merge0: draw done']
 rows = []
 for i in range(4, N - 1):
     tt = t[i].copy(); nxt = t[i + 1][0]
@@ -37,3 +38,18 @@ print('%d evaluating trips traced; mean ticks per segment (median in brackets):'
 for k in range(11):
     print('  %-22s -> next: %7.0f  [%6.0f]' % (names[k], rows[:, k].mean(), np.median(rows[:, k])))
 print('  trip total: %.0f [%.0f]' % (rows.sum(1).mean(), np.median(rows.sum(1))))
+
+# finer points inside the NUTS leaf unit (slots 11-15), relative to '9 C done'
+rows2 = []
+for i in range(4, N - 1):
+    tt = t[i]
+    if tt[9] == 0 or tt[11] == 0 or tt[12] == 0: continue
+    seq = [tt[9], tt[11], tt[12]] + ([tt[13], tt[14], tt[15]] if tt[13] and tt[14] and tt[15] else []) + [tt[10]]
+    rows2.append((len(seq), np.diff(seq)))
+for ln, lab in ((4, ['C done -> dE', 'dE -> weights', 'weights -> unit done (even leaf)']),
+                (7, ['C done -> dE', 'dE -> weights', 'weights -> partial dots', 'partial dots -> reduced', 'reduced -> draw', 'draw -> unit done (odd leaf)'])):
+    sel = np.array([r[1] for r in rows2 if r[0] == ln])
+    if len(sel):
+        print('leaf unit, %d trips:' % len(sel))
+        for k, nm in enumerate(lab):
+            print('  %-34s %7.0f [%6.0f]' % (nm, sel[:, k].mean(), np.median(sel[:, k])))
