@@ -392,6 +392,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     // BF_TRACE=<n> (tuning builds only): wave 0 of workgroup 0 records s_memtime at up to 16 points of its first n
     // trips in LDS and dumps them to the stamps buffer
     int trip_no = 0;
+    (void)trip_no;
 #ifdef BF_TRACE
     __shared__ unsigned long long TRC[BF_TRACE * 16];
 #define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
