@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--iters', type=int, default=100, help='NUTS iterations per step (per launch)')
     ap.add_argument('--seed', type=int, default=2024)
+    ap.add_argument('--backend', default='nccl', help="process-group backend: 'nccl' (= RCCL; default) or 'gloo' (plumbing tests)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fit', action='store_true', help='skip the (untimed, separately reported) surrogate fit')
     a = ap.parse_args()
@@ -99,16 +100,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)  # one process per GPU; the modulo only matters for plumbing tests on fewer GPUs
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(dev_index)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(a.backend)
     if a.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
 
     d, C = a.dim, a.chains
     spec, cov = correlated_gaussian_spec(d)
-    ctx = DeviceContext(local_rank)
+    ctx = DeviceContext(dev_index)
     with torch.cuda.device(ctx.device):
         dens = DeviceDensity(spec, ctx)
         # chain starts: N(0, I) rows (core/sample.py:111-112), one global array sliced per rank
@@ -143,8 +149,9 @@ def main():
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if a.steps else 0.
         st_last = stats.cpu().numpy()
 
-        tot = torch.tensor([float(n_lf)], dtype=torch.float64, device=ctx.device)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        red_dev = ctx.device if (dist is None or a.backend == 'nccl') else torch.device('cpu')
+        tot = torch.tensor([float(n_lf)], dtype=torch.float64, device=red_dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         if dist is not None:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
