@@ -10,5 +10,8 @@ from .core.module import Surrogate
 from .core.density import SurrogateDensity
 from .core.sample import sample
 from .samplers import NTrace, HTrace, TraceTuple
+from .utils import SystematicResampler
+from .core.refit import select_fit_points, importance_weights
 
-__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'sample', 'NTrace', 'HTrace', 'TraceTuple']
+__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'sample', 'NTrace', 'HTrace', 'TraceTuple',
+           'SystematicResampler', 'select_fit_points', 'importance_weights']

@@ -160,3 +160,56 @@ def test_local_device_selection():
     from bayesfast_amd import parallel
     assert parallel.local_device(8, env={'LOCAL_RANK': '3'}) is None  # no process group: nothing to decide
     assert parallel.shard_range(10, 3, 4) == (8, 10)
+
+
+def test_systematic_resampler_matches_reference_pattern():
+    """SystematicResampler (utils/misc.py:21-108): ranks evenly spaced between the node percentiles of the sorted
+    array, weights per interval, uniqueness check."""
+    from bayesfast_amd import SystematicResampler
+    a = np.random.default_rng(0).normal(size=1000)
+    i = SystematicResampler()(a, 10)
+    order = np.argsort(a)
+    expect = order[np.linspace(1. * 999 / 100, 100. * 999 / 100, 10, True).astype(int)]
+    assert np.array_equal(i, expect)
+    i2 = SystematicResampler(nodes=(0., 50., 100.), weights=(1., 3.))(a, 8)   # 2 from the lower half, 6 from the upper
+    ranks = np.argsort(order)[i2]
+    assert np.array_equal(ranks, [0, 249, 499, 599, 699, 799, 899, 999])
+    with pytest.raises(RuntimeError):
+        SystematicResampler()(a[:5], 10)          # repeated indices
+    with pytest.warns(RuntimeWarning):
+        SystematicResampler(require_unique=False)(a[:5], 10)
+    for bad in (dict(nodes=(5.,)), dict(nodes=(50., 10.)), dict(nodes=(0., 101.)), dict(weights=(1., 2.))):
+        with pytest.raises(ValueError):
+            SystematicResampler(**bad)
+
+
+def test_select_fit_points_logp_cutoff_and_importance_weights():
+    """Refit glue of Recipe._sam_step (core/recipe.py:1060-1155) and the truncated weights of PostStep (:1289-1296)."""
+    from bayesfast_amd import select_fit_points, importance_weights
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(5000, 3))
+    logq = -0.5 * np.sum(x**2, 1)
+    calls = []
+
+    def logp_true(z):  # the true model agrees with the surrogate, except that a slab of points is "bad"
+        calls.append(len(z))
+        return np.where(z[:, 0] > 1., -1e3, -0.5 * np.sum(z**2, 1))
+
+    xf, lf, n_calls = select_fit_points(x, logq, logp_true, 400, logp_cutoff=False)
+    assert xf.shape == (400, 3) and n_calls == 400 and np.allclose(lf, logp_true(xf))
+    calls.clear()
+    import warnings
+    with warnings.catch_warnings():  # supplementary rounds until alpha_min * n_eval good points remain
+        warnings.simplefilter('ignore')
+        xf, lf, n_calls = select_fit_points(x, logq, logp_true, 400, alpha_min=0.95)
+    assert xf.shape[0] >= int(0.95 * 400) and np.all(lf > -1e3) and np.all(xf[:, 0] <= 1.)
+    assert n_calls == sum(calls) and len(calls) >= 2
+    with pytest.raises(RuntimeError):
+        select_fit_points(x, logq, lambda z: np.full(len(z), -np.inf), 100)   # f_good == 0
+    with pytest.raises(RuntimeError):
+        select_fit_points(x[:50], logq[:50], logp_true, 100)                  # not enough points
+    ratio = np.ones(logq.size)
+    ratio[7] = 1e6                                   # one wild weight is clipped at mean(w) n^k_trunc
+    w, wt = importance_weights(logq + np.log(ratio), logq, k_trunc=0.25)
+    assert np.allclose(w, ratio) and wt.max() == pytest.approx(np.mean(w) * logq.size**0.25) and wt[0] == pytest.approx(1.)
+    assert np.array_equal(*importance_weights(logq, logq - 1., k_trunc=-1))
