@@ -4,13 +4,17 @@
 //   * A workgroup of 16 wavefronts owns a GROUP of 16 chains for the whole launch: 4 waves per SIMD, so the
 //     latency-bound per-chain logic of one wave hides behind the other three.
 //   * Chain phase (everything O(d)): ONE WAVE PER CHAIN.  Lane l holds dimensions l*E .. l*E+E-1 of every
-//     state vector (E = DP/64, 1 at d <= 64).  All tree control flow is wave-uniform: no cross-chain
-//     divergence, dot products are wave reductions, per-chain scalars live once per wave.
+//     state vector (E = DP/64, 1 at d <= 64).  All tree control flow is wave-uniform (and declared so, rfl()):
+//     no cross-chain divergence, per-chain scalars live once per wave in scalar registers, dot products are
+//     wave reductions on the matrix pipe (two v_mfma_f64_4x4x4 and two row rotations per value).
 //   * Tile phase (gradient): the batched matvecs G^T = S X^T and H (X - mu)^T of the 16 chains run on
-//     v_mfma_f64_16x16x4_f64 in the first W = DP/16 waves (wave w: output rows 16w..16w+15 for all 16 chains).
-//     The coefficient matrices S, H (, H_decay) are staged once per launch in LDS as A-operand fragments.
+//     v_mfma_f64_16x16x4_f64; (matrix, row tile, K part) jobs are dealt over the 16 waves.  In the plain
+//     instantiation every wave owns one fixed job and keeps its A operands in registers; otherwise the
+//     coefficient matrices are staged once per launch in LDS as A-operand fragments.
 //   * The two layouts meet in LDS: XB (B operands, written by the chain waves) and GB (matvec results).
 //     Two workgroup barriers per trip, none inside the tree logic.
+//   * While at most four chains of a group are still evaluating, the plain instantiation replaces the MFMA
+//     tiles by per-row FMA chains that reproduce the MFMA rounding bit for bit (see the tail path below).
 //
 // Every chain is an independent state machine (INIT -> LEAF ... -> iteration end -> INIT ...); one loop
 // trip evaluates ONE gradient for all 16 chains of the group, whatever each chain needs it for.  The
@@ -19,10 +23,14 @@
 //
 // The recursion of Tree._build_subtree (samplers/nuts.py:134-178) is flattened: leaf i of a 2^depth
 // subtree is merged upwards while bit `level` of i is set; completed sub-subtrees wait on a per-chain
-// stack (vectors in global scratch, scalars in LDS).  The per-chain logic is time-sliced into UNITS (finish
-// an evaluation / one merge level / end of a doubling / three pieces of the iteration end), one unit per
-// chain per trip, so the workgroup barrier never waits for a long bookkeeping path of one chain.  Random draws are consumed in the recursion's
-// post-order, so a chain reproduces the CPU oracle's trajectory for the same xoshiro stream.
+// stack (level 0 in registers, vectors of the other levels in global scratch, scalars in LDS).  The per-chain
+// logic is time-sliced into UNITS (finish an evaluation / one merge level / end of a doubling / three pieces of
+// the iteration end), one unit per chain per trip, so the workgroup barrier never waits for a long bookkeeping
+// path of one chain.  Random draws are consumed in the recursion's post-order, so a chain reproduces the CPU
+// oracle's trajectory for the same xoshiro stream.
+//
+// Template instantiations: W = DP/16 (1, 2, 4, 8); NUTS / HMC; PLAIN (compile-time feature set of the common
+// surrogate) or generic; FULLM (full-rank metric, bfhip_metric.h); STAMPS (diagnostic phase counters).
 #include <type_traits>
 #include "bfhip_eval.h"
 #include "bfhip_metric.h"
