@@ -19,7 +19,7 @@ def flops_per_leapfrog(d, use_bound=True):
     return (4 if use_bound else 2) * d * d
 
 
-def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7):
+def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7, fit_scale=1.5):
     """Config-2 family of SURVEY.md section 8(d) at dimension d: target logp = -x^T P x / 2 with P = L L^T,
     L = I + 0.3 tril(G, -1) / sqrt(d), G ~ N(0, 1) from default_rng(seed).
 
@@ -27,8 +27,15 @@ def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7):
     modules/poly.py:185-186,232-260).  The target is exactly quadratic, so the least-squares solution is
     known in closed form (linear part 0, upper-triangular a[j,k] from -P/2); the bound statistics
     mu, H = inv(cov), alpha = max Mahalanobis radius (modules/poly.py:268-276) are those of the
-    n_fit_mult * P fit points x ~ N(0, I) from default_rng(fit_seed), and f_mu is the surrogate at the
-    fit point of largest logp (center_max)."""
+    n_fit_mult * P fit points x ~ N(0, fit_scale^2 I) from default_rng(fit_seed), and f_mu is the surrogate at the
+    fit point of largest logp (center_max).
+
+    fit_scale = 1.5 makes the training set broader than the posterior, as the first rounds of a recipe are: the
+    alpha-ellipsoid then contains the posterior with a wide margin.  With a training set as tight as the
+    posterior (fit_scale = 1) the linear extrapolation outside the ellipsoid (modules/poly.py:480-503) wins in 64
+    dimensions: its radial density beta^63 exp(-c beta) still rises just outside the bound, chains leak out and
+    stay there (99 % of 4096 chains after 900 iterations, every leapfrog then paying the second evaluation at the
+    projected point) -- a property of the reference's bound without its decay term, not a sampling workload."""
     rng = np.random.default_rng(seed)
     L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
     P = L @ L.T
@@ -37,7 +44,7 @@ def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7):
     iu = np.triu_indices(d)
     quad[iu] = A[iu] * np.where(iu[0] == iu[1], 1., 2.)
     n_param = 1 + d + d * (d + 1) // 2
-    x = np.random.default_rng(fit_seed).normal(size=(n_fit_mult * n_param, d))
+    x = fit_scale * np.random.default_rng(fit_seed).normal(size=(n_fit_mult * n_param, d))
     mu = np.mean(x, axis=0)
     hess = np.linalg.inv(np.atleast_2d(np.cov(x, rowvar=False)))
     beta = np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5
