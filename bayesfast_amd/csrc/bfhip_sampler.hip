@@ -72,7 +72,7 @@ enum { SL_LEFT_Q = 0, SL_LEFT_P, SL_LEFT_G, SL_RIGHT_Q, SL_RIGHT_P, SL_RIGHT_G, 
 enum { LS_LS = 0, LS_E, LS_LOGP, LS_ACC, LS_N };
 // cold per-chain scalars parked in LDS (one writer: lane 0 of the chain's wave; broadcast reads)
 enum { CS_LOG_STEP = 0, CS_LOG_BAR, CS_HBAR, CS_SMU, CS_COUNT, CS_PROP_E, CS_PROP_LOGP, CS_MAX_DE, CS_HACC, CS_HDE,
-       CS_W_OFF, CS_TREE_W, CS_BETA, CS_T_E, CS_T_LOGP, CS_N };
+       CS_W_OFF, CS_TREE_W, CS_BETA, CS_T_E, CS_T_LOGP, CS_STEP_NOW, CS_STEP_BAR, CS_N };
 
 // one DPP move of a double (both halves)
 template <int CTRL>
@@ -384,6 +384,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         cs_set(CS_HBAR, rfl(scp[BFHIP_SC_HBAR]));
         cs_set(CS_SMU, rfl(scp[BFHIP_SC_MU]));
         cs_set(CS_COUNT, rfl(scp[BFHIP_SC_COUNT]));
+        cs_set(CS_STEP_NOW, uexp(rfl(scp[BFHIP_SC_LOG_STEP])));  // exp(log_step), exp(log_bar): what the statistics report
+        cs_set(CS_STEP_BAR, uexp(rfl(scp[BFHIP_SC_LOG_BAR])));
         i_iter = rfl((int)scp[BFHIP_SC_I_ITER]);
         err = rfl((int)scp[BFHIP_SC_ERROR]);
         load_vec(BFHIP_VEC_Q, q, 0.);
@@ -670,6 +672,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 cs_set(CS_LOG_STEP, log_step);
                 cs_set(CS_LOG_BAR, log_bar);
                 cs_set(CS_COUNT, count + 1.);
+                cs_set(CS_STEP_NOW, uexp(log_step));
+                cs_set(CS_STEP_BAR, uexp(log_bar));
             }
             const double prop_E = cs_get(CS_PROP_E), prop_logp = cs_get(CS_PROP_LOGP);
             const int orow = i_iter - a.iter_out0;
@@ -681,8 +685,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     st[BFHIP_NS_TREE_DEPTH] = (double)depth;
                     st[BFHIP_NS_TREE_SIZE] = (double)n_prop;
                     st[BFHIP_NS_MEAN_TREE_ACCEPT] = accept_stat;
-                    st[BFHIP_NS_STEP_SIZE] = exp(log_step);
-                    st[BFHIP_NS_STEP_SIZE_BAR] = exp(log_bar);
+                    st[BFHIP_NS_STEP_SIZE] = cs_get(CS_STEP_NOW);
+                    st[BFHIP_NS_STEP_SIZE_BAR] = cs_get(CS_STEP_BAR);
                     st[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
                     st[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
                     st[BFHIP_NS_MAX_ENERGY_CHANGE] = max_de;
@@ -693,8 +697,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                     st[BFHIP_HS_N_INT_STEP] = (double)a.cfg.n_int_step;
                     st[BFHIP_HS_ACCEPT_STAT] = accept_stat;
                     st[BFHIP_HS_ACCEPTED] = (double)h_accepted;
-                    st[BFHIP_HS_STEP_SIZE] = exp(log_step);
-                    st[BFHIP_HS_STEP_SIZE_BAR] = exp(log_bar);
+                    st[BFHIP_HS_STEP_SIZE] = cs_get(CS_STEP_NOW);
+                    st[BFHIP_HS_STEP_SIZE_BAR] = cs_get(CS_STEP_BAR);
                     st[BFHIP_HS_WARMUP] = warm ? 1. : 0.;
                     st[BFHIP_HS_ENERGY_CHANGE] = cs_get(CS_HDE);
                     st[BFHIP_HS_DIVERGING] = (double)diverged;
