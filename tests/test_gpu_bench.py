@@ -1,0 +1,44 @@
+"""The bench contract on a GPU box: one JSON line with the required keys at N = 1, and the one-process-per-GPU path
+(sharded chains, max-over-ranks time, summed leapfrogs) exercised with two ranks sharing the box's GPU over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+        'vs_baseline', 'dtype', 'data', 'config', 'roofline')
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '2', '--chains', '512', '--no-cpu-baseline'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    for k in KEYS:
+        assert k in j, k
+    assert j['n_gpus'] == 1 and j['steps'] == 2 and j['warmup'] == 2 and j['value'] > 0 and j['dtype'] == 'f64'
+    rf = j['roofline']
+    assert rf['bound'] in ('hbm', 'mfma') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
+    assert 'workload' in j['config'] and 'model' not in j['config']
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '2', '--chains', '256',
+           '--backend', 'gloo', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
+    assert j['config']['chains_per_gpu'] == 256
