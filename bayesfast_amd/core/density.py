@@ -99,6 +99,21 @@ class SurrogateDensity:
     def to_original_grad2(self, x):
         return self._constraint('to_original_grad2', x)
 
+    # device-tensor variants used by ``sample`` (no host round trip; identity without input_scales, as the
+    # reference's ``_constraint`` returns x / ones / zeros then, core/density.py:100-107)
+    def to_original_device(self, x_dev):
+        if self._input_scales is None:
+            return x_dev
+        return self._transform_device().constraint('to_original', x_dev)
+
+    def to_original_density_device(self, density_dev, x_dev):
+        """core/density.py:188-195 on device tensors: density - sum(log|d x_orig / d x_trans|)."""
+        if self._input_scales is None:
+            return density_dev
+        import torch
+        g = self._transform_device().constraint('to_original_grad', x_dev)
+        return density_dev - torch.sum(torch.log(torch.abs(g)), dim=-1)
+
     def to_original_density(self, density, x_trans):
         """core/density.py:188-195: density in the original space from the transformed-space value."""
         diff = np.sum(np.log(np.abs(self.to_original_grad(x_trans))), axis=-1)

@@ -9,6 +9,21 @@ from .. import parallel
 __all__ = ['sample']
 
 
+def _to_host(t):
+    """Device tensor -> NumPy array through a pinned staging buffer (pageable copies run at a third of the PCIe rate)."""
+    import torch
+    if not t.is_cuda:
+        return t.numpy()
+    t = t.contiguous()
+    try:
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return h.numpy()
+    except RuntimeError:  # no pinned memory left: plain copy
+        return t.cpu().numpy()
+
+
 def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_backend=None, verbose=True,
            iters_per_launch=None):
     """Sample a surrogate density.
@@ -92,17 +107,30 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
         ss.append(s)
         sts.append(st)
         left -= k
-    s = torch.cat(ss, 1)
-    st = torch.cat(sts, 1)
+    s = ss[0] if len(ss) == 1 else torch.cat(ss, 1)
+    st = sts[0] if len(sts) == 1 else torch.cat(sts, 1)
+    # boundary conversions on device (core/sample.py:175-177), then ONE pass of device-to-host copies
+    s_orig = density.to_original_device(s)
+    lp_orig = density.to_original_density_device(st[:, :, 0], s)
     if ws > 1:
+        s_orig = s_orig if s_orig is s else parallel.all_gather_chains(s_orig, trace.n_chain)
+        lp_orig = parallel.all_gather_chains(lp_orig.contiguous(), trace.n_chain)
         s = parallel.all_gather_chains(s, trace.n_chain)
         st = parallel.all_gather_chains(st, trace.n_chain)
-    s, st = s.cpu().numpy(), st.cpu().numpy()
+        if density._input_scales is None:
+            s_orig = s
+    same = s_orig is s
+    s, st, lp_orig = _to_host(s), _to_host(st), _to_host(lp_orig)
+    s_orig = s if same else _to_host(s_orig)
     if prev is not None:
+        shared = same and prev._samples_original is prev._samples
+        if not shared:
+            s_orig = np.concatenate([prev._samples_original, s_orig], 1)
         s = np.concatenate([prev._samples, s], 1)
+        if shared:
+            s_orig = s
         st = np.concatenate([prev._stats, st], 1)
-    s_orig = density.to_original(s)                                 # core/sample.py:175
-    lp_orig = density.to_original_density(st[:, :, 0], x_trans=s)   # :176-177
+        lp_orig = np.concatenate([prev._logp_original, lp_orig], 1)
     if verbose and rank == 0:
         nl = st[:, :, 3].sum() if trace._sampler == 'NUTS' else st[:, :, 2].sum()
         print(' sampling finished [ {} / {} ], {} chains, {} leapfrog steps.'.format(s.shape[1], trace.n_iter,
