@@ -29,7 +29,7 @@
 // path of one chain.  Random draws are consumed in the recursion's post-order, so a chain reproduces the CPU
 // oracle's trajectory for the same xoshiro stream.
 //
-// Template instantiations: W = DP/16 (1, 2, 4, 8); NUTS / HMC; PLAIN (compile-time feature set of the common
+// Template instantiations: W = DP/16 (1, 2, 4, 8); NUTS / HMC; FS (compile-time feature set; 1 = PLAIN, the common
 // surrogate) or generic; FULLM (full-rank metric, bfhip_metric.h); STAMPS (diagnostic phase counters).
 #include <type_traits>
 #include "bfhip_eval.h"
@@ -200,11 +200,15 @@ struct SamplerGeo {
 // and the state of the optional features disappear from the instantiation.
 // FULLM: full-rank metric (velocity = cov p with a per-chain covariance, adapted by Welford windows and refactorised
 // every update_window iterations); the diagonal metric is the default instantiation.
-template <int W, bool NUTS, bool STAMPS, bool PLAIN, bool FULLM>
+// FS (feature spec): 0 = everything decided at run time; otherwise linear + quadratic configs with the bound, no input
+// scaling, no cubic configs, and bit 1 (value 2) = decay penalty on, bit 2 (value 4) = constraint transform on.
+// FS == 1 is the PLAIN instantiation with its register-resident A operands and tail path.
+template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
 __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
-    const bool f_quad = PLAIN ? true : (bool)m.has_quad, f_bound = PLAIN ? true : (bool)m.use_bound;
-    const bool f_decay = PLAIN ? false : (bool)m.use_decay, f_tr = PLAIN ? false : (bool)m.has_transform;
-    const bool f_su = PLAIN ? false : (bool)m.has_su, f_cubic = PLAIN ? false : (bool)m.has_cubic;
+    constexpr bool PLAIN = FS == 1, SPEC = FS != 0;
+    const bool f_quad = SPEC ? true : (bool)m.has_quad, f_bound = SPEC ? true : (bool)m.use_bound;
+    const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
+    const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = SPEC ? false : (bool)m.has_cubic;
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
     // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
     // (matrix, row tile, K part) on every trip and keeps its A operands in registers for the whole launch:
@@ -1273,10 +1277,10 @@ static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
     return dbl * sizeof(double);
 }
 
-template <int W, bool NUTS, bool STAMPS, bool PLAIN, bool FULLM = false>
+template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM = false>
 static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
-    auto k = bf_sampler_kernel<W, NUTS, STAMPS, PLAIN, FULLM>;
-    const size_t lds = sampler_lds_bytes(ctx->model, PLAIN);
+    auto k = bf_sampler_kernel<W, NUTS, STAMPS, FS, FULLM>;
+    const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + 15) / 16;
@@ -1293,13 +1297,24 @@ template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
     const bool plain = sampler_plain(m) && !args.mat;
-    if (args.mat) return launch_sampler_t<W, NUTS, false, false, true>(ctx, args);
+    if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);
 #ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
-        return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS)>(ctx, args)
-                     : launch_sampler_t<W, NUTS, (W == 4 && NUTS), false>(ctx, args);
+        return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS) ? 1 : 0>(ctx, args)
+                     : launch_sampler_t<W, NUTS, (W == 4 && NUTS), 0>(ctx, args);
 #endif
-    return plain ? launch_sampler_t<W, NUTS, false, true>(ctx, args) : launch_sampler_t<W, NUTS, false, false>(ctx, args);
+    if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
+#ifndef BF_ONLY_HEADLINE
+    // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
+    // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)
+    if (W == 4 && !g_no_plain && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic) {
+        constexpr int W4 = W == 4 ? 4 : W;  // (keeps the other W from instantiating these)
+        if (m.use_decay && m.has_transform) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 7 : 0)>(ctx, args);
+        if (m.use_decay) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 3 : 0)>(ctx, args);
+        if (m.has_transform) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 5 : 0)>(ctx, args);
+    }
+#endif
+    return launch_sampler_t<W, NUTS, false, 0>(ctx, args);
 }
 
 extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_chain, int iter_end,

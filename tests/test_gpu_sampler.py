@@ -351,3 +351,21 @@ def test_odd_shapes_match_oracle(ctx, d):
                     so, sto = orc.hmc_run(spec, ch, rng, 12, 8, n_int_step=6)
                     assert np.array_equal(st[i, :, _lib.HSTATS.index('accepted')], sto['accepted']), (d, C, i)
                 np.testing.assert_allclose(s[i, :5], so[:5], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize('decay,bounds', [(True, False), (False, True), (True, True)])
+def test_compile_time_feature_sets_64d_match_oracle(ctx, samp, decay, bounds):
+    """The 64-d instantiations with the decay penalty and / or the constraint transform fixed at compile time
+    (sampler template parameter FS = 3, 5, 7) against the oracle."""
+    spec = dict(_spec(samp, 'd64.'))
+    d = 64
+    if decay:
+        spec.update(use_decay=True, decay_mu=spec['poly']['mu'], decay_hess=spec['poly']['hess'],
+                    decay_alpha2=float(spec['poly']['alpha'])**2 * 0.6, decay_gamma=0.1)
+    if bounds:
+        lo = np.full(d, -9.) + np.arange(d) * 0.01
+        spec.update(ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * 16, dtype=np.uint8))
+    x0 = np.random.default_rng(8).normal(size=(5, d)) * 0.3
+    dev = _device_chains(ctx, spec, x0, 14, 9)
+    orc_runs = _oracle_chains(spec, x0, 14, 9)
+    _compare_nuts(dev, orc_runs, 14, n_head=6, tol_head=1e-8)
