@@ -88,18 +88,11 @@ __device__ inline double readlane_f64(double v, int l) {
 // divergent to the compiler, which then keeps the whole chain state machine in VGPRs and lowers its branches to
 // exec-mask manipulation.  rfl() states the uniformity: the value moves to scalar registers and everything
 // derived from it (unit, mode, depth, the branch conditions) stays scalar.
-#ifdef BF_NO_RFL  // tuning experiment: leave the uniformity undeclared
-__device__ inline int rfl(int v) { return v; }
-__device__ inline double rfl(double v) { return v; }
-__device__ inline uint64_t rfl(uint64_t v) { return v; }
-__device__ inline uint64_t rfl_unused(uint64_t v) {
-#else
 __device__ inline int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline double rfl(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 __device__ inline uint64_t rfl(uint64_t v) {
-#endif
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
@@ -117,18 +110,17 @@ __device__ inline double swap32_add_f64(double v) {
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
-// Sums over the 64 lanes of N independent values, wave-uniform results in a fixed order: DPP butterflies
-// inside each row of 16 lanes, then two row swaps (no LDS crossbar).  The N reductions advance step by
-// step together so that the latency of each f64 add is covered by the other values' instructions.
-#ifndef BF_WSUM_MODE
-#define BF_WSUM_MODE 3
-#endif
+// Sums over the 64 lanes of N independent values, wave-uniform results in a fixed order.  The N reductions advance
+// step by step together so that the latency of each step is covered by the other values' instructions.
+// Default: two v_mfma_f64_4x4x4 per value (the matrix pipe is idle in the chain phase) and two row rotations; with
+// BF_WSUM_BUTTERFLY: four DPP butterfly steps inside the rows of 16 lanes and two gfx950 row swaps (11 % slower on the
+// headline workload, kept as the reference form of the reduction).
 template <int N>
 __device__ inline void wave_sum_n(double (&v)[N]) {
-#if BF_WSUM_MODE == 3
-    // two v_mfma_f64_4x4x4 per value: with B = 1 the first leaves, in lane 16i + 4b + j, the sum of the four lanes
-    // 16k + 4b + i (k = 0..3); fed back as the B operand with A = 1 the second sums those over i: every lane of
-    // block b = (lane >> 2) & 3 holds the total of its block's 16 lanes; two row rotations add the four blocks.
+#ifndef BF_WSUM_BUTTERFLY
+    // with B = 1 the first MFMA leaves, in lane 16i + 4b + j, the sum of the four lanes 16k + 4b + i (k = 0..3); fed
+    // back as the B operand with A = 1 the second sums those over i: every lane of block b = (lane >> 2) & 3 holds the
+    // total of its block's 16 lanes; two row rotations add the four blocks.
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[i], 1., 0., 0, 0, 0);
 #pragma unroll
@@ -137,24 +129,7 @@ __device__ inline void wave_sum_n(double (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x128>(v[i]);  // row_ror:8
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x124>(v[i]);  // row_ror:4
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = rfl(v[i]);
-#elif BF_WSUM_MODE == 0
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double t = v[i];
-        t += dpp_f64<0xB1>(t);
-        t += dpp_f64<0x4E>(t);
-        t += dpp_f64<0x141>(t);
-        t += dpp_f64<0x140>(t);
-        v[i] = ((readlane_f64(t, 0) + readlane_f64(t, 16)) + readlane_f64(t, 32)) + readlane_f64(t, 48);
-    }
 #else
-#ifdef BF_X_NOSUM  // timing experiment only (wrong sums): what do the reductions cost on the critical path?
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = rfl(v[i]) * 64.;
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] += dpp_f64<0xB1>(v[i]);   // quad_perm [1,0,3,2]
 #pragma unroll
@@ -163,21 +138,13 @@ __device__ inline void wave_sum_n(double (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x141>(v[i]);  // row_half_mirror
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] += dpp_f64<0x140>(v[i]);  // row_mirror
-#if BF_WSUM_MODE == 1
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-        v[i] = ((readlane_f64(v[i], 0) + readlane_f64(v[i], 16)) + readlane_f64(v[i], 32)) + readlane_f64(v[i], 48);
-#else
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = swap16_add_f64(v[i]);
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = swap32_add_f64(v[i]);
+#endif
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        v[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v[i])),
-                                __builtin_amdgcn_readfirstlane(__double2loint(v[i])));
-#endif
-#endif
+    for (int i = 0; i < N; ++i) v[i] = rfl(v[i]);
 }
 __device__ inline double wave_sum(double v) {
     double t[1] = {v};
@@ -213,16 +180,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
     // (matrix, row tile, K part) on every trip and keeps its A operands in registers for the whole launch:
     // the coefficient matrices are not staged in LDS at all.
-#ifdef BF_NO_AREG
-    constexpr bool AREG = false;
-#else
     constexpr bool AREG = PLAIN && W <= 4;
-#endif
-#ifdef BF_NO_TAIL
-    constexpr bool TAIL = false;
-#else
     constexpr bool TAIL = AREG;
-#endif
     constexpr int KS_P = (W == 2 || W == 4) ? 2 : 1, KPJ_P = (4 * W) / KS_P, NJOB_P = 2 * W * KS_P;
     using G = SamplerGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
@@ -415,17 +374,12 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #define TRACE(k) do { } while (0)
 #endif
 
-#ifndef BF_FUSE
-#define BF_FUSE 0
-#endif
     auto run_unit = [&](bool have_ev, double E_new, double logp_new) {
         // ================= per-chain state machine: ONE unit of work per trip =================
         // (wave-uniform control flow; the barrier-to-barrier critical path is the longest single unit.)
-        // BF_FUSE >= 1 (tuning) runs the merge levels / doubling end that follow a leaf in the leaf's own trip.
-        // Measured slower while the subtree stack lives in global memory: the stack loads of a fused merge
-        // are consumed at once, and their latency is longer than the trip they save (1.7e8 against 2.2e8
-        // leapfrog steps/s on the headline workload); with one unit per trip they are prefetched a trip ahead.
-        for (;;) {
+        // (Running the merge levels / the doubling end that follow a leaf in the leaf's own trip was measured slower
+        // twice: with the subtree stack in global memory a fused merge consumes its loads at once, and the larger live
+        // ranges triple the register spills; with one unit per trip the operands are prefetched a trip ahead.)
         if (unit == U_EVAL) {
             if (have_ev && mode == M_INIT) {
                 // BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43
@@ -891,9 +845,6 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             }
         }
         if (err != 0) { mode = M_DONE; unit = U_DONE; }
-        if (!((BF_FUSE >= 1 && unit == U_MERGE_RUN) || (BF_FUSE >= 2 && unit == U_DBL_END))) break;
-        have_ev = false;
-        }
     };
 
     // enabled coefficient matrices in slot order: mat0 = id of the first, mat1 = id of the second (the third is 2)
@@ -992,10 +943,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         auto run_jobs = [&](auto ks_tag) {
             constexpr int KS = decltype(ks_tag)::value;
             constexpr int KPJ = NS / KS;                        // k-steps per job
-#ifndef BF_JOB_CH
-#define BF_JOB_CH 8
-#endif
-            constexpr int CH = KPJ < BF_JOB_CH ? KPJ : BF_JOB_CH;  // k-steps fetched together
+            constexpr int CH = KPJ < 8 ? KPJ : 8;               // k-steps fetched together
             const int mc = lane & 15, mg = lane >> 4;
             const int n_job = n_mat * (W * KS);
             for (int job = w; job < n_job; job += 16) {
@@ -1049,20 +997,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
                 const double *Xf = XB + (slot_m * NS + kp * KPJ_P) * XS + lane;  // PLAIN: matrix id == slot
                 d4_t acc = {0., 0., 0., 0.};
-#ifndef BF_X_NOMFMA  // (timing experiment: skip the matvec, results are zeros)
                 double xv[KPJ_P];
 #pragma unroll
                 for (int s = 0; s < KPJ_P; ++s) xv[s] = Xf[s * XS];
-#ifdef BF_X_MFMA_N  // timing experiment: BF_X_MFMA_N MFMAs per job instead of KPJ_P
-#pragma unroll
-                for (int s = 0; s < BF_X_MFMA_N; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s % KPJ_P], xv[s % KPJ_P], acc, 0, 0, 0);
-#else
 #pragma unroll
                 for (int s = 0; s < KPJ_P; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], xv[s], acc, 0, 0, 0);
-#endif
-#else
-                acc[0] = afr[0] * 1e-300 + Xf[0] * 1e-300;
-#endif
                 TRACE(4);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
