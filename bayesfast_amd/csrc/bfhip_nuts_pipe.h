@@ -1,0 +1,643 @@
+// bfhip_nuts_pipe.h -- software-pipelined NUTS transitions for the common surrogate at d <= 64 (gfx950).
+// Included by bfhip_sampler.hip (uses its helpers: rfl, wave_sum_n, the out-of-line libm wrappers, SamplerArgs, enums).
+//
+// Same decomposition as bf_sampler_kernel (one wave per chain, 16 chains per workgroup, the batched matvecs S X^T and
+// H (X - mu)^T of the group on v_mfma_f64_16x16x4_f64, two workgroup barriers per trip) and the SAME arithmetic per
+// chain, in the same order: a chain's samples and statistics are bit-identical to bf_sampler_kernel's.  What changes is
+// WHEN the tree bookkeeping runs:
+//
+//   * bf_sampler_kernel gives every unit of bookkeeping (leaf logic, a merge level, the end of a doubling, the pieces
+//     of the iteration end) a trip of its own or the tail of one, so a 7-leaf iteration takes 15 trips and the matrix
+//     pipe idles while the chain waves run their latency-bound scalar logic (and vice versa).
+//   * Here the bookkeeping of leaf n is DEFERRED into the MFMA window of trip n+1: after the barrier that publishes the
+//     positions, every wave issues the MFMAs of its job and, while the matrix pipe works through the four waves' tiles,
+//     runs the pending bookkeeping of its chain (leaf weights, merges, doubling end, iteration end) on the VALU.
+//     The leapfrog step of trip n+1 therefore starts BEFORE leaf n has been accounted for: it is speculative.  The
+//     speculation is exact whenever the tree goes on: inside a doubling the next leaf continues from the current one,
+//     and at the end of a doubling the direction of the next one is read ahead from the chain's random stream (the
+//     number of draws the pending bookkeeping will consume is known: one per merge level and one for the swap,
+//     samplers/nuts.py:163-167,81-83, then the direction, :210).  When the pending bookkeeping ends the tree (U-turn,
+//     divergence, depth limit) the evaluation in flight is dropped; that is one wasted evaluation per iteration, in a
+//     trip the group runs anyway.  A 7-leaf iteration takes 9 trips.
+//   * The subtree ends, the proposal, p_sum and stack level 1 live in LDS (12 vectors per chain); only the deeper
+//     stack levels go to global scratch.  There is no prefetch buffer and no tail path (the row-major matrices of the
+//     tail path do not fit next to the tree vectors; a lone chain is faster here than on the tail path there).
+//
+// E = 1 throughout (lane = dimension, d <= 64).
+
+
+enum { M_END = 4 };  // the tree has ended; the iteration-end work runs in the window of the next trip
+
+template <int W>
+struct PipeGeo {
+    static constexpr int KS = (W == 2 || W == 4) ? 2 : 1;  // K-split of the matvec jobs: every wave owns one job
+    static constexpr int KPJ = (4 * W) / KS, NJOB = 2 * W * KS, NTL = 12;
+    static constexpr size_t lds_doubles() {
+        using G = SamplerGeo<W>;
+        return (size_t)2 * G::NS * G::XS + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 + (size_t)16 * CS_N +
+               (size_t)16 * NTL * G::DP + (size_t)2 * KS * 16 * G::GS;
+    }
+};
+
+template <int W>
+__global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
+    using G = SamplerGeo<W>;
+    using PG = PipeGeo<W>;
+    constexpr int DP = G::DP, NS = G::NS, XS = G::XS, GS = G::GS;
+    constexpr int KS_P = PG::KS, KPJ_P = PG::KPJ, NJOB_P = PG::NJOB, NTL = PG::NTL;
+    constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
+    static_assert(DP <= 64, "one dimension per lane");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *XB = lds;                             // [2][NS][XS]   B operands: x | x - mu
+    double *LS = XB + 2 * NS * XS;                // [16][MAXL][LS_N] per-chain stack scalars
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity)
+    double *CS = LS + 16 * MAXL * LS_N + 2;       // [16][CS_N]    cold per-chain scalars
+    double *TB = CS + 16 * CS_N;                  // [16][NTL][DP] tree vectors: slots 0-7, stack level 1
+    double *GB = TB + 16 * NTL * DP;              // [2 KS][16][GS] matvec results
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
+    const int chain = blockIdx.x * 16 + w;
+    const bool real = chain < a.n_chain;
+    const int d = m.d;
+    const bool lane_ok = lane < DP;
+
+    // A operands of this wave's job (matrix, row tile, K part) stay in registers for the whole launch
+    double afr[KPJ_P];
+    {
+        const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
+        const double *Af = (slot_m == 0 ? m.Sf : m.Hf) + (t * NS + kp * KPJ_P) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KPJ_P; ++s) afr[s] = (w < NJOB_P) ? Af[s * 64] : 0.;
+    }
+    if (tid < 4) alive[tid] = 0;
+    const double c_lin = lane_ok ? m.pd[PD_LIN * DP + lane] : 0.;
+    const double c_mu = lane_ok ? m.pd[PD_MU * DP + lane] : 0.;
+
+    // ---- per-chain state (scalars are wave-uniform) ----
+    double q = 0., p = 0., g = 0., var = 1.;
+    double TLp = 0., TPs = 0., TPq = 0.;  // the subtree under construction: left end p, p_sum, proposal q
+    double TRp = 0.;                      // p of the newest accounted leaf (the subtree's right end in time order)
+    double L0p = 0., L0q = 0.;            // stack level 0 (a single waiting leaf)
+    uint64_t rs[4] = {0, 0, 0, 0};
+    int i_iter = 0, mode = M_DONE, prev_mode = M_INIT, err = 0;
+    double eps = 0., eps_t = 0.;
+    int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0;
+    double start_energy = 0., acc_sum = 0.;
+    double T_W = 0., T_acc = 0.;
+    double max_de = 0., w_off = 0., L0_W = 0., L0_acc = 0.;
+    bool pend = false;                    // a finished leaf evaluation waits for its bookkeeping
+    double E_pend = 0., lp_pend = 0.;
+    double *csw = CS + w * CS_N;
+    auto cs_set = [&](int i, double v) { if (lane == 0) csw[i] = v; };
+    auto cs_get = [&](int i) -> double { return rfl(csw[i]); };
+    unsigned long long nlf = 0;
+    double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + lane;
+    double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
+    double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
+    double *lsw = LS + w * (MAXL * LS_N);
+    double *tbw = TB + (w * NTL) * DP + lane;
+    const int nw = a.cfg.n_warmup;
+
+    auto load_vec = [&](int field, double pad) -> double { return (lane < d) ? vecp[field * d + lane] : pad; };
+    auto store_vec = [&](int field, double v) { if (lane < d) vecp[field * d + lane] = v; };
+    // tree vectors: slots 0-7 (ends, proposal, p_sum) and stack level 1 in LDS, deeper stack levels in scratch
+    auto ldv = [&](int slot) -> double {
+        double v = 0.;
+        if (lane_ok) {
+            if (slot < SL_STACK + 8) v = tbw[(slot < 8 ? slot : slot - 4) * DP];
+            else v = sbase[(size_t)slot * DP];
+        }
+        return v;
+    };
+    auto stv = [&](int slot, double v) {
+        if (lane_ok) {
+            if (slot < SL_STACK + 8) tbw[(slot < 8 ? slot : slot - 4) * DP] = v;
+            else sbase[(size_t)slot * DP] = v;
+        }
+    };
+    // metric.random: samplers/hmc_utils/metrics.py:83-86 (same stream layout as bf_sampler_kernel)
+    auto draw_momentum = [&]() {
+        const uint64_t K = bf_xoshiro_next(rs);
+        const uint64_t P = (uint64_t)(lane >> 1);
+        const double u1 = bf_u01_open0(bf_mix64(K + (2 * P + 1) * BF_GOLDEN));
+        const double u2 = bf_u01(bf_mix64(K + (2 * P + 2) * BF_GOLDEN));
+        const double rad = sqrt(-2. * log(u1));
+        double sn, cs;
+        sincospi(2. * u2, &sn, &cs);
+        const double z = (lane & 1) ? rad * sn : rad * cs;
+        p = (lane < d) ? (1. / sqrt(var)) * z : 0.;
+        g = 0.;
+    };
+    if (real) {
+        for (int k = 0; k < 4; ++k) rs[k] = rfl((uint64_t)a.rng[(size_t)chain * 4 + k]);
+        cs_set(CS_LOG_STEP, rfl(scp[BFHIP_SC_LOG_STEP]));
+        cs_set(CS_LOG_BAR, rfl(scp[BFHIP_SC_LOG_BAR]));
+        cs_set(CS_HBAR, rfl(scp[BFHIP_SC_HBAR]));
+        cs_set(CS_SMU, rfl(scp[BFHIP_SC_MU]));
+        cs_set(CS_COUNT, rfl(scp[BFHIP_SC_COUNT]));
+        cs_set(CS_STEP_NOW, uexp(rfl(scp[BFHIP_SC_LOG_STEP])));
+        cs_set(CS_STEP_BAR, uexp(rfl(scp[BFHIP_SC_LOG_BAR])));
+        i_iter = rfl((int)scp[BFHIP_SC_I_ITER]);
+        err = rfl((int)scp[BFHIP_SC_ERROR]);
+        q = load_vec(BFHIP_VEC_Q, 0.);
+        var = load_vec(BFHIP_VEC_VAR, 1.);
+        if (i_iter < a.iter_end && err == 0) {
+            mode = M_INIT;
+            draw_momentum();
+        }
+    }
+    __syncthreads();
+
+#ifdef BF_TRACE
+    __shared__ unsigned long long TRC[BF_TRACE * 16];
+    for (int i = threadIdx.x; i < BF_TRACE * 16; i += 1024) TRC[i] = 0;
+    int trip_no = 0;
+#endif
+    // ---- iteration end: step-size adaptation, statistics, the new sample, metric adaptation, next momentum ----
+    auto iteration_end = [&]() {
+        // ================= iteration end (base_hmc.py:80-85) =================
+        {
+            const bool warm = i_iter < nw;
+            const double accept_stat = acc_sum / (double)n_prop;  // nuts.py:186
+            double log_step = cs_get(CS_LOG_STEP), log_bar = cs_get(CS_LOG_BAR);
+            if (warm && a.cfg.adapt_step_size) {  // step_size.py:31-45
+                const double count = cs_get(CS_COUNT);
+                const double wgt = 1. / (count + a.cfg.t_0);
+                const double hbar = ((1. - wgt) * cs_get(CS_HBAR) + wgt * (a.cfg.target_accept - accept_stat));
+                log_step = cs_get(CS_SMU) - hbar * usqrt(count) / a.cfg.gamma;
+                const double mk = uexp(-a.cfg.k * ulog(count));  // count ** -k
+                log_bar = mk * log_step + (1. - mk) * log_bar;
+                cs_set(CS_HBAR, hbar);
+                cs_set(CS_LOG_STEP, log_step);
+                cs_set(CS_LOG_BAR, log_bar);
+                cs_set(CS_COUNT, count + 1.);
+                cs_set(CS_STEP_NOW, uexp(log_step));
+                cs_set(CS_STEP_BAR, uexp(log_bar));
+            }
+            const double prop_E = cs_get(CS_PROP_E), prop_logp = cs_get(CS_PROP_LOGP);
+            const int orow = i_iter - a.iter_out0;
+            if (orow >= 0 && orow < a.n_out) {  // (q is the new sample: phase A of this trip took it from the proposal slot)
+                if (lane == 0) {
+                    double *st = a.stats + ((size_t)chain * a.n_out + orow) * BFHIP_STAT_STRIDE;
+                    st[BFHIP_NS_LOGP] = prop_logp;
+                    st[BFHIP_NS_ENERGY] = prop_E;
+                    st[BFHIP_NS_TREE_DEPTH] = (double)depth;
+                    st[BFHIP_NS_TREE_SIZE] = (double)n_prop;
+                    st[BFHIP_NS_MEAN_TREE_ACCEPT] = accept_stat;
+                    st[BFHIP_NS_STEP_SIZE] = cs_get(CS_STEP_NOW);
+                    st[BFHIP_NS_STEP_SIZE_BAR] = cs_get(CS_STEP_BAR);
+                    st[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
+                    st[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
+                    st[BFHIP_NS_MAX_ENERGY_CHANGE] = max_de;
+                    st[BFHIP_NS_DIVERGING] = (double)diverged;
+                }
+                double *sp = a.samples + ((size_t)chain * a.n_out + orow) * d;
+                if (lane < d) sp[lane] = q;
+            }
+            // QuadMetricDiagAdapt.update: metrics.py:186-211, _WeightedVariance.add_sample :354-360
+            if (warm && a.cfg.adapt_metric) {
+                double fg_n = rfl(scp[BFHIP_SC_FG_N]), bg_n = rfl(scp[BFHIP_SC_BG_N]);
+                double n_samples = rfl(scp[BFHIP_SC_N_SAMPLES]), prev_upd = rfl(scp[BFHIP_SC_PREV_UPDATE]);
+                double adapt_window = rfl(scp[BFHIP_SC_ADAPT_WINDOW]);
+                const long delta = (long)(n_samples - prev_upd);
+                double fm = load_vec(BFHIP_VEC_FG_MEAN, 0.), fr = load_vec(BFHIP_VEC_FG_RAW, 0.);
+                double bm = load_vec(BFHIP_VEC_BG_MEAN, 0.), br = load_vec(BFHIP_VEC_BG_RAW, 0.);
+                fg_n += 1.;
+                bg_n += 1.;
+                double od = q - fm;
+                fm += od / fg_n;
+                fr += 1. * od * (q - fm);
+                od = q - bm;
+                bm += od / bg_n;
+                br += 1. * od * (q - bm);
+                if ((delta + 1) % (long)a.cfg.update_window == 0) {  // metrics.py:181-184
+                    if (lane < d) var = fr / fg_n;
+                    store_vec(BFHIP_VEC_VAR, var);
+                }
+                if ((double)delta >= adapt_window) {
+                    fm = bm; fr = br; bm = 0.; br = 0.;
+                    fg_n = bg_n;
+                    bg_n = 10.;
+                    prev_upd = n_samples;
+                    if (a.cfg.doubling) adapt_window *= 2.;
+                }
+                n_samples += 1.;
+                store_vec(BFHIP_VEC_FG_MEAN, fm);
+                store_vec(BFHIP_VEC_FG_RAW, fr);
+                store_vec(BFHIP_VEC_BG_MEAN, bm);
+                store_vec(BFHIP_VEC_BG_RAW, br);
+                if (lane == 0) {
+                    scp[BFHIP_SC_FG_N] = fg_n;
+                    scp[BFHIP_SC_BG_N] = bg_n;
+                    scp[BFHIP_SC_N_SAMPLES] = n_samples;
+                    scp[BFHIP_SC_PREV_UPDATE] = prev_upd;
+                    scp[BFHIP_SC_ADAPT_WINDOW] = adapt_window;
+                }
+            }
+            i_iter += 1;
+            TRACE(12);
+            if (i_iter < a.iter_end && err == 0) {
+                mode = M_INIT;
+                draw_momentum();
+            } else {
+                mode = M_DONE;
+            }
+        }
+    };
+
+    auto gb_read = [&](int slot_m) -> double {
+        const double *gp = GB + ((slot_m * KS_P) * 16 + w) * GS + lane;
+        double r = gp[0];
+        if (KS_P > 1) r += gp[16 * GS];
+        return r;
+    };
+
+    for (int trip = 0;; ++trip) {
+#ifdef BF_TRACE
+        trip_no = trip;
+#endif
+        TRACE(0);
+        // ================= phase A: first half of the (speculative) leapfrog step, B operands =================
+        bool evaluating = false;
+        if (mode == M_OOB) {
+            evaluating = true;  // second pass at the projected point (eps_t stays: the step's second half comes after it)
+        } else if (mode == M_END) {
+            // the tree ended in the last window: the proposal becomes the sample and the start of the next iteration; its
+            // compute_state evaluation (base_hmc.py:70) needs only q, so it runs now, while this trip's window does the
+            // iteration-end work and draws the momentum that phase C needs
+            evaluating = true;
+            eps_t = 0.;
+            q = ldv(SL_PROP_Q);
+        } else if (mode == M_INIT) {
+            evaluating = true;  // compute_state at the start of an iteration (base_hmc.py:70): a step of length 0
+            eps_t = 0.;
+        } else if (mode == M_LEAF) {
+            int dir_use = dir;
+            evaluating = true;
+            if (pend && i_leaf == (1 << depth) - 1) {
+                // the leaf in flight closes its doubling: park the new end (its p waits in TRp until the pending
+                // full-tree checks have read the p of the end it replaces) and start the next doubling in the direction
+                // the stream will give it
+                const int eo = (dir > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
+                stv(eo + 0, q); stv(eo + 2, g);
+                if (depth + 1 >= a.cfg.max_treedepth) {
+                    evaluating = false;  // the tree stops at this depth whatever the checks say
+                } else {
+                    uint64_t t[4] = {rs[0], rs[1], rs[2], rs[3]};
+                    for (int k = 0; k <= depth; ++k) (void)bf_xoshiro_next(t);  // `depth` merges and the swap
+                    dir_use = (bf_u01(bf_xoshiro_next(t)) < 0.5) ? 1 : -1;
+                    if (dir_use != dir) {
+                        const int eo2 = (dir_use > 0) ? SL_RIGHT_Q : SL_LEFT_Q;
+                        q = ldv(eo2 + 0); p = ldv(eo2 + 1); g = ldv(eo2 + 2);
+                    }
+                }
+            }
+            if (evaluating) eps_t = eps * (double)dir_use;
+        }
+        if (evaluating) {
+            if (mode != M_OOB && mode != M_END) {  // (M_END: a step of length 0 from the new sample; p is drawn below)
+                const double dt = 0.5 * eps_t;
+                p = p + dt * g;                    // integration.py:80
+                q = q + eps_t * (var * p);         // :82-85
+            }
+            double x_eval = q;
+            if (mode == M_OOB)  // modules/poly.py:482
+                x_eval = (m.alpha * q + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
+            if (lane_ok) {
+                const int xi = (lane >> 2) * XS + w + 16 * (lane & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
+                XB[xi] = x_eval;
+                XB[NS * XS + xi] = q - c_mu;
+            }
+        }
+        if (lane == 0) {
+            if (mode != M_DONE) alive[trip & 1] = 1;
+            if (evaluating) atomicOr((unsigned *)&alive[2 + (trip & 1)], 1u << w);
+        }
+        TRACE(1);
+        __syncthreads();  // B1
+        TRACE(2);
+        if (rfl(alive[trip & 1]) == 0) break;  // every chain of the group is done (uniform)
+        const unsigned ev_mask = (unsigned)rfl(alive[2 + (trip & 1)]);
+        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; }
+
+        // ================= phase B: gradient tiles on MFMA, the pending bookkeeping between them =================
+        // A wave's MFMAs form one dependent chain (the accumulator), and a dependent v_mfma_f64_16x16x4_f64 issues
+        // about 256 cycles after its predecessor, whatever the other waves do (the pipe takes a new one every 64
+        // cycles, from four waves in turn).  Issued back to back they would block the wave's in-order instruction
+        // stream for 8 x 256 cycles.  So the chain is spread over the stages of the pending bookkeeping: one MFMA at
+        // each of KPJ fixed points of the code below, the VALU work of a stage running while the MFMA before it
+        // executes.  (Stages that have nothing to do fall through; the MFMAs then simply queue up.)
+        const bool job = ev_mask != 0 && w < NJOB_P;
+        d4_t acc = {0., 0., 0., 0.};
+        const double *Xf = XB + ((w / (W * KS_P)) * NS + (w % KS_P) * KPJ_P) * XS + lane;
+        double x_next = job ? Xf[0] : 0.;
+#define BF_MF(K)                                                                                            \
+        do {                                                                                                \
+            if ((K) < KPJ_P) {                                                                              \
+                const double x_cur = x_next;                                                                \
+                if ((K) + 1 < KPJ_P && job) x_next = Xf[((K) + 1 < KPJ_P ? (K) + 1 : 0) * XS];            \
+                asm volatile("" : "+v"(acc) : : "memory");                                                  \
+                if (job) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[(K) < KPJ_P ? (K) : 0], x_cur, acc, 0, 0, 0); \
+                asm volatile("" : "+v"(acc) : : "memory");                                                  \
+            }                                                                                               \
+        } while (0)
+        int unit = pend ? U_EVAL : U_DONE, lev = 0;
+        bool ended = false;
+        pend = false;
+        BF_MF(0);
+        TRACE(3);
+        double dE = 0.;
+        if (unit == U_EVAL) {
+            // ---- Tree._single_step: nuts.py:105-132 ----
+            nlf += 1;
+            n_prop += 1;
+            dE = E_pend - start_energy;
+            if (dE != dE) dE = INFINITY;
+            if (fabs(dE) > fabs(max_de)) max_de = dE;
+            cs_set(CS_T_E, E_pend);
+            cs_set(CS_T_LOGP, lp_pend);
+            T_acc = 0.;
+            if (!(fabs(dE) < a.cfg.max_change)) {
+                diverged = 1;
+                unit = U_ABORT;
+            }
+        }
+        BF_MF(1);
+        if (unit == U_EVAL) {
+            // multinomial weight exp(-dE) relative to a running offset w_off (exact streaming log-sum-exp)
+            double aw = -dE - w_off;
+            if (aw > 600.) {
+                const double sc_ = uexp(-aw);
+                cs_set(CS_TREE_W, cs_get(CS_TREE_W) * sc_);
+                if (lane == 0)
+                    for (int l2 = 0; l2 < depth; ++l2) lsw[l2 * LS_N + LS_LS] *= sc_;
+                L0_W *= sc_;
+                w_off = w_off + aw;
+                aw = 0.;
+            }
+            T_W = uexp(aw);
+            const double pacc = (w_off == 0.) ? T_W : uexp(-dE);
+            T_acc = pacc > 1. ? 1. : pacc;
+            TLp = TRp;
+            TPs = TRp;  // (TPq was set when the evaluation finished)
+            unit = U_MERGE;
+        }
+        BF_MF(2);
+        TRACE(9);
+        if (unit == U_MERGE && (i_leaf & 1) && depth > 0) {
+            // ---- level-0 merge with the previous leaf, whose (p, q) wait in L0p / L0q (nuts.py:146-178) ----
+            const double ps0 = L0p + TRp;
+            double r2[2] = {ps0 * (var * L0p), ps0 * (var * TRp)};  // nuts.py:150-151
+            wave_sum_n<2>(r2);
+            T_acc = L0_acc + T_acc;  // :173
+            const double Wsum = L0_W + T_W;
+            if (Wsum != Wsum) err = 2;
+            const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
+            lev = 1;
+            if ((r2[0] <= 0.) || (r2[1] <= 0.)) {
+                unit = U_ABORT;
+            } else {
+                if (!((u * Wsum < T_W) || (u == 0.))) {
+                    TPq = L0q;
+                    cs_set(CS_T_E, rfl(lsw[LS_E]));
+                    cs_set(CS_T_LOGP, rfl(lsw[LS_LOGP]));
+                }
+                T_W = Wsum;
+                TPs = L0p + TRp;
+                TLp = L0p;
+            }
+        }
+        BF_MF(3);
+        // ---- merge upwards while the finished subtree is a right child (nuts.py:146-178) ----
+        while (unit == U_MERGE && lev < depth && ((i_leaf >> lev) & 1)) {
+            const int slot = SL_STACK + 4 * lev;
+            const double A = ldv(slot + 0), B = ldv(slot + 1), S1 = ldv(slot + 2);
+            const double psum = S1 + TPs;
+            const double vA = var * A, vB = var * B, vC = var * TLp, vD = var * TRp;
+            const double ps1 = S1 + TLp;   // :155-157
+            const double ps2 = B + TPs;    // :158-160
+            double r6[6] = {psum * vA, psum * vD, ps1 * vA, ps1 * vC, ps2 * vB, ps2 * vD};
+            wave_sum_n<6>(r6);
+            const bool turning = (r6[0] <= 0.) || (r6[1] <= 0.) || (r6[2] <= 0.) || (r6[3] <= 0.) || (r6[4] <= 0.) || (r6[5] <= 0.);
+            const double *lsp = lsw + lev * LS_N;
+            T_acc = rfl(lsp[LS_ACC]) + T_acc;  // :173
+            const double Wsum = rfl(lsp[LS_LS]) + T_W;
+            if (Wsum != Wsum) err = 2;
+            const double u = bf_u01(bf_xoshiro_next(rs));  // consumed even when this merge's check says turning
+            const bool keep_t2 = (u * Wsum < T_W) || (u == 0.);
+            lev += 1;
+            if (turning) {
+                unit = U_ABORT;  // ancestors above this level still add their accept sums
+            } else {
+                if (!keep_t2) {
+                    TPq = ldv(slot + 3);  // the sibling's proposal
+                    cs_set(CS_T_E, rfl(lsp[LS_E]));
+                    cs_set(CS_T_LOGP, rfl(lsp[LS_LOGP]));
+                }
+                T_W = Wsum;
+                TLp = A;
+                TPs = psum;
+            }
+        }
+        BF_MF(4);
+        TRACE(10);
+        if (unit == U_MERGE) {
+            if (lev < depth) {
+                // the subtree waits for its right sibling
+                if (lev == 0) {
+                    L0p = TRp;
+                    L0q = TPq;  // a single leaf: its proposal is its own position
+                    L0_W = T_W;
+                    L0_acc = T_acc;
+                } else {
+                    const int slot = SL_STACK + 4 * lev;
+                    stv(slot + 0, TLp); stv(slot + 1, TRp); stv(slot + 2, TPs); stv(slot + 3, TPq);
+                }
+                if (lane == 0) {
+                    double *lsp = lsw + lev * LS_N;
+                    lsp[LS_LS] = T_W; lsp[LS_ACC] = T_acc;
+                    lsp[LS_E] = (lev == 0) ? E_pend : cs_get(CS_T_E);
+                    lsp[LS_LOGP] = (lev == 0) ? lp_pend : cs_get(CS_T_LOGP);
+                }
+                i_leaf += 1;
+                unit = U_DONE;
+            } else {
+                unit = U_DBL_END;
+            }
+        }
+        BF_MF(5);
+        if (unit == U_ABORT) {
+            // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
+            for (int al = (diverged ? 0 : lev); al < depth; ++al)
+                if ((i_leaf >> al) & 1) T_acc = rfl(lsw[al * LS_N + LS_ACC]) + T_acc;
+            depth += 1;  // nuts.py:71-73
+            acc_sum += T_acc;
+            unit = U_END1;
+        } else if (unit == U_DBL_END) {
+            // ---- Tree.extend after a complete subtree: nuts.py:71-103 ----
+            // (phase A has already parked the q and the gradient of the new end; its p is still TRp)
+            double ps = ldv(SL_PSUM);
+            const double oldL = ldv(SL_LEFT_P), oldR = ldv(SL_RIGHT_P);
+            depth += 1;
+            acc_sum += T_acc;
+            {   // :81-83  logbern(ls_new - ls_old)  <=>  U * W_old < W_new
+                const double tree_W = cs_get(CS_TREE_W);
+                if (T_W != T_W || tree_W != tree_W) err = 2;
+                const double u = bf_u01(bf_xoshiro_next(rs));
+                if ((u * tree_W < T_W) || (u == 0.)) {
+                    stv(SL_PROP_Q, TPq);
+                    cs_set(CS_PROP_E, cs_get(CS_T_E));
+                    cs_set(CS_PROP_LOGP, cs_get(CS_T_LOGP));
+                }
+                cs_set(CS_TREE_W, tree_W + T_W);  // :85
+            }
+            ps += TPs;  // :86 (in place)
+            const double vN = var * TRp, vT = var * TLp, vL = var * oldL, vR = var * oldR;
+            double r6[6];
+            // NOTE (reference behaviour, kept on purpose): leftmost_p_sum (dir > 0) / rightmost_p_sum (dir < 0) alias
+            // self.p_sum, which line 86 has just updated in place.
+            if (dir > 0) {
+                const double ps1 = ps + TLp, ps2 = oldR + TPs;
+                r6[0] = ps * vL; r6[1] = ps * vN; r6[2] = ps1 * vL; r6[3] = ps1 * vT; r6[4] = ps2 * vR; r6[5] = ps2 * vN;
+            } else {
+                const double ps1 = TPs + oldL, ps2 = TLp + ps;
+                r6[0] = ps * vN; r6[1] = ps * vR; r6[2] = ps1 * vN; r6[3] = ps1 * vL; r6[4] = ps2 * vT; r6[5] = ps2 * vR;
+            }
+            wave_sum_n<6>(r6);
+            stv(SL_PSUM, ps);
+            stv((dir > 0) ? SL_RIGHT_P : SL_LEFT_P, TRp);
+            const bool turning = (r6[0] <= 0.) || (r6[1] <= 0.) || (r6[2] <= 0.) || (r6[3] <= 0.) || (r6[4] <= 0.) || (r6[5] <= 0.);
+            if (turning || depth >= a.cfg.max_treedepth) {
+                unit = U_END1;
+            } else {
+                dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210 (phase A read this draw ahead)
+                i_leaf = 0;
+                unit = U_DONE;
+            }
+        }
+        BF_MF(6);
+        TRACE(11);
+        if (unit == U_END1) {
+            ended = true;  // the tree the evaluation in flight belongs to has ended: the evaluation is dropped
+            mode = M_END;
+        } else if (mode == M_END) {
+            iteration_end();  // -> M_INIT with a fresh momentum, or M_DONE
+            if (mode == M_DONE) ended = true;
+        }
+        if (err != 0) { mode = M_DONE; ended = true; }
+        BF_MF(7);
+#undef BF_MF
+        TRACE(4);
+        if (job) {
+            const int mc = lane & 15, mg = lane >> 4;
+            const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
+        }
+        TRACE(5);
+        __syncthreads();  // B2
+        TRACE(6);
+
+        // ================= phase C: finish the evaluation =================
+        if (evaluating && !ended) {
+            const double sx = lane_ok ? gb_read(0) : 0.;
+            const double hv = lane_ok ? gb_read(1) : 0.;
+            double xev = q;
+            if (mode == M_OOB) xev = (m.alpha * q + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
+            double gn = sx + c_lin;
+            const double xm = q - c_mu;
+            const bool fast_kin = mode != M_OOB;
+            double r4[4] = {0., xev * sx, c_lin * xev, xm * hv};
+            double r_dotj = gn * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
+            if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
+                const double pe = p + (0.5 * eps_t) * gn;
+                r4[0] = pe * (var * pe);
+            }
+            TRACE(7);
+            wave_sum_n<4>(r4);
+            TRACE(8);
+            const double r_kin = r4[0], r_quad = r4[1], r_lin = r4[2], r_b2 = r4[3];
+            if (mode == M_OOB) r_dotj = wave_sum(r_dotj);
+            double f = ((m.c0 + r_lin) + 0.5 * r_quad) + 0.;
+            double beta = 0.;
+            bool oob_now = false;
+            {
+                const double a2 = m.alpha * m.alpha;
+                if (mode != M_OOB && !(r_b2 < a2 * (1. - 1e-12))) beta = usqrt(r_b2);
+                if (mode == M_OOB) {  // second pass: f, gn currently hold f_0 and jj_0 (poly.py:484-496)
+                    const double f0 = f, beta_saved = cs_get(CS_BETA);
+                    f = (beta_saved * f0 - (beta_saved - m.alpha) * m.f_mu) / m.alpha;
+                    const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta_saved;
+                    gn = gn + coef * (hv / beta_saved);
+                } else if (beta > m.alpha) {
+                    oob_now = true;
+                }
+            }
+            if (oob_now) {
+                // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
+                cs_set(CS_BETA, beta);
+                prev_mode = mode;
+                mode = M_OOB;
+            } else {
+                const bool kin_ready = fast_kin;
+                if (mode == M_OOB) mode = prev_mode;
+                gn = gn * 1.;  // (the chain-rule factor of the identity transform)
+                const double logp_new = f;
+                // second half of the leapfrog and the kinetic energy
+                const double dt = 0.5 * eps_t;
+                p = p + dt * gn;        // integration.py:90
+                g = gn;
+                double kin = p * (var * p);   // metrics.py:88-91
+                kin = kin_ready ? r_kin : wave_sum(kin);
+                const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93
+                if (mode == M_INIT) {
+                    // BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43
+                    if (!(fabs(E_new) <= 1.7976931348623157e308)) {
+                        err = 1;
+                    } else {
+                        start_energy = E_new;
+                        stv(SL_LEFT_Q, q); stv(SL_LEFT_P, p); stv(SL_LEFT_G, g);
+                        stv(SL_RIGHT_Q, q); stv(SL_RIGHT_P, p); stv(SL_RIGHT_G, g);
+                        stv(SL_PROP_Q, q); stv(SL_PSUM, p);
+                        cs_set(CS_PROP_E, E_new);
+                        cs_set(CS_PROP_LOGP, logp_new);
+                        cs_set(CS_TREE_W, 1.);
+                        w_off = 0.;
+                        max_de = 0.;
+                        depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
+                        eps = uexp(i_iter < nw ? cs_get(CS_LOG_STEP) : cs_get(CS_LOG_BAR));  // step_size.py:25-29
+                        dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
+                        mode = M_LEAF;
+                    }
+                    if (err != 0) mode = M_DONE;
+                } else {
+                    pend = true;
+                    E_pend = E_new;
+                    lp_pend = logp_new;
+                    TRp = p;
+                    TPq = q;
+                }
+            }
+        }
+    }
+
+#ifdef BF_TRACE
+    if (a.stamps && w == 0 && blockIdx.x == 0)
+        for (int i = lane; i < BF_TRACE * 16; i += 64) a.stamps[i] = TRC[i];
+#endif
+    // ---- write the chain state back ----
+    if (real) {
+        store_vec(BFHIP_VEC_Q, q);
+        if (lane == 0) {
+            for (int k = 0; k < 4; ++k) a.rng[(size_t)chain * 4 + k] = rs[k];
+            scp[BFHIP_SC_LOG_STEP] = cs_get(CS_LOG_STEP);
+            scp[BFHIP_SC_LOG_BAR] = cs_get(CS_LOG_BAR);
+            scp[BFHIP_SC_HBAR] = cs_get(CS_HBAR);
+            scp[BFHIP_SC_COUNT] = cs_get(CS_COUNT);
+            scp[BFHIP_SC_I_ITER] = (double)i_iter;
+            scp[BFHIP_SC_ERROR] = (double)err;
+            if (a.n_leapfrog && nlf) atomicAdd(a.n_leapfrog, nlf);
+        }
+    }
+}

@@ -32,6 +32,8 @@
 // Template instantiations: W = DP/16 (1, 2, 4, 8); NUTS / HMC; FS (compile-time feature set; 1 = PLAIN, the common
 // surrogate) or generic; FULLM (full-rank metric, bfhip_metric.h); STAMPS (diagnostic phase counters).
 #include <type_traits>
+#include <cstring>
+#include <cstdlib>
 #include "bfhip_eval.h"
 #include "bfhip_metric.h"
 
@@ -403,6 +405,9 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 }
             } else if (have_ev && mode == M_LEAF) {
                 nlf += 1;
+#ifdef BF_DBGPRINT
+                if (chain == 1 && lane == 0 && i_iter <= 1) printf("base it %d depth %d ileaf %d dir %d eps %.17g E %.17g E0 %.17g\n", i_iter, depth, i_leaf, dir, eps, E_new, start_energy);
+#endif
                 if (NUTS) {
                     // ---- Tree._single_step: nuts.py:105-132 ----
                     n_prop += 1;
@@ -1183,6 +1188,8 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     }
 }
 
+#include "bfhip_nuts_pipe.h"
+
 static int g_tail_max = 4;  // tuning / test hook: 0 disables the VALU matvec of the plain kernel
 extern "C" void bfhip_debug_tail_max(int v) { g_tail_max = v; }
 static bool g_no_plain = false;  // tuning hook: force the generic instantiation
@@ -1228,6 +1235,23 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
     return 0;
 }
 
+// test / tuning hook: NUTS on the common surrogate through bf_sampler_kernel instead of the pipelined kernel
+// (also selected by the environment variable BFHIP_NUTS_KERNEL=sliced)
+static bool g_no_pipe = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && !strcmp(e, "sliced"); }();
+extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
+
+template <int W>
+static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args) {
+    auto k = bf_nuts_pipe_kernel<W>;
+    const size_t lds = PipeGeo<W>::lds_doubles() * sizeof(double);
+    if (lds > 64 * 1024)
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int groups = (args.n_chain + 15) / 16;
+    hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
@@ -1242,6 +1266,12 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS) ? 1 : 0>(ctx, args)
                      : launch_sampler_t<W, NUTS, (W == 4 && NUTS), 0>(ctx, args);
 #endif
+#ifdef BF_TRACE
+    if (plain && NUTS && W == 4 && !g_no_pipe)
+#else
+    if (plain && NUTS && W == 4 && !g_no_pipe && !args.stamps)
+#endif
+        return launch_nuts_pipe<(W == 4 ? 4 : 1)>(ctx, args);
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at

@@ -53,3 +53,12 @@ for ln, lab in ((4, ['C done -> dE', 'dE -> weights', 'weights -> unit done (eve
         print('leaf unit, %d trips:' % len(sel))
         for k, nm in enumerate(lab):
             print('  %-34s %7.0f [%6.0f]' % (nm, sel[:, k].mean(), np.median(sel[:, k])))
+
+# raw timeline of consecutive trips (all kinds): ticks from the trip's loop top to every recorded point
+if os.environ.get('RAW'):
+    print('raw trips (ticks since loop top; 0 = point not reached):')
+    for i in range(8, min(N - 1, 8 + int(os.environ['RAW']))):
+        tt = t[i]
+        if tt[0] == 0: continue
+        rel = [(int(tt[k] - tt[0]) if tt[k] else 0) for k in range(16)]
+        print('  trip %3d total %6d | ' % (i, int(t[i + 1][0] - tt[0]) if t[i + 1][0] else -1) + ' '.join('%5d' % r for r in rel[1:]))
