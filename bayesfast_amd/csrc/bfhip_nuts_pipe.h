@@ -7,21 +7,26 @@
 // WHEN the tree bookkeeping runs:
 //
 //   * bf_sampler_kernel gives every unit of bookkeeping (leaf logic, a merge level, the end of a doubling, the pieces
-//     of the iteration end) a trip of its own or the tail of one, so a 7-leaf iteration takes 15 trips and the matrix
-//     pipe idles while the chain waves run their latency-bound scalar logic (and vice versa).
-//   * Here the bookkeeping of leaf n is DEFERRED into the MFMA window of trip n+1: after the barrier that publishes the
-//     positions, every wave issues the MFMAs of its job and, while the matrix pipe works through the four waves' tiles,
-//     runs the pending bookkeeping of its chain (leaf weights, merges, doubling end, iteration end) on the VALU.
-//     The leapfrog step of trip n+1 therefore starts BEFORE leaf n has been accounted for: it is speculative.  The
-//     speculation is exact whenever the tree goes on: inside a doubling the next leaf continues from the current one,
-//     and at the end of a doubling the direction of the next one is read ahead from the chain's random stream (the
-//     number of draws the pending bookkeeping will consume is known: one per merge level and one for the swap,
-//     samplers/nuts.py:163-167,81-83, then the direction, :210).  When the pending bookkeeping ends the tree (U-turn,
-//     divergence, depth limit) the evaluation in flight is dropped; that is one wasted evaluation per iteration, in a
-//     trip the group runs anyway.  A 7-leaf iteration takes 9 trips.
+//     of the iteration end) a trip of its own or the tail of one, so a 7-leaf iteration takes 15 trips, each with its
+//     two workgroup barriers, flag exchange and loop overhead, and seven of them without any gradient work.
+//   * Here the bookkeeping of leaf n is DEFERRED into trip n+1, between the two barriers, next to the MFMAs of that
+//     trip's gradient tiles.  The leapfrog step of trip n+1 therefore starts BEFORE leaf n has been accounted for: it
+//     is speculative.  The speculation is exact whenever the tree goes on: inside a doubling the next leaf continues
+//     from the current one, and at the end of a doubling the direction of the next one is read ahead from the chain's
+//     random stream (the number of draws the pending bookkeeping will consume is known: one per merge level and one
+//     for the swap, samplers/nuts.py:163-167,81-83, then the direction, :210).  When the pending bookkeeping ends the
+//     tree (U-turn, divergence, depth limit) the evaluation in flight is dropped; that is one wasted evaluation per
+//     iteration, in a trip the group runs anyway.  The iteration-end work (step size, statistics, sample, metric
+//     window, next momentum) runs in the trip that evaluates the new iteration's starting point, which needs only q.
+//     A 7-leaf iteration takes 9 trips, every one of them with a gradient evaluation for the chain.
 //   * The subtree ends, the proposal, p_sum and stack level 1 live in LDS (12 vectors per chain); only the deeper
 //     stack levels go to global scratch.  There is no prefetch buffer and no tail path (the row-major matrices of the
-//     tail path do not fit next to the tree vectors; a lone chain is faster here than on the tail path there).
+//     tail path do not fit next to the tree vectors).
+//   * What does NOT happen: the bookkeeping does not hide behind the MFMAs.  On gfx950 v_mfma_f64_16x16x4_f64 and
+//     the FP64 VALU instructions share one pipe (tools/probe/mfma_overlap_probe.hip: a SIMD's time is the SUM of its
+//     MFMA cycles and its FP64 VALU cycles, from one wave or from four), so a trip costs its 32 MFMAs per SIMD plus
+//     the VALU instructions of its four waves.  The gain over bf_sampler_kernel is the 6 trips per iteration that no
+//     longer exist (+10 % on the headline workload, +11 % on the default 1500-iteration run).
 //
 // E = 1 throughout (lane = dimension, d <= 64).
 
@@ -322,12 +327,12 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; }
 
         // ================= phase B: gradient tiles on MFMA, the pending bookkeeping between them =================
-        // A wave's MFMAs form one dependent chain (the accumulator), and a dependent v_mfma_f64_16x16x4_f64 issues
-        // about 256 cycles after its predecessor, whatever the other waves do (the pipe takes a new one every 64
-        // cycles, from four waves in turn).  Issued back to back they would block the wave's in-order instruction
-        // stream for 8 x 256 cycles.  So the chain is spread over the stages of the pending bookkeeping: one MFMA at
-        // each of KPJ fixed points of the code below, the VALU work of a stage running while the MFMA before it
-        // executes.  (Stages that have nothing to do fall through; the MFMAs then simply queue up.)
+        // A wave's MFMAs form one dependent chain (the accumulator); a dependent v_mfma_f64_16x16x4_f64 issues about
+        // 256 cycles after its predecessor while the pipe takes a new one every 64 cycles, from four waves in turn.
+        // The chain is spread over the stages of the pending bookkeeping, one MFMA at each of KPJ fixed points of the
+        // code below, so that a wave waiting for its accumulator leaves the issue slots to the stages of the others.
+        // (Stages that have nothing to do fall through; the MFMAs then simply queue up.  The FP64 VALU work does not
+        // overlap with the MFMAs themselves: they share the pipe.)
         const bool job = ev_mask != 0 && w < NJOB_P;
         d4_t acc = {0., 0., 0., 0.};
         const double *Xf = XB + ((w / (W * KS_P)) * NS + (w % KS_P) * KPJ_P) * XS + lane;

@@ -123,6 +123,7 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     x0 = np.random.default_rng(1).normal(size=(150, d))  # 9 full groups and a ragged one
     out = {}
     try:
+        _lib.lib().bfhip_debug_no_pipe(1)  # (at 33 <= d <= 64 NUTS runs on the pipelined kernel by default, which has no tail path)
         for tm in (0, 4):
             _lib.lib().bfhip_debug_tail_max(tm)
             dc = DeviceChains(dens, x0, seed=5)
@@ -130,8 +131,65 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
             out[tm] = (s.cpu().numpy(), st.cpu().numpy())
     finally:
         _lib.lib().bfhip_debug_tail_max(4)
+        _lib.lib().bfhip_debug_no_pipe(0)
     assert np.array_equal(out[0][0], out[4][0])
     assert np.array_equal(out[0][1], out[4][1], equal_nan=True)
+
+
+@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40'])
+def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
+    """bf_nuts_pipe_kernel (deferred bookkeeping, speculative next step, tree vectors in LDS) performs the same
+    arithmetic per chain in the same order as bf_sampler_kernel: samples, statistics, adapted state and the random
+    streams must agree bit for bit -- through warm-up (long and short trees, direction changes), with most evaluations
+    outside the bound (two passes per leaf), at the depth limit (no speculation past the last doubling), with divergent
+    first steps, and for a ragged dimension.  The leapfrog count excludes the dropped speculative evaluations."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = 40 if case == 'd40' else 64
+    spec, _ = correlated_gaussian_spec(d, fit_scale=1.0 if case == 'leaky_bound' else 1.5)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(2).normal(size=(150, d)) * (3. if case == 'divergent' else 1.)
+    kw = {'depth_limit': dict(max_treedepth=2), 'divergent': dict(max_change=5.)}.get(case, {})
+    out = {}
+    try:
+        for sliced in (0, 1):
+            _lib.lib().bfhip_debug_no_pipe(sliced)
+            dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
+            s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw)
+            s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw)   # resume: the second launch starts from the stored state
+            out[sliced] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
+    finally:
+        _lib.lib().bfhip_debug_no_pipe(0)
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert out[0][-1] == out[1][-1] == int(out[0][1][:, :, _lib.NSTATS.index('tree_size')].sum() + out[0][3][:, :, _lib.NSTATS.index('tree_size')].sum())
+    ts = out[0][1][:, :, _lib.NSTATS.index('tree_size')]
+    if case == 'depth_limit':
+        assert ts.max() == 3 and (out[0][1][:, :, _lib.NSTATS.index('tree_depth')] == 2).any()
+    if case == 'divergent':
+        assert out[0][1][:, :, _lib.NSTATS.index('diverging')].sum() > 0
+    if case == 'balanced':
+        assert ts.max() >= 15 and ts.min() <= 3   # warm-up went through long and short trees
+
+
+def test_launch_cuts_do_not_change_results(ctx):
+    """DeviceChains.run queues launches of launch_iters iterations; the cut must not show in any output."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    spec, _ = correlated_gaussian_spec(64)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(3).normal(size=(40, 64))
+    out = []
+    for li in (None, 7, 250):
+        dc = DeviceChains(dens, x0, seed=3)
+        s, st = dc.run(50, 'NUTS', n_warmup=30, launch_iters=li)
+        out.append((s.cpu().numpy(), st.cpu().numpy(), dc.sc.cpu().numpy(), dc.total_leapfrog))
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1], equal_nan=True)
+        assert np.array_equal(o[2], out[0][2], equal_nan=True) and o[3] == out[0][3]
 
 
 def test_nuts_divergences_and_max_treedepth(ctx, samp):

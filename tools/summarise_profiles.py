@@ -2,7 +2,7 @@
 import sys, os, glob, json, csv
 import numpy as np
 out, tag = sys.argv[1], sys.argv[2]
-KERNEL = 'bf_sampler_kernel'
+KERNEL = 'bf_nuts_pipe_kernel'
 
 
 def rows(pattern):
