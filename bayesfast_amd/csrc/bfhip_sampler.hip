@@ -1267,11 +1267,11 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
                      : launch_sampler_t<W, NUTS, (W == 4 && NUTS), 0>(ctx, args);
 #endif
 #ifdef BF_TRACE
-    if (plain && NUTS && W == 4 && !g_no_pipe)
+    if (plain && NUTS && W <= 4 && !g_no_pipe)
 #else
-    if (plain && NUTS && W == 4 && !g_no_pipe && !args.stamps)
+    if (plain && NUTS && W <= 4 && !g_no_pipe && !args.stamps)
 #endif
-        return launch_nuts_pipe<(W == 4 ? 4 : 1)>(ctx, args);
+        return launch_nuts_pipe<(W <= 4 ? W : 1)>(ctx, args);
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at

@@ -123,7 +123,7 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     x0 = np.random.default_rng(1).normal(size=(150, d))  # 9 full groups and a ragged one
     out = {}
     try:
-        _lib.lib().bfhip_debug_no_pipe(1)  # (at 33 <= d <= 64 NUTS runs on the pipelined kernel by default, which has no tail path)
+        _lib.lib().bfhip_debug_no_pipe(1)  # (at d <= 64 NUTS runs on the pipelined kernel by default, which has no tail path)
         for tm in (0, 4):
             _lib.lib().bfhip_debug_tail_max(tm)
             dc = DeviceChains(dens, x0, seed=5)
@@ -136,7 +136,7 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     assert np.array_equal(out[0][1], out[4][1], equal_nan=True)
 
 
-@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40'])
+@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40', 'd32', 'd10'])
 def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     """bf_nuts_pipe_kernel (deferred bookkeeping, speculative next step, tree vectors in LDS) performs the same
     arithmetic per chain in the same order as bf_sampler_kernel: samples, statistics, adapted state and the random
@@ -147,7 +147,7 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
     from bayesfast_amd import _lib
-    d = 40 if case == 'd40' else 64
+    d = int(case[1:]) if case[0] == 'd' and case[1:].isdigit() else 64
     spec, _ = correlated_gaussian_spec(d, fit_scale=1.0 if case == 'leaky_bound' else 1.5)
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(2).normal(size=(150, d)) * (3. if case == 'divergent' else 1.)
