@@ -553,18 +553,19 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             double gn = sx + c_lin;
             const double xm = q - c_mu;
             const bool fast_kin = mode != M_OOB;
-            double r4[4] = {0., xev * sx, c_lin * xev, xm * hv};
+            // (the surrogate's value, linear + quadratic term, summed per lane: one reduction for both)
+            double r3[3] = {0., __builtin_fma(0.5 * xev, sx, c_lin * xev), xm * hv};
             double r_dotj = gn * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
             if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
                 const double pe = p + (0.5 * eps_t) * gn;
-                r4[0] = pe * (var * pe);
+                r3[0] = pe * (var * pe);
             }
             TRACE(7);
-            wave_sum_n<4>(r4);
+            wave_sum_n<3>(r3);
             TRACE(8);
-            const double r_kin = r4[0], r_quad = r4[1], r_lin = r4[2], r_b2 = r4[3];
+            const double r_kin = r3[0], r_val = r3[1], r_b2 = r3[2];
             if (mode == M_OOB) r_dotj = wave_sum(r_dotj);
-            double f = ((m.c0 + r_lin) + 0.5 * r_quad) + 0.;
+            double f = (m.c0 + r_val) + 0.;
             double beta = 0.;
             bool oob_now = false;
             {

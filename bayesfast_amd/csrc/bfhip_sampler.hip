@@ -1038,8 +1038,14 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
                 xev[e] = xs[e];
                 if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (cs_get(CS_BETA) - m.alpha) * c_mu[e]) / cs_get(CS_BETA);
-                r_quad += xev[e] * sx;
-                r_lin += c_lin[e] * xev[e];
+                if constexpr (PLAIN) {
+                    // value of the linear + quadratic surrogate summed per lane: one reduction instead of two (the
+                    // same expression, spelled with an explicit fma, in bf_nuts_pipe_kernel)
+                    r_lin += __builtin_fma(0.5 * xev[e], sx, c_lin[e] * xev[e]);
+                } else {
+                    r_quad += xev[e] * sx;
+                    r_lin += c_lin[e] * xev[e];
+                }
                 gn[e] = sx + c_lin[e];
             }
             if (f_cubic) {  // cubic configs: x_k of this chain is lane k / E, element k % E
@@ -1069,7 +1075,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 }
             }
             TRACE(7);
-            {   // the four reductions every evaluation needs, advanced together
+            if constexpr (PLAIN) {  // the reductions every evaluation needs, advanced together
+                double r3[3] = {r_kin, r_lin, r_b2};
+                wave_sum_n<3>(r3);
+                r_kin = r3[0]; r_lin = r3[1]; r_b2 = r3[2];
+            } else {
                 double r4[4] = {r_kin, r_quad, r_lin, r_b2};
                 wave_sum_n<4>(r4);
                 r_kin = r4[0]; r_quad = r4[1]; r_lin = r4[2]; r_b2 = r4[3];
@@ -1079,7 +1089,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             if (f_decay) r_bd2 = wave_sum(r_bd2);
             if (f_tr) logdet = wave_sum(logdet);
 
-            double f = ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
+            double f = PLAIN ? (m.c0 + r_lin) + r_cub : ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
             // beta = sqrt(r_b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
             // decided on the squares whenever r_b2 is not within rounding distance of alpha^2, so the common
             // in-bound evaluation has no sqrt on its critical path and the decision is still the reference's
