@@ -405,9 +405,6 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
                 }
             } else if (have_ev && mode == M_LEAF) {
                 nlf += 1;
-#ifdef BF_DBGPRINT
-                if (chain == 1 && lane == 0 && i_iter <= 1) printf("base it %d depth %d ileaf %d dir %d eps %.17g E %.17g E0 %.17g\n", i_iter, depth, i_leaf, dir, eps, E_new, start_energy);
-#endif
                 if (NUTS) {
                     // ---- Tree._single_step: nuts.py:105-132 ----
                     n_prop += 1;

@@ -1,5 +1,6 @@
 """Tuning/verification: the plain kernel's VALU matvec (tail mode) must reproduce the MFMA path bit for bit."""
 import sys, os, ctypes as C, time
+os.environ.setdefault("BFHIP_NUTS_KERNEL", "sliced")  # the tail path belongs to the sliced kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bayesfast_amd.device import get_context, DeviceDensity

@@ -1,5 +1,6 @@
 """Tuning: timeline of one wave's trips (needs a tools/variant.sh build with -DBF_TRACE=64)."""
 import sys, os, ctypes as C
+os.environ.setdefault("BFHIP_NUTS_KERNEL", "sliced")  # this timeline is the sliced kernel's (tools/trace_pipe.py: pipelined)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bayesfast_amd.device import get_context, DeviceDensity
