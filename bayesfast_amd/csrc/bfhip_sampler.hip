@@ -164,6 +164,11 @@ struct SamplerGeo {
     static constexpr bool STAGE = DP <= 64;           // coefficient fragments fit in LDS
 };
 
+// Waves (= chains) per workgroup.  16 fills the 16 columns of the MFMA tiles; at d = 128 a chain's state takes two
+// registers per vector and lane, and 16 waves (128 VGPRs each) spill ~180 of them: there a workgroup is 8 waves with
+// 256 VGPRs each (half-empty tiles, twice as many workgroups).
+#define BF_SAMPLER_WAVES(W) ((W) == 8 ? 8 : 16)
+
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
 // extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
 // and the state of the optional features disappear from the instantiation.
@@ -173,7 +178,8 @@ struct SamplerGeo {
 // scaling, no cubic configs, and bit 1 (value 2) = decay penalty on, bit 2 (value 4) = constraint transform on.
 // FS == 1 is the PLAIN instantiation with its register-resident A operands and tail path.
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
-__global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
+__global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
+    constexpr int NWV = BF_SAMPLER_WAVES(W), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0;
     const bool f_quad = SPEC ? true : (bool)m.has_quad, f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
-    const int chain = blockIdx.x * 16 + w;
+    const int chain = blockIdx.x * NWV + w;
     const bool real = chain < a.n_chain;
     const int d = m.d;
 
@@ -216,11 +222,11 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     if constexpr (G::STAGE && !AREG) {
         double *pS = FR, *pH = pS + (f_quad ? MAT : 0), *pD = pH + (f_bound ? MAT : 0);
         if (f_quad)
-            for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pS)[i] = ((const d2_t *)m.Sf)[i];
+            for (int i = tid; i < MAT / 2; i += NTH) ((d2_t *)pS)[i] = ((const d2_t *)m.Sf)[i];
         if (f_bound)
-            for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pH)[i] = ((const d2_t *)m.Hf)[i];
+            for (int i = tid; i < MAT / 2; i += NTH) ((d2_t *)pH)[i] = ((const d2_t *)m.Hf)[i];
         if (f_decay)
-            for (int i = tid; i < MAT / 2; i += 1024) ((d2_t *)pD)[i] = ((const d2_t *)m.Hdf)[i];
+            for (int i = tid; i < MAT / 2; i += NTH) ((d2_t *)pD)[i] = ((const d2_t *)m.Hdf)[i];
         Sf = pS; Hf = pH; Hdf = pD;
     }
     double afr[AREG ? KPJ_P : 1];
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
     }
     if constexpr (TAIL) {
         // frag[(t * NS + s) * 64 + l] = M[16 t + (l & 15)][4 s + (l >> 4)]  ->  RM[b][row][col]
-        for (int i = tid; i < MAT; i += 1024) {
+        for (int i = tid; i < MAT; i += NTH) {
             const int l = i & 63, s = (i >> 6) % NS, t = (i >> 6) / NS;
             const int row = 16 * t + (l & 15), col = 4 * s + (l >> 4);
             RM[(0 * DP + row) * RS + col] = m.Sf[i];
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
         }
     }
     if (tid < 4) alive[tid] = 0;
-    for (int i = tid; i < PD_N * DP; i += 1024) PDL[i] = m.pd[i];
+    for (int i = tid; i < PD_N * DP; i += NTH) PDL[i] = m.pd[i];
 
     // ---- per-lane constants: the per-dimension table rows of this lane's dimensions ----
     double c_lin[E], c_mu[E];
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
 #ifdef BF_TRACE
     __shared__ unsigned long long TRC[BF_TRACE * 16];
 #define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
-    for (int i = threadIdx.x; i < BF_TRACE * 16; i += 1024) TRC[i] = 0;
+    for (int i = threadIdx.x; i < BF_TRACE * 16; i += NTH) TRC[i] = 0;
 #else
 #define TRACE(k) do { } while (0)
 #endif
@@ -948,7 +954,7 @@ __global__ __launch_bounds__(1024) void bf_sampler_kernel(DevModel m, SamplerArg
             constexpr int CH = KPJ < 8 ? KPJ : 8;               // k-steps fetched together
             const int mc = lane & 15, mg = lane >> 4;
             const int n_job = n_mat * (W * KS);
-            for (int job = w; job < n_job; job += 16) {
+            for (int job = w; job < n_job; job += NWV) {
                 const int slot_m = job / (W * KS), rem = job % (W * KS);
                 const int t = rem / KS, kp = rem % KS;
                 const int b = slot_m == 0 ? mat0 : (slot_m == 1 ? mat1 : 2);  // 0 S, 1 H, 2 H_decay
@@ -1236,8 +1242,9 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
     const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int groups = (args.n_chain + 15) / 16;
-    hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
+    constexpr int NWV = BF_SAMPLER_WAVES(W);
+    const int groups = (args.n_chain + NWV - 1) / NWV;
+    hipLaunchKernelGGL(k, dim3(groups), dim3(NWV * 64), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

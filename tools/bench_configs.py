@@ -9,7 +9,7 @@ from bayesfast_amd import _lib
 ctx = get_context(0)
 res = {}
 for name, d, C, kw in (('config2_32d_1024', 32, 1024, {}), ('config2_32d_4096', 32, 4096, {}), ('headline_64d_4096', 64, 4096, {}),
-                       ('config4_64d_4096_ta95', 64, 4096, dict(target_accept=0.95)), ('config5_128d_1024', 128, 1024, {}),
+                       ('config4_64d_4096_ta95', 64, 4096, dict(target_accept=0.95)), ('config5_128d_1024', 128, 1024, {}), ('config5_128d_4096', 128, 4096, {}),
                        ('full_metric_64d_1024', 64, 1024, dict(metric='full'))):
     spec, _ = correlated_gaussian_spec(d)
     dens = DeviceDensity(spec, ctx)
@@ -20,10 +20,13 @@ for name, d, C, kw in (('config2_32d_1024', 32, 1024, {}), ('config2_32d_4096', 
     for _ in range(3):
         dc.run(100, 'NUTS', n_warmup=300, check=False, **rkw)
     ts = []
-    for _ in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); l0 = dc.total_leapfrog
-        s, st = dc.run(100, 'NUTS', n_warmup=300, check=False, **rkw)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    s = st = None
+    for _ in range(3):  # HIP events around the launch; the output arrays of the previous launch are reused
+        l0 = dc.total_leapfrog
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        s, st = dc.run(100, 'NUTS', n_warmup=300, check=False, samples=s, stats=st, **rkw)
+        e1.record(); torch.cuda.synchronize(); dt = e0.elapsed_time(e1) * 1e-3
         ts.append(((dc.total_leapfrog - l0) / dt, dt * 1e3))
     dc.raise_on_error()
     r = np.array(ts)
