@@ -44,7 +44,10 @@ struct PipeGeo {
     }
 };
 
-template <int W>
+// TR: the density lives behind the constraint transform (Density.input_scales / hard_bounds: density.py:92-140,
+// 747-750): the surrogate is evaluated at x(q), its gradient gets the chain-rule factor dx/dq and the log-Jacobian
+// term; same arithmetic as the FS = 5 instantiation of bf_sampler_kernel.
+template <int W, bool TR>
 __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
     using G = SamplerGeo<W>;
     using PG = PipeGeo<W>;
@@ -78,6 +81,11 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     if (tid < 4) alive[tid] = 0;
     const double c_lin = lane_ok ? m.pd[PD_LIN * DP + lane] : 0.;
     const double c_mu = lane_ok ? m.pd[PD_MU * DP + lane] : 0.;
+    // constraint transform of this lane's dimension (TR) and what phase A leaves for phase C: x(q), dx/dq,
+    // (d2x/dq2) / (dx/dq), log |dx/dq|
+    const int c_kind = (TR && lane_ok) ? (int)m.pd[PD_KIND * DP + lane] : 0;
+    const double c_lo = (TR && lane_ok) ? m.pd[PD_LO * DP + lane] : 0., c_rg = (TR && lane_ok) ? m.pd[PD_RG * DP + lane] : 1.;
+    double xs = 0., jac = 1., gj = 0., logdet_l = 0.;
 
     // ---- per-chain state (scalars are wave-uniform) ----
     double q = 0., p = 0., g = 0., var = 1.;
@@ -306,13 +314,21 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 p = p + dt * g;                    // integration.py:80
                 q = q + eps_t * (var * p);         // :82-85
             }
-            double x_eval = q;
+            xs = q;
+            if constexpr (TR) {
+                double J, J2;
+                bf_to_original(q, c_kind, c_lo, c_rg, xs, J, J2);
+                logdet_l = 0. + log(fabs(J));
+                jac = J;
+                gj = J2 / J;
+            }
+            double x_eval = xs;
             if (mode == M_OOB)  // modules/poly.py:482
-                x_eval = (m.alpha * q + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
+                x_eval = (m.alpha * xs + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
             if (lane_ok) {
                 const int xi = (lane >> 2) * XS + w + 16 * (lane & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
                 XB[xi] = x_eval;
-                XB[NS * XS + xi] = q - c_mu;
+                XB[NS * XS + xi] = xs - c_mu;
             }
         }
         if (lane == 0) {
@@ -548,16 +564,18 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         if (evaluating && !ended) {
             const double sx = lane_ok ? gb_read(0) : 0.;
             const double hv = lane_ok ? gb_read(1) : 0.;
-            double xev = q;
-            if (mode == M_OOB) xev = (m.alpha * q + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
+            double xev = xs;
+            if (mode == M_OOB) xev = (m.alpha * xs + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
             double gn = sx + c_lin;
-            const double xm = q - c_mu;
+            const double xm = xs - c_mu;
             const bool fast_kin = mode != M_OOB;
             // (the surrogate's value, linear + quadratic term, summed per lane: one reduction for both)
             double r3[3] = {0., __builtin_fma(0.5 * xev, sx, c_lin * xev), xm * hv};
             double r_dotj = gn * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
             if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
-                const double pe = p + (0.5 * eps_t) * gn;
+                double ge = gn * jac;
+                if constexpr (TR) ge += gj;
+                const double pe = p + (0.5 * eps_t) * ge;
                 r3[0] = pe * (var * pe);
             }
             TRACE(7);
@@ -565,6 +583,8 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             TRACE(8);
             const double r_kin = r3[0], r_val = r3[1], r_b2 = r3[2];
             if (mode == M_OOB) r_dotj = wave_sum(r_dotj);
+            double logdet = 0.;
+            if constexpr (TR) logdet = wave_sum(logdet_l);
             double f = (m.c0 + r_val) + 0.;
             double beta = 0.;
             bool oob_now = false;
@@ -588,7 +608,11 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             } else {
                 const bool kin_ready = fast_kin;
                 if (mode == M_OOB) mode = prev_mode;
-                gn = gn * 1.;  // (the chain-rule factor of the identity transform)
+                gn = gn * jac;  // chain rule (module.py:226, density.py:558); 1 without the transform
+                if constexpr (TR) {  // density.py:747-750
+                    f += logdet;
+                    gn += gj;
+                }
                 const double logp_new = f;
                 // second half of the leapfrog and the kinetic energy
                 const double dt = 0.5 * eps_t;

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                 dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
                 xev[e] = xs[e];
                 if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (cs_get(CS_BETA) - m.alpha) * c_mu[e]) / cs_get(CS_BETA);
-                if constexpr (PLAIN) {
+                if constexpr (SPEC) {
                     // value of the linear + quadratic surrogate summed per lane: one reduction instead of two (the
                     // same expression, spelled with an explicit fma, in bf_nuts_pipe_kernel)
                     r_lin += __builtin_fma(0.5 * xev[e], sx, c_lin[e] * xev[e]);
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                 }
             }
             TRACE(7);
-            if constexpr (PLAIN) {  // the reductions every evaluation needs, advanced together
+            if constexpr (SPEC) {  // the reductions every evaluation needs, advanced together
                 double r3[3] = {r_kin, r_lin, r_b2};
                 wave_sum_n<3>(r3);
                 r_kin = r3[0]; r_lin = r3[1]; r_b2 = r3[2];
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
             if (f_decay) r_bd2 = wave_sum(r_bd2);
             if (f_tr) logdet = wave_sum(logdet);
 
-            double f = PLAIN ? (m.c0 + r_lin) + r_cub : ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
+            double f = SPEC ? (m.c0 + r_lin) + r_cub : ((m.c0 + r_lin) + 0.5 * r_quad) + r_cub;
             // beta = sqrt(r_b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
             // decided on the squares whenever r_b2 is not within rounding distance of alpha^2, so the common
             // in-bound evaluation has no sqrt on its critical path and the decision is still the reference's
@@ -1254,9 +1254,9 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
 static bool g_no_pipe = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && !strcmp(e, "sliced"); }();
 extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 
-template <int W>
+template <int W, bool TR = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args) {
-    auto k = bf_nuts_pipe_kernel<W>;
+    auto k = bf_nuts_pipe_kernel<W, TR>;
     const size_t lds = PipeGeo<W>::lds_doubles() * sizeof(double);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1287,6 +1287,10 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
 #endif
         return launch_nuts_pipe<(W <= 4 ? W : 1)>(ctx, args);
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
+    // ... and the same surrogate behind the constraint transform (bounded parameters), 33 <= d <= 64
+    if (W == 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
+        !m.has_su && !m.has_cubic)
+        return launch_nuts_pipe<(W == 4 ? 4 : 1), (W == 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
     // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)

@@ -136,7 +136,7 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     assert np.array_equal(out[0][1], out[4][1], equal_nan=True)
 
 
-@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40', 'd32', 'd10'])
+@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40', 'd32', 'd10', 'bounded'])
 def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     """bf_nuts_pipe_kernel (deferred bookkeeping, speculative next step, tree vectors in LDS) performs the same
     arithmetic per chain in the same order as bf_sampler_kernel: samples, statistics, adapted state and the random
@@ -149,8 +149,11 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     from bayesfast_amd import _lib
     d = int(case[1:]) if case[0] == 'd' and case[1:].isdigit() else 64
     spec, _ = correlated_gaussian_spec(d, fit_scale=1.0 if case == 'leaky_bound' else 1.5)
+    if case == 'bounded':  # the same surrogate behind the constraint transform: all four kinds of bounds (density.py:92-140)
+        lo = np.full(d, -9.) + np.arange(d) * 0.01
+        spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * 16, dtype=np.uint8))
     dens = DeviceDensity(spec, ctx)
-    x0 = np.random.default_rng(2).normal(size=(150, d)) * (3. if case == 'divergent' else 1.)
+    x0 = np.random.default_rng(2).normal(size=(150, d)) * (3. if case == 'divergent' else (0.3 if case == 'bounded' else 1.))
     kw = {'depth_limit': dict(max_treedepth=2), 'divergent': dict(max_change=5.)}.get(case, {})
     out = {}
     try:

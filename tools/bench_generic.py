@@ -23,10 +23,13 @@ for name, spec in variants.items():
     for _ in range(3):
         dc.run(100, 'NUTS', n_warmup=300, check=False)
     ts = []
-    for _ in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); l0 = dc.total_leapfrog
-        s, st = dc.run(100, 'NUTS', n_warmup=300, check=False)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    s = st = None
+    for _ in range(3):  # HIP events around the launch; output arrays reused
+        l0 = dc.total_leapfrog
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        s, st = dc.run(100, 'NUTS', n_warmup=300, check=False, samples=s, stats=st)
+        e1.record(); torch.cuda.synchronize(); dt = e0.elapsed_time(e1) * 1e-3
         ts.append(((dc.total_leapfrog - l0) / dt, dt * 1e3))
     dc.raise_on_error()
     r = np.array(ts)
