@@ -1287,10 +1287,10 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
 #endif
         return launch_nuts_pipe<(W <= 4 ? W : 1)>(ctx, args);
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
-    // ... and the same surrogate behind the constraint transform (bounded parameters), 33 <= d <= 64
-    if (W == 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
+    // ... and the same surrogate behind the constraint transform (bounded parameters)
+    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
         !m.has_su && !m.has_cubic)
-        return launch_nuts_pipe<(W == 4 ? 4 : 1), (W == 4)>(ctx, args);
+        return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
     // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)

@@ -188,7 +188,7 @@ def main():
                        'parallelism': 'chains sharded over %d rank(s), no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'achieved': ach_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': ach_tf / peak_tf, 'traffic': traffic,
-                         'kernel': 'bf_nuts_pipe_kernel<4>', 'kernel_ms_per_launch': kernel_ms,
+                         'kernel': 'bf_nuts_pipe_kernel<4, false>', 'kernel_ms_per_launch': kernel_ms,
                          'flops_per_leapfrog': flops_per_leapfrog(d, use_bound)},
             'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
                                          'peak': 8000., 'unit': 'GB/s',

@@ -414,6 +414,31 @@ def test_odd_shapes_match_oracle(ctx, d):
                 np.testing.assert_allclose(s[i, :5], so[:5], rtol=1e-8, atol=1e-8)
 
 
+@pytest.mark.parametrize('d', [5, 16, 30, 48])
+def test_bounded_parameters_small_dims_match_oracle(ctx, d):
+    """NUTS behind the constraint transform at d <= 64 runs on the pipelined kernel's transform instantiation for every
+    padded dimension: chains with all four kinds of bounds against the oracle (ragged workgroup of 17 chains)."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    from oracle import oracle as orc
+    spec, _ = correlated_gaussian_spec(d)
+    lo = np.full(d, -9.) + np.arange(d) * 0.01
+    hb = np.array(([[1, 1], [1, 0], [0, 1], [0, 0]] * d)[:d], dtype=np.uint8)
+    spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=hb)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(d).normal(size=(17, d)) * 0.3
+    dc = DeviceChains(dens, x0, seed=4)
+    s, st = dc.run(14, 'NUTS', n_warmup=9)
+    s, st = s.cpu().numpy(), st.cpu().numpy()
+    for i in (0, 8, 16):
+        so, sto = orc.nuts_run(spec, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=4, stream=i), 14, 9)
+        assert np.array_equal(st[i, :, _lib.NSTATS.index('tree_size')], sto['tree_size']), (d, i)
+        np.testing.assert_allclose(s[i, :6], so[:6], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(st[i, :6, _lib.NSTATS.index('logp')], sto['logp'][:6], rtol=1e-8, atol=1e-8)
+
+
 @pytest.mark.parametrize('decay,bounds', [(True, False), (False, True), (True, True)])
 def test_compile_time_feature_sets_64d_match_oracle(ctx, samp, decay, bounds):
     """The 64-d instantiations with the decay penalty and / or the constraint transform fixed at compile time
