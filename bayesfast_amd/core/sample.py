@@ -9,14 +9,24 @@ from .. import parallel
 __all__ = ['sample']
 
 
-def _to_host(t):
+def _pinned_like(shape, dtype):
+    """Pinned host buffer or None (page-locking gigabytes takes a few 100 ms: sample() does it while the kernels run)."""
+    import torch
+    try:
+        return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+    except RuntimeError:
+        return None
+
+
+def _to_host(t, h=None):
     """Device tensor -> NumPy array through a pinned staging buffer (pageable copies run at a third of the PCIe rate)."""
     import torch
     if not t.is_cuda:
         return t.numpy()
     t = t.contiguous()
     try:
-        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        if h is None or tuple(h.shape) != tuple(t.shape) or h.dtype != t.dtype:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         h.copy_(t, non_blocking=True)
         torch.cuda.current_stream(t.device).synchronize()
         return h.numpy()
@@ -103,10 +113,15 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     left = n_run
     while left > 0:
         k = min(step, left)
-        s, st = chains.run(k, trace._sampler, **trace.run_kwargs())
+        s, st = chains.run(k, trace._sampler, check=False, **trace.run_kwargs())  # queued; errors are raised below
         ss.append(s)
         sts.append(st)
         left -= k
+    # the host staging buffers are page-locked while the launches run
+    n_loc = ss[0].shape[0]
+    h_s = _pinned_like((n_loc if ws == 1 else trace.n_chain, n_run, d), torch.float64) if ss[0].is_cuda else None
+    h_st = _pinned_like((n_loc if ws == 1 else trace.n_chain, n_run, sts[0].shape[2]), torch.float64) if ss[0].is_cuda else None
+    chains.raise_on_error()
     s = ss[0] if len(ss) == 1 else torch.cat(ss, 1)
     st = sts[0] if len(sts) == 1 else torch.cat(sts, 1)
     # boundary conversions on device (core/sample.py:175-177), then ONE pass of device-to-host copies
@@ -120,7 +135,7 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
         if density._input_scales is None:
             s_orig = s
     same = s_orig is s
-    s, st, lp_orig = _to_host(s), _to_host(st), _to_host(lp_orig)
+    s, st, lp_orig = _to_host(s, h_s), _to_host(st, h_st), _to_host(lp_orig)
     s_orig = s if same else _to_host(s_orig)
     if prev is not None:
         shared = same and prev._samples_original is prev._samples
