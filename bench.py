@@ -83,7 +83,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--chains', type=int, default=4096, help='chains per GPU')
     ap.add_argument('--dim', type=int, default=64)
-    ap.add_argument('--iters', type=int, default=100, help='NUTS iterations per step (per launch)')
+    ap.add_argument('--iters', type=int, default=250, help='NUTS iterations per step = per launch (the launch length DeviceChains.run uses)')
     ap.add_argument('--seed', type=int, default=2024)
     ap.add_argument('--backend', default='nccl', help="process-group backend: 'nccl' (= RCCL; default) or 'gloo' (plumbing tests)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
