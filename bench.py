@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+N_ADAPT = 750  # NUTS adaptation iterations before anything is timed (GPU path and CPU baseline alike)
+
+
 def cpu_baseline(spec, d, n_warm_iter, seed, target_seconds=15.):
     """Leapfrog steps/sec of the CPU oracle on all host cores, post-warm-up, on a bounded sample."""
     from oracle import oracle as orc  # the checker, timed as a baseline only
@@ -120,10 +123,14 @@ def main():
         # chain starts: N(0, I) rows (core/sample.py:111-112), one global array sliced per rank
         x0 = np.random.default_rng(a.seed).normal(size=(world * C, d))[rank * C:(rank + 1) * C]
         chains = DeviceChains(dens, x0, seed=a.seed, first_stream=rank * C)
-        n_warm_iter = a.warmup * a.iters
+        # set-up, like the fit of the surrogate: the NUTS adaptation (step size, diagonal metric) of the chains, a fixed
+        # N_ADAPT iterations whatever --warmup is; the W warm-up steps and the K timed steps are all post-adaptation
+        # launches of the same steady-state transition loop
+        n_warm_iter = N_ADAPT
         kw = dict(n_warmup=n_warm_iter, check=False)
         samples = ctx.empty((C, a.iters, d))
         stats = ctx.empty((C, a.iters, _lib.STAT_STRIDE))
+        chains.run(n_warm_iter, 'NUTS', **kw)
 
         for _ in range(a.warmup):
             chains.run(a.iters, 'NUTS', samples=samples, stats=stats, **kw)
