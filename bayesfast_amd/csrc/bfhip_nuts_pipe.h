@@ -31,7 +31,9 @@
 // E = 1 throughout (lane = dimension, d <= 64).
 
 
-enum { M_END = 4 };  // the tree has ended; the iteration-end work runs in the window of the next trip
+// scratch slots behind the subtree stack: the gradient at the tree's proposal and at the proposals of the stacked subtrees
+// (levels >= 1); they let an iteration start from its predecessor's proposal without evaluating it again
+enum { SL_PROPG = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH, SL_PG = SL_PROPG + 1, SL_PIPE_N = SL_PG + BFHIP_MAX_TREEDEPTH };
 
 template <int W>
 struct PipeGeo {
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     double TLp = 0., TPs = 0., TPq = 0.;  // the subtree under construction: left end p, p_sum, proposal q
     double TRp = 0.;                      // p of the newest accounted leaf (the subtree's right end in time order)
     double L0p = 0., L0q = 0.;            // stack level 0 (a single waiting leaf)
+    double TPg = 0., L0g = 0.;            // the gradient at the proposals TPq / L0q (the next iteration may start there)
     uint64_t rs[4] = {0, 0, 0, 0};
     int i_iter = 0, mode = M_DONE, prev_mode = M_INIT, err = 0;
     double eps = 0., eps_t = 0.;
@@ -167,6 +170,29 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     for (int i = threadIdx.x; i < BF_TRACE * 16; i += 1024) TRC[i] = 0;
     int trip_no = 0;
 #endif
+    // ---- BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43 (state in q, p, g; energy and logp given) ----
+    auto init_tree = [&](double E0, double logp0) {
+        if (!(fabs(E0) <= 1.7976931348623157e308)) {
+            err = 1;
+        } else {
+            start_energy = E0;
+            stv(SL_LEFT_Q, q); stv(SL_LEFT_P, p); stv(SL_LEFT_G, g);
+            stv(SL_RIGHT_Q, q); stv(SL_RIGHT_P, p); stv(SL_RIGHT_G, g);
+            stv(SL_PROP_Q, q); stv(SL_PSUM, p);
+            stv(SL_PROPG, g);
+            cs_set(CS_PROP_E, E0);
+            cs_set(CS_PROP_LOGP, logp0);
+            cs_set(CS_TREE_W, 1.);
+            w_off = 0.;
+            max_de = 0.;
+            depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
+            eps = uexp(i_iter < nw ? cs_get(CS_LOG_STEP) : cs_get(CS_LOG_BAR));  // step_size.py:25-29
+            dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
+            pend = false;
+            mode = M_LEAF;
+        }
+        if (err != 0) mode = M_DONE;
+    };
     // ---- iteration end: step-size adaptation, statistics, the new sample, metric adaptation, next momentum ----
     auto iteration_end = [&]() {
         // ================= iteration end (base_hmc.py:80-85) =================
@@ -275,15 +301,8 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         bool evaluating = false;
         if (mode == M_OOB) {
             evaluating = true;  // second pass at the projected point (eps_t stays: the step's second half comes after it)
-        } else if (mode == M_END) {
-            // the tree ended in the last window: the proposal becomes the sample and the start of the next iteration; its
-            // compute_state evaluation (base_hmc.py:70) needs only q, so it runs now, while this trip's window does the
-            // iteration-end work and draws the momentum that phase C needs
-            evaluating = true;
-            eps_t = 0.;
-            q = ldv(SL_PROP_Q);
         } else if (mode == M_INIT) {
-            evaluating = true;  // compute_state at the start of an iteration (base_hmc.py:70): a step of length 0
+            evaluating = true;  // compute_state at the start of a launch (base_hmc.py:70): a step of length 0
             eps_t = 0.;
         } else if (mode == M_LEAF) {
             int dir_use = dir;
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             if (evaluating) eps_t = eps * (double)dir_use;
         }
         if (evaluating) {
-            if (mode != M_OOB && mode != M_END) {  // (M_END: a step of length 0 from the new sample; p is drawn below)
+            if (mode != M_OOB) {
                 const double dt = 0.5 * eps_t;
                 p = p + dt * g;                    // integration.py:80
                 q = q + eps_t * (var * p);         // :82-85
@@ -421,6 +440,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             } else {
                 if (!((u * Wsum < T_W) || (u == 0.))) {
                     TPq = L0q;
+                    TPg = L0g;
                     cs_set(CS_T_E, rfl(lsw[LS_E]));
                     cs_set(CS_T_LOGP, rfl(lsw[LS_LOGP]));
                 }
@@ -453,6 +473,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             } else {
                 if (!keep_t2) {
                     TPq = ldv(slot + 3);  // the sibling's proposal
+                    TPg = ldv(SL_PG + lev - 1);
                     cs_set(CS_T_E, rfl(lsp[LS_E]));
                     cs_set(CS_T_LOGP, rfl(lsp[LS_LOGP]));
                 }
@@ -469,11 +490,13 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 if (lev == 0) {
                     L0p = TRp;
                     L0q = TPq;  // a single leaf: its proposal is its own position
+                    L0g = TPg;
                     L0_W = T_W;
                     L0_acc = T_acc;
                 } else {
                     const int slot = SL_STACK + 4 * lev;
                     stv(slot + 0, TLp); stv(slot + 1, TRp); stv(slot + 2, TPs); stv(slot + 3, TPq);
+                    stv(SL_PG + lev, TPg);
                 }
                 if (lane == 0) {
                     double *lsp = lsw + lev * LS_N;
@@ -508,6 +531,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 const double u = bf_u01(bf_xoshiro_next(rs));
                 if ((u * tree_W < T_W) || (u == 0.)) {
                     stv(SL_PROP_Q, TPq);
+                    stv(SL_PROPG, TPg);
                     cs_set(CS_PROP_E, cs_get(CS_T_E));
                     cs_set(CS_PROP_LOGP, cs_get(CS_T_LOGP));
                 }
@@ -541,10 +565,20 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         TRACE(11);
         if (unit == U_END1) {
             ended = true;  // the tree the evaluation in flight belongs to has ended: the evaluation is dropped
-            mode = M_END;
-        } else if (mode == M_END) {
-            iteration_end();  // -> M_INIT with a fresh momentum, or M_DONE
-            if (mode == M_DONE) ended = true;
+            if (err == 0) {
+                // the proposal becomes the sample and the start of the next iteration.  base_hmc.py:70 evaluates it again
+                // (compute_state); value and gradient are the ones of the leaf it was (kept next to its position through
+                // the merges), so the iteration starts right here, without that evaluation
+                const double g_prop = ldv(SL_PROPG);  // (issued early: global scratch)
+                q = ldv(SL_PROP_Q);
+                iteration_end();  // -> M_INIT with a fresh momentum, or M_DONE
+                if (mode == M_INIT) {
+                    g = g_prop;
+                    const double logp0 = cs_get(CS_PROP_LOGP);
+                    const double kin0 = wave_sum(p * (var * p));   // metrics.py:88-91
+                    init_tree(0.5 * kin0 - logp0, logp0);          // integration.py:28-34
+                }
+            }
         }
         if (err != 0) { mode = M_DONE; ended = true; }
         BF_MF(7);
@@ -622,31 +656,14 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 kin = kin_ready ? r_kin : wave_sum(kin);
                 const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93
                 if (mode == M_INIT) {
-                    // BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43
-                    if (!(fabs(E_new) <= 1.7976931348623157e308)) {
-                        err = 1;
-                    } else {
-                        start_energy = E_new;
-                        stv(SL_LEFT_Q, q); stv(SL_LEFT_P, p); stv(SL_LEFT_G, g);
-                        stv(SL_RIGHT_Q, q); stv(SL_RIGHT_P, p); stv(SL_RIGHT_G, g);
-                        stv(SL_PROP_Q, q); stv(SL_PSUM, p);
-                        cs_set(CS_PROP_E, E_new);
-                        cs_set(CS_PROP_LOGP, logp_new);
-                        cs_set(CS_TREE_W, 1.);
-                        w_off = 0.;
-                        max_de = 0.;
-                        depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
-                        eps = uexp(i_iter < nw ? cs_get(CS_LOG_STEP) : cs_get(CS_LOG_BAR));  // step_size.py:25-29
-                        dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
-                        mode = M_LEAF;
-                    }
-                    if (err != 0) mode = M_DONE;
+                    init_tree(E_new, logp_new);
                 } else {
                     pend = true;
                     E_pend = E_new;
                     lp_pend = logp_new;
                     TRp = p;
                     TPq = q;
+                    TPg = g;
                 }
             }
         }

@@ -1327,7 +1327,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.iter_end = iter_end;
     args.iter_out0 = iter_out0;
     args.n_out = n_out;
-    args.nslot = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH;
+    args.nslot = SL_PIPE_N;  // both ends, proposal, p_sum, 4 vectors per stack level (+ the proposals' gradients: pipelined kernel)
     args.tail_max = g_tail_max;
     args.ks = sampler_ksplit(m);
     args.gbn = sampler_gb_slots(m);
