@@ -16,9 +16,11 @@
 //     random stream (the number of draws the pending bookkeeping will consume is known: one per merge level and one
 //     for the swap, samplers/nuts.py:163-167,81-83, then the direction, :210).  When the pending bookkeeping ends the
 //     tree (U-turn, divergence, depth limit) the evaluation in flight is dropped; that is one wasted evaluation per
-//     iteration, in a trip the group runs anyway.  The iteration-end work (step size, statistics, sample, metric
-//     window, next momentum) runs in the trip that evaluates the new iteration's starting point, which needs only q.
-//     A 7-leaf iteration takes 9 trips, every one of them with a gradient evaluation for the chain.
+//     iteration, in a trip the group runs anyway.  The same bookkeeping pass then does the iteration-end work (step
+//     size, statistics, sample, metric window, next momentum) and starts the next iteration WITHOUT the evaluation
+//     that opens it in the reference (compute_state, base_hmc.py:70): its point is the proposal, a leaf whose value
+//     and gradient the tree has computed; the gradient travels with the proposal through the merges (TPg, L0g, one
+//     scratch vector per stack level).  A 7-leaf iteration takes 8 trips.
 //   * The subtree ends, the proposal, p_sum and stack level 1 live in LDS (12 vectors per chain); only the deeper
 //     stack levels go to global scratch.  There is no prefetch buffer and no tail path (the row-major matrices of the
 //     tail path do not fit next to the tree vectors).
