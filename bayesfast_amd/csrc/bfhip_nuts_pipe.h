@@ -188,7 +188,9 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             w_off = 0.;
             max_de = 0.;
             depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
-            eps = uexp(i_iter < nw ? cs_get(CS_LOG_STEP) : cs_get(CS_LOG_BAR));  // step_size.py:25-29
+            // step_size.py:25-29: exp(log_step) while warming up, exp(log_step_bar) after; both are kept up to date for the
+            // statistics (CS_STEP_NOW / CS_STEP_BAR), so no exponential is needed here
+            eps = (i_iter < nw) ? cs_get(CS_STEP_NOW) : cs_get(CS_STEP_BAR);
             dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
             pend = false;
             mode = M_LEAF;
