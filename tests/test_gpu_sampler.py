@@ -287,6 +287,42 @@ def test_nuts_posterior_moments_quadratic_target(ctx):
     assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.03
 
 
+def test_headline_size_properties(ctx):
+    """BASELINE's headline size (4096 chains x 64-d, bound on) through properties that do not need the oracle: posterior
+    moments against the analytic N(0, Sigma), no sample outside the bound ellipsoid of a well-posed surrogate, the leapfrog
+    counter equal to the sum of the tree sizes, shard invariance (two halves with their global stream indices == the
+    full run) and invariance to the launch length."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d, C, n_it, n_w = 64, 4096, 420, 220
+    spec, cov = correlated_gaussian_spec(d)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(5).normal(size=(C, d))
+    dc = DeviceChains(dens, x0, seed=17)
+    s, st = dc.run(n_it, 'NUTS', n_warmup=n_w)
+    ts = st[:, :, _lib.NSTATS.index('tree_size')]
+    assert dc.total_leapfrog == int(ts.sum().item())
+    assert float(st[:, n_w:, _lib.NSTATS.index('diverging')].sum().item()) == 0.
+    x = s[:, n_w:].reshape(-1, d).cpu().numpy()
+    sd = np.sqrt(np.diag(cov))
+    assert np.abs(x.mean(0) / sd).max() < 0.01          # 820 k draws, autocorrelated: se of the mean ~ 0.002 sd
+    np.testing.assert_allclose(x.var(0), np.diag(cov), rtol=0.02)
+    emp = np.cov(x[::3], rowvar=False)
+    assert np.max(np.abs(emp - cov) / np.outer(sd, sd)) < 0.02
+    pm = spec['poly']
+    xm = x[::7] - np.asarray(pm['mu'])
+    assert np.einsum('ni,ij,nj->n', xm, np.asarray(pm['hess']), xm).max() < float(pm['alpha'])**2   # never outside the bound
+    # shards and launch cuts
+    dc_a = DeviceChains(dens, x0[:C // 2], seed=17, first_stream=0)
+    dc_b = DeviceChains(dens, x0[C // 2:], seed=17, first_stream=C // 2)
+    sa, _ = dc_a.run(60, 'NUTS', n_warmup=n_w, launch_iters=25)
+    sb, _ = dc_b.run(60, 'NUTS', n_warmup=n_w, launch_iters=None)
+    assert np.array_equal(sa.cpu().numpy(), s[:C // 2, :60].cpu().numpy())
+    assert np.array_equal(sb.cpu().numpy(), s[C // 2:, :60].cpu().numpy())
+
+
 def _cubic_spec(d=6, seed=3):
     """Negative-definite quadratic + small masked cubic-2 / cubic-3 terms, bound on."""
     rng = np.random.default_rng(seed)
