@@ -28,7 +28,7 @@
 //     the FP64 VALU instructions share one pipe (tools/probe/mfma_overlap_probe.hip: a SIMD's time is the SUM of its
 //     MFMA cycles and its FP64 VALU cycles, from one wave or from four), so a trip costs its 32 MFMAs per SIMD plus
 //     the VALU instructions of its four waves.  The gain over bf_sampler_kernel is the 6 trips per iteration that no
-//     longer exist (+17 % on the headline workload, +11 % on the default 1500-iteration run).
+//     longer exist (with the cached start of an iteration: +29 % on the headline workload, 8.0e8 against 6.2e8 leapfrog steps/s).
 //
 // E = 1 throughout (lane = dimension, d <= 64).
 
