@@ -27,8 +27,8 @@
 //   * What does NOT happen: the bookkeeping does not hide behind the MFMAs.  On gfx950 v_mfma_f64_16x16x4_f64 and
 //     the FP64 VALU instructions share one pipe (tools/probe/mfma_overlap_probe.hip: a SIMD's time is the SUM of its
 //     MFMA cycles and its FP64 VALU cycles, from one wave or from four), so a trip costs its 32 MFMAs per SIMD plus
-//     the VALU instructions of its four waves.  The gain over bf_sampler_kernel is the 6 trips per iteration that no
-//     longer exist (with the cached start of an iteration: +29 % on the headline workload, 8.0e8 against 6.2e8 leapfrog steps/s).
+//     the VALU instructions of its four waves.  The gain over bf_sampler_kernel is the 7 of 15 trips per iteration that
+//     no longer exist: +29 % on the headline workload (8.0e8 against 6.2e8 leapfrog steps/s).
 //
 // E = 1 throughout (lane = dimension, d <= 64).
 
