@@ -1,3 +1,4 @@
+"""Exploration: posterior moments and the share of samples outside the bound ellipsoid for a workload spec."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""Tuning: launch time of 100 NUTS iterations against the number of chains (d = 128 by default)."""
 import sys, os, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

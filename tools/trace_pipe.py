@@ -1,4 +1,4 @@
-"""Tuning: timeline of wave 0's trips in the pipelined NUTS kernel (needs a tools/variant.sh build with -DBF_TRACE=64)."""
+"""Tuning: timeline of wave 0's trips in the pipelined NUTS kernel (needs a tools/variant.sh build with -DBF_TRACE=32 (the trace buffer shares the 160 KB of LDS with the tree vectors))."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
