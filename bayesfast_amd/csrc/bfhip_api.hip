@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include "bfhip_common.h"
+#include "bfhip_pack.h"
 
 static thread_local char g_err[512] = "";
 
@@ -59,21 +60,6 @@ extern "C" int bfhip_ctx_synchronize(bfhip_ctx *ctx) {
     return 0;
 }
 
-static int padded_tiles(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : 8; }
-
-// M (d,d) row-major (optionally transposed) -> A-fragments of the DP x DP zero-padded matrix
-static void to_fragments(const double *M, int d, int DP, bool transpose, double *frag) {
-    const int T = DP / 16, NS = DP / 4;
-    for (int t = 0; t < T; ++t)
-        for (int s = 0; s < NS; ++s)
-            for (int l = 0; l < 64; ++l) {
-                int row = 16 * t + (l & 15), col = 4 * s + (l >> 4);
-                double v = 0.;
-                if (row < d && col < d) v = transpose ? M[(size_t)col * d + row] : M[(size_t)row * d + col];
-                frag[((size_t)t * NS + s) * 64 + l] = v;
-            }
-}
-
 extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || !ds) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: NULL argument");
@@ -84,45 +70,9 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     if (ds->use_decay && (!ds->decay_mu || !ds->decay_hess))
         return bf_set_error(BFHIP_ERR_ARG, "use_decay needs decay_mu and decay_hess");
     if ((ds->su_lo == NULL) != (ds->su_diff == NULL)) return bf_set_error(BFHIP_ERR_ARG, "su_lo and su_diff go together");
-    const int T = padded_tiles(d), DP = 16 * T;
-    const size_t MAT = (size_t)DP * DP;
-    const size_t n_dbl = (size_t)PD_N * DP + 3 * MAT;
-    std::vector<double> h(n_dbl, 0.);
-    double *pd = h.data(), *Sf = pd + (size_t)PD_N * DP, *Hf = Sf + MAT, *Hdf = Hf + MAT;
-    for (int i = 0; i < DP; ++i) {
-        pd[PD_RG * DP + i] = 1.;
-        pd[PD_SU_DIFF * DP + i] = 1.;
-    }
-    for (int i = 0; i < d; ++i) {
-        if (ds->ranges) {
-            int lo = ds->hard_bounds ? ds->hard_bounds[2 * i] : 0, hi = ds->hard_bounds ? ds->hard_bounds[2 * i + 1] : 0;
-            pd[PD_KIND * DP + i] = (lo && hi) ? 1. : (lo ? 2. : (hi ? 3. : 0.));
-            pd[PD_LO * DP + i] = ds->ranges[2 * i];
-            pd[PD_RG * DP + i] = ds->ranges[2 * i + 1] - ds->ranges[2 * i];
-        }
-        if (ds->su_lo) {
-            pd[PD_SU_LO * DP + i] = ds->su_lo[i];
-            pd[PD_SU_DIFF * DP + i] = ds->su_diff[i];
-        }
-        if (ds->lin) pd[PD_LIN * DP + i] = ds->lin[i];
-        if (ds->use_bound) pd[PD_MU * DP + i] = ds->mu[i];
-        if (ds->use_decay) pd[PD_DMU * DP + i] = ds->decay_mu[i];
-    }
-    if (ds->quad) {
-        // S = A + A^T from the upper triangle the reference reads (modules/_poly.pyx:13-43)
-        std::vector<double> S((size_t)d * d, 0.);
-        for (int j = 0; j < d; ++j)
-            for (int k = j; k < d; ++k) {
-                double a = ds->quad[(size_t)j * d + k];
-                if (j == k) S[(size_t)j * d + j] = 2. * a;
-                else { S[(size_t)j * d + k] = a; S[(size_t)k * d + j] = a; }
-            }
-        to_fragments(S.data(), d, DP, false, Sf);
-    }
-    if (ds->use_bound) to_fragments(ds->hess, d, DP, false, Hf);
-    // decay gradient is (x - mu) H, i.e. H^T (x - mu): core/density.py:745
-    if (ds->use_decay) to_fragments(ds->decay_hess, d, DP, true, Hdf);
-
+    std::vector<double> h;
+    const int DP = bf_pack_density(ds, h);
+    const size_t MAT = (size_t)DP * DP, n_dbl = h.size();
     BF_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = n_dbl * sizeof(double);
     if (ctx->model_bytes < bytes) {
@@ -219,20 +169,11 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     return 0;
 }
 
-// stream = global chain index, so results do not depend on how chains are sharded over GPUs
-static void seed_state(uint64_t seed, uint64_t stream, uint64_t s[4]) {
-    uint64_t x = seed ^ (0xD1B54A32D192ED03ULL * (stream + 1));
-    for (int i = 0; i < 4; ++i) {
-        x += BF_GOLDEN;
-        s[i] = bf_mix64(x);
-    }
-}
-
 extern "C" int bfhip_rng_seed(bfhip_ctx *ctx, int n_chain, uint64_t seed, uint64_t first_stream, uint64_t *rng) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || n_chain < 0 || !rng) return bf_set_error(BFHIP_ERR_ARG, "bfhip_rng_seed: invalid argument");
     std::vector<uint64_t> h((size_t)n_chain * 4);
-    for (int c = 0; c < n_chain; ++c) seed_state(seed, first_stream + (uint64_t)c, &h[(size_t)c * 4]);
+    for (int c = 0; c < n_chain; ++c) bf_seed_state(seed, first_stream + (uint64_t)c, &h[(size_t)c * 4]);
     BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     BF_HIP_CHECK(hipMemcpy(rng, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     return 0;

@@ -1,0 +1,861 @@
+// bfhip_group.h -- NUTS / HMC transitions for the common surrogate at d <= 64, "group" layout (gfx950).
+//
+// Replaces, for all chains of a launch: BaseHMC.run / astep (samplers/hmc_utils/base_hmc.py:62-85,155-156), the NUTS
+// tree (samplers/nuts.py:21-217) or the static HMC trajectory (samplers/hmc.py:16-49), CpuLeapfrogIntegrator._step
+// (samplers/hmc_utils/integration.py:68-95), Density.logp_and_grad on the linear + quadratic surrogate with its
+// extrapolation bound (core/density.py:724-754, modules/poly.py:466-503), DualAverageAdaptation
+// (samplers/hmc_utils/step_size.py:10-51) and QuadMetricDiagAdapt (samplers/hmc_utils/metrics.py:135-237,333-371).
+//
+// Layout.  A workgroup of W = DP/16 waves owns a GROUP of 16 chains for the whole launch.  Lane l = (c = l & 15,
+// g = l >> 4) of wave j holds, for chain c, the four dimensions 16 j + g + 4 r (r = 0..3) of every state vector:
+//   * Per-chain scalars (tree weights, accept sums, step-size state, xoshiro state, counters) live ONCE PER LANE: one
+//     instruction advances the scalar logic of all 16 chains (the sliced kernel bf_sampler_kernel spends one wave per
+//     chain, i.e. one instruction per chain, on it).  Control flow is per lane (exec masks), not per wave.
+//   * The gradient tiles need no transposition: wave j computes row tile j of S X^T and H (X - mu)^T with
+//     v_mfma_f64_16x16x4_f64, whose result registers are exactly the wave's own elements (D[4 r + g][c]); the B operand
+//     of k-step s is element s & 3 of wave s >> 2, exchanged through LDS (XB) once per trip.
+//   * Dot products over the dimensions (energies, the value of the surrogate, the bound test, the U-turn checks) are
+//     summed per lane over r, over g by two row swaps, and over the waves through LDS (RB): ONE exchange per trip carries
+//     the evaluation's sums AND every U-turn check the finished leaf can trigger -- which subtrees merge after leaf i of
+//     a doubling is known beforehand (the trailing one bits of i), and the vectors involved do not depend on the
+//     multinomial draws -- so a trip is: first half step + operands | barrier | 8 W MFMAs + partial sums | barrier |
+//     scalar logic + vector bookkeeping.  Two workgroup barriers per leapfrog step, no speculation, no wasted evaluation;
+//     an iteration starts from its predecessor's proposal, whose value and gradient travel with it through the merges
+//     (base_hmc.py:70 evaluates it again; the numbers are the same).
+//   * Summation order is fixed and the same as the sliced kernel's butterfly: r (dims 4 apart), then g, then waves; the
+//     K halves of a matvec are added as part0 + part1.  A chain's results do not depend on its group or lane.
+//
+// The subtree stack (left p, right p, p_sum, proposal q, proposal gradient per level) keeps level 0 in registers,
+// levels 1..NLV in LDS and deeper levels in the context's global scratch.
+//
+// FS (feature set): 1 = linear + quadratic configs with the bound; bit 1 (2) = decay penalty (density.py:740-746);
+// bit 2 (4) = constraint transform (density.py:92-140,747-750).
+#pragma once
+#include "bfhip_lane.h"
+#include "bfhip_sampler_defs.h"
+
+#define BF_DBL_MAX 1.7976931348623157e308
+
+template <int W>
+struct GroupGeo {
+    static constexpr int DP = 16 * W, NS = 4 * W;
+    static constexpr int KS = (W == 2 || W == 4) ? 2 : 1;  // K halves of a matvec (same association as the sliced kernel)
+    static constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
+    static constexpr int NLV = 2;                            // stack levels 1..NLV in LDS
+    static constexpr int CS = DP + 2;                        // chain stride of an LDS vector (conflict-free b64 access)
+    static constexpr int LSS = 4 * MAXL + 1;                 // chain stride of the stack scalars
+    // exchanged sums
+    static constexpr int V_KIN = 0, V_VAL = 1, V_B2 = 2, V_DOTJ = 3, V_BD2 = 4, V_LOGDET = 5, V_KIN0 = 6, V_M0 = 7;
+    static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * (MAXL - 1), NVAL = V_EXT + 6;
+    static constexpr size_t lds_doubles(int nmat) {
+        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NLV * 5 * 16 * CS + (size_t)16 * LSS;
+    }
+    static constexpr int scratch_slots() { return 5 * (MAXL - NLV); }
+};
+
+// constraint transform of one coordinate: transforms/_constraint.pyx:133-215 (to_original f, j, jj); same expressions
+// as bf_to_original (bfhip_eval.h)
+BF_DEV void bf_to_original_g(double x, int kind, double lo, double rg, double &xo, double &J, double &J2) {
+    double tmp, jt, j2t;
+    if (kind == 1) {
+        tmp = 1. / (1. + bf_exp(-x));
+        jt = tmp * (1. - tmp);
+        const double t2 = bf_exp(x);
+        j2t = -t2 * (t2 - 1.) / (t2 + 1.) / (t2 + 1.) / (t2 + 1.);
+    } else if (kind == 2) {
+        tmp = bf_exp(x);
+        jt = tmp;
+        j2t = tmp;
+    } else if (kind == 3) {
+        const double ex = bf_exp(x);
+        tmp = 1. - ex;
+        jt = -ex;
+        j2t = -ex;
+    } else {
+        tmp = x;
+        jt = 1.;
+        j2t = 0.;
+    }
+    xo = lo + tmp * rg;
+    J = jt * rg;
+    J2 = j2t * rg;
+}
+
+template <int W, bool NUTS, int FS>
+BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) {
+    using G = GroupGeo<W>;
+    constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0;
+    constexpr int DP = G::DP, NS = G::NS, KS = G::KS, MAXL = G::MAXL, NMAT = DEC ? 3 : 2, NLV = G::NLV, CS = G::CS,
+                  LSS = G::LSS;
+    double *XB = lds;                          // [NMAT][NS][64]  B operands: x | x - mu | x_orig - mu_decay
+    double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
+    double *SV = RB + G::NVAL * W * 16;        // [NLV * 5][16][CS] subtree stack vectors, levels 1..NLV
+    double *LS = SV + NLV * 5 * 16 * CS;       // [16][LSS]       subtree stack scalars (one writer: wave 0)
+
+    const int tid = bf_tid(), lane = tid & 63, j = tid >> 6, c = lane & 15, gq = lane >> 4;
+    const int chain = bf_group() * 16 + c;
+    const bool real = chain < a.n_chain;
+    const bool writer = j == 0 && gq == 0;     // the lane that owns chain c's scalar outputs
+    const int d = m.d, dbase = 16 * j + gq;    // element r is dimension dbase + 4 r
+    const int nw = a.cfg.n_warmup;
+
+    // ---- constants: A operands of this wave's row tile, per-dimension table rows ----
+    double afS[NS], afH[NS], afD[DEC ? NS : 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        afS[s] = m.Sf[(j * NS + s) * 64 + lane];
+        afH[s] = m.Hf[(j * NS + s) * 64 + lane];
+        if constexpr (DEC) afD[s] = m.Hdf[(j * NS + s) * 64 + lane];
+    }
+    double c_lin[4], c_mu[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1];
+    int c_kind[TR ? 4 : 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int dim = dbase + 4 * r;
+        c_lin[r] = m.pd[PD_LIN * DP + dim];
+        c_mu[r] = m.pd[PD_MU * DP + dim];
+        if constexpr (TR) {
+            c_kind[r] = (int)m.pd[PD_KIND * DP + dim];
+            c_lo[r] = m.pd[PD_LO * DP + dim];
+            c_rg[r] = m.pd[PD_RG * DP + dim];
+        }
+        if constexpr (DEC) c_dmu[r] = m.pd[PD_DMU * DP + dim];
+    }
+
+    // ---- per-chain state: vectors (4 elements per lane) ----
+    double q[4], p[4], g[4], var[4];
+    double Lq[4], Lp[4], Lg[4], Rq[4], Rp[4], Rg[4];  // the tree's ends (nuts.py:24-43)
+    double PRq[4], PRg[4], PS[4];                     // the tree's proposal (position, gradient) and p_sum
+    double L0p[4], L0q[4], L0g[4];                    // stack level 0: a single waiting leaf
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        q[r] = 0.; p[r] = 0.; g[r] = 0.; var[r] = 1.;
+        Lq[r] = Lp[r] = Lg[r] = Rq[r] = Rp[r] = Rg[r] = PRq[r] = PRg[r] = PS[r] = L0p[r] = L0q[r] = L0g[r] = 0.;
+    }
+    // ---- per-chain state: scalars (one copy per lane) ----
+    uint64_t rs[4] = {0, 0, 0, 0};
+    int mode = M_DONE, prev_mode = M_INIT, i_iter = 0, err = 0;
+    int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0, h_accepted = 0;
+    double eps = 0., eps_t = 0., start_energy = 0., acc_sum = 0.;
+    double T_W = 0., T_acc = 0., T_E = 0., T_logp = 0.;
+    double max_de = 0., w_off = 0., tree_W = 1., beta = 1.;
+    double L0_W = 0., L0_acc = 0., L0_E = 0., L0_logp = 0.;
+    double prop_E = 0., prop_logp = 0.;
+    double h_acc = 0., h_de = 0., h_end_E = 0., h_end_logp = 0.;
+    double log_step = 0., log_bar = 0., hbar = 0., smu = 0., count = 1., step_now = 0., step_bar = 0.;
+    // Welford window counters (metrics.py:186-211): every lane of a chain keeps its own copy in step
+    double fg_n = 0., bg_n = 0., n_samples = 0., prev_upd = 0., adapt_window = 0.;
+    bool need_E0 = false;     // the running iteration's start energy waits for its kinetic part (this trip's exchange)
+    double kin0_part = 0.;
+    unsigned long long nlf = 0;
+
+    double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
+    double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
+    double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + dbase;
+    double *svb = SV + c * CS + dbase;
+    double *lsc = LS + c * LSS;
+
+    auto load_vec = [&](int field, double (&v)[4], double pad) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dim = dbase + 4 * r;
+            v[r] = (dim < d) ? vecp[field * d + dim] : pad;
+        }
+    };
+    auto store_vec = [&](int field, const double (&v)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dim = dbase + 4 * r;
+            if (dim < d) vecp[field * d + dim] = v[r];
+        }
+    };
+    // subtree stack vector k (0 left p, 1 right p, 2 p_sum, 3 proposal q, 4 proposal gradient) of level lev >= 1
+    auto stk_ld = [&](int lev, int k, double (&v)[4]) {
+        if (lev <= NLV) {
+            const double *sp = svb + ((lev - 1) * 5 + k) * (16 * CS);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sp[4 * r];
+        } else {
+            const double *sp = sbase + (size_t)((lev - NLV - 1) * 5 + k) * DP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sp[4 * r];
+        }
+    };
+    auto stk_st = [&](int lev, int k, const double (&v)[4]) {
+        if (lev <= NLV) {
+            double *sp = svb + ((lev - 1) * 5 + k) * (16 * CS);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[4 * r] = v[r];
+        } else {
+            double *sp = sbase + (size_t)((lev - NLV - 1) * 5 + k) * DP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[4 * r] = v[r];
+        }
+    };
+    // sum over this lane's four dimensions, in the butterfly's association (dims 4 apart, then 8 apart)
+    auto sum4 = [](const double (&v)[4]) -> double { return (v[0] + v[1]) + (v[2] + v[3]); };
+    // sum over g (dims 1 apart, then 2 apart) and post this wave's partial: called by ALL lanes
+    bool post_on = true;  // second round: only the chains that take part overwrite their slots
+    auto post = [&](int vi, double part) {
+        const double t = bf_xor32_add(bf_xor16_add(part));
+        if (gq == 0 && post_on) RB[(vi * W + j) * 16 + c] = t;
+    };
+    // the group-wide sum: waves 16 dims apart, then 32 apart
+    auto rd = [&](int vi) -> double {
+        const double *rp = RB + (vi * W) * 16 + c;
+        if constexpr (W == 4) return (rp[0] + rp[16]) + (rp[32] + rp[48]);
+        else if constexpr (W == 2) return rp[0] + rp[16];
+        else return rp[0];
+    };
+    // metric.random (samplers/hmc_utils/metrics.py:83-86): one xoshiro draw K keys a SplitMix64 counter stream; pair P
+    // of the stream gives dimensions 2P (cos) and 2P+1 (sin) by Box-Muller -- the same numbers as the sliced kernel
+    auto draw_momentum = [&]() {
+        const uint64_t K = bf_xoshiro_next(rs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dim = dbase + 4 * r;
+            const uint64_t P = (uint64_t)(dim >> 1);
+            const double u1 = bf_u01_open0(bf_mix64(K + (2 * P + 1) * BF_GOLDEN));
+            const double u2 = bf_u01(bf_mix64(K + (2 * P + 2) * BF_GOLDEN));
+            const double rad = bf_sqrt(-2. * bf_log(u1));
+            double sn, cs;
+            bf_sincospi(2. * u2, &sn, &cs);
+            const double z = (dim & 1) ? rad * sn : rad * cs;
+            p[r] = (dim < d) ? (1. / bf_sqrt(var[r])) * z : 0.;
+        }
+    };
+    // Tree.__init__ (nuts.py:24-43) at the current (q, p, g); the proposal is the starting point
+    auto tree_reset = [&]() {
+        tree_W = 1.;
+        w_off = 0.;
+        max_de = 0.;
+        depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
+        eps = (i_iter < nw) ? step_now : step_bar;  // step_size.py:25-29
+        dir = 1;
+        if (NUTS) dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Lq[r] = q[r]; Lp[r] = p[r]; Lg[r] = g[r];
+            Rq[r] = q[r]; Rp[r] = p[r]; Rg[r] = g[r];
+            PRq[r] = q[r]; PRg[r] = g[r]; PS[r] = p[r];
+        }
+        mode = M_LEAF;
+    };
+
+    if (real) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rs[k] = a.rng[(size_t)chain * 4 + k];
+        log_step = scp[BFHIP_SC_LOG_STEP];
+        log_bar = scp[BFHIP_SC_LOG_BAR];
+        hbar = scp[BFHIP_SC_HBAR];
+        smu = scp[BFHIP_SC_MU];
+        count = scp[BFHIP_SC_COUNT];
+        fg_n = scp[BFHIP_SC_FG_N];
+        bg_n = scp[BFHIP_SC_BG_N];
+        n_samples = scp[BFHIP_SC_N_SAMPLES];
+        prev_upd = scp[BFHIP_SC_PREV_UPDATE];
+        adapt_window = scp[BFHIP_SC_ADAPT_WINDOW];
+        step_now = bf_exp(log_step);   // exp(log_step), exp(log_bar): what the statistics report
+        step_bar = bf_exp(log_bar);
+        i_iter = (int)scp[BFHIP_SC_I_ITER];
+        err = (int)scp[BFHIP_SC_ERROR];
+        load_vec(BFHIP_VEC_Q, q, 0.);
+        load_vec(BFHIP_VEC_VAR, var, 1.);
+        if (i_iter < a.iter_end && err == 0) {
+            mode = M_INIT;
+            draw_momentum();
+        }
+    }
+
+    for (;;) {
+        if (!bf_any(mode != M_DONE)) break;  // (every wave holds all 16 chains' state: the same decision in all of them)
+
+        // ================= phase A: first half of the leapfrog step, B operands =================
+        const bool ev = mode != M_DONE;
+        double xs[4], xev[4], jac[4], gj[4], xo[4];
+        double ldet[4] = {0., 0., 0., 0.};
+        if (ev && mode != M_OOB) {
+            eps_t = (mode == M_LEAF) ? eps * (double)dir : 0.;  // compute_state (base_hmc.py:70) is a step of length 0
+            const double dt = 0.5 * eps_t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = bf_fma(dt, g[r], p[r]);             // integration.py:80
+                q[r] = bf_fma(eps_t, var[r] * p[r], q[r]);  // :82-85
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xs[r] = ev ? q[r] : 0.;
+            jac[r] = 1.;
+            gj[r] = 0.;
+            if constexpr (TR) {
+                if (ev) {
+                    double J, J2;
+                    bf_to_original_g(q[r], c_kind[r], c_lo[r], c_rg[r], xs[r], J, J2);
+                    ldet[r] = 0. + bf_log(bf_fabs(J));
+                    jac[r] = J;
+                    gj[r] = J2 / J;
+                }
+            }
+            xo[r] = xs[r];
+            xev[r] = xs[r];
+            if (mode == M_OOB)  // second pass at the projected point, modules/poly.py:482
+                xev[r] = (m.alpha * xs[r] + (beta - m.alpha) * c_mu[r]) / beta;
+            XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
+            XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
+            if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
+        }
+        bf_sync();  // B1
+
+        // ================= phase B: row tile j of S x, H (x - mu) (, H_decay^T (x - mu_decay)) on MFMA =================
+        double sx[4], hv[4], dgr[4];
+        {
+            bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
+            bf_acc4 aD0 = bf_acc4_zero(), aD1 = bf_acc4_zero();
+            constexpr int KH = NS / KS;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) {
+                aS0 = bf_mfma(afS[s], XB[(0 * NS + s) * 64 + lane], aS0);
+                aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
+                if constexpr (DEC) aD0 = bf_mfma(afD[s], XB[(2 * NS + s) * 64 + lane], aD0);
+                if constexpr (KS == 2) {
+                    aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
+                    aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
+                    if constexpr (DEC) aD1 = bf_mfma(afD[KH + s], XB[(2 * NS + KH + s) * 64 + lane], aD1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sx[r] = (KS == 2) ? aS0[r] + aS1[r] : aS0[r];
+                hv[r] = (KS == 2) ? aH0[r] + aH1[r] : aH0[r];
+                dgr[r] = DEC ? ((KS == 2) ? aD0[r] + aD1[r] : aD0[r]) : 0.;
+            }
+        }
+
+        // ================= phase C: the evaluation's sums, and the U-turn sums of the leaf it completes =================
+        double gn[4], ge[4], pn[4];
+        const double dt_c = 0.5 * eps_t;
+        {
+            double t_val[4], t_b2[4], t_dotj[4], t_bd2[4], t_kin[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gn[r] = sx[r] + c_lin[r];
+                // value of the linear + quadratic surrogate per dimension: lin_r x_r + x_r (S x)_r / 2
+                t_val[r] = bf_fma(0.5 * xev[r], sx[r], c_lin[r] * xev[r]);
+                const double xm = xs[r] - c_mu[r];
+                t_b2[r] = xm * hv[r];
+                t_dotj[r] = gn[r] * xm;  // dot(jj_0, x - mu), poly.py:496 (second pass only)
+                t_bd2[r] = DEC ? (xo[r] - c_dmu[r]) * dgr[r] : 0.;
+                // inside the bound (and the decay ellipsoid) the gradient is already final: chain rule, transform term
+                // (module.py:226, density.py:558,747-750), second half of the step (integration.py:90) and the kinetic
+                // energy (metrics.py:88-91) ride along
+                double t = gn[r];
+                if constexpr (TR) t = t * jac[r] + gj[r];
+                ge[r] = t;
+                pn[r] = bf_fma(dt_c, ge[r], p[r]);
+                t_kin[r] = pn[r] * (var[r] * pn[r]);
+            }
+            post(G::V_KIN, sum4(t_kin));
+            post(G::V_VAL, sum4(t_val));
+            post(G::V_B2, sum4(t_b2));
+            if (bf_any(mode == M_OOB)) post(G::V_DOTJ, sum4(t_dotj));
+            if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
+            if constexpr (TR) post(G::V_LOGDET, sum4(ldet));
+            if (bf_any(need_E0)) post(G::V_KIN0, kin0_part);
+        }
+        // U-turn sums for the subtrees that the leaf in flight completes (nuts.py:146-161 per merge, :88-101 per doubling).
+        // tTL / tTPs: the merged subtree's first momentum and p_sum; tPS: the tree's p_sum after the doubling.
+        double tTL[4], tTPs[4], tPS[4];
+        int nm = 0;  // number of merge levels: trailing one bits of i_leaf, at most depth
+        auto uturn_sums = [&](bool act) {
+            // act: this lane's chain takes part (all lanes run the collectives)
+            nm = 0;
+            if (act) {
+                while (nm < depth && ((i_leaf >> nm) & 1)) ++nm;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { tTL[r] = pn[r]; tTPs[r] = pn[r]; tPS[r] = 0.; }
+            if (bf_any(act && nm >= 1)) {  // level 0: the waiting leaf L0 and the new one (nuts.py:150-151; no sub-span checks)
+                double t0[4], t1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double ps0 = L0p[r] + pn[r];
+                    t0[r] = ps0 * (var[r] * L0p[r]);
+                    t1[r] = ps0 * (var[r] * pn[r]);
+                    if (act && nm >= 1) { tTPs[r] = ps0; tTL[r] = L0p[r]; }
+                }
+                post(G::V_M0 + 0, sum4(t0));
+                post(G::V_M0 + 1, sum4(t1));
+            }
+            for (int lev = 1; bf_any(act && lev < nm); ++lev) {
+                const bool on = act && lev < nm;
+                double A[4] = {0., 0., 0., 0.}, B[4] = {0., 0., 0., 0.}, S1[4] = {0., 0., 0., 0.};
+                if (on) { stk_ld(lev, 0, A); stk_ld(lev, 1, B); stk_ld(lev, 2, S1); }
+                double t[6][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double psum = S1[r] + tTPs[r];
+                    const double vA = var[r] * A[r], vB = var[r] * B[r], vC = var[r] * tTL[r], vD = var[r] * pn[r];
+                    const double ps1 = S1[r] + tTL[r];   // :155-157
+                    const double ps2 = B[r] + tTPs[r];   // :158-160
+                    t[0][r] = psum * vA; t[1][r] = psum * vD; t[2][r] = ps1 * vA; t[3][r] = ps1 * vC;
+                    t[4][r] = ps2 * vB; t[5][r] = ps2 * vD;
+                    if (on) { tTL[r] = A[r]; tTPs[r] = psum; }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) post(G::V_LV + 6 * (lev - 1) + k, sum4(t[k]));
+            }
+            if (bf_any(act && nm == depth)) {  // the doubling completes: Tree.extend's checks, nuts.py:86-101
+                const bool on = act && nm == depth;
+                double t[6][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double ps = PS[r] + tTPs[r];  // :86 (in place)
+                    const double vN = var[r] * pn[r], vT = var[r] * tTL[r], vL = var[r] * Lp[r], vR = var[r] * Rp[r];
+                    // NOTE (reference behaviour, kept on purpose): leftmost_p_sum (dir > 0) / rightmost_p_sum (dir < 0)
+                    // alias self.p_sum, which line 86 has just updated in place.
+                    if (dir > 0) {
+                        const double ps1 = ps + tTL[r], ps2 = Rp[r] + tTPs[r];
+                        t[0][r] = ps * vL; t[1][r] = ps * vN; t[2][r] = ps1 * vL; t[3][r] = ps1 * vT;
+                        t[4][r] = ps2 * vR; t[5][r] = ps2 * vN;
+                    } else {
+                        const double ps1 = tTPs[r] + Lp[r], ps2 = tTL[r] + ps;
+                        t[0][r] = ps * vN; t[1][r] = ps * vR; t[2][r] = ps1 * vN; t[3][r] = ps1 * vL;
+                        t[4][r] = ps2 * vT; t[5][r] = ps2 * vR;
+                    }
+                    if (on) tPS[r] = ps;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) post(G::V_EXT + k, sum4(t[k]));
+            }
+        };
+        // first round: every chain that is finishing a leaf inside the bound (the common case)
+        const bool spec1 = NUTS && ev && mode == M_LEAF;
+        if (NUTS) uturn_sums(spec1);
+        bf_sync();  // B2
+
+        // ================= the evaluation's scalars =================
+        bool fin = false, need2 = false;
+        double logp_new = 0., kin = 0., coef2 = 0.;
+        bool was_oob = false, dec_on = false;
+        if (ev) {
+            const double r_val = rd(G::V_VAL), r_b2 = rd(G::V_B2);
+            double f = (m.c0 + r_val) + 0.;
+            if (mode == M_OOB) {
+                // second pass: f and gn hold f_0 and jj_0 at the projected point (poly.py:484-496)
+                const double r_dotj = rd(G::V_DOTJ);
+                const double f0 = f;
+                f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
+                coef2 = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
+                mode = prev_mode;
+                was_oob = true;
+                need2 = true;
+                fin = true;
+            } else {
+                // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is decided
+                // on the squares whenever b2 is not within rounding distance of alpha^2
+                const double a2 = m.alpha * m.alpha;
+                double bt = 0.;
+                if (!(r_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(r_b2);
+                if (bt > m.alpha) {
+                    beta = bt;  // outside the alpha-ellipsoid: one more trip on the projected point x_0
+                    prev_mode = mode;
+                    mode = M_OOB;
+                } else {
+                    fin = true;
+                }
+            }
+            if (fin) {
+                if constexpr (DEC) {  // density.py:740-746
+                    const double r_bd2 = rd(G::V_BD2);
+                    const double ex = r_bd2 - m.decay_alpha2;
+                    f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                    if (r_bd2 > m.decay_alpha2) { dec_on = true; need2 = true; }
+                }
+                if constexpr (TR) f += rd(G::V_LOGDET);
+                logp_new = f;
+                kin = rd(G::V_KIN);
+            }
+        }
+        // ---- second round (rare): the gradient depends on the sums (outside the bound, decay term active) ----
+        if (bf_any(need2)) {
+            if (need2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double t = gn[r];
+                    if (was_oob) t = t + coef2 * (hv[r] / beta);  // poly.py:496-503
+                    if constexpr (TR) t = t * jac[r];
+                    if constexpr (DEC) { if (dec_on) t -= 2. * m.decay_gamma * dgr[r]; }
+                    if constexpr (TR) t += gj[r];
+                    ge[r] = t;
+                    pn[r] = bf_fma(dt_c, t, p[r]);
+                }
+            }
+            bf_sync();  // (the first round's sums of these chains have been read by every wave)
+            post_on = need2;
+            double t_kin[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t_kin[r] = pn[r] * (var[r] * pn[r]);
+            post(G::V_KIN, sum4(t_kin));
+            // (chains not in this round keep what the first round gave them)
+            double sTL[4], sTPs[4], sPS[4];
+            const int nm1 = nm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sTL[r] = tTL[r]; sTPs[r] = tTPs[r]; sPS[r] = tPS[r]; }
+            const bool spec2 = NUTS && need2 && mode == M_LEAF;
+            if (NUTS) uturn_sums(spec2);
+            post_on = true;
+            bf_sync();
+            if (need2) kin = rd(G::V_KIN);
+            if (!spec2) {
+                nm = nm1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { tTL[r] = sTL[r]; tTPs[r] = sTPs[r]; tPS[r] = sPS[r]; }
+            }
+        }
+        double E_new = 0.;
+        if (fin) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = pn[r]; g[r] = ge[r]; }  // integration.py:90
+            E_new = 0.5 * kin - logp_new;                                  // :92-93
+        }
+        // the start energy of an iteration that began at the end of the previous trip
+        if (need_E0 && ev) {
+            const double E0 = 0.5 * rd(G::V_KIN0) - prop_logp;  // integration.py:28-34
+            if (!(bf_fabs(E0) <= BF_DBL_MAX)) err = 1;           // base_hmc.py:72-76
+            start_energy = E0;
+            prop_E = E0;
+            need_E0 = false;
+        }
+
+        // ================= per-chain state machine =================
+        enum { S_NONE, S_MERGE, S_ABORT, S_DBL_END, S_END };
+        int st = S_NONE, lev = 0, src = -1;  // src: whose proposal the finished subtree holds (-1 this leaf, 0 L0, l stack level l)
+        double dE = 0., aw = 0., sc_ = 1.;
+        bool resc = false;
+        if (fin && err == 0 && mode == M_INIT) {
+            // BaseHMC.astep start (the first iteration of a launch): base_hmc.py:70-76
+            if (!(bf_fabs(E_new) <= BF_DBL_MAX)) {
+                err = 1;
+            } else {
+                start_energy = E_new;
+                prop_E = E_new;
+                prop_logp = logp_new;
+                tree_reset();
+            }
+        } else if (fin && err == 0 && mode == M_LEAF) {
+            nlf += 1;
+            if constexpr (NUTS) {
+                // ---- Tree._single_step: nuts.py:105-132 ----
+                n_prop += 1;
+                dE = E_new - start_energy;
+                if (dE != dE) dE = __builtin_inf();
+                if (bf_fabs(dE) > bf_fabs(max_de)) max_de = dE;
+                T_E = E_new;
+                T_logp = logp_new;
+                T_acc = 0.;
+                st = S_MERGE;
+                if (!(bf_fabs(dE) < a.cfg.max_change)) {
+                    diverged = 1;
+                    st = S_ABORT;
+                } else {
+                    // multinomial weight exp(-dE) relative to a running offset w_off (exact streaming log-sum-exp)
+                    aw = -dE - w_off;
+                    if (aw > 600.) {
+                        sc_ = bf_exp(-aw);
+                        tree_W = tree_W * sc_;
+                        L0_W *= sc_;
+                        w_off = w_off + aw;
+                        aw = 0.;
+                        resc = true;
+                    }
+                }
+            } else {
+                // ---- HMC._hamiltonian_step: samplers/hmc.py:16-49 ----
+                i_leaf += 1;
+                if (i_leaf >= a.cfg.n_int_step) {
+                    const bool finite = bf_fabs(E_new) <= BF_DBL_MAX;
+                    const double h_dE = finite ? (start_energy - E_new) : -__builtin_inf();
+                    diverged = (!finite || bf_fabs(h_dE) > a.cfg.max_change) ? 1 : 0;
+                    double h_accept_stat = bf_exp(h_dE);
+                    if (h_accept_stat > 1.) h_accept_stat = 1.;
+                    h_accepted = 0;
+                    if (!diverged) h_accepted = !(bf_u01(bf_xoshiro_next(rs)) >= h_accept_stat);
+                    if (h_accepted) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { PRq[r] = q[r]; PRg[r] = g[r]; }
+                        prop_logp = logp_new;
+                    }
+                    h_de = h_dE;
+                    h_acc = h_accept_stat;
+                    h_end_E = E_new;
+                    h_end_logp = logp_new;
+                    st = S_END;
+                }
+            }
+        }
+        if constexpr (NUTS) {
+            if (bf_any(resc)) {  // (rare) the stacked subtrees' weights follow the new offset; wave 0 owns them
+                bf_sync();
+                if (writer && resc)
+                    for (int l2 = 1; l2 < depth; ++l2) lsc[l2 * 4 + LS_LS] *= sc_;
+                bf_sync();
+            }
+            if (st == S_MERGE) {
+                T_W = bf_exp(aw);
+                const double pacc = (w_off == 0.) ? T_W : bf_exp(-dE);
+                T_acc = pacc > 1. ? 1. : pacc;
+                if (nm >= 1) {
+                    // ---- level-0 merge with the waiting leaf L0 (nuts.py:146-178) ----
+                    const double d0 = rd(G::V_M0 + 0), d1 = rd(G::V_M0 + 1);
+                    T_acc = L0_acc + T_acc;  // :173
+                    const double Wsum = L0_W + T_W;
+                    if (Wsum != Wsum) err = 2;
+                    const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
+                    lev = 1;
+                    if ((d0 <= 0.) || (d1 <= 0.)) {
+                        st = S_ABORT;
+                    } else {
+                        // logbern(ls2 - logaddexp(ls1, ls2))  <=>  U * (W1 + W2) < W2
+                        if (!((u * Wsum < T_W) || (u == 0.))) { src = 0; T_E = L0_E; T_logp = L0_logp; }
+                        T_W = Wsum;
+                    }
+                }
+                // ---- merge upwards while the finished subtree is a right child ----
+                while (st == S_MERGE && lev < nm) {
+                    bool turning = false;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) turning = turning || (rd(G::V_LV + 6 * (lev - 1) + k) <= 0.);
+                    const double *lsp = lsc + lev * 4;
+                    T_acc = lsp[LS_ACC] + T_acc;  // :173
+                    const double Wsum = lsp[LS_LS] + T_W;
+                    if (Wsum != Wsum) err = 2;
+                    const double u = bf_u01(bf_xoshiro_next(rs));  // consumed even when this merge's check says turning
+                    const bool keep_t2 = (u * Wsum < T_W) || (u == 0.);
+                    if (turning) {
+                        st = S_ABORT;  // ancestors above this level still add their accept sums
+                    } else {
+                        if (!keep_t2) { src = lev; T_E = lsp[LS_E]; T_logp = lsp[LS_LOGP]; }
+                        T_W = Wsum;
+                    }
+                    lev += 1;
+                }
+                if (st == S_MERGE) {
+                    if (lev < depth) {
+                        // the subtree waits for its right sibling
+                        if (lev == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { L0p[r] = p[r]; L0q[r] = q[r]; L0g[r] = g[r]; }
+                            L0_W = T_W; L0_acc = T_acc; L0_E = E_new; L0_logp = logp_new;
+                        } else {
+                            double tq[4], tg[4];
+                            if (src < 0) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { tq[r] = q[r]; tg[r] = g[r]; }
+                            } else if (src == 0) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { tq[r] = L0q[r]; tg[r] = L0g[r]; }
+                            } else {
+                                stk_ld(src, 3, tq);
+                                stk_ld(src, 4, tg);
+                            }
+                            stk_st(lev, 0, tTL); stk_st(lev, 1, p); stk_st(lev, 2, tTPs); stk_st(lev, 3, tq); stk_st(lev, 4, tg);
+                            if (writer) {
+                                double *lsp = lsc + lev * 4;
+                                lsp[LS_LS] = T_W; lsp[LS_ACC] = T_acc; lsp[LS_E] = T_E; lsp[LS_LOGP] = T_logp;
+                            }
+                        }
+                        i_leaf += 1;
+                        st = S_NONE;
+                    } else {
+                        st = S_DBL_END;
+                    }
+                }
+            }
+            if (st == S_ABORT) {
+                // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
+                for (int al = (diverged ? 0 : lev); al < depth; ++al)
+                    if ((i_leaf >> al) & 1) T_acc = (al == 0 ? L0_acc : lsc[al * 4 + LS_ACC]) + T_acc;
+                depth += 1;  // nuts.py:71-73
+                acc_sum += T_acc;
+                st = S_END;
+            } else if (st == S_DBL_END) {
+                // ---- Tree.extend after a complete subtree: nuts.py:71-103 ----
+                depth += 1;
+                acc_sum += T_acc;
+                {   // :81-83  logbern(ls_new - ls_old)  <=>  U * W_old < W_new
+                    if (T_W != T_W || tree_W != tree_W) err = 2;
+                    const double u = bf_u01(bf_xoshiro_next(rs));
+                    if ((u * tree_W < T_W) || (u == 0.)) {
+                        if (src < 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { PRq[r] = q[r]; PRg[r] = g[r]; }
+                        } else if (src == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { PRq[r] = L0q[r]; PRg[r] = L0g[r]; }
+                        } else {
+                            stk_ld(src, 3, PRq);
+                            stk_ld(src, 4, PRg);
+                        }
+                        prop_E = T_E;
+                        prop_logp = T_logp;
+                    }
+                    tree_W = tree_W + T_W;  // :85
+                }
+                bool turning = false;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) turning = turning || (rd(G::V_EXT + k) <= 0.);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    PS[r] = tPS[r];
+                    if (dir > 0) { Rq[r] = q[r]; Rp[r] = p[r]; Rg[r] = g[r]; }
+                    else { Lq[r] = q[r]; Lp[r] = p[r]; Lg[r] = g[r]; }
+                }
+                if (turning || depth >= a.cfg.max_treedepth) {
+                    st = S_END;
+                } else {
+                    const int nd = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
+                    if (nd != dir) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            q[r] = (nd > 0) ? Rq[r] : Lq[r];
+                            p[r] = (nd > 0) ? Rp[r] : Lp[r];
+                            g[r] = (nd > 0) ? Rg[r] : Lg[r];
+                        }
+                    }
+                    dir = nd;
+                    i_leaf = 0;
+                    st = S_NONE;
+                }
+            }
+        }
+        // ================= iteration end: base_hmc.py:80-85 =================
+        if (st == S_END && err == 0) {
+            const bool warm = i_iter < nw;
+            const double accept_stat = NUTS ? acc_sum / (double)n_prop : h_acc;  // nuts.py:186
+            if (warm && a.cfg.adapt_step_size) {  // step_size.py:31-45
+                const double wgt = 1. / (count + a.cfg.t_0);
+                hbar = ((1. - wgt) * hbar + wgt * (a.cfg.target_accept - accept_stat));
+                log_step = smu - hbar * bf_sqrt(count) / a.cfg.gamma;
+                const double mk = bf_exp(-a.cfg.k * bf_log(count));  // count ** -k
+                log_bar = mk * log_step + (1. - mk) * log_bar;
+                count = count + 1.;
+                step_now = bf_exp(log_step);
+                step_bar = bf_exp(log_bar);
+            }
+            // the proposal is the new sample and the start of the next iteration (value and gradient came with it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { q[r] = PRq[r]; g[r] = PRg[r]; }
+            const int orow = i_iter - a.iter_out0;
+            if (orow >= 0 && orow < a.n_out) {
+                if (writer) {
+                    double *sp = a.stats + ((size_t)chain * a.n_out + orow) * BFHIP_STAT_STRIDE;
+                    if (NUTS) {
+                        sp[BFHIP_NS_LOGP] = prop_logp;
+                        sp[BFHIP_NS_ENERGY] = prop_E;
+                        sp[BFHIP_NS_TREE_DEPTH] = (double)depth;
+                        sp[BFHIP_NS_TREE_SIZE] = (double)n_prop;
+                        sp[BFHIP_NS_MEAN_TREE_ACCEPT] = accept_stat;
+                        sp[BFHIP_NS_STEP_SIZE] = step_now;
+                        sp[BFHIP_NS_STEP_SIZE_BAR] = step_bar;
+                        sp[BFHIP_NS_WARMUP] = warm ? 1. : 0.;
+                        sp[BFHIP_NS_ENERGY_CHANGE] = prop_E - start_energy;
+                        sp[BFHIP_NS_MAX_ENERGY_CHANGE] = max_de;
+                        sp[BFHIP_NS_DIVERGING] = (double)diverged;
+                    } else {
+                        sp[BFHIP_HS_LOGP] = h_end_logp;
+                        sp[BFHIP_HS_ENERGY] = h_end_E;
+                        sp[BFHIP_HS_N_INT_STEP] = (double)a.cfg.n_int_step;
+                        sp[BFHIP_HS_ACCEPT_STAT] = accept_stat;
+                        sp[BFHIP_HS_ACCEPTED] = (double)h_accepted;
+                        sp[BFHIP_HS_STEP_SIZE] = step_now;
+                        sp[BFHIP_HS_STEP_SIZE_BAR] = step_bar;
+                        sp[BFHIP_HS_WARMUP] = warm ? 1. : 0.;
+                        sp[BFHIP_HS_ENERGY_CHANGE] = h_de;
+                        sp[BFHIP_HS_DIVERGING] = (double)diverged;
+                        sp[10] = 0.;
+                    }
+                }
+                double *xp = a.samples + ((size_t)chain * a.n_out + orow) * d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (dbase + 4 * r < d) xp[dbase + 4 * r] = q[r];
+            }
+            // QuadMetricDiagAdapt.update: metrics.py:186-211, _WeightedVariance.add_sample :354-360
+            if (warm && a.cfg.adapt_metric) {
+                const long delta = (long)(n_samples - prev_upd);
+                double fm[4], fr[4], bm[4], br[4];
+                load_vec(BFHIP_VEC_FG_MEAN, fm, 0.);
+                load_vec(BFHIP_VEC_FG_RAW, fr, 0.);
+                load_vec(BFHIP_VEC_BG_MEAN, bm, 0.);
+                load_vec(BFHIP_VEC_BG_RAW, br, 0.);
+                fg_n += 1.;
+                bg_n += 1.;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double od = q[r] - fm[r];
+                    fm[r] += od / fg_n;
+                    fr[r] += 1. * od * (q[r] - fm[r]);
+                    od = q[r] - bm[r];
+                    bm[r] += od / bg_n;
+                    br[r] += 1. * od * (q[r] - bm[r]);
+                }
+                if ((delta + 1) % (long)a.cfg.update_window == 0) {  // metrics.py:181-184
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (dbase + 4 * r < d) var[r] = fr[r] / fg_n;
+                    store_vec(BFHIP_VEC_VAR, var);
+                }
+                if ((double)delta >= adapt_window) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { fm[r] = bm[r]; fr[r] = br[r]; bm[r] = 0.; br[r] = 0.; }
+                    fg_n = bg_n;
+                    bg_n = 10.;
+                    prev_upd = n_samples;
+                    if (a.cfg.doubling) adapt_window *= 2.;
+                }
+                n_samples += 1.;
+                store_vec(BFHIP_VEC_FG_MEAN, fm);
+                store_vec(BFHIP_VEC_FG_RAW, fr);
+                store_vec(BFHIP_VEC_BG_MEAN, bm);
+                store_vec(BFHIP_VEC_BG_RAW, br);
+            }
+            i_iter += 1;
+            if (i_iter < a.iter_end) {
+                // next iteration: metric.random, then the tree starts at (q, p) with the proposal's value and gradient;
+                // the start energy needs the kinetic energy of the new momentum: it joins the next trip's exchange
+                draw_momentum();
+                tree_reset();
+                double t_k0[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t_k0[r] = p[r] * (var[r] * p[r]);  // metrics.py:88-91
+                kin0_part = sum4(t_k0);
+                need_E0 = true;
+            } else {
+                mode = M_DONE;
+            }
+        }
+        if (err != 0) mode = M_DONE;
+    }
+
+    // ---- write the chain state back ----
+    if (real) {
+        store_vec(BFHIP_VEC_Q, q);
+        if (writer) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.rng[(size_t)chain * 4 + k] = rs[k];
+            scp[BFHIP_SC_LOG_STEP] = log_step;
+            scp[BFHIP_SC_LOG_BAR] = log_bar;
+            scp[BFHIP_SC_HBAR] = hbar;
+            scp[BFHIP_SC_COUNT] = count;
+            scp[BFHIP_SC_FG_N] = fg_n;
+            scp[BFHIP_SC_BG_N] = bg_n;
+            scp[BFHIP_SC_N_SAMPLES] = n_samples;
+            scp[BFHIP_SC_PREV_UPDATE] = prev_upd;
+            scp[BFHIP_SC_ADAPT_WINDOW] = adapt_window;
+            scp[BFHIP_SC_I_ITER] = (double)i_iter;
+            scp[BFHIP_SC_ERROR] = (double)err;
+            if (a.n_leapfrog && nlf) bf_atomic_add_u64(a.n_leapfrog, nlf);
+        }
+    }
+}

@@ -1,0 +1,75 @@
+// bfhip_pack.h -- host-side re-layout of a bfhip_density_desc into the device model's tables (no HIP dependency;
+// shared by bfhip_density_upload and the host emulation of the group kernel under tests/emu).
+#pragma once
+#include <vector>
+#include "bfhip_model.h"
+
+static inline int padded_tiles(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : 8; }
+
+// M (d,d) row-major (optionally transposed) -> A-fragments of the DP x DP zero-padded matrix
+static inline void to_fragments(const double *M, int d, int DP, bool transpose, double *frag) {
+    const int T = DP / 16, NS = DP / 4;
+    for (int t = 0; t < T; ++t)
+        for (int s = 0; s < NS; ++s)
+            for (int l = 0; l < 64; ++l) {
+                int row = 16 * t + (l & 15), col = 4 * s + (l >> 4);
+                double v = 0.;
+                if (row < d && col < d) v = transpose ? M[(size_t)col * d + row] : M[(size_t)row * d + col];
+                frag[((size_t)t * NS + s) * 64 + l] = v;
+            }
+}
+
+
+// pd table [PD_N][DP] followed by the A-operand fragments of S, H and H_decay^T ([DP*DP] each); returns DP
+static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<double> &h) {
+    const int d = ds->d;
+    const int T = padded_tiles(d), DP = 16 * T;
+    const size_t MAT = (size_t)DP * DP;
+    const size_t n_dbl = (size_t)PD_N * DP + 3 * MAT;
+    h.assign(n_dbl, 0.);
+    double *pd = h.data(), *Sf = pd + (size_t)PD_N * DP, *Hf = Sf + MAT, *Hdf = Hf + MAT;
+    for (int i = 0; i < DP; ++i) {
+        pd[PD_RG * DP + i] = 1.;
+        pd[PD_SU_DIFF * DP + i] = 1.;
+    }
+    for (int i = 0; i < d; ++i) {
+        if (ds->ranges) {
+            int lo = ds->hard_bounds ? ds->hard_bounds[2 * i] : 0, hi = ds->hard_bounds ? ds->hard_bounds[2 * i + 1] : 0;
+            pd[PD_KIND * DP + i] = (lo && hi) ? 1. : (lo ? 2. : (hi ? 3. : 0.));
+            pd[PD_LO * DP + i] = ds->ranges[2 * i];
+            pd[PD_RG * DP + i] = ds->ranges[2 * i + 1] - ds->ranges[2 * i];
+        }
+        if (ds->su_lo) {
+            pd[PD_SU_LO * DP + i] = ds->su_lo[i];
+            pd[PD_SU_DIFF * DP + i] = ds->su_diff[i];
+        }
+        if (ds->lin) pd[PD_LIN * DP + i] = ds->lin[i];
+        if (ds->use_bound) pd[PD_MU * DP + i] = ds->mu[i];
+        if (ds->use_decay) pd[PD_DMU * DP + i] = ds->decay_mu[i];
+    }
+    if (ds->quad) {
+        // S = A + A^T from the upper triangle the reference reads (modules/_poly.pyx:13-43)
+        std::vector<double> S((size_t)d * d, 0.);
+        for (int j = 0; j < d; ++j)
+            for (int k = j; k < d; ++k) {
+                double a = ds->quad[(size_t)j * d + k];
+                if (j == k) S[(size_t)j * d + j] = 2. * a;
+                else { S[(size_t)j * d + k] = a; S[(size_t)k * d + j] = a; }
+            }
+        to_fragments(S.data(), d, DP, false, Sf);
+    }
+    if (ds->use_bound) to_fragments(ds->hess, d, DP, false, Hf);
+    // decay gradient is (x - mu) H, i.e. H^T (x - mu): core/density.py:745
+    if (ds->use_decay) to_fragments(ds->decay_hess, d, DP, true, Hdf);
+
+    return DP;
+}
+
+// stream = global chain index, so results do not depend on how chains are sharded over GPUs
+static inline void bf_seed_state(uint64_t seed, uint64_t stream, uint64_t s[4]) {
+    uint64_t x = seed ^ (0xD1B54A32D192ED03ULL * (stream + 1));
+    for (int i = 0; i < 4; ++i) {
+        x += BF_GOLDEN;
+        s[i] = bf_mix64(x);
+    }
+}

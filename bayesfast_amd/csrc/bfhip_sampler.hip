@@ -54,27 +54,7 @@ __device__ __attribute__((noinline)) static void bf_sincospi_ni(double x, double
 #define ulog(x) rfl(bf_log_ni(x))
 #define usqrt(x) rfl(bf_sqrt_ni(x))
 
-struct SamplerArgs {
-    bfhip_sampler_config cfg;
-    int n_chain, iter_end, iter_out0, n_out, nslot;
-    int tail_max;  // plain kernel: at most this many evaluating chains of a group take the VALU matvec (0: never)
-    int ks, gbn;  // K-split of the matvec jobs (so that all 16 waves get one) and the number of result slots
-    uint64_t *rng;
-    double *sc, *vec, *samples, *stats;
-    unsigned long long *n_leapfrog;
-    double *scratch;
-    double *mat;  // full-rank metric: [n_chain][BF_MAT_N][d][d] (transposed storage, bfhip_metric.h), or NULL
-    unsigned long long *stamps;  // diagnostics only: [groups][16 waves][20]: 10 cycle counters + 10 event counts, or NULL
-};
-
-enum { M_INIT = 0, M_LEAF = 1, M_OOB = 2, M_DONE = 3 };
-// units of per-chain work; a chain runs one per trip (U_EVAL needs this trip's gradient)
-enum { U_EVAL = 0, U_MERGE_RUN, U_DBL_END, U_END1, U_END2, U_END3, U_DONE, U_MERGE, U_ABORT };
-enum { SL_LEFT_Q = 0, SL_LEFT_P, SL_LEFT_G, SL_RIGHT_Q, SL_RIGHT_P, SL_RIGHT_G, SL_PROP_Q, SL_PSUM, SL_STACK };
-enum { LS_LS = 0, LS_E, LS_LOGP, LS_ACC, LS_N };
-// cold per-chain scalars parked in LDS (one writer: lane 0 of the chain's wave; broadcast reads)
-enum { CS_LOG_STEP = 0, CS_LOG_BAR, CS_HBAR, CS_SMU, CS_COUNT, CS_PROP_E, CS_PROP_LOGP, CS_MAX_DE, CS_HACC, CS_HDE,
-       CS_W_OFF, CS_TREE_W, CS_BETA, CS_T_E, CS_T_LOGP, CS_STEP_NOW, CS_STEP_BAR, CS_N };
+#include "bfhip_sampler_defs.h"
 
 // one DPP move of a double (both halves)
 template <int CTRL>

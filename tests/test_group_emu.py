@@ -1,0 +1,190 @@
+"""CPU checks of the group sampler kernel (bayesfast_amd/csrc/bfhip_group.h) through its host emulation.
+
+The same header that hipcc compiles for gfx950 is compiled for the host with one fibre per lane (tests/emu): the
+per-lane chain state machines, the cross-wave reductions through the emulated LDS, the barrier placement and the
+MFMA tile ownership run exactly as on the device (a collective called from divergent control flow deadlocks the
+emulation, a cross-wave race shows up as a wrong result), only libm and the instruction timing differ.  The oracle
+shares the xoshiro256++ streams, so tree depth / size / divergence must match exactly and positions to 1e-9 on the
+head of a run (float64 summation order is the only difference).  The GPU parity tests proper are tests/test_gpu_*.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'emu'))
+G = os.path.join(HERE, 'golden')
+SEED = 20240917
+
+
+@pytest.fixture(scope='module')
+def samp():
+    return np.load(os.path.join(G, 'sampler.npz'))
+
+
+def _spec(z, prefix):
+    from specio import rebuild_spec
+    return rebuild_spec(z, prefix)
+
+
+def _emu(spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, split=None, seed=SEED, launch_iters=None, **kw):
+    import emu
+    ec = emu.EmuChains(spec, x0, seed=seed, first_stream=first_stream, step_size=kw.get('step_size', 1.))
+    run_kw = {k: v for k, v in kw.items() if k in ('max_treedepth', 'max_change', 'n_int_step', 'target_accept')}
+    if split is None:
+        s, st = ec.run(n_iter, sampler, n_warmup=n_warmup, launch_iters=launch_iters, **run_kw)
+    else:
+        s1, st1 = ec.run(split, sampler, n_warmup=n_warmup, **run_kw)
+        s2, st2 = ec.run(n_iter - split, sampler, n_warmup=n_warmup, **run_kw)
+        s = np.concatenate([s1, s2], 1)
+        st = {k: np.concatenate([st1[k], st2[k]], 1) for k in st1}
+    return s, st, ec
+
+
+def _oracle(spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, seed=SEED, **kw):
+    from oracle import oracle as orc
+    out = []
+    for i in range(x0.shape[0]):
+        ch = orc.Chain(x0[i], **{k: v for k, v in kw.items() if k in ('step_size', 'target_accept')})
+        rng = orc.make_rng('xoshiro', seed=seed, stream=first_stream + i)
+        if sampler == 'NUTS':
+            out.append(orc.nuts_run(spec, ch, rng, n_iter, n_warmup, max_treedepth=kw.get('max_treedepth', 10),
+                                    max_change=kw.get('max_change', 1000.)) + (ch,))
+        else:
+            out.append(orc.hmc_run(spec, ch, rng, n_iter, n_warmup, n_int_step=kw.get('n_int_step', 32),
+                                   max_change=kw.get('max_change', 1000.)) + (ch,))
+    return out
+
+
+def _compare_nuts(dev, orc_runs, n_exact, rtol_q=1e-5, n_head=8, tol_head=1e-9):
+    s, st, ec = dev
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        for f in ('tree_depth', 'tree_size', 'diverging', 'warmup'):
+            assert np.array_equal(st[f][i][:n_exact], sto[f][:n_exact]), (i, f, st[f][i][:n_exact], sto[f][:n_exact])
+        np.testing.assert_allclose(s[i][:n_head], so[:n_head], rtol=tol_head, atol=tol_head, err_msg='chain %d' % i)
+        np.testing.assert_allclose(s[i][:n_exact], so[:n_exact], rtol=rtol_q, atol=rtol_q, err_msg='chain %d' % i)
+        for f in ('logp', 'energy', 'mean_tree_accept', 'step_size', 'step_size_bar', 'energy_change', 'max_energy_change'):
+            np.testing.assert_allclose(st[f][i][:n_head], sto[f][:n_head], rtol=1e-8, atol=1e-8, err_msg=f)
+            np.testing.assert_allclose(st[f][i][:n_exact], sto[f][:n_exact], rtol=1e-4, atol=1e-4, err_msg=f)
+
+
+@pytest.mark.parametrize('name,n_chain,n_iter,n_warmup', [('plain16', 5, 40, 25), ('d64', 18, 14, 9)])
+def test_group_kernel_nuts_trajectories_match_oracle(samp, name, n_chain, n_iter, n_warmup):
+    """W = 1 (one wave per group) and W = 4 (four waves, two groups, the second one ragged)."""
+    spec = _spec(samp, name + '.')
+    x0 = np.random.default_rng(3).normal(size=(n_chain, spec['d'])) * 0.5
+    dev = _emu(spec, x0, n_iter, n_warmup)
+    orc_runs = _oracle(spec, x0, n_iter, n_warmup)
+    _compare_nuts(dev, orc_runs, n_iter)
+    s, st, ec = dev
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        np.testing.assert_allclose(ec.field('var')[i], ch.vec('var'), rtol=1e-5)
+    assert int(ec.n_leapfrog[0]) == int(sum(r[1]['tree_size'].sum() for r in orc_runs))
+    assert (ec.field('error') == 0).all()
+
+
+def test_group_kernel_resume_shard_and_launch_cut_invariance(samp):
+    """Two launches == one launch == launches of 7 iterations; a chain's result depends on its GLOBAL stream index only,
+    not on its group or lane (bitwise)."""
+    spec = _spec(samp, 'plain16.')
+    x0 = np.random.default_rng(4).normal(size=(20, 16)) * 0.5
+    s_all, st_all, ec_all = _emu(spec, x0, 30, 20)
+    s_split, st_split, ec_split = _emu(spec, x0, 30, 20, split=13)
+    assert np.array_equal(s_all, s_split)
+    assert np.array_equal(st_all['tree_size'], st_split['tree_size'])
+    s_cut, st_cut, ec_cut = _emu(spec, x0, 30, 20, launch_iters=7)
+    assert np.array_equal(s_all, s_cut) and np.array_equal(ec_all.sc, ec_cut.sc) and np.array_equal(ec_all.rng, ec_cut.rng)
+    for k in st_all:
+        assert np.array_equal(st_all[k], st_cut[k])
+    s_tail, st_tail, _ = _emu(spec, x0[7:], 30, 20, first_stream=7)
+    assert np.array_equal(s_all[7:], s_tail)
+
+
+def test_group_kernel_divergences_depth_cap_and_far_start(samp):
+    """Divergent leaves and immediate U-turns (huge step), the depth cap, and chains that start 6 sigma out, i.e.
+    outside the alpha-ellipsoid (two-pass evaluations, poly.py:480-503; weights over a huge dynamic range)."""
+    spec = _spec(samp, 'div5.')
+    x0 = np.repeat(samp['div5.x0'], 4, 0) + np.arange(4)[:, None] * 0.1
+    kw = dict(step_size=40., max_change=50.)
+    dev = _emu(spec, x0, 30, 10, **kw)
+    orc_runs = _oracle(spec, x0, 30, 10, **kw)
+    assert sum(r[1]['diverging'].sum() for r in orc_runs) >= 1
+    _compare_nuts(dev, orc_runs, 30)
+    spec = _spec(samp, 'plain16.')
+    x0 = np.random.default_rng(5).normal(size=(4, 16))
+    kw = dict(step_size=0.05, max_treedepth=3)
+    dev = _emu(spec, x0, 12, 0, **kw)
+    orc_runs = _oracle(spec, x0, 12, 0, **kw)
+    assert dev[1]['tree_depth'].max() == 3 and dev[1]['tree_size'].max() == 7
+    _compare_nuts(dev, orc_runs, 12)
+    spec = _spec(samp, 'd64.')
+    x0 = np.random.default_rng(6).normal(size=(3, 64)) * 6.
+    dev = _emu(spec, x0, 8, 6)
+    orc_runs = _oracle(spec, x0, 8, 6)
+    _compare_nuts(dev, orc_runs, 8, tol_head=1e-8)
+
+
+def test_group_kernel_hmc_matches_oracle(samp):
+    spec = _spec(samp, 'plain16.')
+    x0 = np.random.default_rng(7).normal(size=(6, 16)) * 0.5
+    s, st, ec = _emu(spec, x0, 30, 20, sampler='HMC', n_int_step=8)
+    orc_runs = _oracle(spec, x0, 30, 20, sampler='HMC', n_int_step=8)
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        for f in ('accepted', 'diverging', 'n_int_step'):
+            assert np.array_equal(st[f][i], sto[f]), (i, f)
+        np.testing.assert_allclose(s[i][:8], so[:8], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(st['accept_stat'][i], sto['accept_stat'], rtol=1e-3, atol=1e-3)
+        for f in ('logp', 'energy', 'energy_change', 'step_size'):
+            np.testing.assert_allclose(st[f][i][:8], sto[f][:8], rtol=1e-8, atol=1e-8, err_msg=f)
+    assert int(ec.n_leapfrog[0]) == 6 * 30 * 8
+
+
+@pytest.mark.parametrize('decay,bounds,d', [(True, False, 64), (False, True, 30), (True, True, 48)])
+def test_group_kernel_feature_sets_match_oracle(samp, decay, bounds, d):
+    """Decay penalty (density.py:740-746) and / or constraint transform with all four kinds of bounds
+    (density.py:92-140,747-750): template parameter FS = 3, 5, 7."""
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    spec = dict(_spec(samp, 'd64.')) if d == 64 else dict(correlated_gaussian_spec(d)[0])
+    if decay:
+        spec.update(use_decay=True, decay_mu=spec['poly']['mu'], decay_hess=spec['poly']['hess'],
+                    decay_alpha2=float(spec['poly']['alpha'])**2 * 0.6, decay_gamma=0.1)
+    if bounds:
+        lo = np.full(d, -9.) + np.arange(d) * 0.01
+        hb = np.array(([[1, 1], [1, 0], [0, 1], [0, 0]] * d)[:d], dtype=np.uint8)
+        spec.update(ranges=np.stack([lo, lo + 18.], 1), hard_bounds=hb)
+    x0 = np.random.default_rng(8).normal(size=(5, d)) * 0.3
+    dev = _emu(spec, x0, 12, 8)
+    orc_runs = _oracle(spec, x0, 12, 8)
+    _compare_nuts(dev, orc_runs, 12, n_head=6, tol_head=1e-8)
+    # HMC through the same feature set
+    s, st, ec = _emu(spec, x0[:3], 8, 5, sampler='HMC', n_int_step=5)
+    for i, (so, sto, ch) in enumerate(_oracle(spec, x0[:3], 8, 5, sampler='HMC', n_int_step=5)):
+        assert np.array_equal(st['accepted'][i], sto['accepted'])
+        np.testing.assert_allclose(s[i][:5], so[:5], rtol=1e-8, atol=1e-8)
+
+
+def test_group_kernel_bad_initial_energy_sets_error_flag(samp):
+    """Non-finite initial energy is an error, not a divergence (base_hmc.py:72-76): error code 1, nothing sampled."""
+    spec = _spec(samp, 'plain16.')
+    x0 = np.zeros((3, 16))
+    x0[1, 0] = np.inf
+    s, st, ec = _emu(spec, x0, 3, 1)
+    assert list(ec.field('error')) == [0., 1., 0.]
+    assert list(ec.field('i_iter')) == [3., 0., 3.]
+
+
+@pytest.mark.parametrize('d', [1, 3, 17, 33])
+def test_group_kernel_odd_shapes(d):
+    """Dimensions that are not multiples of the 16-wide tiles; 1 and 17 chains (ragged groups)."""
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from oracle import oracle as orc
+    spec, _ = correlated_gaussian_spec(d)
+    for C in (1, 17):
+        x0 = np.random.default_rng(d * 1000 + C).normal(size=(C, d)) * 0.7
+        s, st, ec = _emu(spec, x0, 10, 7, seed=9)
+        for i in sorted(set((0, C - 1))):
+            so, sto = orc.nuts_run(spec, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=9, stream=i), 10, 7)
+            assert np.array_equal(st['tree_size'][i], sto['tree_size']), (d, C, i)
+            np.testing.assert_allclose(s[i, :5], so[:5], rtol=1e-8, atol=1e-8)
