@@ -25,8 +25,8 @@
 //   * Summation order is fixed and the same as the sliced kernel's butterfly: r (dims 4 apart), then g, then waves; the
 //     K halves of a matvec are added as part0 + part1.  A chain's results do not depend on its group or lane.
 //
-// The subtree stack (left p, right p, p_sum, proposal q, proposal gradient per level) keeps level 0 in registers,
-// levels 1..NLV in LDS and deeper levels in the context's global scratch.
+// The subtree stack (left p, right p, p_sum, proposal q, proposal gradient per level) keeps level 0 in registers, level 1
+// in LDS next to the tree's ends, proposal and p_sum, and deeper levels in the context's global scratch.
 //
 // FS (feature set): 1 = linear + quadratic configs with the bound; bit 1 (2) = decay penalty (density.py:740-746);
 // bit 2 (4) = constraint transform (density.py:92-140,747-750).
@@ -36,21 +36,36 @@
 
 #define BF_DBL_MAX 1.7976931348623157e308
 
+// tuning builds (tools/gvariant.sh -DBF_GTRACE=<n>): lane 0 of workgroup 0 stamps the cycle counter at up to 8 points
+// of each of its first n trips into a.stamps
+#if defined(BF_GTRACE) && !defined(BF_HOST_EMU)
+#define GTRACE(k) do { if (tid == 0 && bf_group() == 0 && a.stamps && trip_no < BF_GTRACE) a.stamps[trip_no * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GTRACE(k) do { } while (0)
+#endif
+
 template <int W>
 struct GroupGeo {
     static constexpr int DP = 16 * W, NS = 4 * W;
     static constexpr int KS = (W == 2 || W == 4) ? 2 : 1;  // K halves of a matvec (same association as the sliced kernel)
     static constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
-    static constexpr int NLV = 2;                            // stack levels 1..NLV in LDS
-    static constexpr int CS = DP + 2;                        // chain stride of an LDS vector (conflict-free b64 access)
     static constexpr int LSS = 4 * MAXL + 1;                 // chain stride of the stack scalars
-    // exchanged sums
+    // tree vectors in LDS, [slot][dimension][chain] (a wave's access covers 64 consecutive doubles): stack level 1
+    // (left p, right p, p_sum, proposal q, proposal gradient), both ends of the tree (q, p, grad), its proposal
+    // (q, grad) and its p_sum.  Deeper stack levels live in the context's global scratch.
+    static constexpr int T_STK1 = 0, T_LEFT = 5, T_RIGHT = 8, T_PROP = 11, T_PSUM = 13, NTV = 14;
+    // exchanged sums: evaluation, level-0 merge, merge levels 1..LSH, the doubling's checks in LDS; the merge levels
+    // above LSH (one leaf in 2^LSH reaches them) go through global scratch
+    static constexpr int LSH = 3;
     static constexpr int V_KIN = 0, V_VAL = 1, V_B2 = 2, V_DOTJ = 3, V_BD2 = 4, V_LOGDET = 5, V_KIN0 = 6, V_M0 = 7;
-    static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * (MAXL - 1), NVAL = V_EXT + 6;
+    static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * LSH, NVAL = V_EXT + 6;
+    static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);       // sums of the merge levels LSH+1 .. MAXL-1
     static constexpr size_t lds_doubles(int nmat) {
-        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NLV * 5 * 16 * CS + (size_t)16 * LSS;
+        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS;
     }
-    static constexpr int scratch_slots() { return 5 * (MAXL - NLV); }
+    // per-chain global scratch, in vectors of DP doubles: 5 per stack level 2 .. MAXL-1, then the deep sums
+    static constexpr int S_DEEP = 5 * (MAXL - 2);
+    static constexpr int scratch_slots() { return S_DEEP + (NDEEP * W + DP - 1) / DP; }
 };
 
 // constraint transform of one coordinate: transforms/_constraint.pyx:133-215 (to_original f, j, jj); same expressions
@@ -85,12 +100,11 @@ template <int W, bool NUTS, int FS>
 BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) {
     using G = GroupGeo<W>;
     constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0;
-    constexpr int DP = G::DP, NS = G::NS, KS = G::KS, MAXL = G::MAXL, NMAT = DEC ? 3 : 2, NLV = G::NLV, CS = G::CS,
-                  LSS = G::LSS;
+    constexpr int DP = G::DP, NS = G::NS, KS = G::KS, NMAT = DEC ? 3 : 2, LSS = G::LSS;
     double *XB = lds;                          // [NMAT][NS][64]  B operands: x | x - mu | x_orig - mu_decay
     double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
-    double *SV = RB + G::NVAL * W * 16;        // [NLV * 5][16][CS] subtree stack vectors, levels 1..NLV
-    double *LS = SV + NLV * 5 * 16 * CS;       // [16][LSS]       subtree stack scalars (one writer: wave 0)
+    double *TV = RB + G::NVAL * W * 16;        // [NTV][DP][16]   tree vectors
+    double *LS = TV + G::NTV * DP * 16;        // [16][LSS]       subtree stack scalars (one writer: wave 0)
 
     const int tid = bf_tid(), lane = tid & 63, j = tid >> 6, c = lane & 15, gq = lane >> 4;
     const int chain = bf_group() * 16 + c;
@@ -124,13 +138,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 
     // ---- per-chain state: vectors (4 elements per lane) ----
     double q[4], p[4], g[4], var[4];
-    double Lq[4], Lp[4], Lg[4], Rq[4], Rp[4], Rg[4];  // the tree's ends (nuts.py:24-43)
-    double PRq[4], PRg[4], PS[4];                     // the tree's proposal (position, gradient) and p_sum
     double L0p[4], L0q[4], L0g[4];                    // stack level 0: a single waiting leaf
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         q[r] = 0.; p[r] = 0.; g[r] = 0.; var[r] = 1.;
-        Lq[r] = Lp[r] = Lg[r] = Rq[r] = Rp[r] = Rg[r] = PRq[r] = PRg[r] = PS[r] = L0p[r] = L0q[r] = L0g[r] = 0.;
+        L0p[r] = L0q[r] = L0g[r] = 0.;
     }
     // ---- per-chain state: scalars (one copy per lane) ----
     uint64_t rs[4] = {0, 0, 0, 0};
@@ -139,6 +151,12 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     double eps = 0., eps_t = 0., start_energy = 0., acc_sum = 0.;
     double T_W = 0., T_acc = 0., T_E = 0., T_logp = 0.;
     double max_de = 0., w_off = 0., tree_W = 1., beta = 1.;
+    // an evaluation whose gradient depends on its own sums takes a further pass over the same point, M_FIN, with the
+    // scalars of the pass before: outside the bound (fin_oob: poly.py:496-503, after the pass at the projected point,
+    // M_OOB) and / or with the decay term active (fin_dec: density.py:744-746)
+    constexpr int M_FIN = 4;
+    bool fin_oob = false, fin_dec = false;
+    double coef2 = 0., logp_keep = 0.;
     double L0_W = 0., L0_acc = 0., L0_E = 0., L0_logp = 0.;
     double prop_E = 0., prop_logp = 0.;
     double h_acc = 0., h_de = 0., h_end_E = 0., h_end_logp = 0.;
@@ -152,7 +170,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
     double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
     double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + dbase;
-    double *svb = SV + c * CS + dbase;
+    double *tvb = TV + dbase * 16 + c;
+    double *rbg = a.scratch + ((size_t)(real ? chain : 0) * a.nslot + G::S_DEEP) * DP;  // this chain's deep sums [v][wave]
     double *lsc = LS + c * LSS;
 
     auto load_vec = [&](int field, double (&v)[4], double pad) {
@@ -169,25 +188,32 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             if (dim < d) vecp[field * d + dim] = v[r];
         }
     };
+    // tree vector `slot` in LDS (slot may differ from lane to lane)
+    auto tv_ld = [&](int slot, double (&v)[4]) {
+        const double *sp = tvb + slot * (DP * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sp[64 * r];
+    };
+    auto tv_st = [&](int slot, const double (&v)[4]) {
+        double *sp = tvb + slot * (DP * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp[64 * r] = v[r];
+    };
     // subtree stack vector k (0 left p, 1 right p, 2 p_sum, 3 proposal q, 4 proposal gradient) of level lev >= 1
     auto stk_ld = [&](int lev, int k, double (&v)[4]) {
-        if (lev <= NLV) {
-            const double *sp = svb + ((lev - 1) * 5 + k) * (16 * CS);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = sp[4 * r];
+        if (lev == 1) {
+            tv_ld(G::T_STK1 + k, v);
         } else {
-            const double *sp = sbase + (size_t)((lev - NLV - 1) * 5 + k) * DP;
+            const double *sp = sbase + (size_t)((lev - 2) * 5 + k) * DP;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = sp[4 * r];
         }
     };
     auto stk_st = [&](int lev, int k, const double (&v)[4]) {
-        if (lev <= NLV) {
-            double *sp = svb + ((lev - 1) * 5 + k) * (16 * CS);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sp[4 * r] = v[r];
+        if (lev == 1) {
+            tv_st(G::T_STK1 + k, v);
         } else {
-            double *sp = sbase + (size_t)((lev - NLV - 1) * 5 + k) * DP;
+            double *sp = sbase + (size_t)((lev - 2) * 5 + k) * DP;
 #pragma unroll
             for (int r = 0; r < 4; ++r) sp[4 * r] = v[r];
         }
@@ -195,33 +221,89 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     // sum over this lane's four dimensions, in the butterfly's association (dims 4 apart, then 8 apart)
     auto sum4 = [](const double (&v)[4]) -> double { return (v[0] + v[1]) + (v[2] + v[3]); };
     // sum over g (dims 1 apart, then 2 apart) and post this wave's partial: called by ALL lanes
-    bool post_on = true;  // second round: only the chains that take part overwrite their slots
     auto post = [&](int vi, double part) {
         const double t = bf_xor32_add(bf_xor16_add(part));
-        if (gq == 0 && post_on) RB[(vi * W + j) * 16 + c] = t;
+        if (gq == 0) RB[(vi * W + j) * 16 + c] = t;
+    };
+    // N sums posted together: the row swaps of the N values advance side by side, so each step's latency is covered by
+    // the other values' instructions (one wave per SIMD: nothing else hides it)
+    auto post_n = [&](int vi0, auto &part) {
+        constexpr int N = sizeof(part) / sizeof(double);
+#pragma unroll
+        for (int i = 0; i < N; ++i) part[i] = bf_xor16_add(part[i]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) part[i] = bf_xor32_add(part[i]);
+        if (gq == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) RB[((vi0 + i) * W + j) * 16 + c] = part[i];
+        }
+    };
+    // N group-wide sums read together (all loads in flight before the first add)
+    auto rd_n = [&](int vi0, auto &out) {
+        constexpr int N = sizeof(out) / sizeof(double);
+        double t[N][W];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) t[i][w2] = RB[((vi0 + i) * W + w2) * 16 + c];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if constexpr (W == 4) out[i] = (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+            else if constexpr (W == 2) out[i] = t[i][0] + t[i][1];
+            else out[i] = t[i][0];
+        }
     };
     // the group-wide sum: waves 16 dims apart, then 32 apart
-    auto rd = [&](int vi) -> double {
-        const double *rp = RB + (vi * W) * 16 + c;
-        if constexpr (W == 4) return (rp[0] + rp[16]) + (rp[32] + rp[48]);
-        else if constexpr (W == 2) return rp[0] + rp[16];
+    auto sumw = [](const double *rp, int st) -> double {
+        if constexpr (W == 4) return (rp[0] + rp[st]) + (rp[2 * st] + rp[3 * st]);
+        else if constexpr (W == 2) return rp[0] + rp[st];
         else return rp[0];
+    };
+    auto rd = [&](int vi) -> double { return sumw(RB + (vi * W) * 16 + c, 16); };
+    // sums of merge level lev >= 1, k = 0..5: LDS up to level LSH, this chain's global scratch above
+    auto post_lv = [&](int lev, int k, double part) {
+        if (lev <= G::LSH) {
+            post(G::V_LV + 6 * (lev - 1) + k, part);
+        } else {
+            const double t = bf_xor32_add(bf_xor16_add(part));
+            if (gq == 0 && real) rbg[(6 * (lev - 1 - G::LSH) + k) * W + j] = t;
+        }
+    };
+    auto rd_lv = [&](int lev, int k) -> double {
+        if (lev <= G::LSH) return rd(G::V_LV + 6 * (lev - 1) + k);
+        return sumw(rbg + (6 * (lev - 1 - G::LSH) + k) * W, 1);
     };
     // metric.random (samplers/hmc_utils/metrics.py:83-86): one xoshiro draw K keys a SplitMix64 counter stream; pair P
     // of the stream gives dimensions 2P (cos) and 2P+1 (sin) by Box-Muller -- the same numbers as the sliced kernel
-    auto draw_momentum = [&]() {
-        const uint64_t K = bf_xoshiro_next(rs);
+    // Dimensions d and d ^ 1 of a chain sit in lanes 16 apart (g and g ^ 1, same element r): the even-g lane runs the
+    // Box-Muller transform of the pairs of its elements 0 and 1, the odd-g lane of elements 2 and 3, and they trade the
+    // halves they do not use (called by all lanes: the exchange is a wave collective; `on` lanes take the result).
+    auto draw_momentum = [&](bool on) {
+        uint64_t K = 0;
+        if (on) K = bf_xoshiro_next(rs);
+        const int godd = gq & 1;
+        double mine[2], theirs[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int dim = dbase + 4 * r;
-            const uint64_t P = (uint64_t)(dim >> 1);
+        for (int h = 0; h < 2; ++h) {
+            const int r = 2 * godd + h;                       // the element whose pair this lane computes
+            const uint64_t P = (uint64_t)((dbase + 4 * r) >> 1);
             const double u1 = bf_u01_open0(bf_mix64(K + (2 * P + 1) * BF_GOLDEN));
             const double u2 = bf_u01(bf_mix64(K + (2 * P + 2) * BF_GOLDEN));
             const double rad = bf_sqrt(-2. * bf_log(u1));
             double sn, cs;
             bf_sincospi(2. * u2, &sn, &cs);
-            const double z = (dim & 1) ? rad * sn : rad * cs;
-            p[r] = (dim < d) ? (1. / bf_sqrt(var[r])) * z : 0.;
+            mine[h] = godd ? rad * sn : rad * cs;             // odd dimension: sin, even: cos
+            theirs[h] = godd ? rad * cs : rad * sn;
+        }
+        theirs[0] = bf_xor16_get(theirs[0]);
+        theirs[1] = bf_xor16_get(theirs[1]);
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // elements 2 godd, 2 godd + 1 are this lane's own pairs; the other two come from the partner
+                const double z = ((r >> 1) == godd) ? mine[r & 1] : theirs[r & 1];
+                p[r] = (dbase + 4 * r < d) ? (1. / bf_sqrt(var[r])) * z : 0.;
+            }
         }
     };
     // Tree.__init__ (nuts.py:24-43) at the current (q, p, g); the proposal is the starting point
@@ -233,12 +315,10 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         eps = (i_iter < nw) ? step_now : step_bar;  // step_size.py:25-29
         dir = 1;
         if (NUTS) dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Lq[r] = q[r]; Lp[r] = p[r]; Lg[r] = g[r];
-            Rq[r] = q[r]; Rp[r] = p[r]; Rg[r] = g[r];
-            PRq[r] = q[r]; PRg[r] = g[r]; PS[r] = p[r];
-        }
+        tv_st(G::T_LEFT + 0, q); tv_st(G::T_LEFT + 1, p); tv_st(G::T_LEFT + 2, g);
+        tv_st(G::T_RIGHT + 0, q); tv_st(G::T_RIGHT + 1, p); tv_st(G::T_RIGHT + 2, g);
+        tv_st(G::T_PROP + 0, q); tv_st(G::T_PROP + 1, g);
+        tv_st(G::T_PSUM, p);
         mode = M_LEAF;
     };
 
@@ -261,20 +341,22 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         err = (int)scp[BFHIP_SC_ERROR];
         load_vec(BFHIP_VEC_Q, q, 0.);
         load_vec(BFHIP_VEC_VAR, var, 1.);
-        if (i_iter < a.iter_end && err == 0) {
-            mode = M_INIT;
-            draw_momentum();
-        }
+        if (i_iter < a.iter_end && err == 0) mode = M_INIT;
     }
+    draw_momentum(mode == M_INIT);
 
+    int trip_no = -1;
+    (void)trip_no;
     for (;;) {
+        ++trip_no;
+        GTRACE(0);
         if (!bf_any(mode != M_DONE)) break;  // (every wave holds all 16 chains' state: the same decision in all of them)
 
         // ================= phase A: first half of the leapfrog step, B operands =================
         const bool ev = mode != M_DONE;
         double xs[4], xev[4], jac[4], gj[4], xo[4];
         double ldet[4] = {0., 0., 0., 0.};
-        if (ev && mode != M_OOB) {
+        if (ev && mode != M_OOB && mode != M_FIN) {
             eps_t = (mode == M_LEAF) ? eps * (double)dir : 0.;  // compute_state (base_hmc.py:70) is a step of length 0
             const double dt = 0.5 * eps_t;
 #pragma unroll
@@ -299,13 +381,15 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             xo[r] = xs[r];
             xev[r] = xs[r];
-            if (mode == M_OOB)  // second pass at the projected point, modules/poly.py:482
+            if (mode == M_OOB || (mode == M_FIN && fin_oob))  // passes at the projected point, modules/poly.py:482
                 xev[r] = (m.alpha * xs[r] + (beta - m.alpha) * c_mu[r]) / beta;
             XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
             XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
             if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
         }
+        GTRACE(1);
         bf_sync();  // B1
+        GTRACE(2);
 
         // ================= phase B: row tile j of S x, H (x - mu) (, H_decay^T (x - mu_decay)) on MFMA =================
         double sx[4], hv[4], dgr[4];
@@ -332,11 +416,12 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
         }
 
+        GTRACE(3);
         // ================= phase C: the evaluation's sums, and the U-turn sums of the leaf it completes =================
         double gn[4], ge[4], pn[4];
         const double dt_c = 0.5 * eps_t;
         {
-            double t_val[4], t_b2[4], t_dotj[4], t_bd2[4], t_kin[4];
+            double t_val[4], t_b2[4], t_bd2[4], t_kin[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 gn[r] = sx[r] + c_lin[r];
@@ -344,21 +429,28 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 t_val[r] = bf_fma(0.5 * xev[r], sx[r], c_lin[r] * xev[r]);
                 const double xm = xs[r] - c_mu[r];
                 t_b2[r] = xm * hv[r];
-                t_dotj[r] = gn[r] * xm;  // dot(jj_0, x - mu), poly.py:496 (second pass only)
                 t_bd2[r] = DEC ? (xo[r] - c_dmu[r]) * dgr[r] : 0.;
-                // inside the bound (and the decay ellipsoid) the gradient is already final: chain rule, transform term
-                // (module.py:226, density.py:558,747-750), second half of the step (integration.py:90) and the kinetic
-                // energy (metrics.py:88-91) ride along
+                // inside the bound (and the decay ellipsoid), and in a final pass, the gradient is complete: chain rule,
+                // transform term (module.py:226, density.py:558,747-750), second half of the step (integration.py:90)
+                // and the kinetic energy (metrics.py:88-91) ride along
                 double t = gn[r];
-                if constexpr (TR) t = t * jac[r] + gj[r];
+                if (mode == M_FIN && fin_oob) t = t + coef2 * (hv[r] / beta);  // poly.py:496-503
+                if constexpr (TR) t = t * jac[r];
+                if constexpr (DEC) { if (mode == M_FIN && fin_dec) t -= 2. * m.decay_gamma * dgr[r]; }
+                if constexpr (TR) t += gj[r];
                 ge[r] = t;
                 pn[r] = bf_fma(dt_c, ge[r], p[r]);
                 t_kin[r] = pn[r] * (var[r] * pn[r]);
             }
-            post(G::V_KIN, sum4(t_kin));
-            post(G::V_VAL, sum4(t_val));
-            post(G::V_B2, sum4(t_b2));
-            if (bf_any(mode == M_OOB)) post(G::V_DOTJ, sum4(t_dotj));
+            double e3[3] = {sum4(t_kin), sum4(t_val), sum4(t_b2)};
+            static_assert(G::V_KIN == 0 && G::V_VAL == 1 && G::V_B2 == 2, "posted as one batch");
+            post_n(G::V_KIN, e3);
+            if (bf_any(mode == M_OOB)) {
+                double t_dotj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t_dotj[r] = gn[r] * (xs[r] - c_mu[r]);  // dot(jj_0, x - mu), poly.py:496
+                post(G::V_DOTJ, sum4(t_dotj));
+            }
             if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
             if constexpr (TR) post(G::V_LOGDET, sum4(ldet));
             if (bf_any(need_E0)) post(G::V_KIN0, kin0_part);
@@ -367,6 +459,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // tTL / tTPs: the merged subtree's first momentum and p_sum; tPS: the tree's p_sum after the doubling.
         double tTL[4], tTPs[4], tPS[4];
         int nm = 0;  // number of merge levels: trailing one bits of i_leaf, at most depth
+        bool any_m0 = false, any_lv1 = false, any_ext = false;  // which groups of sums this trip carries (wave-uniform)
         auto uturn_sums = [&](bool act) {
             // act: this lane's chain takes part (all lanes run the collectives)
             nm = 0;
@@ -375,7 +468,10 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { tTL[r] = pn[r]; tTPs[r] = pn[r]; tPS[r] = 0.; }
-            if (bf_any(act && nm >= 1)) {  // level 0: the waiting leaf L0 and the new one (nuts.py:150-151; no sub-span checks)
+            any_m0 = bf_any(act && nm >= 1);
+            any_lv1 = bf_any(act && nm >= 2);
+            any_ext = bf_any(act && nm == depth);
+            if (any_m0) {  // level 0: the waiting leaf L0 and the new one (nuts.py:150-151; no sub-span checks)
                 double t0[4], t1[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -384,8 +480,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     t1[r] = ps0 * (var[r] * pn[r]);
                     if (act && nm >= 1) { tTPs[r] = ps0; tTL[r] = L0p[r]; }
                 }
-                post(G::V_M0 + 0, sum4(t0));
-                post(G::V_M0 + 1, sum4(t1));
+                double m2[2] = {sum4(t0), sum4(t1)};
+                post_n(G::V_M0, m2);
             }
             for (int lev = 1; bf_any(act && lev < nm); ++lev) {
                 const bool on = act && lev < nm;
@@ -402,11 +498,20 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     t[4][r] = ps2 * vB; t[5][r] = ps2 * vD;
                     if (on) { tTL[r] = A[r]; tTPs[r] = psum; }
                 }
+                if (lev <= G::LSH) {
+                    double s6[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) post(G::V_LV + 6 * (lev - 1) + k, sum4(t[k]));
+                    for (int k = 0; k < 6; ++k) s6[k] = sum4(t[k]);
+                    post_n(G::V_LV + 6 * (lev - 1), s6);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) post_lv(lev, k, sum4(t[k]));
+                }
             }
-            if (bf_any(act && nm == depth)) {  // the doubling completes: Tree.extend's checks, nuts.py:86-101
+            if (any_ext) {  // the doubling completes: Tree.extend's checks, nuts.py:86-101
                 const bool on = act && nm == depth;
+                double PS[4] = {0., 0., 0., 0.}, Lp[4] = {0., 0., 0., 0.}, Rp[4] = {0., 0., 0., 0.};
+                if (on) { tv_ld(G::T_PSUM, PS); tv_ld(G::T_LEFT + 1, Lp); tv_ld(G::T_RIGHT + 1, Rp); }
                 double t[6][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -425,92 +530,82 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     }
                     if (on) tPS[r] = ps;
                 }
+                double s6[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) post(G::V_EXT + k, sum4(t[k]));
+                for (int k = 0; k < 6; ++k) s6[k] = sum4(t[k]);
+                post_n(G::V_EXT, s6);
             }
         };
-        // first round: every chain that is finishing a leaf inside the bound (the common case)
-        const bool spec1 = NUTS && ev && mode == M_LEAF;
+        // every chain whose leaf this pass may complete
+        const bool spec1 = NUTS && ev && (mode == M_LEAF || (mode == M_FIN && prev_mode == M_LEAF));
+        GTRACE(4);
         if (NUTS) uturn_sums(spec1);
+        GTRACE(5);
         bf_sync();  // B2
+        GTRACE(6);
 
         // ================= the evaluation's scalars =================
-        bool fin = false, need2 = false;
-        double logp_new = 0., kin = 0., coef2 = 0.;
-        bool was_oob = false, dec_on = false;
+        // this trip's sums, fetched together (one LDS round trip instead of one per value)
+        double sv_e[3], sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
+        rd_n(G::V_KIN, sv_e);
+        const bool any_e0 = bf_any(need_E0);
+        if (any_e0) rd_n(G::V_KIN0, sv_k0);
+        if (any_m0) rd_n(G::V_M0, sv_m0);
+        if (any_lv1) rd_n(G::V_LV, sv_l1);
+        if (any_ext) rd_n(G::V_EXT, sv_x);
+        bool fin = false;
+        double logp_new = 0., kin = 0.;
         if (ev) {
-            const double r_val = rd(G::V_VAL), r_b2 = rd(G::V_B2);
-            double f = (m.c0 + r_val) + 0.;
-            if (mode == M_OOB) {
-                // second pass: f and gn hold f_0 and jj_0 at the projected point (poly.py:484-496)
-                const double r_dotj = rd(G::V_DOTJ);
-                const double f0 = f;
-                f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
-                coef2 = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
-                mode = prev_mode;
-                was_oob = true;
-                need2 = true;
+            if (mode == M_FIN) {
                 fin = true;
+                logp_new = logp_keep;
+                kin = sv_e[0];
+                mode = prev_mode;
             } else {
-                // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is decided
-                // on the squares whenever b2 is not within rounding distance of alpha^2
-                const double a2 = m.alpha * m.alpha;
-                double bt = 0.;
-                if (!(r_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(r_b2);
-                if (bt > m.alpha) {
-                    beta = bt;  // outside the alpha-ellipsoid: one more trip on the projected point x_0
-                    prev_mode = mode;
-                    mode = M_OOB;
+                const double r_val = sv_e[1], r_b2 = sv_e[2];
+                double f = (m.c0 + r_val) + 0.;
+                bool have_f = false;
+                if (mode == M_OOB) {
+                    // f holds f_0 at the projected point (poly.py:484-496)
+                    const double r_dotj = rd(G::V_DOTJ);
+                    const double f0 = f;
+                    f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
+                    coef2 = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
+                    have_f = true;
                 } else {
-                    fin = true;
+                    // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
+                    // decided on the squares whenever b2 is not within rounding distance of alpha^2
+                    const double a2 = m.alpha * m.alpha;
+                    double bt = 0.;
+                    if (!(r_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(r_b2);
+                    if (bt > m.alpha) {
+                        beta = bt;  // outside the alpha-ellipsoid: next pass at the projected point x_0
+                        prev_mode = mode;
+                        mode = M_OOB;
+                    } else {
+                        have_f = true;
+                    }
                 }
-            }
-            if (fin) {
-                if constexpr (DEC) {  // density.py:740-746
-                    const double r_bd2 = rd(G::V_BD2);
-                    const double ex = r_bd2 - m.decay_alpha2;
-                    f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
-                    if (r_bd2 > m.decay_alpha2) { dec_on = true; need2 = true; }
+                if (have_f) {
+                    fin_oob = mode == M_OOB;
+                    fin_dec = false;
+                    if constexpr (DEC) {  // density.py:740-746
+                        const double r_bd2 = rd(G::V_BD2);
+                        const double ex = r_bd2 - m.decay_alpha2;
+                        f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                        fin_dec = r_bd2 > m.decay_alpha2;
+                    }
+                    if constexpr (TR) f += rd(G::V_LOGDET);
+                    if (fin_oob || fin_dec) {
+                        if (!fin_oob) prev_mode = mode;
+                        logp_keep = f;
+                        mode = M_FIN;
+                    } else {
+                        fin = true;
+                        logp_new = f;
+                        kin = sv_e[0];
+                    }
                 }
-                if constexpr (TR) f += rd(G::V_LOGDET);
-                logp_new = f;
-                kin = rd(G::V_KIN);
-            }
-        }
-        // ---- second round (rare): the gradient depends on the sums (outside the bound, decay term active) ----
-        if (bf_any(need2)) {
-            if (need2) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double t = gn[r];
-                    if (was_oob) t = t + coef2 * (hv[r] / beta);  // poly.py:496-503
-                    if constexpr (TR) t = t * jac[r];
-                    if constexpr (DEC) { if (dec_on) t -= 2. * m.decay_gamma * dgr[r]; }
-                    if constexpr (TR) t += gj[r];
-                    ge[r] = t;
-                    pn[r] = bf_fma(dt_c, t, p[r]);
-                }
-            }
-            bf_sync();  // (the first round's sums of these chains have been read by every wave)
-            post_on = need2;
-            double t_kin[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t_kin[r] = pn[r] * (var[r] * pn[r]);
-            post(G::V_KIN, sum4(t_kin));
-            // (chains not in this round keep what the first round gave them)
-            double sTL[4], sTPs[4], sPS[4];
-            const int nm1 = nm;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sTL[r] = tTL[r]; sTPs[r] = tTPs[r]; sPS[r] = tPS[r]; }
-            const bool spec2 = NUTS && need2 && mode == M_LEAF;
-            if (NUTS) uturn_sums(spec2);
-            post_on = true;
-            bf_sync();
-            if (need2) kin = rd(G::V_KIN);
-            if (!spec2) {
-                nm = nm1;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { tTL[r] = sTL[r]; tTPs[r] = sTPs[r]; tPS[r] = sPS[r]; }
             }
         }
         double E_new = 0.;
@@ -521,13 +616,14 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
         // the start energy of an iteration that began at the end of the previous trip
         if (need_E0 && ev) {
-            const double E0 = 0.5 * rd(G::V_KIN0) - prop_logp;  // integration.py:28-34
+            const double E0 = 0.5 * sv_k0[0] - prop_logp;  // integration.py:28-34
             if (!(bf_fabs(E0) <= BF_DBL_MAX)) err = 1;           // base_hmc.py:72-76
             start_energy = E0;
             prop_E = E0;
             need_E0 = false;
         }
 
+        GTRACE(7);
         // ================= per-chain state machine =================
         enum { S_NONE, S_MERGE, S_ABORT, S_DBL_END, S_END };
         int st = S_NONE, lev = 0, src = -1;  // src: whose proposal the finished subtree holds (-1 this leaf, 0 L0, l stack level l)
@@ -582,8 +678,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     h_accepted = 0;
                     if (!diverged) h_accepted = !(bf_u01(bf_xoshiro_next(rs)) >= h_accept_stat);
                     if (h_accepted) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { PRq[r] = q[r]; PRg[r] = g[r]; }
+                        tv_st(G::T_PROP + 0, q);
+                        tv_st(G::T_PROP + 1, g);
                         prop_logp = logp_new;
                     }
                     h_de = h_dE;
@@ -607,7 +703,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 T_acc = pacc > 1. ? 1. : pacc;
                 if (nm >= 1) {
                     // ---- level-0 merge with the waiting leaf L0 (nuts.py:146-178) ----
-                    const double d0 = rd(G::V_M0 + 0), d1 = rd(G::V_M0 + 1);
+                    const double d0 = sv_m0[0], d1 = sv_m0[1];
                     T_acc = L0_acc + T_acc;  // :173
                     const double Wsum = L0_W + T_W;
                     if (Wsum != Wsum) err = 2;
@@ -624,8 +720,13 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 // ---- merge upwards while the finished subtree is a right child ----
                 while (st == S_MERGE && lev < nm) {
                     bool turning = false;
+                    if (lev == 1) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) turning = turning || (rd(G::V_LV + 6 * (lev - 1) + k) <= 0.);
+                        for (int k = 0; k < 6; ++k) turning = turning || (sv_l1[k] <= 0.);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) turning = turning || (rd_lv(lev, k) <= 0.);
+                    }
                     const double *lsp = lsc + lev * 4;
                     T_acc = lsp[LS_ACC] + T_acc;  // :173
                     const double Wsum = lsp[LS_LS] + T_W;
@@ -688,14 +789,17 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     const double u = bf_u01(bf_xoshiro_next(rs));
                     if ((u * tree_W < T_W) || (u == 0.)) {
                         if (src < 0) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { PRq[r] = q[r]; PRg[r] = g[r]; }
+                            tv_st(G::T_PROP + 0, q);
+                            tv_st(G::T_PROP + 1, g);
                         } else if (src == 0) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { PRq[r] = L0q[r]; PRg[r] = L0g[r]; }
+                            tv_st(G::T_PROP + 0, L0q);
+                            tv_st(G::T_PROP + 1, L0g);
                         } else {
-                            stk_ld(src, 3, PRq);
-                            stk_ld(src, 4, PRg);
+                            double tq[4], tg[4];
+                            stk_ld(src, 3, tq);
+                            stk_ld(src, 4, tg);
+                            tv_st(G::T_PROP + 0, tq);
+                            tv_st(G::T_PROP + 1, tg);
                         }
                         prop_E = T_E;
                         prop_logp = T_logp;
@@ -704,24 +808,19 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
                 bool turning = false;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) turning = turning || (rd(G::V_EXT + k) <= 0.);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    PS[r] = tPS[r];
-                    if (dir > 0) { Rq[r] = q[r]; Rp[r] = p[r]; Rg[r] = g[r]; }
-                    else { Lq[r] = q[r]; Lp[r] = p[r]; Lg[r] = g[r]; }
+                for (int k = 0; k < 6; ++k) turning = turning || (sv_x[k] <= 0.);
+                tv_st(G::T_PSUM, tPS);
+                {
+                    const int eo = (dir > 0) ? G::T_RIGHT : G::T_LEFT;
+                    tv_st(eo + 0, q); tv_st(eo + 1, p); tv_st(eo + 2, g);
                 }
                 if (turning || depth >= a.cfg.max_treedepth) {
                     st = S_END;
                 } else {
                     const int nd = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
                     if (nd != dir) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            q[r] = (nd > 0) ? Rq[r] : Lq[r];
-                            p[r] = (nd > 0) ? Rp[r] : Lp[r];
-                            g[r] = (nd > 0) ? Rg[r] : Lg[r];
-                        }
+                        const int eo = (nd > 0) ? G::T_RIGHT : G::T_LEFT;
+                        tv_ld(eo + 0, q); tv_ld(eo + 1, p); tv_ld(eo + 2, g);
                     }
                     dir = nd;
                     i_leaf = 0;
@@ -730,6 +829,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
         }
         // ================= iteration end: base_hmc.py:80-85 =================
+        bool new_iter = false;
         if (st == S_END && err == 0) {
             const bool warm = i_iter < nw;
             const double accept_stat = NUTS ? acc_sum / (double)n_prop : h_acc;  // nuts.py:186
@@ -744,8 +844,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 step_bar = bf_exp(log_bar);
             }
             // the proposal is the new sample and the start of the next iteration (value and gradient came with it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { q[r] = PRq[r]; g[r] = PRg[r]; }
+            tv_ld(G::T_PROP + 0, q);
+            tv_ld(G::T_PROP + 1, g);
             const int orow = i_iter - a.iter_out0;
             if (orow >= 0 && orow < a.n_out) {
                 if (writer) {
@@ -821,18 +921,20 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 store_vec(BFHIP_VEC_BG_RAW, br);
             }
             i_iter += 1;
-            if (i_iter < a.iter_end) {
-                // next iteration: metric.random, then the tree starts at (q, p) with the proposal's value and gradient;
-                // the start energy needs the kinetic energy of the new momentum: it joins the next trip's exchange
-                draw_momentum();
+            if (i_iter < a.iter_end) new_iter = true;
+            else mode = M_DONE;
+        }
+        if (bf_any(new_iter)) {
+            // next iteration: metric.random, then the tree starts at (q, p) with the proposal's value and gradient; the
+            // start energy needs the kinetic energy of the new momentum: it joins the next trip's exchange
+            draw_momentum(new_iter);
+            if (new_iter) {
                 tree_reset();
                 double t_k0[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t_k0[r] = p[r] * (var[r] * p[r]);  // metrics.py:88-91
                 kin0_part = sum4(t_k0);
                 need_E0 = true;
-            } else {
-                mode = M_DONE;
             }
         }
         if (err != 0) mode = M_DONE;

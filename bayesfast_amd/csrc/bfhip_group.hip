@@ -1,0 +1,74 @@
+// bfhip_group.hip -- device build and launch of the group sampler kernel (bfhip_group.h), gfx950.
+// Compiled with -ffp-contract=off: the arithmetic is spelled out in the header (explicit fma where one is meant), so
+// that a chain's numbers do not depend on what the optimiser fuses.
+#include "bfhip_common.h"
+#include "bfhip_group.h"
+
+template <int W, bool NUTS, int FS>
+__global__ __launch_bounds__(64 * W) void bf_group_kernel(DevModel m, SamplerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double bf_group_lds[];
+    bf_group_body<W, NUTS, FS>(m, a, bf_group_lds);
+}
+
+template <int W, bool NUTS, int FS>
+static int launch_t(bfhip_ctx *ctx, const SamplerArgs &args) {
+    auto k = bf_group_kernel<W, NUTS, FS>;
+    const size_t lds = GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
+    if (lds > 64 * 1024)
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int groups = (args.n_chain + 15) / 16;
+    hipLaunchKernelGGL(k, dim3(groups), dim3(64 * W), lds, ctx->stream, ctx->model, args);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <int W>
+static int launch_w(bfhip_ctx *ctx, const SamplerArgs &args, bool nuts, int fs) {
+#ifdef BF_ONLY_HEADLINE  // tuning builds (tools/gvariant.sh): the 64-d plain NUTS instantiation only
+    if (W == 4 && nuts && fs == 1) return launch_t<(W == 4 ? 4 : W), true, 1>(ctx, args);
+    return bf_set_error(BFHIP_ERR_UNSUPPORTED, "tuning build: headline instantiation only");
+#else
+    if (nuts) {
+        switch (fs) {
+        case 1: return launch_t<W, true, 1>(ctx, args);
+        case 3: return launch_t<W, true, 3>(ctx, args);
+        case 5: return launch_t<W, true, 5>(ctx, args);
+        case 7: return launch_t<W, true, 7>(ctx, args);
+        }
+    } else {
+        switch (fs) {
+        case 1: return launch_t<W, false, 1>(ctx, args);
+        case 3: return launch_t<W, false, 3>(ctx, args);
+        case 5: return launch_t<W, false, 5>(ctx, args);
+        case 7: return launch_t<W, false, 7>(ctx, args);
+        }
+    }
+    return bf_set_error(BFHIP_ERR_UNSUPPORTED, "group kernel: feature set %d", fs);
+#endif
+}
+
+bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {
+    return m.DP <= 64 && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !args.mat;
+}
+
+int bf_group_scratch_slots(int DP) { return 5 * (BFHIP_MAX_TREEDEPTH - 2); }
+
+// tuning hook (not part of include/bfhip.h): cycle stamps of workgroup 0's first trips, see GTRACE in bfhip_group.h
+static unsigned long long *g_gstamps = NULL;
+extern "C" void bfhip_debug_gstamps(unsigned long long *buf) { g_gstamps = buf; }
+
+int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args_in) {
+    SamplerArgs args = args_in;
+    args.stamps = g_gstamps;
+    const DevModel &m = ctx->model;
+    const bool nuts = args.cfg.sampler == 0;
+    const int fs = 1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0);
+    switch (m.DP / 16) {
+#ifndef BF_ONLY_HEADLINE
+    case 1: return launch_w<1>(ctx, args, nuts, fs);
+    case 2: return launch_w<2>(ctx, args, nuts, fs);
+#endif
+    case 4: return launch_w<4>(ctx, args, nuts, fs);
+    }
+    return bf_set_error(BFHIP_ERR_UNSUPPORTED, "group kernel: padded dimension %d", m.DP);
+}

@@ -35,6 +35,15 @@ BF_DEV double bf_xor32_add(double v) {
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
+// the value of lane l ^ 16.  v_permlane16_swap with both operands v leaves rows (0, 0, 2, 2) of v in the first result
+// and rows (1, 1, 3, 3) in the second: a lane of an even row finds its partner in the second, of an odd row in the first
+BF_DEV double bf_xor16_get(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const bool odd = (threadIdx.x >> 4) & 1;
+    return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
+}
 BF_DEV double bf_exp(double x) { return exp(x); }
 BF_DEV double bf_log(double x) { return log(x); }
 BF_DEV double bf_sqrt(double x) { return sqrt(x); }

@@ -1246,6 +1246,11 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args) {
     return 0;
 }
 
+// test / tuning hook: keep NUTS / HMC on the common surrogate off the group kernel (bfhip_group.hip), i.e. on the
+// kernels of this file (also selected by BFHIP_NUTS_KERNEL=sliced or =pipe)
+static bool g_no_group = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && (!strcmp(e, "sliced") || !strcmp(e, "pipe")); }();
+extern "C" void bfhip_debug_no_group(int v) { g_no_group = v != 0; }
+
 static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
@@ -1331,6 +1336,9 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     }
     args.scratch = (double *)ctx->scratch;
     const bool nuts = cfg->sampler == 0;
+    // the common surrogate (linear + quadratic configs with the bound; decay and constraint transform optional) at
+    // d <= 64 with the diagonal metric: the group kernel
+    if (!g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_group_supports(m, args)) return bf_launch_group(ctx, args);
     switch (W) {
 #ifndef BF_ONLY_HEADLINE  // tuning builds (tools/variant.sh) compile the 64-d instantiations only
     case 1: return nuts ? launch_sampler<1, true>(ctx, args) : launch_sampler<1, false>(ctx, args);

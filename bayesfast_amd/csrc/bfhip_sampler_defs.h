@@ -24,3 +24,8 @@ enum { LS_LS = 0, LS_E, LS_LOGP, LS_ACC, LS_N };
 enum { CS_LOG_STEP = 0, CS_LOG_BAR, CS_HBAR, CS_SMU, CS_COUNT, CS_PROP_E, CS_PROP_LOGP, CS_MAX_DE, CS_HACC, CS_HDE,
        CS_W_OFF, CS_TREE_W, CS_BETA, CS_T_E, CS_T_LOGP, CS_STEP_NOW, CS_STEP_BAR, CS_N };
 
+
+// bfhip_group.hip: NUTS / HMC for the common surrogate (optionally with decay / constraint transform) at d <= 64
+struct bfhip_ctx;
+bool bf_group_supports(const DevModel &m, const SamplerArgs &args);
+int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args);

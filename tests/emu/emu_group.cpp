@@ -131,6 +131,14 @@ double emu_xor_add(double v, int mask) {
     emu_barrier(E->wave[w], 64);
     return v + o;
 }
+double emu_xor_get(double v, int mask) {
+    const int w = E->cur >> 6, l = E->cur & 63;
+    E->xa[w][l] = v;
+    emu_barrier(E->wave[w], 64);
+    const double o = E->xa[w][l ^ mask];
+    emu_barrier(E->wave[w], 64);
+    return o;
+}
 bf_acc4 emu_mfma(double a, double b, bf_acc4 c) {
     const int w = E->cur >> 6, l = E->cur & 63;
     E->xa[w][l] = a;  // A[i = l & 15][k = l >> 4]

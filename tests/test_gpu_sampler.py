@@ -157,6 +157,7 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     kw = {'depth_limit': dict(max_treedepth=2), 'divergent': dict(max_change=5.)}.get(case, {})
     out = {}
     try:
+        _lib.lib().bfhip_debug_no_group(1)  # (the default dispatch is the group kernel, bfhip_group.hip)
         for sliced in (0, 1):
             _lib.lib().bfhip_debug_no_pipe(sliced)
             dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
@@ -165,6 +166,7 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
             out[sliced] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
     finally:
         _lib.lib().bfhip_debug_no_pipe(0)
+        _lib.lib().bfhip_debug_no_group(0)
     for a, b in zip(out[0][:-1], out[1][:-1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert out[0][-1] == out[1][-1] == int(out[0][1][:, :, _lib.NSTATS.index('tree_size')].sum() + out[0][3][:, :, _lib.NSTATS.index('tree_size')].sum())
