@@ -103,6 +103,13 @@ class DeviceChains:
             samples = self.ctx.empty((self.n_chain, n_run, self.d))
         if stats is None:
             stats = self.ctx.empty((self.n_chain, n_run, _lib.STAT_STRIDE))
+        # caller-supplied output buffers: the kernel writes n_chain * n_run rows with these strides, so anything else
+        # would be a silent out-of-bounds or garbled write
+        for name, t, shape in (('samples', samples, (self.n_chain, n_run, self.d)),
+                               ('stats', stats, (self.n_chain, n_run, _lib.STAT_STRIDE))):
+            if (tuple(t.shape) != shape or t.dtype != torch.float64 or t.device != self.ctx.device or
+                    not t.is_contiguous()):
+                raise ValueError('{} should be a contiguous float64 tensor of shape {} on {}.'.format(name, shape, self.ctx.device))
         step = max(1, int(launch_iters) if launch_iters else n_run)
         for done in range(step, n_run + step, step):  # iter_end of each launch; the output rows are relative to i_iter
             _lib.check(self.ctx._lib.bfhip_sampler_run(

@@ -9,31 +9,6 @@ from .. import parallel
 __all__ = ['sample']
 
 
-def _pinned_like(shape, dtype):
-    """Pinned host buffer or None (page-locking gigabytes takes a few 100 ms: sample() does it while the kernels run)."""
-    import torch
-    try:
-        return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
-    except RuntimeError:
-        return None
-
-
-def _to_host(t, h=None):
-    """Device tensor -> NumPy array through a pinned staging buffer (pageable copies run at a third of the PCIe rate)."""
-    import torch
-    if not t.is_cuda:
-        return t.numpy()
-    t = t.contiguous()
-    try:
-        if h is None or tuple(h.shape) != tuple(t.shape) or h.dtype != t.dtype:
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        h.copy_(t, non_blocking=True)
-        torch.cuda.current_stream(t.device).synchronize()
-        return h.numpy()
-    except RuntimeError:  # no pinned memory left: plain copy
-        return t.cpu().numpy()
-
-
 def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_backend=None, verbose=True,
            iters_per_launch=None):
     """Sample a surrogate density.
@@ -44,7 +19,8 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     n_run : number of iterations to run now (default: up to ``n_iter``)
     parallel_backend : accepted for signature compatibility and ignored; chains shard over the ranks of the
         default ``torch.distributed`` process group instead (one process per GPU)
-    Returns a ``TraceTuple`` holding ALL chains on every rank (one all-gather over RCCL when world_size > 1).
+    Returns a ``TraceTuple`` whose arrays stay on this rank's GPU (this rank's chains); its host views gather all chains
+    on first use, and the refit path (``bayesfast_amd.core.refit.select_fit_points``) exchanges only the selected rows.
     """
     import torch
     from ..chains import DeviceChains
@@ -94,13 +70,11 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
                               metric=trace._metric, initial_mean=trace._initial_mean,
                               initial_weight=trace._initial_weight, adapt_window=trace._adapt_window)
         done = 0
-        old_s = old_st = None
     else:
         chains = prev._chains
         if chains is None:
             raise ValueError('this TraceTuple cannot be continued on this rank.')
         done = prev.i_iter
-        old_s, old_st = prev._samples[b:e], prev._stats[b:e]
     if n_run is None:
         n_run = trace.n_iter - done
     n_run = int(n_run)
@@ -117,37 +91,24 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
         ss.append(s)
         sts.append(st)
         left -= k
-    # the host staging buffers are page-locked while the launches run
-    n_loc = ss[0].shape[0]
-    h_s = _pinned_like((n_loc if ws == 1 else trace.n_chain, n_run, d), torch.float64) if ss[0].is_cuda else None
-    h_st = _pinned_like((n_loc if ws == 1 else trace.n_chain, n_run, sts[0].shape[2]), torch.float64) if ss[0].is_cuda else None
     chains.raise_on_error()
     s = ss[0] if len(ss) == 1 else torch.cat(ss, 1)
     st = sts[0] if len(sts) == 1 else torch.cat(sts, 1)
-    # boundary conversions on device (core/sample.py:175-177), then ONE pass of device-to-host copies
+    # boundary conversions on the device (core/sample.py:175-177); nothing crosses to the host here
     s_orig = density.to_original_device(s)
     lp_orig = density.to_original_density_device(st[:, :, 0], s)
-    if ws > 1:
-        s_orig = s_orig if s_orig is s else parallel.all_gather_chains(s_orig, trace.n_chain)
-        lp_orig = parallel.all_gather_chains(lp_orig.contiguous(), trace.n_chain)
-        s = parallel.all_gather_chains(s, trace.n_chain)
-        st = parallel.all_gather_chains(st, trace.n_chain)
-        if density._input_scales is None:
-            s_orig = s
-    same = s_orig is s
-    s, st, lp_orig = _to_host(s, h_s), _to_host(st, h_st), _to_host(lp_orig)
-    s_orig = s if same else _to_host(s_orig)
     if prev is not None:
-        shared = same and prev._samples_original is prev._samples
-        if not shared:
-            s_orig = np.concatenate([prev._samples_original, s_orig], 1)
-        s = np.concatenate([prev._samples, s], 1)
-        if shared:
-            s_orig = s
-        st = np.concatenate([prev._stats, st], 1)
-        lp_orig = np.concatenate([prev._logp_original, lp_orig], 1)
-    if verbose and rank == 0:
-        nl = st[:, :, 3].sum() if trace._sampler == 'NUTS' else st[:, :, 2].sum()
-        print(' sampling finished [ {} / {} ], {} chains, {} leapfrog steps.'.format(s.shape[1], trace.n_iter,
-                                                                                     trace.n_chain, int(nl)))
+        p_s, p_so = prev.device('samples'), prev.device('samples_original')
+        shared = (s_orig is s) and (p_so is p_s)
+        s_new = torch.cat([chains.ctx.tensor(p_s), s], 1)
+        s_orig = s_new if shared else torch.cat([chains.ctx.tensor(p_so), s_orig], 1)
+        s = s_new
+        st = torch.cat([chains.ctx.tensor(prev.device('stats')), st], 1)
+        lp_orig = torch.cat([chains.ctx.tensor(prev.device('logp_original')), lp_orig], 1)
+    if verbose:
+        col = 3 if trace._sampler == 'NUTS' else 2
+        nl = parallel.all_reduce_sum(st[:, -n_run:, col].sum().reshape(1))
+        if rank == 0:
+            print(' sampling finished [ {} / {} ], {} chains, {} leapfrog steps.'.format(s.shape[1], trace.n_iter,
+                                                                                         trace.n_chain, int(nl.item())))
     return TraceTuple(trace, s, st, s_orig, lp_orig, chains)

@@ -6,8 +6,8 @@ and the least-squares fit run in libbfhip.so.  What differs from the reference, 
 * ``fit`` solves the normal equations (FP64-MFMA Gram + equilibrated Cholesky) instead of LAPACK gelsd,
   and factorises once for all outputs that share a set of configs (the reference rebuilds and
   re-factorises A for every output, modules/poly.py:529).
-* ``fun``/``jac``/``fun_and_jac`` are implemented on device for ``output_size == 1`` (the log-density
-  surrogate of the sampler path); multi-output evaluation is the next row of SURVEY.md section 8(f).
+* ``fun``/``jac``/``fun_and_jac`` run on the device: single-output surrogates (the log-density surrogate of the sampler
+  path) through ``bfhip_logp_grad``, multi-output modules through one ``bfhip_polymodel_eval`` launch.
 """
 import ctypes as C
 import warnings

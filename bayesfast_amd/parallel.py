@@ -7,7 +7,7 @@ chain index, so results do not depend on the number of ranks.  The refit needs e
 ONE all-gather per sampling round (RCCL over xGMI with backend "nccl"; gloo in the CPU tests)."""
 import numpy as np
 
-__all__ = ['world', 'shard_range', 'all_gather_chains', 'local_device']
+__all__ = ['world', 'shard_range', 'all_gather_chains', 'local_device', 'broadcast_int', 'all_reduce_sum']
 
 
 def world():
@@ -60,3 +60,30 @@ def all_gather_chains(t, n_chain):
     out = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(out, pad.contiguous())
     return torch.cat([o[:s] for o, s in zip(out, sizes)], 0)
+
+
+def broadcast_int(v, src=0):
+    """The value rank ``src`` holds, on every rank (a no-op without a process group)."""
+    rank, ws = world()
+    if ws == 1:
+        return int(v)
+    import torch
+    import torch.distributed as dist
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src)
+    return int(t.item())
+
+
+def all_reduce_sum(t):
+    """Sum of a tensor over the ranks, in place (a no-op without a process group)."""
+    rank, ws = world()
+    if ws > 1:
+        import torch.distributed as dist
+        if dist.get_backend() == 'gloo' and t.is_cuda:  # (plumbing tests: gloo moves host tensors)
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

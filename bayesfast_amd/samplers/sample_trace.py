@@ -88,13 +88,20 @@ class _HTrace:
             return None
 
     def seed(self):
-        """Integer seed of the per-chain xoshiro streams, from ``random_generator`` (None: OS entropy)."""
-        g = self.random_generator
-        if g is None:
-            return int(np.random.SeedSequence().generate_state(1, np.uint64)[0])
-        if isinstance(g, (int, np.integer)):
-            return int(g)
-        return int(np.random.default_rng(g).integers(0, 2**63 - 1))
+        """Integer seed of the per-chain xoshiro streams, from ``random_generator`` (None: OS entropy).  Resolved ONCE per
+        trace and, under ``torch.distributed``, taken from rank 0, so that every rank derives the same starting points
+        and stream keys from it (results do not depend on the number of ranks)."""
+        if getattr(self, '_seed', None) is None:
+            g = self.random_generator
+            if g is None:
+                v = int(np.random.SeedSequence().generate_state(1, np.uint64)[0] >> 1)
+            elif isinstance(g, (int, np.integer)):
+                v = int(g)
+            else:
+                v = int(np.random.default_rng(g).integers(0, 2**63 - 1))
+            from .. import parallel
+            self._seed = parallel.broadcast_int(v)
+        return self._seed
 
     def run_kwargs(self):
         kw = dict(n_warmup=self.n_warmup, max_change=self.max_change, target_accept=self._target_accept,
@@ -205,31 +212,87 @@ class ChainView:
 
 
 class TraceTuple:
-    """All chains of one ``sample`` call (samplers/sample_trace.py:631-801)."""
+    """All chains of one ``sample`` call (samplers/sample_trace.py:631-801).
+
+    The arrays stay where the sampler wrote them: on this rank's GPU, for this rank's chains.  The reference's array
+    views (``samples``, ``logp``, ``stats``, ``get`` ...) materialise them on the host on first use -- under
+    ``torch.distributed`` after an all-gather over the ranks, so every rank must then make the same call -- and are
+    cached.  The refit path does not need them: ``refit_shard`` hands the device-resident rows to
+    ``bayesfast_amd.core.refit.select_fit_points``, and the warm-start helpers reduce over the ranks on the device."""
+
+    _FIELDS = ('samples', 'stats', 'samples_original', 'logp_original')
 
     def __init__(self, trace, samples, stats, samples_original, logp_original, chains=None):
         self._trace = trace
         self.sampler = trace._sampler
-        self._samples = np.asarray(samples)
-        self._stats = np.asarray(stats)
         self._stat_items = _lib.NSTATS if self.sampler == 'NUTS' else _lib.HSTATS
-        self._samples_original = np.asarray(samples_original)
-        self._logp_original = np.asarray(logp_original)
-        self._chains = chains  # DeviceChains of this rank (None for a gathered result on another rank)
+        self._parts = dict(samples=samples, stats=stats, samples_original=samples_original, logp_original=logp_original)
+        self._host = {}
+        self._chains = chains  # DeviceChains of this rank
+
+    # ---- lazily materialised host arrays (all chains) ----
+    def _array(self, name):
+        if name not in self._host:
+            t = self._parts[name]
+            if not isinstance(t, np.ndarray):  # this rank's shard as a tensor
+                from .. import parallel
+                if parallel.world()[1] > 1:
+                    t = parallel.all_gather_chains(t.contiguous(), self._trace.n_chain)
+                t = t.cpu().numpy()
+            self._host[name] = np.asarray(t)
+        return self._host[name]
+
+    _samples = property(lambda self: self._array('samples'))
+    _stats = property(lambda self: self._array('stats'))
+    _logp_original = property(lambda self: self._array('logp_original'))
+
+    @property
+    def _samples_original(self):
+        if self._parts['samples_original'] is self._parts['samples']:
+            return self._samples
+        return self._array('samples_original')
+
+    def device(self, name):
+        """This rank's shard of one of ``samples``, ``stats``, ``samples_original``, ``logp_original`` as stored
+        (a device tensor after ``sample``; rows = this rank's chains)."""
+        return self._parts[name]
+
+    def _local_tensor(self, name):
+        import torch
+        t = self._parts[name]
+        return t if hasattr(t, 'is_cuda') else torch.as_tensor(np.asarray(t))
+
+    def n_refit_rows(self, since_iter=None):
+        since = self.n_warmup if since_iter is None else int(since_iter)
+        return self.n_chain * max(self.i_iter - since, 0)
+
+    def refit_shard(self, since_iter=None):
+        """(x (n_loc, d) original-space samples, logq (n_loc,), n_total): this rank's rows of what
+        ``get(flatten=True)`` / ``get(return_type='logp', flatten=True)`` return, in the same (chain-major) order."""
+        since = self.n_warmup if since_iter is None else int(since_iter)
+        x = self._local_tensor('samples_original')[:, since:]
+        lq = self._local_tensor('logp_original')[:, since:]
+        return x.reshape(-1, x.shape[-1]), lq.reshape(-1), self.n_refit_rows(since)
 
     sample_traces = property(lambda self: tuple(ChainView(self, i) for i in range(self.n_chain)))
-    n_chain = property(lambda self: self._samples.shape[0])
+    n_chain = property(lambda self: self._trace.n_chain)
     n_iter = property(lambda self: self._trace.n_iter)
-    i_iter = property(lambda self: self._samples.shape[1])
+    i_iter = property(lambda self: int(self._parts['samples'].shape[1]))
     n_warmup = property(lambda self: self._trace.n_warmup)
-    input_size = property(lambda self: self._samples.shape[-1])
+    input_size = property(lambda self: int(self._parts['samples'].shape[-1]))
     finished = property(lambda self: self.i_iter >= self.n_iter)
     samples = property(lambda self: self._samples)
     samples_original = property(lambda self: self._samples_original)
     logp = property(lambda self: self._stats[:, :, 0])
     logp_original = property(lambda self: self._logp_original)
     stats = property(lambda self: [t.stats for t in self.sample_traces])
-    n_call = property(lambda self: sum(t.n_call for t in self.sample_traces))
+
+    @property
+    def n_call(self):
+        st = self._stats
+        if self.sampler == 'NUTS':  # samplers/sample_trace.py:529-530, summed over chains
+            return int(st[:, 1:, self._stat_items.index('tree_size')].sum()) + self.n_chain * (self.i_iter + 1)
+        return self.n_chain * (self.i_iter * (self._trace.n_int_step + 1) + 1)  # :487-489
 
     def stat(self, name):
         """(n_chain, i_iter) array of one statistic by its reference name."""
@@ -264,26 +327,36 @@ class TraceTuple:
 
 
 def _get_step_size(sample_trace):
-    """Warm-start step size for the next round (samplers/sample_trace.py:804-817): exp(log_bar) * d^(1/4),
-    averaged over chains."""
+    """Warm-start step size for the next round (samplers/sample_trace.py:804-817): exp(log_bar) * d^(1/4), averaged
+    over ALL chains (summed on this rank's device, all-reduced over the ranks)."""
     if not isinstance(sample_trace, TraceTuple) or sample_trace._chains is None:
         raise ValueError('invalid value for sample_trace.')
-    lb = sample_trace._chains.field('log_bar').cpu().numpy()
-    return float(np.mean(np.exp(lb) * sample_trace.input_size**0.25))
+    from .. import parallel
+    lb = sample_trace._chains.field('log_bar')
+    tot = parallel.all_reduce_sum((lb.exp() * sample_trace.input_size**0.25).sum().reshape(1))
+    return float(tot.item()) / sample_trace.n_chain
 
 
 def _get_metric(sample_trace, target, from_samples=True):
-    """Warm-start metric (samplers/sample_trace.py:820-847)."""
+    """Warm-start metric (samplers/sample_trace.py:820-847): the covariance of the post-warm-up samples in the sampler's
+    space (two passes on the device: mean, then the centred Gram matrix, each all-reduced over the ranks), or the mean
+    of the chains' adapted covariances."""
     if not isinstance(sample_trace, TraceTuple):
         raise ValueError('invalid value for sample_trace.')
+    if target not in ('diag', 'full'):
+        raise ValueError('unexpected value for target.')
+    from .. import parallel
+    import torch
     if from_samples:
-        cov = np.cov(sample_trace.get(original_space=False, flatten=True), rowvar=False)
+        x = sample_trace._local_tensor('samples')[:, sample_trace.n_warmup:]
+        x = x.reshape(-1, x.shape[-1]).to(torch.float64)
+        n = sample_trace.n_refit_rows()
+        mean = parallel.all_reduce_sum(x.sum(0)) / n
+        xc = x - mean
+        cov = parallel.all_reduce_sum(xc.T @ xc) / (n - 1)  # np.cov(..., rowvar=False)
     else:
         if sample_trace._chains is None:
             raise ValueError('invalid value for sample_trace.')
-        cov = sample_trace._chains.covariance().cpu().numpy().mean(0)
-    if target == 'diag':
-        return np.diag(cov)
-    if target == 'full':
-        return cov
-    raise ValueError('unexpected value for target.')
+        cov = parallel.all_reduce_sum(sample_trace._chains.covariance().sum(0)) / sample_trace.n_chain
+    cov = cov.cpu().numpy()
+    return np.diag(cov) if target == 'diag' else cov

@@ -247,6 +247,27 @@ int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, co
  * r (P,m) by the solution.  info (1,) int32 device flag: 0 ok, k>0 pivot k not positive. */
 int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info);
 
+/* ------------------------------------------------------------------------------------------------
+ * Refit glue: the steps either side of the sampler inside Recipe._sam_step / _pos_step.
+ * ---------------------------------------------------------------------------------------------- */
+/* Stable ascending sort of a (n,) float64 by value, every NaN last (the order of np.argsort(a), utils/misc.py:108, with
+ * ties kept in index order): keys_sorted (n,) uint64 order-preserving keys, order (n,) int64 the permutation.
+ * SystematicResampler.run(a, m) is order[ranks] for the m ranks of its index pattern (utils/misc.py:92-100). */
+int bfhip_sort_keys(bfhip_ctx *ctx, long n, const double *a, uint64_t *keys_sorted, int64_t *order);
+
+/* keys (n,) uint64 of a (n,) float64, unsorted (the same mapping as bfhip_sort_keys). */
+int bfhip_order_keys(bfhip_ctx *ctx, long n, const double *a, uint64_t *keys);
+
+/* For a sorted shard keys_sorted (n,): counts[i] = number of keys < q[i] (upper = 0) or <= q[i] (upper = 1), q (nq,).
+ * The sharded form of the rank selection: ranks that share no data-path collective bisect on the key values and
+ * all-reduce these counts (bayesfast_amd/core/refit.py; SURVEY section 8e option ii). */
+int bfhip_count_keys(bfhip_ctx *ctx, long n, const uint64_t *keys_sorted, long nq, const uint64_t *q, int upper, int64_t *counts);
+
+/* PostStep's importance weights (core/recipe.py:1289-1296): w = exp(logp - logq), w_trunc = clip(w, 0, mean(w) n^k_trunc)
+ * (w_trunc = w for k_trunc < 0); all arrays (n,) float64 on the device. */
+int bfhip_importance_weights(bfhip_ctx *ctx, long n, const double *logp, const double *logq, double k_trunc, double *w,
+                             double *w_trunc);
+
 #ifdef __cplusplus
 }
 #endif

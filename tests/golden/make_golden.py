@@ -443,6 +443,47 @@ def gen_sampler_fullmetric(bf, out):
     np.savez_compressed(os.path.join(out, 'sampler_fullmetric.npz'), **z)
 
 
+def gen_refit(bf, out):
+    """Refit glue: SystematicResampler.run (utils/misc.py:61-108) on arrays with and without ties, for
+    several node / weight settings, and the truncated importance weights of PostStep (core/recipe.py:1289-1296)."""
+    from bayesfast.utils.misc import SystematicResampler
+    rng = np.random.default_rng(77)
+    z = {}
+    cases = [dict(m=5000, n=400, nodes=(1., 100.), weights=None),
+             dict(m=20011, n=2145, nodes=(1., 100.), weights=None),
+             dict(m=4096, n=333, nodes=(0., 50., 90., 100.), weights=(1., 2., 3.)),
+             dict(m=1000, n=1000, nodes=(0., 100.), weights=None),
+             dict(m=3000, n=7, nodes=(5., 25., 100.), weights=(0.2, 0.8))]
+    z['n_case'] = np.asarray(len(cases))
+    for i, c in enumerate(cases):
+        a = rng.normal(size=c['m']) * 3. - 40.
+        r = SystematicResampler(nodes=c['nodes'], weights=c['weights'])
+        idx = r.run(a, c['n'])
+        z['c%d.a' % i] = a
+        z['c%d.n' % i] = np.asarray(c['n'])
+        z['c%d.nodes' % i] = np.asarray(c['nodes'], dtype=np.float64)
+        z['c%d.weights' % i] = np.asarray(c['weights'] if c['weights'] is not None else [], dtype=np.float64)
+        z['c%d.idx' % i] = np.asarray(idx, dtype=np.int64)
+    # ties (repeated samples of a chain that stayed put): the selected VALUES are what is pinned
+    a = np.repeat(rng.normal(size=700), 3)[rng.permutation(2100)]
+    r = SystematicResampler(require_unique=False)
+    idx = r.run(a, 150)
+    z['ties.a'] = a
+    z['ties.n'] = np.asarray(150)
+    z['ties.values'] = a[idx]
+    # importance weights with truncation, recipe.py:1289-1296
+    logp = rng.normal(size=3000) * 2.
+    logq = logp + rng.normal(size=3000) * 0.7
+    for k_trunc in (0.25, -1.):
+        w = np.exp(logp - logq)
+        wt = w.copy() if k_trunc < 0 else np.clip(w, 0, np.mean(w) * w.size**k_trunc)
+        z['iw.k%g.w' % k_trunc] = w
+        z['iw.k%g.wt' % k_trunc] = wt
+    z['iw.logp'] = logp
+    z['iw.logq'] = logq
+    np.savez_compressed(os.path.join(out, 'refit.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -451,7 +492,7 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric)
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue

@@ -493,3 +493,35 @@ def test_compile_time_feature_sets_64d_match_oracle(ctx, samp, decay, bounds):
     dev = _device_chains(ctx, spec, x0, 14, 9)
     orc_runs = _oracle_chains(spec, x0, 14, 9)
     _compare_nuts(dev, orc_runs, 14, n_head=6, tol_head=1e-8)
+
+
+@pytest.mark.parametrize('order', ['linear', 'quadratic'])
+def test_config1_donut_shapes_2d_decay_no_bound(ctx, order):
+    """BASELINE config 1 (examples/2d-donut.ipynb): d = 2, 4 chains, the surrogate of the radius module is 'linear'
+    (OptimizeStep) and then 'quadratic' with use_bound=False, and the density carries the decay penalty
+    (use_decay=True, core/density.py:740-746).  Here the same kernel instantiation -- d = 2, no bound, decay on -- with
+    a surrogate log-density of that shape, NUTS and HMC against the oracle."""
+    from oracle import oracle as orc
+    d = 2
+    rng = np.random.default_rng(12)
+    xf = rng.normal(size=(40, d)) * 1.5 + np.array([0.3, -0.2])
+    cfgs = [dict(order='linear', input_mask=np.arange(d), output_mask=np.array([0]), coef=np.array([[-1.2, 0.4, -0.3]]))]
+    if order == 'quadratic':
+        A = np.zeros((1, d, d))
+        A[0, 0, 0], A[0, 0, 1], A[0, 1, 1] = -0.45, 0.12, -0.3   # only j <= k is read (modules/_poly.pyx:13-28)
+        cfgs.append(dict(order='quadratic', input_mask=np.arange(d), output_mask=np.array([0]), coef=A))
+    mu = xf.mean(0)
+    hess = np.linalg.inv(np.cov(xf, rowvar=False))
+    beta = np.einsum('ij,jk,ik->i', xf - mu, hess, xf - mu)**0.5
+    alpha = float(np.max(beta) * 1.5)                              # alpha_p = 150 (density.py:761-762,803-810)
+    spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None,
+                poly=dict(input_size=d, output_size=1, configs=cfgs, use_bound=False),
+                use_decay=True, decay_mu=mu, decay_hess=hess, decay_alpha2=alpha**2, decay_gamma=0.1)
+    x0 = rng.normal(size=(4, d))
+    dev = _device_chains(ctx, spec, x0, 40, 25)
+    orc_runs = _oracle_chains(spec, x0, 40, 25)
+    _compare_nuts(dev, orc_runs, 40)
+    s, st, dc = _device_chains(ctx, spec, x0, 20, 12, sampler='HMC', n_int_step=6)
+    for i, (so, sto, ch) in enumerate(_oracle_chains(spec, x0, 20, 12, sampler='HMC', n_int_step=6)):
+        assert np.array_equal(st['accepted'][i], sto['accepted'])
+        np.testing.assert_allclose(s[i][:8], so[:8], rtol=1e-9, atol=1e-9)
