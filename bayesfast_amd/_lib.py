@@ -39,7 +39,8 @@ class SamplerConfig(C.Structure):
     _fields_ = [('sampler', C.c_int), ('n_warmup', C.c_int), ('max_treedepth', C.c_int), ('n_int_step', C.c_int),
                 ('max_change', C.c_double), ('target_accept', C.c_double), ('gamma', C.c_double), ('k', C.c_double),
                 ('t_0', C.c_double), ('adapt_step_size', C.c_int), ('adapt_metric', C.c_int),
-                ('update_window', C.c_int), ('doubling', C.c_int), ('full_metric', C.c_int), ('metric_mat', C.c_void_p)]
+                ('update_window', C.c_int), ('doubling', C.c_int), ('full_metric', C.c_int), ('metric_mat', C.c_void_p),
+                ('chain_layout', C.c_int)]
 
 
 class PolymodelDesc(C.Structure):  # bfhip_polymodel_desc

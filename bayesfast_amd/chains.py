@@ -74,7 +74,7 @@ class DeviceChains:
 
     def run(self, n_run, sampler='NUTS', n_warmup=500, max_treedepth=10, n_int_step=32, max_change=1000.,
             target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,
-            update_window=1, doubling=True, samples=None, stats=None, check=True, launch_iters=250):
+            update_window=1, doubling=True, samples=None, stats=None, check=True, launch_iters=250, layout='auto'):
         """Advance every chain by ``n_run`` iterations, in kernel launches of at most ``launch_iters`` iterations
         (None: one launch) queued back to back on the context's stream.
 
@@ -82,6 +82,12 @@ class DeviceChains:
         trees differ drift apart inside a launch and every launch boundary lines them up again (measured on the
         default 1500-iteration run: 83 ms in one launch, 75 ms in launches of 250).  The cut does not change any
         chain's results.
+
+        ``layout`` chooses how a workgroup's 16 chains are laid out (``bfhip_sampler_config.chain_layout``): 'group' (lane
+        per chain: fastest while the chains of a workgroup stay in step), 'wave' (wave per chain: insensitive to chains
+        out of step) or 'auto': 'group' when at least 98 % of the NUTS trees of the previous run's last iterations had one
+        and the same size (static HMC: always), 'wave' otherwise and for the first run.  Both layouts follow the same
+        per-chain arithmetic and random streams; their floating-point sums are ordered differently.
 
         Returns (samples (n_chain, n_run, d), stats (n_chain, n_run, 11)) device tensors; the stats columns
         follow ``_lib.NSTATS`` / ``_lib.HSTATS`` (samplers/hmc_utils/stats.py:7-14)."""
@@ -98,6 +104,12 @@ class DeviceChains:
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
         cfg.full_metric = int(self.full_metric)
         cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
+        if layout not in ('auto', 'group', 'wave'):
+            raise ValueError("layout should be 'auto', 'group' or 'wave'.")
+        if layout == 'auto':
+            layout = 'group' if (sampler == 'HMC' or self._trees_in_step()) else 'wave'
+        cfg.chain_layout = {'group': 1, 'wave': 2}[layout]
+        self.last_layout = layout
         n_run = int(n_run)
         if samples is None:
             samples = self.ctx.empty((self.n_chain, n_run, self.d))
@@ -116,9 +128,22 @@ class DeviceChains:
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),
                 _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
         self.i_iter += n_run
+        self._last_stats = (stats, sampler)
         if check:
             self.raise_on_error()
         return samples, stats
+
+    def _trees_in_step(self, n_last=64, share=0.98):
+        """Did the chains run in step lately?  True when at least ``share`` of the NUTS trees in the last ``n_last``
+        iterations of the previous run (all chains) had the most common size.  (Reads the previous run's statistics: the
+        launches queued by that run are waited for.)"""
+        torch = _torch()
+        prev = getattr(self, '_last_stats', None)
+        if prev is None or prev[1] != 'NUTS' or prev[0].shape[1] == 0:
+            return False
+        ts = prev[0][:, -n_last:, _lib.NSTATS.index('tree_size')].reshape(-1)
+        hist = torch.bincount(ts.to(torch.int64).clamp_(0, 4096), minlength=2)  # (a histogram pass; sorting is 0.5 ms)
+        return bool((hist.max() >= share * ts.numel()).item())
 
     def raise_on_error(self):
         """Synchronises; raises like the reference does for a chain that hit a fatal condition."""

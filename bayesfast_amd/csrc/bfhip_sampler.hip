@@ -33,6 +33,7 @@
 // surrogate) or generic; FULLM (full-rank metric, bfhip_metric.h); STAMPS (diagnostic phase counters).
 #include <type_traits>
 #include <cstring>
+#include <cstdio>
 #include <cstdlib>
 #include "bfhip_eval.h"
 #include "bfhip_metric.h"
@@ -1251,6 +1252,10 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args) {
 static bool g_no_group = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && (!strcmp(e, "sliced") || !strcmp(e, "pipe")); }();
 extern "C" void bfhip_debug_no_group(int v) { g_no_group = v != 0; }
 
+// measurement hook (not part of include/bfhip.h): the kernel the last bfhip_sampler_run dispatched to
+static char g_last_kernel[96] = "";
+extern "C" const char *bfhip_debug_last_kernel(void) { return g_last_kernel; }
+
 static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
@@ -1338,7 +1343,15 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     const bool nuts = cfg->sampler == 0;
     // the common surrogate (linear + quadratic configs with the bound; decay and constraint transform optional) at
     // d <= 64 with the diagonal metric: the group kernel
-    if (!g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_group_supports(m, args)) return bf_launch_group(ctx, args);
+    if (cfg->chain_layout < 0 || cfg->chain_layout > 2) return bf_set_error(BFHIP_ERR_ARG, "chain_layout should be 0, 1 or 2");
+    const bool want_group = cfg->chain_layout == 1 || (cfg->chain_layout == 0 && !nuts);
+    if (want_group && !g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_group_supports(m, args)) {
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_group_kernel<%d, %s, %d>", W, nuts ? "true" : "false",
+                 1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0));
+        return bf_launch_group(ctx, args);
+    }
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>",
+             (nuts && W <= 4 && !g_no_pipe && !args.mat && sampler_plain(m)) ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
     switch (W) {
 #ifndef BF_ONLY_HEADLINE  // tuning builds (tools/variant.sh) compile the 64-d instantiations only
     case 1: return nuts ? launch_sampler<1, true>(ctx, args) : launch_sampler<1, false>(ctx, args);

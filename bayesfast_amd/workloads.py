@@ -19,7 +19,7 @@ def flops_per_leapfrog(d, use_bound=True):
     return (4 if use_bound else 2) * d * d
 
 
-def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7, fit_scale=1.5):
+def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7, fit_scale=1.5, scales=None):
     """Config-2 family of SURVEY.md section 8(d) at dimension d: target logp = -x^T P x / 2 with P = L L^T,
     L = I + 0.3 tril(G, -1) / sqrt(d), G ~ N(0, 1) from default_rng(seed).
 
@@ -39,12 +39,17 @@ def correlated_gaussian_spec(d=64, seed=123, n_fit_mult=2, fit_seed=7, fit_scale
     rng = np.random.default_rng(seed)
     L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
     P = L @ L.T
+    if scales is not None:  # x_i -> x_i / s_i: standard deviations spread by the given factors (anisotropic target)
+        sinv = 1. / np.asarray(scales, dtype=np.float64)
+        P = P * np.outer(sinv, sinv)
     A = -0.5 * P
     quad = np.zeros((d, d))
     iu = np.triu_indices(d)
     quad[iu] = A[iu] * np.where(iu[0] == iu[1], 1., 2.)
     n_param = 1 + d + d * (d + 1) // 2
     x = fit_scale * np.random.default_rng(fit_seed).normal(size=(n_fit_mult * n_param, d))
+    if scales is not None:
+        x = x * np.asarray(scales, dtype=np.float64)
     mu = np.mean(x, axis=0)
     hess = np.linalg.inv(np.atleast_2d(np.cov(x, rowvar=False)))
     beta = np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5

@@ -50,9 +50,108 @@ def cpu_baseline(spec, d, n_warm_iter, seed, target_seconds=15.):
         model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
     except Exception:
         model = 'unknown'
-    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': n_thr, 'kind': 'port',
+    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': physical_cores(n_thr), 'threads': n_thr, 'kind': 'port',
             'sample': '%d chains x %d post-warm-up NUTS iterations (%d leapfrogs in %.1f s) of the same 64-d workload, '
                       'one chain per OpenMP thread, %s' % (n_chain, n_it, nl, dt, model)}
+
+
+def physical_cores(default):
+    """Physical cores of the host (distinct (package, core id) pairs of /proc/cpuinfo); the baseline runs one chain per
+    hardware THREAD, which is reported separately."""
+    try:
+        seen, pkg = set(), None
+        for l in open('/proc/cpuinfo'):
+            if l.startswith('physical id'):
+                pkg = l.split(':')[1].strip()
+            elif l.startswith('core id'):
+                seen.add((pkg, l.split(':')[1].strip()))
+        return len(seen) or default
+    except Exception:
+        return default
+
+
+def hetero_rate(ctx, d, C, seed, iters, steps=3):
+    """Secondary figure: the same surrogate family on a target whose trees differ from chain to chain and from iteration
+    to iteration (per-dimension scales spread over a decade, identity metric kept fixed: tree sizes 7 .. 63 side by side
+    in one workgroup), so that the 16 chains of a group do NOT run in step.  Post-adaptation launches, HIP events."""
+    import torch
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    spec, _ = correlated_gaussian_spec(d, scales=np.logspace(-0.5, 0.5, d))
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(seed + 1).normal(size=(C, d))
+    ch = DeviceChains(dens, x0, seed=seed + 1)
+    kw = dict(n_warmup=N_ADAPT, check=False, adapt_metric=False, target_accept=0.9)
+    ch.run(N_ADAPT, 'NUTS', **kw)
+    s = ctx.empty((C, iters, d))
+    st = ctx.empty((C, iters, _lib.STAT_STRIDE))
+    ch.run(iters, 'NUTS', samples=s, stats=st, **kw)
+    ch.raise_on_error()
+    lf0 = ch.total_leapfrog
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(ctx.stream)
+    for _ in range(steps):
+        ch.run(iters, 'NUTS', samples=s, stats=st, **kw)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    ch.raise_on_error()
+    ts = st[:, :, _lib.NSTATS.index('tree_size')].cpu().numpy()
+    sizes, counts = np.unique(ts, return_counts=True)
+    return {'value': (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), 'unit': 'leapfrog steps/sec',
+            'mean_tree_size': float(ts.mean()),
+            'tree_size_share': {str(int(k)): round(float(v) / ts.size, 4) for k, v in zip(sizes, counts)},
+            'workload': '%d chains x %d-d Gaussian with per-dimension scales 10^-0.5 .. 10^0.5, identity metric '
+                        '(adapt_metric off), target_accept 0.9, %d x %d post-adaptation iterations' % (C, d, steps, iters)}
+
+
+def refit_cycle(d, cov, C, seed):
+    """One refit cycle end to end through the package API (BASELINE config 3's shape: sample -> choose 2P points by
+    logq -> true logp -> fit -> sample), wall-clock per stage.  The true model is the exactly quadratic target evaluated
+    on the host; the banana of config 3 is a parity case (its quadratic surrogate is indefinite)."""
+    import torch
+    import bayesfast_amd as bfa
+    from bayesfast_amd.core.refit import select_fit_points
+    prec = np.linalg.inv(cov)
+
+    def logp_true(x):
+        return -0.5 * np.einsum('ij,jk,ik->i', x, prec, x)
+
+    # the extrapolation bound at 150 % of the largest Mahalanobis radius of the fit points (PolyModel bound_options,
+    # modules/poly.py:232-260): refitted on points drawn FROM the posterior, an ellipsoid through the outermost fit point
+    # (alpha_p = 100) cuts into the posterior's own tail in 64 dimensions, and the linear extrapolation outside lets
+    # chains leak out (DESIGN.md section 5)
+    su = bfa.PolyModel('quadratic', input_size=d, output_size=1, bound_options=dict(alpha_p=150.))
+    dens = bfa.SurrogateDensity(su)
+    n_eval = 2 * su.n_param
+    x = 1.5 * np.random.default_rng(seed).normal(size=(n_eval, d))
+    t = {}
+
+    def timed(name, f):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = f()
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) * 1e3
+        return r
+
+    timed('fit_0_ms', lambda: dens.fit(x, logp_true(x)))
+    kw = dict(n_chain=C, n_iter=1500, n_warmup=500, random_generator=seed)
+    bfa.sample(dens, dict(kw, n_iter=40, n_warmup=20), verbose=False)  # allocator warm-up, untimed
+    t0 = time.perf_counter()
+    tt = timed('sample_0_ms', lambda: bfa.sample(dens, dict(kw), verbose=False))
+    xf, lf, n_true = timed('select_and_true_logp_ms', lambda: select_fit_points(tt, None, logp_true, n_eval, logp_cutoff=False))
+    timed('fit_1_ms', lambda: dens.fit(xf, lf))
+    tt2 = timed('sample_1_ms', lambda: bfa.sample(dens, dict(kw), verbose=False))
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) * 1e3
+    var_ratio = float(np.mean(tt2.device('samples')[:, 500:].reshape(-1, d).var(0).cpu().numpy() / np.diag(cov)))
+    return dict(t, total_ms=total, n_fit_points=int(xf.shape[0]), n_param=int(su.n_param),
+                chains=C, iterations_per_round=1500, posterior_variance_ratio_after_refit=var_ratio,
+                note='sample_0 -> select (device sort of %d logq values, %d rows to the host) -> true logp on the host -> '
+                     'fit_1 -> sample_1; total excludes fit_0' % (C * 1000, int(xf.shape[0])))
 
 
 def fit_timing(d, cov, seed=7):
@@ -91,6 +190,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help="process-group backend: 'nccl' (= RCCL; default) or 'gloo' (plumbing tests)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fit', action='store_true', help='skip the (untimed, separately reported) surrogate fit')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary figures (hetero workload, refit cycle)')
     a = ap.parse_args()
 
     import torch
@@ -155,6 +255,9 @@ def main():
         n_lf = chains.total_leapfrog - lf0
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if a.steps else 0.
         st_last = stats.cpu().numpy()
+        kname = _lib.lib().bfhip_debug_last_kernel
+        kname.restype = __import__('ctypes').c_char_p
+        kernel_name = kname().decode()
 
         red_dev = ctx.device if (dist is None or a.backend == 'nccl') else torch.device('cpu')
         tot = torch.tensor([float(n_lf)], dtype=torch.float64, device=red_dev)
@@ -172,17 +275,19 @@ def main():
         bytes_alg = B_STEP_BYTES(d) * lf_per_launch
         ach_tf = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms else 0.
         peak_tf = 78.6  # FP64 MFMA, 256 CUs x 4 SIMDs x 2.4 GHz x 2048 flop / 64 cyc; 77.7 measured (profiles/r01_probe_mfma_f64.log)
+        # HBM-side bytes per launch: a STORED profile value (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
+        # profiles/hbm_traffic.json), used only when it was taken on this kernel at this dimension
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not os.environ.get('BFHIP_LIBRARY'):
             try:
                 tj = json.load(open(tpath))
-                if tj.get('dim') == d:
+                if tj.get('dim') == d and tj.get('kernel') == kernel_name:
                     traffic = tj['hbm_bytes_per_leapfrog'] * lf_per_launch
             except Exception:
                 traffic = None
         out = {
-            'metric': 'leapfrog steps/sec (all chains), 4096 chains x 64-d quadratic surrogate',
+            'metric': 'leapfrog steps/sec (all chains), %d chains x %d-d quadratic surrogate' % (C, d),
             'value': value, 'unit': 'leapfrog steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': elapsed_max / max(a.steps, 1) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -195,7 +300,8 @@ def main():
                        'parallelism': 'chains sharded over %d rank(s), no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'achieved': ach_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': ach_tf / peak_tf, 'traffic': traffic,
-                         'kernel': 'bf_nuts_pipe_kernel<4, false>', 'kernel_ms_per_launch': kernel_ms,
+                         'kernel': kernel_name, 'kernel_ms_per_launch': kernel_ms,
+                         'traffic_source': None if traffic is None else 'stored profile (profiles/hbm_traffic.json), not this run',
                          'flops_per_leapfrog': flops_per_leapfrog(d, use_bound)},
             'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
                                          'peak': 8000., 'unit': 'GB/s',
@@ -208,6 +314,13 @@ def main():
                     out['fit'] = fit_timing(d, cov)
             except Exception as ex:  # the fit is a side measurement; the headline line must still print
                 out['fit'] = {'error': repr(ex)}
+        if not a.no_extras and world == 1:
+            try:
+                with torch.cuda.device(ctx.device):
+                    out['hetero'] = hetero_rate(ctx, d, C, a.seed, a.iters)
+                    out['refit_cycle'] = refit_cycle(d, cov, C, a.seed)
+            except Exception as ex:  # side measurements; the headline line must still print
+                out['extras_error'] = repr(ex)
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, d, n_warm_iter, a.seed)
         elif not a.no_cpu_baseline:

@@ -129,6 +129,15 @@ typedef struct {
      * fixed (QuadMetricFull) and the adaptive (QuadMetricFullAdapt) variant exactly as for the diagonal metric. */
     int full_metric;
     double *metric_mat;
+    /* How the chains of a 16-chain workgroup are laid out (common surrogate at d <= 64, diagonal metric; ignored elsewhere).
+     * 1 = lane per chain (bfhip_group.hip): one instruction advances the scalar logic of all 16 chains; fastest while the
+     *     chains of a workgroup stay in step (every tree the same size), slow when they do not, because every trip then
+     *     executes the union of the chains' paths.
+     * 2 = wave per chain (bfhip_sampler.hip: pipelined / sliced kernels): each chain follows its own path; insensitive to
+     *     chains out of step.
+     * 0 = library default: 2 for NUTS, 1 for HMC (whose chains are always in step).  bayesfast_amd.chains.DeviceChains
+     *     chooses 1 or 2 per run from the tree sizes of the previous run. */
+    int chain_layout;
 } bfhip_sampler_config;
 
 /* matrices per chain for the full-rank metric (layout documented in bayesfast_amd/csrc/bfhip_metric.h; slot

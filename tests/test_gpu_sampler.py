@@ -46,6 +46,17 @@ def _oracle_chains(spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, *
     return out
 
 
+_LAYOUT = {'v': 'group'}
+
+
+@pytest.fixture(autouse=True, params=['group', 'wave'])
+def _both_layouts(request):
+    """Every test of this module runs on both chain layouts of the sampler (lane per chain: bfhip_group.hip; wave per
+    chain: bf_nuts_pipe_kernel / bf_sampler_kernel)."""
+    _LAYOUT['v'] = request.param
+    yield
+
+
 def _device_chains(ctx, spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, split=None, **kw):
     from bayesfast_amd.device import DeviceDensity
     from bayesfast_amd.chains import DeviceChains
@@ -53,6 +64,7 @@ def _device_chains(ctx, spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream
     dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=SEED, first_stream=first_stream,
                       step_size=kw.get('step_size', 1.))
     run_kw = {k: v for k, v in kw.items() if k in ('max_treedepth', 'max_change', 'n_int_step', 'target_accept')}
+    run_kw['layout'] = _LAYOUT['v']
     if split is None:
         s, st = dc.run(n_iter, sampler, n_warmup=n_warmup, **run_kw)
     else:  # two launches: the state arrays carry the chains across (resume)
@@ -127,7 +139,7 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
         for tm in (0, 4):
             _lib.lib().bfhip_debug_tail_max(tm)
             dc = DeviceChains(dens, x0, seed=5)
-            s, st = dc.run(40, 'NUTS', n_warmup=20)
+            s, st = dc.run(40, 'NUTS', n_warmup=20, layout='wave')
             out[tm] = (s.cpu().numpy(), st.cpu().numpy())
     finally:
         _lib.lib().bfhip_debug_tail_max(4)
@@ -161,8 +173,8 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
         for sliced in (0, 1):
             _lib.lib().bfhip_debug_no_pipe(sliced)
             dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
-            s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw)
-            s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw)   # resume: the second launch starts from the stored state
+            s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw, layout='wave')
+            s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw, layout='wave')   # resume: the second launch starts from the stored state
             out[sliced] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
     finally:
         _lib.lib().bfhip_debug_no_pipe(0)
@@ -190,7 +202,7 @@ def test_launch_cuts_do_not_change_results(ctx):
     out = []
     for li in (None, 7, 250):
         dc = DeviceChains(dens, x0, seed=3)
-        s, st = dc.run(50, 'NUTS', n_warmup=30, launch_iters=li)
+        s, st = dc.run(50, 'NUTS', n_warmup=30, launch_iters=li, layout=_LAYOUT['v'])
         out.append((s.cpu().numpy(), st.cpu().numpy(), dc.sc.cpu().numpy(), dc.total_leapfrog))
     for o in out[1:]:
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1], equal_nan=True)
@@ -303,7 +315,7 @@ def test_headline_size_properties(ctx):
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(5).normal(size=(C, d))
     dc = DeviceChains(dens, x0, seed=17)
-    s, st = dc.run(n_it, 'NUTS', n_warmup=n_w)
+    s, st = dc.run(n_it, 'NUTS', n_warmup=n_w, layout=_LAYOUT['v'])
     ts = st[:, :, _lib.NSTATS.index('tree_size')]
     assert dc.total_leapfrog == int(ts.sum().item())
     assert float(st[:, n_w:, _lib.NSTATS.index('diverging')].sum().item()) == 0.
@@ -319,8 +331,8 @@ def test_headline_size_properties(ctx):
     # shards and launch cuts
     dc_a = DeviceChains(dens, x0[:C // 2], seed=17, first_stream=0)
     dc_b = DeviceChains(dens, x0[C // 2:], seed=17, first_stream=C // 2)
-    sa, _ = dc_a.run(60, 'NUTS', n_warmup=n_w, launch_iters=25)
-    sb, _ = dc_b.run(60, 'NUTS', n_warmup=n_w, launch_iters=None)
+    sa, _ = dc_a.run(60, 'NUTS', n_warmup=n_w, launch_iters=25, layout=_LAYOUT['v'])
+    sb, _ = dc_b.run(60, 'NUTS', n_warmup=n_w, launch_iters=None, layout=_LAYOUT['v'])
     assert np.array_equal(sa.cpu().numpy(), s[:C // 2, :60].cpu().numpy())
     assert np.array_equal(sb.cpu().numpy(), s[C // 2:, :60].cpu().numpy())
 
@@ -438,7 +450,7 @@ def test_odd_shapes_match_oracle(ctx, d):
         x0 = np.random.default_rng(d * 1000 + C).normal(size=(C, d)) * 0.7
         for smp in ('NUTS', 'HMC'):
             dc = DeviceChains(dens, x0, seed=9)
-            s, st = dc.run(12, smp, n_warmup=8, n_int_step=6)
+            s, st = dc.run(12, smp, n_warmup=8, n_int_step=6, layout=_LAYOUT['v'])
             s, st = s.cpu().numpy(), st.cpu().numpy()
             for i in sorted(set((0, C - 1))):
                 ch = orc.Chain(x0[i])
@@ -468,7 +480,7 @@ def test_bounded_parameters_small_dims_match_oracle(ctx, d):
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(d).normal(size=(17, d)) * 0.3
     dc = DeviceChains(dens, x0, seed=4)
-    s, st = dc.run(14, 'NUTS', n_warmup=9)
+    s, st = dc.run(14, 'NUTS', n_warmup=9, layout=_LAYOUT['v'])
     s, st = s.cpu().numpy(), st.cpu().numpy()
     for i in (0, 8, 16):
         so, sto = orc.nuts_run(spec, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=4, stream=i), 14, 9)

@@ -9,15 +9,17 @@ from bayesfast_amd.workloads import correlated_gaussian_spec
 from bayesfast_amd import _lib
 N = int(os.environ.get("NTRACE", 64))
 ctx = get_context(0)
-spec, _ = correlated_gaussian_spec(64)
+HET = int(os.environ.get('HETERO', 0))
+spec, _ = correlated_gaussian_spec(64, scales=np.logspace(-0.5, 0.5, 64) if HET else None)
+RKW = dict(adapt_metric=False, target_accept=0.9) if HET else {}
 C_ = int(os.environ.get('CHAINS', 4096))
 dc = DeviceChains(DeviceDensity(spec, ctx), np.random.default_rng(1).normal(size=(C_, 64)), seed=1)
-dc.run(800, 'NUTS', n_warmup=750)
+dc.run(800, 'NUTS', n_warmup=750, **RKW)
 buf = torch.zeros((N * 8,), dtype=torch.int64, device='cuda')
 L = _lib.lib()
 L.bfhip_debug_gstamps.argtypes = [C.c_void_p]
 L.bfhip_debug_gstamps(C.c_void_p(buf.data_ptr()))
-dc.run(20, 'NUTS', n_warmup=750)
+dc.run(20, 'NUTS', n_warmup=750, **RKW)
 L.bfhip_debug_gstamps(None)
 t = buf.cpu().numpy().reshape(N, 8).astype(np.int64)
 print('points: 1 phase A done | 2 after B1 | 3 MFMAs + tile sums | 4 eval sums posted | 5 U-turn sums posted | 6 after B2 | 7 eval scalars | (next 0) state machine')
