@@ -12,6 +12,8 @@ from .core.sample import sample
 from .samplers import NTrace, HTrace, TraceTuple
 from .utils import SystematicResampler
 from .core.refit import select_fit_points, importance_weights
+from .transforms import SIT
+from .evidence import GBS, bridge
 
 __all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'sample', 'NTrace', 'HTrace', 'TraceTuple',
-           'SystematicResampler', 'select_fit_points', 'importance_weights']
+           'SystematicResampler', 'select_fit_points', 'importance_weights', 'SIT', 'GBS', 'bridge']

@@ -128,22 +128,38 @@ class DeviceChains:
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),
                 _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
         self.i_iter += n_run
-        self._last_stats = (stats, sampler)
+        self._note_trees(stats, sampler)
         if check:
             self.raise_on_error()
         return samples, stats
 
-    def _trees_in_step(self, n_last=64, share=0.98):
-        """Did the chains run in step lately?  True when at least ``share`` of the NUTS trees in the last ``n_last``
-        iterations of the previous run (all chains) had the most common size.  (Reads the previous run's statistics: the
-        launches queued by that run are waited for.)"""
+    def _note_trees(self, stats, sampler, n_last=64, share=0.98):
+        """Queue, behind the launches of this run, the answer to "did the chains run in step?": at least ``share`` of the
+        NUTS trees of the last ``n_last`` iterations (all chains) had the most common size.  The flag travels to pinned
+        host memory asynchronously; nothing waits for it."""
         torch = _torch()
-        prev = getattr(self, '_last_stats', None)
-        if prev is None or prev[1] != 'NUTS' or prev[0].shape[1] == 0:
-            return False
-        ts = prev[0][:, -n_last:, _lib.NSTATS.index('tree_size')].reshape(-1)
-        hist = torch.bincount(ts.to(torch.int64).clamp_(0, 4096), minlength=2)  # (a histogram pass; sorting is 0.5 ms)
-        return bool((hist.max() >= share * ts.numel()).item())
+        if sampler != 'NUTS' or stats.shape[1] == 0 or not stats.is_cuda:
+            self._step_flag = None
+            return
+        ts = stats[:, -n_last:, _lib.NSTATS.index('tree_size')].reshape(-1)
+        hist = torch.bincount(ts.to(torch.int64).clamp_(0, 4096), minlength=2)  # (a histogram pass; a sort takes 0.5 ms)
+        flag = (hist.max() >= share * ts.numel()).to(torch.int32).reshape(1)
+        if getattr(self, '_step_host', None) is None:
+            self._step_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        with torch.cuda.stream(self.ctx.stream):
+            self._step_host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.ctx.stream)
+        self._step_flag = ev
+
+    def _trees_in_step(self):
+        """The most recent answer of ``_note_trees`` that has arrived (False before the first one): the decision for a
+        run lags the statistics by at most one run when runs are queued back to back, and never stalls the stream."""
+        ev = getattr(self, '_step_flag', None)
+        if ev is not None and ev.query():
+            self._in_step = bool(int(self._step_host[0]))
+            self._step_flag = None
+        return getattr(self, '_in_step', False)
 
     def raise_on_error(self):
         """Synchronises; raises like the reference does for a chain that hit a fatal condition."""

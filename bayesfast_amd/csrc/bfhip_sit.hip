@@ -1,0 +1,248 @@
+// bfhip_sit.hip -- data-parallel pieces of the evidence path: Gaussianized bridge sampling =
+// SIT (transforms/sit.py:223-459) + bridge (evidence/bridge.py:10-76).
+//
+//   bfhip_kde_cdf        1-d weighted Gaussian KDE cdf of every dimension at a set of points (utils/kde.py:322-354);
+//                        the Gaussianizing map of SIT._gaussianize_1d is norm.ppf of it at the spline knots
+//   bfhip_spline_apply   evaluate / derivative / solve of the per-dimension piecewise cubics (utils/_cubic.pyx:188-336)
+//                        for a batch of points: SIT.forward_transform / backward_transform / logq
+//   bfhip_bridge_sums    the two log-sum-exp terms of the bridge estimator's score function (evidence/bridge.py:44-49)
+//   bfhip_bridge_terms   the per-sample terms f1, f2 of its error estimate (:52-57)
+//
+// HBM-/ALU-bound elementwise and reduction work in float64; every reduction has a fixed order (per-block partial sums
+// combined by one thread), so results do not depend on the launch.
+#include <cmath>
+#include "bfhip_common.h"
+
+static int ensure_ws(bfhip_ctx *ctx, size_t need) {
+    if (ctx->scratch_bytes >= need) return 0;
+    BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) BF_HIP_CHECK(hipFree(ctx->scratch));
+    ctx->scratch = NULL;
+    ctx->scratch_bytes = 0;
+    BF_HIP_CHECK(hipMalloc(&ctx->scratch, need));
+    ctx->scratch_bytes = need;
+    return 0;
+}
+
+// ---- KDE cdf -----------------------------------------------------------------------------------------------------
+// out[j][i] = sum_k w[k] ndtr((pts[j][i] - data[j][k]) / h[j]);  data (d, n), pts (d, m): one row per dimension.
+// grid (point tiles, data splits, d); a thread keeps KP points in registers and strides over its split of the data.
+#define KDE_KP 8
+#define KDE_TH 256
+__global__ __launch_bounds__(KDE_TH) void bf_kde_cdf_kernel(int n, int m, const double *__restrict__ data, const double *__restrict__ w,
+                                                           const double *__restrict__ h, const double *__restrict__ pts, int n_split,
+                                                           double *__restrict__ partial) {
+    const int j = blockIdx.z, sp = blockIdx.y, i0 = blockIdx.x * KDE_KP;
+    const double inv = 0.70710678118654752440 / h[j];  // ndtr(z) = erfc(-z / sqrt 2) / 2
+    const double *dj = data + (size_t)j * n;
+    double p[KDE_KP], acc[KDE_KP];
+#pragma unroll
+    for (int t = 0; t < KDE_KP; ++t) {
+        p[t] = (i0 + t < m) ? pts[(size_t)j * m + i0 + t] : 0.;
+        acc[t] = 0.;
+    }
+    const long per = ((long)n + n_split - 1) / n_split, k0 = (long)sp * per, k1 = (k0 + per < n) ? k0 + per : n;
+    for (long k = k0 + threadIdx.x; k < k1; k += KDE_TH) {
+        const double xk = dj[k], wk = 0.5 * w[k];
+#pragma unroll
+        for (int t = 0; t < KDE_KP; ++t) acc[t] += wk * erfc((xk - p[t]) * inv);
+    }
+    __shared__ double red[KDE_TH];
+#pragma unroll
+    for (int t = 0; t < KDE_KP; ++t) {
+        red[threadIdx.x] = acc[t];
+        __syncthreads();
+        for (int o = KDE_TH / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && i0 + t < m) partial[((size_t)j * n_split + sp) * m + i0 + t] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ void bf_kde_combine_kernel(int d, int m, int n_split, const double *__restrict__ partial, double *__restrict__ out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)d * m) return;
+    const int j = (int)(e / m), i = (int)(e % m);
+    double s = 0.;
+    for (int sp = 0; sp < n_split; ++sp) s += partial[((size_t)j * n_split + sp) * m + i];
+    out[e] = s;
+}
+
+extern "C" int bfhip_kde_cdf(bfhip_ctx *ctx, int d, long n, const double *data, const double *w, const double *h, int m,
+                             const double *pts, double *out) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || d < 1 || n < 1 || m < 0 || !data || !w || !h || (m > 0 && (!pts || !out)) || n > 0x7fffffffL)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_kde_cdf: invalid argument");
+    if (m == 0) return 0;
+    const int tiles = (m + KDE_KP - 1) / KDE_KP;
+    int n_split = (int)((n + 16383) / 16384);
+    const int want = (4 * ctx->n_cu + tiles * d - 1) / (tiles * d);  // enough workgroups to fill the chip
+    if (n_split > want) n_split = want;
+    if (n_split < 1) n_split = 1;
+    if (int rc = ensure_ws(ctx, (size_t)d * n_split * m * sizeof(double))) return rc;
+    double *partial = (double *)ctx->scratch;
+    hipLaunchKernelGGL(bf_kde_cdf_kernel, dim3(tiles, n_split, d), dim3(KDE_TH), 0, ctx->stream, (int)n, m, data, w, h, pts, n_split,
+                       partial);
+    hipLaunchKernelGGL(bf_kde_combine_kernel, dim3((unsigned)(((long)d * m + 255) / 256)), dim3(256), 0, ctx->stream, d, m, n_split,
+                       partial, out);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- piecewise cubics ----------------------------------------------------------------------------------------------
+// Dimension j owns knots x[off[j] .. off[j+1]) (m_j of them), their values y, and m_j + 1 rows of coefficients
+// c[(off[j] + j + r) * 4 + 0..3] (highest order first; row 0 and row m_j are the linear extrapolations), exactly the
+// arrays of utils/cubic.py:cubic_spline (_x, _y, _c).
+
+// utils/_cubic.pyx:24-96: interval with x[i-1] <= v < x[i]; 0 below x[0], m at or above x[m-1], -1 for NaN
+__device__ inline int bf_find_interval(const double *x, int m, double v) {
+    if (!(v >= x[0] && v < x[m - 1])) return (v < x[0]) ? 0 : ((v >= x[m - 1]) ? m : -1);
+    int lo = 1, hi = m - 1;  // answer in [1, m-1]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v < x[mid]) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ inline double bf_cubic_val(const double *c, double x) { return c[0] * x * x * x + c[1] * x * x + c[2] * x + c[3]; }
+__device__ inline double bf_cubic_der(const double *c, double x) { return 3 * c[0] * x * x + 2 * c[1] * x + c[2]; }
+
+// mode 0 evaluate (_cubic.pyx:188-231), 1 derivative (:237-279), 2 solve (:285-331, bisection :131-163)
+__global__ void bf_spline_apply_kernel(int mode, long n, int d, const double *__restrict__ x, const int *__restrict__ off,
+                                       const double *__restrict__ xk, const double *__restrict__ yk, const double *__restrict__ ck,
+                                       double *__restrict__ out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * d) return;
+    const int j = (int)(e % d);
+    const int o = off[j], m = off[j + 1] - o;
+    const double *xj = xk + o, *yj = yk + o, *cj = ck + (size_t)(o + j) * 4;
+    const double v = x[e];
+    const int iv = bf_find_interval(mode == 2 ? yj : xj, m, v);
+    double r = NAN;
+    if (mode == 0) {
+        if (iv > 0 && iv < m) r = bf_cubic_val(cj + 4 * iv, v - xj[iv - 1]);
+        else if (iv == 0) r = cj[2] * (v - xj[0]) + cj[3];
+        else if (iv == m) r = cj[4 * m + 2] * (v - xj[m - 1]) + cj[4 * m + 3];
+    } else if (mode == 1) {
+        if (iv > 0 && iv < m) r = bf_cubic_der(cj + 4 * iv, v - xj[iv - 1]);
+        else if (iv == 0) r = cj[2];
+        else if (iv == m) r = cj[4 * m + 2];
+    } else {
+        if (iv > 0 && iv < m) {
+            const double *c = cj + 4 * iv;
+            double a = 0., b = xj[iv] - xj[iv - 1], t = (a + b) / 2, f = bf_cubic_val(c, t) - v;
+            int it = 0;
+            while (!(f < 1e-10 && f > -1e-10)) {
+                if (f > 0) b = t;
+                else a = t;
+                t = (a + b) / 2;
+                f = bf_cubic_val(c, t) - v;
+                if (++it >= 100) { t = NAN; break; }
+            }
+            r = xj[iv - 1] + t;
+        } else if (iv == 0) {
+            r = xj[0] + (v - cj[3]) / cj[2];
+        } else if (iv == m) {
+            r = xj[m - 1] + (v - cj[4 * m + 3]) / cj[4 * m + 2];
+        }
+    }
+    out[e] = r;
+}
+
+extern "C" int bfhip_spline_apply(bfhip_ctx *ctx, int mode, long n, int d, const double *x, const int *knot_off, const double *knots,
+                                  const double *values, const double *coef, double *out) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || mode < 0 || mode > 2 || n < 0 || d < 1 || !knot_off || !knots || !values || !coef || (n > 0 && (!x || !out)))
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_spline_apply: invalid argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bf_spline_apply_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, ctx->stream, mode, n, d, x, knot_off,
+                       knots, values, coef, out);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- bridge sampling ---------------------------------------------------------------------------------------------
+// log sum_i exp(t_i),  t_i = (s + a_i) - logaddexp(s + a_i, 0)  (evidence/bridge.py:45-48 with s = logr or -logr)
+__device__ inline double bf_log_sigmoid(double x) {  // x - logaddexp(x, 0) = -softplus(-x)
+    return (x < 0.) ? x - log1p(exp(x)) : -log1p(exp(-x));
+}
+__global__ __launch_bounds__(256) void bf_lse_sig_kernel(long n, const double *__restrict__ a, double s, double *__restrict__ part) {
+    __shared__ double rm[256], rs[256];
+    double mx = -INFINITY, sm = 0.;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double t = bf_log_sigmoid(s + a[i]);
+        if (t > mx) { sm = sm * exp(mx - t) + 1.; mx = t; }  // (mx = -inf: exp(-inf) = 0)
+        else if (t > -INFINITY) sm += exp(t - mx);
+        else if (t != t) sm = NAN;                            // NaN propagates through the sums
+    }
+    rm[threadIdx.x] = mx;
+    rs[threadIdx.x] = sm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double m1 = rm[threadIdx.x], m2 = rm[threadIdx.x + o], s1 = rs[threadIdx.x], s2 = rs[threadIdx.x + o];
+            const double mm = m1 > m2 ? m1 : m2;
+            rs[threadIdx.x] = (mm == -INFINITY) ? s1 + s2 : s1 * exp(m1 - mm) + s2 * exp(m2 - mm);
+            rm[threadIdx.x] = mm;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = rm[0]; part[2 * blockIdx.x + 1] = rs[0]; }
+}
+__global__ void bf_lse_combine_kernel(int nb_a, int nb_b, const double *__restrict__ part, double *__restrict__ out) {
+    if (threadIdx.x >= 2 || blockIdx.x != 0) return;
+    const double *p = part + (threadIdx.x == 0 ? 0 : 2 * nb_a);
+    const int nb = threadIdx.x == 0 ? nb_a : nb_b;
+    double mx = -INFINITY;
+    for (int i = 0; i < nb; ++i)
+        if (p[2 * i] > mx) mx = p[2 * i];
+    double s = 0.;
+    for (int i = 0; i < nb; ++i) s += (p[2 * i] == -INFINITY) ? p[2 * i + 1] : p[2 * i + 1] * exp(p[2 * i] - mx);
+    out[threadIdx.x] = mx + log(s);
+}
+
+extern "C" int bfhip_bridge_sums(bfhip_ctx *ctx, long n_a, const double *a, long n_b, const double *b, double logr, double *out2) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || n_a < 1 || n_b < 1 || !a || !b || !out2) return bf_set_error(BFHIP_ERR_ARG, "bfhip_bridge_sums: invalid argument");
+    const int nb_a = (int)((n_a + 255) / 256 < 512 ? (n_a + 255) / 256 : 512), nb_b = (int)((n_b + 255) / 256 < 512 ? (n_b + 255) / 256 : 512);
+    if (int rc = ensure_ws(ctx, (size_t)2 * (nb_a + nb_b) * sizeof(double))) return rc;
+    double *part = (double *)ctx->scratch;
+    hipLaunchKernelGGL(bf_lse_sig_kernel, dim3(nb_a), dim3(256), 0, ctx->stream, n_a, a, logr, part);
+    hipLaunchKernelGGL(bf_lse_sig_kernel, dim3(nb_b), dim3(256), 0, ctx->stream, n_b, b, -logr, part + 2 * nb_a);
+    hipLaunchKernelGGL(bf_lse_combine_kernel, dim3(1), dim3(64), 0, ctx->stream, nb_a, nb_b, part, out2);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// numpy.logaddexp
+__device__ inline double bf_lae(double x, double y) {
+    if (x == y) return x + 0.6931471805599453094;
+    const double t = x - y;
+    if (t > 0) return x + log1p(exp(-t));
+    if (t <= 0) return y + log1p(exp(t));
+    return t;
+}
+// evidence/bridge.py:52-57: f1 over the q samples, f2 over the p samples
+__global__ void bf_bridge_terms_kernel(long n_p, const double *__restrict__ lpp, const double *__restrict__ lqp, long n_q,
+                                       const double *__restrict__ lpq, const double *__restrict__ lqq, double logr, double *__restrict__ f1,
+                                       double *__restrict__ f2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double lp = log((double)n_p / (double)(n_p + n_q)), lq = log((double)n_q / (double)(n_p + n_q));
+    if (i < n_q) f1[i] = exp(lpq[i] - logr - bf_lae(lpq[i] - logr + lp, lqq[i] + lq));
+    if (i < n_p) f2[i] = exp(lqp[i] - bf_lae(lpp[i] - logr + lp, lqp[i] + lq));
+}
+
+extern "C" int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const double *logq_p, long n_q, const double *logp_q,
+                                  const double *logq_q, double logr, double *f1, double *f2) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || n_p < 1 || n_q < 1 || !logp_p || !logq_p || !logp_q || !logq_q || !f1 || !f2)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_bridge_terms: invalid argument");
+    const long nmax = n_p > n_q ? n_p : n_q;
+    hipLaunchKernelGGL(bf_bridge_terms_kernel, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, ctx->stream, n_p, logp_p, logq_p, n_q,
+                       logp_q, logq_q, logr, f1, f2);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}

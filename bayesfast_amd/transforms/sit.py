@@ -1,0 +1,251 @@
+"""Sliced Iterative Transform: the generative model of Gaussianized bridge sampling (bayesfast/transforms/sit.py).
+
+Each iteration rotates the data with FastICA and then Gaussianizes every rotated coordinate by a monotone map
+``norm.ppf(KDE cdf)`` represented as a piecewise cubic (transforms/sit.py:223-255,305-321).  What runs where:
+
+* FastICA (scikit-learn, as in the reference) and the construction of the ~100-knot splines: host;
+* the KDE cdf at the knots -- an (n_data x n_knot) reduction per coordinate, the dominant cost of ``fit`` --
+  ``bfhip_kde_cdf``; the rotations of the whole data set: device matmuls; applying the d splines to all points
+  (``fit``'s update of the data, ``forward_transform`` / ``logq``, ``backward_transform`` / ``sample``):
+  ``bfhip_spline_apply``.  The data stay on the GPU between iterations.
+
+Differences from the reference, on purpose: ``mvn_generator`` defaults to NumPy normals (the reference's Sobol generator
+is outside this build's scope); there is no plotting."""
+import warnings
+
+import numpy as np
+
+from ..utils.spline import GaussianizingSpline, SplineTable
+
+__all__ = ['SIT']
+
+
+def _default_mvn(rng):
+    def gen(mean, cov, size):
+        a, w = np.linalg.eigh(np.atleast_2d(cov))
+        return np.atleast_1d(mean) + (rng.normal(size=(int(size), len(a))) * a**0.5) @ w.T
+    return gen
+
+
+class SIT:
+    """Same constructor arguments as the reference where they apply (transforms/sit.py:60-75)."""
+
+    def __init__(self, n_iter=10, parallel_backend=None, bw_factor=1., m_ica=20000, random_generator=None, m_plot=8,
+                 cubic_options=None, ica_options=None, mvn_generator=None):
+        try:
+            self.n_iter = int(n_iter)
+            assert self.n_iter > 0
+        except Exception:
+            raise ValueError('n_iter should be a positive int.')
+        try:
+            self.bw_factor = float(bw_factor)
+            assert self.bw_factor > 0
+        except Exception:
+            raise ValueError('bw_factor should be a positive float.')
+        try:
+            self.m_ica = int(m_ica)
+            assert self.m_ica > 0
+        except Exception:
+            raise ValueError('m_ica should be a positive int.')
+        self.random_generator = np.random.default_rng(random_generator)
+        self.cubic_options = dict(cubic_options or {})
+        self.ica_options = dict(ica_options if ica_options is not None else {'max_iter': 100})
+        if mvn_generator is not None and not callable(mvn_generator):
+            raise ValueError('invalid value for mvn_generator.')
+        self.mvn_generator = mvn_generator or _default_mvn(self.random_generator)
+        self._data = None
+        self._tables = []
+        self._A = self._B = self._m = self._logdetA = None
+
+    @classmethod
+    def _from_parts(cls, A, B, m, logdetA, splines):
+        """A fitted model from its arrays: rotations (n_iter, d, d), means (n_iter, d), log|det A| (n_iter,) and, per
+        iteration and coordinate, the (knots, values, coefficient rows) of the Gaussianizing spline."""
+        import torch
+
+        class _S:
+            def __init__(self, x, y, c):
+                self.x, self.y, self.c = np.asarray(x), np.asarray(y), np.asarray(c)
+
+        self = cls(n_iter=len(splines))
+        ctx = self._ctx()
+        self._A, self._B, self._m = np.asarray(A), np.asarray(B), np.asarray(m)
+        self._logdetA = np.asarray(logdetA)
+        self._tables = [SplineTable([_S(*t) for t in it], ctx) for it in splines]
+        self._data = torch.zeros((1, self._A.shape[-1]), dtype=torch.float64, device=ctx.device)
+        self._weights = np.ones(1)
+        return self
+
+    i_iter = property(lambda self: len(self._tables))
+    dim = property(lambda self: int(self._data.shape[-1]))
+    weights = property(lambda self: self._weights)
+
+    @property
+    def data(self):
+        return None if self._data is None else self._data.cpu().numpy()
+
+    def add_iter(self, n):
+        self.n_iter += int(n)
+
+    def _ctx(self):
+        from ..device import get_context
+        return get_context()
+
+    # ---- one iteration: transforms/sit.py:229-255 ----
+    def _ica(self, x_host):
+        from sklearn.decomposition import FastICA
+        io = dict(self.ica_options)
+        if 'random_state' not in io:
+            io['random_state'] = int(self.random_generator.integers(0, 2**32))
+        ica = FastICA(**io)
+        n_ica = min(x_host.shape[0], self.m_ica)
+        ica.fit(x_host[self.random_generator.choice(x_host.shape[0], n_ica, False)])
+        return ica.components_, ica.mean_
+
+    def _gaussianize(self, y):
+        """Splines of all coordinates of y (n, d) device tensor: knots and edge points on the host, KDE cdfs on the device."""
+        import torch
+        from scipy.stats import norm
+        from .. import _lib
+        from ..device import _ptr
+        ctx = self._ctx()
+        n, d = y.shape
+        yT = y.T.contiguous()                       # (d, n): one row per coordinate
+        # kde bandwidth (utils/kde.py:85-151): sqrt of the weighted variance times Scott's factor times bw_factor
+        wn = self._weights / np.sum(self._weights)
+        w = ctx.tensor(wn)                          # (kde normalises its weights, utils/kde.py:76-77)
+        neff = 1. / np.sum(wn**2)
+        mean = (yT * w).sum(1) / w.sum()
+        var = (((yT - mean[:, None])**2) * w).sum(1) / w.sum() / (1. - float(np.sum(wn**2)))  # np.cov(aweights=w, bias=False)
+        h = torch.sqrt(var) * (neff**(-1. / 5)) * self.bw_factor
+        y_host = yT.cpu().numpy()
+        splines = []
+        for j in range(d):
+            hj = h[j:j + 1].contiguous()
+            dj = yT[j:j + 1].contiguous()
+
+            def fun(pts, dj=dj, hj=hj):
+                pts = np.ascontiguousarray(np.atleast_1d(pts), dtype=np.float64)
+                p = ctx.tensor(pts.reshape(1, -1))
+                out = torch.empty_like(p)
+                _lib.check(ctx._lib.bfhip_kde_cdf(ctx.handle, 1, n, _ptr(dj), _ptr(w), _ptr(hj), p.shape[1], _ptr(p), _ptr(out)))
+                return norm.ppf(out.cpu().numpy().reshape(-1))
+
+            splines.append(GaussianizingSpline(y_host[j], fun, **self.cubic_options))
+        return SplineTable(splines, ctx)
+
+    def fit(self, data=None, weights=None, n_run=None):
+        """transforms/sit.py:257-341 (without the plots)."""
+        import torch
+        ctx = self._ctx()
+        if data is not None:
+            try:
+                data = np.array(data, dtype=np.float64)
+                assert data.size > 0
+            except Exception:
+                raise ValueError('invalid value for data.')
+            if data.ndim == 2:
+                pass
+            elif data.ndim >= 3:
+                data = data.reshape((-1, data.shape[-1]))
+            else:
+                raise ValueError('invalid shape for data.ndim.')
+            if data.shape[-1] == 1:
+                raise ValueError('I cannot do rotations for only one variable.')
+            n = data.shape[0]
+            if weights is not None:
+                weights = np.asarray(weights, dtype=np.float64)
+                if weights.shape != (n,):
+                    raise ValueError('invalid value for weights.')
+                self._weights = weights
+            else:
+                self._weights = np.ones(n) / n
+            self._data = ctx.tensor(data)
+            self._data_init = data.copy()
+            d = data.shape[-1]
+            self._tables = []
+            self._A, self._B = np.zeros((0, d, d)), np.zeros((0, d, d))
+            self._m, self._logdetA = np.zeros((0, d)), np.zeros(0)
+        elif self._data is None:
+            raise ValueError('you have not given me the data to fit.')
+        if n_run is None:
+            n_run = self.n_iter - self.i_iter
+        else:
+            n_run = int(n_run)
+            if n_run <= 0:
+                raise ValueError('invalid value for n_run.')
+            if n_run > self.n_iter - self.i_iter:
+                self.n_iter = self.i_iter + n_run
+        for _ in range(n_run):
+            x_host = self._data.cpu().numpy()
+            comp, ica_mean = self._ica(x_host)
+            # y = ica.transform(x) scaled to unit variance; A = components / std, B = inv(A), m = mean(x) (:237-243)
+            m = np.mean(x_host, axis=0)
+            y = (self._data - ctx.tensor(ica_mean)) @ ctx.tensor(comp.T.copy())
+            s = y.std(0, unbiased=False)
+            y = y / s
+            A = comp / s.cpu().numpy()[:, None]
+            table = self._gaussianize(y)
+            self._tables.append(table)
+            self._data = table.apply('evaluate', y)
+            self._A = np.concatenate((self._A, A[None]), 0)
+            self._B = np.concatenate((self._B, np.linalg.inv(A)[None]), 0)
+            self._m = np.concatenate((self._m, m[None]), 0)
+            self._logdetA = np.append(self._logdetA, np.log(np.abs(np.linalg.det(A))))
+            finite = torch.isfinite(self._data).all(1)
+            if not bool(finite.all()):
+                warnings.warn('inf encountered for some data points. We will remove these inf points for now.', RuntimeWarning)
+                self._data = self._data[finite]
+                self._weights = self._weights[finite.cpu().numpy()]
+
+    # ---- transforms: transforms/sit.py:372-459 ----
+    def _points(self, x):
+        try:
+            y = np.array(x, dtype=np.float64)
+        except Exception:
+            raise ValueError('invalid value for x.')
+        if y.ndim == 1:
+            y = y[None]
+        if y.shape[-1] != self.dim:
+            raise ValueError('invalid shape for x.')
+        return y.reshape((-1, y.shape[-1])), y.shape
+
+    def forward_transform(self, x, use_parallel=False):
+        import torch
+        ctx = self._ctx()
+        flat, shape = self._points(x)
+        y = ctx.tensor(flat)
+        log_j = torch.zeros(y.shape[0], dtype=torch.float64, device=y.device)
+        for i in range(self.i_iter):
+            y = (y - ctx.tensor(self._m[i])) @ ctx.tensor(self._A[i].T.copy())
+            log_j += torch.log(self._tables[i].apply('derivative', y)).sum(1)
+            y = self._tables[i].apply('evaluate', y)
+        log_j += float(np.sum(self._logdetA))
+        return y.cpu().numpy().reshape(shape), log_j.cpu().numpy().reshape(shape[:-1])
+
+    def backward_transform(self, y, use_parallel=False):
+        import torch
+        ctx = self._ctx()
+        flat, shape = self._points(y)
+        x = ctx.tensor(flat)
+        log_j = torch.zeros(x.shape[0], dtype=torch.float64, device=x.device)
+        for i in reversed(range(self.i_iter)):
+            x = self._tables[i].apply('solve', x)
+            log_j += torch.log(self._tables[i].apply('derivative', x)).sum(1)
+            x = x @ ctx.tensor(self._B[i].T.copy()) + ctx.tensor(self._m[i])
+        log_j += float(np.sum(self._logdetA))
+        return x.cpu().numpy().reshape(shape), log_j.cpu().numpy().reshape(shape[:-1])
+
+    def logq(self, x, use_parallel=False):
+        y, log_j = self.forward_transform(x)
+        return np.sum(-0.5 * y * y - 0.9189385332046727, axis=-1) + log_j  # norm.logpdf
+
+    def sample(self, n, use_parallel=False):
+        try:
+            n = int(n)
+            assert n > 0
+        except Exception:
+            raise ValueError('n should be a positive int.')
+        y = self.mvn_generator(np.zeros(self.dim), np.eye(self.dim), n)
+        x, log_j = self.backward_transform(y)
+        return x, log_j, y

@@ -277,6 +277,30 @@ int bfhip_count_keys(bfhip_ctx *ctx, long n, const uint64_t *keys_sorted, long n
 int bfhip_importance_weights(bfhip_ctx *ctx, long n, const double *logp, const double *logq, double k_trunc, double *w,
                              double *w_trunc);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evidence: Gaussianized bridge sampling = SIT + bridge.
+ * ---------------------------------------------------------------------------------------------- */
+/* kde.cdf (utils/kde.py:322-354) of d one-dimensional weighted Gaussian KDEs at m points each:
+ * out[j][i] = sum_k w[k] ndtr((pts[j][i] - data[j][k]) / h[j]).  data (d,n), w (n) normalised, h (d) bandwidths,
+ * pts (d,m), out (d,m).  SIT._gaussianize_1d (transforms/sit.py:223-227) applies norm.ppf to it at the spline knots. */
+int bfhip_kde_cdf(bfhip_ctx *ctx, int d, long n, const double *data, const double *w, const double *h, int m, const double *pts,
+                  double *out);
+
+/* The per-dimension piecewise cubics of SIT for n points x (n,d) -> out (n,d): mode 0 evaluate, 1 derivative, 2 solve
+ * (utils/_cubic.pyx:188-336, called per dimension by SIT.forward_transform / backward_transform, transforms/sit.py:372-451).
+ * Dimension j owns knots[knot_off[j] .. knot_off[j+1]), values there, and m_j + 1 coefficient rows of 4 at
+ * coef[(knot_off[j] + j) * 4] (cubic_spline._x, ._y, ._c of utils/cubic.py).  knot_off (d+1,) int32. */
+int bfhip_spline_apply(bfhip_ctx *ctx, int mode, long n, int d, const double *x, const int *knot_off, const double *knots,
+                       const double *values, const double *coef, double *out);
+
+/* Score function of the bridge estimator (evidence/bridge.py:44-49): out2[0] = logsumexp_i(logr + a_i - logaddexp(logr + a_i, 0)),
+ * out2[1] = logsumexp_j(-logr + b_j - logaddexp(-logr + b_j, 0)); score = out2[0] - out2[1]. */
+int bfhip_bridge_sums(bfhip_ctx *ctx, long n_a, const double *a, long n_b, const double *b, double logr, double *out2);
+
+/* Per-sample terms of its error estimate (evidence/bridge.py:52-57): f1 (n_q), f2 (n_p). */
+int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const double *logq_p, long n_q, const double *logp_q,
+                       const double *logq_q, double logr, double *f1, double *f2);
+
 #ifdef __cplusplus
 }
 #endif

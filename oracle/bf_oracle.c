@@ -1159,3 +1159,69 @@ int bfo_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ================= evidence path: utils/_cubic.pyx, utils/kde.py, evidence/bridge.py ======== */
+
+/* utils/_cubic.pyx:24-96 (binary search with the same interval convention; the locality hint is not needed) */
+static int find_interval(const double *x, int m, double v) {
+    if (!(x[0] <= v && v < x[m - 1])) {
+        if (v < x[0]) return 0;
+        if (v >= x[m - 1]) return m;
+        return -1;
+    }
+    int low = 1, high = m - 1;
+    while (low < high) {
+        int mid = (low + high) / 2;
+        if (v < x[mid]) high = mid;
+        else low = mid + 1;
+    }
+    return low;
+}
+static double cubic_eval(const double *c, double x) { return c[0] * x * x * x + c[1] * x * x + c[2] * x + c[3]; } /* :99-100 */
+static double cubic_der(const double *c, double x) { return 3 * c[0] * x * x + 2 * c[1] * x + c[2]; }            /* :105-106 */
+
+/* utils/_cubic.pyx:131-163 */
+static double solve_bisect(const double *c, double yp, double x0, double x1) {
+    const double tol = 1e-10;
+    int i = 0;
+    double a = 0., b = x1 - x0, x = (a + b) / 2, y = cubic_eval(c, x) - yp;
+    while (!(y < tol && y > -tol)) {
+        if (y > 0) b = x;
+        else a = x;
+        x = (a + b) / 2;
+        y = cubic_eval(c, x) - yp;
+        if (++i >= 100) { x = NAN; break; }
+    }
+    return x;
+}
+
+/* mode 0: evaluate (:188-231); 1: derivative (:237-279); 2: solve (:285-331).  c: (m+1, 4), x, y: (m,) */
+void bfo_spline_apply(int mode, const double *c, const double *x, const double *y, int m, const double *in, double *out, size_t r) {
+    for (size_t i = 0; i < r; ++i) {
+        double v = in[i], o = NAN;
+        int j = find_interval(mode == 2 ? y : x, m, v);
+        if (mode == 0) {
+            if (j > 0 && j < m) o = cubic_eval(c + 4 * j, v - x[j - 1]);
+            else if (j == 0) o = c[2] * (v - x[0]) + c[3];
+            else if (j == m) o = c[4 * m + 2] * (v - x[m - 1]) + c[4 * m + 3];
+        } else if (mode == 1) {
+            if (j > 0 && j < m) o = cubic_der(c + 4 * j, v - x[j - 1]);
+            else if (j == 0) o = c[2];
+            else if (j == m) o = c[4 * m + 2];
+        } else {
+            if (j > 0 && j < m) o = x[j - 1] + solve_bisect(c + 4 * j, v, x[j - 1], x[j]);
+            else if (j == 0) o = x[0] + (v - c[3]) / c[2];
+            else if (j == m) o = x[m - 1] + (v - c[4 * m + 3]) / c[4 * m + 2];
+        }
+        out[i] = o;
+    }
+}
+
+/* kde.cdf for a 1-d KDE, utils/kde.py:322-354: sum_k w_k ndtr((x - data_k) / h) */
+void bfo_kde_cdf(const double *data, const double *w, size_t n, double h, const double *pts, double *out, size_t m) {
+    for (size_t i = 0; i < m; ++i) {
+        double s = 0.;
+        for (size_t k = 0; k < n; ++k) s += w[k] * 0.5 * erfc(-(pts[i] - data[k]) / h * 0.70710678118654752440);
+        out[i] = s;
+    }
+}

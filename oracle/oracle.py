@@ -517,3 +517,44 @@ class ChainSet:
 
 def max_threads():
     return int(lib().bfo_max_threads())
+
+
+# ---- evidence path ------------------------------------------------------------
+def spline_apply(mode, c, x, y, pts):
+    """utils/_cubic.pyx:188-336 on one spline: mode 'evaluate' | 'derivative' | 'solve'."""
+    c, x, y, pts = _f64(c), _f64(x), _f64(y), _f64(pts)
+    out = np.empty_like(pts)
+    f = lib().bfo_spline_apply
+    f.restype = None
+    f(C.c_int({'evaluate': 0, 'derivative': 1, 'solve': 2}[mode]), _p(c), _p(x), _p(y), C.c_int(x.size), _p(pts), _p(out),
+      C.c_size_t(pts.size))
+    return out
+
+
+def kde_cdf(data, weights, h, pts):
+    """kde.cdf (utils/kde.py:322-354) of a 1-d weighted Gaussian KDE with bandwidth h."""
+    data, w, pts = _f64(data), _f64(weights), _f64(np.atleast_1d(pts))
+    out = np.empty_like(pts)
+    f = lib().bfo_kde_cdf
+    f.restype = None
+    f(_p(data), _p(w), C.c_size_t(data.size), C.c_double(h), _p(pts), _p(out), C.c_size_t(pts.size))
+    return out
+
+
+def kde_bandwidth(data, weights, bw_factor=1.):
+    """Bandwidth of the reference's 1-d kde (utils/kde.py:85-151): Scott's factor neff^(-1/5) times bw_factor times the
+    square root of the weighted, unbiased variance."""
+    w = np.asarray(weights, dtype=np.float64)
+    w = w / w.sum()
+    neff = 1. / np.sum(w**2)
+    cov = float(np.cov(np.asarray(data, dtype=np.float64), bias=False, aweights=w))
+    return np.sqrt(cov) * neff**(-1. / 5) * bw_factor
+
+
+def bridge_score(logr, a, b):
+    """evidence/bridge.py:44-49."""
+    from scipy.special import logsumexp
+    a, b = np.asarray(a), np.asarray(b)
+    c = logsumexp(logr + a - logsumexp(np.array((logr + a, np.zeros_like(a))), axis=0))
+    d = logsumexp(-logr + b - logsumexp(np.array((-logr + b, np.zeros_like(b))), axis=0))
+    return c - d

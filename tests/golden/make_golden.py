@@ -484,6 +484,72 @@ def gen_refit(bf, out):
     np.savez_compressed(os.path.join(out, 'refit.npz'), **z)
 
 
+def gen_evidence(bf, out):
+    """Evidence path: kde.cdf, the cubic_spline arrays and kernels, a fitted SIT (rotations, splines,
+    logq, forward / backward transforms) on funnel-shaped samples, and bridge() inputs / outputs."""
+    if not hasattr(np, 'asscalar'):  # removed NumPy alias still used by utils/kde.py:347
+        np.asscalar = lambda a: np.asarray(a).item()
+    from bayesfast.utils.kde import kde
+    from bayesfast.utils.cubic import cubic_spline
+    from bayesfast.transforms import SIT
+    from bayesfast.evidence.bridge import bridge
+    from scipy.stats import norm
+    rng = np.random.default_rng(2024)
+    z = {}
+    # -- 1-d kde + Gaussianizing spline of a skewed sample
+    x1 = np.concatenate((rng.normal(size=3000), rng.normal(size=1500) * 0.4 + 2.5, rng.standard_t(3, size=500)))
+    w1 = np.full(x1.size, 1. / x1.size)
+    k = kde(x1, bw_factor=1., weights=w1)
+    pts = np.linspace(-6, 6, 41)
+    z['kde.x'], z['kde.w'], z['kde.pts'] = x1, w1, pts
+    z['kde.h'] = np.asarray(float(np.asarray(k.covariance).item())**0.5)
+    z['kde.cdf'] = k.cdf(pts)
+    c = cubic_spline(x1, lambda xx: norm.ppf(k.cdf(xx)))
+    z['spl.x'], z['spl.y'], z['spl.c'] = c._x, c._y, c._c
+    tp = np.concatenate((np.linspace(x1.min() - 1, x1.max() + 1, 97), c._x[:5], [np.nan]))
+    z['spl.pts'] = tp
+    z['spl.evaluate'] = c.evaluate(tp)
+    z['spl.derivative'] = c.derivative(tp)
+    yp = np.concatenate((np.linspace(c._y[0] - 1, c._y[-1] + 1, 83), c._y[:4]))
+    z['spl.ypts'] = yp
+    z['spl.solve'] = c.solve(yp)
+    # -- SIT on a 6-d funnel (examples/funnel-gbs.ipynb shape, a = 1, b = 0.5), 3 iterations
+    D, n = 6, 4000
+    x0 = rng.normal(size=n)
+    data = np.concatenate((x0[:, None], rng.normal(size=(n, D - 1)) * np.exp(0.5 * x0)[:, None]), 1)
+    sit = SIT(n_iter=3, parallel_backend=1, random_generator=11, mvn_generator=lambda m, c, s: rng.normal(size=(s, len(m))))
+    sit.fit(data)
+    z['sit.data'] = data
+    z['sit.A'], z['sit.B'], z['sit.m'], z['sit.logdetA'] = sit._A, sit._B, sit._m, sit._logdetA
+    for i in range(3):
+        for j in range(D):
+            cs = sit._cubic[i][j]
+            z['sit.it%d.d%d.x' % (i, j)], z['sit.it%d.d%d.y' % (i, j)], z['sit.it%d.d%d.c' % (i, j)] = cs._x, cs._y, cs._c
+    z['sit.data_final'] = sit._data
+    xt = data[:200] * 1.1
+    z['sit.xt'] = xt
+    z['sit.logq'] = sit.logq(xt)
+    yf, ljf = sit.forward_transform(xt)
+    z['sit.forward_y'], z['sit.forward_logj'] = yf, ljf
+    yb = rng.normal(size=(150, D))
+    xb, ljb = sit.backward_transform(yb)
+    z['sit.yb'], z['sit.backward_x'], z['sit.backward_logj'] = yb, xb, ljb
+    # -- bridge: p samples as (chains, iterations) with autocorrelation, q samples flat
+    n_c, n_i, n_q = 4, 600, 2000
+    e = rng.normal(size=(n_c, n_i))
+    for t in range(1, n_i):
+        e[:, t] = 0.6 * e[:, t - 1] + 0.8 * e[:, t]
+    lpp = -0.5 * e**2 - 3.
+    lqp = -0.5 * (e / 1.2)**2 - np.log(1.2) + 0.05 * np.sin(e)
+    q = rng.normal(size=n_q) * 1.2
+    lpq = -0.5 * q**2 - 3.
+    lqq = -0.5 * (q / 1.2)**2 - np.log(1.2) + 0.05 * np.sin(q)
+    logr, err = bridge(lpp, lpq, lqp, lqq)
+    z['br.lpp'], z['br.lpq'], z['br.lqp'], z['br.lqq'] = lpp, lpq, lqp, lqq
+    z['br.logr'], z['br.err'] = np.asarray(logr), np.asarray(err)
+    np.savez_compressed(os.path.join(out, 'evidence.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -492,7 +558,7 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit)
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue
