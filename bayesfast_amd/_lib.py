@@ -46,7 +46,9 @@ class SamplerConfig(C.Structure):
 class PolymodelDesc(C.Structure):  # bfhip_polymodel_desc
     _fields_ = [('d', C.c_int), ('m', C.c_int), ('c0', C.POINTER(C.c_double)), ('lin', C.POINTER(C.c_double)),
                 ('quad', C.POINTER(C.c_double)), ('use_bound', C.c_int), ('mu', C.POINTER(C.c_double)),
-                ('hess', C.POINTER(C.c_double)), ('alpha', C.c_double), ('f_mu', C.POINTER(C.c_double))]
+                ('hess', C.POINTER(C.c_double)), ('alpha', C.c_double), ('f_mu', C.POINTER(C.c_double)),
+                ('n2', C.c_int), ('mask2', C.POINTER(C.c_int)), ('cubic2', C.POINTER(C.c_double)),
+                ('n3', C.c_int), ('mask3', C.POINTER(C.c_int)), ('cubic3', C.POINTER(C.c_double))]
 
 
 # every symbol include/bfhip.h declares: (restype, argtypes)
@@ -69,6 +71,7 @@ SYMBOLS = {
     'bfhip_metric_init_full': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp]),
     'bfhip_polymodel_upload': (C.c_int, [_vp, C.POINTER(PolymodelDesc)]),
     'bfhip_polymodel_eval': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    'bfhip_chi2_stage': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp]),
     'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
     'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_solve_spd': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),

@@ -7,7 +7,7 @@ import numpy as np
 
 from ..modules.poly import PolyModel
 
-__all__ = ['SurrogateDensity']
+__all__ = ['SurrogateDensity', 'Chi2PipelineDensity']
 
 
 class SurrogateDensity:
@@ -176,3 +176,64 @@ class SurrogateDensity:
 
     def grad(self, x, original_space=True):
         return self.logp_and_grad(x, original_space)[1]
+
+
+class Chi2PipelineDensity:
+    """A two-module pipeline evaluated on the device: a multi-output ``PolyModel`` surrogate (x -> m outputs) followed by
+    a Gaussian likelihood of those outputs, i.e. the reference's ``Density(module_list=[model, chi2],
+    surrogate_list=[PolyModel])`` with ``use_surrogate=True`` (core/density.py:487-566: the surrogate replaces the module
+    in its scope, :527-551; the Jacobians are chained, ``jac = np.dot(J_out, J_in)``, :552-560; ``logp`` and ``grad`` are
+    read from the density variable, :737-739).
+
+    surrogate : PolyModel with output_size m (any config orders)
+    y : (m,) data vector;  prec : (m, m) precision matrix, or  prec_diag : (m,) inverse variances
+    logp0 : additive constant of the log-likelihood
+
+    ``logp_and_grad(x)`` runs ``bfhip_polymodel_eval`` (f and the (n, m, d) Jacobians) and ``bfhip_chi2_stage``
+    (r = prec (f - y), logp = logp0 - (f - y).r / 2, grad = -J^T r) without leaving the GPU."""
+
+    def __init__(self, surrogate, y, prec=None, prec_diag=None, logp0=0.):
+        if not isinstance(surrogate, PolyModel):
+            raise ValueError('surrogate should be a PolyModel.')
+        self.surrogate = surrogate
+        m = surrogate.output_size
+        self._y = np.ascontiguousarray(y, dtype=np.float64).reshape(m)
+        if (prec is None) == (prec_diag is None):
+            raise ValueError('give me exactly one of prec and prec_diag.')
+        self._prec = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64).reshape(m, m)
+        self._pdiag = None if prec_diag is None else np.ascontiguousarray(prec_diag, dtype=np.float64).reshape(m)
+        self._logp0 = float(logp0)
+
+    input_size = property(lambda self: self.surrogate.input_size)
+
+    def logp_and_grad_device(self, x, grad=True):
+        """x (n, d) array or device tensor -> logp (n,), grad (n, d) device tensors."""
+        import torch
+        from .. import _lib
+        from ..device import _ptr
+        dm = self.surrogate.device_model()
+        ctx = dm.ctx
+        xt = ctx.tensor(x, torch.float64).reshape(-1, self.input_size)
+        f, j = dm.fun_and_jac(xt, jac=grad)
+        n, m, d = xt.shape[0], self.surrogate.output_size, self.input_size
+        lp = ctx.empty((n,))
+        g = ctx.empty((n, d)) if grad else None
+        y = ctx.tensor(self._y)
+        pr = None if self._prec is None else ctx.tensor(self._prec)
+        pd = None if self._pdiag is None else ctx.tensor(self._pdiag)
+        _lib.check(ctx._lib.bfhip_chi2_stage(ctx.handle, n, m, d, _ptr(f), _ptr(j) if grad else None, _ptr(y), _ptr(pr), _ptr(pd),
+                                             self._logp0, _ptr(lp), _ptr(g)))
+        return lp, g
+
+    def logp_and_grad(self, x, original_space=True):
+        x = np.asarray(x, dtype=np.float64)
+        lp, g = self.logp_and_grad_device(x.reshape(-1, self.input_size))
+        lp, g = lp.cpu().numpy(), g.cpu().numpy()
+        return (lp[0], g[0]) if x.ndim == 1 else (lp, g)
+
+    def logp(self, x, original_space=True):
+        x = np.asarray(x, dtype=np.float64)
+        lp = self.logp_and_grad_device(x.reshape(-1, self.input_size), grad=False)[0].cpu().numpy()
+        return lp[0] if x.ndim == 1 else lp
+
+    __call__ = logp

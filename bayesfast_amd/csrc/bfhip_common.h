@@ -46,6 +46,10 @@ struct bfhip_ctx {
         const double *mu;    // [DP]
         const double *Hf;    // [DP*DP]
         double alpha;
+        // cubic configs, compact over their masks (per output o: A2[o][n2][n2], A2t[o], T3t[o][n3][n3][n3] as in DevModel)
+        int n2, n3;
+        const int *mask2, *pos2, *mask3, *pos3;
+        const double *A2, *A2t, *T3t;
     } pm;
     void *scratch;        // sampler tree scratch (grow-only)
     size_t scratch_bytes;

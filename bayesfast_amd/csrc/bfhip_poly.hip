@@ -1,4 +1,5 @@
-// bfhip_poly.hip -- multi-output PolyModel evaluation (modules/poly.py:430-503) for linear + quadratic configs.
+// bfhip_poly.hip -- multi-output PolyModel evaluation (modules/poly.py:430-503): linear, quadratic and cubic configs, and
+// the chi-square stage that follows it in a pipeline (core/density.py:552-560).
 //
 // Same wave-local MFMA layout as bfhip_eval.h (one wave = 16 points, lane (c, g) owns dimensions 4e + g); the
 // outputs are a loop around the matvec: G_o = S_o x gives value and Jacobian row of output o.  A workgroup of four
@@ -56,7 +57,35 @@ extern "C" int bfhip_polymodel_upload(bfhip_ctx *ctx, const bfhip_polymodel_desc
         for (int i = 0; i < d; ++i) mu[i] = ds->mu[i];
         pm_to_fragments(ds->hess, d, DP, Hf);
     }
-    const size_t bytes = n_dbl * sizeof(double);
+    // cubic configs: per-output compact tables (same layouts as DevModel: A2, its transpose, and the symmetric fill of
+    // the j < k < l coefficients stored [k][l][j]) and the dimension -> mask position maps
+    const int n2 = (ds->cubic2 && ds->n2 > 0) ? ds->n2 : 0, n3 = (ds->cubic3 && ds->n3 > 0) ? ds->n3 : 0;
+    if ((n2 && !ds->mask2) || (n3 && !ds->mask3)) return bf_set_error(BFHIP_ERR_ARG, "cubic configs need their masks");
+    const size_t c2 = (size_t)m * n2 * n2, c3 = (size_t)m * n3 * n3 * n3;
+    const size_t off_c = h.size();
+    h.resize(off_c + 2 * c2 + c3, 0.);
+    for (int o = 0; o < m; ++o) {
+        for (int a = 0; a < n2; ++a)
+            for (int b = 0; b < n2; ++b) {
+                const double v = ds->cubic2[((size_t)o * n2 + a) * n2 + b];
+                h[off_c + ((size_t)o * n2 + a) * n2 + b] = v;
+                h[off_c + c2 + ((size_t)o * n2 + b) * n2 + a] = v;
+            }
+        double *T3 = h.data() + off_c + 2 * c2 + (size_t)o * n3 * n3 * n3;
+        for (int a = 0; a < n3; ++a)
+            for (int b = a + 1; b < n3; ++b)
+                for (int c = b + 1; c < n3; ++c) {
+                    const double v = ds->cubic3[(((size_t)o * n3 + a) * n3 + b) * n3 + c];
+                    const int pp[3] = {a, b, c};
+                    static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+                    for (int q = 0; q < 6; ++q) T3[((size_t)pp[perm[q][0]] * n3 + pp[perm[q][1]]) * n3 + pp[perm[q][2]]] = v;
+                }
+    }
+    std::vector<int> hi((size_t)n2 + n3 + 2 * DP, -1);
+    for (int a = 0; a < n2; ++a) { hi[a] = ds->mask2[a]; if (ds->mask2[a] < 0 || ds->mask2[a] >= d) return bf_set_error(BFHIP_ERR_ARG, "mask2 out of range"); hi[n2 + ds->mask2[a]] = a; }
+    for (int a = 0; a < n3; ++a) { hi[n2 + DP + a] = ds->mask3[a]; if (ds->mask3[a] < 0 || ds->mask3[a] >= d) return bf_set_error(BFHIP_ERR_ARG, "mask3 out of range"); hi[n2 + DP + n3 + ds->mask3[a]] = a; }
+    const size_t dbl_bytes = h.size() * sizeof(double);
+    const size_t bytes = dbl_bytes + hi.size() * sizeof(int);
     if (ctx->pm_bytes < bytes) {
         BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (ctx->pm_buf) BF_HIP_CHECK(hipFree(ctx->pm_buf));
@@ -66,7 +95,8 @@ extern "C" int bfhip_polymodel_upload(bfhip_ctx *ctx, const bfhip_polymodel_desc
         ctx->pm_bytes = bytes;
     }
     BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    BF_HIP_CHECK(hipMemcpy(ctx->pm_buf, h.data(), bytes, hipMemcpyHostToDevice));
+    BF_HIP_CHECK(hipMemcpy(ctx->pm_buf, h.data(), dbl_bytes, hipMemcpyHostToDevice));
+    BF_HIP_CHECK(hipMemcpy((char *)ctx->pm_buf + dbl_bytes, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice));
     PolyDev &p = ctx->pm;
     memset(&p, 0, sizeof(p));
     p.d = d; p.DP = DP; p.m = m; p.use_bound = ds->use_bound != 0; p.has_quad = ds->quad != NULL;
@@ -78,6 +108,10 @@ extern "C" int bfhip_polymodel_upload(bfhip_ctx *ctx, const bfhip_polymodel_desc
     p.mu = p.f_mu + m;
     p.Hf = p.mu + DP;
     p.alpha = ds->alpha;
+    p.n2 = n2; p.n3 = n3;
+    p.A2 = base + off_c; p.A2t = p.A2 + c2; p.T3t = p.A2t + c2;
+    const int *ib = (const int *)((const char *)ctx->pm_buf + dbl_bytes);
+    p.mask2 = ib; p.pos2 = ib + n2; p.mask3 = ib + n2 + DP; p.pos3 = ib + n2 + DP + n3;
     ctx->has_pm = 1;
     return 0;
 }
@@ -105,7 +139,9 @@ __global__ __launch_bounds__(256) void bf_polymodel_eval_kernel(PolyDev pm, int 
     }
     double beta = 0.;
     bool oob = false;
-    if (pm.use_bound && pm.has_quad) {  // the bound test of PolyModel._fun_and_jac: modules/poly.py:467-469
+    const bool has_cubic = pm.n2 > 0 || pm.n3 > 0;
+    double *xst = lds + (STAGE ? MAT : 0) + wave * 16 * DP;  // this wave's points, plain layout (cubic configs)
+    if (pm.use_bound) {  // the bound test of PolyModel._fun_and_jac: modules/poly.py:467-469
         double b2 = 0.;
 #pragma unroll
         for (int e = 0; e < E; ++e) xm[e] = xv[e] - pm.mu[4 * e + g];
@@ -119,6 +155,12 @@ __global__ __launch_bounds__(256) void bf_polymodel_eval_kernel(PolyDev pm, int 
 #pragma unroll
             for (int e = 0; e < E; ++e) xe[e] = (pm.alpha * xv[e] + (beta - pm.alpha) * pm.mu[4 * e + g]) / beta;  // :482
         }
+    }
+    if (has_cubic) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) xst[c * DP + 4 * e + g] = xe[e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     // the outputs are split over blockIdx.y so that small batches still fill the chip (the bound test above is
     // repeated per chunk; it is one matvec)
@@ -139,19 +181,37 @@ __global__ __launch_bounds__(256) void bf_polymodel_eval_kernel(PolyDev pm, int 
 #pragma unroll
             for (int e = 0; e < E; ++e) G[e] = 0.;
         }
-        double quad = 0., lin = 0., dotj = 0.;
+        double quad = 0., lin = 0., dotj = 0., fcub = 0.;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const double cl = pm.lin[(size_t)o * DP + 4 * e + g];
             quad += xe[e] * G[e];
             lin += cl * xe[e];
             G[e] += cl;                 // Jacobian row at the evaluation point
-            dotj += G[e] * xm[e];
         }
+        if (has_cubic) {  // cubic-2 / cubic-3 configs of this output (modules/_poly.pyx:49-137), compact tables
+            DevModel cm;
+            cm.DP = DP;
+            cm.n2 = pm.n2; cm.n3 = pm.n3;
+            cm.mask2 = pm.mask2; cm.pos2 = pm.pos2; cm.mask3 = pm.mask3; cm.pos3 = pm.pos3;
+            cm.A2 = pm.A2 + (size_t)o * pm.n2 * pm.n2;
+            cm.A2t = pm.A2t + (size_t)o * pm.n2 * pm.n2;
+            cm.T3t = pm.T3t + (size_t)o * pm.n3 * pm.n3 * pm.n3;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                double gc, fc;
+                bf_cubic_grad(cm, 4 * e + g, xe[e], [&](int k) { return xst[c * DP + k]; }, gc, fc);
+                G[e] += gc;
+                fcub += fc;
+            }
+            fcub = bf_sum_g(fcub);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) dotj += G[e] * xm[e];
         quad = bf_sum_g(quad);
         lin = bf_sum_g(lin);
-        double fo = (pm.c0[o] + lin) + 0.5 * quad;
-        if (pm.use_bound && pm.has_quad) {
+        double fo = ((pm.c0[o] + lin) + 0.5 * quad) + fcub;
+        if (pm.use_bound) {
             dotj = bf_sum_g(dotj);
             if (oob) {  // linear extrapolation from the projected point: modules/poly.py:484-503
                 const double f0 = fo;
@@ -177,7 +237,9 @@ __global__ __launch_bounds__(256) void bf_polymodel_eval_kernel(PolyDev pm, int 
 template <int T>
 static int launch_polymodel_eval(bfhip_ctx *ctx, int n, const double *x, double *f, double *jac) {
     auto k = bf_polymodel_eval_kernel<T>;
-    const size_t lds = T <= 4 ? (size_t)256 * T * T * sizeof(double) : 0;
+    const bool cubic = ctx->pm.n2 > 0 || ctx->pm.n3 > 0;
+    const size_t lds = ((T <= 4 ? (size_t)256 * T * T : 0) + (cubic ? (size_t)4 * 16 * 16 * T : 0)) * sizeof(double);
+    if (lds > 64 * 1024) BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (n + 63) / 64;
     int ny = (4 * ctx->n_cu + grid - 1) / grid;  // aim at about four workgroups per CU
     if (ny > ctx->pm.m) ny = ctx->pm.m;
@@ -199,4 +261,63 @@ extern "C" int bfhip_polymodel_eval(bfhip_ctx *ctx, int n, const double *x, doub
     case 8: return launch_polymodel_eval<8>(ctx, n, x, f, jac);
     }
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->pm.DP);
+}
+
+
+// ---- chi-square stage of a surrogate pipeline (core/density.py:552-560 chain rule fused with the module) ------------
+// One wave per point: lanes stride over the m outputs for r = prec (f - y) and the value, then over the d inputs for
+// grad = -J^T r (coalesced reads of the Jacobian rows).
+__global__ __launch_bounds__(256) void bf_chi2_stage_kernel(int n, int m, int d, const double *__restrict__ f, const double *__restrict__ jac,
+                                                           const double *__restrict__ y, const double *__restrict__ prec,
+                                                           const double *__restrict__ pdiag, double logp0, double *__restrict__ logp,
+                                                           double *__restrict__ grad, double *__restrict__ rbuf) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pt = blockIdx.x * 4 + wv;
+    if (pt >= n) return;
+    const double *fp = f + (size_t)pt * m;
+    double *r = rbuf + (size_t)pt * m;
+    double acc = 0.;
+    for (int o = lane; o < m; o += 64) {
+        double ro;
+        if (prec) {
+            ro = 0.;
+            for (int k = 0; k < m; ++k) ro += prec[(size_t)o * m + k] * (fp[k] - y[k]);
+        } else {
+            ro = pdiag[o] * (fp[o] - y[o]);
+        }
+        r[o] = ro;
+        acc += (fp[o] - y[o]) * ro;
+    }
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (lane == 0) logp[pt] = logp0 - 0.5 * acc;
+    if (!grad) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double *jp = jac + (size_t)pt * m * d;
+    for (int i = lane; i < d; i += 64) {
+        double g = 0.;
+        for (int o = 0; o < m; ++o) g += jp[(size_t)o * d + i] * r[o];
+        grad[(size_t)pt * d + i] = -g;
+    }
+}
+
+extern "C" int bfhip_chi2_stage(bfhip_ctx *ctx, int n, int m, int d, const double *f, const double *jac, const double *y,
+                                const double *prec, const double *prec_diag, double logp0, double *logp, double *grad) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || n < 0 || m < 1 || d < 1 || !y || (!prec && !prec_diag) || (n > 0 && (!f || !logp)) || (grad && !jac))
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_chi2_stage: invalid argument");
+    if (n == 0) return 0;
+    const size_t need = (size_t)n * m * sizeof(double);
+    if (ctx->scratch_bytes < need) {
+        BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) BF_HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = NULL;
+        ctx->scratch_bytes = 0;
+        BF_HIP_CHECK(hipMalloc(&ctx->scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    hipLaunchKernelGGL(bf_chi2_stage_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, n, m, d, f, jac, y, prec, prec_diag, logp0,
+                       logp, grad, (double *)ctx->scratch);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
 }

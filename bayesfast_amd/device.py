@@ -253,7 +253,7 @@ class DeviceDensity:
 
 class DevicePolyModel:
     """A multi-output PolyModel resident on one GPU: ``PolyModel.fun / jac / fun_and_jac`` over batches of points
-    (modules/poly.py:430-503) for linear and quadratic configs; masks are scattered to dense per-output
+    (modules/poly.py:430-503) for linear, quadratic and cubic configs; masks are scattered to dense per-output
     coefficients here, which is what ``_fun_and_jac`` does on every call (modules/poly.py:474-477).
 
     poly : the dict ``PolyModel.poly_spec()`` returns."""
@@ -265,6 +265,7 @@ class DevicePolyModel:
         lin = np.zeros((m, d))
         quad = np.zeros((m, d, d))
         has_quad = False
+        cubic = []
         for cf in poly['configs']:
             im = np.asarray(cf['input_mask'], dtype=np.int64)
             om = np.asarray(cf['output_mask'], dtype=np.int64)
@@ -277,8 +278,27 @@ class DevicePolyModel:
                 iu = np.triu_indices(im.size)
                 for q, o in enumerate(om):
                     quad[o, im[iu[0]], im[iu[1]]] += coef[q][iu]
+            elif cf['order'] in ('cubic-2', 'cubic-3'):
+                cubic.append((cf['order'], im, om, coef))
             else:
-                raise NotImplementedError('cubic configs are evaluated per output through DeviceDensity.')
+                raise ValueError('unexpected PolyConfig order "{}".'.format(cf['order']))
+        # cubic configs, compact over the union of the dimensions they touch (per order)
+        mask2 = np.unique(np.concatenate([c[1] for c in cubic if c[0] == 'cubic-2'] or [np.zeros(0, np.int64)])).astype(np.int32)
+        mask3 = np.unique(np.concatenate([c[1] for c in cubic if c[0] == 'cubic-3'] or [np.zeros(0, np.int64)])).astype(np.int32)
+        cub2 = np.zeros((m, mask2.size, mask2.size))
+        cub3 = np.zeros((m, mask3.size, mask3.size, mask3.size))
+        for order, im, om, coef in cubic:
+            if order == 'cubic-2':
+                pos = np.searchsorted(mask2, im)
+                for q, o in enumerate(om):
+                    cub2[o][np.ix_(pos, pos)] += coef[q]
+            else:
+                pos = np.searchsorted(mask3, im)
+                n_ = im.size
+                jj, kk, ll = np.meshgrid(np.arange(n_), np.arange(n_), np.arange(n_), indexing='ij')
+                sel = (jj < kk) & (kk < ll)  # only j < k < l is defined (modules/_poly.pyx:86-137)
+                for q, o in enumerate(om):
+                    cub3[o, pos[jj[sel]], pos[kk[sel]], pos[ll[sel]]] += coef[q][sel]
         self.d, self.m = d, m
         ds = _lib.PolymodelDesc()
         keep = []
@@ -292,7 +312,13 @@ class DevicePolyModel:
         ds.c0, ds.lin = f64(c0), f64(lin)
         if has_quad:
             ds.quad = f64(quad)
-        if poly.get('use_bound', False) and has_quad:
+        if mask2.size:
+            keep.append(mask2)
+            ds.n2, ds.mask2, ds.cubic2 = int(mask2.size), mask2.ctypes.data_as(C.POINTER(C.c_int)), f64(cub2)
+        if mask3.size:
+            keep.append(mask3)
+            ds.n3, ds.mask3, ds.cubic3 = int(mask3.size), mask3.ctypes.data_as(C.POINTER(C.c_int)), f64(cub3)
+        if poly.get('use_bound', False) and (has_quad or cubic):  # (not for an all-linear model, modules/poly.py:467)
             ds.use_bound = 1
             ds.mu, ds.hess = f64(poly['mu']), f64(poly['hess'])
             ds.alpha = float(poly['alpha'])

@@ -240,8 +240,8 @@ class PolyModel(Surrogate):
                     use_decay=False)
 
     def device_model(self, use_bound=None):
-        """The multi-output module on the GPU (``DevicePolyModel``): batched ``fun_and_jac`` for linear + quadratic
-        configs in one launch.  Rebuilt after every fit."""
+        """The multi-output module on the GPU (``DevicePolyModel``): batched ``fun_and_jac`` in one launch.  Rebuilt
+        after every fit."""
         from ..device import DevicePolyModel
         key = (id(self._configs[0]._coef), use_bound)
         if getattr(self, '_dev_model_key', None) != key:
@@ -257,16 +257,8 @@ class PolyModel(Surrogate):
         """f (m,), j (m, d) of one point, on device."""
         from ..device import DeviceDensity
         x = np.asarray(x, dtype=np.float64).reshape(1, -1)
-        if all(c.order in ('linear', 'quadratic') for c in self._configs):  # one launch for all outputs
-            f, j = self.device_model(use_bound).fun_and_jac(x)
-            return f[0].cpu().numpy(), j[0].cpu().numpy()
-        f = np.empty(self._output_size)
-        j = np.empty((self._output_size, self._input_size))
-        for ii in range(self._output_size):
-            lp, g = DeviceDensity(self._output_spec(ii, use_bound)).logp_and_grad(x, original_space=True)
-            f[ii] = lp.item()
-            j[ii] = g.cpu().numpy().reshape(-1)
-        return f, j
+        f, j = self.device_model(use_bound).fun_and_jac(x)  # one launch for all outputs and config orders
+        return f[0].cpu().numpy(), j[0].cpu().numpy()
 
     def _fun(self, x):
         return self._device_eval(x)[0]

@@ -218,7 +218,7 @@ int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const double *cov
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-output surrogate module: PolyModel.fun / jac / fun_and_jac for output_size m > 1
- * (modules/poly.py:430-503).  Linear and quadratic configs, masks already scattered by
+ * (modules/poly.py:430-503).  Linear, quadratic and cubic configs, masks already scattered by
  * the caller: c0 (m), lin (m,d), quad (m,d,d) with the upper triangle j <= k as in bfhip_density_desc.
  * The extrapolation bound (mu, hess, alpha) is shared by all outputs, f_mu (m) is per output.
  * ---------------------------------------------------------------------------------------------- */
@@ -229,6 +229,15 @@ typedef struct bfhip_polymodel_desc {
     const double *mu, *hess;        /* (d), (d,d) */
     double alpha;
     const double *f_mu;             /* (m) */
+    /* cubic configs (modules/_poly.pyx:49-137), compact over the dimensions they touch: mask2 (n2,) / mask3 (n3,) sorted
+     * dimension indices; cubic2 (m, n2, n2): f_o += sum_{j,k} cubic2[o,j,k] x_j^2 x_k; cubic3 (m, n3, n3, n3), only
+     * j < k < l is read: f_o += sum_{j<k<l} cubic3[o,j,k,l] x_j x_k x_l (x restricted to the mask).  NULL / 0: none. */
+    int n2;
+    const int *mask2;
+    const double *cubic2;
+    int n3;
+    const int *mask3;
+    const double *cubic3;
 } bfhip_polymodel_desc;
 
 /* Copies the module into device memory owned by the context (host pointers in the descriptor). */
@@ -237,6 +246,14 @@ int bfhip_polymodel_upload(bfhip_ctx *ctx, const bfhip_polymodel_desc *desc);
 /* f (n,m) and, if jac != NULL, jac (n,m,d) for n points x (n,d); device pointers.  Outside the bound every output
  * is extrapolated linearly from the projected point, PolyModel._fj_bound (modules/poly.py:480-503). */
 int bfhip_polymodel_eval(bfhip_ctx *ctx, int n, const double *x, double *f, double *jac);
+
+/* Downstream analytic module of a pipeline whose first module is the multi-output surrogate: a Gaussian likelihood
+ * (chi-square) of its m outputs, with the pipeline's chain rule (core/density.py:552-560: jac = dot(J_out, J_in)) fused in:
+ *   r = prec (f - y)  (prec (m,m) row-major, or prec_diag (m) when prec is NULL),  logp = -1/2 (f - y).r + logp0,
+ *   grad = -J^T r,  J (n,m,d) the surrogate's Jacobians.
+ * f (n,m), jac (n,m,d) as written by bfhip_polymodel_eval; logp (n), grad (n,d); grad may be NULL. */
+int bfhip_chi2_stage(bfhip_ctx *ctx, int n, int m, int d, const double *f, const double *jac, const double *y, const double *prec,
+                     const double *prec_diag, double logp0, double *logp, double *grad);
 
 /* ------------------------------------------------------------------------------------------------
  * Surrogate fit, PolyModel.fit (modules/poly.py:505-589).

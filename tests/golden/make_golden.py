@@ -550,6 +550,50 @@ def gen_evidence(bf, out):
     np.savez_compressed(os.path.join(out, 'evidence.npz'), **z)
 
 
+def gen_pipeline(bf, out):
+    """a reference Density whose first module is replaced by a multi-output PolyModel surrogate with linear,
+    quadratic and cubic configs, followed by an analytic chi-square module: fitted coefficients, and
+    Density.logp_and_grad(use_surrogate=True) (core/density.py:487-566,724-754) at points inside and outside the bound."""
+    rng = np.random.default_rng(31)
+    d, m = 7, 5
+    W1 = rng.normal(size=(m, d)) * 0.4
+    ydat = rng.normal(size=m)
+    cov = np.diag(rng.uniform(0.5, 2., m)) + 0.1
+    prec = np.linalg.inv(cov)
+
+    def f_model(x):
+        return W1 @ x + 0.3 * np.tanh(x[:m]) * x[1:m + 1] + 0.05 * x[:m]**3
+
+    def f_chi2(y):
+        r = y - ydat
+        return -0.5 * r @ prec @ r
+
+    def j_chi2(y):
+        return -(prec @ (y - ydat))[np.newaxis]
+
+    mod0 = bf.Module(fun=f_model, input_vars='x', output_vars='y')
+    mod1 = bf.Module(fun=f_chi2, jac=j_chi2, input_vars='y', output_vars='logp')
+    cfgs = [bf.modules.PolyConfig('linear'), bf.modules.PolyConfig('quadratic'),
+            bf.modules.PolyConfig('cubic-2', input_mask=[0, 2, 3, 5], output_mask=[0, 1, 3]),
+            bf.modules.PolyConfig('cubic-3', input_mask=[1, 2, 4, 5, 6], output_mask=[1, 2, 4])]
+    su = bf.modules.PolyModel(cfgs, input_size=d, output_size=m, input_vars='x', output_vars='y')
+    den = bf.Density(module_list=[mod0, mod1], surrogate_list=[su], input_shapes=[d], input_vars='x', density_name='logp')
+    xf = rng.normal(size=(3 * su.n_param, d))
+    yf = np.array([f_model(x) for x in xf])
+    lpf = np.array([f_chi2(y) for y in yf])
+    su.fit(xf, yf, lpf)
+    z = flatten_poly(poly_spec_from_reference(su), 'poly.')
+    z['x_fit'], z['y_fit'], z['logp_fit'] = xf, yf, lpf
+    z['ydat'], z['prec'] = ydat, prec
+    xt = np.concatenate((rng.normal(size=(25, d)) * 0.7, rng.normal(size=(10, d)) * 3.))
+    lg = [den.logp_and_grad(x, use_surrogate=True) for x in xt]
+    z['xt'] = xt
+    z['logp'] = np.array([v[0] for v in lg])
+    z['grad'] = np.array([v[1] for v in lg])
+    z['su_f'] = np.array([su.fun(x)[0] for x in xt]).reshape(len(xt), m)
+    np.savez_compressed(os.path.join(out, 'pipeline.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -558,7 +602,7 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence)
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue

@@ -393,3 +393,40 @@ def test_multi_output_polymodel_batched_fun_and_jac(d, m):
     f_one, j_one = pm.fun_and_jac(x[5])
     np.testing.assert_allclose(f_one[0], f_ref[5], rtol=1e-10, atol=1e-10 * np.abs(f_ref).max())
     np.testing.assert_allclose(j_one[0], j_ref[5], rtol=1e-9, atol=1e-9 * np.abs(j_ref).max())
+
+
+def test_surrogate_plus_chi2_pipeline_matches_reference_density():
+    """SURVEY 8f-1 against a fixture recorded from the reference (tests/golden/pipeline.npz, make_golden.py:gen_pipeline):
+    ``Density(module_list=[model, chi2], surrogate_list=[PolyModel(linear, quadratic, cubic-2, cubic-3)])``, evaluated
+    with ``use_surrogate=True`` (core/density.py:487-566).  (1) The reference's fitted coefficients through
+    bfhip_polymodel_eval + bfhip_chi2_stage: logp and grad of the pipeline, inside and outside the bound.  (2) Our own
+    fit of the same data gives the same pipeline density."""
+    import os
+    from specio import rebuild_poly
+    from bayesfast_amd import PolyModel, PolyConfig, Chi2PipelineDensity
+    from bayesfast_amd.device import DevicePolyModel
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pipeline.npz'))
+    poly = rebuild_poly(z, 'poly.')
+    d, m = poly['input_size'], poly['output_size']
+    f, j = DevicePolyModel(poly).fun_and_jac(z['xt'])
+    np.testing.assert_allclose(f.cpu().numpy(), z['su_f'], rtol=1e-10, atol=1e-10)
+
+    class _Fixed(PolyModel):  # a PolyModel carrying the reference's coefficients
+        def poly_spec(self, use_bound=None):
+            return poly
+
+    cfgs = [PolyConfig('linear'), PolyConfig('quadratic'), PolyConfig('cubic-2', input_mask=[0, 2, 3, 5], output_mask=[0, 1, 3]),
+            PolyConfig('cubic-3', input_mask=[1, 2, 4, 5, 6], output_mask=[1, 2, 4])]
+    ref = Chi2PipelineDensity(_Fixed(cfgs, input_size=d, output_size=m), z['ydat'], prec=z['prec'])
+    lp, g = ref.logp_and_grad(z['xt'])
+    np.testing.assert_allclose(lp, z['logp'], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(g, z['grad'], rtol=1e-9, atol=1e-9 * np.abs(z['grad']).max())
+    lp1, g1 = ref.logp_and_grad(z['xt'][30])
+    np.testing.assert_allclose([lp1], [z['logp'][30]], rtol=1e-10)
+    np.testing.assert_allclose(g1, z['grad'][30], rtol=1e-9, atol=1e-9 * np.abs(z['grad']).max())
+    # our fit of the same (x, y) data: same density up to the fit's accuracy
+    su = PolyModel(cfgs, input_size=d, output_size=m)
+    su.fit(z['x_fit'], z['y_fit'], z['logp_fit'])
+    lp2, g2 = Chi2PipelineDensity(su, z['ydat'], prec=z['prec']).logp_and_grad(z['xt'])
+    np.testing.assert_allclose(lp2, z['logp'], rtol=1e-6, atol=1e-6 * np.abs(z['logp']).max())
+    np.testing.assert_allclose(g2, z['grad'], rtol=1e-5, atol=1e-6 * np.abs(z['grad']).max())
