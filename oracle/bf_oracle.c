@@ -703,6 +703,7 @@ static void step_size_update(bfo_chain *c, double accept_stat, int warmup) {
 typedef struct {
     double *q, *p, *v, *grad; /* (d,) each, one allocation at q */
     double energy, logp;
+    double u, vt, weight;     /* tempered samplers (TState, integration.py:98-222): tempering coordinate, its momentum, P(beta=1|x) */
 } lf_state;
 
 static lf_state state_alloc(int d) {
@@ -710,6 +711,7 @@ static lf_state state_alloc(int d) {
     s.q = (double *)malloc(sizeof(double) * (size_t)d * 4);
     s.p = s.q + d; s.v = s.q + 2 * d; s.grad = s.q + 3 * d;
     s.energy = s.logp = 0.;
+    s.u = s.vt = s.weight = 0.;
     return s;
 }
 static void state_free(lf_state *s) { free(s->q); s->q = NULL; }
@@ -717,6 +719,7 @@ static lf_state state_clone(const lf_state *a, int d) {
     lf_state s = state_alloc(d);
     memcpy(s.q, a->q, sizeof(double) * (size_t)d * 4);
     s.energy = a->energy; s.logp = a->logp;
+    s.u = a->u; s.vt = a->vt; s.weight = a->weight;
     return s;
 }
 
@@ -770,6 +773,7 @@ typedef struct {
     double *p_sum;      /* (d,) */
     double *prop_q;     /* (d,) proposal position */
     double prop_energy, prop_logp;
+    double prop_u, prop_weight; /* TProposal, tnuts.py:12-19 */
     double log_size, accept_sum;
     long n_proposals;
 } subtree;
@@ -782,7 +786,13 @@ typedef struct {
     double max_change, start_energy, max_energy_change;
     long n_leapfrog;
     int err; /* -3 logbern(NaN) */
+    /* tempered samplers: the base density and log xi (base_hmc.py:220-231); NULL for NUTS / HMC */
+    const bfo_density *base;
+    double logxi;
 } tree_ctx;
+
+static void tempered_step(const bfo_density *dn, const bfo_density *base, double logxi, const bfo_chain *c, double eps,
+                          const lf_state *s0, lf_state *s1);
 
 static void subtree_free(subtree *t) {
     if (t->has) {
@@ -817,8 +827,9 @@ static subtree single_step(tree_ctx *cx, const lf_state *left, double eps, int *
     subtree t;
     memset(&t, 0, sizeof(t));
     lf_state right = state_alloc(d);
-    leapfrog_chain(cx->dn, cx->ch, eps, left->q, left->p, left->grad, right.q, right.p, right.v, right.grad,
-                 &right.energy, &right.logp);
+    if (cx->base) tempered_step(cx->dn, cx->base, cx->logxi, cx->ch, eps, left, &right);
+    else leapfrog_chain(cx->dn, cx->ch, eps, left->q, left->p, left->grad, right.q, right.p, right.v, right.grad,
+                        &right.energy, &right.logp);
     cx->n_leapfrog += 1;
     if (bfo_trace_buf && bfo_trace_n + 8 <= bfo_trace_cap) {
         double *t = bfo_trace_buf + bfo_trace_n;
@@ -839,6 +850,7 @@ static subtree single_step(tree_ctx *cx, const lf_state *left, double eps, int *
         t.prop_q = (double *)malloc(sizeof(double) * (size_t)d);
         memcpy(t.prop_q, right.q, sizeof(double) * (size_t)d);
         t.prop_energy = right.energy; t.prop_logp = right.logp;
+        t.prop_u = right.u; t.prop_weight = right.weight;
         t.log_size = -energy_change; t.accept_sum = p_accept; t.n_proposals = 1;
         *diverging = 0;
         return t;
@@ -892,15 +904,18 @@ static subtree build_subtree(tree_ctx *cx, const lf_state *left, int depth, doub
         if (logbern(cx, t2.log_size - t.log_size)) { /* nuts.py:164-167 */
             memcpy(t.prop_q, t2.prop_q, sizeof(double) * (size_t)d);
             t.prop_energy = t2.prop_energy; t.prop_logp = t2.prop_logp;
+            t.prop_u = t2.prop_u; t.prop_weight = t2.prop_weight;
         } else {
             memcpy(t.prop_q, t1.prop_q, sizeof(double) * (size_t)d);
             t.prop_energy = t1.prop_energy; t.prop_logp = t1.prop_logp;
+            t.prop_u = t1.prop_u; t.prop_weight = t1.prop_weight;
         }
     } else { /* nuts.py:168-171 */
         memcpy(t.p_sum, t1.p_sum, sizeof(double) * (size_t)d);
         t.log_size = t1.log_size;
         memcpy(t.prop_q, t1.prop_q, sizeof(double) * (size_t)d);
         t.prop_energy = t1.prop_energy; t.prop_logp = t1.prop_logp;
+        t.prop_u = t1.prop_u; t.prop_weight = t1.prop_weight;
     }
     t.accept_sum = t1.accept_sum + t2.accept_sum;
     t.n_proposals = t1.n_proposals + t2.n_proposals;
@@ -910,22 +925,32 @@ static subtree build_subtree(tree_ctx *cx, const lf_state *left, int depth, doub
 }
 
 /* BaseHMC.astep with NUTS._hamiltonian_step; base_hmc.py:62-85, nuts.py:205-217, 24-103 */
-static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int warmup, int max_treedepth,
-                          double max_change, double *sample_out, double *st, long *n_leapfrog) {
+static void tempered_state(const bfo_density *dn, const bfo_density *base, double logxi, const bfo_chain *c, lf_state *s);
+
+static int nuts_iteration_t(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int warmup, int max_treedepth,
+                            double max_change, double *sample_out, double *st, long *n_leapfrog, const bfo_density *base,
+                            double logxi, double *u_io, double *st_t) {
     int d = c->d;
     tree_ctx cx;
     cx.dn = dn; cx.ch = c; cx.rng = rng; cx.d = d; cx.max_change = max_change; cx.max_energy_change = 0.;
     cx.n_leapfrog = 0; cx.err = 0;
+    cx.base = base; cx.logxi = logxi;
     /* p0 = metric.random(rng): metrics.py:83-86 */
     lf_state start = state_alloc(d);
     metric_random(c, rng, start.p);
     memcpy(start.q, c->q, sizeof(double) * (size_t)d);
+    if (base) { /* BaseTHMC.astep: base_hmc.py:233-262: u continues from the last iteration, v0 is one more normal draw */
+        start.u = *u_io;
+        bfo_rng_normal(rng, &start.vt, 1);
+        tempered_state(dn, base, logxi, c, &start);
+    } else {
     /* integrator.compute_state: integration.py:28-34 */
     bfo_logp_and_grad(dn, start.q, 0, &start.logp, start.grad);
     double kin = 0.;
     metric_velocity(c, start.p, start.v);
     for (int i = 0; i < d; ++i) kin += start.p[i] * start.v[i];
     start.energy = 0.5 * kin - start.logp;
+    }
     if (!isfinite(start.energy)) { state_free(&start); return -1; } /* base_hmc.py:72-76 */
     double step_size = exp(warmup ? c->log_step : c->log_bar);      /* step_size.py:25-29 */
 
@@ -937,6 +962,7 @@ static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int
     memcpy(prop_q, start.q, sizeof(double) * (size_t)d);
     memcpy(p_sum, start.p, sizeof(double) * (size_t)d);
     double prop_energy = start.energy, prop_logp = start.logp;
+    double prop_u = start.u, prop_weight = start.weight;
     int depth = 0;
     double log_size = 0., accept_sum = 0.;
     long n_proposals = 0;
@@ -963,6 +989,7 @@ static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int
             if (logbern(&cx, tree.log_size - log_size)) { /* nuts.py:81-83 */
                 memcpy(prop_q, tree.prop_q, sizeof(double) * (size_t)d);
                 prop_energy = tree.prop_energy; prop_logp = tree.prop_logp;
+                prop_u = tree.prop_u; prop_weight = tree.prop_weight;
             }
             { /* nuts.py:85 */
                 double a = log_size, b = tree.log_size, mx = a > b ? a : b, mn = a > b ? b : a;
@@ -1011,6 +1038,7 @@ static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int
         st[BFO_ST_ENERGY_CHANGE] = prop_energy - start.energy;
         st[BFO_ST_MAX_ENERGY_CHANGE] = cx.max_energy_change;
         st[BFO_ST_DIVERGING] = diverging;
+        if (base) { *u_io = prop_u; st_t[0] = prop_u; st_t[1] = prop_weight; } /* tnuts.py:21-32 */
         c->i_iter += 1;
         *n_leapfrog += cx.n_leapfrog;
     }
@@ -1018,6 +1046,117 @@ static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int
     free(prop_q);
     if (!rc && rng->exhausted) rc = -2;
     return rc;
+}
+
+static int nuts_iteration(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, int warmup, int max_treedepth,
+                          double max_change, double *sample_out, double *st, long *n_leapfrog) {
+    return nuts_iteration_t(dn, c, rng, warmup, max_treedepth, max_change, sample_out, st, n_leapfrog, NULL, 0., NULL, NULL);
+}
+
+/* ================= tempered integrator: samplers/hmc_utils/integration.py:98-222 ================================ */
+static double t_beta(double u) { return 1 / (1 + exp(-u)); }                                   /* :108-110 */
+static double t_dbeta(double u) { double e = exp(-u); return e / ((1 + e) * (1 + e)); }         /* :113-116 */
+static double t_pot(double u) { return u + 2 * log(1 + exp(-u)); }                              /* :119-124 */
+static double t_dpot(double u) { double e = exp(u); return (e - 1) / (e + 1); }                 /* :127-130 */
+
+/* phi, dphi = -logp_and_grad(q); psi, dpsi = -(base.logp_and_grad(q) + logxi): base_hmc.py:227-231 */
+static void t_potentials(const bfo_density *dn, const bfo_density *base, double logxi, const double *q, double *phi, double *dphi,
+                         double *psi, double *dpsi, int d) {
+    bfo_logp_and_grad(dn, q, 0, phi, dphi);
+    bfo_logp_and_grad(base, q, 0, psi, dpsi);
+    *phi = -*phi;
+    *psi = -(*psi + logxi);
+    for (int i = 0; i < d; ++i) { dphi[i] = -dphi[i]; dpsi[i] = -dpsi[i]; }
+}
+
+/* compute_state: integration.py:132-151 (q, p, u, vt given) */
+static void tempered_state(const bfo_density *dn, const bfo_density *base, double logxi, const bfo_chain *c, lf_state *s) {
+    int d = c->d;
+    double *dphi = (double *)malloc(sizeof(double) * (size_t)d * 2), *dpsi = dphi + d, phi, psi;
+    t_potentials(dn, base, logxi, s->q, &phi, dphi, &psi, dpsi, d);
+    metric_velocity(c, s->p, s->v);
+    double kin = 0.;
+    for (int i = 0; i < d; ++i) kin += s->p[i] * s->v[i];
+    double kinetic = 0.5 * kin + s->vt * s->vt / 2;
+    double beta = t_beta(s->u);
+    s->energy = kinetic + (beta * phi + (1 - beta) * psi + t_pot(s->u));
+    s->logp = -phi;
+    double delta = phi - psi;
+    s->weight = (delta == 0) ? 1. : delta / expm1(delta);
+    free(dphi);
+}
+
+/* _step: integration.py:153-222 */
+static void tempered_step(const bfo_density *dn, const bfo_density *base, double logxi, const bfo_chain *c, double eps,
+                          const lf_state *s0, lf_state *s1) {
+    int d = c->d;
+    double dt = 0.5 * eps;
+    double *dphi = (double *)malloc(sizeof(double) * (size_t)d * 2), *dpsi = dphi + d, phi, psi;
+    double u = s0->u, vt = s0->vt;
+    memcpy(s1->q, s0->q, sizeof(double) * (size_t)d);
+    memcpy(s1->p, s0->p, sizeof(double) * (size_t)d);
+    memcpy(s1->v, s0->v, sizeof(double) * (size_t)d);
+    u += vt * dt;                                                        /* :173 */
+    for (int i = 0; i < d; ++i) s1->q[i] += dt * s1->v[i];              /* :176 */
+    t_potentials(dn, base, logxi, s1->q, &phi, dphi, &psi, dpsi, d);     /* :180-181 */
+    double beta = t_beta(u), dbeta = t_dbeta(u), dU = t_dpot(u);
+    double dpot_du = dbeta * (phi - psi) + dU;                            /* :185 */
+    vt += -dpot_du * eps;                                                 /* :190 */
+    for (int i = 0; i < d; ++i) s1->p[i] += eps * -(beta * dphi[i] + (1 - beta) * dpsi[i]); /* :186,193 */
+    u += vt * dt;                                                         /* :198 */
+    metric_velocity(c, s1->p, s1->v);                                     /* :201 */
+    for (int i = 0; i < d; ++i) s1->q[i] += dt * s1->v[i];               /* :202 */
+    double kin = 0.;
+    for (int i = 0; i < d; ++i) kin += s1->p[i] * s1->v[i];
+    double kinetic = 0.5 * kin + vt * vt / 2;                              /* :205-206 */
+    t_potentials(dn, base, logxi, s1->q, &phi, dphi, &psi, dpsi, d);      /* :208-209 */
+    beta = t_beta(u);
+    s1->energy = (beta * phi + (1 - beta) * psi + t_pot(u)) + kinetic;    /* :210-213 */
+    s1->logp = -phi;
+    double delta = phi - psi;
+    s1->weight = (delta == 0) ? 1. : delta / expm1(delta);               /* :219-220 */
+    s1->u = u;
+    s1->vt = vt;
+    free(dphi);
+}
+
+/* TState after compute_state and after steps of the given sizes, for the fixtures: out rows of (2 d + 5): q, p, u, vt, weight, energy, logp */
+void bfo_tempered_states(const bfo_density *dn, const bfo_density *base, double logxi, const double *var, const double *q0,
+                         const double *p0, double u0, double v0, const double *eps, int n_step, double *out) {
+    int d = dn->d;
+    bfo_chain c;
+    memset(&c, 0, sizeof(c));
+    c.d = d; c.var = (double *)var;
+    lf_state a = state_alloc(d), b = state_alloc(d);
+    memcpy(a.q, q0, sizeof(double) * (size_t)d);
+    memcpy(a.p, p0, sizeof(double) * (size_t)d);
+    a.u = u0; a.vt = v0;
+    tempered_state(dn, base, logxi, &c, &a);
+    for (int k = 0; k <= n_step; ++k) {
+        double *o = out + (size_t)k * (2 * d + 5);
+        memcpy(o, a.q, sizeof(double) * (size_t)d);
+        memcpy(o + d, a.p, sizeof(double) * (size_t)d);
+        o[2 * d] = a.u; o[2 * d + 1] = a.vt; o[2 * d + 2] = a.weight; o[2 * d + 3] = a.energy; o[2 * d + 4] = a.logp;
+        if (k == n_step) break;
+        tempered_step(dn, base, logxi, &c, eps[k], &a, &b);
+        lf_state t = a; a = b; b = t;
+    }
+    state_free(&a); state_free(&b);
+}
+
+/* TNUTS: BaseTHMC.astep (base_hmc.py:233-262) around the NUTS tree with the tempered integrator (tnuts.py).
+ * u: in = u_0 of the first iteration (the reference draws it from numpy's global generator, base_hmc.py:241), out = last u.
+ * stats: (n_run, BFO_N_NSTATS); stats_t: (n_run, 2) = u, weight of every sample. */
+int bfo_tnuts_run(const bfo_density *dn, const bfo_density *base, double logxi, bfo_chain *c, bfo_rng *rng, double *u, long n_run,
+                  long n_warmup, int max_treedepth, double max_change, double *samples, double *stats, double *stats_t) {
+    long nl = 0;
+    for (long i = 0; i < n_run; ++i) {
+        int warmup = c->i_iter < n_warmup;
+        int rc = nuts_iteration_t(dn, c, rng, warmup, max_treedepth, max_change, samples + (size_t)i * c->d,
+                                  stats + (size_t)i * BFO_N_NSTATS, &nl, base, logxi, u, stats_t + (size_t)i * 2);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int bfo_nuts_run(const bfo_density *dn, bfo_chain *c, bfo_rng *rng, long n_run, long n_warmup,

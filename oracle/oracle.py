@@ -558,3 +558,55 @@ def bridge_score(logr, a, b):
     c = logsumexp(logr + a - logsumexp(np.array((logr + a, np.zeros_like(a))), axis=0))
     d = logsumexp(-logr + b - logsumexp(np.array((-logr + b, np.zeros_like(b))), axis=0))
     return c - d
+
+
+# ---- tempered samplers ---------------------------------------------------------
+def gaussian_base_spec(mean, cov, logz_offset=0.):
+    """Density spec (no bound) of the Gaussian base density N(mean, cov) as a quadratic polynomial:
+    logp = c0 + lin . x + sum_{j<=k} a[j,k] x_j x_k."""
+    mean = np.asarray(mean, dtype=np.float64)
+    prec = np.linalg.inv(np.atleast_2d(cov))
+    d = mean.size
+    lin = prec @ mean
+    c0 = -0.5 * mean @ prec @ mean - 0.5 * (d * np.log(2 * np.pi) + np.linalg.slogdet(np.atleast_2d(cov))[1]) + logz_offset
+    quad = np.zeros((d, d))
+    iu = np.triu_indices(d)
+    quad[iu] = (-0.5 * prec)[iu] * np.where(iu[0] == iu[1], 1., 2.)
+    poly = dict(input_size=d, output_size=1, use_bound=False,
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.array([0]), coef=np.concatenate(([c0], lin))[None]),
+                         dict(order='quadratic', input_mask=np.arange(d), output_mask=np.array([0]), coef=quad[None])])
+    return dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=poly, use_decay=False)
+
+
+def tempered_states(spec, base_spec, logxi, var, q0, p0, u0, v0, eps):
+    """TState rows (q, p, u, v, weight, energy, logp) after compute_state and after each step (integration.py:132-222)."""
+    dn, k1 = density_struct(spec)
+    bs, k2 = density_struct(base_spec)
+    var, q0, p0, eps = _f64(var), _f64(q0), _f64(p0), _f64(eps)
+    d = q0.size
+    out = np.empty((eps.size + 1, 2 * d + 5))
+    f = lib().bfo_tempered_states
+    f.restype = None
+    f(C.byref(dn), C.byref(bs), C.c_double(logxi), _p(var), _p(q0), _p(p0), C.c_double(u0), C.c_double(v0), _p(eps), C.c_int(eps.size),
+      _p(out))
+    return dict(q=out[:, :d], p=out[:, d:2 * d], u=out[:, 2 * d], v=out[:, 2 * d + 1], weight=out[:, 2 * d + 2],
+                energy=out[:, 2 * d + 3], logp=out[:, 2 * d + 4])
+
+
+def tnuts_run(spec, base_spec, logxi, chain, rng, u0, n_run, n_warmup, max_treedepth=10, max_change=1000.):
+    """TNUTS (samplers/tnuts.py, base_hmc.py:220-262).  Returns samples, stats dict (NUTS fields + 'u', 'weight'), last u."""
+    dn, k1 = density_struct(spec)
+    bs, k2 = density_struct(base_spec)
+    samples = np.empty((n_run, chain.d))
+    stats = np.empty((n_run, len(NSTATS)))
+    st_t = np.empty((n_run, 2))
+    u = C.c_double(u0)
+    f = lib().bfo_tnuts_run
+    f.restype = C.c_int
+    rc = f(C.byref(dn), C.byref(bs), C.c_double(logxi), chain._c, C.byref(rng[0]), C.byref(u), C.c_long(int(n_run)),
+           C.c_long(int(n_warmup)), C.c_int(int(max_treedepth)), C.c_double(max_change), _p(samples), _p(stats), _p(st_t))
+    if rc:
+        raise RuntimeError({-1: 'bad initial energy', -2: 'replay stream exhausted', -3: "logp can't be nan"}.get(rc, str(rc)))
+    st = {k: stats[:, i].copy() for i, k in enumerate(NSTATS)}
+    st['u'], st['weight'] = st_t[:, 0].copy(), st_t[:, 1].copy()
+    return samples, st, u.value

@@ -131,8 +131,8 @@ class LoggingGenerator:
         self.normals = []
         self.uniforms = []
 
-    def normal(self, size=None):
-        v = self._g.normal(size=size)
+    def normal(self, loc=0., scale=1., size=None):
+        v = self._g.normal(loc, scale, size=size)
         self.normals.extend(np.atleast_1d(v).tolist())
         return v
 
@@ -594,6 +594,79 @@ def gen_pipeline(bf, out):
     np.savez_compressed(os.path.join(out, 'pipeline.npz'), **z)
 
 
+def gen_tempered(bf, out):
+    """Tempered samplers: TCpuLeapfrogIntegrator states (integration.py:98-222) and TNUTS trajectories with
+    logged draws (tnuts.py, base_hmc.py:220-262) on a surrogate target with a Gaussian base density.  (THMC is not
+    recorded: the reference's THTrace constructor raises, samplers/sample_trace.py:600.)"""
+    from bayesfast.samplers.sample_trace import TNTrace
+    from bayesfast.samplers.tnuts import TNUTS
+    from bayesfast.samplers.hmc_utils.integration import TCpuLeapfrogIntegrator
+    from bayesfast.samplers.hmc_utils.metrics import QuadMetricDiag
+    z = {}
+    d = 6
+    den, rng = make_density(bf, d, 57)
+    spec = density_spec_from_reference(den)
+    z.update(flatten_spec(spec, 't6.'))
+
+    def lg(x):
+        return den.logp_and_grad(x, original_space=False, use_surrogate=True)
+
+    bmean = rng.normal(size=d) * 0.2
+    L = np.eye(d) * 1.3 + 0.2 * np.tril(rng.normal(size=(d, d)), -1)
+    bcov = L @ L.T
+    bprec = np.linalg.inv(bcov)
+    blogdet = np.linalg.slogdet(bcov)[1]
+
+    def blogp(x):
+        r = x - bmean
+        return -0.5 * r @ bprec @ r - 0.5 * (d * np.log(2 * np.pi) + blogdet)
+
+    base = bf.DensityLite(logp=blogp, grad=lambda x: -bprec @ (x - bmean), input_size=d)
+    logxi = 0.37
+    z['t6.base_mean'], z['t6.base_cov'], z['t6.logxi'] = bmean, bcov, np.asarray(logxi)
+    # integrator states
+    var = rng.uniform(0.5, 2., size=d)
+
+    def lgb(x):
+        lp, g = base.logp_and_grad(x, original_space=False)
+        return lp + logxi, g
+
+    integ = TCpuLeapfrogIntegrator(QuadMetricDiag(var), lg, lgb)
+    q0, p0 = rng.normal(size=d) * 0.5, rng.normal(size=d)
+    u0, v0 = 0.4, -0.7
+    s0 = integ.compute_state(np.append(u0, q0), np.append(v0, p0))
+    s1 = integ.step(0.11, s0)
+    s2 = integ.step(-0.06, s1)
+    for tag, st in (('s0', s0), ('s1', s1), ('s2', s2)):
+        for fld in ('q', 'u', 'p', 'v', 'weight', 'energy', 'logp'):
+            z['t6.lf.%s.%s' % (tag, fld)] = np.asarray(getattr(st, fld), dtype=float)
+    z['t6.lf.var'], z['t6.lf.eps'] = var, np.array([0.11, -0.06])
+    z['t6.lf.q0'], z['t6.lf.p0'], z['t6.lf.u0v0'] = q0, p0, np.array([u0, v0])
+    # TNUTS trajectories
+    n_chain, n_iter, n_warmup = 2, 40, 25
+    x0 = rng.normal(size=(n_chain, d)) * 0.5
+    z['t6.x0'] = x0
+    z['t6.n_iter'], z['t6.n_warmup'] = np.asarray(n_iter), np.asarray(n_warmup)
+    for c in range(n_chain):
+        np.random.seed(100 + c)  # u_0 of the first iteration comes from numpy's global generator (base_hmc.py:241)
+        u_first = np.random.normal(0, 1)
+        np.random.seed(100 + c)
+        t = TNTrace(density_base=base, logxi=logxi, n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, x_0=x0.copy(),
+                    random_generator=2468)
+        t._init_chain(c)
+        log = LoggingGenerator(t._random_generator)
+        t._random_generator = log
+        TNUTS(logp_and_grad=lg, sample_trace=t).run(verbose=False)
+        k = 't6.tnuts%d.' % c
+        z[k + 'u_first'] = np.asarray(u_first)
+        z[k + 'samples'] = t.samples
+        z[k + 'normals'] = np.array(log.normals)
+        z[k + 'uniforms'] = np.array(log.uniforms)
+        for si in t.stats.stats_items:
+            z[k + si] = np.array(getattr(t.stats, '_' + si), dtype=float)
+    np.savez_compressed(os.path.join(out, 'tempered.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -602,7 +675,7 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline)
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, tempered=gen_tempered)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue
