@@ -9,11 +9,11 @@ from .modules import PolyConfig, PolyModel
 from .core.module import Surrogate
 from .core.density import SurrogateDensity, Chi2PipelineDensity
 from .core.sample import sample
-from .samplers import NTrace, HTrace, TraceTuple
+from .samplers import NTrace, HTrace, TNTrace, GaussianBase, TraceTuple
 from .utils import SystematicResampler
 from .core.refit import select_fit_points, importance_weights
 from .transforms import SIT
 from .evidence import GBS, bridge
 
-__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'Chi2PipelineDensity', 'sample', 'NTrace', 'HTrace', 'TraceTuple',
+__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'Chi2PipelineDensity', 'sample', 'NTrace', 'HTrace', 'TNTrace', 'GaussianBase', 'TraceTuple',
            'SystematicResampler', 'select_fit_points', 'importance_weights', 'SIT', 'GBS', 'bridge']

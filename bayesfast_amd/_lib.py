@@ -43,6 +43,10 @@ class SamplerConfig(C.Structure):
                 ('chain_layout', C.c_int)]
 
 
+class Tempering(C.Structure):  # bfhip_tempering
+    _fields_ = [('base_S', C.c_void_p), ('base_lin', C.c_void_p), ('base_c0', C.c_double), ('logxi', C.c_double)]
+
+
 class PolymodelDesc(C.Structure):  # bfhip_polymodel_desc
     _fields_ = [('d', C.c_int), ('m', C.c_int), ('c0', C.POINTER(C.c_double)), ('lin', C.POINTER(C.c_double)),
                 ('quad', C.POINTER(C.c_double)), ('use_bound', C.c_int), ('mu', C.POINTER(C.c_double)),
@@ -66,6 +70,8 @@ SYMBOLS = {
     'bfhip_leapfrog': (C.c_int, [_vp, C.c_int] + [_vp] * 8),
     'bfhip_sampler_run': (C.c_int, [_vp, C.POINTER(SamplerConfig), C.c_int, C.c_int, _vp, _vp, _vp, C.c_int,
                                     C.c_int, _vp, _vp, _vp]),
+    'bfhip_tnuts_run': (C.c_int, [_vp, C.POINTER(SamplerConfig), C.POINTER(Tempering), C.c_int, C.c_int, _vp, _vp, _vp, _vp,
+                                  C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     'bfhip_rng_seed': (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint64, _vp]),
     'bfhip_chain_init': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp, C.c_double, C.c_int, _vp, _vp]),
     'bfhip_metric_init_full': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_double, _vp, _vp]),

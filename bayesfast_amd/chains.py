@@ -133,6 +133,50 @@ class DeviceChains:
             self.raise_on_error()
         return samples, stats
 
+    def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
+                     target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,
+                     update_window=1, doubling=True, check=True):
+        """TNUTS (samplers/tnuts.py; ``bfhip_tnuts_run``) with a Gaussian base density N(base_mean, base_cov) and
+        ``logxi`` (``TNTrace(density_base=..., logxi=...)``, samplers/sample_trace.py:540-567).  ``u_0`` (n_chain,): the
+        tempering coordinate at the start of a fresh run (default: standard normal draws, as the reference takes them
+        from NumPy's global generator, base_hmc.py:241); later calls continue from the chains' own u.
+
+        Returns (samples (n_chain, n_run, d), stats (n_chain, n_run, 11), stats_t (n_chain, n_run, 2) = u and weight)."""
+        torch = _torch()
+        self.density.upload_if_needed()
+        d = self.d
+        mean = np.asarray(base_mean, dtype=np.float64).reshape(d)
+        cov = np.asarray(base_cov, dtype=np.float64).reshape(d, d)
+        prec = np.linalg.inv(cov)
+        tp = _lib.Tempering()
+        S = self.ctx.tensor(-prec)                     # log N = c0 + lin.x + x.S x / 2
+        lin = self.ctx.tensor(prec @ mean)
+        tp.base_S, tp.base_lin = S.data_ptr(), lin.data_ptr()
+        tp.base_c0 = float(-0.5 * mean @ prec @ mean - 0.5 * (d * np.log(2 * np.pi) + np.linalg.slogdet(cov)[1]))
+        tp.logxi = float(logxi)
+        if getattr(self, 'tu', None) is None:
+            if u_0 is None:
+                u_0 = np.random.normal(0, 1, size=self.n_chain)
+            self.tu = self.ctx.tensor(np.asarray(u_0, dtype=np.float64).reshape(self.n_chain))
+        cfg = _lib.SamplerConfig()
+        cfg.sampler, cfg.n_warmup, cfg.max_treedepth, cfg.n_int_step = 0, int(n_warmup), int(max_treedepth), 1
+        cfg.max_change = float(max_change)
+        cfg.target_accept, cfg.gamma, cfg.k, cfg.t_0 = float(target_accept), float(gamma), float(k), float(t_0)
+        cfg.adapt_step_size, cfg.adapt_metric = int(bool(adapt_step_size)), int(bool(adapt_metric))
+        cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
+        n_run = int(n_run)
+        samples = self.ctx.empty((self.n_chain, n_run, d))
+        stats = self.ctx.empty((self.n_chain, n_run, _lib.STAT_STRIDE))
+        stats_t = self.ctx.empty((self.n_chain, n_run, 2))
+        _lib.check(self.ctx._lib.bfhip_tnuts_run(
+            self.ctx.handle, C.byref(cfg), C.byref(tp), self.n_chain, self.i_iter + n_run, _ptr(self.rng), _ptr(self.sc),
+            _ptr(self.vec), _ptr(self.tu), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(stats_t), _ptr(self.n_leapfrog)))
+        self.i_iter += n_run
+        self._step_flag = None
+        if check:
+            self.raise_on_error()
+        return samples, stats, stats_t
+
     def _note_trees(self, stats, sampler, n_last=64, share=0.98):
         """Queue, behind the launches of this run, the answer to "did the chains run in step?": at least ``share`` of the
         NUTS trees of the last ``n_last`` iterations (all chains) had the most common size.  The flag travels to pinned

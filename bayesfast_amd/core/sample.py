@@ -2,7 +2,7 @@
 running all chains of this rank in fused device launches instead of one worker process per chain."""
 import numpy as np
 
-from ..samplers.sample_trace import NTrace, HTrace, TraceTuple
+from ..samplers.sample_trace import NTrace, HTrace, TNTrace, TraceTuple
 from .density import SurrogateDensity
 from .. import parallel
 
@@ -15,7 +15,9 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
 
     density : SurrogateDensity
     sample_trace : NTrace / HTrace / dict of their keyword arguments / TraceTuple (continue the chains)
-    sampler : 'NUTS' or 'HMC' (ignored when ``sample_trace`` is a trace object)
+    sampler : 'NUTS', 'HMC' or 'TNUTS' (ignored when ``sample_trace`` is a trace object; 'TNUTS' needs ``density_base`` and
+        ``logxi`` among the trace arguments, samplers/sample_trace.py:607-629).  'THMC' raises: the reference's THTrace
+        cannot be constructed (samplers/sample_trace.py:600)
     n_run : number of iterations to run now (default: up to ``n_iter``)
     parallel_backend : accepted for signature compatibility and ignored; chains shard over the ranks of the
         default ``torch.distributed`` process group instead (one process per GPU)
@@ -38,7 +40,9 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
             trace = NTrace(**kw)
         elif sampler == 'HMC':
             trace = HTrace(**kw)
-        elif sampler in ('TNUTS', 'THMC', 'Ensemble'):
+        elif sampler == 'TNUTS':
+            trace = TNTrace(**kw)
+        elif sampler in ('THMC', 'Ensemble'):
             raise NotImplementedError
         else:
             raise ValueError('unexpected value for sampler.')
@@ -83,17 +87,23 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     if done + n_run > trace.n_iter:
         trace.n_iter = done + n_run
     step = n_run if not iters_per_launch else int(iters_per_launch)
-    ss, sts = [], []
+    ss, sts, stts = [], [], []
     left = n_run
     while left > 0:
         k = min(step, left)
-        s, st = chains.run(k, trace._sampler, check=False, **trace.run_kwargs())  # queued; errors are raised below
+        if isinstance(trace, TNTrace):
+            s, st, stt = chains.run_tempered(k, trace.density_base.mean, trace.density_base.cov, logxi=trace.logxi, check=False,
+                                             **trace.run_kwargs())
+            stts.append(stt)
+        else:
+            s, st = chains.run(k, trace._sampler, check=False, **trace.run_kwargs())  # queued; errors are raised below
         ss.append(s)
         sts.append(st)
         left -= k
     chains.raise_on_error()
     s = ss[0] if len(ss) == 1 else torch.cat(ss, 1)
     st = sts[0] if len(sts) == 1 else torch.cat(sts, 1)
+    stt = None if not stts else (stts[0] if len(stts) == 1 else torch.cat(stts, 1))
     # boundary conversions on the device (core/sample.py:175-177); nothing crosses to the host here
     s_orig = density.to_original_device(s)
     lp_orig = density.to_original_density_device(st[:, :, 0], s)
@@ -105,10 +115,12 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
         s = s_new
         st = torch.cat([chains.ctx.tensor(prev.device('stats')), st], 1)
         lp_orig = torch.cat([chains.ctx.tensor(prev.device('logp_original')), lp_orig], 1)
+        if stt is not None:
+            stt = torch.cat([chains.ctx.tensor(prev.device('stats_t')), stt], 1)
     if verbose:
-        col = 3 if trace._sampler == 'NUTS' else 2
+        col = 2 if trace._sampler == 'HMC' else 3
         nl = parallel.all_reduce_sum(st[:, -n_run:, col].sum().reshape(1))
         if rank == 0:
             print(' sampling finished [ {} / {} ], {} chains, {} leapfrog steps.'.format(s.shape[1], trace.n_iter,
                                                                                          trace.n_chain, int(nl.item())))
-    return TraceTuple(trace, s, st, s_orig, lp_orig, chains)
+    return TraceTuple(trace, s, st, s_orig, lp_orig, chains, stats_t=stt)

@@ -1,3 +1,3 @@
-from .sample_trace import NTrace, HTrace, TraceTuple, ChainView, _get_step_size, _get_metric
+from .sample_trace import NTrace, HTrace, TNTrace, GaussianBase, TraceTuple, ChainView, _get_step_size, _get_metric
 
-__all__ = ['NTrace', 'HTrace', 'TraceTuple', 'ChainView', '_get_step_size', '_get_metric']
+__all__ = ['NTrace', 'HTrace', 'TNTrace', 'GaussianBase', 'TraceTuple', 'ChainView', '_get_step_size', '_get_metric']

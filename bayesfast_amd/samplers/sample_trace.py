@@ -10,7 +10,7 @@ import numpy as np
 
 from .. import _lib
 
-__all__ = ['NTrace', 'HTrace', 'TraceTuple', 'ChainView', '_get_step_size', '_get_metric']
+__all__ = ['NTrace', 'HTrace', 'TNTrace', 'GaussianBase', 'TraceTuple', 'ChainView', '_get_step_size', '_get_metric']
 
 
 class _HTrace:
@@ -132,6 +132,40 @@ class NTrace(_HTrace):
         return dict(super().run_kwargs(), max_treedepth=self.max_treedepth)
 
 
+class GaussianBase:
+    """Base density of the tempered samplers (``TNTrace(density_base=...)``): the Gaussian N(mean, cov) in the sampler's
+    space.  (The reference accepts any Density there, samplers/sample_trace.py:540-557; the device path covers quadratic
+    log-densities, of which this is the one in use: a Gaussian approximation of the posterior.)"""
+
+    def __init__(self, mean, cov):
+        self.mean = np.atleast_1d(np.asarray(mean, dtype=np.float64))
+        self.cov = np.atleast_2d(np.asarray(cov, dtype=np.float64))
+        if self.cov.shape != (self.mean.size, self.mean.size):
+            raise ValueError('invalid value for density_base.')
+
+    def logp(self, x):
+        r = np.asarray(x, dtype=np.float64) - self.mean
+        d = self.mean.size
+        return -0.5 * np.einsum('...i,ij,...j->...', r, np.linalg.inv(self.cov), r) - 0.5 * (
+            d * np.log(2 * np.pi) + np.linalg.slogdet(self.cov)[1])
+
+
+class TNTrace(NTrace):
+    """Trace options of the tempered NUTS sampler (samplers/sample_trace.py:540-567,607-629): ``NTrace`` plus the base
+    density and ``logxi``."""
+    _sampler = 'TNUTS'
+
+    def __init__(self, density_base, logxi=0., **kwargs):
+        if not isinstance(density_base, GaussianBase):
+            raise ValueError('invalid value for density_base.')
+        self.density_base = density_base
+        try:
+            self.logxi = float(logxi)
+        except Exception:
+            raise ValueError('invalid value for logxi.')
+        super().__init__(**kwargs)
+
+
 class HTrace(_HTrace):
     """Trace options of the static HMC sampler (samplers/sample_trace.py:458-497)."""
     _sampler = 'HMC'
@@ -201,7 +235,7 @@ class ChainView:
     @property
     def n_call(self):
         t = self._tt
-        if t.sampler == 'NUTS':  # samplers/sample_trace.py:529-530
+        if t.sampler in ('NUTS', 'TNUTS'):  # samplers/sample_trace.py:529-530
             return int(t._stats[self.chain_id, 1:, t._stat_items.index('tree_size')].sum()) + t.i_iter + 1
         return t.i_iter * (t._trace.n_int_step + 1) + 1  # :487-489
 
@@ -222,11 +256,13 @@ class TraceTuple:
 
     _FIELDS = ('samples', 'stats', 'samples_original', 'logp_original')
 
-    def __init__(self, trace, samples, stats, samples_original, logp_original, chains=None):
+    def __init__(self, trace, samples, stats, samples_original, logp_original, chains=None, stats_t=None):
         self._trace = trace
         self.sampler = trace._sampler
-        self._stat_items = _lib.NSTATS if self.sampler == 'NUTS' else _lib.HSTATS
+        self._stat_items = _lib.HSTATS if self.sampler == 'HMC' else _lib.NSTATS
         self._parts = dict(samples=samples, stats=stats, samples_original=samples_original, logp_original=logp_original)
+        if stats_t is not None:  # TNUTS: (u, weight) of every sample (TNStepStats)
+            self._parts['stats_t'] = stats_t
         self._host = {}
         self._chains = chains  # DeviceChains of this rank
 
@@ -290,12 +326,14 @@ class TraceTuple:
     @property
     def n_call(self):
         st = self._stats
-        if self.sampler == 'NUTS':  # samplers/sample_trace.py:529-530, summed over chains
+        if self.sampler in ('NUTS', 'TNUTS'):  # samplers/sample_trace.py:529-530, summed over chains
             return int(st[:, 1:, self._stat_items.index('tree_size')].sum()) + self.n_chain * (self.i_iter + 1)
         return self.n_chain * (self.i_iter * (self._trace.n_int_step + 1) + 1)  # :487-489
 
     def stat(self, name):
-        """(n_chain, i_iter) array of one statistic by its reference name."""
+        """(n_chain, i_iter) array of one statistic by its reference name ('u' and 'weight' for TNUTS included)."""
+        if name in ('u', 'weight') and 'stats_t' in self._parts:
+            return self._array('stats_t')[:, :, ('u', 'weight').index(name)]
         return self._stats[:, :, self._stat_items.index(name)]
 
     def get(self, since_iter=None, include_warmup=False, original_space=True, return_type='samples', flatten=True):

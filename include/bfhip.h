@@ -197,6 +197,28 @@ int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_cha
                       uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
                       double *stats, unsigned long long *n_leapfrog);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tempered NUTS: TNUTS (samplers/tnuts.py:15-41) = BaseTHMC.astep
+ * (samplers/hmc_utils/base_hmc.py:220-262) + the NUTS tree + TCpuLeapfrogIntegrator (samplers/hmc_utils/integration.py:98-222).
+ * The target is the uploaded surrogate density (common surrogate: linear + quadratic configs with the bound, d <= 64,
+ * diagonal metric); the base density of TNTrace(density_base=..., logxi=...) (samplers/sample_trace.py:540-567,607-629) is a
+ * quadratic log-density  c0 + lin.x + x.S x / 2  given by DEVICE arrays (e.g. a Gaussian).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const double *base_S;    /* (d,d) symmetric, device */
+    const double *base_lin;  /* (d,), device */
+    double base_c0;
+    double logxi;            /* _TTrace.logxi */
+} bfhip_tempering;
+
+/* As bfhip_sampler_run (sampler = NUTS), plus: u (C,) the tempering coordinate of every chain (in: u_0 -- the reference draws
+ * it from numpy's global generator, base_hmc.py:241 --, out: u of the last sample); stats_t (C,n_out,2) = (u, weight) of every
+ * sample (TNStepStats, samplers/hmc_utils/stats.py).  One normal draw more per iteration than NUTS (v_0, base_hmc.py:245).
+ * THMC is not offered: the reference's THTrace constructor raises (samplers/sample_trace.py:600). */
+int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, const bfhip_tempering *tp, int n_chain, int iter_end,
+                    uint64_t *rng, double *sc, double *vec, double *u, int iter_out0, int n_out, double *samples, double *stats,
+                    double *stats_t, unsigned long long *n_leapfrog);
+
 /* Fills rng (C,4) with xoshiro256++ states for streams first_stream .. first_stream+C-1 of `seed`
  * (counterpart of utils/random.py:20-32 spawn_generator: one independent stream per GLOBAL chain index). */
 int bfhip_rng_seed(bfhip_ctx *ctx, int n_chain, uint64_t seed, uint64_t first_stream, uint64_t *rng);

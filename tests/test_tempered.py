@@ -49,3 +49,67 @@ def test_oracle_tnuts_replays_reference_trajectories(fx, c):
     for f in ('u', 'weight', 'logp', 'energy', 'mean_tree_accept', 'step_size', 'step_size_bar', 'energy_change', 'max_energy_change'):
         np.testing.assert_allclose(st[f], fx[k + f], rtol=1e-7, atol=1e-8, err_msg=f)
     assert rng[0].i_normal == fx[k + 'normals'].size and rng[0].i_uniform == fx[k + 'uniforms'].size
+
+
+@pytest.mark.gpu
+def test_device_tnuts_matches_oracle_on_shared_streams(fx):
+    """bfhip_tnuts_run against the oracle's TNUTS on the same xoshiro256++ streams: tree depth / size / divergence exactly,
+    positions, u and weights to 1e-8 on the head of the run (17 chains: a ragged workgroup)."""
+    from oracle import oracle as orc
+    from bayesfast_amd.device import get_context, DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd import _lib
+    spec, base, logxi = _specs(fx)
+    ctx = get_context(0)
+    rng = np.random.default_rng(21)
+    n_chain, n_iter, n_warmup = 17, 30, 20
+    x0 = rng.normal(size=(n_chain, spec['d'])) * 0.5
+    u0 = rng.normal(size=n_chain)
+    dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=99)
+    s, st, stt = dc.run_tempered(n_iter, fx['t6.base_mean'], fx['t6.base_cov'], logxi=logxi, u_0=u0, n_warmup=n_warmup)
+    s, st, stt = s.cpu().numpy(), st.cpu().numpy(), stt.cpu().numpy()
+    nl = 0
+    for i in (0, 5, 16):
+        so, sto, _ = orc.tnuts_run(spec, base, logxi, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=99, stream=i), u0[i], n_iter, n_warmup)
+        for f in ('tree_depth', 'tree_size', 'diverging'):
+            assert np.array_equal(st[i, :, _lib.NSTATS.index(f)], sto[f]), (i, f)
+        np.testing.assert_allclose(s[i, :8], so[:8], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(stt[i, :8, 0], sto['u'][:8], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(stt[i, :8, 1], sto['weight'][:8], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
+        for f in ('logp', 'energy', 'step_size'):
+            np.testing.assert_allclose(st[i, :8, _lib.NSTATS.index(f)], sto[f][:8], rtol=1e-8, atol=1e-8, err_msg=f)
+    assert dc.total_leapfrog == int(st[:, :, _lib.NSTATS.index('tree_size')].sum())
+    # resume: a second call continues the chains (u included)
+    s2, st2, stt2 = dc.run_tempered(5, fx['t6.base_mean'], fx['t6.base_cov'], logxi=logxi, n_warmup=n_warmup)
+    so, sto, _ = orc.tnuts_run(spec, base, logxi, orc.Chain(x0[5]), orc.make_rng('xoshiro', seed=99, stream=5), u0[5], n_iter + 5, n_warmup)
+    assert np.array_equal(st2.cpu().numpy()[5, :, _lib.NSTATS.index('tree_size')], sto['tree_size'][n_iter:])
+
+
+@pytest.mark.gpu
+def test_sample_entry_point_runs_tnuts_and_tempering_brings_base_mass(fx):
+    """bayesfast_amd.sample(..., sampler='TNUTS'): TraceTuple with the (u, weight) statistics; continuing a run; 'THMC' is
+    refused (the reference's THTrace cannot be constructed, samplers/sample_trace.py:600)."""
+    import bayesfast_amd as bfa
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    d = 8
+    _, cov = correlated_gaussian_spec(d)
+    prec = np.linalg.inv(cov)
+    rng = np.random.default_rng(2)
+    su = bfa.PolyModel('quadratic', input_size=d, output_size=1, bound_options=dict(alpha_p=150.))
+    dens = bfa.SurrogateDensity(su)
+    xf = rng.multivariate_normal(np.zeros(d), cov * 2.25, size=4 * su.n_param)
+    dens.fit(xf, -0.5 * np.einsum('ij,jk,ik->i', xf, prec, xf))
+    np.random.seed(0)
+    kw = dict(density_base=bfa.GaussianBase(np.zeros(d), cov * 1.5), logxi=0., n_chain=24, n_iter=200, n_warmup=100, random_generator=4)
+    tt = bfa.sample(dens, kw, sampler='TNUTS', n_run=150, verbose=False)
+    assert tt.sampler == 'TNUTS' and tt.samples.shape == (24, 150, d) and tt.stat('u').shape == (24, 150)
+    w = tt.stat('weight')
+    assert np.isfinite(w).all() and (w > 0).all()
+    tt = bfa.sample(dens, tt, verbose=False)
+    assert tt.samples.shape == (24, 200, d) and tt.stat('weight').shape == (24, 200)
+    # the tempered chain mixes target and base: its spread lies between the two (base covariance = 1.5 x target's)
+    ratio = np.mean(tt.samples[:, 100:].reshape(-1, d).var(0) / np.diag(cov))
+    assert 0.9 < ratio < 1.7
+    with pytest.raises(NotImplementedError):
+        bfa.sample(dens, dict(n_chain=4), sampler='THMC')
