@@ -91,36 +91,8 @@ def prepare_reference(ref, work):
 
 # ---------------------------------------------------------------------------------------------------
 
-def poly_spec_from_reference(pm):
-    """PolyModel -> spec dict (data only)."""
-    cfgs = [dict(order=c.order, input_mask=np.array(c.input_mask), output_mask=np.array(c.output_mask),
-                 coef=np.array(c._coef)) for c in pm.configs]
-    poly = dict(input_size=pm._input_size, output_size=pm._output_size, configs=cfgs,
-                use_bound=bool(pm._use_bound and not pm._all_linear))
-    if poly['use_bound']:
-        poly.update(mu=np.array(pm._mu), hess=np.array(pm._hess), alpha=float(pm._alpha),
-                    f_mu=np.array(pm._f_mu))
-    return poly
-
-
-def density_spec_from_reference(den):
-    su = den._surrogate_list[0]
-    d = int(den.input_size)
-    spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None,
-                poly=poly_spec_from_reference(su), use_decay=bool(den._use_decay))
-    if den._input_scales is not None:
-        spec['ranges'] = np.array(den._input_scales)
-        hb = den._hard_bounds
-        if isinstance(hb, bool):
-            hb = hb * np.ones((d, 2), np.uint8)
-        spec['hard_bounds'] = np.array(hb, dtype=np.uint8)
-    if su._input_scales is not None:
-        spec['su_lo'] = np.array(su._input_scales[:, 0])
-        spec['su_diff'] = np.array(su._input_scales_diff)
-    if den._use_decay:
-        spec.update(decay_mu=np.array(den._mu), decay_hess=np.array(den._hess),
-                    decay_alpha2=float(den._alpha_2), decay_gamma=float(den._gamma))
-    return spec
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from bayesfast_amd.adapters import poly_spec_from_reference, density_spec_from_reference  # noqa: E402  (the shipped adapter)
 
 
 class LoggingGenerator:
