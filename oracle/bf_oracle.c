@@ -379,7 +379,12 @@ void bfo_poly_fun_and_jac(const bfo_poly_model *pm, const double *x, double *f, 
 
 /* ================= Density.logp_and_grad: bayesfast/core/density.py:724-754 ======================= */
 
+/* measurement hook (bf_cpu_tuned.c): a registered tuned evaluation of the same density; NULL unless bench.py's CPU baseline
+ * asked for it.  Returns 0 when it declines a point (outside the bound), and the statement-by-statement path below runs. */
+int (*bfo_fast_hook)(const bfo_density *, const double *, int, double *, double *) = NULL;
+
 void bfo_logp_and_grad(const bfo_density *dn, const double *x, int original_space, double *logp, double *grad) {
+    if (bfo_fast_hook && bfo_fast_hook(dn, x, original_space, logp, grad)) return;
     int d = dn->d;
     double *xo = (double *)malloc(sizeof(double) * (size_t)d * 5);
     double *jd = xo + d, *xs = xo + 2 * d, *g = xo + 3 * d, *hv = xo + 4 * d;

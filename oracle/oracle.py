@@ -227,9 +227,15 @@ def poly_fun_and_jac(poly, x):
     return (f[0], j[0]) if single else (f, j)
 
 
-def logp_and_grad(spec, x, original_space=False):
-    """Density.logp_and_grad(x, original_space) for one point or a batch."""
+def logp_and_grad(spec, x, original_space=False, tuned=False):
+    """Density.logp_and_grad(x, original_space) for one point or a batch (tuned: through bf_cpu_tuned.c, the evaluation
+    bench.py's CPU baseline times)."""
     dn, keep = density_struct(spec)
+    if tuned:
+        f = lib().bfo_tuned_prepare
+        f.restype = C.c_int
+        if f(C.byref(dn)) != 0:
+            raise ValueError('the tuned evaluation covers the plain linear + quadratic surrogate only')
     x = _f64(x)
     single = x.ndim == 1
     x2 = np.atleast_2d(x)
@@ -238,6 +244,8 @@ def logp_and_grad(spec, x, original_space=False):
     L = lib()
     for i in range(x2.shape[0]):
         L.bfo_logp_and_grad(C.byref(dn), _p(x2[i]), int(original_space), _p(logp[i:i + 1]), _p(grad[i]))
+    if tuned:
+        L.bfo_tuned_clear()
     return (logp[0], grad[0]) if single else (logp, grad)
 
 
@@ -491,8 +499,13 @@ def set_decay(x, alpha=None, alpha_p=150., gamma=0.1):
 class ChainSet:
     """Persistent chains + xoshiro streams for timing phases separately (bench.py cpu_baseline)."""
 
-    def __init__(self, spec, x0, seed, first_stream=0, **chain_kw):
+    def __init__(self, spec, x0, seed, first_stream=0, tuned=False, **chain_kw):
         self.dn, self._keep = density_struct(spec)
+        self.tuned = False
+        if tuned:  # bench.py's baseline: the same density through bf_cpu_tuned.c (one dense matvec pair, no allocation)
+            f = lib().bfo_tuned_prepare
+            f.restype = C.c_int
+            self.tuned = f(C.byref(self.dn)) == 0
         x0 = _f64(x0)
         self.n_chain, self.d = x0.shape
         self.chains = [Chain(x0[i], **chain_kw) for i in range(self.n_chain)]
@@ -513,6 +526,12 @@ class ChainSet:
         if total < 0:
             raise RuntimeError('oracle chain failed with code %d' % total)
         return samples, {k: stats[:, :, i].copy() for i, k in enumerate(NSTATS)}, int(total)
+
+
+    def close(self):
+        if self.tuned:
+            lib().bfo_tuned_clear()
+            self.tuned = False
 
 
 def max_threads():

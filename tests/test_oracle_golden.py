@@ -286,3 +286,20 @@ def test_full_metric_fixed_nuts_and_hmc_replay(fullm):
 def test_full_metric_rejects_indefinite_covariance():
     with pytest.raises(ValueError):
         orc.Chain(np.zeros(3), metric=np.diag([1., -1., 1.]))
+
+
+def test_tuned_baseline_evaluation_agrees_with_the_faithful_one():
+    """bench.py's CPU baseline times bf_cpu_tuned.c (symmetrised dense matvec, AVX2); it must be the same density: equal
+    to rounding inside the bound, and the faithful extrapolation outside (it declines those points)."""
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    spec, cov = correlated_gaussian_spec(64)
+    rng = np.random.default_rng(3)
+    L = np.linalg.cholesky(cov)
+    x = np.concatenate((rng.normal(size=(200, 64)) @ L.T, 6. * rng.normal(size=(20, 64)) @ L.T))
+    f0, g0 = orc.logp_and_grad(spec, x)
+    f1, g1 = orc.logp_and_grad(spec, x, tuned=True)
+    np.testing.assert_allclose(f1, f0, rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(g1, g0, rtol=1e-11, atol=1e-11)
+    assert np.array_equal(f1[200:], f0[200:])  # outside the bound: the faithful path itself
+    f2, _ = orc.logp_and_grad(spec, x)  # and the registration does not outlive the call
+    assert np.array_equal(f2, f0)
