@@ -81,6 +81,7 @@ SYMBOLS = {
     'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
     'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_solve_spd': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    'bfhip_lstsq': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     'bfhip_sort_keys': (C.c_int, [_vp, C.c_long, _vp, _vp, _vp]),
     'bfhip_order_keys': (C.c_int, [_vp, C.c_long, _vp, _vp]),
     'bfhip_count_keys': (C.c_int, [_vp, C.c_long, _vp, C.c_long, _vp, C.c_int, _vp]),

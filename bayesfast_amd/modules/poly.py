@@ -270,6 +270,8 @@ class PolyModel(Surrogate):
         return self._device_eval(x)
 
     # ---- fit ----
+    _N_REFINE = 2  # refinement steps of the least-squares solve
+
     def fit(self, x, y, logp=None, w=None):
         """Fit the polynomial model (modules/poly.py:505-589) on device.
 
@@ -317,8 +319,11 @@ class PolyModel(Surrogate):
             G = ctx.empty((P, P))
             r = ctx.empty((P, len(outs)))
             info = torch.zeros((1,), dtype=torch.int32, device=ctx.device)
-            _lib.check(lib.bfhip_gram(h, n, P, len(outs), _ptr(A), P, _ptr(B), _ptr(G), _ptr(r)))
-            _lib.check(lib.bfhip_solve_spd(h, P, len(outs), _ptr(G), _ptr(r), _ptr(info)))
+            # normal equations + two refinement steps on the true residual: the accuracy of an orthogonal factorisation
+            # for every design the pivot threshold lets through (include/bfhip.h: bfhip_lstsq)
+            work = ctx.empty((n * len(outs) + P * len(outs),))
+            _lib.check(lib.bfhip_lstsq(h, n, P, len(outs), _ptr(A), P, _ptr(B), _ptr(G), _ptr(r), self._N_REFINE, _ptr(work),
+                                       _ptr(info)))
             if int(info.item()) != 0:
                 # numerically rank-deficient design matrix: LAPACK gelsd (modules/poly.py:570) would return the
                 # minimum-norm solution; here the normal equations get a relative ridge of 1e-9 on the diagonal

@@ -75,7 +75,7 @@ def physical_cores(default):
         return default
 
 
-def hetero_rate(ctx, d, C, seed, iters, steps=3):
+def hetero_rate(ctx, d, C, seed, iters, steps=3, layout='auto'):
     """Secondary figure: the same surrogate family on a target whose trees differ from chain to chain and from iteration
     to iteration (per-dimension scales spread over a decade, identity metric kept fixed: tree sizes 7 .. 63 side by side
     in one workgroup), so that the 16 chains of a group do NOT run in step.  Post-adaptation launches, HIP events."""
@@ -88,7 +88,7 @@ def hetero_rate(ctx, d, C, seed, iters, steps=3):
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(seed + 1).normal(size=(C, d))
     ch = DeviceChains(dens, x0, seed=seed + 1)
-    kw = dict(n_warmup=N_ADAPT, check=False, adapt_metric=False, target_accept=0.9)
+    kw = dict(n_warmup=N_ADAPT, check=False, adapt_metric=False, target_accept=0.9, layout=layout)
     ch.run(N_ADAPT, 'NUTS', **kw)
     s = ctx.empty((C, iters, d))
     st = ctx.empty((C, iters, _lib.STAT_STRIDE))
@@ -106,7 +106,7 @@ def hetero_rate(ctx, d, C, seed, iters, steps=3):
     ts = st[:, :, _lib.NSTATS.index('tree_size')].cpu().numpy()
     sizes, counts = np.unique(ts, return_counts=True)
     return {'value': (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), 'unit': 'leapfrog steps/sec',
-            'mean_tree_size': float(ts.mean()),
+            'mean_tree_size': float(ts.mean()), 'chain_layout': layout,
             'tree_size_share': {str(int(k)): round(float(v) / ts.size, 4) for k, v in zip(sizes, counts)},
             'workload': '%d chains x %d-d Gaussian with per-dimension scales 10^-0.5 .. 10^0.5, identity metric '
                         '(adapt_metric off), target_accept 0.9, %d x %d post-adaptation iterations' % (C, d, steps, iters)}

@@ -295,6 +295,16 @@ int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, co
  * r (P,m) by the solution.  info (1,) int32 device flag: 0 ok, k>0 pivot k not positive. */
 int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info);
 
+/* The least-squares solve of PolyModel.fit in one call (scipy.linalg.lstsq(A, b), modules/poly.py:570): c (P,m) =
+ * argmin |A c - B| for A (n,lda>=P), B (n,m), by the normal equations above followed by n_refine steps of refinement on
+ * the true residual, c += G^-1 A^T (B - A c), with the kept Cholesky factor (corrected semi-normal equations: the
+ * coefficient error drops from cond(A)^2 eps to the cond(A) eps of an orthogonal factorisation).  G (P,P) receives the
+ * factor; work holds n*m + P*m doubles (may be NULL when n_refine = 0).  info as in bfhip_solve_spd: a pivot of the
+ * equilibrated matrix below 1e-11 (cond(A) beyond ~3e5 after column scaling) is reported as rank deficiency and c is
+ * then not meaningful -- the caller regularises, it is never silent. */
+int bfhip_lstsq(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, const double *B, double *G, double *c,
+                int n_refine, double *work, int *info);
+
 /* ------------------------------------------------------------------------------------------------
  * Refit glue: the steps either side of the sampler inside Recipe._sam_step / _pos_step.
  * ---------------------------------------------------------------------------------------------- */

@@ -1,10 +1,11 @@
 """A/B of the NUTS kernels on the heterogeneous-tree workload of bench.py (hetero_rate) and on the config-4 style
-workload (target_accept 0.95): BFHIP_NUTS_KERNEL=group|pipe|sliced python tools/hetero_ab.py"""
+workload (target_accept 0.95): LAYOUT=auto|group|wave BFHIP_NUTS_KERNEL=pipe|sliced python tools/hetero_ab.py"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from bayesfast_amd.device import get_context
 ctx = get_context(0)
-r = bench.hetero_rate(ctx, 64, 4096, 2024, 250)
-print(os.environ.get('BFHIP_NUTS_KERNEL', 'group'), 'hetero %.4g' % r['value'], 'mean tree', r['mean_tree_size'])
+lay = os.environ.get('LAYOUT', 'auto')
+r = bench.hetero_rate(ctx, 64, 4096, 2024, 250, layout=lay)
+print('layout', lay, 'BFHIP_NUTS_KERNEL', os.environ.get('BFHIP_NUTS_KERNEL', '-'), 'hetero %.4g' % r['value'], 'mean tree', r['mean_tree_size'])

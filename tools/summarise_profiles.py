@@ -2,7 +2,7 @@
 import sys, os, glob, json, csv
 import numpy as np
 out, tag = sys.argv[1], sys.argv[2]
-KERNEL = 'bf_nuts_pipe_kernel'
+KERNEL = None  # the kernel the bench line names (roofline.kernel): set below
 
 
 def rows(pattern):
@@ -14,7 +14,17 @@ def rows(pattern):
     return r
 
 
+def line(fn):
+    try:
+        return json.loads([l for l in open(os.path.join(out, fn)) if l.startswith('{')][-1])
+    except Exception:
+        return None
+
+
 res = {}
+b = line('bench_line.json')
+FULL = (b or {}).get('roofline', {}).get('kernel') or 'bf_group_kernel'
+KERNEL = FULL.split('<')[0]
 # kernel trace: durations of the sampler dispatches
 kt = [r for r in rows('trace/**/*kernel_trace.csv') if KERNEL in r.get('Kernel_Name', '')]
 dur = np.array([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6 for r in kt])
@@ -34,14 +44,6 @@ def counter(pattern, name):
     return v
 
 
-def line(fn):
-    try:
-        return json.loads([l for l in open(os.path.join(out, fn)) if l.startswith('{')][-1])
-    except Exception:
-        return None
-
-
-b = line('bench_line.json')
 res['bench_line'] = b
 for nm, pat in (('FETCH_SIZE', 'pmc_fetch/**/*counter_collection.csv'), ('WRITE_SIZE', 'pmc_write/**/*counter_collection.csv')):
     v = counter(pat, nm)
@@ -54,7 +56,7 @@ if res.get('FETCH_SIZE_per_dispatch_raw_KB') and res.get('WRITE_SIZE_per_dispatc
     w = float(np.mean(res['WRITE_SIZE_per_dispatch_raw_KB'][-nst:])) * 1024.
     lf_f = fl['value'] * fl['ms_per_step'] * 1e-3
     lf_w = wl['value'] * wl['ms_per_step'] * 1e-3
-    tr = {'dim': 64, 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 3, timed dispatches only',
+    tr = {'dim': 64, 'kernel': FULL, 'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 3, timed dispatches only',
           'fetch_bytes_per_launch_raw': f, 'write_bytes_per_launch': w, 'leapfrogs_per_launch': 0.5 * (lf_f + lf_w),
           'note': 'FETCH_SIZE is the raw counter (KB -> bytes); the gfx950 x2 correction of MI355X_MICROARCH.md is calibrated for 16-B/lane '
                   'streaming reads only and this kernel reads 8 B/lane, so the raw value is a lower bound and 2x it an upper bound',
