@@ -300,8 +300,9 @@ int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *inf
  * the true residual, c += G^-1 A^T (B - A c), with the kept Cholesky factor (corrected semi-normal equations: the
  * coefficient error drops from cond(A)^2 eps to the cond(A) eps of an orthogonal factorisation).  G (P,P) receives the
  * factor; work holds n*m + P*m doubles (may be NULL when n_refine = 0).  info as in bfhip_solve_spd: a pivot of the
- * equilibrated matrix below 1e-11 (cond(A) beyond ~3e5 after column scaling) is reported as rank deficiency and c is
- * then not meaningful -- the caller regularises, it is never silent. */
+ * equilibrated matrix below 1e-11 is reported as rank deficiency and c is then not meaningful -- the caller
+ * regularises, it is never silent.  Checked against the reference's gelsd up to a column-equilibrated cond(A) of 1e7
+ * (two steps: 1e-10 of the coefficient scale, tests/golden/fit_illcond.npz). */
 int bfhip_lstsq(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, const double *B, double *G, double *c,
                 int n_refine, double *work, int *info);
 

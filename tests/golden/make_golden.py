@@ -639,6 +639,57 @@ def gen_tempered(bf, out):
     np.savez_compressed(os.path.join(out, 'tempered.npz'), **z)
 
 
+def gen_fit_illcond(bf, out):
+    """PolyModel.fit (scipy.linalg.lstsq = LAPACK gelsd, modules/poly.py:566-587) on ill-conditioned and rank-deficient
+    designs: a cubic model whose inputs sit far from the origin (the monomials are nearly collinear) at two offsets, and a
+    quadratic model with a duplicated input column.  Recorded: the data, the reference's coefficients and predictions,
+    and the condition number of the column-equilibrated design matrix."""
+    from bayesfast.modules import PolyModel, PolyConfig
+    from bayesfast.modules import _poly
+    rng = np.random.default_rng(2145)
+    z = {}
+
+    def design(x, orders):
+        n, d = x.shape
+        blocks = [np.ones((n, 1)), x]
+        if 'quadratic' in orders:
+            a = np.empty((n, d * (d + 1) // 2)); _poly._lsq_quadratic(x, a, n, d); blocks.append(a)
+        if 'cubic-2' in orders:
+            a = np.empty((n, d * d)); _poly._lsq_cubic_2(x, a, n, d); blocks.append(a)
+        if 'cubic-3' in orders:
+            a = np.empty((n, d * (d - 1) * (d - 2) // 6)); _poly._lsq_cubic_3(x, a, n, d); blocks.append(a)
+        return np.concatenate(blocks, 1)
+
+    for tag, off, sc in (('ill5', 2.5, 0.3), ('ill7', 4.0, 0.11)):
+        d = 5
+        orders = ['linear', 'quadratic', 'cubic-2', 'cubic-3']
+        pm = PolyModel(orders, input_size=d, output_size=1, bound_options=dict(use_bound=False))
+        n = pm.n_param + 25
+        x = off + sc * rng.normal(size=(n, d))
+        y = (np.sin(x.sum(1)) + 0.3 * x[:, 0] * x[:, 1] * x[:, 2] - 0.1 * x[:, 3]**2 * x[:, 4] + 0.5 * x[:, 1]**2)[:, None]
+        pm.fit(x, y)
+        A = design(x, orders)
+        sv = np.linalg.svd(A / np.linalg.norm(A, axis=0), compute_uv=False)
+        xe = off + sc * rng.normal(size=(30, d))
+        z[tag + '.x'], z[tag + '.y'], z[tag + '.xe'] = x, y, xe
+        z[tag + '.f_fit'] = np.array([pm._fun(xx) for xx in x])
+        z[tag + '.f_eval'] = np.array([pm._fun(xx) for xx in xe])
+        z[tag + '.cond_equilibrated'] = np.asarray(sv[0] / sv[-1])
+        z.update(flatten_poly(poly_spec_from_reference(pm), tag + '.poly.'))
+    # rank deficient: input 3 duplicates input 0
+    d = 4
+    pm = PolyModel('quadratic', input_size=d, output_size=1, bound_options=dict(use_bound=False))
+    n = 3 * pm.n_param
+    x = rng.normal(size=(n, d))
+    x[:, 3] = x[:, 0]
+    y = (x[:, 0]**2 - x[:, 1] * x[:, 2] + 0.7 * x[:, 2] + 0.01 * rng.normal(size=n))[:, None]
+    pm.fit(x, y)
+    z['rankdef.x'], z['rankdef.y'] = x, y
+    z['rankdef.f_fit'] = np.array([pm._fun(xx) for xx in x])
+    z.update(flatten_poly(poly_spec_from_reference(pm), 'rankdef.poly.'))
+    np.savez_compressed(os.path.join(out, 'fit_illcond.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -647,7 +698,8 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, tempered=gen_tempered)
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, tempered=gen_tempered,
+                fit_illcond=gen_fit_illcond)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue

@@ -252,6 +252,49 @@ def test_config4_funnel_target_accept_095():
     assert acc > 0.85, acc
 
 
+def test_fit_ill_conditioned_designs_match_reference_lstsq():
+    """PolyModel.fit against the reference's LAPACK gelsd (modules/poly.py:570) on fixtures recorded from it
+    (tests/golden/fit_illcond.npz, make_golden.py:gen_fit_illcond): cubic designs whose column-equilibrated condition
+    number is 2.1e5 and 1.0e7, and an exactly rank-deficient one.  The device solve is normal equations + two refinement
+    steps on the true residual (include/bfhip.h: bfhip_lstsq): plain normal equations lose cond^2 eps (1e-4 of the
+    coefficient scale at cond 1e7), the refined solve agrees with the orthogonal factorisation to 1e-9.  Designs whose
+    equilibrated Cholesky pivots fall below 1e-11 are reported (RuntimeWarning) and ridge-regularised: what is pinned
+    there is the fitted function, not the coefficients along the null directions."""
+    import warnings
+    from bayesfast_amd import PolyModel
+    from specio import rebuild_poly
+    z = np.load(os.path.join(G, 'fit_illcond.npz'))
+    orders = ['linear', 'quadratic', 'cubic-2', 'cubic-3']
+    for tag, lo, hi, plain_floor in (('ill5', 1e5, 3e5, 0.), ('ill7', 5e6, 2e7, 1e-6)):
+        assert lo < float(z[tag + '.cond_equilibrated']) < hi
+        ref = rebuild_poly(z, tag + '.poly.')
+        scale = max(np.abs(_indep(r['order'], r['coef'])).max() for r in ref['configs'])
+
+        def coef_err(pm):
+            return max(np.abs(_indep(c.order, c._coef) - _indep(r['order'], r['coef'])).max()
+                       for c, r in zip(pm.configs, ref['configs'])) / scale
+
+        pm = PolyModel(orders, input_size=5, output_size=1, bound_options=dict(use_bound=False))
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')  # silent: these designs are inside the stated range
+            pm.fit(z[tag + '.x'], z[tag + '.y'])
+        assert coef_err(pm) < 1e-9, (tag, coef_err(pm))
+        f = np.array([pm.fun(x)[0] for x in z[tag + '.xe']])
+        np.testing.assert_allclose(f, z[tag + '.f_eval'], rtol=1e-10, atol=1e-10)
+        # the refinement is what buys it
+        pm0 = PolyModel(orders, input_size=5, output_size=1, bound_options=dict(use_bound=False))
+        pm0._N_REFINE = 0
+        pm0.fit(z[tag + '.x'], z[tag + '.y'])
+        assert coef_err(pm0) > max(plain_floor, 20. * coef_err(pm)), (tag, coef_err(pm0), coef_err(pm))
+    # exactly rank deficient (duplicated input): gelsd returns the minimum-norm coefficients, the ridge solve another
+    # member of the solution set; on the data both give the same fitted values
+    pr = PolyModel('quadratic', input_size=4, output_size=1, bound_options=dict(use_bound=False))
+    with pytest.warns(RuntimeWarning, match='rank deficient'):
+        pr.fit(z['rankdef.x'], z['rankdef.y'])
+    f = np.array([pr.fun(x)[0] for x in z['rankdef.x'][:40]])
+    np.testing.assert_allclose(f, z['rankdef.f_fit'][:40], rtol=0, atol=1e-5)
+
+
 def test_fit_rank_deficient_design_warns_and_regularises():
     """Duplicate columns: gelsd would return a min-norm solution; the device fit warns and solves ridge-regularised
     normal equations (predictions on the fit points still match the data)."""
