@@ -30,6 +30,8 @@ def local_device(n_visible, env=None):
     if ws == 1 or 'LOCAL_RANK' not in env:
         return None
     lr = int(env['LOCAL_RANK'])
+    if env.get('BFHIP_SHARE_DEVICE') and n_visible > 0:
+        return lr % n_visible  # several ranks per GPU, on request (the two-rank tests on a one-GPU box)
     if not 0 <= lr < n_visible:
         raise RuntimeError('LOCAL_RANK {} but only {} visible device(s).'.format(lr, n_visible))
     return lr

@@ -1,0 +1,45 @@
+"""Helper of tests/test_gpu_fit_sample.py::test_sample_two_ranks_equals_one_rank: runs bfa.sample() twice on a fixed density
+(under torch.distributed.run with gloo when WORLD_SIZE > 1; all ranks share the box's GPU) and lets rank 0 save the result."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+import bayesfast_amd as bfa  # noqa: E402
+from bayesfast_amd.samplers import _get_step_size, _get_metric  # noqa: E402
+
+
+def main(out):
+    ws = int(os.environ.get('WORLD_SIZE', 1))
+    if ws > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+    d = 6
+    rng = np.random.default_rng(3)
+    Pm = np.eye(d) + 0.3 * rng.normal(size=(d, d)) / np.sqrt(d)
+    Pm = Pm @ Pm.T
+    den = bfa.SurrogateDensity(bfa.PolyModel('quadratic', input_size=d, output_size=1))
+    xf = rng.normal(size=(120, d)) * 1.5
+    den.fit(xf, -0.5 * np.einsum('ij,jk,ik->i', xf, Pm, xf))
+    # default trace: no seed given by the caller (rank 0's entropy is what every rank must use), then a second round
+    # warm-started from the first (_get_step_size / _get_metric reduce over all ranks)
+    seed = int(os.environ['BF_TEST_SEED'])
+    tt = bfa.sample(den, {'n_chain': 22, 'n_iter': 60, 'n_warmup': 40, 'random_generator': seed}, verbose=False)
+    step = _get_step_size(tt)
+    metric = _get_metric(tt, 'diag')
+    tt2 = bfa.sample(den, {'n_chain': 22, 'n_iter': 30, 'n_warmup': 10, 'random_generator': seed + 1, 'step_size': step,
+                           'metric': metric}, verbose=False)
+    res = dict(s=np.asarray(tt.samples), ts=np.stack([np.asarray(tt[i].stats._tree_size) for i in range(22)]),
+               step=np.asarray(step), metric=np.asarray(metric), s2=np.asarray(tt2.samples),
+               logp=np.asarray(tt.get(include_warmup=True, return_type='logp')))
+    if int(os.environ.get('RANK', 0)) == 0:
+        np.savez(out, **res)
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

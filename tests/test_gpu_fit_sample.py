@@ -252,6 +252,34 @@ def test_config4_funnel_target_accept_095():
     assert acc > 0.85, acc
 
 
+def test_sample_two_ranks_equals_one_rank(tmp_path):
+    """sample() under torch.distributed (two ranks sharing the box's GPU over gloo, ragged shards 11 + 11 of 22 chains) returns
+    exactly what one rank returns: x_0 and the xoshiro streams follow the global chain index, the trace's seed is resolved
+    once and broadcast, and the warm start of the next round (_get_step_size, _get_metric) reduces over all ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    helper = os.path.join(root, 'tests', 'helpers', 'sample_ranks.py')
+    env = dict(os.environ, BF_TEST_SEED='17', BFHIP_SHARE_DEVICE='1')
+    one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
+    r = subprocess.run([sys.executable, helper, one], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    port = 29500 + os.getpid() % 150
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), helper, two], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    a, b = np.load(one), np.load(two)
+    assert a['s'].shape == (22, 60, 6)
+    for k in ('ts', 's', 'logp'):
+        assert np.array_equal(a[k], b[k]), k
+    # the reductions over ranks sum in a different order than one rank does: the warm start agrees to rounding, and so
+    # does the round that starts from it
+    np.testing.assert_allclose(b['step'], a['step'], rtol=1e-13)
+    np.testing.assert_allclose(b['metric'], a['metric'], rtol=1e-12)
+    np.testing.assert_allclose(b['s2'][:, :5], a['s2'][:, :5], rtol=1e-9, atol=1e-9)
+
+
 def test_fit_ill_conditioned_designs_match_reference_lstsq():
     """PolyModel.fit against the reference's LAPACK gelsd (modules/poly.py:570) on fixtures recorded from it
     (tests/golden/fit_illcond.npz, make_golden.py:gen_fit_illcond): cubic designs whose column-equilibrated condition
