@@ -61,7 +61,7 @@ struct GroupGeo {
     static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * LSH, NVAL = V_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);       // sums of the merge levels LSH+1 .. MAXL-1
     static constexpr size_t lds_doubles(int nmat) {
-        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS;
+        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS + (size_t)W * 16;
     }
     // per-chain global scratch, in vectors of DP doubles: 5 per stack level 2 .. MAXL-1, then the deep sums
     static constexpr int S_DEEP = 5 * (MAXL - 2);
@@ -105,6 +105,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
     double *TV = RB + G::NVAL * W * 16;        // [NTV][DP][16]   tree vectors
     double *LS = TV + G::NTV * DP * 16;        // [16][LSS]       subtree stack scalars (one writer: wave 0)
+    double *PB = LS + 16 * LSS;                // [W][16]         per-wave |x - mu|^2 of the point in flight (bound proof)
 
     const int tid = bf_tid(), lane = tid & 63, j = tid >> 6, c = lane & 15, gq = lane >> 4;
     const int chain = bf_group() * 16 + c;
@@ -112,6 +113,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     const bool writer = j == 0 && gq == 0;     // the lane that owns chain c's scalar outputs
     const int d = m.d, dbase = 16 * j + gq;    // element r is dimension dbase + 4 r
     const int nw = a.cfg.n_warmup;
+    const double bound_thr = m.use_bound ? m.alpha * m.alpha * (1. - 1e-9) : __builtin_inf();
 
     // ---- constants: A operands of this wave's row tile, per-dimension table rows ----
     double afS[NS], afH[NS], afD[DEC ? NS : 1];
@@ -387,6 +389,21 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
             if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
         }
+        // Bound proof.  (x - mu)^T H (x - mu) <= lam_max(H) |x - mu|^2: when that is below alpha^2 for every chain of the
+        // group the test of modules/poly.py:467-469 is decided (inside) without the H (x - mu) tiles -- half of the trip's
+        // MFMAs.  The partial |x - mu|^2 rides through the barrier the operands need anyway; the outcome is the one the
+        // full computation has (margin 1e-9 against its rounding), so results do not depend on whether a group skips.
+        {
+            double t_r2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double xm = xs[r] - c_mu[r];
+                t_r2[r] = ev ? xm * xm : 0.;
+            }
+            double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
+            if (mode == M_OOB || mode == M_FIN) r2p = __builtin_inf();  // passes that need H (x - mu) itself
+            if (gq == 0) PB[j * 16 + c] = r2p;
+        }
         GTRACE(1);
         bf_sync();  // B1
         GTRACE(2);
@@ -400,12 +417,21 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
             for (int s = 0; s < KH; ++s) {
                 aS0 = bf_mfma(afS[s], XB[(0 * NS + s) * 64 + lane], aS0);
-                aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
                 if constexpr (DEC) aD0 = bf_mfma(afD[s], XB[(2 * NS + s) * 64 + lane], aD0);
                 if constexpr (KS == 2) {
                     aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
-                    aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
                     if constexpr (DEC) aD1 = bf_mfma(afD[KH + s], XB[(2 * NS + KH + s) * 64 + lane], aD1);
+                }
+            }
+            double r2 = PB[c];  // (read behind the S tiles: the matrix pipe is busy with them while the loads travel)
+#pragma unroll
+            for (int w2 = 1; w2 < W; ++w2) r2 += PB[w2 * 16 + c];
+            const bool inside = !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven)
+            if (bf_any(!inside)) {
+#pragma unroll
+                for (int s = 0; s < KH; ++s) {
+                    aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
+                    if constexpr (KS == 2) aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
                 }
             }
 #pragma unroll

@@ -57,9 +57,14 @@ int bf_group_scratch_slots(int DP) { return 5 * (BFHIP_MAX_TREEDEPTH - 2); }
 static unsigned long long *g_gstamps = NULL;
 extern "C" void bfhip_debug_gstamps(unsigned long long *buf) { g_gstamps = buf; }
 
+// test hook (not part of include/bfhip.h): 1 = never skip the bound's tiles (the results must not change)
+static int g_no_bound_proof = 0;
+extern "C" void bfhip_debug_no_bound_proof(int on) { g_no_bound_proof = on; }
+
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
     args.stamps = g_gstamps;
+    args.no_bound_proof = g_no_bound_proof;
     const DevModel &m = ctx->model;
     const bool nuts = args.cfg.sampler == 0;
     const int fs = 1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0);

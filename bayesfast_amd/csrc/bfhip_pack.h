@@ -1,6 +1,7 @@
 // bfhip_pack.h -- host-side re-layout of a bfhip_density_desc into the device model's tables (no HIP dependency;
 // shared by bfhip_density_upload and the host emulation of the group kernel under tests/emu).
 #pragma once
+#include <cmath>
 #include <vector>
 #include "bfhip_model.h"
 
@@ -63,6 +64,53 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
     if (ds->use_decay) to_fragments(ds->decay_hess, d, DP, true, Hdf);
 
     return DP;
+}
+
+// An upper bound c of the largest eigenvalue of the symmetric part of H, PROVEN by a successful Cholesky factorisation of
+// c' I - sym(H) for a c' slightly below c (so that (x - mu)^T H (x - mu) <= c |x - mu|^2 for every x): a power iteration
+// proposes, the factorisation disposes; the Gershgorin bound is the fallback.  Host side, once per upload.
+static inline double bf_bound_lam_max(const double *hess, int d) {
+    std::vector<double> A((size_t)d * d), v(d, 1.), w(d), L((size_t)d * d);
+    double gersh = 0.;
+    for (int i = 0; i < d; ++i) {
+        double rs = 0.;
+        for (int k = 0; k < d; ++k) {
+            A[(size_t)i * d + k] = 0.5 * (hess[(size_t)i * d + k] + hess[(size_t)k * d + i]);
+            rs += std::fabs(A[(size_t)i * d + k]);
+        }
+        if (rs > gersh) gersh = rs;
+    }
+    if (!(gersh > 0.) || !std::isfinite(gersh)) return std::isfinite(gersh) ? 0. : gersh;
+    double lam = 0.;
+    for (int it = 0; it < 200; ++it) {
+        double nn = 0.;
+        for (int i = 0; i < d; ++i) {
+            double s = 0.;
+            for (int k = 0; k < d; ++k) s += A[(size_t)i * d + k] * v[k];
+            w[i] = s;
+            nn += s * s;
+        }
+        nn = std::sqrt(nn);
+        if (!(nn > 0.)) break;
+        lam = nn;
+        for (int i = 0; i < d; ++i) v[i] = w[i] / nn;
+    }
+    for (double c = lam * 1.01; c < gersh; c *= 1.05) {
+        bool ok = true;
+        for (int i = 0; i < d && ok; ++i)
+            for (int k = 0; k <= i; ++k) {
+                double s = (i == k ? c : 0.) - A[(size_t)i * d + k];
+                for (int q = 0; q < k; ++q) s -= L[(size_t)i * d + q] * L[(size_t)k * d + q];
+                if (i == k) {
+                    if (!(s > 1e-12 * c)) { ok = false; break; }
+                    L[(size_t)i * d + i] = std::sqrt(s);
+                } else {
+                    L[(size_t)i * d + k] = s / L[(size_t)k * d + k];
+                }
+            }
+        if (ok) return c * (1. + 1e-9);
+    }
+    return gersh * (1. + 1e-9);
 }
 
 // stream = global chain index, so results do not depend on how chains are sharded over GPUs

@@ -307,7 +307,11 @@ def main():
                          'frac': ach_tf / peak_tf, 'traffic': traffic,
                          'kernel': kernel_name, 'kernel_ms_per_launch': kernel_ms,
                          'traffic_source': None if traffic is None else 'stored profile (profiles/hbm_traffic.json), not this run',
-                         'flops_per_leapfrog': flops_per_leapfrog(d, use_bound)},
+                         'flops_per_leapfrog': flops_per_leapfrog(d, use_bound),
+                         'flops_note': 'algorithmic: S x and H (x - mu) per step (4 d^2). bf_group_kernel leaves the H tiles out of a '
+                                       'trip when lam_max(H) |x - mu|^2 < alpha^2 proves all 16 chains of the group inside the bound '
+                                       '(identical results); on this workload that is nearly every trip, so about half of the '
+                                       'algorithmic flops are decided, not executed'},
             'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
                                          'peak': 8000., 'unit': 'GB/s',
                                          'frac': (bytes_alg / (kernel_ms * 1e-3) / 1e9 / 8000.) if kernel_ms else 0.,

@@ -148,6 +148,45 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     assert np.array_equal(out[0][1], out[4][1], equal_nan=True)
 
 
+@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'divergent', 'd40', 'd10', 'bounded', 'decay', 'hmc'])
+def test_group_kernel_bound_proof_never_changes_results(ctx, case):
+    """The group kernel leaves out the H (x - mu) tiles of a trip when lam_max(H) |x - mu|^2 < alpha^2 proves every chain of
+    the group inside the bound (modules/poly.py:467-469 decided without the matvec).  With the proof switched off every
+    trip computes them: samples, statistics, adapted state, random streams and the leapfrog count must be bit-identical --
+    with groups that always skip, groups mostly outside the bound (never skip), mixed groups, transforms, decay, HMC."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = int(case[1:]) if case[0] == 'd' and case[1:].isdigit() else 64
+    spec, _ = correlated_gaussian_spec(d, fit_scale=1.0 if case == 'leaky_bound' else 1.5)
+    if case == 'bounded':
+        lo = np.full(d, -9.) + np.arange(d) * 0.01
+        spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * 16, dtype=np.uint8))
+    if case == 'decay':
+        pm = spec['poly']
+        spec = dict(spec, use_decay=True, decay_mu=np.asarray(pm['mu']), decay_hess=np.asarray(pm['hess']),
+                    decay_alpha2=float(pm['alpha'])**2 * 0.5, decay_gamma=0.1)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(2).normal(size=(150, d)) * (3. if case == 'divergent' else (0.3 if case == 'bounded' else 1.))
+    kw = {'divergent': dict(max_change=5.)}.get(case, {})
+    sampler = 'HMC' if case == 'hmc' else 'NUTS'
+    out = {}
+    hook = _lib.lib().bfhip_debug_no_bound_proof
+    try:
+        for off in (0, 1):
+            hook(off)
+            dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
+            s1, st1 = dc.run(45, sampler, n_warmup=30, **kw, layout='group')
+            s2, st2 = dc.run(15, sampler, n_warmup=30, **kw, layout='group')
+            out[off] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
+    finally:
+        hook(0)
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert out[0][-1] == out[1][-1]
+
+
 @pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40', 'd32', 'd10', 'bounded'])
 def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     """bf_nuts_pipe_kernel (deferred bookkeeping, speculative next step, tree vectors in LDS) performs the same

@@ -3,7 +3,7 @@
 cd /root/repo
 for n in "$@"; do
   for rep in 1 2; do
-    BFHIP_LIBRARY=$PWD/bayesfast_amd/variants/libbfhip_$n.so timeout 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fit 2>/dev/null | python3 -c "
+    BFHIP_LIBRARY=$PWD/bayesfast_amd/variants/libbfhip_$n.so timeout 300 python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fit --no-extras 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
