@@ -85,9 +85,11 @@ class DeviceChains:
 
         ``layout`` chooses how a workgroup's 16 chains are laid out (``bfhip_sampler_config.chain_layout``): 'group' (lane
         per chain: fastest while the chains of a workgroup stay in step), 'wave' (wave per chain: insensitive to chains
-        out of step) or 'auto': 'group' when at least 98 % of the NUTS trees of the previous run's last iterations had one
-        and the same size (static HMC: always), 'wave' otherwise and for the first run.  Both layouts follow the same
-        per-chain arithmetic and random streams; their floating-point sums are ordered differently.
+        out of step) or 'auto', decided per launch: 'group' when at least 98 % of the NUTS trees of the previous launch's
+        last 64 iterations had one and the same size (static HMC: always), 'wave' otherwise and for the first launch.
+        Both layouts follow the same per-chain arithmetic and random streams; their floating-point sums are ordered
+        differently, so results are bit-reproducible (and independent of sharding and launch cuts) for a fixed layout,
+        and agree to rounding between layouts.
 
         Returns (samples (n_chain, n_run, d), stats (n_chain, n_run, 11)) device tensors; the stats columns
         follow ``_lib.NSTATS`` / ``_lib.HSTATS`` (samplers/hmc_utils/stats.py:7-14)."""
@@ -106,10 +108,6 @@ class DeviceChains:
         cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
         if layout not in ('auto', 'group', 'wave'):
             raise ValueError("layout should be 'auto', 'group' or 'wave'.")
-        if layout == 'auto':
-            layout = 'group' if (sampler == 'HMC' or self._trees_in_step()) else 'wave'
-        cfg.chain_layout = {'group': 1, 'wave': 2}[layout]
-        self.last_layout = layout
         n_run = int(n_run)
         if samples is None:
             samples = self.ctx.empty((self.n_chain, n_run, self.d))
@@ -123,12 +121,22 @@ class DeviceChains:
                     not t.is_contiguous()):
                 raise ValueError('{} should be a contiguous float64 tensor of shape {} on {}.'.format(name, shape, self.ctx.device))
         step = max(1, int(launch_iters) if launch_iters else n_run)
-        for done in range(step, n_run + step, step):  # iter_end of each launch; the output rows are relative to i_iter
+        ts_col = _lib.NSTATS.index('tree_size')
+        for i_launch, done in enumerate(range(step, n_run + step, step)):  # iter_end of each launch; output rows are relative to i_iter
+            # the layout is chosen per launch from the trees of the launch before: the first launch of a run takes the
+            # latest answer that has already arrived (never waits: back-to-back runs stay queued), the following ones
+            # wait for their predecessor's -- the host has nothing else to queue, and the gap is a launch latency
+            lay = layout
+            if lay == 'auto':
+                lay = 'group' if (sampler == 'HMC' or self._trees_in_step(wait=i_launch > 0)) else 'wave'
+            cfg.chain_layout = {'group': 1, 'wave': 2}[lay]
+            self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),
                 _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
+            if layout == 'auto':
+                self._note_trees(stats[:, done - step:min(done, n_run), ts_col], sampler)
         self.i_iter += n_run
-        self._note_trees(stats, sampler)
         if check:
             self.raise_on_error()
         return samples, stats
@@ -177,30 +185,32 @@ class DeviceChains:
             self.raise_on_error()
         return samples, stats, stats_t
 
-    def _note_trees(self, stats, sampler, n_last=64, share=0.98):
-        """Queue, behind the launches of this run, the answer to "did the chains run in step?": at least ``share`` of the
-        NUTS trees of the last ``n_last`` iterations (all chains) had the most common size.  The flag travels to pinned
-        host memory asynchronously; nothing waits for it."""
+    def _note_trees(self, tree_sizes, sampler, n_last=64, share=0.98):
+        """Queue, behind the launch that wrote them, the answer to "did the chains run in step?": at least ``share`` of the
+        NUTS trees of its last ``n_last`` iterations (all chains; ``tree_sizes`` (n_chain, iterations)) had the most common
+        size.  The flag travels to pinned host memory asynchronously."""
         torch = _torch()
-        if sampler != 'NUTS' or stats.shape[1] == 0 or not stats.is_cuda:
+        if sampler != 'NUTS' or tree_sizes.shape[1] == 0 or not tree_sizes.is_cuda:
             self._step_flag = None
             return
-        ts = stats[:, -n_last:, _lib.NSTATS.index('tree_size')].reshape(-1)
-        hist = torch.bincount(ts.to(torch.int64).clamp_(0, 4096), minlength=2)  # (a histogram pass; a sort takes 0.5 ms)
-        flag = (hist.max() >= share * ts.numel()).to(torch.int32).reshape(1)
-        if getattr(self, '_step_host', None) is None:
-            self._step_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
         with torch.cuda.stream(self.ctx.stream):
+            ts = tree_sizes[:, -n_last:].reshape(-1)
+            hist = torch.bincount(ts.to(torch.int64).clamp_(0, 4096), minlength=2)  # (a histogram pass; a sort takes 0.5 ms)
+            flag = (hist.max() >= share * ts.numel()).to(torch.int32).reshape(1)
+            if getattr(self, '_step_host', None) is None:
+                self._step_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
             self._step_host.copy_(flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.ctx.stream)
         self._step_flag = ev
 
-    def _trees_in_step(self):
-        """The most recent answer of ``_note_trees`` that has arrived (False before the first one): the decision for a
-        run lags the statistics by at most one run when runs are queued back to back, and never stalls the stream."""
+    def _trees_in_step(self, wait=False):
+        """The most recent answer of ``_note_trees`` (False before the first one).  ``wait``: block until the pending answer
+        has arrived; otherwise use it only if it already has, so that runs queued back to back never stall the stream."""
         ev = getattr(self, '_step_flag', None)
-        if ev is not None and ev.query():
+        if ev is not None and (wait or ev.query()):
+            if wait:
+                ev.synchronize()
             self._in_step = bool(int(self._step_host[0]))
             self._step_flag = None
         return getattr(self, '_in_step', False)

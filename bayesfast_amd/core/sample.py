@@ -10,7 +10,7 @@ __all__ = ['sample']
 
 
 def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_backend=None, verbose=True,
-           iters_per_launch=None):
+           iters_per_launch=None, layout='auto'):
     """Sample a surrogate density.
 
     density : SurrogateDensity
@@ -21,6 +21,8 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     n_run : number of iterations to run now (default: up to ``n_iter``)
     parallel_backend : accepted for signature compatibility and ignored; chains shard over the ranks of the
         default ``torch.distributed`` process group instead (one process per GPU)
+    layout : 'auto' | 'group' | 'wave', the chain layout of the kernel (``DeviceChains.run``).  'auto' switches per launch
+        by how uniform the trees are; results are bit-reproducible for a fixed layout and agree to rounding between them
     Returns a ``TraceTuple`` whose arrays stay on this rank's GPU (this rank's chains); its host views gather all chains
     on first use, and the refit path (``bayesfast_amd.core.refit.select_fit_points``) exchanges only the selected rows.
     """
@@ -96,7 +98,7 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
                                              **trace.run_kwargs())
             stts.append(stt)
         else:
-            s, st = chains.run(k, trace._sampler, check=False, **trace.run_kwargs())  # queued; errors are raised below
+            s, st = chains.run(k, trace._sampler, check=False, layout=layout, **trace.run_kwargs())  # queued; errors are raised below
         ss.append(s)
         sts.append(st)
         left -= k
