@@ -79,11 +79,22 @@ _contexts = {}
 def get_context(device=None):
     """Process-wide default context of a device (default: torch's current device, i.e. the one a rank selected with
     ``torch.cuda.set_device(local_rank)``)."""
+    torch = _torch()
     if device is None:
-        device = _torch().cuda.current_device()
+        device = torch.cuda.current_device()
     if device not in _contexts:
         _contexts[device] = DeviceContext(device)
-    return _contexts[device]
+    ctx = _contexts[device]
+    # the default context follows torch's current stream: the torch ops of the host side (cat, copies, conversions) and
+    # the library's launches then share one stream whatever ``torch.cuda.stream(...)`` block the caller is in; work
+    # already queued on the previous stream is ordered before anything that follows
+    cur = torch.cuda.current_stream(ctx.device)
+    if cur.cuda_stream != ctx.stream.cuda_stream:
+        ev = torch.cuda.Event()
+        ev.record(ctx.stream)
+        cur.wait_event(ev)
+        ctx.set_stream(cur)
+    return ctx
 
 
 def _ptr(t):

@@ -124,3 +124,25 @@ def test_constraint_transforms_golden(ctx):
     plain = SurrogateDensity(PolyModel('quadratic', input_size=n, output_size=1))
     assert np.array_equal(plain.to_original(z['x_trans']), z['x_trans'])
     assert np.array_equal(plain.to_original_grad(z['x_trans']), np.ones_like(z['x_trans']))
+
+
+def test_default_context_follows_torchs_current_stream():
+    """get_context() re-binds the process-wide context to torch's current stream (ordered after the work queued on the
+    previous one), so host-side torch ops and the library's launches share a stream inside ``torch.cuda.stream`` blocks."""
+    import torch
+    from bayesfast_amd.device import get_context, DeviceDensity
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    ctx = get_context(0)
+    s0 = ctx.stream
+    side = torch.cuda.Stream()
+    spec, _ = correlated_gaussian_spec(16)
+    x = np.random.default_rng(0).normal(size=(4096, 16))
+    lp0, g0 = DeviceDensity(spec, ctx).logp_and_grad(ctx.tensor(x))
+    with torch.cuda.stream(side):
+        c2 = get_context(0)
+        assert c2 is ctx and ctx.stream.cuda_stream == side.cuda_stream
+        xt = ctx.tensor(x)  # an H2D copy on the side stream, then a launch that reads it
+        lp1, g1 = DeviceDensity(spec, ctx).logp_and_grad(xt)
+    side.synchronize()
+    assert get_context(0).stream.cuda_stream == torch.cuda.current_stream().cuda_stream == s0.cuda_stream
+    assert torch.equal(lp0, lp1) and torch.equal(g0, g1)
