@@ -80,6 +80,7 @@ SYMBOLS = {
     'bfhip_chi2_stage': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp]),
     'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
     'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
+    'bfhip_tree_size_mode_share': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_double, _vp]),
     'bfhip_solve_spd': (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     'bfhip_lstsq': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     'bfhip_sort_keys': (C.c_int, [_vp, C.c_long, _vp, _vp, _vp]),

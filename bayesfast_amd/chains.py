@@ -86,7 +86,7 @@ class DeviceChains:
         ``layout`` chooses how a workgroup's 16 chains are laid out (``bfhip_sampler_config.chain_layout``): 'group' (lane
         per chain: fastest while the chains of a workgroup stay in step), 'wave' (wave per chain: insensitive to chains
         out of step) or 'auto', decided per launch: 'group' when at least 98 % of the NUTS trees of the previous launch's
-        last 64 iterations had one and the same size (static HMC: always), 'wave' otherwise and for the first launch.
+        last 32 iterations had one and the same size (static HMC: always), 'wave' otherwise and for the first launch.
         Both layouts follow the same per-chain arithmetic and random streams; their floating-point sums are ordered
         differently, so results are bit-reproducible (and independent of sharding and launch cuts) for a fixed layout,
         and agree to rounding between layouts.
@@ -121,7 +121,6 @@ class DeviceChains:
                     not t.is_contiguous()):
                 raise ValueError('{} should be a contiguous float64 tensor of shape {} on {}.'.format(name, shape, self.ctx.device))
         step = max(1, int(launch_iters) if launch_iters else n_run)
-        ts_col = _lib.NSTATS.index('tree_size')
         for i_launch, done in enumerate(range(step, n_run + step, step)):  # iter_end of each launch; output rows are relative to i_iter
             # the layout is chosen per launch from the trees of the launch before: the first launch of a run takes the
             # latest answer that has already arrived (never waits: back-to-back runs stay queued), the following ones
@@ -135,7 +134,7 @@ class DeviceChains:
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),
                 _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
             if layout == 'auto':
-                self._note_trees(stats[:, done - step:min(done, n_run), ts_col], sampler)
+                self._note_trees(stats, done - step, min(done, n_run), sampler)
         self.i_iter += n_run
         if check:
             self.raise_on_error()
@@ -185,21 +184,23 @@ class DeviceChains:
             self.raise_on_error()
         return samples, stats, stats_t
 
-    def _note_trees(self, tree_sizes, sampler, n_last=64, share=0.98):
-        """Queue, behind the launch that wrote them, the answer to "did the chains run in step?": at least ``share`` of the
-        NUTS trees of its last ``n_last`` iterations (all chains; ``tree_sizes`` (n_chain, iterations)) had the most common
-        size.  The flag travels to pinned host memory asynchronously."""
+    def _note_trees(self, stats, row0, row1, sampler, n_last=32, share=0.98):
+        """Queue, behind the launch that wrote rows [row0, row1) of ``stats``, the answer to "did the chains run in step?":
+        at least ``share`` of the NUTS trees of its last ``n_last`` iterations (all chains) had the most common size
+        (``bfhip_tree_size_mode_share``: one small kernel).  The flag travels to pinned host memory asynchronously;
+        nothing here synchronises."""
         torch = _torch()
-        if sampler != 'NUTS' or tree_sizes.shape[1] == 0 or not tree_sizes.is_cuda:
+        if sampler != 'NUTS' or row1 <= row0:
             self._step_flag = None
             return
+        if getattr(self, '_step_host', None) is None:
+            self._step_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            self._step_dev = torch.zeros(4098, dtype=torch.int32, device=self.ctx.device)  # BFHIP_TREE_MODE_WORK
+        r0 = max(row0, row1 - n_last)
+        _lib.check(self.ctx._lib.bfhip_tree_size_mode_share(self.ctx.handle, self.n_chain, stats.shape[1], _ptr(stats), r0,
+                                                            row1 - r0, float(share), _ptr(self._step_dev)))
         with torch.cuda.stream(self.ctx.stream):
-            ts = tree_sizes[:, -n_last:].reshape(-1)
-            hist = torch.bincount(ts.to(torch.int64).clamp_(0, 4096), minlength=2)  # (a histogram pass; a sort takes 0.5 ms)
-            flag = (hist.max() >= share * ts.numel()).to(torch.int32).reshape(1)
-            if getattr(self, '_step_host', None) is None:
-                self._step_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-            self._step_host.copy_(flag, non_blocking=True)
+            self._step_host.copy_(self._step_dev[:1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.ctx.stream)
         self._step_flag = ev

@@ -1406,3 +1406,60 @@ extern "C" int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const 
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// "Did the chains run in step?" -- the share of the most common NUTS tree size among rows [row0, row0 + n_rows) of the
+// statistics of all chains, compared with a threshold.  work (BFHIP_TREE_MODE_WORK int32, zeroed once by the caller):
+// [0] the answer, [1 .. 4096] histogram of the sizes 0 .. 4095, [4097] arrival counter; every workgroup adds its LDS
+// histogram, the last one to arrive decides and clears the buffer for the next call.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_out, const double *__restrict__ stats, int row0,
+                                                           int n_rows, double share, int *__restrict__ work) {
+    __shared__ unsigned int hist[4096];
+    __shared__ unsigned int best;
+    __shared__ int last;
+    for (int i = threadIdx.x; i < 4096; i += 256) hist[i] = 0;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    const long total = (long)n_chain * n_rows;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long c = i / n_rows, r = row0 + i % n_rows;
+        const double t = stats[(c * n_out + r) * BFHIP_STAT_STRIDE + BFHIP_NS_TREE_SIZE];
+        const int b = t >= 0. && t < 4095. ? (int)t : 4095;
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    unsigned int *gh = (unsigned int *)work + 1;
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (hist[i]) atomicAdd(&gh[i], hist[i]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&work[4097], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    unsigned int mx = 0;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const unsigned int v = atomicExch(&gh[i], 0u);  // (read through the atomic path, and cleared for the next call)
+        mx = v > mx ? v : mx;
+    }
+    atomicMax(&best, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        work[0] = ((double)best >= share * (double)total) ? 1 : 0;
+        work[4097] = 0;
+    }
+}
+
+extern "C" int bfhip_tree_size_mode_share(bfhip_ctx *ctx, int n_chain, int n_out, const double *stats, int row0, int n_rows,
+                                          double share, int *work) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || n_chain < 1 || n_out < 1 || !stats || row0 < 0 || n_rows < 1 || row0 + n_rows > n_out || !work)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_tree_size_mode_share: invalid argument");
+    const long total = (long)n_chain * n_rows;
+    int grid = (int)((total + 1023) / 1024);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(bf_tree_mode_kernel, dim3(grid), dim3(256), 0, ctx->stream, n_chain, n_out, stats, row0, n_rows, share, work);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
