@@ -61,39 +61,28 @@ struct GroupGeo {
     static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * LSH, NVAL = V_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);       // sums of the merge levels LSH+1 .. MAXL-1
     static constexpr size_t lds_doubles(int nmat) {
-        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS + (size_t)W * 16;
+        return (size_t)nmat * NS * 64 + (size_t)NVAL * W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS + (size_t)2 * W * 16;
     }
     // per-chain global scratch, in vectors of DP doubles: 5 per stack level 2 .. MAXL-1, then the deep sums
     static constexpr int S_DEEP = 5 * (MAXL - 2);
     static constexpr int scratch_slots() { return S_DEEP + (NDEEP * W + DP - 1) / DP; }
 };
 
-// constraint transform of one coordinate: transforms/_constraint.pyx:133-215 (to_original f, j, jj); same expressions
-// as bf_to_original (bfhip_eval.h)
-BF_DEV void bf_to_original_g(double x, int kind, double lo, double rg, double &xo, double &J, double &J2) {
-    double tmp, jt, j2t;
-    if (kind == 1) {
-        tmp = 1. / (1. + bf_exp(-x));
-        jt = tmp * (1. - tmp);
-        const double t2 = bf_exp(x);
-        j2t = -t2 * (t2 - 1.) / (t2 + 1.) / (t2 + 1.) / (t2 + 1.);
-    } else if (kind == 2) {
-        tmp = bf_exp(x);
-        jt = tmp;
-        j2t = tmp;
-    } else if (kind == 3) {
-        const double ex = bf_exp(x);
-        tmp = 1. - ex;
-        jt = -ex;
-        j2t = -ex;
-    } else {
-        tmp = x;
-        jt = 1.;
-        j2t = 0.;
-    }
+// Constraint transform of one coordinate, transforms/_constraint.pyx:133-215: the original coordinate xo, the Jacobian J and
+// the ratio J2 / J the gradient needs (density.py:749-750).  One exponential serves every kind (lanes of a wave hold
+// coordinates of different kinds, so branches would run all of them): with e = exp(-x) the logistic kind is
+// t = 1 / (1 + e), J = t (1 - t) rg and J2 / J = -t2 (t2 - 1) / (t2 + 1)^3 / (t (1 - t)) = (e - 1) t  (t2 = exp(x) = 1 / e);
+// the one-sided kinds have J2 = J.  Agrees with the statement-by-statement form (bf_to_original, bfhip_eval.h) to rounding.
+BF_DEV void bf_to_original_g(double x, int kind, double lo, double rg, double &xo, double &J, double &gj) {
+    const double e = bf_exp(kind == 1 ? -x : x);
+    const double t = 1. / (1. + e);
+    double tmp = x, jt = 1., gq_ = 0.;
+    if (kind == 1) { tmp = t; jt = t * (1. - t); gq_ = (e - 1.) * t; }
+    if (kind == 2) { tmp = e; jt = e; gq_ = 1.; }
+    if (kind == 3) { tmp = 1. - e; jt = -e; gq_ = 1.; }
     xo = lo + tmp * rg;
     J = jt * rg;
-    J2 = j2t * rg;
+    gj = gq_;
 }
 
 template <int W, bool NUTS, int FS>
@@ -105,7 +94,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
     double *TV = RB + G::NVAL * W * 16;        // [NTV][DP][16]   tree vectors
     double *LS = TV + G::NTV * DP * 16;        // [16][LSS]       subtree stack scalars (one writer: wave 0)
-    double *PB = LS + 16 * LSS;                // [W][16]         per-wave |x - mu|^2 of the point in flight (bound proof)
+    double *PB = LS + 16 * LSS;                // [2][W][16]      per-wave |x - mu|^2, |x - mu_decay|^2 of the point in flight (proofs)
 
     const int tid = bf_tid(), lane = tid & 63, j = tid >> 6, c = lane & 15, gq = lane >> 4;
     const int chain = bf_group() * 16 + c;
@@ -114,6 +103,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     const int d = m.d, dbase = 16 * j + gq;    // element r is dimension dbase + 4 r
     const int nw = a.cfg.n_warmup;
     const double bound_thr = m.use_bound ? m.alpha * m.alpha * (1. - 1e-9) : __builtin_inf();
+    const double decay_thr = m.decay_alpha2 * (1. - 1e-9);
 
     // ---- constants: A operands of this wave's row tile, per-dimension table rows ----
     double afS[NS], afH[NS], afD[DEC ? NS : 1];
@@ -374,11 +364,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             gj[r] = 0.;
             if constexpr (TR) {
                 if (ev) {
-                    double J, J2;
-                    bf_to_original_g(q[r], c_kind[r], c_lo[r], c_rg[r], xs[r], J, J2);
+                    double J, g2;
+                    bf_to_original_g(q[r], c_kind[r], c_lo[r], c_rg[r], xs[r], J, g2);
                     ldet[r] = 0. + bf_log(bf_fabs(J));
                     jac[r] = J;
-                    gj[r] = J2 / J;
+                    gj[r] = g2;
                 }
             }
             xo[r] = xs[r];
@@ -403,6 +393,17 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
             if (mode == M_OOB || mode == M_FIN) r2p = __builtin_inf();  // passes that need H (x - mu) itself
             if (gq == 0) PB[j * 16 + c] = r2p;
+            if constexpr (DEC) {
+                // the same for the decay term (density.py:740-746): inactive while (x - mu_d)^T H_d (x - mu_d) <= alpha_d^2
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double xm = xo[r] - c_dmu[r];
+                    t_r2[r] = ev ? xm * xm : 0.;
+                }
+                double r2d = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
+                if (mode == M_FIN) r2d = __builtin_inf();  // the pass that needs the decay gradient itself
+                if (gq == 0) PB[(W + j) * 16 + c] = r2d;
+            }
         }
         GTRACE(1);
         bf_sync();  // B1
@@ -417,21 +418,30 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
             for (int s = 0; s < KH; ++s) {
                 aS0 = bf_mfma(afS[s], XB[(0 * NS + s) * 64 + lane], aS0);
-                if constexpr (DEC) aD0 = bf_mfma(afD[s], XB[(2 * NS + s) * 64 + lane], aD0);
-                if constexpr (KS == 2) {
-                    aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
-                    if constexpr (DEC) aD1 = bf_mfma(afD[KH + s], XB[(2 * NS + KH + s) * 64 + lane], aD1);
-                }
+                if constexpr (KS == 2) aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
             }
-            double r2 = PB[c];  // (read behind the S tiles: the matrix pipe is busy with them while the loads travel)
+            double r2 = PB[c], r2d = DEC ? PB[W * 16 + c] : 0.;  // (read behind the S tiles: the matrix pipe is busy with them)
 #pragma unroll
-            for (int w2 = 1; w2 < W; ++w2) r2 += PB[w2 * 16 + c];
+            for (int w2 = 1; w2 < W; ++w2) {
+                r2 += PB[w2 * 16 + c];
+                if constexpr (DEC) r2d += PB[(W + w2) * 16 + c];
+            }
             const bool inside = !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven)
             if (bf_any(!inside)) {
 #pragma unroll
                 for (int s = 0; s < KH; ++s) {
                     aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
                     if constexpr (KS == 2) aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
+                }
+            }
+            if constexpr (DEC) {
+                const bool calm = !a.no_bound_proof && m.lam_max_d * r2d < decay_thr;
+                if (bf_any(!calm)) {
+#pragma unroll
+                    for (int s = 0; s < KH; ++s) {
+                        aD0 = bf_mfma(afD[s], XB[(2 * NS + s) * 64 + lane], aD0);
+                        if constexpr (KS == 2) aD1 = bf_mfma(afD[KH + s], XB[(2 * NS + KH + s) * 64 + lane], aD1);
+                    }
                 }
             }
 #pragma unroll

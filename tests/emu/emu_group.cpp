@@ -251,6 +251,7 @@ extern "C" int bfemu_sampler_run(const bfhip_density_desc *ds, const bfhip_sampl
     m.c0 = ds->c0;
     m.alpha = ds->alpha;
     m.lam_max = ds->use_bound ? bf_bound_lam_max(ds->hess, ds->d) : 0.;
+    m.lam_max_d = ds->use_decay ? bf_bound_lam_max(ds->decay_hess, ds->d) : 0.;
     m.f_mu = ds->f_mu;
     m.decay_alpha2 = ds->decay_alpha2;
     m.decay_gamma = ds->decay_gamma;
