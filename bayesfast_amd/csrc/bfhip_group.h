@@ -129,11 +129,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     }
 
     // ---- per-chain state: vectors (4 elements per lane) ----
-    double q[4], p[4], g[4], var[4];
+    double q[4], p[4], g[4], var[4], isd[4];           // isd = var^-1/2 (momentum draws)
     double L0p[4], L0q[4], L0g[4];                    // stack level 0: a single waiting leaf
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        q[r] = 0.; p[r] = 0.; g[r] = 0.; var[r] = 1.;
+        q[r] = 0.; p[r] = 0.; g[r] = 0.; var[r] = 1.; isd[r] = 1.;
         L0p[r] = L0q[r] = L0g[r] = 0.;
     }
     // ---- per-chain state: scalars (one copy per lane) ----
@@ -294,7 +294,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             for (int r = 0; r < 4; ++r) {
                 // elements 2 godd, 2 godd + 1 are this lane's own pairs; the other two come from the partner
                 const double z = ((r >> 1) == godd) ? mine[r & 1] : theirs[r & 1];
-                p[r] = (dbase + 4 * r < d) ? (1. / bf_sqrt(var[r])) * z : 0.;
+                p[r] = (dbase + 4 * r < d) ? isd[r] * z : 0.;
             }
         }
     };
@@ -333,6 +333,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         err = (int)scp[BFHIP_SC_ERROR];
         load_vec(BFHIP_VEC_Q, q, 0.);
         load_vec(BFHIP_VEC_VAR, var, 1.);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) isd[r] = 1. / bf_sqrt(var[r]);  // metrics.py:83-86: kept between the metric's updates
         if (i_iter < a.iter_end && err == 0) mode = M_INIT;
     }
     draw_momentum(mode == M_INIT);
@@ -939,7 +941,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 if ((delta + 1) % (long)a.cfg.update_window == 0) {  // metrics.py:181-184
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (dbase + 4 * r < d) var[r] = fr[r] / fg_n;
+                        if (dbase + 4 * r < d) { var[r] = fr[r] / fg_n; isd[r] = 1. / bf_sqrt(var[r]); }
                     store_vec(BFHIP_VEC_VAR, var);
                 }
                 if ((double)delta >= adapt_window) {
