@@ -221,14 +221,25 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     // the other values' instructions (one wave per SIMD: nothing else hides it)
     auto post_n = [&](int vi0, auto &part) {
         constexpr int N = sizeof(part) / sizeof(double);
+        // four values take three swaps (bf_pair16_add twice, bf_pair32_add once) and end up one per row g; two values take
+        // two; the additions are those of bf_xor32_add(bf_xor16_add(.)) for every value
+        constexpr int NQ = N / 4, NP = (N % 4) / 2, N1 = N % 2;
+        double sq[NQ > 0 ? 2 * NQ : 1], sp[NP > 0 ? NP : 1], s1[N1 > 0 ? N1 : 1];
 #pragma unroll
-        for (int i = 0; i < N; ++i) part[i] = bf_xor16_add(part[i]);
-#pragma unroll
-        for (int i = 0; i < N; ++i) part[i] = bf_xor32_add(part[i]);
-        if (gq == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) RB[((vi0 + i) * W + j) * 16 + c] = part[i];
+        for (int k = 0; k < NQ; ++k) {
+            sq[2 * k] = bf_pair16_add(part[4 * k], part[4 * k + 1]);
+            sq[2 * k + 1] = bf_pair16_add(part[4 * k + 2], part[4 * k + 3]);
         }
+        if constexpr (NP > 0) sp[0] = bf_pair16_add(part[4 * NQ], part[4 * NQ + 1]);
+        if constexpr (N1 > 0) s1[0] = bf_xor16_add(part[N - 1]);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) sq[k] = bf_pair32_add(sq[2 * k], sq[2 * k + 1]);
+        if constexpr (NP > 0) sp[0] = bf_xor32_add(sp[0]);
+        if constexpr (N1 > 0) s1[0] = bf_xor32_add(s1[0]);
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) RB[((vi0 + 4 * k + gq) * W + j) * 16 + c] = sq[k];
+        if constexpr (NP > 0) { if (gq < 2) RB[((vi0 + 4 * NQ + gq) * W + j) * 16 + c] = sp[0]; }
+        if constexpr (N1 > 0) { if (gq == 0) RB[((vi0 + N - 1) * W + j) * 16 + c] = s1[0]; }
     };
     // N group-wide sums read together (all loads in flight before the first add)
     auto rd_n = [&](int vi0, auto &out) {
@@ -413,6 +424,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 
         // ================= phase B: row tile j of S x, H (x - mu) (, H_decay^T (x - mu_decay)) on MFMA =================
         double sx[4], hv[4], dgr[4];
+        bool skipH = false;  // wave-uniform (and the same in every wave): the bound's tiles were left out, b2 is not posted
         {
             bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
             bf_acc4 aD0 = bf_acc4_zero(), aD1 = bf_acc4_zero();
@@ -429,7 +441,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 if constexpr (DEC) r2d += PB[(W + w2) * 16 + c];
             }
             const bool inside = !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven)
-            if (bf_any(!inside)) {
+            skipH = !bf_any(!inside);
+            if (!skipH) {
 #pragma unroll
                 for (int s = 0; s < KH; ++s) {
                     aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
@@ -480,9 +493,14 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 pn[r] = bf_fma(dt_c, ge[r], p[r]);
                 t_kin[r] = pn[r] * (var[r] * pn[r]);
             }
-            double e3[3] = {sum4(t_kin), sum4(t_val), sum4(t_b2)};
             static_assert(G::V_KIN == 0 && G::V_VAL == 1 && G::V_B2 == 2, "posted as one batch");
-            post_n(G::V_KIN, e3);
+            if (skipH) {
+                double e2[2] = {sum4(t_kin), sum4(t_val)};
+                post_n(G::V_KIN, e2);
+            } else {
+                double e3[3] = {sum4(t_kin), sum4(t_val), sum4(t_b2)};
+                post_n(G::V_KIN, e3);
+            }
             if (bf_any(mode == M_OOB)) {
                 double t_dotj[4];
 #pragma unroll
@@ -585,7 +603,13 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // ================= the evaluation's scalars =================
         // this trip's sums, fetched together (one LDS round trip instead of one per value)
         double sv_e[3], sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
-        rd_n(G::V_KIN, sv_e);
+        if (skipH) {
+            double sv_2[2];
+            rd_n(G::V_KIN, sv_2);
+            sv_e[0] = sv_2[0]; sv_e[1] = sv_2[1]; sv_e[2] = 0.;  // inside the bound, proven
+        } else {
+            rd_n(G::V_KIN, sv_e);
+        }
         const bool any_e0 = bf_any(need_E0);
         if (any_e0) rd_n(G::V_KIN0, sv_k0);
         if (any_m0) rd_n(G::V_M0, sv_m0);

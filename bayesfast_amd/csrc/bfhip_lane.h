@@ -35,6 +35,19 @@ BF_DEV double bf_xor32_add(double v) {
     const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
+// Two values reduced over lane pairs by ONE swap: v_permlane16_swap(a, b) leaves rows (a0, b0, a2, b2) in its first result
+// and (a1, b1, a3, b3) in its second, so their sum is a + a(l ^ 16) in the even rows and b + b(l ^ 16) in the odd rows;
+// v_permlane32_swap likewise for the lower / upper 32 lanes.  (The same additions as bf_xor16_add / bf_xor32_add.)
+BF_DEV double bf_pair16_add(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+BF_DEV double bf_pair32_add(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
 // the value of lane l ^ 16.  v_permlane16_swap with both operands v leaves rows (0, 0, 2, 2) of v in the first result
 // and rows (1, 1, 3, 3) in the second: a lane of an even row finds its partner in the second, of an odd row in the first
 BF_DEV double bf_xor16_get(double v) {

@@ -139,6 +139,16 @@ double emu_xor_get(double v, int mask) {
     emu_barrier(E->wave[w], 64);
     return o;
 }
+// lanes with the mask bit clear: a + a(l ^ mask); lanes with it set: b + b(l ^ mask)
+double emu_pair_add(double a, double b, int mask) {
+    const int w = E->cur >> 6, l = E->cur & 63;
+    E->xa[w][l] = a;
+    E->xb[w][l] = b;
+    emu_barrier(E->wave[w], 64);
+    const double r = (l & mask) ? b + E->xb[w][l ^ mask] : a + E->xa[w][l ^ mask];
+    emu_barrier(E->wave[w], 64);
+    return r;
+}
 bf_acc4 emu_mfma(double a, double b, bf_acc4 c) {
     const int w = E->cur >> 6, l = E->cur & 63;
     E->xa[w][l] = a;  // A[i = l & 15][k = l >> 4]

@@ -24,6 +24,7 @@ void emu_sync();
 bool emu_any(bool p);
 double emu_xor_add(double v, int mask);
 double emu_xor_get(double v, int mask);
+double emu_pair_add(double a, double b, int mask);
 bf_acc4 emu_mfma(double a, double b, bf_acc4 c);
 
 BF_DEV int bf_tid() { return emu_tid(); }
@@ -34,6 +35,8 @@ BF_DEV bf_acc4 bf_mfma(double a, double b, bf_acc4 c) { return emu_mfma(a, b, c)
 BF_DEV double bf_xor16_add(double v) { return emu_xor_add(v, 16); }
 BF_DEV double bf_xor32_add(double v) { return emu_xor_add(v, 32); }
 BF_DEV double bf_xor16_get(double v) { return emu_xor_get(v, 16); }
+BF_DEV double bf_pair16_add(double a, double b) { return emu_pair_add(a, b, 16); }
+BF_DEV double bf_pair32_add(double a, double b) { return emu_pair_add(a, b, 32); }
 BF_DEV double bf_exp(double x) { return std::exp(x); }
 BF_DEV double bf_log(double x) { return std::log(x); }
 BF_DEV double bf_sqrt(double x) { return std::sqrt(x); }
