@@ -519,8 +519,9 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         auto uturn_sums = [&](bool act) {
             // act: this lane's chain takes part (all lanes run the collectives)
             nm = 0;
-            if (act) {
-                while (nm < depth && ((i_leaf >> nm) & 1)) ++nm;
+            if (act) {  // trailing one bits of i_leaf, at most depth
+                const int t1 = __builtin_ctz(~(unsigned)i_leaf);
+                nm = t1 < depth ? t1 : depth;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { tTL[r] = pn[r]; tTPs[r] = pn[r]; tPS[r] = 0.; }
