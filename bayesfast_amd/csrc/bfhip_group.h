@@ -38,10 +38,16 @@
 
 // tuning builds (tools/gvariant.sh -DBF_GTRACE=<n>): lane 0 of workgroup 0 stamps the cycle counter at up to 8 points
 // of each of its first n trips into a.stamps
-#if defined(BF_GTRACE) && !defined(BF_HOST_EMU)
+#if defined(BF_GTRACE2) && !defined(BF_HOST_EMU)
+// second set of stamp points (inside the state machine): -DBF_GTRACE2=<n>
+#define GTRACE(k) do { if ((k) == 0 && tid == 0 && bf_group() == 0 && a.stamps && trip_no < BF_GTRACE2) a.stamps[trip_no * 8] = __builtin_readcyclecounter(); } while (0)
+#define GTRACE2(k) do { if (tid == 0 && bf_group() == 0 && a.stamps && trip_no < BF_GTRACE2) a.stamps[trip_no * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#elif defined(BF_GTRACE) && !defined(BF_HOST_EMU)
+#define GTRACE2(k) do { } while (0)
 #define GTRACE(k) do { if (tid == 0 && bf_group() == 0 && a.stamps && trip_no < BF_GTRACE) a.stamps[trip_no * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define GTRACE(k) do { } while (0)
+#define GTRACE2(k) do { } while (0)
 #endif
 
 template <int W>
@@ -618,6 +624,34 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         if (any_ext) rd_n(G::V_EXT, sv_x);
         bool fin = false;
         double logp_new = 0., kin = 0.;
+        // The common trip: every evaluating chain is in its first pass over the point and proven inside the bound, so the
+        // value is complete (the branches below are skipped as one; per-lane branches cost a round trip through the scalar
+        // unit each, with one wave per SIMD nothing hides it).  Same arithmetic as the general path.
+        const bool first_pass = mode != M_FIN && mode != M_OOB;
+        const bool all_plain = skipH && !bf_any(ev && !first_pass);
+        if (all_plain) {
+            if (ev) {
+                double f = (m.c0 + sv_e[1]) + 0.;
+                fin_oob = false;
+                fin_dec = false;
+                if constexpr (DEC) {  // density.py:740-746
+                    const double r_bd2 = rd(G::V_BD2);
+                    const double ex = r_bd2 - m.decay_alpha2;
+                    f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                    fin_dec = r_bd2 > m.decay_alpha2;
+                }
+                if constexpr (TR) f += rd(G::V_LOGDET);
+                if (DEC && fin_dec) {
+                    prev_mode = mode;
+                    logp_keep = f;
+                    mode = M_FIN;
+                } else {
+                    fin = true;
+                    logp_new = f;
+                    kin = sv_e[0];
+                }
+            }
+        } else
         if (ev) {
             if (mode == M_FIN) {
                 fin = true;
@@ -678,7 +712,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             E_new = 0.5 * kin - logp_new;                                  // :92-93
         }
         // the start energy of an iteration that began at the end of the previous trip
-        if (need_E0 && ev) {
+        if (any_e0 && need_E0 && ev) {
             const double E0 = 0.5 * sv_k0[0] - prop_logp;  // integration.py:28-34
             if (!(bf_fabs(E0) <= BF_DBL_MAX)) err = 1;           // base_hmc.py:72-76
             start_energy = E0;
@@ -687,48 +721,44 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
 
         GTRACE(7);
+        GTRACE2(1);
         // ================= per-chain state machine =================
         enum { S_NONE, S_MERGE, S_ABORT, S_DBL_END, S_END };
         int st = S_NONE, lev = 0, src = -1;  // src: whose proposal the finished subtree holds (-1 this leaf, 0 L0, l stack level l)
         double dE = 0., aw = 0., sc_ = 1.;
         bool resc = false;
-        if (fin && err == 0 && mode == M_INIT) {
-            // BaseHMC.astep start (the first iteration of a launch): base_hmc.py:70-76
-            if (!(bf_fabs(E_new) <= BF_DBL_MAX)) {
-                err = 1;
-            } else {
-                start_energy = E_new;
-                prop_E = E_new;
-                prop_logp = logp_new;
-                tree_reset();
+        const bool ok = fin && err == 0;
+        const bool is_init = ok && mode == M_INIT, leaf = ok && mode == M_LEAF;
+        if (bf_any(is_init)) {  // the first iteration of a launch only
+            if (is_init) {
+                // BaseHMC.astep start: base_hmc.py:70-76
+                if (!(bf_fabs(E_new) <= BF_DBL_MAX)) {
+                    err = 1;
+                } else {
+                    start_energy = E_new;
+                    prop_E = E_new;
+                    prop_logp = logp_new;
+                    tree_reset();
+                }
             }
-        } else if (fin && err == 0 && mode == M_LEAF) {
+        }
+        if (leaf) {
             nlf += 1;
             if constexpr (NUTS) {
-                // ---- Tree._single_step: nuts.py:105-132 ----
+                // ---- Tree._single_step: nuts.py:105-132 (selects instead of branches: see above) ----
                 n_prop += 1;
                 dE = E_new - start_energy;
-                if (dE != dE) dE = __builtin_inf();
-                if (bf_fabs(dE) > bf_fabs(max_de)) max_de = dE;
+                dE = (dE != dE) ? __builtin_inf() : dE;
+                max_de = (bf_fabs(dE) > bf_fabs(max_de)) ? dE : max_de;
                 T_E = E_new;
                 T_logp = logp_new;
                 T_acc = 0.;
-                st = S_MERGE;
-                if (!(bf_fabs(dE) < a.cfg.max_change)) {
-                    diverged = 1;
-                    st = S_ABORT;
-                } else {
-                    // multinomial weight exp(-dE) relative to a running offset w_off (exact streaming log-sum-exp)
-                    aw = -dE - w_off;
-                    if (aw > 600.) {
-                        sc_ = bf_exp(-aw);
-                        tree_W = tree_W * sc_;
-                        L0_W *= sc_;
-                        w_off = w_off + aw;
-                        aw = 0.;
-                        resc = true;
-                    }
-                }
+                const bool dv = !(bf_fabs(dE) < a.cfg.max_change);
+                diverged = dv ? 1 : diverged;
+                st = dv ? S_ABORT : S_MERGE;
+                // multinomial weight exp(-dE) relative to a running offset w_off (exact streaming log-sum-exp)
+                aw = dv ? 0. : -dE - w_off;
+                resc = aw > 600.;
             } else {
                 // ---- HMC._hamiltonian_step: samplers/hmc.py:16-49 ----
                 i_leaf += 1;
@@ -753,8 +783,16 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
         }
+        GTRACE2(2);
         if constexpr (NUTS) {
-            if (bf_any(resc)) {  // (rare) the stacked subtrees' weights follow the new offset; wave 0 owns them
+            if (bf_any(resc)) {  // (rare) the weights follow a new offset; the stacked subtrees' are wave 0's
+                if (resc) {
+                    sc_ = bf_exp(-aw);
+                    tree_W = tree_W * sc_;
+                    L0_W *= sc_;
+                    w_off = w_off + aw;
+                    aw = 0.;
+                }
                 bf_sync();
                 if (writer && resc)
                     for (int l2 = 1; l2 < depth; ++l2) lsc[l2 * 4 + LS_LS] *= sc_;
@@ -764,6 +802,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 T_W = bf_exp(aw);
                 const double pacc = (w_off == 0.) ? T_W : bf_exp(-dE);
                 T_acc = pacc > 1. ? 1. : pacc;
+                GTRACE2(3);
                 if (nm >= 1) {
                     // ---- level-0 merge with the waiting leaf L0 (nuts.py:146-178) ----
                     const double d0 = sv_m0[0], d1 = sv_m0[1];
@@ -836,6 +875,12 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     }
                 }
             }
+        }
+        GTRACE2(4);
+        // nothing below happens in a trip in which no chain of the group ends a subtree's doubling, a tree or an iteration
+        const bool any_end = bf_any(st != S_NONE);
+        if (any_end) {
+        if constexpr (NUTS) {
             if (st == S_ABORT) {
                 // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
                 for (int al = (diverged ? 0 : lev); al < depth; ++al)
@@ -891,6 +936,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
         }
+        GTRACE2(5);
         // ================= iteration end: base_hmc.py:80-85 =================
         bool new_iter = false;
         if (st == S_END && err == 0) {
@@ -987,6 +1033,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             if (i_iter < a.iter_end) new_iter = true;
             else mode = M_DONE;
         }
+        GTRACE2(6);
         if (bf_any(new_iter)) {
             // next iteration: metric.random, then the tree starts at (q, p) with the proposal's value and gradient; the
             // start energy needs the kinetic energy of the new momentum: it joins the next trip's exchange
@@ -1000,6 +1047,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 need_E0 = true;
             }
         }
+        }  // any_end
+        GTRACE2(7);
         if (err != 0) mode = M_DONE;
     }
 

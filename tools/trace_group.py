@@ -22,7 +22,7 @@ L.bfhip_debug_gstamps(C.c_void_p(buf.data_ptr()))
 dc.run(20, 'NUTS', n_warmup=750, **RKW)
 L.bfhip_debug_gstamps(None)
 t = buf.cpu().numpy().reshape(N, 8).astype(np.int64)
-print('points: 1 phase A done | 2 after B1 | 3 MFMAs + tile sums | 4 eval sums posted | 5 U-turn sums posted | 6 after B2 | 7 eval scalars | (next 0) state machine')
+LBL = os.environ.get("GLABELS", "1 phase A done | 2 after B1 | 3 MFMAs + tile sums | 4 eval sums posted | 5 U-turn sums posted | 6 after B2 | 7 eval scalars | (next 0) state machine"); print("points:", LBL)
 for i in range(2, N - 1):
     tt = t[i]
     if tt[0] == 0 or t[i + 1][0] == 0: continue
