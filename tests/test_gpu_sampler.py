@@ -576,3 +576,27 @@ def test_config1_donut_shapes_2d_decay_no_bound(ctx, order):
     for i, (so, sto, ch) in enumerate(_oracle_chains(spec, x0, 20, 12, sampler='HMC', n_int_step=6)):
         assert np.array_equal(st['accepted'][i], sto['accepted'])
         np.testing.assert_allclose(s[i][:8], so[:8], rtol=1e-9, atol=1e-9)
+
+
+def test_tree_size_mode_share_flag_matches_numpy(ctx):
+    """bfhip_tree_size_mode_share (the layout choice's helper): flag = [share of the most common tree_size in the given rows
+    >= threshold], for uniform, mixed and out-of-range sizes; the work buffer is left clean between calls."""
+    import torch
+    from bayesfast_amd import _lib
+    from bayesfast_amd.device import _ptr
+    rng = np.random.default_rng(8)
+    n_chain, n_out = 300, 40
+    work = torch.zeros(4098, dtype=torch.int32, device=ctx.device)
+    ts_col = _lib.NSTATS.index('tree_size')
+    for p_mode, row0, n_rows, share in ((1.0, 0, 40, 0.98), (0.99, 8, 32, 0.98), (0.9, 8, 32, 0.98), (0.9, 0, 7, 0.85), (0.5, 39, 1, 0.5)):
+        st = np.zeros((n_chain, n_out, _lib.STAT_STRIDE))
+        sizes = np.where(rng.uniform(size=(n_chain, n_out)) < p_mode, 7, rng.choice([1, 3, 15, 31, 5000], size=(n_chain, n_out)))
+        st[:, :, ts_col] = sizes
+        blk = np.minimum(sizes[:, row0:row0 + n_rows], 4095).reshape(-1)
+        want = int(np.bincount(blk).max() >= share * blk.size)
+        t = ctx.tensor(st)
+        _lib.check(ctx._lib.bfhip_tree_size_mode_share(ctx.handle, n_chain, n_out, _ptr(t), row0, n_rows, float(share), _ptr(work)))
+        torch.cuda.synchronize()
+        w = work.cpu().numpy()
+        assert int(w[0]) == want, (p_mode, row0, n_rows)
+        assert not w[1:].any()  # histogram and arrival counter cleared for the next call
