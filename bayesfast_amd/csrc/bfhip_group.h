@@ -164,6 +164,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     bool need_E0 = false;     // the running iteration's start energy waits for its kinetic part (this trip's exchange)
     double kin0_part = 0.;
     unsigned long long nlf = 0;
+    unsigned int n_trip = 0, n_trip_h = 0;  // measurement: trips of this group, trips that ran the bound's tiles
 
     double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
     double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
@@ -448,6 +449,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             const bool inside = !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven)
             skipH = !bf_any(!inside);
+            n_trip += 1;
+            n_trip_h += skipH ? 0 : 1;
             if (!skipH) {
 #pragma unroll
                 for (int s = 0; s < KH; ++s) {
@@ -1052,6 +1055,10 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         if (err != 0) mode = M_DONE;
     }
 
+    if (a.gcount && tid == 0) {
+        bf_atomic_add_u64(a.gcount, n_trip);
+        bf_atomic_add_u64(a.gcount + 1, n_trip_h);
+    }
     // ---- write the chain state back ----
     if (real) {
         store_vec(BFHIP_VEC_Q, q);

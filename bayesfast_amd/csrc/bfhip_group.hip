@@ -61,8 +61,13 @@ extern "C" void bfhip_debug_gstamps(unsigned long long *buf) { g_gstamps = buf; 
 static int g_no_bound_proof = 0;
 extern "C" void bfhip_debug_no_bound_proof(int on) { g_no_bound_proof = on; }
 
+// measurement hook (not part of include/bfhip.h): device buffer of two counters, trips and trips with the bound's tiles
+static unsigned long long *g_gcount = NULL;
+extern "C" void bfhip_debug_group_counters(unsigned long long *buf) { g_gcount = buf; }
+
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
+    args.gcount = g_gcount;
     args.stamps = g_gstamps;
     args.no_bound_proof = g_no_bound_proof;
     const DevModel &m = ctx->model;

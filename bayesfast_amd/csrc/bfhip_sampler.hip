@@ -1329,6 +1329,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.n_leapfrog = n_leapfrog;
     args.stamps = g_stamps;
     args.no_bound_proof = 0;
+    args.gcount = NULL;
     args.mat = (cfg->full_metric && cfg->metric_mat) ? cfg->metric_mat : NULL;
     if (cfg->full_metric && !cfg->metric_mat) return bf_set_error(BFHIP_ERR_ARG, "bfhip_sampler_run: full_metric without metric_mat");
     const size_t need = (size_t)((n_chain + 15) / 16 * 16) * args.nslot * m.DP * sizeof(double);

@@ -248,6 +248,10 @@ def main():
             torch.cuda.synchronize()
 
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        # measurement hook of the group kernel: trips, and trips that executed the bound's H (x - mu) tiles
+        gcount = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+        import ctypes
+        _lib.lib().bfhip_debug_group_counters(ctypes.c_void_p(gcount.data_ptr()))
         sync()
         t0 = time.perf_counter()
         for k in range(a.steps):
@@ -257,6 +261,8 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         chains.raise_on_error()
+        _lib.lib().bfhip_debug_group_counters(None)
+        g_trips, g_trips_h = [int(v) for v in gcount.cpu().numpy()]
         n_lf = chains.total_leapfrog - lf0
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if a.steps else 0.
         st_last = stats.cpu().numpy()
@@ -308,10 +314,14 @@ def main():
                          'kernel': kernel_name, 'kernel_ms_per_launch': kernel_ms,
                          'traffic_source': None if traffic is None else 'stored profile (profiles/hbm_traffic.json), not this run',
                          'flops_per_leapfrog': flops_per_leapfrog(d, use_bound),
+                         'group_trips': g_trips, 'group_trips_with_bound_tiles': g_trips_h,
+                         'frac_executed': (None if not g_trips or not use_bound else
+                                           (ach_tf / peak_tf) * 0.5 * (1. + g_trips_h / g_trips)),
                          'flops_note': 'algorithmic: S x and H (x - mu) per step (4 d^2). bf_group_kernel leaves the H tiles out of a '
                                        'trip when lam_max(H) |x - mu|^2 < alpha^2 proves all 16 chains of the group inside the bound '
                                        '(identical results); on this workload that is nearly every trip, so about half of the '
-                                       'algorithmic flops are decided, not executed'},
+                                       'algorithmic flops are decided, not executed (frac_executed: the same fraction counting the H tiles only '
+                                       'for the group_trips_with_bound_tiles of group_trips trips that ran them)'},
             'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
                                          'peak': 8000., 'unit': 'GB/s',
                                          'frac': (bytes_alg / (kernel_ms * 1e-3) / 1e9 / 8000.) if kernel_ms else 0.,
