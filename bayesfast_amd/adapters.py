@@ -14,7 +14,8 @@ Fields read, with the reference lines that define them:
 """
 import numpy as np
 
-__all__ = ['poly_spec_from_reference', 'density_spec_from_reference', 'device_density_from_reference']
+__all__ = ['poly_spec_from_reference', 'density_spec_from_reference', 'device_density_from_reference',
+           'polymodel_from_reference', 'surrogate_density_from_reference']
 
 
 def poly_spec_from_reference(pm):
@@ -58,3 +59,55 @@ def device_density_from_reference(den, ctx=None):
     ``bayesfast_amd.chains.DeviceChains`` samples it."""
     from .device import DeviceDensity
     return DeviceDensity(density_spec_from_reference(den), ctx)
+
+
+def polymodel_from_reference(pm):
+    """``bayesfast.modules.PolyModel`` -> ``bayesfast_amd.PolyModel`` with the same configs, coefficients, bound and input
+    scales (attributes copied; nothing is re-fitted)."""
+    from .modules.poly import PolyConfig, PolyModel
+    configs = [PolyConfig(c.order, np.array(c.input_mask), np.array(c.output_mask)) for c in pm.configs]
+    use_bound = bool(pm._use_bound)
+    out = PolyModel(configs, input_size=int(pm._input_size), output_size=int(pm._output_size),
+                    bound_options=dict(use_bound=use_bound),
+                    input_scales=None if pm._input_scales is None else np.array(pm._input_scales, dtype=np.float64))
+    for c, r in zip(out.configs, pm.configs):
+        c._coef = np.array(r._coef, dtype=np.float64)
+    if use_bound and not pm._all_linear:
+        out._mu = np.array(pm._mu, dtype=np.float64)
+        out._hess = np.array(pm._hess, dtype=np.float64)
+        out._alpha = float(pm._alpha)
+        out._f_mu = np.array(pm._f_mu, dtype=np.float64)
+    for k in ('_alpha_p', '_center_max'):
+        if hasattr(pm, k) and hasattr(out, k):
+            setattr(out, k, getattr(pm, k))
+    out._dev_model_key = None
+    return out
+
+
+def surrogate_density_from_reference(den):
+    """``bayesfast.Density`` (one PolyModel surrogate with output_size 1) -> ``bayesfast_amd.SurrogateDensity``: what
+    ``bayesfast_amd.sample`` runs on, with the reference object's transforms, bound and decay state.  ``sample()`` calls this
+    for any density object that is not a ``SurrogateDensity`` but has a ``_surrogate_list``."""
+    from .core.density import SurrogateDensity
+    surrogates = list(den._surrogate_list)
+    if len(surrogates) != 1:
+        raise ValueError('the device density takes exactly one surrogate (the log-density PolyModel).')
+    d = int(den.input_size)
+    hb = den._hard_bounds
+    if isinstance(hb, (bool, np.bool_)):
+        hb = bool(hb)
+    else:
+        hb = np.array(hb)
+    out = SurrogateDensity(polymodel_from_reference(surrogates[0]),
+                           input_scales=None if den._input_scales is None else np.array(den._input_scales, dtype=np.float64),
+                           hard_bounds=hb if den._input_scales is not None else False,
+                           decay_options=dict(use_decay=bool(den._use_decay)))
+    if den._use_decay:
+        out._mu = np.array(den._mu, dtype=np.float64)
+        out._hess = np.array(den._hess, dtype=np.float64)
+        out._alpha_2 = float(den._alpha_2)
+        out._alpha = float(den._alpha_2)**0.5
+        out._gamma = float(den._gamma)
+    assert out._d == d
+    out._device = None
+    return out

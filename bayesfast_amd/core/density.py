@@ -120,8 +120,21 @@ class SurrogateDensity:
         return np.asarray(density) - diff
 
     # ---- fit ----
-    def fit(self, x, logp):
-        """``Density.fit`` (core/density.py:813-830) for x (n, d) original-space points with true logp (n,)."""
+    input_vars = ('__var__',)   # Density(input_vars=...), core/density.py:256
+    density_name = '__var__'    # Density(density_name=...), core/density.py:640
+
+    def fit(self, x, logp=None):
+        """``Density.fit`` (core/density.py:813-830): either ``fit(var_dicts)`` as in the reference -- a sequence of
+        VariableDict-like objects whose ``_fun`` (or ``fun``) maps variable names to arrays; the points are the
+        concatenated ``input_vars`` and the true log-densities ``_fun[density_name][0]`` (:833-838) -- or
+        ``fit(x, logp)`` with x (n, d) original-space points and logp (n,)."""
+        if logp is None:
+            vds = list(x)
+            if not vds or not all(hasattr(v, '_fun') or hasattr(v, 'fun') for v in vds):
+                raise ValueError('var_dicts should consist of VariableDict(s).')
+            get = lambda v: v._fun if hasattr(v, '_fun') else v.fun
+            x = np.array([np.concatenate([np.atleast_1d(get(v)[n]) for n in self.input_vars]) for v in vds])
+            logp = np.array([np.atleast_1d(get(v)[self.density_name])[0] for v in vds])
         x = np.ascontiguousarray(x, dtype=np.float64)
         logp = np.asarray(logp, dtype=np.float64).reshape(-1)
         if x.ndim != 2 or x.shape != (logp.size, self._d):

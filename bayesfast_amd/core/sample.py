@@ -29,7 +29,12 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     import torch
     from ..chains import DeviceChains
     if not isinstance(density, SurrogateDensity):
-        raise ValueError('density should be a SurrogateDensity.')
+        if hasattr(density, '_surrogate_list') and hasattr(density, 'input_size'):
+            # a (fitted) reference-style Density: read its state by duck typing (bayesfast_amd/adapters.py)
+            from ..adapters import surrogate_density_from_reference
+            density = surrogate_density_from_reference(density)
+        else:
+            raise ValueError('density should be a SurrogateDensity (or a Density with one PolyModel surrogate).')
     prev = None
     if isinstance(sample_trace, TraceTuple):
         prev = sample_trace
@@ -72,7 +77,7 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
         lp0, g0 = dd.logp_and_grad(x0[b:e])
         if not (bool(torch.isfinite(lp0).all()) and bool(torch.isfinite(g0).all())):  # base_hmc.py:42-46
             raise ValueError('failed to get finite logp and/or grad at x_0.')
-        chains = DeviceChains(dd, x0[b:e], seed=trace.seed(), first_stream=b, step_size=trace._step_size,
+        chains = DeviceChains(dd, x0[b:e], seed=trace.seed(), first_stream=b, step_size=1. if trace._step_size is None else trace._step_size,
                               metric=trace._metric, initial_mean=trace._initial_mean,
                               initial_weight=trace._initial_weight, adapt_window=trace._adapt_window)
         done = 0

@@ -37,19 +37,18 @@ class _HTrace:
         self.x_0 = None if x_0 is None else np.atleast_1d(x_0).copy()
         self._x_0_transformed = False
         self.random_generator = random_generator
-        if step_size is None:
-            step_size = 1.
-        try:
-            step_size = float(step_size)
-            assert step_size > 0
-        except Exception:
-            raise ValueError('invalid value for step_size.')
+        if step_size is not None:  # None: 1 at use (_set_step_size_2, samplers/sample_trace.py:365-373); Recipe fills it in
+            try:                   # from the previous round when it is None (core/recipe.py:1033-1038)
+                step_size = float(step_size)
+                assert step_size > 0
+            except Exception:
+                raise ValueError('invalid value for step_size.')
         self._step_size = step_size
         self._adapt_step_size = bool(adapt_step_size)
         if isinstance(metric, str):
             if metric not in ('diag', 'full'):
                 raise ValueError('invalid value for metric.')
-            self._metric = None if metric == 'diag' else 'full'  # 'full': QuadMetricFullAdapt from the identity
+            self._metric = metric  # kept as given: Recipe tests `_metric == 'diag'` / `'full'` (core/recipe.py:971-974,1040-1045)
         else:
             metric = np.asarray(metric, dtype=np.float64)
             n = metric.shape[0] if metric.ndim else 0

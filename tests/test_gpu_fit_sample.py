@@ -501,3 +501,34 @@ def test_surrogate_plus_chi2_pipeline_matches_reference_density():
     lp2, g2 = Chi2PipelineDensity(su, z['ydat'], prec=z['prec']).logp_and_grad(z['xt'])
     np.testing.assert_allclose(lp2, z['logp'], rtol=1e-6, atol=1e-6 * np.abs(z['logp']).max())
     np.testing.assert_allclose(g2, z['grad'], rtol=1e-5, atol=1e-6 * np.abs(z['grad']).max())
+
+
+def test_sample_accepts_a_reference_style_density_and_fit_takes_var_dicts():
+    """The Python seam as Recipe uses it: Density.fit(var_dicts) (core/density.py:813-838), and sample() on
+    a density object that only exposes the reference's attribute names (read through bayesfast_amd/adapters.py)."""
+    from types import SimpleNamespace
+    from bayesfast_amd import PolyModel, SurrogateDensity, sample
+    from test_host_api import _RefDensity
+    d = 5
+    rng = np.random.default_rng(12)
+    Pm = np.eye(d) + 0.2 * rng.normal(size=(d, d)) / np.sqrt(d)
+    Pm = Pm @ Pm.T
+    xf = rng.normal(size=(90, d)) * 1.5
+    lp = -0.5 * np.einsum('ij,jk,ik->i', xf, Pm, xf)
+    den = SurrogateDensity(PolyModel('quadratic', input_size=d, output_size=1), input_scales=np.stack([-9. * np.ones(d), 9. * np.ones(d)], 1),
+                           hard_bounds=True, decay_options=dict(use_decay=True))
+    den.fit(xf, lp)
+    den2 = SurrogateDensity(PolyModel('quadratic', input_size=d, output_size=1), input_scales=np.stack([-9. * np.ones(d), 9. * np.ones(d)], 1),
+                            hard_bounds=True, decay_options=dict(use_decay=True))
+    # var_dicts: x under the input variable's name, the true log-density under density_name
+    den2.input_vars, den2.density_name = ('x',), 'logp'
+    den2.fit([SimpleNamespace(_fun={'x': x, 'logp': np.array([l])}) for x, l in zip(xf, lp)])
+    a, b = den.spec(), den2.spec()
+    for c0, c1 in zip(a['poly']['configs'], b['poly']['configs']):
+        assert np.array_equal(c0['coef'], c1['coef'])
+    assert np.array_equal(a['decay_hess'], b['decay_hess']) and a['decay_alpha2'] == b['decay_alpha2']
+    opts = {'n_chain': 12, 'n_iter': 40, 'n_warmup': 25, 'random_generator': 3}
+    t0 = sample(den, dict(opts), verbose=False)
+    t1 = sample(_RefDensity(den), dict(opts), verbose=False)
+    assert np.array_equal(t0.samples, t1.samples) and np.array_equal(t0.samples_original, t1.samples_original)
+    assert np.array_equal(t0.get(return_type='logp'), t1.get(return_type='logp'))

@@ -213,3 +213,83 @@ def test_select_fit_points_logp_cutoff_and_importance_weights():
     w, wt = importance_weights(logq + np.log(ratio), logq, k_trunc=0.25)
     assert np.allclose(w, ratio) and wt.max() == pytest.approx(np.mean(w) * logq.size**0.25) and wt[0] == pytest.approx(1.)
     assert np.array_equal(*importance_weights(logq, logq - 1., k_trunc=-1))
+
+
+def test_trace_fields_recipe_pokes_keep_the_reference_meaning():
+    """core/recipe.py:967-975,1028-1045 reads and writes sample_trace.x_0, ._x_0_transformed, ._metric ('diag' / 'full' /
+    array) and ._step_size (None until filled from the previous round) directly."""
+    from bayesfast_amd import NTrace
+    t = NTrace(n_chain=4, n_iter=20, n_warmup=5, step_size=None)
+    assert t.x_0 is None and t._x_0_transformed is False
+    assert t._metric == 'diag' and t._step_size is None
+    t._step_size = 0.3
+    t._metric = np.array([1., 2., 3.])
+    t.x_0 = np.zeros((4, 3))
+    t._x_0_transformed = True
+    assert NTrace(metric='full')._metric == 'full'
+    with pytest.raises(ValueError):
+        NTrace(step_size=-1.)
+
+
+class _RefConfig:
+    def __init__(self, c):
+        self.order, self.input_mask, self.output_mask, self._coef = c.order, c._input_mask, c._output_mask, c._coef
+
+
+class _RefPoly:
+    """The attributes adapters.py reads from a reference PolyModel, taken from this package's own object."""
+
+    def __init__(self, pm):
+        self.configs = [_RefConfig(c) for c in pm.configs]
+        for k in ('_input_size', '_output_size', '_use_bound', '_all_linear', '_mu', '_hess', '_alpha', '_f_mu', '_input_scales',
+                  '_input_scales_diff'):
+            setattr(self, k, getattr(pm, k, None))
+
+
+class _RefDensity:
+    def __init__(self, den):
+        self._surrogate_list = [_RefPoly(den.surrogate)]
+        self.input_size = den._d
+        for k in ('_input_scales', '_hard_bounds', '_use_decay', '_mu', '_hess', '_alpha_2', '_gamma'):
+            setattr(self, k, getattr(den, k, None))
+
+
+def _fitted_density_on_host():
+    """A SurrogateDensity with hand-set (not fitted: no GPU here) coefficients, bound, scales and decay."""
+    from bayesfast_amd import PolyModel, SurrogateDensity
+    rng = np.random.default_rng(4)
+    d = 4
+    su = PolyModel('quadratic', input_size=d, output_size=1)
+    for c in su.configs:  # PolyConfig._set: the packed coefficients of output 0 (modules/poly.py:131-158)
+        a = rng.normal(size=c._a_shape) * 0.1
+        c._set(a, 0)
+    su._mu, su._hess, su._alpha, su._f_mu = np.zeros(d), np.eye(d), 5., np.array([-1.])
+    den = SurrogateDensity(su, input_scales=np.stack([-8. * np.ones(d), 9. * np.ones(d)], 1), hard_bounds=np.array([[1, 1], [0, 1], [1, 0], [0, 0]]),
+                           decay_options=dict(use_decay=True))
+    den._mu, den._hess, den._alpha_2, den._alpha = np.zeros(d), np.eye(d), 30., 30.**0.5
+    return den
+
+
+def test_adapters_read_a_reference_density_by_duck_typing():
+    """adapters.density_spec_from_reference / surrogate_density_from_reference on an object that exposes the reference's
+    attribute names give the same device description as the package's own density."""
+    from bayesfast_amd import adapters
+    den = _fitted_density_on_host()
+    ref = _RefDensity(den)
+    a, b = adapters.density_spec_from_reference(ref), den.spec()
+    c = adapters.surrogate_density_from_reference(ref).spec()
+
+    def same(u, v):
+        if isinstance(u, dict):
+            assert set(u) == set(v)
+            [same(u[k], v[k]) for k in u]
+        elif isinstance(u, (list, tuple)):
+            assert len(u) == len(v)
+            [same(x, y) for x, y in zip(u, v)]
+        elif u is None or isinstance(u, str):
+            assert u == v
+        else:
+            assert np.array_equal(np.asarray(u, dtype=np.float64), np.asarray(v, dtype=np.float64))
+
+    same(a, b)
+    same(c, b)
