@@ -32,7 +32,25 @@ __device__ inline bool bf_chol_rows(const double *aT, double *lT, int d, int lan
             const int i = lane * E + e;
             acc[e] = (i < d) ? aT[(size_t)j * d + i] : 0.;  // a[i][j]
         }
-        for (int k = 0; k < j; ++k) {
+        constexpr int B = 16;  // (loads of a block of columns in flight together, as in bf_velocity_full; same order of sums)
+        int k = 0;
+        for (; k + B <= j; k += B) {
+            double lb[B][E];
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = lane * E + e;
+                    lb[u][e] = (i < d) ? lT[(size_t)(k + u) * d + i] : 0.;  // L[i][k + u], written by this lane earlier
+                }
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const double ljk = bf_pick<E>(lb[u], j);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = __dsub_rn(acc[e], __dmul_rn(lb[u][e], ljk));
+            }
+        }
+        for (; k < j; ++k) {
             double lik[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -76,7 +94,30 @@ template <int E>
 __device__ inline void bf_velocity_full(const double *covT, const double (&pv)[E], double (&out)[E], int d, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) out[e] = 0.;
-    for (int k = 0; k < d; ++k) {
+    // columns in blocks of BF_MV_BLOCK: all loads of a block are in flight before the first multiply-add (a dependent
+    // load -> add chain per column leaves the wave waiting a full memory latency 64 times); the sum stays k-ascending
+    constexpr int B = 16;
+    int k = 0;
+    for (; k + B <= d; k += B) {
+        double c[B][E];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                c[u][e] = (i < d) ? covT[(size_t)(k + u) * d + i] : 0.;
+            }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const double pk = bf_pick<E>(pv, k + u);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < d) out[e] = __dadd_rn(out[e], __dmul_rn(c[u][e], pk));
+            }
+        }
+    }
+    for (; k < d; ++k) {
         const double pk = bf_pick<E>(pv, k);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -90,7 +131,30 @@ __device__ inline void bf_velocity_full(const double *covT, const double (&pv)[E
 // by the column sweep of BLAS dtrsv: j = d-1 .. 0: p_j = z_j / L[j][j]; z_i -= L[j][i] p_j for i < j.
 template <int E>
 __device__ inline void bf_solve_lt(const double *cholR, double (&z)[E], int d, int lane) {
-    for (int j = d - 1; j >= 0; --j) {
+    constexpr int B = 8;
+    int j = d - 1;
+    for (; j - B + 1 >= 0; j -= B) {
+        double rb[B][E];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                rb[u][e] = (i <= j - u) ? cholR[(size_t)(j - u) * d + i] : 0.;  // L[j - u][i]
+            }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int jj = j - u;
+            const double pj = __ddiv_rn(bf_pick<E>(z, jj), bf_pick<E>(rb[u], jj));
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < jj) z[e] = __dsub_rn(z[e], __dmul_rn(rb[u][e], pj));
+                else if (i == jj) z[e] = pj;
+            }
+        }
+    }
+    for (; j >= 0; --j) {
         double row[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -110,7 +174,28 @@ __device__ inline void bf_solve_lt(const double *cholR, double (&z)[E], int d, i
 // _WeightedCovariance.add_sample (metrics.py:401-407) on the transposed accumulator: raw[i][j] += new_i * old_j
 template <int E>
 __device__ inline void bf_welford_cov(double *rawT, const double (&new_diff)[E], const double (&old_diff)[E], int d, int lane) {
-    for (int j = 0; j < d; ++j) {
+    constexpr int B = 8;
+    int j = 0;
+    for (; j + B <= d; j += B) {
+        double rb[B][E];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                rb[u][e] = (i < d) ? rawT[(size_t)(j + u) * d + i] : 0.;
+            }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const double oj = bf_pick<E>(old_diff, j + u);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < d) rawT[(size_t)(j + u) * d + i] = __dadd_rn(rb[u][e], __dmul_rn(__dmul_rn(1., new_diff[e]), oj));
+            }
+        }
+    }
+    for (; j < d; ++j) {
         const double oj = bf_pick<E>(old_diff, j);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
