@@ -60,6 +60,7 @@ extern "C" void bfhip_debug_gstamps(unsigned long long *buf) { g_gstamps = buf; 
 // test hook (not part of include/bfhip.h): 1 = never skip the bound's tiles (the results must not change)
 static int g_no_bound_proof = 0;
 extern "C" void bfhip_debug_no_bound_proof(int on) { g_no_bound_proof = on; }
+int bf_no_bound_proof() { return g_no_bound_proof; }
 
 // measurement hook (not part of include/bfhip.h): device buffer of two counters, trips and trips with the bound's tiles
 static unsigned long long *g_gcount = NULL;

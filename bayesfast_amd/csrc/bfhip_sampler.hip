@@ -158,6 +158,8 @@ struct SamplerGeo {
 // FS (feature spec): 0 = everything decided at run time; otherwise linear + quadratic configs with the bound, no input
 // scaling, no cubic configs, and bit 1 (value 2) = decay penalty on, bit 2 (value 4) = constraint transform on.
 // FS == 1 is the PLAIN instantiation with its register-resident A operands and tail path.
+__device__ inline bool g_sliced_proof_on(const SamplerArgs &a) { return a.no_bound_proof == 0; }
+
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
 __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
     constexpr int NWV = BF_SAMPLER_WAVES(W), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XB = lds;                         // [3][NS][XS]   B operands
     double *LS = XB + 3 * NS * XS;            // [16][MAXL][LS_N] per-chain stack scalars
-    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity)
-    double *CS = LS + 16 * MAXL * LS_N + 2;   // [16][CS_N]    cold per-chain scalars (kept out of the VGPR budget)
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating | [2] some chain
+                                                  // is not proven inside the bound (all by trip parity)
+    double *CS = LS + 16 * MAXL * LS_N + 4;   // (an even offset: the regions behind keep their 16-byte alignment)   // [16][CS_N]    cold per-chain scalars (kept out of the VGPR budget)
     double *PDL = CS + 16 * CS_N;             // [PD_N][DP]    per-dimension table (rarely used rows are read from here)
     double *FR = PDL + PD_N * DP;             // staged A fragments: S | H | H_decay
     // the matvec results [gbn][16][GS] (slot = enabled matrix x K part) come last: every region above keeps a
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
             RM[(1 * DP + row) * RS + col] = m.Hf[i];
         }
     }
-    if (tid < 4) alive[tid] = 0;
+    if (tid < 6) alive[tid] = 0;
     for (int i = tid; i < PD_N * DP; i += NTH) PDL[i] = m.pd[i];
 
     // ---- per-lane constants: the per-dimension table rows of this lane's dimensions ----
@@ -909,6 +912,23 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                 }
             }
         }
+        // Bound proof at d = 128 (two jobs per wave: the H (x - mu) job is half of the tile phase): as in bfhip_group.h, the
+        // test of modules/poly.py:467-469 is decided without those tiles while lam_max(H) |x - mu|^2 < alpha^2 holds for
+        // every evaluating chain of the group; the outcome is the one the full computation has.
+        constexpr bool PROOF = W == 8 && !FULLM;
+        if constexpr (PROOF) {
+            if (evaluating && f_bound) {
+                double r2 = 0.;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double xm = xs[e] - c_mu[e];
+                    r2 += (lane * E + e < d) ? xm * xm : 0.;
+                }
+                r2 = wave_sum(r2);
+                const bool inside = mode != M_OOB && g_sliced_proof_on(a) && m.lam_max * r2 < m.alpha * m.alpha * (1. - 1e-9);
+                if (lane == 0 && !inside) alive[4 + (trip & 1)] = 1;
+            }
+        }
         TRACE(1);
         if (lane == 0) {
             if (unit != U_DONE) alive[trip & 1] = 1;
@@ -920,7 +940,8 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
         stamp(1);
         if (rfl(alive[trip & 1]) == 0) break;  // every chain of the group is done (uniform)
         const unsigned ev_mask = TAIL ? (unsigned)rfl(alive[2 + (trip & 1)]) : 0u;
-        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; }
+        const bool skip_h = PROOF && f_bound && f_quad && !f_decay && rfl(alive[4 + (trip & 1)]) == 0;  // (uniform over the workgroup)
+        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; }
         TRACE(3);
 
         // ================= phase B: gradient tiles on MFMA =================
@@ -934,7 +955,8 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
             constexpr int KPJ = NS / KS;                        // k-steps per job
             constexpr int CH = KPJ < 8 ? KPJ : 8;               // k-steps fetched together
             const int mc = lane & 15, mg = lane >> 4;
-            const int n_job = n_mat * (W * KS);
+            // (skip_h: S and H are the only matrices and the H jobs, the second half of the list, are left out)
+            const int n_job = (skip_h && n_mat == 2 && mat0 == 0 && mat1 == 1) ? W * KS : n_mat * (W * KS);
             for (int job = w; job < n_job; job += NWV) {
                 const int slot_m = job / (W * KS), rem = job % (W * KS);
                 const int t = rem / KS, kp = rem % KS;
@@ -1018,7 +1040,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
             for (int e = 0; e < E; ++e) {
                 const int dim = lane * E + e;
                 const double sx = (f_quad && lane_ok) ? gb_read(slot_S, dim) : 0.;
-                hv[e] = (f_bound && lane_ok) ? gb_read(slot_H, dim) : 0.;
+                hv[e] = (f_bound && lane_ok && !skip_h) ? gb_read(slot_H, dim) : 0.;
                 dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
                 xev[e] = xs[e];
                 if (mode == M_OOB) xev[e] = (m.alpha * xs[e] + (cs_get(CS_BETA) - m.alpha) * c_mu[e]) / cs_get(CS_BETA);
@@ -1208,7 +1230,7 @@ static int sampler_gb_slots(const DevModel &m) {
 
 static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
     const int W = m.DP / 16, DP = m.DP, NS = 4 * W;
-    size_t dbl = (size_t)3 * NS * 65 + (size_t)sampler_gb_slots(m) * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 +
+    size_t dbl = (size_t)3 * NS * 65 + (size_t)sampler_gb_slots(m) * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 4 +
                  (size_t)16 * CS_N + (size_t)PD_N * DP;
     if (DP <= 64 && plain)  // A operands in registers; row-major S, H and plain x for the VALU matvec
         dbl += (size_t)2 * DP * (DP + 2) + (size_t)2 * 16 * DP;
@@ -1328,7 +1350,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.stats = stats;
     args.n_leapfrog = n_leapfrog;
     args.stamps = g_stamps;
-    args.no_bound_proof = 0;
+    args.no_bound_proof = bf_no_bound_proof();
     args.gcount = NULL;
     args.mat = (cfg->full_metric && cfg->metric_mat) ? cfg->metric_mat : NULL;
     if (cfg->full_metric && !cfg->metric_mat) return bf_set_error(BFHIP_ERR_ARG, "bfhip_sampler_run: full_metric without metric_mat");

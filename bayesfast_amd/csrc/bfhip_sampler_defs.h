@@ -31,3 +31,4 @@ enum { CS_LOG_STEP = 0, CS_LOG_BAR, CS_HBAR, CS_SMU, CS_COUNT, CS_PROP_E, CS_PRO
 struct bfhip_ctx;
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args);
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args);
+int bf_no_bound_proof();  // test hook state (bfhip_debug_no_bound_proof, bfhip_group.hip)

@@ -600,3 +600,31 @@ def test_tree_size_mode_share_flag_matches_numpy(ctx):
         w = work.cpu().numpy()
         assert int(w[0]) == want, (p_mode, row0, n_rows)
         assert not w[1:].any()  # histogram and arrival counter cleared for the next call
+
+
+@pytest.mark.parametrize('case', ['inside', 'leaky'])
+def test_sliced_kernel_bound_proof_at_d128_never_changes_results(ctx, case):
+    """The same proof in bf_sampler_kernel at d = 128 (two tile jobs per wave: the H (x - mu) job is skipped while every
+    evaluating chain of the 8-chain group is provably inside the bound): bit-identical with the proof switched off."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = 128
+    spec, _ = correlated_gaussian_spec(d, fit_scale=1.0 if case == 'leaky' else 1.5)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(2).normal(size=(44, d))
+    hook = _lib.lib().bfhip_debug_no_bound_proof
+    out = {}
+    try:
+        for off in (0, 1):
+            hook(off)
+            dc = DeviceChains(dens, x0, seed=11)
+            s1, st1 = dc.run(30, 'NUTS', n_warmup=20)
+            s2, st2 = dc.run(10, 'NUTS', n_warmup=20)
+            out[off] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
+    finally:
+        hook(0)
+    for a, b in zip(out[0][:-1], out[1][:-1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert out[0][-1] == out[1][-1]
