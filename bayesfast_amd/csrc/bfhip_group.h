@@ -386,7 +386,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 if (ev) {
                     double J, g2;
                     bf_to_original_g(q[r], c_kind[r], c_lo[r], c_rg[r], xs[r], J, g2);
-                    ldet[r] = 0. + bf_log(bf_fabs(J));
+                    ldet[r] = bf_fabs(J);  // (|dx/dx_t| of this coordinate; its logarithm is taken below, once per lane)
                     jac[r] = J;
                     gj[r] = g2;
                 }
@@ -517,7 +517,22 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 post(G::V_DOTJ, sum4(t_dotj));
             }
             if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
-            if constexpr (TR) post(G::V_LOGDET, sum4(ldet));
+            if constexpr (TR) {
+                // sum_r log|J_r| (density.py:748) as the logarithm of the lane's product: one log instead of four.  The
+                // product of four Jacobians stays far from underflow unless a coordinate sits ~700 logistic units deep
+                // in a bound's tail; then (any lane of the wave) the four logarithms are taken one by one.
+                double pj = (ldet[0] * ldet[1]) * (ldet[2] * ldet[3]);
+                double lsum;
+                if (bf_any(ev && !(pj > 1e-280 && pj < 1e280))) {
+                    double l4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) l4[r] = ev ? bf_log(ldet[r]) : 0.;
+                    lsum = sum4(l4);
+                } else {
+                    lsum = ev ? bf_log(pj) : 0.;
+                }
+                post(G::V_LOGDET, lsum);
+            }
             if (bf_any(need_E0)) post(G::V_KIN0, kin0_part);
         }
         // U-turn sums for the subtrees that the leaf in flight completes (nuts.py:146-161 per merge, :88-101 per doubling).
