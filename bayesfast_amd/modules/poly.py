@@ -3,9 +3,11 @@
 State is host NumPy (so ``copy.deepcopy`` and pickling keep working, core/recipe.py:822,1163); evaluation
 and the least-squares fit run in libbfhip.so.  What differs from the reference, on purpose:
 
-* ``fit`` solves the normal equations (FP64-MFMA Gram + equilibrated Cholesky) instead of LAPACK gelsd,
-  and factorises once for all outputs that share a set of configs (the reference rebuilds and
-  re-factorises A for every output, modules/poly.py:529).
+* ``fit`` solves the normal equations (FP64-MFMA Gram + equilibrated Cholesky) and refines the solution twice on the
+  true residual (``bfhip_lstsq``: the accuracy of LAPACK gelsd up to a condition number of 1e7, tested against
+  fixtures of the reference), and factorises once for all outputs that share a set of configs (the reference
+  rebuilds and re-factorises A for every output, modules/poly.py:529).  A numerically rank-deficient design is
+  reported (RuntimeWarning) and ridge-regularised; gelsd would return the minimum-norm solution.
 * ``fun``/``jac``/``fun_and_jac`` run on the device: single-output surrogates (the log-density surrogate of the sampler
   path) through ``bfhip_logp_grad``, multi-output modules through one ``bfhip_polymodel_eval`` launch.
 """
