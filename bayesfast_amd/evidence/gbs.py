@@ -1,5 +1,6 @@
-"""Gaussianized bridge sampling (bayesfast/evidence/gaussianized.py:179-216): fit a SIT to the first half of the
-posterior samples, draw from it, and bridge between the two sample sets."""
+"""Gaussianized bridge sampling (reference: bayesfast/evidence/gaussianized.py:179-216): the evidence of a posterior from
+its samples.  The first half of the samples trains a ``SIT`` density q, the second half and fresh draws from q feed the
+bridge estimator, and since q is normalised the bridge's log r is the log-evidence."""
 import warnings
 
 import numpy as np
@@ -10,90 +11,95 @@ from .bridge import bridge
 __all__ = ['GBS']
 
 
+def _optional_positive(value, kind, name):
+    if value is None:
+        return None
+    try:
+        value = kind(value)
+    except Exception:
+        value = None
+    if value is None or not value > 0:
+        raise ValueError('invalid value for {}.'.format(name))
+    return value
+
+
+def _evaluate(logp, points):
+    """logp on an array of points (..., d): in one call when the callable takes a batch, point by point otherwise."""
+    lead, d = points.shape[:-1], points.shape[-1]
+    rows = points.reshape(-1, d)
+    values = None
+    try:
+        values = np.asarray(logp(rows), dtype=np.float64)
+        if values.shape != (rows.shape[0],):
+            values = None
+    except Exception:
+        values = None
+    if values is None:
+        values = np.array([logp(row) for row in rows], dtype=np.float64)
+    return values.reshape(lead)
+
+
 class GBS:
-    """``GBS(sit=None, parallel_backend=None, n_q=None, f_call=0.05)`` with the reference's meaning; ``parallel_backend``
-    is accepted and ignored (``logp`` is called on whole arrays when it accepts them, row by row otherwise)."""
+    """``GBS(sit=None, parallel_backend=None, n_q=None, f_call=0.05)`` with the reference's meaning: ``sit`` a ``SIT``, the
+    keyword arguments of one, or None; ``n_q`` draws from the fitted SIT, or ``f_call`` times the number of density calls
+    the sampler spent when the samples come as a ``TraceTuple``.  ``parallel_backend`` is accepted and ignored."""
 
     def __init__(self, sit=None, parallel_backend=None, n_q=None, f_call=0.05):
-        if sit is None:
-            sit = {}
-        if isinstance(sit, dict):
-            sit = SIT(**sit)
-        elif not isinstance(sit, SIT):
+        if isinstance(sit, SIT):
+            self.sit = sit
+        elif sit is None or isinstance(sit, dict):
+            self.sit = SIT(**(sit or {}))
+        else:
             raise ValueError('invalid value for sit.')
-        self.sit = sit
-        if n_q is not None:
-            try:
-                n_q = int(n_q)
-                assert n_q > 0
-            except Exception:
-                raise ValueError('invalid value for n_q.')
-        self.n_q = n_q
-        if f_call is not None:
-            try:
-                f_call = float(f_call)
-                assert f_call > 0
-            except Exception:
-                raise ValueError('invalid value for f_call.')
-        self.f_call = f_call
+        self.n_q = _optional_positive(n_q, int, 'n_q')
+        self.f_call = _optional_positive(f_call, float, 'f_call')
 
-    @staticmethod
-    def _map(logp, x):
-        shape = x.shape
-        flat = x.reshape((-1, shape[-1]))
-        try:
-            out = np.asarray(logp(flat), dtype=np.float64)
-            assert out.shape == (flat.shape[0],)
-        except Exception:
-            out = np.asarray([logp(r) for r in flat], dtype=np.float64)
-        return out.reshape(shape[:-1])
+    def _draws_from_q(self, n_samples, n_call):
+        if self.n_q is not None:
+            return self.n_q
+        if self.f_call is not None:
+            if n_call is not None:
+                return int(n_call * self.f_call)
+            warnings.warn('f_call should be used only when x_p is a TraceTuple. Using equal-sample allocation for now.',
+                          RuntimeWarning)
+        return n_samples
 
     def run(self, x_p, logp, logp_p=None):
+        """x_p: posterior samples (n, d), (chain, iteration, d) or a ``TraceTuple``; logp: the unnormalised log-posterior;
+        logp_p: its values on x_p if already known.  Returns ``(logz, logz_err)``."""
         from ..samplers.sample_trace import TraceTuple
         if not callable(logp):
             raise ValueError('logp should be callable.')
         n_call = None
         if isinstance(x_p, TraceTuple):
-            n_call = x_p.n_call
-            x_p = x_p.get(flatten=False)
+            n_call, x_p = x_p.n_call, x_p.get(flatten=False)
         else:
             try:
-                x_p = np.asarray(x_p)
-                assert 2 <= x_p.ndim <= 3
+                x_p = np.asarray(x_p, dtype=np.float64)
             except Exception:
+                x_p = None
+            if x_p is None or x_p.ndim not in (2, 3):
                 raise ValueError('invalid value for x_p.')
-        if self.n_q is not None:
-            n_q = self.n_q
-        elif self.f_call is not None and n_call is not None:
-            n_q = int(n_call * self.f_call)
-        else:
-            if self.f_call is not None:
-                warnings.warn('f_call should be used only when x_p is a TraceTuple. Using equal-sample allocation for now.',
-                              RuntimeWarning)
-            n_q = int(np.prod(x_p.shape[:-1]))
-        if not (x_p.shape[-1] > 1 and np.prod(x_p.shape[:-1]) > 1):
+        n_samples = int(np.prod(x_p.shape[:-1]))
+        if x_p.shape[-1] < 2 or n_samples < 2:
             raise ValueError('invalid shape for x_p.')
-        if x_p.shape[0] == 1:
+        n_q = self._draws_from_q(n_samples, n_call)
+        if x_p.shape[0] == 1:   # a single chain: drop the chain axis, the halves are then halves of the iterations
             x_p = x_p[0]
-        return self._compute_evidence(logp, x_p, logp_p, n_q)
+        cut = x_p.shape[0] // 2
+        train, test = x_p[:cut], x_p[cut:]
+        self.sit.fit(data=train)
+        x_q = self.sit.sample(n_q)[0]
+        known = None
+        if logp_p is not None:
+            known = np.asarray(logp_p)
+            if known.shape == x_p.shape[:-1]:
+                known = known[cut:]
+            else:
+                warnings.warn('the logp_p you gave me seems not correct. Will recompute it from logp and x_p.', RuntimeWarning)
+                known = None
+        if known is None:
+            known = _evaluate(logp, test)
+        return bridge(known, _evaluate(logp, x_q), self.sit.logq(test), self.sit.logq(x_q))
 
     __call__ = run
-
-    def _compute_evidence(self, logp, x_p, logp_p, n_q):
-        n_half = x_p.shape[0] // 2
-        self.sit.fit(data=x_p[:n_half])
-        x_q = self.sit.sample(n_q)[0]
-        if logp_p is not None:
-            try:
-                logp_p = np.asarray(logp_p)
-                assert logp_p.shape == x_p.shape[:-1]
-                logp_p = logp_p[n_half:]
-            except Exception:
-                warnings.warn('the logp_p you gave me seems not correct. Will recompute it from logp and x_p.', RuntimeWarning)
-                logp_p = None
-        if logp_p is None:
-            logp_p = self._map(logp, x_p[n_half:])
-        logp_q = self._map(logp, x_q)
-        logq_p = self.sit.logq(x_p[n_half:])
-        logq_q = self.sit.logq(x_q)
-        return bridge(logp_p, logp_q, logq_p, logq_q)
