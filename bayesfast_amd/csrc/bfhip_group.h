@@ -18,12 +18,19 @@
 //     summed per lane over r, over g by two row swaps, and over the waves through LDS (RB): ONE exchange per trip carries
 //     the evaluation's sums AND every U-turn check the finished leaf can trigger -- which subtrees merge after leaf i of
 //     a doubling is known beforehand (the trailing one bits of i), and the vectors involved do not depend on the
-//     multinomial draws -- so a trip is: first half step + operands | barrier | 8 W MFMAs + partial sums | barrier |
-//     scalar logic + vector bookkeeping.  Two workgroup barriers per leapfrog step, no speculation, no wasted evaluation;
+//     multinomial draws -- so a trip is: first half step + operands | barrier | 4 W .. 8 W MFMAs + partial sums |
+//     barrier | scalar logic + vector bookkeeping.  Two workgroup barriers per leapfrog step, no speculation, no wasted
+//     evaluation;
 //     an iteration starts from its predecessor's proposal, whose value and gradient travel with it through the merges
 //     (base_hmc.py:70 evaluates it again; the numbers are the same).
 //   * Summation order is fixed and the same as the sliced kernel's butterfly: r (dims 4 apart), then g, then waves; the
-//     K halves of a matvec are added as part0 + part1.  A chain's results do not depend on its group or lane.
+//     K halves of a matvec are added as part0 + part1.  A chain's results do not depend on its group or lane.  Two
+//     (four) sums are reduced over g by one row swap per step (bf_pair16_add / bf_pair32_add: the swap of two different
+//     registers is a transposed reduction) -- the same additions, value k ending up in row k.
+//   * The extrapolation bound's test is decided without its H (x - mu) tiles whenever lam_max(H) |x - mu|^2 < alpha^2
+//     proves every chain of the group inside (the outcome of the full test, so results do not depend on it); likewise
+//     the decay term.  The common trip then skips its rare branches as one (wave-uniform guards): per-lane branches
+//     cost a round trip through the scalar unit each, and with one wave per SIMD nothing hides it.
 //
 // The subtree stack (left p, right p, p_sum, proposal q, proposal gradient per level) keeps level 0 in registers, level 1
 // in LDS next to the tree's ends, proposal and p_sum, and deeper levels in the context's global scratch.
