@@ -39,18 +39,46 @@ def _monotone_flags(coef, knots):
     return ok
 
 
+def percentile_sorted(xs, q):
+    """``np.percentile(x, q)`` (the default linear method) from the SORTED copy xs of x: the same two order statistics and
+    the same interpolation arithmetic as numpy's (virtual index (n - 1) q, lerp a + (b - a) t, taken from the
+    other end for t >= 1/2), so the result is bit-identical -- without a selection pass over the data per call
+    (tests/test_evidence.py checks it against numpy)."""
+    xs = np.asarray(xs, dtype=np.float64)
+    n = xs.shape[0]
+    quant = np.true_divide(np.asarray(q, dtype=np.float64), np.float64(100))
+    virt = (n - 1) * quant
+    lo = np.floor(virt).astype(np.intp)
+    hi = lo + 1
+    over = virt >= n - 1
+    lo[over] = -1
+    hi[over] = -1
+    under = virt < 0
+    lo[under] = 0
+    hi[under] = 0
+    t = virt - lo
+    a, b = xs[lo], xs[hi]
+    step = b - a
+    out = a + step * t
+    far = t >= 0.5
+    out[far] = (b - step * (1 - t))[far]
+    return out
+
+
 class GaussianizingSpline:
     """``cubic_spline(x_all, fun, **options)``: knots ``x``, values ``y`` and coefficient rows ``c`` (n + 1, 4)."""
 
     def __init__(self, x_all, fun, bins=100, edge_bins=1, edge_points=10, max_width=5, split=4, max_add=5):
-        x_all = np.ascontiguousarray(x_all, dtype=np.float64)
+        xs = np.sort(np.asarray(x_all, dtype=np.float64).reshape(-1))  # one sort serves the three percentile sets below
         edge_bins = int(min(edge_bins, bins // 4))
         grid = np.linspace(0, 100, bins + 1)[edge_bins:-edge_bins]
-        self.x = np.unique(np.percentile(x_all, grid))
+        self.x = np.unique(percentile_sorted(xs, grid))
         self.y = np.asarray(fun(self.x), dtype=np.float64)
         inner = np.linspace(0, 100, edge_points + 2)[1:-1]
-        self._k_left = self._edge_slope(x_all[x_all < self.x[edge_bins]], self.x[0], self.y[0], fun, inner)
-        self._k_right = self._edge_slope(x_all[x_all > self.x[-edge_bins - 1]], self.x[-1], self.y[-1], fun, inner)
+        below = xs[:np.searchsorted(xs, self.x[edge_bins], 'left')]            # x_all[x_all < knot], sorted
+        above = xs[np.searchsorted(xs, self.x[-edge_bins - 1], 'right'):]      # x_all[x_all > knot], sorted
+        self._k_left = self._edge_slope(below, self.x[0], self.y[0], fun, inner)
+        self._k_right = self._edge_slope(above, self.x[-1], self.y[-1], fun, inner)
         self._fill_wide_gaps(fun, max_width, split)
         self._fit()
         good = _monotone_flags(self.c, self.x)
@@ -71,7 +99,7 @@ class GaussianizingSpline:
 
     @staticmethod
     def _edge_slope(outside, knot, value, fun, inner):
-        t = np.percentile(outside - knot, inner)
+        t = percentile_sorted(outside - knot, inner)  # (outside is sorted, and stays so under the shift)
         f = np.asarray(fun(t + knot)) - value
         return np.sum(t * f) / np.sum(t * t)
 

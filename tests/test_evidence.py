@@ -45,6 +45,17 @@ def test_spline_construction_matches_reference(fx):
         np.testing.assert_allclose(orc.spline_apply(mode, sp.c, sp.x, sp.y, pts), fx['spl.' + mode], rtol=1e-9, atol=1e-10, equal_nan=True)
 
 
+def test_percentile_sorted_is_bitwise_numpys_percentile():
+    """utils/spline.py computes its three percentile sets from one sorted copy of the data; the values must be numpy's."""
+    from bayesfast_amd.utils.spline import percentile_sorted
+    rng = np.random.default_rng(5)
+    for n in (7, 100, 1001, 40000):
+        x = np.round(rng.normal(size=n) * 3., 2 if n < 1001 else 6)  # (rounded: ties)
+        xs = np.sort(x)
+        for q in (np.linspace(0, 100, 101), np.linspace(0, 100, 12)[1:-1], np.array([0., 100., 50., 33.3333]), rng.uniform(0, 100, 200)):
+            assert np.array_equal(percentile_sorted(xs, q), np.percentile(x, q))
+
+
 def test_integrated_time_matches_known_ar1():
     """AR(1) with coefficient 0.6: tau = (1 + rho) / (1 - rho) = 4."""
     from bayesfast_amd.utils.acor import integrated_time
