@@ -628,3 +628,31 @@ def test_sliced_kernel_bound_proof_at_d128_never_changes_results(ctx, case):
     for a, b in zip(out[0][:-1], out[1][:-1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert out[0][-1] == out[1][-1]
+
+
+def test_launches_may_alternate_between_the_layouts(ctx):
+    """chain_layout = auto switches layouts between launches: the chain state (positions, adaptation, streams) written by
+    one layout's kernel is what the other continues from.  Four launches group / wave / group / wave through the warm-up
+    and beyond follow the oracle like a single-layout run: tree sizes and divergences exactly, positions to rounding."""
+    from oracle import oracle as orc
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    import torch
+    d = 24
+    spec, _ = correlated_gaussian_spec(d)
+    x0 = np.random.default_rng(9).normal(size=(37, d))
+    dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=21)
+    parts = []
+    for n, lay in ((9, 'group'), (8, 'wave'), (7, 'group'), (6, 'wave')):
+        parts.append(dc.run(n, 'NUTS', n_warmup=20, layout=lay))
+        assert dc.last_layout == lay
+    s = torch.cat([p[0] for p in parts], 1).cpu().numpy()
+    st = torch.cat([p[1] for p in parts], 1).cpu().numpy()
+    for i in (0, 15, 16, 36):
+        so, sto = orc.nuts_run(spec, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=21, stream=i), 30, 20)
+        assert np.array_equal(st[i, :, _lib.NSTATS.index('tree_size')], sto['tree_size']), i
+        assert np.array_equal(st[i, :, _lib.NSTATS.index('diverging')], sto['diverging']), i
+        np.testing.assert_allclose(s[i, :10], so[:10], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
