@@ -185,3 +185,29 @@ def test_gbs_recovers_the_32d_banana_evidence():
         logz, err = GBS(sit=dict(random_generator=5), n_q=12000)(z @ A, logp)
     assert 0. < err < 0.25
     assert abs(logz - (-127.364)) < 3. * err + 0.02
+
+
+@pytest.mark.gpu
+def test_gbs_recovers_the_48d_cauchy_mixture_evidence():
+    """examples/cauchy-gbs.ipynb: per dimension an equal mixture of two unit Cauchy densities at -5 and 5, under a flat prior
+    on [-100, 100]^48 -- heavy tails, two modes per dimension.  logZ = 48 log((atan 105 + atan 95) / pi) - 48 log 200 =
+    -254.627.  Exact (truncated) posterior draws stand in for the NUTS chains (8 x 1500)."""
+    from bayesfast_amd.evidence import GBS
+    D, a = 48, 5.
+    const = D * np.log(200.)
+
+    def logp(x):
+        return (np.sum(np.log(1 / ((x + a)**2 + 1) + 1 / ((x - a)**2 + 1)), axis=-1) + x.shape[-1] * np.log(0.5 / np.pi) - const)
+
+    rng = np.random.default_rng(1)
+    shape = (8, 1500, D)
+    cen = np.where(rng.uniform(size=shape) < 0.5, -a, a)
+    lo, hi = np.arctan(-100. - cen), np.arctan(100. - cen)  # the truncated Cauchy by its inverse cdf
+    x = cen + np.tan(lo + rng.uniform(size=shape) * (hi - lo))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        logz, err = GBS(sit=dict(random_generator=5), n_q=12000)(x, logp)
+    fiducial = D * np.log((np.arctan(105.) + np.arctan(95.)) / np.pi) - const
+    assert abs(fiducial - (-254.627)) < 1e-3
+    assert 0. < err < 0.2
+    assert abs(logz - fiducial) < 3. * err + 0.02
