@@ -211,3 +211,28 @@ def test_gbs_recovers_the_48d_cauchy_mixture_evidence():
     assert abs(fiducial - (-254.627)) < 1e-3
     assert 0. < err < 0.2
     assert abs(logz - fiducial) < 3. * err + 0.02
+
+
+@pytest.mark.gpu
+def test_sample_then_gbs_end_to_end_on_a_gaussian_surrogate():
+    """The whole device path in one line of a recipe: fit a quadratic surrogate, sample it with NUTS (bayesfast_amd.sample), hand
+    the TraceTuple to GBS with the surrogate's own logp.  The surrogate is an unnormalised Gaussian, so its evidence is
+    known: log Z = c0 + d/2 log(2 pi) + 1/2 log det Sigma."""
+    import bayesfast_amd as bfa
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    d = 12
+    _, cov = correlated_gaussian_spec(d)
+    prec = np.linalg.inv(cov)
+    c0 = -3.5
+    rng = np.random.default_rng(7)
+    su = bfa.PolyModel('quadratic', input_size=d, output_size=1, bound_options=dict(alpha_p=150.))
+    den = bfa.SurrogateDensity(su)
+    xf = rng.normal(size=(4 * su.n_param, d)) @ np.linalg.cholesky(cov).T * 1.6
+    den.fit(xf, c0 - 0.5 * np.einsum('ij,jk,ik->i', xf, prec, xf))
+    tt = bfa.sample(den, {'n_chain': 16, 'n_iter': 1500, 'n_warmup': 500, 'random_generator': 4}, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        logz, err = bfa.GBS(sit=dict(random_generator=5), n_q=12000)(tt, den.logp)
+    exact = c0 + 0.5 * d * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(cov)[1]
+    assert 0. < err < 0.1
+    assert abs(logz - exact) < 3. * err + 0.02, (logz, err, exact)
