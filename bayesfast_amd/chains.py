@@ -122,19 +122,23 @@ class DeviceChains:
                 raise ValueError('{} should be a contiguous float64 tensor of shape {} on {}.'.format(name, shape, self.ctx.device))
         step = max(1, int(launch_iters) if launch_iters else n_run)
         for i_launch, done in enumerate(range(step, n_run + step, step)):  # iter_end of each launch; output rows are relative to i_iter
-            # the layout is chosen per launch from the trees of the launch before: the first launch of a run takes the
-            # latest answer that has already arrived (never waits: back-to-back runs stay queued), the following ones
-            # wait for their predecessor's -- the host has nothing else to queue, and the gap is a launch latency
+            # the layout is chosen per launch from the trees of an earlier launch.  Inside a run: the launch just before
+            # (the host waits for its flag: it has nothing else to queue, and the gap is a launch latency).  The first
+            # launch of a run: the launch before the last one at the latest, so that runs issued back to back keep one
+            # launch queued behind the running one and still follow the chains' behaviour, one launch late.
             lay = layout
             if lay == 'auto':
-                lay = 'group' if (sampler == 'HMC' or self._trees_in_step(wait=i_launch > 0)) else 'wave'
+                lay = 'group' if (sampler == 'HMC' or self._trees_in_step(keep=0 if i_launch > 0 else 1)) else 'wave'
             cfg.chain_layout = {'group': 1, 'wave': 2}[lay]
             self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),
                 _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
             if layout == 'auto':
-                self._note_trees(stats, done - step, min(done, n_run), sampler)
+                # a launch that ends the warm-up is judged more leniently: its last iterations still adapt the step size
+                # (a few trees of another size), the launch after it runs with the frozen, averaged one
+                i0, i1 = self.i_iter + done - step, self.i_iter + min(done, n_run)
+                self._note_trees(stats, done - step, min(done, n_run), sampler, share=0.85 if i0 < n_warmup <= i1 else 0.98)
         self.i_iter += n_run
         if check:
             self.raise_on_error()
@@ -179,7 +183,7 @@ class DeviceChains:
             self.ctx.handle, C.byref(cfg), C.byref(tp), self.n_chain, self.i_iter + n_run, _ptr(self.rng), _ptr(self.sc),
             _ptr(self.vec), _ptr(self.tu), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(stats_t), _ptr(self.n_leapfrog)))
         self.i_iter += n_run
-        self._step_flag = None
+        self._flags = []
         if check:
             self.raise_on_error()
         return samples, stats, stats_t
@@ -187,33 +191,39 @@ class DeviceChains:
     def _note_trees(self, stats, row0, row1, sampler, n_last=32, share=0.98):
         """Queue, behind the launch that wrote rows [row0, row1) of ``stats``, the answer to "did the chains run in step?":
         at least ``share`` of the NUTS trees of its last ``n_last`` iterations (all chains) had the most common size
-        (``bfhip_tree_size_mode_share``: one small kernel).  The flag travels to pinned host memory asynchronously;
-        nothing here synchronises."""
+        (``bfhip_tree_size_mode_share``: one small kernel).  The flag travels to a slot of a small pinned ring
+        asynchronously; nothing here synchronises."""
         torch = _torch()
         if sampler != 'NUTS' or row1 <= row0:
-            self._step_flag = None
+            self._flags = []
             return
         if getattr(self, '_step_host', None) is None:
-            self._step_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            self._step_host = torch.zeros(8, dtype=torch.int32, pin_memory=True)
             self._step_dev = torch.zeros(4098, dtype=torch.int32, device=self.ctx.device)  # BFHIP_TREE_MODE_WORK
+            self._n_flag = 0
+        if not hasattr(self, '_flags'):
+            self._flags = []
+        if len(self._flags) >= 6:  # (never with the waiting rules of run(); keeps the ring's slots unambiguous anyway)
+            self._trees_in_step(keep=2)
         r0 = max(row0, row1 - n_last)
         _lib.check(self.ctx._lib.bfhip_tree_size_mode_share(self.ctx.handle, self.n_chain, stats.shape[1], _ptr(stats), r0,
                                                             row1 - r0, float(share), _ptr(self._step_dev)))
+        slot = self._n_flag % 8
+        self._n_flag += 1
         with torch.cuda.stream(self.ctx.stream):
-            self._step_host.copy_(self._step_dev[:1], non_blocking=True)
+            self._step_host[slot:slot + 1].copy_(self._step_dev[:1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.ctx.stream)
-        self._step_flag = ev
+        self._flags.append((ev, slot))
 
-    def _trees_in_step(self, wait=False):
-        """The most recent answer of ``_note_trees`` (False before the first one).  ``wait``: block until the pending answer
-        has arrived; otherwise use it only if it already has, so that runs queued back to back never stall the stream."""
-        ev = getattr(self, '_step_flag', None)
-        if ev is not None and (wait or ev.query()):
-            if wait:
-                ev.synchronize()
-            self._in_step = bool(int(self._step_host[0]))
-            self._step_flag = None
+    def _trees_in_step(self, keep=0):
+        """The most recent answer of ``_note_trees`` that may be used (False before the first one): all pending answers but
+        the newest ``keep`` are waited for; newer ones are taken too if they have already arrived."""
+        pending = getattr(self, '_flags', [])
+        while pending and (len(pending) > keep or pending[0][0].query()):
+            ev, slot = pending.pop(0)
+            ev.synchronize()
+            self._in_step = bool(int(self._step_host[slot]))
         return getattr(self, '_in_step', False)
 
     def raise_on_error(self):
