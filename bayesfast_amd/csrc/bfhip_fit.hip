@@ -365,9 +365,7 @@ __global__ __launch_bounds__(256) void bf_chol_syrk_kernel(int P, int k0, double
             }
 }
 
-// L y = r then L^T x = y in ONE launch of one 1024-thread workgroup (the right-hand side lives in LDS); per 64-block
-// wave 0 solves the diagonal block by substitution, then all 16 waves sweep the rows below / above it with coalesced
-// 512-byte row reads.  Summation orders are fixed.
+// (wave-level sums used by the residual kernel of bfhip_lstsq)
 template <int CTRL>
 __device__ inline double bf_dpp_f64(double v) {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
@@ -389,76 +387,14 @@ __device__ inline void bf_wave_sum_n(double (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = ((bf_readlane(v[i], 0) + bf_readlane(v[i], 16)) + bf_readlane(v[i], 32)) + bf_readlane(v[i], 48);
 }
-__global__ __launch_bounds__(1024) void bf_trsv_kernel(int P, int m, const double *__restrict__ G, double *__restrict__ r) {
-    extern __shared__ double sm[];
-    double *y = sm;                 // [P]
-    double *Lb = y + P;             // [NB_][NB_ + 1]
-    double *part = Lb + NB_ * (NB_ + 1);  // [16][NB_]
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    for (int c = 0; c < m; ++c) {
-        for (int i = t; i < P; i += 1024) y[i] = r[(size_t)i * m + c];
-        __syncthreads();
-        // ---- forward: L y = r ----
-        for (int k0 = 0; k0 < P; k0 += NB_) {
-            const int nbk = min(NB_, P - k0);
-            for (int i = wv; i < NB_; i += 16) Lb[i * (NB_ + 1) + lane] = (i < nbk && lane < nbk) ? G[(size_t)(k0 + i) * P + k0 + lane] : (i == lane ? 1. : 0.);
-            __syncthreads();
-            if (wv == 0) {
-                double yi = lane < nbk ? y[k0 + lane] : 0.;
-                for (int j = 0; j < nbk; ++j) {
-                    const double yj = bf_readlane(yi, j) / Lb[j * (NB_ + 1) + j];
-                    if (lane == j) yi = yj;
-                    else if (lane > j) yi -= Lb[lane * (NB_ + 1) + j] * yj;
-                }
-                if (lane < nbk) y[k0 + lane] = yi;
-            }
-            __syncthreads();
-            const double yl = lane < nbk ? y[k0 + lane] : 0.;
-            for (int i0 = k0 + nbk + 4 * wv; i0 < P; i0 += 64) {  // four rows per wave and pass: the reductions overlap
-                double v4[4];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int i = i0 + q4;
-                    v4[q4] = (i < P && lane < nbk) ? G[(size_t)i * P + k0 + lane] * yl : 0.;
-                }
-                bf_wave_sum_n<4>(v4);
-                if (lane < 4 && i0 + lane < P) y[i0 + lane] -= (lane == 0 ? v4[0] : (lane == 1 ? v4[1] : (lane == 2 ? v4[2] : v4[3])));
-            }
-            __syncthreads();
-        }
-        // ---- backward: L^T x = y ----
-        for (int k0 = (P - 1) / NB_ * NB_; k0 >= 0; k0 -= NB_) {
-            const int nbk = min(NB_, P - k0);
-            for (int i = wv; i < NB_; i += 16) Lb[i * (NB_ + 1) + lane] = (i < nbk && lane < nbk) ? G[(size_t)(k0 + i) * P + k0 + lane] : (i == lane ? 1. : 0.);
-            // y_j -= sum_{i below the block} L[i][k0 + j] x_i : every wave takes rows i = k0 + nbk + wv, + 16, ...
-            double acc = 0.;
-            for (int i = k0 + nbk + wv; i < P; i += 16) acc += (lane < nbk ? G[(size_t)i * P + k0 + lane] : 0.) * y[i];
-            part[wv * NB_ + lane] = acc;
-            __syncthreads();
-            if (wv == 0) {
-                double yi = lane < nbk ? y[k0 + lane] : 0.;
-                for (int w2 = 0; w2 < 16; ++w2) yi -= part[w2 * NB_ + lane];
-                for (int j = nbk - 1; j >= 0; --j) {
-                    const double xj = bf_readlane(yi, j) / Lb[j * (NB_ + 1) + j];
-                    if (lane == j) yi = xj;
-                    else if (lane < j) yi -= Lb[j * (NB_ + 1) + lane] * xj;
-                }
-                if (lane < nbk) y[k0 + lane] = yi;
-            }
-            __syncthreads();
-        }
-        for (int i = t; i < P; i += 1024) r[(size_t)i * m + c] = y[i];
-        __syncthreads();
-    }
-}
-
-static int solve_spd_impl(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info, double *dsc, double *Linv) {
+static int solve_spd_impl(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info, double *dsc, double *LinvAll) {
     hipStream_t st = ctx->stream;
     BF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
     hipLaunchKernelGGL(bf_diag_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, G, dsc);
     hipLaunchKernelGGL(bf_scale_kernel, dim3(P), dim3(256), 0, st, P, m, G, r, dsc);
     for (int k0 = 0; k0 < P; k0 += NB_) {
         const int nbk = P - k0 < NB_ ? P - k0 : NB_;
+        double *Linv = LinvAll + (size_t)(k0 / NB_) * NB_ * NB_;  // kept: the triangular solves multiply by it
         hipLaunchKernelGGL(bf_chol_diag_kernel, dim3(1), dim3(64), 0, st, P, k0, G, Linv, info);
         const int below = P - k0 - nbk;
         if (below > 0) {
@@ -471,15 +407,95 @@ static int solve_spd_impl(bfhip_ctx *ctx, int P, int m, double *G, double *r, in
     return 0;
 }
 
-// x = (D L L^T D)^-1 r with the kept factor L and scales D = diag(dsc): r is overwritten
-static int chol_apply(bfhip_ctx *ctx, int P, int m, const double *L, const double *dsc, double *r, bool scale_in) {
+// ---------------------------------------------------------------------------------------------------
+// Triangular solves by block columns, one launch per 64-column panel and sweep (the single-workgroup sweep this
+// replaces read the whole factor through one CU: 1.1 ms per sweep at P = 2145).  Every workgroup of a launch forms the
+// panel's 64 unknowns itself, by a product with the inverse of the diagonal block kept from the factorisation, and
+// then takes the panel's contribution out of its own 64 rows (forward) or columns (backward) of the right-hand side.
+// Sums run in index order: the result does not depend on the grid.
+// ---------------------------------------------------------------------------------------------------
+// forward, panel at k0: y_k = L_kk^-1 r_k;  r_i -= L_ik y_k for the rows i below the panel
+__global__ __launch_bounds__(256) void bf_trsv_fwd_kernel(int P, int m, int k0, const double *__restrict__ L,
+                                                          const double *__restrict__ Linv, double *__restrict__ r,
+                                                          double *__restrict__ y) {
+    __shared__ double T[NB_][NB_ + 1];
+    __shared__ double rk[NB_], yk[NB_];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nbk = min(NB_, P - k0);
+    const int i0 = k0 + nbk + blockIdx.x * NB_;
+    for (int q = 0; q < m; ++q) {
+        for (int i = wv; i < NB_; i += 4) T[i][lane] = Linv[i * NB_ + lane];
+        if (t < NB_) rk[t] = t < nbk ? r[(size_t)(k0 + t) * m + q] : 0.;
+        __syncthreads();
+        if (t < NB_) {
+            double acc = 0.;
+            for (int c = 0; c <= t; ++c) acc += T[t][c] * rk[c];
+            yk[t] = acc;
+            if (blockIdx.x == 0 && t < nbk) y[(size_t)(k0 + t) * m + q] = acc;
+        }
+        __syncthreads();
+        if (i0 < P) {
+            for (int i = wv; i < NB_; i += 4) T[i][lane] = (i0 + i < P && lane < nbk) ? L[(size_t)(i0 + i) * P + k0 + lane] : 0.;
+            __syncthreads();
+            if (t < NB_ && i0 + t < P) {
+                double acc = 0.;
+                for (int c = 0; c < nbk; ++c) acc += T[t][c] * yk[c];
+                r[(size_t)(i0 + t) * m + q] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+// backward, panel at k0: x_k = L_kk^-T y_k;  y_j -= L_kj^T x_k for the columns j left of the panel
+__global__ __launch_bounds__(256) void bf_trsv_bwd_kernel(int P, int m, int k0, const double *__restrict__ L,
+                                                          const double *__restrict__ Linv, double *__restrict__ y,
+                                                          double *__restrict__ x) {
+    __shared__ double T[NB_][NB_ + 1];
+    __shared__ double yk[NB_], xk[NB_];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nbk = min(NB_, P - k0);
+    const int j0 = blockIdx.x * NB_;
+    for (int q = 0; q < m; ++q) {
+        for (int i = wv; i < NB_; i += 4) T[i][lane] = Linv[i * NB_ + lane];
+        if (t < NB_) yk[t] = t < nbk ? y[(size_t)(k0 + t) * m + q] : 0.;
+        __syncthreads();
+        if (t < NB_) {
+            double acc = 0.;
+            for (int i = t; i < NB_; ++i) acc += T[i][t] * yk[i];
+            xk[t] = acc;
+            if (blockIdx.x == 0 && t < nbk) x[(size_t)(k0 + t) * m + q] = acc;
+        }
+        __syncthreads();
+        if (j0 < k0) {
+            for (int i = wv; i < NB_; i += 4) T[i][lane] = i < nbk ? L[(size_t)(k0 + i) * P + j0 + lane] : 0.;
+            __syncthreads();
+            if (t < NB_) {
+                double acc = 0.;
+                for (int i = 0; i < nbk; ++i) acc += T[i][t] * xk[i];
+                y[(size_t)(j0 + t) * m + q] -= acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// x = (D L L^T D)^-1 r with the kept factor L, the inverses of its diagonal blocks and the scales D = diag(dsc): r is
+// overwritten by x; ybuf (P, m) is work space
+static int chol_apply(bfhip_ctx *ctx, int P, int m, const double *L, const double *dsc, const double *LinvAll, double *ybuf,
+                      double *r, bool scale_in) {
     hipStream_t st = ctx->stream;
-    const size_t lds = ((size_t)P + NB_ * (NB_ + 1) + 16 * NB_) * sizeof(double);
-    if (lds > 160 * 1024) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_solve_spd: P = %d is beyond the LDS-resident solve", P);
-    if (lds > 64 * 1024)
-        BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_trsv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (scale_in) hipLaunchKernelGGL(bf_unscale_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, m, r, dsc);
-    hipLaunchKernelGGL(bf_trsv_kernel, dim3(1), dim3(1024), lds, st, P, m, L, r);
+    const int nblk = (P + NB_ - 1) / NB_;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int k0 = kb * NB_, nbk = P - k0 < NB_ ? P - k0 : NB_, below = P - k0 - nbk;
+        const int grid = below > 0 ? (below + NB_ - 1) / NB_ : 1;
+        hipLaunchKernelGGL(bf_trsv_fwd_kernel, dim3(grid), dim3(256), 0, st, P, m, k0, L, LinvAll + (size_t)kb * NB_ * NB_, r, ybuf);
+    }
+    for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int k0 = kb * NB_;
+        const int grid = kb > 0 ? kb : 1;
+        hipLaunchKernelGGL(bf_trsv_bwd_kernel, dim3(grid), dim3(256), 0, st, P, m, k0, L, LinvAll + (size_t)kb * NB_ * NB_, ybuf, r);
+    }
     hipLaunchKernelGGL(bf_unscale_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, m, r, dsc);
     return 0;
 }
@@ -487,10 +503,11 @@ static int chol_apply(bfhip_ctx *ctx, int P, int m, const double *L, const doubl
 extern "C" int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || P < 1 || m < 1 || !G || !r || !info) return bf_set_error(BFHIP_ERR_ARG, "bfhip_solve_spd: invalid argument");
-    if (int rc = ensure_scratch(ctx, (size_t)(P + NB_ * NB_) * sizeof(double))) return rc;
-    double *dsc = (double *)ctx->scratch;
-    if (int rc = solve_spd_impl(ctx, P, m, G, r, info, dsc, dsc + P)) return rc;
-    if (int rc = chol_apply(ctx, P, m, G, dsc, r, false)) return rc;
+    const size_t n_inv = (size_t)((P + NB_ - 1) / NB_) * NB_ * NB_;
+    if (int rc = ensure_scratch(ctx, ((size_t)P + n_inv + (size_t)P * m) * sizeof(double))) return rc;
+    double *dsc = (double *)ctx->scratch, *LinvAll = dsc + P, *ybuf = LinvAll + n_inv;
+    if (int rc = solve_spd_impl(ctx, P, m, G, r, info, dsc, LinvAll)) return rc;
+    if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, ybuf, r, false)) return rc;
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -528,18 +545,18 @@ extern "C" int bfhip_lstsq(bfhip_ctx *ctx, int n, int P, int m, const double *A,
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_lstsq: invalid argument");
     if (int rc = bfhip_gram(ctx, n, P, m, A, lda, B, G, c)) return rc;
     // (the Gram scratch is free again; the scales and the block inverse live behind the A^T S partials of the refinement)
-    const size_t n_atb = (size_t)ATB_SEG_ * m * P;
-    if (int rc = ensure_scratch(ctx, (n_atb + P + NB_ * NB_) * sizeof(double))) return rc;
-    double *part = (double *)ctx->scratch, *dsc = part + n_atb, *Linv = dsc + P;
-    if (int rc = solve_spd_impl(ctx, P, m, G, c, info, dsc, Linv)) return rc;
-    if (int rc = chol_apply(ctx, P, m, G, dsc, c, false)) return rc;
+    const size_t n_atb = (size_t)ATB_SEG_ * m * P, n_inv = (size_t)((P + NB_ - 1) / NB_) * NB_ * NB_;
+    if (int rc = ensure_scratch(ctx, (n_atb + P + n_inv + (size_t)P * m) * sizeof(double))) return rc;
+    double *part = (double *)ctx->scratch, *dsc = part + n_atb, *LinvAll = dsc + P, *ybuf = LinvAll + n_inv;
+    if (int rc = solve_spd_impl(ctx, P, m, G, c, info, dsc, LinvAll)) return rc;
+    if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, ybuf, c, false)) return rc;
     double *S = work, *dc = work + (size_t)n * m;
     hipStream_t st = ctx->stream;
     for (int it = 0; it < n_refine; ++it) {
         hipLaunchKernelGGL(bf_resid_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, P, m, A, lda, B, c, S);
         hipLaunchKernelGGL(bf_atb_kernel, dim3((P + 127) / 128, m, ATB_SEG_), dim3(128), 0, st, n, P, m, A, lda, S, part);
         hipLaunchKernelGGL(bf_atb_reduce_kernel, dim3((P + 127) / 128, m), dim3(128), 0, st, P, m, part, dc);
-        if (int rc = chol_apply(ctx, P, m, G, dsc, dc, true)) return rc;
+        if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, ybuf, dc, true)) return rc;
         hipLaunchKernelGGL(bf_axpy_kernel, dim3((P * m + 255) / 256), dim3(256), 0, st, P * m, c, dc);
     }
     BF_HIP_CHECK(hipGetLastError());
