@@ -72,15 +72,18 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
 static inline double bf_bound_lam_max(const double *hess, int d) {
     std::vector<double> A((size_t)d * d), v(d, 1.), w(d), L((size_t)d * d);
     double gersh = 0.;
+    bool finite = true;
     for (int i = 0; i < d; ++i) {
         double rs = 0.;
         for (int k = 0; k < d; ++k) {
             A[(size_t)i * d + k] = 0.5 * (hess[(size_t)i * d + k] + hess[(size_t)k * d + i]);
             rs += std::fabs(A[(size_t)i * d + k]);
         }
+        finite = finite && std::isfinite(rs);
         if (rs > gersh) gersh = rs;
     }
-    if (!(gersh > 0.) || !std::isfinite(gersh)) return std::isfinite(gersh) ? 0. : gersh;
+    if (!finite) return NAN;  // (no bound: `lam_max * r2 < alpha^2` is false for every r2 and the proof never claims anything)
+    if (!(gersh > 0.)) return 0.;
     double lam = 0.;
     for (int it = 0; it < 200; ++it) {
         double nn = 0.;

@@ -201,6 +201,9 @@ void (*pick_body())() {
 }
 }  // namespace
 
+// the proven eigenvalue bound behind the kernels' bound proof (bfhip_pack.h), exposed for tests
+extern "C" double bfemu_bound_lam_max(const double *hess, int d) { return bf_bound_lam_max(hess, d); }
+
 extern "C" void bfemu_rng_seed(int n_chain, uint64_t seed, uint64_t first_stream, uint64_t *rng) {
     for (int c = 0; c < n_chain; ++c) bf_seed_state(seed, first_stream + (uint64_t)c, rng + (size_t)c * 4);
 }

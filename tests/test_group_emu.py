@@ -188,3 +188,37 @@ def test_group_kernel_odd_shapes(d):
             so, sto = orc.nuts_run(spec, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=9, stream=i), 10, 7)
             assert np.array_equal(st['tree_size'][i], sto['tree_size']), (d, C, i)
             np.testing.assert_allclose(s[i, :5], so[:5], rtol=1e-8, atol=1e-8)
+
+
+def test_bound_proof_eigenvalue_bound_is_proven_and_tight():
+    """bf_bound_lam_max (bfhip_pack.h): the upper bound of lam_max((H + H^T) / 2) that the kernels' bound proof multiplies
+    |x - mu|^2 with.  It must never be below the true largest eigenvalue (the proof would be wrong) and should not be far
+    above it (the proof would rarely hold); NaN input must not produce a usable bound."""
+    import ctypes as C
+    import emu
+    f = emu.lib().bfemu_bound_lam_max
+    f.restype = C.c_double
+    rng = np.random.default_rng(3)
+    for d in (1, 2, 7, 64, 128):
+        for kind in ('spd', 'ill', 'nonsym', 'indefinite', 'diag'):
+            a = rng.normal(size=(d, d))
+            if kind == 'spd':
+                h = a @ a.T / d + 0.1 * np.eye(d)
+            elif kind == 'ill':
+                q, _ = np.linalg.qr(a)
+                h = (q * np.logspace(-8, 2, d)) @ q.T
+            elif kind == 'nonsym':
+                h = a @ a.T / d + 0.3 * (a - a.T)
+            elif kind == 'indefinite':
+                h = 0.5 * (a + a.T)
+            else:
+                h = np.diag(rng.uniform(0.1, 5., d))
+            h = np.ascontiguousarray(h)
+            lam = float(np.linalg.eigvalsh(0.5 * (h + h.T))[-1])
+            got = f(h.ctypes.data_as(C.c_void_p), C.c_int(d))
+            assert got >= lam, (d, kind, got, lam)
+            scale = max(abs(lam), float(np.abs(np.linalg.eigvalsh(0.5 * (h + h.T))).max()))
+            assert got <= 1.2 * scale + 1e-300, (d, kind, got, lam)
+    bad = np.full((4, 4), np.nan)
+    got = f(bad.ctypes.data_as(C.c_void_p), C.c_int(4))
+    assert not (got < np.inf)  # NaN or inf: `lam_max * r2 < alpha^2` is then false and the proof never claims anything
