@@ -519,6 +519,16 @@ def gen_evidence(bf, out):
     logr, err = bridge(lpp, lpq, lqp, lqq)
     z['br.lpp'], z['br.lpq'], z['br.lqp'], z['br.lqq'] = lpp, lpq, lqp, lqq
     z['br.logr'], z['br.err'] = np.asarray(logr), np.asarray(err)
+    # -- integrated autocorrelation time (utils/acor.py:79-145) of correlated series: (walker, time, dimension), (time, dimension), (time,)
+    from bayesfast.utils.acor import integrated_time
+    rng2 = np.random.default_rng(31)
+    e = rng2.normal(size=(3, 3000, 2))
+    for t in range(1, e.shape[1]):
+        e[:, t] = np.array([0.5, 0.8]) * e[:, t - 1] + e[:, t]
+    z['acor.x'] = e
+    z['acor.tau3'] = integrated_time(e)
+    z['acor.tau2'] = integrated_time(e[0])
+    z['acor.tau1'] = integrated_time(e[1, :, 0])
     np.savez_compressed(os.path.join(out, 'evidence.npz'), **z)
 
 

@@ -56,6 +56,14 @@ def test_percentile_sorted_is_bitwise_numpys_percentile():
             assert np.array_equal(percentile_sorted(xs, q), np.percentile(x, q))
 
 
+def test_integrated_time_matches_the_reference(fx):
+    """utils/acor.py against values recorded from the reference's estimator (vectorised here over walkers and dimensions)."""
+    from bayesfast_amd.utils.acor import integrated_time
+    np.testing.assert_allclose(integrated_time(fx['acor.x']), fx['acor.tau3'], rtol=1e-12)
+    np.testing.assert_allclose(integrated_time(fx['acor.x'][0]), fx['acor.tau2'], rtol=1e-12)
+    np.testing.assert_allclose(integrated_time(fx['acor.x'][1, :, 0]), fx['acor.tau1'], rtol=1e-12)
+
+
 def test_integrated_time_matches_known_ar1():
     """AR(1) with coefficient 0.6: tau = (1 + rho) / (1 - rho) = 4."""
     from bayesfast_amd.utils.acor import integrated_time
