@@ -85,8 +85,11 @@ class DeviceChains:
 
         ``layout`` chooses how a workgroup's 16 chains are laid out (``bfhip_sampler_config.chain_layout``): 'group' (lane
         per chain: fastest while the chains of a workgroup stay in step), 'wave' (wave per chain: insensitive to chains
-        out of step) or 'auto', decided per launch: 'group' when at least 98 % of the NUTS trees of the previous launch's
-        last 32 iterations had one and the same size (static HMC: always), 'wave' otherwise and for the first launch.
+        out of step) or 'auto', decided per launch: 'group' when at least 98 % of the NUTS trees of an earlier launch's
+        last 32 iterations had one and the same size (static HMC: always), 'wave' otherwise and for the first launches.
+        "Earlier" is the launch just before inside a run, and the one before that for the first launch of a run: a pure
+        function of the sequence of launches, never of host timing.  With ``hist_reduce`` set (``sample()`` does it when the
+        chains are sharded over ranks) the trees of all ranks decide, so the choice does not depend on the sharding.
         Both layouts follow the same per-chain arithmetic and random streams; their floating-point sums are ordered
         differently, so results are bit-reproducible (and independent of sharding and launch cuts) for a fixed layout,
         and agree to rounding between layouts.
@@ -122,13 +125,14 @@ class DeviceChains:
                 raise ValueError('{} should be a contiguous float64 tensor of shape {} on {}.'.format(name, shape, self.ctx.device))
         step = max(1, int(launch_iters) if launch_iters else n_run)
         for i_launch, done in enumerate(range(step, n_run + step, step)):  # iter_end of each launch; output rows are relative to i_iter
-            # the layout is chosen per launch from the trees of an earlier launch.  Inside a run: the launch just before
-            # (the host waits for its flag: it has nothing else to queue, and the gap is a launch latency).  The first
-            # launch of a run: the launch before the last one at the latest, so that runs issued back to back keep one
-            # launch queued behind the running one and still follow the chains' behaviour, one launch late.
+            # the layout is chosen per launch from the trees of an EARLIER launch, as a pure function of the sequence of
+            # launches (never of host timing): inside a run, the launch just before (the host waits for its answer: it has
+            # nothing else to queue, and the gap is a launch latency); the first launch of a run, the launch before the
+            # last one, so that runs issued back to back keep one launch queued behind the running one and still follow
+            # the chains' behaviour, one launch late
             lay = layout
             if lay == 'auto':
-                lay = 'group' if (sampler == 'HMC' or self._trees_in_step(keep=0 if i_launch > 0 else 1)) else 'wave'
+                lay = 'group' if (sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)) else 'wave'
             cfg.chain_layout = {'group': 1, 'wave': 2}[lay]
             self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
@@ -154,6 +158,8 @@ class DeviceChains:
 
         Returns (samples (n_chain, n_run, d), stats (n_chain, n_run, 11), stats_t (n_chain, n_run, 2) = u and weight)."""
         torch = _torch()
+        if self.full_metric:  # bf_tnuts_kernel has the diagonal metric only; running on would silently ignore the covariance
+            raise NotImplementedError('TNUTS with a full-rank metric is not implemented; use a diagonal metric.')
         self.density.upload_if_needed()
         d = self.d
         mean = np.asarray(base_mean, dtype=np.float64).reshape(d)
@@ -183,29 +189,43 @@ class DeviceChains:
             self.ctx.handle, C.byref(cfg), C.byref(tp), self.n_chain, self.i_iter + n_run, _ptr(self.rng), _ptr(self.sc),
             _ptr(self.vec), _ptr(self.tu), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(stats_t), _ptr(self.n_leapfrog)))
         self.i_iter += n_run
-        self._flags = []
+        self._answers = []
         if check:
             self.raise_on_error()
         return samples, stats, stats_t
+
+    # ``hist_reduce``: None, or a callable summing an int64 device tensor over the ranks in place (``parallel.all_reduce_sum``;
+    # ``sample()`` sets it when the chains are sharded).  With it the 'auto' layout is decided from the tree sizes of ALL
+    # ranks' chains -- a collective per launch, the same launches on every rank -- so that every rank picks the same
+    # layout and results do not depend on the number of ranks.  Without it each DeviceChains decides from its own chains.
+    hist_reduce = None
 
     def _note_trees(self, stats, row0, row1, sampler, n_last=32, share=0.98):
         """Queue, behind the launch that wrote rows [row0, row1) of ``stats``, the answer to "did the chains run in step?":
         at least ``share`` of the NUTS trees of its last ``n_last`` iterations (all chains) had the most common size
         (``bfhip_tree_size_mode_share``: one small kernel).  The flag travels to a slot of a small pinned ring
-        asynchronously; nothing here synchronises."""
+        asynchronously; nothing here synchronises (except with ``hist_reduce``, which is a collective)."""
         torch = _torch()
+        if not hasattr(self, '_answers'):
+            self._answers = []   # one entry per launch, oldest first: bool, None (no answer: not NUTS) or (event, slot)
         if sampler != 'NUTS' or row1 <= row0:
-            self._flags = []
+            self._answers.append(None)
+            return
+        r0 = max(row0, row1 - n_last)
+        if self.hist_reduce is not None:
+            with torch.cuda.stream(self.ctx.stream):
+                ts = stats[:, r0:row1, _lib.NSTATS.index('tree_size')].reshape(-1).clamp(0., 4095.).to(torch.int64)
+                hist = torch.zeros(4096, dtype=torch.int64, device=self.ctx.device)
+                hist.scatter_add_(0, ts, torch.ones_like(ts))
+            self.ctx.stream.synchronize()
+            self.hist_reduce(hist)
+            self._answers.append(bool(float(hist.max()) >= share * float(hist.sum())))
+            del self._answers[:-4]
             return
         if getattr(self, '_step_host', None) is None:
             self._step_host = torch.zeros(8, dtype=torch.int32, pin_memory=True)
             self._step_dev = torch.zeros(4098, dtype=torch.int32, device=self.ctx.device)  # BFHIP_TREE_MODE_WORK
             self._n_flag = 0
-        if not hasattr(self, '_flags'):
-            self._flags = []
-        if len(self._flags) >= 6:  # (never with the waiting rules of run(); keeps the ring's slots unambiguous anyway)
-            self._trees_in_step(keep=2)
-        r0 = max(row0, row1 - n_last)
         _lib.check(self.ctx._lib.bfhip_tree_size_mode_share(self.ctx.handle, self.n_chain, stats.shape[1], _ptr(stats), r0,
                                                             row1 - r0, float(share), _ptr(self._step_dev)))
         slot = self._n_flag % 8
@@ -214,17 +234,22 @@ class DeviceChains:
             self._step_host[slot:slot + 1].copy_(self._step_dev[:1], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.ctx.stream)
-        self._flags.append((ev, slot))
+        self._answers.append((ev, slot))
+        del self._answers[:-4]  # (at most the last two are ever read: the ring's 8 slots stay unambiguous)
 
-    def _trees_in_step(self, keep=0):
-        """The most recent answer of ``_note_trees`` that may be used (False before the first one): all pending answers but
-        the newest ``keep`` are waited for; newer ones are taken too if they have already arrived."""
-        pending = getattr(self, '_flags', [])
-        while pending and (len(pending) > keep or pending[0][0].query()):
-            ev, slot = pending.pop(0)
+    def _trees_in_step(self, lag=1):
+        """The answer of ``_note_trees`` for the launch ``lag`` launches back (1 = the last one), waited for if it is still
+        on its way; False when there is none (the first launches of a chain set, launches that were not NUTS).  A pure
+        function of the launches so far: an answer that happens to have arrived early is not used before its turn."""
+        ans = getattr(self, '_answers', [])
+        if len(ans) < lag:
+            return False
+        a = ans[-lag]
+        if isinstance(a, tuple):
+            ev, slot = a
             ev.synchronize()
-            self._in_step = bool(int(self._step_host[slot]))
-        return getattr(self, '_in_step', False)
+            a = ans[-lag] = bool(int(self._step_host[slot]))
+        return bool(a)
 
     def raise_on_error(self):
         """Synchronises; raises like the reference does for a chain that hit a fatal condition."""

@@ -10,7 +10,7 @@ __all__ = ['sample']
 
 
 def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_backend=None, verbose=True,
-           iters_per_launch=None, layout='auto'):
+           iters_per_launch=None, layout='auto', gather=False):
     """Sample a surrogate density.
 
     density : SurrogateDensity
@@ -22,9 +22,15 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     parallel_backend : accepted for signature compatibility and ignored; chains shard over the ranks of the
         default ``torch.distributed`` process group instead (one process per GPU)
     layout : 'auto' | 'group' | 'wave', the chain layout of the kernel (``DeviceChains.run``).  'auto' switches per launch
-        by how uniform the trees are; results are bit-reproducible for a fixed layout and agree to rounding between them
-    Returns a ``TraceTuple`` whose arrays stay on this rank's GPU (this rank's chains); its host views gather all chains
-    on first use, and the refit path (``bayesfast_amd.core.refit.select_fit_points``) exchanges only the selected rows.
+        by how uniform the trees of ALL ranks' chains were in the launches before (a pure function of the launch sequence,
+        the same on every rank); results are bit-reproducible for a fixed layout and agree to rounding between them
+    gather : also materialise the host arrays of all chains before returning (``TraceTuple.gather()``)
+
+    Under ``torch.distributed`` this is a COLLECTIVE call: every rank must call it with the same arguments (the seed is
+    broadcast from rank 0, the 'auto' layout and the verbose line reduce over the ranks).  Returns a ``TraceTuple`` whose
+    arrays stay on this rank's GPU (this rank's chains); its host views need ``gather()`` (a collective) first when there
+    is more than one rank, and the refit path (``bayesfast_amd.core.refit.select_fit_points``) exchanges only the
+    selected rows.
     """
     import torch
     from ..chains import DeviceChains
@@ -94,6 +100,8 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     if done + n_run > trace.n_iter:
         trace.n_iter = done + n_run
     step = n_run if not iters_per_launch else int(iters_per_launch)
+    if ws > 1:  # the 'auto' layout is decided from every rank's trees (DeviceChains.hist_reduce)
+        chains.hist_reduce = parallel.all_reduce_sum
     ss, sts, stts = [], [], []
     left = n_run
     while left > 0:
@@ -130,4 +138,5 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
         if rank == 0:
             print(' sampling finished [ {} / {} ], {} chains, {} leapfrog steps.'.format(s.shape[1], trace.n_iter,
                                                                                          trace.n_chain, int(nl.item())))
-    return TraceTuple(trace, s, st, s_orig, lp_orig, chains, stats_t=stt)
+    tt = TraceTuple(trace, s, st, s_orig, lp_orig, chains, stats_t=stt)
+    return tt.gather() if gather else tt

@@ -70,7 +70,9 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
 // c' I - sym(H) for a c' slightly below c (so that (x - mu)^T H (x - mu) <= c |x - mu|^2 for every x): a power iteration
 // proposes, the factorisation disposes; the Gershgorin bound is the fallback.  Host side, once per upload.
 static inline double bf_bound_lam_max(const double *hess, int d) {
-    std::vector<double> A((size_t)d * d), v(d, 1.), w(d), L((size_t)d * d);
+    std::vector<double> A((size_t)d * d), v(d), w(d), L((size_t)d * d);
+    // (a start vector without symmetry: the all-ones vector lies in the null space of every H with zero row sums)
+    for (int i = 0; i < d; ++i) v[i] = 1. + 0.37 * std::sin(1.7 * (double)i + 0.3);
     double gersh = 0.;
     bool finite = true;
     for (int i = 0; i < d; ++i) {
@@ -98,7 +100,12 @@ static inline double bf_bound_lam_max(const double *hess, int d) {
         lam = nn;
         for (int i = 0; i < d; ++i) v[i] = w[i] / nn;
     }
-    for (double c = lam * 1.01; c < gersh; c *= 1.05) {
+    // the search starts above zero whatever the iteration found (lam = 0: v hit the null space) and ends after a bounded
+    // number of steps: 1.05^n covers 1e-6 gersh .. gersh in 284 steps
+    double c0 = lam * 1.01;
+    if (!(c0 > 1e-6 * gersh)) c0 = 1e-6 * gersh;
+    int n_try = 0;
+    for (double c = c0; c < gersh && n_try < 400; c *= 1.05, ++n_try) {
         bool ok = true;
         for (int i = 0; i < d && ok; ++i)
             for (int k = 0; k <= i; ++k) {

@@ -248,9 +248,11 @@ class TraceTuple:
     """All chains of one ``sample`` call (samplers/sample_trace.py:631-801).
 
     The arrays stay where the sampler wrote them: on this rank's GPU, for this rank's chains.  The reference's array
-    views (``samples``, ``logp``, ``stats``, ``get`` ...) materialise them on the host on first use -- under
-    ``torch.distributed`` after an all-gather over the ranks, so every rank must then make the same call -- and are
-    cached.  The refit path does not need them: ``refit_shard`` hands the device-resident rows to
+    views (``samples``, ``logp``, ``stats``, ``get`` ...) materialise them on the host on first use and are cached.  Under
+    ``torch.distributed`` with more than one rank they need every rank's chains: call ``gather()`` -- a collective, on
+    EVERY rank -- first (or ``sample(..., gather=True)``); a view asked for before that raises instead of starting a
+    collective behind the caller's back (``if rank == 0: save(tt.samples)`` would otherwise hang).  The refit path does
+    not need them: ``refit_shard`` hands the device-resident rows to
     ``bayesfast_amd.core.refit.select_fit_points``, and the warm-start helpers reduce over the ranks on the device."""
 
     _FIELDS = ('samples', 'stats', 'samples_original', 'logp_original')
@@ -266,16 +268,27 @@ class TraceTuple:
         self._chains = chains  # DeviceChains of this rank
 
     # ---- lazily materialised host arrays (all chains) ----
-    def _array(self, name):
+    def _array(self, name, collective=False):
         if name not in self._host:
             t = self._parts[name]
             if not isinstance(t, np.ndarray):  # this rank's shard as a tensor
                 from .. import parallel
                 if parallel.world()[1] > 1:
+                    if not collective:
+                        raise RuntimeError('this TraceTuple holds the chains of one rank only: call gather() on every rank '
+                                           '(or sample(..., gather=True)) before using its host views.')
                     t = parallel.all_gather_chains(t.contiguous(), self._trace.n_chain)
                 t = t.cpu().numpy()
             self._host[name] = np.asarray(t)
         return self._host[name]
+
+    def gather(self):
+        """Materialise the host arrays of ALL chains (one all-gather per field over the ranks: a collective, to be called
+        by every rank; a plain device-to-host copy without a process group).  Returns self."""
+        for name in self._parts:
+            if not (name == 'samples_original' and self._parts[name] is self._parts['samples']):
+                self._array(name, collective=True)
+        return self
 
     _samples = property(lambda self: self._array('samples'))
     _stats = property(lambda self: self._array('stats'))

@@ -26,11 +26,16 @@ def main(out):
     # default trace: no seed given by the caller (rank 0's entropy is what every rank must use), then a second round
     # warm-started from the first (_get_step_size / _get_metric reduce over all ranks)
     seed = int(os.environ['BF_TEST_SEED'])
-    tt = bfa.sample(den, {'n_chain': 22, 'n_iter': 60, 'n_warmup': 40, 'random_generator': seed}, verbose=False)
+    # BF_TEST_IPL: iterations per launch (several launches, each choosing its layout under 'auto' from the launches before)
+    ipl = int(os.environ.get('BF_TEST_IPL', 0)) or None
+    tt = bfa.sample(den, {'n_chain': 22, 'n_iter': 60, 'n_warmup': 40, 'random_generator': seed}, verbose=False,
+                    iters_per_launch=ipl)
     step = _get_step_size(tt)
     metric = _get_metric(tt, 'diag')
     tt2 = bfa.sample(den, {'n_chain': 22, 'n_iter': 30, 'n_warmup': 10, 'random_generator': seed + 1, 'step_size': step,
-                           'metric': metric}, verbose=False)
+                           'metric': metric}, verbose=False, iters_per_launch=ipl)
+    tt.gather()   # collectives, on every rank (a host view before them raises when there is more than one rank)
+    tt2.gather()
     res = dict(s=np.asarray(tt.samples), ts=np.stack([np.asarray(tt[i].stats._tree_size) for i in range(22)]),
                step=np.asarray(step), metric=np.asarray(metric), s2=np.asarray(tt2.samples),
                logp=np.asarray(tt.get(include_warmup=True, return_type='logp')))

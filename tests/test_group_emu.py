@@ -219,6 +219,14 @@ def test_bound_proof_eigenvalue_bound_is_proven_and_tight():
             assert got >= lam, (d, kind, got, lam)
             scale = max(abs(lam), float(np.abs(np.linalg.eigvalsh(0.5 * (h + h.T))).max()))
             assert got <= 1.2 * scale + 1e-300, (d, kind, got, lam)
+    # zero row sums: the all-ones vector is in the null space (a symmetric start vector would stall the power iteration and,
+    # before the search was floored and capped, hang the upload); also the zero and a negative definite matrix
+    lap = np.diag(np.full(8, 2.)) - np.eye(8, k=1) - np.eye(8, k=-1) - np.eye(8, k=7) - np.eye(8, k=-7)
+    for h in (np.array([[1., -1.], [-1., 1.]]), lap, np.zeros((3, 3)), -np.eye(5)):
+        h = np.ascontiguousarray(h)
+        lam = float(np.linalg.eigvalsh(h)[-1])
+        got = f(h.ctypes.data_as(C.c_void_p), C.c_int(h.shape[0]))
+        assert got >= lam and got <= 1.2 * np.abs(np.linalg.eigvalsh(h)).max() + 1e-300, (h, got, lam)
     bad = np.full((4, 4), np.nan)
     got = f(bad.ctypes.data_as(C.c_void_p), C.c_int(4))
     assert not (got < np.inf)  # NaN or inf: `lam_max * r2 < alpha^2` is then false and the proof never claims anything
