@@ -7,7 +7,7 @@ host side that mirrors the reference's ``modules`` / ``samplers`` / ``core.sampl
 from . import _lib  # noqa: F401
 from .modules import PolyConfig, PolyModel
 from .core.module import Surrogate
-from .core.density import SurrogateDensity, Chi2PipelineDensity
+from .core.density import SurrogateDensity, Chi2PipelineDensity, GaussianLink
 from .core.sample import sample
 from .samplers import NTrace, HTrace, TNTrace, GaussianBase, TraceTuple
 from .utils import SystematicResampler
@@ -15,5 +15,5 @@ from .core.refit import select_fit_points, importance_weights
 from .transforms import SIT
 from .evidence import GBS, bridge
 
-__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'Chi2PipelineDensity', 'sample', 'NTrace', 'HTrace', 'TNTrace', 'GaussianBase', 'TraceTuple',
+__all__ = ['PolyConfig', 'PolyModel', 'Surrogate', 'SurrogateDensity', 'Chi2PipelineDensity', 'GaussianLink', 'sample', 'NTrace', 'HTrace', 'TNTrace', 'GaussianBase', 'TraceTuple',
            'SystematicResampler', 'select_fit_points', 'importance_weights', 'SIT', 'GBS', 'bridge']

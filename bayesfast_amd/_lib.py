@@ -32,7 +32,8 @@ class DensityDesc(C.Structure):
                 ('c0', C.c_double), ('lin', _dp), ('quad', _dp), ('cubic2', _dp), ('cubic3', _dp),
                 ('use_bound', C.c_int), ('mu', _dp), ('hess', _dp), ('alpha', C.c_double), ('f_mu', C.c_double),
                 ('use_decay', C.c_int), ('decay_mu', _dp), ('decay_hess', _dp), ('decay_alpha2', C.c_double),
-                ('decay_gamma', C.c_double)]
+                ('decay_gamma', C.c_double),
+                ('link_kind', C.c_int), ('link_y', C.c_double), ('link_prec', C.c_double), ('link_logp0', C.c_double)]
 
 
 class SamplerConfig(C.Structure):

@@ -1,5 +1,5 @@
 """Surrogate density: the part of ``bayesfast.core.density.Density`` that the sampler path touches, for a
-pipeline whose log density is one PolyModel output.
+pipeline whose log density is one PolyModel output, or a Gaussian likelihood of one PolyModel output.
 
 Host state is NumPy; every ``logp``/``grad``/``logp_and_grad`` call is one batched device launch
 (``bfhip_logp_grad``), replacing the per-row Python recursion of core/density.py:523-525."""
@@ -7,7 +7,30 @@ import numpy as np
 
 from ..modules.poly import PolyModel
 
-__all__ = ['SurrogateDensity', 'Chi2PipelineDensity']
+__all__ = ['SurrogateDensity', 'Chi2PipelineDensity', 'GaussianLink']
+
+
+class GaussianLink:
+    """The analytic module downstream of a single-output surrogate: logp = logp0 - prec (m - y)^2 / 2 of the surrogate's
+    output m.  ``SurrogateDensity(surrogate, link=GaussianLink(y, prec))`` is the reference's
+    ``Density(module_list=[model, like], surrogate_list=[PolyModel(scope=(0, 1))])`` with such a ``like`` module
+    (core/density.py:527-560; examples/2d-donut.ipynb: m = |x|, logp = -(m - 5)^2 / 0.5 is GaussianLink(5., 4.)).
+    The fused sampler evaluates it in the kernel (``bfhip_density_desc.link_*``)."""
+
+    def __init__(self, y, prec, logp0=0.):
+        self.y, self.prec, self.logp0 = float(y), float(prec), float(logp0)
+        if not self.prec > 0:
+            raise ValueError('prec should be positive.')
+
+    def spec(self):
+        return dict(kind='gaussian', y=self.y, prec=self.prec, logp0=self.logp0)
+
+    def fun(self, m):
+        r = np.asarray(m, dtype=np.float64) - self.y
+        return self.logp0 - 0.5 * (r * (self.prec * r))
+
+    def jac(self, m):
+        return -(self.prec * (np.asarray(m, dtype=np.float64) - self.y))
 
 
 class SurrogateDensity:
@@ -17,11 +40,16 @@ class SurrogateDensity:
     input_scales : None or (d, 2) array, ``Density(input_scales=...)`` (core/density.py:33-58)
     hard_bounds : bool or (d,) / (d, 2) array_like (core/density.py:60-76)
     decay_options : dict for ``set_decay_options`` (core/density.py:761-794)
+    link : None (the surrogate's output is the log density) or a ``GaussianLink`` (the surrogate replaces the first module
+        of a two-module pipeline; the link is the second)
     """
 
-    def __init__(self, surrogate, input_scales=None, hard_bounds=False, decay_options=None):
+    def __init__(self, surrogate, input_scales=None, hard_bounds=False, decay_options=None, link=None):
         if not isinstance(surrogate, PolyModel) or surrogate.output_size != 1:
             raise ValueError('surrogate should be a PolyModel with output_size 1.')
+        if link is not None and not isinstance(link, GaussianLink):
+            raise ValueError('link should be a GaussianLink or None.')
+        self.link = link
         self.surrogate = surrogate
         self._d = surrogate.input_size
         if input_scales is None:
@@ -79,6 +107,9 @@ class SurrogateDensity:
         return self._tdev
 
     def _constraint(self, which, x):
+        if self._input_scales is None:  # core/density.py:100-107: no scales -> identity, unit Jacobian, zero second derivative
+            x = np.array(x, dtype=np.float64)
+            return x if which in ('from_original', 'to_original') else (np.ones_like(x) if which.endswith('grad') else np.zeros_like(x))
         return self._transform_device().constraint(which, np.asarray(x, dtype=np.float64)).cpu().numpy()
 
     def from_original(self, x):
@@ -123,11 +154,14 @@ class SurrogateDensity:
     input_vars = ('__var__',)   # Density(input_vars=...), core/density.py:256
     density_name = '__var__'    # Density(density_name=...), core/density.py:640
 
-    def fit(self, x, logp=None):
+    output_var = None           # with a link: the name of the surrogate's output variable in the var_dicts
+
+    def fit(self, x, logp=None, y=None):
         """``Density.fit`` (core/density.py:813-830): either ``fit(var_dicts)`` as in the reference -- a sequence of
         VariableDict-like objects whose ``_fun`` (or ``fun``) maps variable names to arrays; the points are the
         concatenated ``input_vars`` and the true log-densities ``_fun[density_name][0]`` (:833-838) -- or
-        ``fit(x, logp)`` with x (n, d) original-space points and logp (n,)."""
+        ``fit(x, logp)`` with x (n, d) original-space points and logp (n,).  With a ``link`` the surrogate is fitted to the
+        true values y (n,) of the module it replaces (:826-830, ``su.fit(x, y, logp)``), not to logp."""
         if logp is None:
             vds = list(x)
             if not vds or not all(hasattr(v, '_fun') or hasattr(v, 'fun') for v in vds):
@@ -135,6 +169,10 @@ class SurrogateDensity:
             get = lambda v: v._fun if hasattr(v, '_fun') else v.fun
             x = np.array([np.concatenate([np.atleast_1d(get(v)[n]) for n in self.input_vars]) for v in vds])
             logp = np.array([np.atleast_1d(get(v)[self.density_name])[0] for v in vds])
+            if self.link is not None:
+                if self.output_var is None:
+                    raise ValueError('set output_var (the name of the surrogate\'s output variable) to fit from var_dicts.')
+                y = np.array([np.atleast_1d(get(v)[self.output_var])[0] for v in vds])
         x = np.ascontiguousarray(x, dtype=np.float64)
         logp = np.asarray(logp, dtype=np.float64).reshape(-1)
         if x.ndim != 2 or x.shape != (logp.size, self._d):
@@ -143,7 +181,15 @@ class SurrogateDensity:
             self._set_decay(x)
         su = self.surrogate
         xs = x if su._input_scales is None else (x - su._input_scales[:, 0]) / su._input_scales_diff
-        su.fit(xs, logp[:, None], logp)
+        if self.link is None:
+            su.fit(xs, logp[:, None], logp)
+        else:
+            if y is None:
+                raise ValueError('a density with a link is fitted to the outputs y of the module the surrogate replaces.')
+            y = np.asarray(y, dtype=np.float64).reshape(-1)
+            if y.size != logp.size:
+                raise ValueError('y should have shape (n,).')
+            su.fit(xs, y[:, None], logp)
         self._device = None
 
     def _set_decay(self, x):
@@ -163,7 +209,7 @@ class SurrogateDensity:
                     hard_bounds=self._hard_bounds if self._input_scales is not None else None,
                     su_lo=None if su._input_scales is None else su._input_scales[:, 0],
                     su_diff=None if su._input_scales is None else su._input_scales_diff,
-                    poly=su.poly_spec(), use_decay=self._use_decay)
+                    poly=su.poly_spec(), use_decay=self._use_decay, link=None if self.link is None else self.link.spec())
         if self._use_decay:
             if self._mu is None:
                 raise RuntimeError('the decay statistics have not been set; call fit first.')

@@ -105,6 +105,11 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     m.f_mu = ds->f_mu;
     m.decay_alpha2 = ds->decay_alpha2;
     m.decay_gamma = ds->decay_gamma;
+    if (ds->link_kind != 0 && ds->link_kind != 1) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: unknown link_kind %d", ds->link_kind);
+    m.has_link = ds->link_kind == 1;
+    m.link_y = ds->link_y;
+    m.link_prec = ds->link_prec;
+    m.link_logp0 = ds->link_logp0;
     // ---- cubic terms, compact over the dimensions they touch (modules/_poly.pyx:49-137) ----
     m.has_cubic = (ds->cubic2 || ds->cubic3) ? 1 : 0;
     if (m.has_cubic) {

@@ -109,12 +109,12 @@ __device__ inline void bf_eval_w1(const DevModel &mm, const double *Sf, const do
     const int DP = 16 * T;
     const int g = lane >> 4;
     struct Flags {  // the model's switches, constants when PL
-        bool has_transform, has_su, use_decay, has_cubic, has_quad, use_bound;
+        bool has_transform, has_su, use_decay, has_cubic, has_quad, use_bound, has_link;
         double c0, alpha, f_mu, decay_gamma, decay_alpha2;
     };
     const Flags m = {PL ? false : (bool)mm.has_transform, PL ? false : (bool)mm.has_su, PL ? false : (bool)mm.use_decay,
                      PL ? false : (bool)mm.has_cubic, PL ? true : (bool)mm.has_quad, PL ? true : (bool)mm.use_bound,
-                     mm.c0, mm.alpha, mm.f_mu, mm.decay_gamma, mm.decay_alpha2};
+                     PL ? false : (bool)mm.has_link, mm.c0, mm.alpha, mm.f_mu, mm.decay_gamma, mm.decay_alpha2};
     const bool tr = m.has_transform && !original_space;
     double xs[E], jac[E], gj[E], hv[E];
     double logdet = 0.;
@@ -238,6 +238,12 @@ __device__ inline void bf_eval_w1(const DevModel &mm, const double *Sf, const do
     for (int e = 0; e < E; ++e) {
         if (m.has_su) grad[e] = grad[e] / pd[PD_SU_DIFF * DP + 4 * e + g];
         grad[e] = grad[e] * jac[e];
+    }
+    if (m.has_link) {  // the next module of the pipeline (density.py:552-560): logp = phi(m), grad = phi'(m) grad m
+        const double r = f - mm.link_y, dphi = -(mm.link_prec * r);
+        f = mm.link_logp0 - 0.5 * (r * (mm.link_prec * r));
+#pragma unroll
+        for (int e = 0; e < E; ++e) grad[e] = dphi * grad[e];
     }
     if (m.use_decay) {
         f -= m.decay_gamma * bf_clip0(bd2 - m.decay_alpha2);

@@ -48,7 +48,7 @@ static int launch_w(bfhip_ctx *ctx, const SamplerArgs &args, bool nuts, int fs) 
 }
 
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {
-    return m.DP <= 64 && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !args.mat;
+    return m.DP <= 64 && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !args.mat;
 }
 
 int bf_group_scratch_slots(int DP) { return 5 * (BFHIP_MAX_TREEDEPTH - 2); }

@@ -41,6 +41,8 @@ struct DevModel {
     const double *Hf;   // bound Hessian
     const double *Hdf;  // decay Hessian
     double c0, alpha, f_mu, decay_alpha2, decay_gamma;
+    int has_link;       // the surrogate's output m feeds a Gaussian likelihood: logp = link_logp0 - link_prec (m - link_y)^2 / 2
+    double link_y, link_prec, link_logp0;
     double lam_max_d;   // the same for the decay Hessian
     double lam_max;     // a proven upper bound of the largest eigenvalue of (H + H^T) / 2 (bf_bound_lam_max), 0 without a bound
     // cubic terms in compact (masked) form; pos2/pos3 map a dimension to its index in the mask or -1

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
     const bool f_quad = SPEC ? true : (bool)m.has_quad, f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
     const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = SPEC ? false : (bool)m.has_cubic;
+    const bool f_link = SPEC ? false : (bool)m.has_link;  // Gaussian likelihood of the surrogate's output (density.py:552-560)
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
     // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
     // (matrix, row tile, K part) on every trip and keeps its A operands in registers for the whole launch:
@@ -1034,7 +1035,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
         double kin_fast = 0.;
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
-            const bool fast_kin = !FULLM && !f_decay && mode != M_OOB;
+            const bool fast_kin = !FULLM && !f_decay && !f_link && mode != M_OOB;
             double xev[E], r_cub = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1129,6 +1130,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                     if (f_su) gn[e] = gn[e] / pdl(PD_SU_DIFF, e);
                     gn[e] = gn[e] * jac[e];
                 }
+                if (f_link) {  // logp = phi(m), grad = phi'(m) grad m
+                    const double r = f - m.link_y, dphi = -(m.link_prec * r);
+                    f = m.link_logp0 - 0.5 * (r * (m.link_prec * r));
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gn[e] = dphi * gn[e];
+                }
                 if (f_decay) {
                     f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
                     if (r_bd2 > m.decay_alpha2) {
@@ -1212,7 +1219,7 @@ static bool g_no_plain = false;  // tuning hook: force the generic instantiation
 extern "C" void bfhip_debug_no_plain(int v) { g_no_plain = v != 0; }
 // the common surrogate: linear + quadratic configs with the extrapolation bound and nothing else
 static bool sampler_plain(const DevModel &m) {
-    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !g_no_plain;
+    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
 }
 
 // K-split of the matvec jobs: the largest power of two KS <= W with n_mat * W * KS <= 16
@@ -1301,12 +1308,12 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
     // ... and the same surrogate behind the constraint transform (bounded parameters)
     if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
-        !m.has_su && !m.has_cubic)
+        !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
     // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)
-    if (W == 4 && !g_no_plain && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic) {
+    if (W == 4 && !g_no_plain && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link) {
         constexpr int W4 = W == 4 ? 4 : W;  // (keeps the other W from instantiating these)
         if (m.use_decay && m.has_transform) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 7 : 0)>(ctx, args);
         if (m.use_decay) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 3 : 0)>(ctx, args);

@@ -107,7 +107,8 @@ def density_desc_from_spec(spec):
     spec = {'d', 'ranges', 'hard_bounds', 'su_lo', 'su_diff',
             'poly': {'input_size', 'output_size' (=1), 'configs': [{'order', 'input_mask', 'output_mask', 'coef'}],
                      'use_bound', 'mu', 'hess', 'alpha', 'f_mu'},
-            'use_decay', 'decay_mu', 'decay_hess', 'decay_alpha2', 'decay_gamma'}
+            'use_decay', 'decay_mu', 'decay_hess', 'decay_alpha2', 'decay_gamma',
+            'link': None | {'kind': 'gaussian', 'y', 'prec', 'logp0'}}
 
     The PolyConfig masks are scattered to the full input here, which is what PolyModel._fun_and_jac does
     on every call (modules/poly.py:474-477)."""
@@ -189,6 +190,12 @@ def density_desc_from_spec(spec):
         ds.decay_hess = f64(spec['decay_hess'], (d, d))
         ds.decay_alpha2 = float(spec['decay_alpha2'])
         ds.decay_gamma = float(spec['decay_gamma'])
+    link = spec.get('link')
+    if link is not None:  # the module downstream of the surrogate's output: {'kind': 'gaussian', 'y', 'prec', 'logp0'}
+        if link.get('kind') != 'gaussian':
+            raise ValueError('unknown link kind.')
+        ds.link_kind, ds.link_y, ds.link_prec = 1, float(link['y']), float(link['prec'])
+        ds.link_logp0 = float(link.get('logp0', 0.))
     return ds, keep
 
 

@@ -290,6 +290,29 @@ class TraceTuple:
                 self._array(name, collective=True)
         return self
 
+    def _adapted_state(self):
+        """Host arrays, all chains, of what the reference keeps per chain next to its samples: the starting points and the
+        adapted step-size (DualAverageAdaptation, step_size.py:10-22) and metric state.  Under ``torch.distributed`` a
+        collective (call it on every rank); cached."""
+        if 'adapted' not in self._host:
+            from .. import parallel
+            ch = self._chains
+            if ch is None:
+                raise ValueError('this TraceTuple does not carry its chains.')
+            out = {}
+            for k in ('log_step', 'log_bar', 'hbar', 'count'):
+                out[k] = parallel.all_gather_chains(ch.field(k).contiguous(), self.n_chain).cpu().numpy()
+            if ch.full_metric:
+                out['cov'] = parallel.all_gather_chains(ch.covariance(), self.n_chain).cpu().numpy()
+            else:
+                out['var'] = parallel.all_gather_chains(ch.field('var').contiguous(), self.n_chain).cpu().numpy()
+            x0 = np.asarray(self._trace.x_0, dtype=np.float64)
+            out['x_0'] = x0.reshape(-1, x0.shape[-1])
+            if out['x_0'].shape[0] != self.n_chain:   # (x_0 was a pool the chains drew their starts from)
+                out['x_0'] = self._samples[:, 0]
+            self._host['adapted'] = out
+        return self._host['adapted']
+
     _samples = property(lambda self: self._array('samples'))
     _stats = property(lambda self: self._array('stats'))
     _logp_original = property(lambda self: self._array('logp_original'))

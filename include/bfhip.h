@@ -53,7 +53,10 @@ int bfhip_ctx_synchronize(bfhip_ctx *ctx);
  * (core/module.py:76-83,226), the PolyModel configs with their masks scattered to full input size
  * (modules/poly.py:466-478, modules/_poly.pyx:13-137), the linear-extrapolation bound
  * (modules/poly.py:480-503) and the decay penalty (core/density.py:740-746).
- * output_size of the surrogate is 1: the surrogate IS the log density.
+ * output_size of the surrogate is 1: the surrogate IS the log density -- or, with link_kind = 1, the input m of one
+ * downstream analytic module, a Gaussian likelihood logp = link_logp0 - link_prec (m - link_y)^2 / 2, chained as the
+ * pipeline does (core/density.py:527-560: the surrogate replaces the modules of its scope, the next module's Jacobian
+ * multiplies the surrogate's; e.g. examples/2d-donut.ipynb: m = |x|, logp = -(m - 5)^2 / 0.5).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int d;                        /* input_size, 1..BFHIP_MAX_DIM */
@@ -83,6 +86,9 @@ typedef struct {
     const double *decay_hess;     /* (d,d) */
     double decay_alpha2;
     double decay_gamma;
+    /* downstream module of the surrogate's output (see above): 0 none, 1 Gaussian likelihood */
+    int link_kind;
+    double link_y, link_prec, link_logp0;
 } bfhip_density_desc;
 
 /* Copies and re-lays-out the description into device memory (MFMA A-operand fragments). Synchronous. */

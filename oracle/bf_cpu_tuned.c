@@ -71,7 +71,7 @@ static int tuned_eval(const bfo_density *dn, const double *x, int original_space
 int bfo_tuned_prepare(const bfo_density *dn) {
     const bfo_poly_model *pm = &dn->poly;
     const int d = dn->d;
-    if (dn->ranges || dn->su_lo || dn->use_decay || !pm->use_bound || pm->n_config != 2 || d > TUNED_MAXD || g_n >= TUNED_MAX) return -1;
+    if (dn->ranges || dn->su_lo || dn->use_decay || dn->link_kind || !pm->use_bound || pm->n_config != 2 || d > TUNED_MAXD || g_n >= TUNED_MAX) return -1;
     const bfo_poly_config *cl = NULL, *cq = NULL;
     for (int c = 0; c < 2; ++c) {
         const bfo_poly_config *cf = &pm->configs[c];

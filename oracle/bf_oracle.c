@@ -405,6 +405,11 @@ void bfo_logp_and_grad(const bfo_density *dn, const double *x, int original_spac
         if (dn->su_diff) g[i] = g[i] / dn->su_diff[i];
         g[i] = g[i] * jd[i];
     }
+    if (dn->link_kind == 1) { /* the next module of the pipeline, density.py:552-560: var_dict._jac[n] = dot(J_out, J_in) */
+        double r = f - dn->link_y, dphi = -(dn->link_prec * r);
+        f = dn->link_logp0 - 0.5 * (r * (dn->link_prec * r));
+        for (int i = 0; i < d; ++i) g[i] = dphi * g[i];
+    }
     if (dn->use_decay) { /* density.py:740-746 */
         double beta2 = mahalanobis2(xo, dn->decay_mu, dn->decay_hess, d, hv);
         double ex = beta2 - dn->decay_alpha2;

@@ -51,7 +51,8 @@ class _PolyModel(C.Structure):
 class _Density(C.Structure):
     _fields_ = [('d', C.c_int), ('ranges', _dp), ('hard_bounds', _u8p), ('su_lo', _dp), ('su_diff', _dp),
                 ('poly', _PolyModel), ('use_decay', C.c_int), ('decay_mu', _dp), ('decay_hess', _dp),
-                ('decay_alpha2', C.c_double), ('decay_gamma', C.c_double)]
+                ('decay_alpha2', C.c_double), ('decay_gamma', C.c_double),
+                ('link_kind', C.c_int), ('link_y', C.c_double), ('link_prec', C.c_double), ('link_logp0', C.c_double)]
 
 
 class _Rng(C.Structure):
@@ -208,6 +209,12 @@ def density_struct(spec):
         dn.decay_hess = keep.f64(spec['decay_hess'])
         dn.decay_alpha2 = float(spec['decay_alpha2'])
         dn.decay_gamma = float(spec['decay_gamma'])
+    link = spec.get('link')
+    if link is not None:  # {'kind': 'gaussian', 'y', 'prec', 'logp0'}: logp = logp0 - prec (m - y)^2 / 2 of the surrogate's output m
+        if link['kind'] != 'gaussian':
+            raise ValueError('unknown link kind.')
+        dn.link_kind, dn.link_y, dn.link_prec = 1, float(link['y']), float(link['prec'])
+        dn.link_logp0 = float(link.get('logp0', 0.))
     return dn, keep
 
 

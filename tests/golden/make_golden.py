@@ -700,6 +700,40 @@ def gen_fit_illcond(bf, out):
     np.savez_compressed(os.path.join(out, 'fit_illcond.npz'), **z)
 
 
+def gen_recipe(bf, out):
+    """Fixture (vi) of SURVEY section 7 step 0: BASELINE config 1, the 2-d donut recipe of examples/2d-donut.ipynb (cell 4,
+    n_chain = 4) run END TO END by the reference itself (its Recipe, its NUTS on 4 worker processes, its PolyModel.fit):
+    the optimiser's log (what the notebook prints at :110-141), and per SampleStep the statistics of the ring and the
+    surrogate it sampled.  The recipe's definition lives in tests/helpers/donut.py (written against the bayesfast API)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'helpers'))
+    import donut
+    rec = donut.build_recipe(bf)
+    rec.run()
+    rt = rec.recipe_trace
+    z = {}
+    opt = rt.results.optimize
+    z['opt.logp'] = np.array([r.f_max.logp for r in opt[:-1]])
+    z['opt.logp_trans'] = np.array([r.f_max.logp_trans for r in opt[:-1]])
+    z['opt.logq_trans'] = np.array([r.f_max.logq_trans for r in opt[:-1]])
+    z['opt.x_max'] = np.array([r.x_max.x for r in opt[:-1]])
+    z['opt.chosen_logp_trans'] = np.array(opt[-1].f_max.logp_trans)
+    z['opt.ring'] = donut.ring_statistics(opt[-1].samples)
+    z['opt.x_0'] = np.array(rt._s_optimize.x_0)
+    steps = rt.results.sample
+    z['ring'] = np.array([donut.ring_statistics(r.samples) for r in steps])          # (10, 5): radius mean, sd, ...
+    z['tree_size_mean'] = np.array([np.mean([np.mean(t.stats._tree_size) for t in r.sample_trace]) for r in steps])
+    z['n_fit'] = np.array([len(r.var_dicts) for r in steps])
+    z['step0.x_fit'] = np.array([np.atleast_1d(vd._fun['x']) for vd in steps[0].var_dicts])   # the 30 points SampleStep #0 fitted on
+    z['step0.step_size'] = np.array(bf.samplers._get_step_size(opt[-1].sample_trace))
+    z['last.samples'] = np.array(steps[-1].sample_trace.get(flatten=False))          # (4, 500, 2)
+    z['last.logq'] = np.array(steps[-1].sample_trace.get(return_type='logp', flatten=False))
+    su = steps[-1].surrogate_list[0]
+    z.update(flatten_poly(poly_spec_from_reference(su), 'last.poly.'))
+    z['n_call'] = np.array(rec.get().n_call)
+    z['post.ring'] = donut.ring_statistics(rec.get().samples)
+    np.savez_compressed(os.path.join(out, 'recipe.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -709,7 +743,7 @@ def main():
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
                 density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, tempered=gen_tempered,
-                fit_illcond=gen_fit_illcond)
+                fit_illcond=gen_fit_illcond, recipe=gen_recipe)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue

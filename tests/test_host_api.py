@@ -293,3 +293,39 @@ def test_adapters_read_a_reference_density_by_duck_typing():
 
     same(a, b)
     same(c, b)
+
+
+def test_gaussian_link_in_the_oracle_and_own_refit_loop_on_the_standin(monkeypatch):
+    """The link (Gaussian likelihood of the surrogate's single output, core/density.py:527-560) in the CPU oracle against
+    the composition written out, and the package's own config-1 loop (tests/helpers/donut.py) with the oracle stand-in
+    behind the device entry points: host logic of fit(x, logp, y=...), sample(), gather(), select_fit_points, warm starts.
+    The same loop runs on the GPU in tests/test_gpu_recipe.py."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers'))
+    import donut
+    import oracle_standin
+    from oracle import oracle as orc
+    d = 3
+    rng = np.random.default_rng(0)
+    poly = dict(input_size=d, output_size=1, use_bound=False,
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.array([0]), coef=rng.normal(size=(1, d + 1))),
+                         dict(order='quadratic', input_mask=np.arange(d), output_mask=np.array([0]), coef=rng.normal(size=(1, d, d)))])
+    spec = dict(d=d, ranges=np.array([[-3., 4.]] * d), hard_bounds=np.array([[1, 1], [0, 0], [1, 0]], np.uint8), su_lo=None,
+                su_diff=None, poly=poly, use_decay=False)
+    x = rng.normal(size=(5, d))
+    m, gm = orc.logp_and_grad(spec, x, original_space=True)
+    lp, g = orc.logp_and_grad(dict(spec, link=dict(kind='gaussian', y=5., prec=4., logp0=0.)), x, original_space=True)
+    np.testing.assert_allclose(lp, -(m - 5.)**2 / 0.5, rtol=1e-14)
+    np.testing.assert_allclose(g, (-2. * (m - 5.) / 0.5)[:, None] * gm, rtol=1e-14)
+    # transformed space: the log-Jacobian is added after the link, as density.py:747-750 does
+    mt, _ = orc.logp_and_grad(spec, x, original_space=False)
+    lpt, _ = orc.logp_and_grad(dict(spec, link=dict(kind='gaussian', y=5., prec=4., logp0=0.)), x, original_space=False)
+    spec_o = dict(spec, ranges=None, hard_bounds=None)
+    assert not np.allclose(lpt, -(mt - 5.)**2 / 0.5)
+    oracle_standin.install(monkeypatch)
+    import bayesfast_amd.modules.poly as mp
+    monkeypatch.setattr(mp.PolyModel, 'fit', lambda self, x, y, logp=None, w=None: oracle_standin.oracle_fit(self, x, y, logp, w))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'recipe.npz'))
+    ring, tt = donut.own_refit_loop(z['step0.x_fit'], float(z['step0.step_size']), n_steps=8)
+    assert abs(ring[-2:, 0].mean() - 5.02) < 0.1 and abs(ring[-2:, 1].mean() - 0.49) < 0.08 and ring[-1, 2] < 0.3, ring

@@ -1,0 +1,141 @@
+"""The drop-in seam (bayesfast_amd/integrate.py) under the REFERENCE's own code.
+
+Container-only: these tests import the reference package (built from /root/reference into a scratch directory by
+tests/golden/make_golden.py's recipe) and are skipped wherever it does not exist -- the reference never travels to the GPU
+box.  There is no GPU here either, so the device entry points (DeviceChains, DeviceDensity, the device fit) are swapped, IN
+THESE TESTS ONLY, for stand-ins backed by the CPU oracle (tests/helpers/oracle_standin.py); everything else -- the seam's
+subclasses, adapters, trace conversion, sample(), TraceTuple -- is the shipped code, driven by the reference's Recipe,
+Density, _get_step_size and _get_metric.  The GPU side of the same workload is tests/test_gpu_recipe.py."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'helpers'))
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'bayesfast')), reason='needs the reference at /root/reference')
+
+
+@pytest.fixture(scope='module')
+def bf():
+    import make_golden
+    return make_golden.prepare_reference(REF, os.environ.get('BF_REF_WORK', '/tmp/bfref'))
+
+
+@pytest.fixture()
+def seam(bf, monkeypatch):
+    import oracle_standin
+    from bayesfast_amd import integrate
+    oracle_standin.install(monkeypatch)
+    unpatch = integrate.patch(bf)
+    yield integrate.reference_classes(bf)
+    unpatch()
+
+
+def test_subclasses_pass_the_reference_isinstance_gates(bf, seam):
+    """core/recipe.py:52-61 (steps), core/density.py:306-310 (Density.surrogate_list), deepcopy / dill (core/recipe.py:822,1163)."""
+    import dill
+    pm = seam.PolyModel('quadratic', input_size=3, output_size=1, input_vars='x', output_vars='y')
+    assert isinstance(pm, bf.core.module.Surrogate) and isinstance(pm, bf.modules.PolyModel)
+    assert bf.modules.PolyModel is seam.PolyModel and bf.core.recipe.sample is not None  # patched names
+    step = bf.recipe.SampleStep(surrogate_list=pm, alpha_n=2)           # raises ValueError for anything that is not a Surrogate
+    assert step.n_eval == 2 * pm.n_param
+    like = seam.GaussianLikelihood(1., 2., input_vars='y', output_vars='logp')
+    assert isinstance(like, bf.core.module.Module)
+    den = bf.Density(module_list=[bf.Module(fun=lambda x: np.sum(x**2, -1, keepdims=True), input_vars='x', output_vars='y'), like],
+                     input_shapes=[3], input_vars='x', density_name='logp')
+    den.surrogate_list = pm                                             # raises ValueError likewise
+    # the likelihood module is the analytic function it claims to be
+    np.testing.assert_allclose(den.logp(np.array([1., 2., 2.]), use_surrogate=False), -0.5 * 2. * (9. - 1.)**2)
+    for clone in (copy.deepcopy(pm), dill.loads(dill.dumps(pm))):
+        assert isinstance(clone, bf.core.module.Surrogate) and clone.n_param == pm.n_param
+    with pytest.raises(ValueError):
+        bf.recipe.SampleStep(surrogate_list=[object()])
+
+
+def test_polymodel_fit_on_the_seam_equals_the_reference_fit(bf, seam):
+    """seam.PolyModel.fit (coefficients from the fit behind integrate._device_fit, bound statistics by the reference's own
+    _set_bound) against the reference class's fit on the same data: same coefficients, bound, evaluation."""
+    ref_cls = [c for c in seam.PolyModel.__mro__ if c.__module__.endswith('modules.poly') and c is not seam.PolyModel][0]
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(60, 3))
+    y = (x[:, 0] * x[:, 1] - 0.3 * x[:, 2]**2 + x[:, 0] + 0.01 * rng.normal(size=60))[:, None]
+    a = seam.PolyModel('quadratic', input_size=3, output_size=1)
+    b = ref_cls('quadratic', input_size=3, output_size=1)
+    a.fit(x, y, y[:, 0])
+    b.fit(x, y, y[:, 0])
+    iu = np.triu_indices(3)
+    np.testing.assert_allclose(a.configs[0]._coef, b.configs[0]._coef, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(a.configs[1]._coef[0][iu], b.configs[1]._coef[0][iu], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose([a._alpha, a._f_mu[0]], [b._alpha, b._f_mu[0]], rtol=1e-9)
+    for xt in (0.1 * np.ones(3), 30. * np.ones(3)):   # inside / outside the bound
+        fa, ja = a.fun_and_jac(xt)
+        fb, jb = b.fun_and_jac(xt)
+        np.testing.assert_allclose(fa[0], fb[0], rtol=1e-9)
+        np.testing.assert_allclose(ja[0], jb[0], rtol=1e-8, atol=1e-10)
+
+
+def test_reference_recipe_runs_config1_on_the_seam(bf, seam):
+    """BASELINE config 1: the reference's Recipe.run() -- OptimizeStep with its sampling, ten SampleSteps, PostStep -- with
+    the seam's PolyModel / GaussianLikelihood in its Density and the seam's sample() behind core/recipe.py:979-981,1160-1173.
+    It must reach `finished`, print the optimiser trace of examples/2d-donut.ipynb:110-111, and land on the ring the
+    reference's own run lands on (tests/golden/recipe.npz, fixture vi), within the T2 bounds of SURVEY section 8c."""
+    import donut
+    z = np.load(os.path.join(HERE, 'golden', 'recipe.npz'))
+    rec = donut.build_recipe(bf, poly_model=seam.PolyModel,
+                             likelihood=seam.GaussianLikelihood(donut.A, 2. / donut.B, input_vars='m', output_vars='logp'))
+    rec.run()
+    rt = rec.recipe_trace
+    assert tuple(rt.finished) == (True, True, True)
+    opt = rt.results.optimize
+    # the optimiser's log is deterministic given the fit (Laplace + the reference's Sobol points): equal to the fixture's
+    np.testing.assert_allclose([r.f_max.logp_trans for r in opt[:-1]], z['opt.logp_trans'], rtol=1e-6)
+    np.testing.assert_allclose([r.f_max.logq_trans for r in opt[:-1]], z['opt.logq_trans'], rtol=1e-6)
+    assert abs(z['opt.logp'][0] - (-1.870)) < 5e-4 and abs(z['opt.logp'][1] - (-1.497)) < 5e-4   # the notebook's printed lines
+    steps = rt.results.sample
+    assert len(steps) == 10
+    ring = np.array([donut.ring_statistics(r.samples) for r in steps])
+    # every step's result is a reference TraceTuple of reference NTraces, accepted by the reference's warm-start helpers
+    tt = steps[-1].sample_trace
+    assert isinstance(tt, bf.samplers.TraceTuple) and all(isinstance(t, bf.samplers.NTrace) for t in tt)
+    ss = bf.samplers._get_step_size(tt)
+    assert 0.01 < ss < 2.
+    m = bf.samplers._get_metric(tt, 'diag')
+    assert m.shape == (2,) and np.all(m > 1.)
+    assert bf.samplers._get_metric(tt, 'full', from_samples=False).shape == (2, 2)
+    assert tt.n_call == sum(t.n_call for t in tt)
+    # T2: the ring of the last four steps against the reference's last four (radius 5.02 +- 0.49 there)
+    want, got = z['ring'][-4:], ring[-4:]
+    assert abs(got[:, 0].mean() - want[:, 0].mean()) < 0.06, (got[:, 0], want[:, 0])
+    assert abs(got[:, 1].mean() - want[:, 1].mean()) < 0.05, (got[:, 1], want[:, 1])
+    assert got[:, 2].max() < 0.15            # the whole ring is covered (mean resultant length of the angle)
+    # ... and the progress towards it: the first step sits on the arc the optimiser found, as the reference's does
+    assert abs(ring[0, 0] - z['ring'][0, 0]) < 0.15 and ring[0, 2] > 0.95
+    res = rec.get()
+    assert res.samples.shape == (2000, 2) and res.n_call == int(z['n_call'])
+
+
+def test_sample_on_the_seam_takes_reference_traces_and_continues(bf, seam):
+    """integrate.sample: dict / NTrace in, reference TraceTuple out; a second call with that tuple continues the chains
+    (core/sample.py:94-96); what the device path does not cover is refused, or left to the reference with fallback=True."""
+    from bayesfast_amd import integrate
+    pm = seam.PolyModel('quadratic', input_size=2, output_size=1, input_vars='x', output_vars='logp')
+    den = bf.Density(module_list=[bf.Module(fun=lambda x: -0.5 * np.sum(x**2, -1, keepdims=True), input_vars='x', output_vars='logp')],
+                     input_shapes=[2], input_vars='x', density_name='logp', surrogate_list=pm)
+    x = np.random.default_rng(1).normal(size=(40, 2)) * 2.
+    pm.fit(x, -0.5 * np.sum(x**2, -1, keepdims=True), -0.5 * np.sum(x**2, -1))
+    den.use_surrogate = True
+    trace = bf.samplers.NTrace(n_chain=3, n_iter=80, n_warmup=50, random_generator=4)
+    tt = bf.sample(den, trace, n_run=60, verbose=False)          # bf.sample is the patched entry point
+    assert isinstance(tt, bf.samplers.TraceTuple) and tt.i_iter == 60 and not tt.finished
+    tt2 = bf.sample(den, tt, verbose=False)
+    assert tt2.i_iter == 80 and tt2.finished
+    assert np.array_equal(tt2.samples[:, :60], tt.samples)
+    assert tt2.get().shape == (3 * 30, 2) and tt2.get(return_type='logp', flatten=False).shape == (3, 30)
+    assert np.isfinite(bf.samplers._get_step_size(tt2))
+    den.use_surrogate = False
+    with pytest.raises(NotImplementedError):
+        integrate.sample(den, {'n_chain': 2, 'n_iter': 20, 'n_warmup': 10})
