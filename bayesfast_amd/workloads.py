@@ -4,7 +4,8 @@ Only NumPy: these build the density *spec* (plain dict) that both the device pat
 """
 import numpy as np
 
-__all__ = ['correlated_gaussian_spec', 'banana_logp', 'sobol_normal', 'B_STEP_BYTES', 'flops_per_leapfrog']
+__all__ = ['correlated_gaussian_spec', 'banana_logp', 'funnel_logp', 'planck_like_logp', 'sobol_normal', 'B_STEP_BYTES',
+           'flops_per_leapfrog', 'flops_per_leapfrog_spec']
 
 
 def B_STEP_BYTES(d):
@@ -76,6 +77,61 @@ def banana_logp(d=64, q=0.01, seed=0):
         return -np.sum((z[..., ::2]**2 - z[..., 1::2])**2 / q + (z[..., ::2] - 1)**2, axis=-1)
 
     return logp
+
+
+def funnel_logp(d=64, a=1., b=0.5):
+    """Config 4 target of SURVEY.md section 8(d): the funnel of examples/funnel-gbs.ipynb cell 3 (a = 1, b = 0.5, D = d)."""
+    def logp(x):
+        x = np.asarray(x, dtype=np.float64)
+        return (-x[..., 0]**2 / (2 * a**2) - np.sum(x[..., 1:]**2, axis=-1) / (2 * np.exp(2 * b * x[..., 0])) -
+                (d - 1) * b * x[..., 0])
+
+    return logp
+
+
+def planck_like_logp(d=128, seed=18, n_cubic=16, amp=0.02):
+    """Config 5 target of SURVEY.md section 8(d) (the reference has no Planck likelihood; examples/planck_18_sterile.ipynb is a
+    stub): N(0, Sigma) with cond(Sigma) = 1e4 (log-uniform spectrum, random rotation, RandomState(seed)) plus a cubic
+    perturbation -- cubic-2 and cubic-3 ("cubic-cross") terms -- on the first n_cubic coordinates.  Returns
+    (logp(x (..., d)) -> (...), chol) with chol chol^T = Sigma (to draw fit points from the Gaussian part)."""
+    from scipy.stats import special_ortho_group
+    rs = np.random.RandomState(seed)
+    R = special_ortho_group.rvs(d, random_state=rs)
+    lam = np.exp(np.linspace(0., np.log(1e4), d))
+    prec = (R * (1. / lam)) @ R.T
+    c2 = rs.normal(size=(n_cubic, n_cubic)) * amp
+    c3 = rs.normal(size=(n_cubic,) * 3) * amp
+    j, k, l = np.meshgrid(*[np.arange(n_cubic)] * 3, indexing='ij')
+    c3 = np.where((j < k) & (k < l), c3, 0.)
+
+    def logp(x):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        z = x[:, :n_cubic]
+        cub = np.einsum('ni,ij,nj->n', z**2, c2, z) + np.einsum('jkl,nj,nk,nl->n', c3, z, z, z, optimize=True)
+        return -0.5 * np.einsum('ni,ij,nj->n', x, prec, x) + cub
+
+    return logp, np.linalg.cholesky((R * lam) @ R.T)
+
+
+def flops_per_leapfrog_spec(spec):
+    """Algorithmic flops of one leapfrog step on a density spec: one d x d matvec (2 d^2) each for S x, the bound's
+    H (x - mu) and the decay term's H_d (x - mu_d), plus the cubic configs' contractions on their masked inputs
+    (cubic-2: two n2 x n2 matvecs; cubic-3: one n3^3 contraction); the O(d) tail is ignored."""
+    d = int(spec['d'])
+    poly = spec['poly']
+    orders = {c['order']: np.asarray(c['input_mask']).size for c in poly['configs']}
+    f = 0
+    if 'quadratic' in orders:
+        f += 2 * d * d
+    if poly.get('use_bound') and len(orders) > (1 if 'linear' in orders else 0):
+        f += 2 * d * d
+    if spec.get('use_decay'):
+        f += 2 * d * d
+    if 'cubic-2' in orders:
+        f += 4 * orders['cubic-2']**2
+    if 'cubic-3' in orders:
+        f += 2 * orders['cubic-3']**3
+    return f
 
 
 def sobol_normal(n, d, seed=0):

@@ -186,6 +186,155 @@ def fit_timing(d, cov, seed=7):
             'note': 'host arrays in, coefficients out: upload, design blocks, split-K MFMA Gram, blocked Cholesky solve, bound statistics'}
 
 
+def _cpu_rate(spec, x0, n_adapt, seed, target_accept, target_seconds):
+    """The CPU port on the same density: the oracle's NUTS driver, one chain per OpenMP thread, post-adaptation, bounded."""
+    from oracle import oracle as orc
+    n_thr = orc.max_threads()
+    n_chain = min(2 * n_thr, x0.shape[0])
+    cs = orc.ChainSet(spec, x0[:n_chain], seed, target_accept=target_accept)
+    t0 = time.perf_counter()
+    cs.run(n_adapt, n_adapt, n_threads=n_thr)
+    t_adapt = time.perf_counter() - t0
+    nl, dt, n_it = 0, 0., 0
+    while dt < target_seconds:
+        t0 = time.perf_counter()
+        _, _, k = cs.run(25, n_adapt, n_threads=n_thr)
+        dt += time.perf_counter() - t0
+        nl += k
+        n_it += 25
+    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': physical_cores(n_thr), 'threads': n_thr, 'kind': 'port',
+            'sample': '%d chains x %d post-adaptation NUTS iterations (%d leapfrogs in %.1f s; adaptation %d iterations, %.1f s, '
+                      'untimed) of the same density, one chain per OpenMP thread' % (n_chain, n_it, nl, dt, n_adapt, t_adapt)}
+
+
+def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu_seconds, what, first_stream=0):
+    """Adapt n_adapt NUTS iterations on the device, then time `steps` launches of `iters` iterations (HIP events on the
+    launch stream).  Returns (block dict, samples (C, iters, d), stats) of the last launch."""
+    import torch
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import B_STEP_BYTES, flops_per_leapfrog_spec
+    from bayesfast_amd import _lib
+    dd = den.device(ctx)
+    C, d = x0.shape
+    ch = DeviceChains(dd, x0, seed=seed, first_stream=first_stream)
+    kw = dict(n_warmup=n_adapt, check=False, target_accept=target_accept)
+    ch.run(n_adapt, 'NUTS', **kw)
+    s = ctx.empty((C, iters, d))
+    st = ctx.empty((C, iters, _lib.STAT_STRIDE))
+    ch.run(iters, 'NUTS', samples=s, stats=st, **kw)   # one untimed post-adaptation launch
+    ch.raise_on_error()
+    lf0 = ch.total_leapfrog
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(ctx.stream)
+    for _ in range(steps):
+        ch.run(iters, 'NUTS', samples=s, stats=st, **kw)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    ch.raise_on_error()
+    ms = e0.elapsed_time(e1)
+    n_lf = ch.total_leapfrog - lf0
+    kname = _lib.lib().bfhip_debug_last_kernel
+    kname.restype = __import__('ctypes').c_char_p
+    stn = st.cpu().numpy()
+    ts = stn[:, :, _lib.NSTATS.index('tree_size')]
+    spec = den.spec()
+    fl = flops_per_leapfrog_spec(spec)
+    ach = n_lf * fl / (ms * 1e-3) / 1e12
+    out = {'workload': what, 'value': n_lf / (ms * 1e-3), 'unit': 'leapfrog steps/sec', 'chains': int(C), 'dim': int(d),
+           'nuts_iterations_timed': steps * iters, 'nuts_adaptation_iterations': n_adapt, 'ms_per_launch': ms / steps,
+           'target_accept': target_accept, 'mean_tree_size': float(ts.mean()), 'max_tree_depth': int(stn[:, :, _lib.NSTATS.index('tree_depth')].max()),
+           'divergence_rate': float(stn[:, :, _lib.NSTATS.index('diverging')].mean()),
+           'mean_accept': float(stn[:, :, _lib.NSTATS.index('mean_tree_accept')].mean()), 'chain_layout': ch.last_layout,
+           'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': ach / 78.6, 'traffic': None,
+                        'kernel': kname().decode(), 'kernel_ms_per_launch': ms / steps, 'flops_per_leapfrog': fl},
+           'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9, 'peak': 8000.,
+                                        'unit': 'GB/s', 'frac': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9 / 8000.}}
+    if cpu_seconds > 0:
+        try:
+            out['cpu_baseline'] = _cpu_rate(spec, x0, n_adapt, seed, target_accept, cpu_seconds)
+        except Exception as ex:
+            out['cpu_baseline'] = {'error': repr(ex)}
+    return out, s, st
+
+
+def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=100, steps=2, n_adapt=300):
+    """The BASELINE configs' own targets, one GPU's shard each, through the package API: fit the surrogate
+    on 2 P points of the true model, adapt, time post-adaptation launches.
+      banana_decay : config 3 -- 64-d rotated banana, quadratic surrogate (P = 2145) WITH the decay term the reference's
+                     recipe uses for such targets (core/density.py:740-746), 4096 chains, and ONE refit cycle (2 P of the
+                     first round's samples by their logq, true logp, refit, sample again); both rounds reported
+      funnel       : config 4's shard -- 64-d funnel, target_accept 0.95, 4096 chains, decay on
+      cubic128     : config 5's shard -- d = 128, linear + quadratic + cubic-2 + cubic-3 on 16 inputs (P = 9201), 1024 chains"""
+    import torch
+    import bayesfast_amd as bfa
+    from bayesfast_amd.workloads import banana_logp, funnel_logp, planck_like_logp
+    from bayesfast_amd.core.refit import select_fit_points
+    rng = np.random.default_rng(seed)
+    t_fit = {}
+
+    def fit(den, x, lp, key):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        den.fit(x, lp)
+        torch.cuda.synchronize()
+        t_fit[key] = (time.perf_counter() - t0) * 1e3
+
+    if name == 'banana_decay':
+        d, C = 64, chains or 4096
+        logp = banana_logp(d)
+        su = bfa.PolyModel('quadratic', input_size=d, output_size=1)
+        den = bfa.SurrogateDensity(su, decay_options=dict(use_decay=True))
+        x_fit = rng.normal(size=(2 * su.n_param, d))
+        fit(den, x_fit, logp(x_fit), 'fit_0_ms')
+        x0 = x_fit[rng.integers(0, x_fit.shape[0], C)] * 0.5
+        what = ('config 3: %d chains x 64-d rotated banana (Q = 0.01), quadratic surrogate P = %d fitted on 2 P N(0, I) points, '
+                'bound and decay on; round %%d' % (C, su.n_param))
+        r0, s, st = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what % 0)
+        # one refit cycle (core/recipe.py:1074-1155 without the cut-off): 2 P of round 0's samples by their logq
+        xs, lq = s.reshape(-1, d).cpu().numpy(), st[:, :, 0].reshape(-1).cpu().numpy()
+        ok = np.isfinite(lq) & np.all(np.isfinite(xs), axis=1)
+        t0 = time.perf_counter()
+        x_new, lp_new, _ = select_fit_points(xs[ok], lq[ok], logp, 2 * su.n_param, logp_cutoff=False)
+        t_sel = (time.perf_counter() - t0) * 1e3
+        fit(den, x_new, lp_new, 'fit_1_ms')
+        x0b = x_new[rng.integers(0, x_new.shape[0], C)]
+        r1, _, _ = _sampler_block(ctx, den, x0b, seed + 1, 0.8, n_adapt, iters, steps, 0., what % 1)
+        return dict(r0, round_1={k: r1[k] for k in ('value', 'ms_per_launch', 'mean_tree_size', 'max_tree_depth', 'divergence_rate',
+                                                    'mean_accept', 'chain_layout', 'roofline')},
+                    refit={'select_and_true_logp_ms': t_sel, **t_fit, 'n_fit_points': int(x_new.shape[0])})
+    if name == 'funnel':
+        d, C = 64, chains or 4096
+        logp = funnel_logp(d)
+        su = bfa.PolyModel('quadratic', input_size=d, output_size=1)
+        den = bfa.SurrogateDensity(su, decay_options=dict(use_decay=True))
+        x_fit = rng.normal(size=(2 * su.n_param, d))
+        fit(den, x_fit, logp(x_fit), 'fit_ms')
+        x0 = x_fit[rng.integers(0, x_fit.shape[0], C)] * 0.5
+        what = ('config 4 (one GPU of 8): %d chains x 64-d funnel (a = 1, b = 0.5), quadratic surrogate P = %d fitted on 2 P N(0, I) '
+                'points, bound and decay on, target_accept 0.95' % (C, su.n_param))
+        r, _, _ = _sampler_block(ctx, den, x0, seed, 0.95, n_adapt, iters, steps, cpu_seconds, what)
+        return dict(r, **t_fit)
+    if name == 'cubic128':
+        d, C = 128, chains or 1024
+        logp, chol = planck_like_logp(d)
+        m16 = np.arange(16)
+        su = bfa.PolyModel([bfa.PolyConfig('linear'), bfa.PolyConfig('quadratic'), bfa.PolyConfig('cubic-2', input_mask=m16),
+                            bfa.PolyConfig('cubic-3', input_mask=m16)], input_size=d, output_size=1)
+        den = bfa.SurrogateDensity(su)
+        x_fit = rng.normal(size=(2 * su.n_param, d)) @ chol.T
+        fit(den, x_fit, logp(x_fit), 'fit_ms')
+        x0 = x_fit[rng.integers(0, x_fit.shape[0], C)] * 0.5
+        what = ('config 5 (one GPU of 8): %d chains x 128-d Planck-18-like synthetic logp (cond 1e4 Gaussian + cubic terms on 16 '
+                'inputs), cubic-cross PolyModel P = %d fitted on 2 P points, bound on' % (C, su.n_param))
+        r, _, _ = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what)
+        return dict(r, **t_fit)
+    raise ValueError(name)
+
+
+CONFIG_BLOCKS = ('banana_decay', 'funnel', 'cubic128')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -199,7 +348,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fit', action='store_true', help='skip the (untimed, separately reported) surrogate fit')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary figures (hetero workload, refit cycle)')
+    ap.add_argument('--no-configs', action='store_true', help="skip the blocks on the BASELINE configs' own targets (config3/4/5)")
+    ap.add_argument('--workload', default=None, choices=CONFIG_BLOCKS,
+                    help='run ONE config block only and print it (profiling: rocprofv3 -- python3 bench.py --workload funnel)')
     a = ap.parse_args()
+    if a.no_extras:
+        a.no_configs = True
 
     import torch
     from bayesfast_amd.device import DeviceContext, DeviceDensity
@@ -226,6 +380,12 @@ def main():
     d, C = a.dim, a.chains
     spec, cov = correlated_gaussian_spec(d)
     ctx = DeviceContext(dev_index)
+    if a.workload:  # one config block on its own (the profiles of profiles/r03_config{3,4,5}.json come from these commands)
+        with torch.cuda.device(ctx.device):
+            blk = config_block(a.workload, ctx, a.seed, cpu_seconds=0. if a.no_cpu_baseline else 4.,
+                               chains=None if a.chains == 4096 else a.chains)
+        print(json.dumps({'config_block': a.workload, **blk}))
+        return
     with torch.cuda.device(ctx.device):
         dens = DeviceDensity(spec, ctx)
         # chain starts: N(0, I) rows (core/sample.py:111-112), one global array sliced per rank
@@ -343,6 +503,13 @@ def main():
                     out['refit_cycle'] = refit_cycle(d, cov, C, a.seed)
             except Exception as ex:  # side measurements; the headline line must still print
                 out['extras_error'] = repr(ex)
+        if not a.no_configs and world == 1:
+            for name, key in zip(CONFIG_BLOCKS, ('config3', 'config4', 'config5')):
+                try:
+                    with torch.cuda.device(ctx.device):
+                        out[key] = config_block(name, ctx, a.seed, cpu_seconds=0. if a.no_cpu_baseline else 4.)
+                except Exception as ex:  # side measurements; the headline line must still print
+                    out[key] = {'error': repr(ex)}
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, d, n_warm_iter, a.seed)
         elif not a.no_cpu_baseline:

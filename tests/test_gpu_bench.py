@@ -20,7 +20,7 @@ def _line(out):
 
 
 def test_bench_single_gpu_line():
-    r = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '2', '--chains', '512', '--no-cpu-baseline'],
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '2', '--warmup', '2', '--chains', '512', '--no-cpu-baseline', '--no-configs'],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
@@ -42,3 +42,19 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     j = _line(r.stdout)
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
     assert j['config']['chains_per_gpu'] == 256
+
+
+@pytest.mark.parametrize('name', ['banana_decay', 'funnel', 'cubic128'])
+def test_bench_config_blocks(name):
+    """The blocks on the BASELINE configs' own targets (bench.py: config_block), at a reduced chain count: each prints its
+    rate, tree statistics, divergence rate and its own roofline."""
+    r = subprocess.run([sys.executable, 'bench.py', '--workload', name, '--chains', '128', '--no-cpu-baseline'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j['config_block'] == name and j['value'] > 0 and j['chains'] == 128
+    for k in ('mean_tree_size', 'divergence_rate', 'roofline', 'workload', 'ms_per_launch'):
+        assert k in j, k
+    assert 0. <= j['divergence_rate'] <= 1. and j['roofline']['frac'] > 0
+    if name == 'banana_decay':
+        assert 'round_1' in j and j['refit']['n_fit_points'] == 4290
