@@ -10,11 +10,11 @@ Two forms of the selection:
 * device-resident and sharded (``select_fit_points`` on a ``TraceTuple``; ``select_rows_sharded``): every rank keeps
   only its own chains' samples on its GPU.  The resampler needs n order statistics of the logq of ALL chains
   (``np.argsort(logq)[ranks]``, utils/misc.py:108).  They are found without moving the samples: each rank sorts its
-  shard once (``bfhip_sort_keys``), the ranks bisect together on the 64-bit order-preserving keys -- per step one
-  ``bfhip_count_keys`` on the local shard and one all-reduce of n counters -- ties are assigned in global index order
-  from an all-gather of per-rank tie counts, and only the n selected rows cross the links, as one all-reduce of an
-  (n, d + 1) array in which every row has exactly one non-zero contributor (SURVEY section 8e option ii: 2.3 MB at
-  n = 4290, d = 64, instead of the 25 GB of all samples).  The result is bit-identical to the single-rank selection.
+  shard once (``bfhip_sort_keys``); the ranks exchange local quantile keys (all-gather), count their shards against all
+  of them (``bfhip_count_keys``, one all-reduce), exchange the few candidates each requested rank is then pinned to
+  (all-gather; ties in global index order from per-rank counts), and only the n selected rows cross the links, as one
+  all-reduce of an (n, d + 1) array in which every row has exactly one non-zero contributor (SURVEY section 8e option
+  ii): four collectives, no host synchronisation in between.  The result is bit-identical to the single-rank selection.
 """
 import warnings
 
@@ -67,71 +67,127 @@ def _device_count(keys_sorted_signed, q_signed, upper):
     return out
 
 
-def select_rows_sharded(local_values, local_rows, ranks, sort_fn=None, count_fn=None, stats=None):
+def select_rows_sharded(local_values, local_rows, ranks, sort_fn=None, count_fn=None, stats=None, n_splitter=None, n_loc_max=None):
     """Rows of the globally ``ranks``-th smallest values (stable order: value, then global index = rank-major position).
 
     local_values (n_loc,) float64 and local_rows (n_loc, k) float64: this rank's shard, in global index order across
     ranks; ranks (n,) int64 global 0-based ranks, identical on every rank.  Returns (rows (n, k), values (n,)) identical
     on every rank.  ``sort_fn`` / ``count_fn`` default to the device kernels (the CPU tests inject torch stand-ins to
-    exercise the collective logic under gloo).  ``stats``, if a dict, receives the bytes this rank put on the wire."""
+    exercise the collective logic under gloo).  ``stats``, if a dict, receives the bytes this rank put on the wire and the
+    number of collectives.
+
+    A splitter exchange, FOUR collectives whatever the sizes, nothing in between waits for the host:
+      1. all-gather of S local quantile keys per rank (positions spread evenly over the rank's sorted shard, ends included);
+      2. all-reduce of the global counts #{keys < b}, #{keys <= b} for every gathered key b.  Between two neighbouring
+         boundaries a rank holds fewer elements than its own splitter spacing g (none of its splitters falls inside), so a
+         requested rank r is now pinned to an interval with at most g candidates per rank -- or to a boundary value itself;
+      3. all-gather of those candidates, (n, g) keys per rank, with the per-rank counts of the boundary (ties in global
+         index order are assigned from them);
+      4. all-reduce of the (n, k + 1) selected rows, every row contributed by its one owner.
+    ``n_loc_max``: the row count of the largest shard (``_resampled_rows`` knows it); without it, it is read from the first
+    gather's header (one small device-to-host read).  S defaults to the value that minimises the bytes,
+    sqrt(n * n_loc_max / 2): at the headline (n = 4290, 4.1 M rows per rank,
+    8 ranks) 94 k splitters, 6 + 12 + 1.5 + 2.2 MB per rank instead of the 25 GB of all samples, and 4 collectives
+    instead of the 68 of a bisection over the 64-bit key space."""
     import torch
-    import torch.distributed as dist
     sort_fn = sort_fn or device_sort
     count_fn = count_fn or _device_count
     rank, ws = parallel.world()
     dev = local_values.device
-    ranks = torch.as_tensor(np.asarray(ranks, dtype=np.int64), device=dev)
+    ranks_host = np.asarray(ranks.cpu() if hasattr(ranks, 'cpu') else ranks, dtype=np.int64)
+    ranks = torch.as_tensor(ranks_host, device=dev)
     n = ranks.shape[0]
     keys, order = sort_fn(local_values)
-    wire = 0
     if ws == 1:
         idx = order[ranks]
         if stats is not None:
             stats['wire_bytes'] = 0
+            stats['collectives'] = 0
         return local_rows[idx], local_values[idx]
+    wire, n_coll = 0, 0
+    n_loc = int(keys.shape[0])
+    i64max = 2**63 - 1
+
+    def gather(t):
+        nonlocal wire, n_coll
+        wire += t.numel() * t.element_size() * ws
+        n_coll += 1
+        return parallel.all_gather_stack(t)
 
     def allsum(t):
-        nonlocal wire
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        nonlocal wire, n_coll
         wire += t.numel() * t.element_size()
-        return t
+        n_coll += 1
+        return parallel.all_reduce_sum(t)
 
-    # 1. the key of every requested rank: smallest K with #{keys <= K} >= rank + 1, by bisection on the int64 key space
-    lo = torch.full((n,), -2**63, dtype=torch.int64, device=dev)
-    hi = torch.full((n,), 2**63 - 1, dtype=torch.int64, device=dev)
-    for _ in range(64):
-        mid = (lo & hi) + ((lo ^ hi) >> 1)  # floor((lo + hi) / 2) without overflow
-        cnt = allsum(count_fn(keys, mid, True))
-        ok = cnt >= ranks + 1
-        hi = torch.where(ok, mid, hi)
-        lo = torch.where(ok, lo, mid + 1)
-    key = lo
-    # 2. ties: the element is number t = rank - #{keys < K} among the elements equal to K, counted in global index order
-    c_lt_loc = count_fn(keys, key, False)
-    c_le_loc = count_fn(keys, key, True)
-    t = ranks - allsum(c_lt_loc.clone())
-    ties = [torch.empty_like(c_lt_loc) for _ in range(ws)]
-    dist.all_gather(ties, (c_le_loc - c_lt_loc).contiguous())
-    wire += n * 8 * ws
-    before = torch.zeros_like(t)
-    mine = torch.zeros_like(t, dtype=torch.bool)
-    off = torch.zeros_like(t)
-    for r in range(ws):
-        owns = (t >= before) & (t < before + ties[r])
-        if r == rank:
-            mine, off = owns, t - before
-        before = before + ties[r]
-    # 3. only the selected rows travel: every row has exactly one owner, the others add zeros
+    # 1. splitters.  S and the candidate width g must be the same on every rank without asking: S is a pure function of
+    # (n, n_loc_max), g the splitter spacing of the largest shard
+    if n_loc_max is None:
+        n_loc_max = -(-(int(np.max(ranks_host)) + 1) // ws) if n > 0 else 1   # (sizes all ranks can derive: ceil(n_total' / ws))
+        exact_sizes = False
+    else:
+        exact_sizes = True
+    S = int(n_splitter) if n_splitter is not None else int(max(64, min(2**20, round((max(n, 1) * max(n_loc_max, 1) / 2.)**0.5))))
+    if n_loc > 0:
+        pos = torch.div(torch.arange(S, device=dev, dtype=torch.int64) * (n_loc - 1), max(S - 1, 1), rounding_mode='floor')
+        spl = keys[pos]
+    else:
+        spl = torch.full((S,), i64max, dtype=torch.int64, device=dev)
+    got = gather(torch.cat([torch.tensor([n_loc], dtype=torch.int64, device=dev), spl]))
+    if not exact_sizes:   # (the caller did not say how large the largest shard is: read it from the gathered header)
+        n_loc_max = int(got[:, 0].max())
+    g = -(-max(int(n_loc_max) - 1, 0) // max(S - 1, 1)) + 1   # more than any rank holds between two of its own splitters
+    B = torch.sort(got[:, 1:].reshape(-1)).values             # (ws * S,) boundaries, ascending (duplicates are harmless)
+    # 2. global counts below / up to every boundary
+    c_lt_loc, c_le_loc = count_fn(keys, B, False), count_fn(keys, B, True)
+    cnt = allsum(torch.stack([c_lt_loc, c_le_loc]))
+    cnt_lt, cnt_le = cnt[0], cnt[1]
+    # the interval of every requested rank: first boundary j with #{keys <= B_j} >= r + 1
+    j = torch.searchsorted(cnt_le, ranks + 1, right=False).clamp_(max=B.shape[0] - 1)
+    jm = (j - 1).clamp_(min=0)
+    base = torch.where(j > 0, cnt_le[jm], torch.zeros_like(ranks))          # #{keys <= B_{j-1}}
+    lo_loc = torch.where(j > 0, c_le_loc[jm], torch.zeros_like(ranks))      # my candidates: sorted positions [lo_loc, hi_loc)
+    hi_loc = c_lt_loc[j]
+    in_open = ranks < cnt_lt[j]                                              # else the element equals B_j (a tie run)
+    # 3. candidates of the open intervals + my count of elements equal to the boundary
+    ar = torch.arange(g, device=dev, dtype=torch.int64)
+    cpos = lo_loc[:, None] + ar[None, :]
+    valid = cpos < hi_loc[:, None]
+    ckey = torch.where(valid, keys[cpos.clamp(max=max(n_loc - 1, 0))] if n_loc > 0 else torch.full_like(cpos, i64max),
+                       torch.full_like(cpos, i64max))
+    payload = torch.cat([ckey, valid.to(torch.int64).sum(1, keepdim=True), (c_le_loc[j] - c_lt_loc[j])[:, None]], 1)
+    allp = gather(payload)                                                   # (ws, n, g + 2)
+    ck = allp[:, :, :g].permute(1, 0, 2).reshape(n, ws * g)                  # rank-major, then local order: global index order
+    ntie = allp[:, :, g + 1]                                                 # (ws, n) elements equal to B_j per rank
+    # open interval: the t-th smallest candidate in (key, rank, local position) order.  Valid candidates lie strictly below
+    # B_j, hence below the int64-max padding, and a stable sort keeps equal keys in global index order
+    t_open = (ranks - base).clamp_(min=0, max=ws * g - 1)
+    pick = torch.gather(torch.sort(ck, dim=1, stable=True).indices, 1, t_open[:, None]).reshape(-1)
+    own_open, idx_open = torch.div(pick, g, rounding_mode='floor'), pick % g
+    # tie run: element number t_tie among the elements equal to B_j, in rank-major order
+    t_tie = (ranks - cnt_lt[j]).clamp_(min=0)
+    cum = torch.cumsum(ntie, 0)                                              # (ws, n)
+    own_tie = (cum <= t_tie[None, :]).sum(0).clamp_(max=ws - 1)
+    before = torch.where(own_tie > 0, torch.gather(cum, 0, (own_tie - 1).clamp(min=0)[None, :]).reshape(-1), torch.zeros_like(t_tie))
+    owner = torch.where(in_open, own_open, own_tie)
+    mypos = torch.where(in_open, lo_loc + idx_open, c_lt_loc[j] + (t_tie - before))
+    mine = owner == rank
+    # 4. only the selected rows travel: every row has exactly one owner, the others add zeros (no host round trip)
     k = local_rows.shape[1]
-    out = torch.zeros((n, k + 1), dtype=torch.float64, device=dev)
-    sel = mine.nonzero().reshape(-1)
-    if sel.numel():
-        idx = order[(c_lt_loc + off)[sel]]
-        out[sel, :k] = local_rows[idx]
-        out[sel, k] = local_values[idx]
+    if n_loc > 0:
+        src = order[mypos.clamp(min=0, max=n_loc - 1)]
+        mine_f = mine[:, None]
+        out = torch.cat([torch.where(mine_f, local_rows[src], torch.zeros((), dtype=local_rows.dtype, device=dev)),
+                         torch.where(mine, local_values[src], torch.zeros((), dtype=local_values.dtype, device=dev))[:, None]], 1)
+        out = out.to(torch.float64).contiguous()
+    else:
+        out = torch.zeros((n, k + 1), dtype=torch.float64, device=dev)
     allsum(out)
     if stats is not None:
         stats['wire_bytes'] = wire
+        stats['collectives'] = n_coll
+        stats['n_splitter'] = S
+        stats['candidates_per_rank'] = g
     return out[:, :k], out[:, k]
 
 
@@ -141,7 +197,11 @@ def _resampled_rows(source, resampler, n, stats=None):
     if isinstance(source, TraceTuple):
         x_loc, logq_loc, n_total = source.refit_shard()
         ranks = resampler.ranks(n_total, n)
-        rows, vals = select_rows_sharded(logq_loc, x_loc, ranks, stats=stats)
+        ws = parallel.world()[1]
+        per_chain = n_total // max(source.n_chain, 1)
+        n_loc_max = max(parallel.shard_range(source.n_chain, r, ws)[1] - parallel.shard_range(source.n_chain, r, ws)[0]
+                        for r in range(ws)) * per_chain
+        rows, vals = select_rows_sharded(logq_loc, x_loc, ranks, stats=stats, n_loc_max=n_loc_max)
         return rows.cpu().numpy(), vals.cpu().numpy()
     prev_samples, prev_logq = source
     i = resampler(prev_logq, n)

@@ -69,5 +69,5 @@ struct BfDeviceGuard {
 
 // the common surrogate: linear + quadratic configs with the extrapolation bound and nothing else
 static inline bool bf_model_plain(const DevModel &m) {
-    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic;
+    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link;
 }

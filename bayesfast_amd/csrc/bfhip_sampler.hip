@@ -1055,16 +1055,68 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                 }
                 gn[e] = sx + c_lin[e];
             }
-            if (f_cubic) {  // cubic configs: x_k of this chain is lane k / E, element k % E
+            if (f_cubic) {
+                // Cubic configs (modules/_poly.pyx:49-137), the whole wave on one chain's terms.  x_k of this chain is lane
+                // k / E, element k % E.  The work is laid out over (j, k): lane (jl = lane & 15, kq = lane >> 4) accumulates, for
+                // output index j = jb + jl, the terms with k = kq, kq + 4, ... -- the coefficient tables are stored with j
+                // contiguous, so a row of 16 lanes reads 128 contiguous bytes -- the four kq parts are added by two row
+                // swaps, and the lane that owns dimension mask[j] fetches its result.  (bf_cubic_grad, the per-dimension
+                // form, left 8 of 64 lanes with n^2 serial iterations each at config 5's 16 masked inputs.)
+                const int jl = lane & 15, kq = lane >> 4;
+                auto xu = [&](int dim) { return readlane_f64((E > 1 && (dim % E)) ? xev[E - 1] : xev[0], dim / E); };  // wave-uniform
+                auto xl = [&](int dim) {  // per-lane dimension
+                    const double a0 = __shfl(xev[0], dim / E, 64);
+                    if constexpr (E > 1) { const double a1 = __shfl(xev[E - 1], dim / E, 64); return (dim % E) ? a1 : a0; }
+                    return a0;
+                };
+                auto fetch = [&](const int *pos, int jb, double val, double (&dst)[E], bool add_value, double fval) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    double gc, fc;
-                    bf_cubic_grad(m, lane * E + e, xev[e],
-                                  [&](int k) { return readlane_f64((E > 1 && (k % E)) ? xev[E - 1] : xev[0], k / E); }, gc, fc);
-                    gn[e] += gc;
-                    r_cub += fc;
+                    for (int e = 0; e < E; ++e) {
+                        const int dim = lane * E + e;
+                        const int pj = dim < m.DP ? pos[dim] : -1;
+                        const bool mine = pj >= jb && pj < jb + 16;
+                        const double gv = __shfl(val, mine ? pj - jb : 0, 64);
+                        if (mine) dst[e] += gv;
+                    }
+                    (void)add_value; (void)fval;
+                };
+                double fsum = 0.;
+                for (int jb = 0; jb < m.n2; jb += 16) {   // cubic-2: f = sum_j x_j^2 v1_j, v1 = A x; df/dx_j = 2 x_j v1_j + (A^T x^2)_j
+                    const int j = jb + jl;
+                    const bool on = j < m.n2;
+                    double v1 = 0., v2 = 0.;
+                    for (int kk = 0; kk < m.n2; kk += 4) {   // (a wave-uniform loop; k differs between the rows of the wave)
+                        const int k = kk + kq;
+                        const bool ok = on && k < m.n2;
+                        const double xk = xl(ok ? m.mask2[k] : 0);
+                        v1 += (ok ? m.A2t[k * m.n2 + j] : 0.) * xk;
+                        v2 += (ok ? m.A2[k * m.n2 + j] : 0.) * (xk * xk);
+                    }
+                    v1 = swap32_add_f64(swap16_add_f64(v1));
+                    v2 = swap32_add_f64(swap16_add_f64(v2));
+                    const double xj = xl(on ? m.mask2[j] : 0);
+                    const double gj2 = 2. * xj * v1 + v2;
+                    if (on && kq == 0) fsum += xj * xj * v1;
+                    fetch(m.pos2, jb, gj2, gn, false, 0.);
                 }
-                r_cub = wave_sum(r_cub);
+                for (int jb = 0; jb < m.n3; jb += 16) {   // cubic-3: df/dx_j = 1/2 sum_{k,l} T[j,k,l] x_k x_l, f = x . grad / 3
+                    const int j = jb + jl;
+                    const bool on = j < m.n3;
+                    double sacc = 0.;
+                    for (int kk = 0; kk < m.n3; kk += 4) {
+                        const int k = kk + kq;
+                        const bool ok = on && k < m.n3;
+                        double t = 0.;
+                        const double *Tk = m.T3t + (size_t)(ok ? k : 0) * m.n3 * m.n3 + (ok ? j : 0);
+                        for (int l = 0; l < m.n3; ++l) t += (ok ? Tk[(size_t)l * m.n3] : 0.) * xu(rfl(m.mask3[l]));
+                        sacc += t * xl(ok ? m.mask3[k] : 0);
+                    }
+                    sacc = swap32_add_f64(swap16_add_f64(sacc));
+                    const double xj = xl(on ? m.mask3[j] : 0);
+                    if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
+                    fetch(m.pos3, jb, 0.5 * sacc, gn, false, 0.);
+                }
+                r_cub = wave_sum(fsum);
             }
 #pragma unroll
             for (int e = 0; e < E; ++e) {

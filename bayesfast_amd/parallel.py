@@ -7,7 +7,7 @@ chain index, so results do not depend on the number of ranks.  The refit needs e
 ONE all-gather per sampling round (RCCL over xGMI with backend "nccl"; gloo in the CPU tests)."""
 import numpy as np
 
-__all__ = ['world', 'shard_range', 'all_gather_chains', 'local_device', 'broadcast_int', 'all_reduce_sum']
+__all__ = ['world', 'shard_range', 'all_gather_chains', 'local_device', 'broadcast_int', 'all_reduce_sum', 'all_gather_stack']
 
 
 def world():
@@ -89,3 +89,18 @@ def all_reduce_sum(t):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def all_gather_stack(t):
+    """(world_size, *t.shape): the tensor ``t`` (same shape on every rank) of every rank, on every rank."""
+    import torch
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return t[None]
+    stage = dist.get_backend() == 'gloo' and t.is_cuda  # (plumbing tests: gloo moves host tensors)
+    src = t.cpu().contiguous() if stage else t.contiguous()
+    out = [torch.empty_like(src) for _ in range(ws)]
+    dist.all_gather(out, src)
+    res = torch.stack(out)
+    return res.to(t.device) if stage else res

@@ -186,25 +186,30 @@ def fit_timing(d, cov, seed=7):
             'note': 'host arrays in, coefficients out: upload, design blocks, split-K MFMA Gram, blocked Cholesky solve, bound statistics'}
 
 
-def _cpu_rate(spec, x0, n_adapt, seed, target_accept, target_seconds):
-    """The CPU port on the same density: the oracle's NUTS driver, one chain per OpenMP thread, post-adaptation, bounded."""
+def _cpu_rate(spec, x_start, step_size, var, seed, target_accept, target_seconds):
+    """The CPU port on the same density: the oracle's NUTS driver, one chain per OpenMP thread, bounded.  The chains start
+    where the device chains are after their adaptation, with the device's adapted step size and diagonal metric (means over
+    the chains) held fixed -- the CPU pays for sampling, not for a second adaptation (minutes on the deep-tree configs)."""
     from oracle import oracle as orc
     n_thr = orc.max_threads()
-    n_chain = min(2 * n_thr, x0.shape[0])
-    cs = orc.ChainSet(spec, x0[:n_chain], seed, target_accept=target_accept)
-    t0 = time.perf_counter()
-    cs.run(n_adapt, n_adapt, n_threads=n_thr)
-    t_adapt = time.perf_counter() - t0
-    nl, dt, n_it = 0, 0., 0
+    n_chain = min(n_thr, x_start.shape[0])
+    cs = orc.ChainSet(spec, x_start[:n_chain], seed, step_size=step_size, metric=var, adapt_step_size=False, adapt_metric=False,
+                      target_accept=target_accept)
+    nl, dt, n_it, slice_it = 0, 0., 0, 2
     while dt < target_seconds:
         t0 = time.perf_counter()
-        _, _, k = cs.run(25, n_adapt, n_threads=n_thr)
-        dt += time.perf_counter() - t0
-        nl += k
-        n_it += 25
+        _, _, k = cs.run(slice_it, 0, n_threads=n_thr)
+        t1 = time.perf_counter() - t0
+        if n_it:   # (the first slice pays the page faults of the threads' stacks: untimed)
+            dt += t1
+            nl += k
+        n_it += slice_it
+        if t1 < 0.3:
+            slice_it = min(4 * slice_it, 200)
     return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': physical_cores(n_thr), 'threads': n_thr, 'kind': 'port',
-            'sample': '%d chains x %d post-adaptation NUTS iterations (%d leapfrogs in %.1f s; adaptation %d iterations, %.1f s, '
-                      'untimed) of the same density, one chain per OpenMP thread' % (n_chain, n_it, nl, dt, n_adapt, t_adapt)}
+            'sample': '%d chains x %d NUTS iterations (%d leapfrogs in %.1f s) of the same density from the device chains\' '
+                      'post-adaptation positions, with their adapted step size and diagonal metric (chain means) held fixed; one '
+                      'chain per OpenMP thread' % (n_chain, n_it, nl, dt)}
 
 
 def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu_seconds, what, first_stream=0):
@@ -252,13 +257,15 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
                                         'unit': 'GB/s', 'frac': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9 / 8000.}}
     if cpu_seconds > 0:
         try:
-            out['cpu_baseline'] = _cpu_rate(spec, x0, n_adapt, seed, target_accept, cpu_seconds)
+            step = float((ch.field('log_bar').exp() * d**0.25).mean())   # what _get_step_size hands to the next round
+            out['cpu_baseline'] = _cpu_rate(spec, ch.field('q').cpu().numpy(), step, ch.field('var').mean(0).cpu().numpy(), seed,
+                                            target_accept, cpu_seconds)
         except Exception as ex:
             out['cpu_baseline'] = {'error': repr(ex)}
     return out, s, st
 
 
-def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=100, steps=2, n_adapt=300):
+def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps=2, n_adapt=None):
     """The BASELINE configs' own targets, one GPU's shard each, through the package API: fit the surrogate
     on 2 P points of the true model, adapt, time post-adaptation launches.
       banana_decay : config 3 -- 64-d rotated banana, quadratic surrogate (P = 2145) WITH the decay term the reference's
@@ -272,6 +279,10 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=100, steps=
     from bayesfast_amd.core.refit import select_fit_points
     rng = np.random.default_rng(seed)
     t_fit = {}
+    # launch lengths that keep a block within seconds: the banana's refitted surrogate and config 5 run every tree to the
+    # depth limit (1023 leapfrogs per iteration)
+    iters = iters or {'banana_decay': 50, 'funnel': 100, 'cubic128': 20}[name]
+    n_adapt = n_adapt or {'banana_decay': 200, 'funnel': 300, 'cubic128': 150}[name]
 
     def fit(den, x, lp, key):
         torch.cuda.synchronize()
@@ -440,6 +451,37 @@ def main():
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         total_lf, elapsed_max = float(tot.item()), float(tmax.item())
+        # the ONE exchange step of the path: the refit's selection of 2 P of ALL ranks' samples by their logq
+        # (core/recipe.py:1024-1025,1074) -- every rank sorts its own shard, four collectives move quantile keys, counts,
+        # candidates and the selected rows (core/refit.py: select_rows_sharded).  Timed on its own, never in `value`.
+        exchange = None
+        if dist is not None:
+            from bayesfast_amd.core.refit import select_rows_sharded
+            from bayesfast_amd.utils.resample import SystematicResampler
+            n_sel = 2 * (1 + d + d * (d + 1) // 2)
+            n_rows = C * a.iters
+            if world * n_rows >= n_sel:
+                rk = SystematicResampler(require_unique=False).ranks(world * n_rows, n_sel)
+                xl, ql = samples.reshape(-1, d), stats[:, :, 0].reshape(-1).contiguous()
+                est = {}
+                select_rows_sharded(ql, xl, rk, n_loc_max=n_rows)   # untimed first call (sort workspace, communicator)
+                tms = []
+                for _ in range(3):
+                    sync()
+                    t1 = time.perf_counter()
+                    rows, vals = select_rows_sharded(ql, xl, rk, stats=est, n_loc_max=n_rows)
+                    sync()
+                    tms.append((time.perf_counter() - t1) * 1e3)
+                tx = torch.tensor([min(tms)], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+                chk = torch.tensor([float(vals.sum())], dtype=torch.float64, device=red_dev)
+                chk_all = [torch.zeros_like(chk) for _ in range(world)]
+                dist.all_gather(chk_all, chk)
+                exchange = {'ms': float(tx.item()), 'wire_bytes_per_rank': int(est['wire_bytes']), 'collectives': int(est['collectives']),
+                            'rows_selected': int(n_sel), 'rows_per_rank': int(n_rows), 'splitters_per_rank': int(est['n_splitter']),
+                            'candidates_per_rank_and_row': int(est['candidates_per_rank']),
+                            'identical_on_all_ranks': bool(all(float(c.item()) == float(chk.item()) for c in chk_all)),
+                            'includes': 'local device sort of %d keys + 4 collectives (%s), max over ranks, best of 3' % (n_rows, a.backend)}
 
     if rank == 0:
         value = total_lf / elapsed_max
@@ -490,6 +532,8 @@ def main():
                                          'frac': (bytes_alg / (kernel_ms * 1e-3) / 1e9 / 8000.) if kernel_ms else 0.,
                                          'bytes_per_leapfrog': B_STEP_BYTES(d)},
         }
+        if exchange is not None:
+            out['refit_exchange'] = exchange
         if not a.no_fit and not a.no_cpu_baseline and world == 1:
             try:
                 with torch.cuda.device(ctx.device):

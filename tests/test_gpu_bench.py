@@ -42,6 +42,9 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     j = _line(r.stdout)
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
     assert j['config']['chains_per_gpu'] == 256
+    ex = j['refit_exchange']   # the path's one exchange step, timed on its own: four collectives, the same rows on every rank
+    assert ex['collectives'] == 4 and ex['identical_on_all_ranks'] and ex['ms'] > 0 and ex['rows_selected'] == 4290
+    assert ex['wire_bytes_per_rank'] < 256 * 250 * 65 * 8 / 4   # far below the shard's samples
 
 
 @pytest.mark.parametrize('name', ['banana_decay', 'funnel', 'cubic128'])

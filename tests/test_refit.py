@@ -78,14 +78,21 @@ def _shard_worker(rank, ws, port, q):
         # single-rank answer: stable argsort of the chain-major flattened array
         idx = np.argsort(lq.reshape(-1), kind='stable')[ranks]
         ok = np.array_equal(rows.numpy(), x.reshape(-1, d)[idx]) and np.array_equal(vals.numpy(), lq.reshape(-1)[idx])
-        q.put((rank, bool(ok), st['wire_bytes'], 257 * (d + 1) * 8))
+        S, g = st['n_splitter'], st['candidates_per_rank']
+        want = (S + 1) * 8 * ws + 2 * ws * S * 8 + 257 * (g + 2) * 8 * ws + 257 * (d + 1) * 8
+        # a second selection with a tiny splitter set (wide candidate intervals) and one with more splitters than rows
+        for ns in (3, 5000):
+            r2, v2 = select_rows_sharded(torch.as_tensor(lq[b:e].reshape(-1)), torch.as_tensor(x[b:e].reshape(-1, d)), ranks,
+                                         sort_fn=_cpu_sort, count_fn=_cpu_count, n_splitter=ns, n_loc_max=4 * n_keep)
+            ok = ok and np.array_equal(r2.numpy(), x.reshape(-1, d)[idx]) and np.array_equal(v2.numpy(), lq.reshape(-1)[idx])
+        q.put((rank, bool(ok), st['wire_bytes'], want, st['collectives']))
     finally:
         dist.destroy_process_group()
 
 
 def test_sharded_selection_gloo_world2_is_exact_and_moves_only_selected_rows():
-    """2 ranks, ragged shards, many ties: both ranks end with the rows a single rank would select, bit for bit, and the
-    bytes on the wire are the bisection counters plus ONE (n, d + 1) array -- not the samples."""
+    """2 ranks, ragged shards, many ties: both ranks end with the rows a single rank would select, bit for bit, in FOUR
+    collectives (splitters, counts, candidates, rows), and the bytes on the wire are those four messages -- not the samples."""
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -95,8 +102,8 @@ def test_sharded_selection_gloo_world2_is_exact_and_moves_only_selected_rows():
     res = sorted(q.get(timeout=180) for _ in range(2))
     [p.join(60) for p in ps]
     assert [r[1] for r in res] == [True, True]
-    for _, _, wire, rows_bytes in res:
-        assert wire == 64 * 257 * 8 + 257 * 8 + 2 * 257 * 8 + rows_bytes  # counters, tie base, tie counts, the rows
+    for _, _, wire, want, n_coll in res:
+        assert n_coll == 4 and wire == want
         assert wire < 7 * 300 * 7 * 8 * 2                                   # (all samples would be 117 600 B per gather)
 
 
@@ -119,6 +126,12 @@ def _warmstart_worker(rank, ws, port, q):
         cov = _get_metric(tt, 'full')
         ref = np.cov(x[:, 10:].reshape(-1, d), rowvar=False)
         ok = np.allclose(cov, ref, rtol=1e-12, atol=1e-14)
+        try:   # a host view before gather() would be a collective behind the caller's back: it raises instead
+            tt.get(flatten=True)
+            ok = False
+        except RuntimeError:
+            pass
+        tt.gather()
         ok = ok and np.array_equal(tt.get(flatten=True), x[:, 10:].reshape(-1, d))  # host view = all chains, on every rank
         q.put((rank, bool(ok), seed))
     finally:
