@@ -534,6 +534,13 @@ def main():
         }
         if exchange is not None:
             out['refit_exchange'] = exchange
+        try:   # the AS-SHIPPED reference's rate: a stored measurement of the build container (tools/time_reference.py), never timed here
+            rt = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_timing.json')))
+            out['reference_as_shipped'] = {'leapfrog_steps_per_sec_per_core': rt['leapfrog_steps_per_sec_per_core'],
+                                           'polymodel_fit_s': rt.get('polymodel_fit_s'), 'host': rt['host']['cpu'],
+                                           'source': 'tests/golden/reference_timing.json (build container; the Python reference does not travel)'}
+        except Exception:
+            pass
         if not a.no_fit and not a.no_cpu_baseline and world == 1:
             try:
                 with torch.cuda.device(ctx.device):

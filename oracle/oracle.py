@@ -23,7 +23,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, '_build', 'libbf_oracle.so')
+# BF_ORACLE_LIB: another build of the same sources (the sanitizer build of `make -C oracle asan`, tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get('BF_ORACLE_LIB') or os.path.join(_HERE, '_build', 'libbf_oracle.so')
 
 ORDERS = {'linear': 0, 'quadratic': 1, 'cubic-2': 2, 'cubic-3': 3}
 
@@ -78,6 +79,8 @@ _lib = None
 
 def build(force=False):
     """Compile the C restatement (building the checker is not using it)."""
+    if os.environ.get('BF_ORACLE_LIB'):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
                                               for f in ('bf_oracle.c', 'bf_oracle.h'))):

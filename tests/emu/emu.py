@@ -10,14 +10,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, '_build', 'libbf_emu.so')
+_LIB = os.environ.get('BF_EMU_LIB') or os.path.join(_HERE, '_build', 'libbf_emu.so')  # BF_EMU_LIB: the sanitizer build
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(['make', '-C', _HERE, '-s'])
+        if not os.environ.get('BF_EMU_LIB'):
+            subprocess.check_call(['make', '-C', _HERE, '-s'])
         _lib = C.CDLL(_LIB)
     return _lib
 

@@ -340,6 +340,40 @@ def test_nuts_posterior_moments_quadratic_target(ctx):
     assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.03
 
 
+def test_config2_fitted_bound_on_surrogate_posterior_moments(ctx):
+    """T2 for BASELINE config 2 as it is specified: d = 32, 1024 chains, ``PolyModel('quadratic')`` FITTED on
+    2 P Sobol-normal points of the target (P = 561) with its extrapolation bound ON, NUTS defaults (1500 iterations, 500
+    warm-up, diagonal adaptation), through the public entry point; against the analytic posterior N(0, P^-1): means within
+    4 sigma / sqrt(ESS), variance ratios within 4 Monte-Carlo standard errors, no draw outside the bound, no divergence.
+    (The fit points are spread 1.5 x wider than the posterior, as in a recipe's first rounds: DESIGN.md section 5.)"""
+    from bayesfast_amd import PolyModel, SurrogateDensity, sample
+    from bayesfast_amd.workloads import sobol_normal
+    d, C = 32, 1024
+    rng = np.random.default_rng(123)
+    L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
+    P = L @ L.T
+    cov = np.linalg.inv(P)
+    su = PolyModel('quadratic', input_size=d, output_size=1)
+    assert su.n_param == 561 and su.bound_options.use_bound
+    den = SurrogateDensity(su)
+    x_fit = 1.5 * sobol_normal(2 * su.n_param, d, seed=1) @ np.linalg.cholesky(cov).T
+    den.fit(x_fit, -0.5 * np.einsum('ij,jk,ik->i', x_fit, P, x_fit))
+    tt = sample(den, dict(n_chain=C, n_iter=1500, n_warmup=500, random_generator=7), verbose=False)
+    draws = tt.get()                                   # (C * 1000, d), post-warm-up
+    assert tt.stat('diverging')[:, 500:].sum() == 0
+    xm = draws - su._mu
+    assert np.sqrt(np.einsum('ij,jk,ik->i', xm, su._hess, xm)).max() < su._alpha     # every draw inside the bound ellipsoid
+    # effective sample size per dimension from the chains' own autocorrelation (batch means over chains of 1000)
+    per_chain = tt.get(flatten=False)                  # (C, 1000, d)
+    sd = np.sqrt(np.diag(cov))
+    ess = C * 1000 * np.clip(per_chain.var(1, ddof=1).mean(0) / (1000 * per_chain.mean(1).var(0, ddof=1)), 0.02, 1.)
+    assert np.all(np.abs(draws.mean(0)) < 4 * sd / np.sqrt(ess)), (draws.mean(0) / (sd / np.sqrt(ess)))
+    ratio = draws.var(0) / np.diag(cov)
+    assert np.all(np.abs(ratio - 1.) < 4 * np.sqrt(2. / ess)), ratio
+    emp = np.cov(draws[::5], rowvar=False)
+    assert np.max(np.abs(emp - cov) / np.outer(sd, sd)) < 0.03
+
+
 def test_headline_size_properties(ctx):
     """BASELINE's headline size (4096 chains x 64-d, bound on) through properties that do not need the oracle: posterior
     moments against the analytic N(0, Sigma), no sample outside the bound ellipsoid of a well-posed surrogate, the leapfrog

@@ -329,3 +329,14 @@ def test_gaussian_link_in_the_oracle_and_own_refit_loop_on_the_standin(monkeypat
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'recipe.npz'))
     ring, tt = donut.own_refit_loop(z['step0.x_fit'], float(z['step0.step_size']), n_steps=8)
     assert abs(ring[-2:, 0].mean() - 5.02) < 0.1 and abs(ring[-2:, 1].mean() - 0.49) < 0.08 and ring[-1, 2] < 0.3, ring
+
+
+def test_reference_timing_fixture_is_present_and_sane():
+    """tests/golden/reference_timing.json (tools/time_reference.py: the as-shipped reference timed in the build container,
+    BASELINE.md section 3): ~1e4 leapfrog steps/s/core, the Python pipeline overhead dominating the Cython kernels."""
+    import json
+    import os
+    rt = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_timing.json')))
+    assert 2e3 < rt['leapfrog_steps_per_sec_per_core'] < 1e5
+    assert rt['quadratic_kernels_us'] < rt['polymodel_fun_and_jac_us'] < rt['logp_and_grad_us'] <= rt['leapfrog_step_us'] * 1.2
+    assert rt['host']['logical_cpus'] >= 1 and rt['polymodel_fit_shape'] == [4290, 2145]
