@@ -57,6 +57,19 @@
 #define GTRACE2(k) do { } while (0)
 #endif
 
+// knock-out builds (tools/gvariant.sh -DBF_KO_...): WRONG results on purpose, to bound what a piece of the trip costs on the
+// critical path (the tree shapes do not depend on the pieces knocked out); never part of the library
+#if defined(BF_KO_EXP) && !defined(BF_HOST_EMU)
+#define BF_LEAF_EXP(x) (1. + 1e-3 * (x))
+#else
+#define BF_LEAF_EXP(x) bf_exp(x)
+#endif
+#if defined(BF_KO_RNG) && !defined(BF_HOST_EMU)
+#define BF_TREE_DRAW(rs) ((rs)[0] += 0x9E3779B97F4A7C15ULL, (rs)[0])
+#else
+#define BF_TREE_DRAW(rs) bf_xoshiro_next(rs)
+#endif
+
 template <int W>
 struct GroupGeo {
     static constexpr int DP = 16 * W, NS = 4 * W;
@@ -306,9 +319,13 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             const uint64_t P = (uint64_t)((dbase + 4 * r) >> 1);
             const double u1 = bf_u01_open0(bf_mix64(K + (2 * P + 1) * BF_GOLDEN));
             const double u2 = bf_u01(bf_mix64(K + (2 * P + 2) * BF_GOLDEN));
+#if defined(BF_KO_MOM) && !defined(BF_HOST_EMU)
+            const double rad = 3.4641016151377544, sn = u1 - 0.5, cs = u2 - 0.5;  // (uniforms of unit variance)
+#else
             const double rad = bf_sqrt(-2. * bf_log(u1));
             double sn, cs;
             bf_sincospi(2. * u2, &sn, &cs);
+#endif
             mine[h] = godd ? rad * sn : rad * cs;             // odd dimension: sin, even: cos
             theirs[h] = godd ? rad * cs : rad * sn;
         }
@@ -331,7 +348,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
         eps = (i_iter < nw) ? step_now : step_bar;  // step_size.py:25-29
         dir = 1;
-        if (NUTS) dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
+        if (NUTS) dir = (bf_u01(BF_TREE_DRAW(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
         tv_st(G::T_LEFT + 0, q); tv_st(G::T_LEFT + 1, p); tv_st(G::T_LEFT + 2, g);
         tv_st(G::T_RIGHT + 0, q); tv_st(G::T_RIGHT + 1, p); tv_st(G::T_RIGHT + 2, g);
         tv_st(G::T_PROP + 0, q); tv_st(G::T_PROP + 1, g);
@@ -824,8 +841,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 bf_sync();
             }
             if (st == S_MERGE) {
-                T_W = bf_exp(aw);
-                const double pacc = (w_off == 0.) ? T_W : bf_exp(-dE);
+                T_W = BF_LEAF_EXP(aw);
+                const double pacc = (w_off == 0.) ? T_W : BF_LEAF_EXP(-dE);
                 T_acc = pacc > 1. ? 1. : pacc;
                 GTRACE2(3);
                 if (nm >= 1) {
@@ -834,7 +851,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     T_acc = L0_acc + T_acc;  // :173
                     const double Wsum = L0_W + T_W;
                     if (Wsum != Wsum) err = 2;
-                    const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
+                    const double u = bf_u01(BF_TREE_DRAW(rs));  // :163-167, drawn even when turning
                     lev = 1;
                     if ((d0 <= 0.) || (d1 <= 0.)) {
                         st = S_ABORT;
@@ -858,7 +875,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     T_acc = lsp[LS_ACC] + T_acc;  // :173
                     const double Wsum = lsp[LS_LS] + T_W;
                     if (Wsum != Wsum) err = 2;
-                    const double u = bf_u01(bf_xoshiro_next(rs));  // consumed even when this merge's check says turning
+                    const double u = bf_u01(BF_TREE_DRAW(rs));  // consumed even when this merge's check says turning
                     const bool keep_t2 = (u * Wsum < T_W) || (u == 0.);
                     if (turning) {
                         st = S_ABORT;  // ancestors above this level still add their accept sums
@@ -919,7 +936,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 acc_sum += T_acc;
                 {   // :81-83  logbern(ls_new - ls_old)  <=>  U * W_old < W_new
                     if (T_W != T_W || tree_W != tree_W) err = 2;
-                    const double u = bf_u01(bf_xoshiro_next(rs));
+                    const double u = bf_u01(BF_TREE_DRAW(rs));
                     if ((u * tree_W < T_W) || (u == 0.)) {
                         if (src < 0) {
                             tv_st(G::T_PROP + 0, q);
@@ -950,7 +967,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 if (turning || depth >= a.cfg.max_treedepth) {
                     st = S_END;
                 } else {
-                    const int nd = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
+                    const int nd = (bf_u01(BF_TREE_DRAW(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
                     if (nd != dir) {
                         const int eo = (nd > 0) ? G::T_RIGHT : G::T_LEFT;
                         tv_ld(eo + 0, q); tv_ld(eo + 1, p); tv_ld(eo + 2, g);
@@ -981,7 +998,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             tv_ld(G::T_PROP + 0, q);
             tv_ld(G::T_PROP + 1, g);
             const int orow = i_iter - a.iter_out0;
+#if defined(BF_KO_STATS) && !defined(BF_HOST_EMU)
+            if (false) {
+#else
             if (orow >= 0 && orow < a.n_out) {
+#endif
                 if (writer) {
                     double *sp = a.stats + ((size_t)chain * a.n_out + orow) * BFHIP_STAT_STRIDE;
                     if (NUTS) {
