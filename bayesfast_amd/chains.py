@@ -8,6 +8,11 @@ from .device import DeviceDensity, _ptr
 
 __all__ = ['DeviceChains']
 
+# what 'auto' runs while the trees of a group are in step: 'group', or 'split' (eight waves per 16 chains, two per SIMD with
+# disjoint work; NUTS on the plain surrogate at 33 <= d <= 64, the library runs everything else as 'group').  Same results
+# either way, bit for bit; 'split' is the slower one today (8.3 against 11.1 x 10^8 on the headline)
+IN_STEP_LAYOUT = __import__('os').environ.get('BFHIP_IN_STEP_LAYOUT', 'group')
+
 
 def _torch():
     import torch
@@ -109,8 +114,8 @@ class DeviceChains:
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
         cfg.full_metric = int(self.full_metric)
         cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
-        if layout not in ('auto', 'group', 'wave'):
-            raise ValueError("layout should be 'auto', 'group' or 'wave'.")
+        if layout not in ('auto', 'group', 'wave', 'split'):
+            raise ValueError("layout should be 'auto', 'group', 'split' or 'wave'.")
         n_run = int(n_run)
         if samples is None:
             samples = self.ctx.empty((self.n_chain, n_run, self.d))
@@ -132,8 +137,8 @@ class DeviceChains:
             # the chains' behaviour, one launch late
             lay = layout
             if lay == 'auto':
-                lay = 'group' if (sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)) else 'wave'
-            cfg.chain_layout = {'group': 1, 'wave': 2}[lay]
+                lay = IN_STEP_LAYOUT if (sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)) else 'wave'
+            cfg.chain_layout = {'group': 1, 'wave': 2, 'split': 3}[lay]
             self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),

@@ -3,6 +3,14 @@
 // that a chain's numbers do not depend on what the optimiser fuses.
 #include "bfhip_common.h"
 #include "bfhip_group.h"
+#include "bfhip_split.h"
+
+// measurement hook (not part of include/bfhip.h): device buffer of two counters, trips and trips with the bound's tiles
+static unsigned long long *g_gcount = NULL;
+extern "C" void bfhip_debug_group_counters(unsigned long long *buf) { g_gcount = buf; }
+static unsigned long long *g_gcount_ptr() { return g_gcount; }
+static unsigned long long *g_gstamps_ptr();
+int bf_no_bound_proof();
 
 template <int W, bool NUTS, int FS>
 __global__ __launch_bounds__(64 * W) void bf_group_kernel(DevModel m, SamplerArgs a) {
@@ -47,6 +55,30 @@ static int launch_w(bfhip_ctx *ctx, const SamplerArgs &args, bool nuts, int fs) 
 #endif
 }
 
+// the split layout (bfhip_split.h): 8 waves per 16 chains, integrator and bookkeeper waves two per SIMD
+__global__ __launch_bounds__(512) void bf_split_kernel(DevModel m, SamplerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double bf_split_lds[];
+    bf_split_body<true>(m, a, bf_split_lds);
+}
+
+bool bf_split_supports(const DevModel &m, const SamplerArgs &args) {
+    return m.DP == 64 && args.cfg.sampler == 0 && m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su &&
+           !m.has_cubic && !m.has_link && !args.mat && args.nslot >= SplitGeo::scratch_slots();
+}
+
+int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args_in) {
+    SamplerArgs args = args_in;
+    args.gcount = g_gcount_ptr();
+    args.no_bound_proof = bf_no_bound_proof();
+    args.stamps = g_gstamps_ptr();
+    const size_t lds = SplitGeo::lds_doubles() * sizeof(double);
+    BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int groups = (args.n_chain + 15) / 16;
+    hipLaunchKernelGGL(bf_split_kernel, dim3(groups), dim3(512), lds, ctx->stream, ctx->model, args);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {
     return m.DP <= 64 && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !args.mat;
 }
@@ -56,15 +88,13 @@ int bf_group_scratch_slots(int DP) { return 5 * (BFHIP_MAX_TREEDEPTH - 2); }
 // tuning hook (not part of include/bfhip.h): cycle stamps of workgroup 0's first trips, see GTRACE in bfhip_group.h
 static unsigned long long *g_gstamps = NULL;
 extern "C" void bfhip_debug_gstamps(unsigned long long *buf) { g_gstamps = buf; }
+static unsigned long long *g_gstamps_ptr() { return g_gstamps; }
 
 // test hook (not part of include/bfhip.h): 1 = never skip the bound's tiles (the results must not change)
 static int g_no_bound_proof = 0;
 extern "C" void bfhip_debug_no_bound_proof(int on) { g_no_bound_proof = on; }
 int bf_no_bound_proof() { return g_no_bound_proof; }
 
-// measurement hook (not part of include/bfhip.h): device buffer of two counters, trips and trips with the bound's tiles
-static unsigned long long *g_gcount = NULL;
-extern "C" void bfhip_debug_group_counters(unsigned long long *buf) { g_gcount = buf; }
 
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;

@@ -1426,8 +1426,12 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     const bool nuts = cfg->sampler == 0;
     // the common surrogate (linear + quadratic configs with the bound; decay and constraint transform optional) at
     // d <= 64 with the diagonal metric: the group kernel
-    if (cfg->chain_layout < 0 || cfg->chain_layout > 2) return bf_set_error(BFHIP_ERR_ARG, "chain_layout should be 0, 1 or 2");
-    const bool want_group = cfg->chain_layout == 1 || (cfg->chain_layout == 0 && !nuts);
+    if (cfg->chain_layout < 0 || cfg->chain_layout > 3) return bf_set_error(BFHIP_ERR_ARG, "chain_layout should be 0, 1, 2 or 3");
+    if (cfg->chain_layout == 3 && !g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_split_supports(m, args)) {
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_split_kernel");
+        return bf_launch_split(ctx, args);
+    }
+    const bool want_group = cfg->chain_layout == 1 || cfg->chain_layout == 3 || (cfg->chain_layout == 0 && !nuts);
     if (want_group && !g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_group_supports(m, args)) {
         snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_group_kernel<%d, %s, %d>", W, nuts ? "true" : "false",
                  1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0));

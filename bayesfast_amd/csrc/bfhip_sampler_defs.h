@@ -32,3 +32,6 @@ struct bfhip_ctx;
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args);
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args);
 int bf_no_bound_proof();  // test hook state (bfhip_debug_no_bound_proof, bfhip_group.hip)
+// bfhip_split.h: NUTS on the plain common surrogate at 33 <= d <= 64, integrator and bookkeeper waves (chain_layout 3)
+bool bf_split_supports(const DevModel &m, const SamplerArgs &args);
+int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args);

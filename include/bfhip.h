@@ -141,8 +141,11 @@ typedef struct {
      *     executes the union of the chains' paths.
      * 2 = wave per chain (bfhip_sampler.hip: pipelined / sliced kernels): each chain follows its own path; insensitive to
      *     chains out of step.
+     * 3 = "split": the lane-per-chain layout with eight waves per 16 chains, two per SIMD with disjoint work -- integrator
+     *     waves (leapfrog step, gradient tiles) and bookkeeper waves (the NUTS tree, one leaf behind); NUTS on the plain
+     *     common surrogate at 33 <= d <= 64, anything else runs as 1.  Bit-identical results to 1.
      * 0 = library default: 2 for NUTS, 1 for HMC (whose chains are always in step).  bayesfast_amd.chains.DeviceChains
-     *     chooses 1 or 2 per run from the tree sizes of the previous run. */
+     *     chooses 1 / 3 or 2 per run from the tree sizes of the previous run. */
     int chain_layout;
 } bfhip_sampler_config;
 

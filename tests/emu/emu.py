@@ -49,7 +49,7 @@ class EmuChains:
 
     def run(self, n_run, sampler='NUTS', n_warmup=500, max_treedepth=10, n_int_step=32, max_change=1000.,
             target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True, update_window=1,
-            doubling=True, launch_iters=None):
+            doubling=True, launch_iters=None, layout='group'):
         bl = self.bl
         cfg = bl.SamplerConfig()
         cfg.sampler = {'NUTS': 0, 'HMC': 1}[sampler]
@@ -60,6 +60,7 @@ class EmuChains:
         cfg.target_accept, cfg.gamma, cfg.k, cfg.t_0 = float(target_accept), float(gamma), float(k), float(t_0)
         cfg.adapt_step_size, cfg.adapt_metric = int(bool(adapt_step_size)), int(bool(adapt_metric))
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
+        cfg.chain_layout = {'group': 1, 'split': 3}[layout]
         samples = np.full((self.n_chain, n_run, self.d), np.nan)
         stats = np.full((self.n_chain, n_run, bl.STAT_STRIDE), np.nan)
         step = max(1, int(launch_iters) if launch_iters else n_run)

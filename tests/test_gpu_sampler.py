@@ -49,10 +49,11 @@ def _oracle_chains(spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, *
 _LAYOUT = {'v': 'group'}
 
 
-@pytest.fixture(autouse=True, params=['group', 'wave'])
+@pytest.fixture(autouse=True, params=['group', 'wave', 'split'])
 def _both_layouts(request):
-    """Every test of this module runs on both chain layouts of the sampler (lane per chain: bfhip_group.hip; wave per
-    chain: bf_nuts_pipe_kernel / bf_sampler_kernel)."""
+    """Every test of this module runs on all chain layouts of the sampler (lane per chain: bfhip_group.hip; wave per
+    chain: bf_nuts_pipe_kernel / bf_sampler_kernel; lane per chain with integrator and bookkeeper waves: bfhip_split.h, which
+    the library runs wherever it applies -- NUTS on the plain surrogate at 33 <= d <= 64 -- and as 'group' elsewhere)."""
     _LAYOUT['v'] = request.param
     yield
 
@@ -338,6 +339,33 @@ def test_nuts_posterior_moments_quadratic_target(ctx):
     np.testing.assert_allclose(draws.var(0), np.diag(cov), rtol=0.05)
     emp = np.cov(draws, rowvar=False)
     assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.03
+
+
+def test_split_layout_is_bit_identical_to_group_layout_on_the_device(ctx):
+    """chain_layout 3 (bfhip_split.h: integrator and bookkeeper waves, two per SIMD, the bookkeepers one leaf behind) against
+    chain_layout 1 on the GPU: equal samples, statistics, chain state and random streams -- ragged groups through warm-up,
+    starts far outside the bound (second passes, the third barrier), launch cuts.  (The CPU emulation checks the same and
+    more: tests/test_group_emu.py.)"""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    import ctypes as C
+    spec, _ = correlated_gaussian_spec(64)
+    dens = DeviceDensity(spec, ctx)
+    rng = np.random.default_rng(3)
+    kname = _lib.lib().bfhip_debug_last_kernel
+    kname.restype = C.c_char_p
+    for x0, n, nw, kw in ((rng.normal(size=(37, 64)), 60, 40, {}), (rng.normal(size=(20, 64)) * 6., 30, 20, {}),
+                          (rng.normal(size=(300, 64)), 90, 50, dict(launch_iters=17))):
+        out = []
+        for layout in ('group', 'split'):
+            ch = DeviceChains(dens, x0, seed=5)
+            s, st = ch.run(n, 'NUTS', n_warmup=nw, layout=layout, **kw)
+            out.append([t.cpu().numpy() for t in (s, st, ch.sc, ch.vec, ch.rng)] + [ch.total_leapfrog])
+            assert kname().decode().startswith('bf_split_kernel' if layout == 'split' else 'bf_group_kernel')
+        for u, v in zip(*out):
+            assert np.array_equal(u, v, equal_nan=True) if isinstance(u, np.ndarray) else u == v
 
 
 def test_config2_fitted_bound_on_surrogate_posterior_moments(ctx):

@@ -31,7 +31,7 @@ def _spec(z, prefix):
 def _emu(spec, x0, n_iter, n_warmup, sampler='NUTS', first_stream=0, split=None, seed=SEED, launch_iters=None, **kw):
     import emu
     ec = emu.EmuChains(spec, x0, seed=seed, first_stream=first_stream, step_size=kw.get('step_size', 1.))
-    run_kw = {k: v for k, v in kw.items() if k in ('max_treedepth', 'max_change', 'n_int_step', 'target_accept')}
+    run_kw = {k: v for k, v in kw.items() if k in ('max_treedepth', 'max_change', 'n_int_step', 'target_accept', 'layout')}
     if split is None:
         s, st = ec.run(n_iter, sampler, n_warmup=n_warmup, launch_iters=launch_iters, **run_kw)
     else:
@@ -123,6 +123,50 @@ def test_group_kernel_divergences_depth_cap_and_far_start(samp):
     dev = _emu(spec, x0, 8, 6)
     orc_runs = _oracle(spec, x0, 8, 6)
     _compare_nuts(dev, orc_runs, 8, tol_head=1e-8)
+
+
+def _same(a, b):
+    sa, sta, ea = a
+    sb, stb, eb = b
+    assert np.array_equal(sa, sb, equal_nan=True)
+    for k in sta:
+        assert np.array_equal(sta[k], stb[k], equal_nan=True), k
+    assert np.array_equal(ea.sc, eb.sc) and np.array_equal(ea.vec, eb.vec) and np.array_equal(ea.rng, eb.rng)
+    assert int(ea.n_leapfrog[0]) == int(eb.n_leapfrog[0])
+
+
+def test_split_layout_is_bit_identical_to_the_group_layout(samp):
+    """bfhip_split.h (chain_layout 3: integrator and bookkeeper waves, two per SIMD, the bookkeepers one leaf behind and the
+    integrators running ahead on the assumption that the tree goes on) against bfhip_group.h on the emulator: every leaf that
+    is used is computed from the same state with the same arithmetic, so samples, all statistics, the adapted state and the
+    random streams are EQUAL -- with trees out of step in a ragged second group, through warm-up with metric updates, across
+    launch cuts and a resumed run, with starts outside the bound (second and third passes, the extra barrier), divergent
+    leaves, the depth cap, a padded dimension, and a chain whose initial energy is not finite."""
+    spec = _spec(samp, 'd64.')
+    x0 = np.random.default_rng(12).normal(size=(18, 64)) * 0.7           # two groups, the second one ragged
+    g = _emu(spec, x0, 9, 6, layout='group')
+    _same(g, _emu(spec, x0, 9, 6, layout='split'))
+    _compare_nuts((g[0][:2], {k: v[:2] for k, v in g[1].items()}, g[2]), _oracle(spec, x0[:2], 9, 6), 9)   # (= the oracle's)
+    _same(g, _emu(spec, x0, 9, 6, layout='split', split=4))              # a resumed run (two launches)
+    far = np.random.default_rng(6).normal(size=(3, 64)) * 6.             # outside the alpha-ellipsoid
+    _same(_emu(spec, far, 5, 4, layout='group'), _emu(spec, far, 5, 4, layout='split'))
+    kw = dict(step_size=30., max_change=20.)                             # divergent leaves, immediate U-turns
+    a = _emu(spec, x0[:4], 6, 2, layout='group', **kw)
+    assert a[1]['diverging'].sum() >= 1
+    _same(a, _emu(spec, x0[:4], 6, 2, layout='split', **kw))
+    kw = dict(step_size=0.02, max_treedepth=3)                           # the depth cap
+    a = _emu(spec, x0[:3], 4, 0, layout='group', **kw)
+    assert a[1]['tree_depth'].max() == 3
+    _same(a, _emu(spec, x0[:3], 4, 0, layout='split', **kw))
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    spec40 = correlated_gaussian_spec(40)[0]                              # d = 40 in the 64-wide layout
+    x40 = np.random.default_rng(9).normal(size=(5, 40))
+    _same(_emu(spec40, x40, 6, 4, layout='group'), _emu(spec40, x40, 6, 4, layout='split'))
+    bad = x0[:3].copy()
+    bad[1, 0] = np.inf                                                   # bad initial energy: error flag, chain stops
+    a, b = _emu(spec, bad, 3, 2, layout='group'), _emu(spec, bad, 3, 2, layout='split')
+    assert a[2].field('error')[1] == 1 and np.array_equal(a[2].field('error'), b[2].field('error'))
+    assert np.array_equal(a[0][[0, 2]], b[0][[0, 2]])
 
 
 def test_group_kernel_hmc_matches_oracle(samp):
