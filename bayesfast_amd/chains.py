@@ -114,6 +114,7 @@ class DeviceChains:
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
         cfg.full_metric = int(self.full_metric)
         cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
+        layout = __import__('os').environ.get('BFHIP_FORCE_LAYOUT') or layout   # (tuning: one layout for every launch)
         if layout not in ('auto', 'group', 'wave', 'split'):
             raise ValueError("layout should be 'auto', 'group', 'split' or 'wave'.")
         n_run = int(n_run)

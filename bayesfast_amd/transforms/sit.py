@@ -3,7 +3,8 @@
 Each iteration rotates the data with FastICA and then Gaussianizes every rotated coordinate by a monotone map
 ``norm.ppf(KDE cdf)`` represented as a piecewise cubic (transforms/sit.py:223-255,305-321).  What runs where:
 
-* FastICA (scikit-learn, as in the reference) and the construction of the ~100-knot splines: host;
+* the construction of the ~100-knot splines: host;  FastICA: scikit-learn's algorithm on the device (``transforms/ica.py``:
+  the (n x d)(d x d) products and the tanh on the GPU, the d x d eigen-decompositions on the host);
 * the KDE cdf at the knots -- an (n_data x n_knot) reduction per coordinate, the dominant cost of ``fit`` --
   ``bfhip_kde_cdf``; the rotations of the whole data set: device matmuls; applying the d splines to all points
   (``fit``'s update of the data, ``forward_transform`` / ``logq``, ``backward_transform`` / ``sample``):
@@ -92,14 +93,26 @@ class SIT:
         return get_context()
 
     # ---- one iteration: transforms/sit.py:229-255 ----
-    def _ica(self, x_host):
-        from sklearn.decomposition import FastICA
+    def _ica(self, x_dev):
+        """``FastICA(**ica_options).fit`` on at most ``m_ica`` of the points (transforms/sit.py:235-244), on the device
+        (``transforms/ica.py``: scikit-learn's algorithm with its defaults; options other than ``max_iter``, ``tol``,
+        ``random_state``, ``w_init`` go to scikit-learn itself, on the host, as the reference does)."""
+        import torch
         io = dict(self.ica_options)
         if 'random_state' not in io:
             io['random_state'] = int(self.random_generator.integers(0, 2**32))
+        n = int(x_dev.shape[0])
+        n_ica = min(n, self.m_ica)
+        rows = self.random_generator.choice(n, n_ica, False)
+        if set(io) <= {'max_iter', 'tol', 'random_state', 'w_init'}:
+            from .ica import fastica_device
+            sub = x_dev[torch.as_tensor(rows, device=x_dev.device)]
+            comp, mean, _ = fastica_device(sub, random_state=io['random_state'], max_iter=io.get('max_iter', 200),
+                                           tol=io.get('tol', 1e-4), w_init=io.get('w_init'))
+            return comp, mean
+        from sklearn.decomposition import FastICA
         ica = FastICA(**io)
-        n_ica = min(x_host.shape[0], self.m_ica)
-        ica.fit(x_host[self.random_generator.choice(x_host.shape[0], n_ica, False)])
+        ica.fit(x_dev.cpu().numpy()[rows])
         return ica.components_, ica.mean_
 
     def _gaussianize(self, y):
@@ -177,10 +190,9 @@ class SIT:
             if n_run > self.n_iter - self.i_iter:
                 self.n_iter = self.i_iter + n_run
         for _ in range(n_run):
-            x_host = self._data.cpu().numpy()
-            comp, ica_mean = self._ica(x_host)
+            comp, ica_mean = self._ica(self._data)
             # y = ica.transform(x) scaled to unit variance; A = components / std, B = inv(A), m = mean(x) (:237-243)
-            m = np.mean(x_host, axis=0)
+            m = self._data.mean(0).cpu().numpy()
             y = (self._data - ctx.tensor(ica_mean)) @ ctx.tensor(comp.T.copy())
             s = y.std(0, unbiased=False)
             y = y / s

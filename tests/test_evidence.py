@@ -168,6 +168,33 @@ def test_gbs_recovers_the_16d_funnel_evidence():
     assert abs(logz - (-63.4988)) < 3. * err + 0.02
 
 
+def test_device_fastica_algorithm_equals_scikit_learns(monkeypatch):
+    """transforms/ica.py against ``sklearn.decomposition.FastICA`` (what the reference's SIT calls, transforms/sit.py:235-244)
+    on the same data and ``random_state``: the same unmixing matrix and mean to 1e-8, the same number of iterations.  The
+    device products are replaced by CPU tensors here (the algorithm is what is checked; tests/test_evidence.py's GPU tests
+    run it on the device, where the Gram matrix comes from ``bfhip_gram``)."""
+    import sys
+    import warnings
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers'))
+    from sklearn.decomposition import FastICA
+    from oracle_standin import _CpuCtx
+    from bayesfast_amd.transforms import ica
+    monkeypatch.setattr(ica, '_gram', lambda ctx, xc: xc.T @ xc)
+    rng = np.random.default_rng(0)
+    for n, d, seed in ((4000, 5, 3), (20000, 16, 11)):
+        s = np.stack([rng.laplace(size=n) if k % 3 == 0 else (rng.uniform(-1, 1, size=n) if k % 3 == 1 else rng.normal(size=n)**3)
+                      for k in range(d)], 1)
+        x = s @ rng.normal(size=(d, d)) + rng.normal(size=d)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ref = FastICA(max_iter=100, random_state=seed).fit(x)
+            comp, mean, n_iter = ica.fastica_device(x, random_state=seed, max_iter=100, ctx=_CpuCtx())
+        assert n_iter == ref.n_iter_
+        np.testing.assert_allclose(mean, ref.mean_, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(comp, ref.components_, rtol=1e-8, atol=1e-8 * np.abs(ref.components_).max())
+
+
 @pytest.mark.gpu
 def test_gbs_recovers_the_32d_banana_evidence():
     """examples/banana-gbs.ipynb: 32-d rotated bananas (Q = 0.01) under a flat prior on [-15, 15]^32; fiducial
@@ -219,6 +246,49 @@ def test_gbs_recovers_the_48d_cauchy_mixture_evidence():
     assert abs(fiducial - (-254.627)) < 1e-3
     assert 0. < err < 0.2
     assert abs(logz - fiducial) < 3. * err + 0.02
+
+
+@pytest.mark.gpu
+def test_gbs_recovers_the_64d_ring_evidence():
+    """examples/ring-gbs.ipynb: the 64-d ring, logp = -sum_i (x_i^2 + x_{i+1}^2 - 2)^2 (cyclic) under a flat prior on
+    [-5, 5]^64 -- a curved, strongly non-Gaussian ridge in every pair of neighbours.  Fiducial logZ = -114.492 (BASELINE.md
+    section 2, examples/ring-gbs.ipynb:284; the reference's own run printed -114.473 +- 0.065 from 8 x 1500 NUTS draws).
+    Posterior draws come from a vectorised HMC (tests/helpers/ring.py); SIT's rotations run on the device
+    (transforms/ica.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers'))
+    import ring
+    from bayesfast_amd.evidence import GBS
+    xs, acc = ring.hmc_draws(n_chain=8, n_keep=1500, seed=0)
+    assert acc > 0.8
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        logz, err = GBS(sit=dict(random_generator=5), n_q=12000)(xs, ring.logp)
+    assert 0. < err < 0.25
+    assert abs(logz - (-114.492)) < 3. * err + 0.05, (logz, err)
+
+
+@pytest.mark.gpu
+def test_sit_iteration_at_full_size_runs_on_the_device():
+    """One SIT iteration at 64 dimensions x 400 000 points (the size of a config-5 evidence run): with FastICA on the device
+    it takes a fraction of a second (3.6 s with scikit-learn's on the host); the rotation it finds whitens the data."""
+    import time
+    import torch
+    from bayesfast_amd.transforms import SIT
+    rng = np.random.default_rng(2)
+    x = rng.laplace(size=(400000, 64)) @ (np.eye(64) + 0.2 * rng.normal(size=(64, 64)))
+    sit = SIT(n_iter=2, random_generator=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sit.fit(x, n_run=1)          # first call: kernels, allocator
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sit.fit(n_run=1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert dt < 1.5, dt
+    assert sit.i_iter == 2 and np.isfinite(sit.data).all()
+    print('SIT iteration, 400000 x 64: %.3f s' % dt)
 
 
 @pytest.mark.gpu
