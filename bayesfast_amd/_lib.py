@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BFHIP_LIBRARY overrides the in-tree library (tuning builds of tools/variant.sh)
+# BFHIP_LIBRARY overrides the in-tree library (tuning builds of tools/gvariant.sh)
 LIB_PATH = os.environ.get('BFHIP_LIBRARY') or os.path.join(_HERE, 'libbfhip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 

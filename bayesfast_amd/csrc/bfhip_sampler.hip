@@ -1440,7 +1440,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>",
              (nuts && W <= 4 && !g_no_pipe && !args.mat && sampler_plain(m)) ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
     switch (W) {
-#ifndef BF_ONLY_HEADLINE  // tuning builds (tools/variant.sh) compile the 64-d instantiations only
+#ifndef BF_ONLY_HEADLINE  // tuning builds (-DBF_ONLY_HEADLINE) compile the 64-d instantiations only
     case 1: return nuts ? launch_sampler<1, true>(ctx, args) : launch_sampler<1, false>(ctx, args);
     case 2: return nuts ? launch_sampler<2, true>(ctx, args) : launch_sampler<2, false>(ctx, args);
     case 8: return nuts ? launch_sampler<8, true>(ctx, args) : launch_sampler<8, false>(ctx, args);
