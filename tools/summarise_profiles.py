@@ -26,7 +26,7 @@ b = line('bench_line.json')
 FULL = (b or {}).get('roofline', {}).get('kernel') or 'bf_group_kernel'
 KERNEL = FULL.split('<')[0]
 # kernel trace: durations of the sampler dispatches
-kt = [r for r in rows('trace/**/*kernel_trace.csv') if KERNEL in r.get('Kernel_Name', '')]
+kt = [r for r in rows('trace/**/*kernel_trace.csv') if FULL in r.get('Kernel_Name', '')]   # the exact instantiation
 dur = np.array([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6 for r in kt])
 if len(dur):
     res['kernel_trace'] = {'kernel': kt[0]['Kernel_Name'], 'calls': int(len(dur)), 'total_ms': float(dur.sum()), 'avg_ms': float(dur.mean()),
@@ -40,7 +40,7 @@ if st:
 
 
 def counter(pattern, name):
-    v = [float(r['Counter_Value']) for r in rows(pattern) if r.get('Counter_Name') == name and KERNEL in r.get('Kernel_Name', '')]
+    v = [float(r['Counter_Value']) for r in rows(pattern) if r.get('Counter_Name') == name and FULL in r.get('Kernel_Name', '')]
     return v
 
 
