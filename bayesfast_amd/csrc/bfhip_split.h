@@ -4,24 +4,25 @@
 // average whatever it is (profiles/r03_knockouts.log, r03b_debranch_*.log: a trip's time is its instruction count; the
 // pipe could take one every 4).  Here a workgroup is EIGHT waves for the same 16 chains, two per SIMD, with DISJOINT work:
 //
-//   integrator waves 0..3   the leapfrog step and the surrogate's value and gradient: half step, B operands, row tile j of
-//                           S x (and H (x - mu) unless the bound proof holds) on MFMA, second half step, the evaluation's
-//                           partial sums.  They keep q, p, grad, the metric and the A operands; no tree state at all.
-//   bookkeeper waves 4..7   everything NUTS: the U-turn sums of the finished leaf, the tree's scalars (lane per chain, as in
-//                           the group kernel), merges, subtree stack, tree ends, doublings, iteration end, adaptation, the
-//                           momentum draw, output rows.  They run ONE LEAF BEHIND the integrator.
+//   integrator waves 0..3   everything that does not depend on a random draw: the leapfrog step, row tile j of S x (and
+//                           H (x - mu) unless the bound proof holds) on MFMA, the evaluation's sums, the U-turn sums of the
+//                           subtrees the leaf completes and the momentum part of the subtree stack (left p, right p, p_sum per
+//                           level, the tree's ends and p_sum): which subtrees a leaf completes follows from its index alone.
+//   bookkeeper waves 4..7   everything that does: the tree's scalars (lane per chain, as in the group kernel), the
+//                           multinomial merges and the proposal part of the stack, doublings, iteration end, adaptation,
+//                           the momentum draw, output rows.  They run ONE LEAF BEHIND the integrators.
 //
 // The integrator does not wait for the verdict on leaf n: it goes on with leaf n + 1 of the same subtree, which is what
-// happens unless the tree ends or a doubling completes.  Then the bookkeeper's command (restart from the left / right
-// end of the tree with a new signed step, start a new iteration, stop) bumps the chain's EPOCH, and the leaf computed
-// meanwhile carries the old epoch and is dropped -- one idle trip per doubling, in which the bookkeeper works anyway.
+// happens unless the tree ends; at the end of a doubling (which it recognises by itself) it pauses.  The bookkeeper's
+// command (next doubling with a signed step, new iteration, stop) bumps the chain's EPOCH, and a leaf computed under an
+// older epoch is dropped.  A doubling's end therefore costs one trip in which only the bookkeepers work -- a short one.
 // Every leaf that is used is computed from exactly the state the group kernel computes it from, with the same arithmetic
 // in the same order, and the bookkeeper's logic is the group kernel's: samples, statistics, adapted state and random
 // streams are BIT-IDENTICAL to bf_group_kernel's (tests/test_gpu_sampler.py, tests/test_group_emu.py).
 //
 // One trip, two workgroup barriers (three when some chain is outside the bound's proof):
-//   integrator: commands | half step, operands | B1 | tiles | sums, leaf -> LDS | [B2a: evaluation scalars] | B2
-//   bookkeeper: leaf n-1, its sums | U-turn partial sums | B1 | sums, state machine, bookkeeping, commands | [B2a] | B2
+//   integrator: commands | half step, operands | B1 | tiles | [B2a: evaluation scalars] | all sums, momentum stack, leaf -> LDS | B2
+//   bookkeeper: leaf n-1 and its sums | B1 | state machine, proposals, commands | [B2a] | B2
 // Replaces the same reference code as bfhip_group.h (samplers/nuts.py:21-217, base_hmc.py:62-85, integration.py:68-95,
 // modules/poly.py:466-503, step_size.py:10-51, metrics.py:135-237,333-371).
 #pragma once
@@ -29,26 +30,32 @@
 
 struct SplitGeo {
     static constexpr int W = 4, DP = 64, NS = 16, MAXL = BFHIP_MAX_TREEDEPTH, LSS = 5 * MAXL + 1, LSH = 2;
-    // tree vectors in LDS [slot][dimension][chain]: stack level 1 (left p, right p, p_sum, proposal q, proposal gradient),
-    // both ends of the tree (q, p, grad).  The proposal and p_sum live in the bookkeepers' registers.
-    static constexpr int T_STK1 = 0, T_LEFT = 5, T_RIGHT = 8, NTV = 11;
-    // sums posted by the integrators (evaluation) and by the bookkeepers (U-turn checks, start energy)
-    static constexpr int E_KIN = 0, E_VAL = 1, E_B2 = 2, E_DOTJ = 3, NE = 4;
-    static constexpr int U_KIN0 = 0, U_M0 = 1, U_LV = 3, U_EXT = U_LV + 6 * LSH, NU = U_EXT + 6;
+    // vectors in LDS, [slot][dimension][chain]
+    //   integrators: stack level 1's momenta (left p, right p, p_sum), the tree's OTHER end (q, p, grad) -- the end being
+    //                extended is the integrators' own state
+    //   bookkeepers: stack level 1's proposal (q, grad); the start of a new iteration (q, p, grad) for the integrators
+    //   integrators -> bookkeepers: the finished leaf (q, grad)
+    static constexpr int T_STKM = 0, T_OEND = 3, T_STKP = 6, T_START = 8, T_LEAF = 11, NTV = 13;
+    // sums posted by the integrators: the evaluation's and the U-turn checks of the subtrees the leaf completes
+    static constexpr int E_KIN = 0, E_VAL = 1, E_B2 = 2, E_DOTJ = 3, U_M0 = 4, U_LV = 6, U_EXT = U_LV + 6 * LSH, NE = U_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);
-    // per-chain words exchanged between the roles (doubles): command, epoch, signed step | leaf tag, provided logp
-    static constexpr int X_CMD = 0, X_EPOCH = 1, X_EPS = 2, X_TAG = 3, X_LOGP = 4, X_HASLP = 5, NX = 6;
+    // per-chain words exchanged between the roles (doubles): command, epoch, signed step, depth | leaf tag, provided logp
+    static constexpr int X_CMD = 0, X_EPOCH = 1, X_EPS = 2, X_DEPTH = 3, X_TAG = 4, X_LOGP = 5, X_HASLP = 6, NX = 7;
     // per-chain scalars that only the end of an iteration touches (step-size and metric adaptation), parked in LDS
     static constexpr int NCOLD = 10;   // two copies, read / written alternately by iteration parity
     static constexpr size_t lds_doubles() {
-        return (size_t)2 * NS * 64 + 4 * 16 + (size_t)NE * W * 16 + (size_t)NU * W * 16 + (size_t)3 * DP * 16 +
-               (size_t)NTV * DP * 16 + (size_t)16 * LSS + (size_t)DP * 16 + (size_t)NX * 16 + 16 + (size_t)2 * NCOLD * 16;
+        return (size_t)2 * NS * 64 + 4 * 16 + (size_t)NE * W * 16 + (size_t)W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS +
+               (size_t)DP * 16 + (size_t)NX * 16 + 16 + (size_t)2 * NCOLD * 16;
     }
+    // per-chain global scratch, in vectors of DP doubles: 5 per stack level 2 .. MAXL-1 (momenta 0-2: integrators, proposal
+    // 3-4: bookkeepers), then the sums of the merge levels above LSH
     static constexpr int S_DEEP = 5 * (MAXL - 2);
     static constexpr int scratch_slots() { return S_DEEP + (NDEEP * W + DP - 1) / DP; }
 };
 
-enum { SC_CONT = 0, SC_LEFT = 1, SC_RIGHT = 2, SC_STOP = 3 };  // commands; + 4: reload the metric's variances first
+// commands of the bookkeepers: go on | start an iteration at T_START (signed step, depth 0) | evaluate T_START's point with a
+// step of length 0 (the launch's first iteration) | next doubling (signed step, depth) | stop; + 8: reload the metric's variances
+enum { SC_CONT = 0, SC_NEW = 1, SC_INIT = 2, SC_DBL = 3, SC_STOP = 4 };
 // stacked subtree scalars per level: weight (relative to the offset SS_OFF it was stored under), energy and logp of its
 // proposal, accept sum
 enum { SS_W = 0, SS_E, SS_LOGP, SS_ACC, SS_OFF, SS_N };
@@ -67,12 +74,11 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     constexpr int W = G::W, DP = G::DP, NS = G::NS, LSS = G::LSS;
     double *XB = lds;                          // [2][NS][64]   B operands: x | x - mu
     double *PB = XB + 2 * NS * 64;             // [W][16]       per-wave |x - mu|^2 (bound proof)
-    double *RBE = PB + W * 16;                 // [NE][W][16]   evaluation sums (integrators)
-    double *RBU = RBE + G::NE * W * 16;        // [NU][W][16]   U-turn and start-energy sums (bookkeepers)
-    double *LEAF = RBU + G::NU * W * 16;       // [3][DP][16]   the finished leaf: q, p, grad
-    double *TV = LEAF + 3 * DP * 16;           // [NTV][DP][16] tree vectors
-    double *LS = TV + G::NTV * DP * 16;        // [16][LSS]     subtree stack scalars
-    double *VARX = LS + 16 * LSS;              // [DP][16]      the metric's variances, bookkeeper -> integrator
+    double *RBE = PB + W * 16;                 // [NE][W][16]   sums posted by the integrators
+    double *RBK = RBE + G::NE * W * 16;        // [W][16]       the start energy's kinetic part (bookkeepers)
+    double *TV = RBK + W * 16;                 // [NTV][DP][16] vectors (SplitGeo)
+    double *LS = TV + G::NTV * DP * 16;        // [16][LSS]     subtree stack scalars (bookkeepers)
+    double *VARX = LS + 16 * LSS;              // [DP][16]      the metric's variances, bookkeepers -> integrators
     double *XC = VARX + DP * 16;               // [NX][16]      commands / tags
     double *FLG = XC + G::NX * 16;             // [0] some chain is alive  [1] some integrator chain is in a second pass
     double *COLD = FLG + 16;                   // [2][NCOLD][16] adaptation scalars (bookkeepers)
@@ -84,18 +90,39 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     const bool real = chain < a.n_chain;
     const int d = m.d, dbase = 16 * j + gq;
     const double bound_thr = m.alpha * m.alpha * (1. - 1e-9);
-    double *lvb = LEAF + dbase * 16 + c;
     double *tvb = TV + dbase * 16 + c;
     double *vxb = VARX + dbase * 16 + c;
-    auto vec_ld = [](const double *base, int slot, double (&v)[4]) {
-        const double *sp = base + slot * (DP * 16);
+    double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + dbase;
+    double *rbg = a.scratch + ((size_t)(real ? chain : 0) * a.nslot + G::S_DEEP) * DP;  // this chain's deep sums [v][wave]
+    auto tv_ld = [&](int slot, double (&v)[4]) {
+        const double *sp = tvb + slot * (DP * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = sp[64 * r];
     };
-    auto vec_st = [](double *base, int slot, const double (&v)[4]) {
-        double *sp = base + slot * (DP * 16);
+    auto tv_st = [&](int slot, const double (&v)[4]) {
+        double *sp = tvb + slot * (DP * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) sp[64 * r] = v[r];
+    };
+    // subtree stack vector k of level lev >= 1: 0 left p, 1 right p, 2 p_sum (integrators) | 3 proposal q, 4 proposal gradient
+    // (bookkeepers); level 1 in LDS, deeper levels in the context's global scratch
+    auto stk_ld = [&](int lev, int k, double (&v)[4]) {
+        if (lev == 1) {
+            tv_ld(k < 3 ? G::T_STKM + k : G::T_STKP + k - 3, v);
+        } else {
+            const double *sp = sbase + (size_t)((lev - 2) * 5 + k) * DP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sp[4 * r];
+        }
+    };
+    auto stk_st = [&](int lev, int k, const double (&v)[4]) {
+        if (lev == 1) {
+            tv_st(k < 3 ? G::T_STKM + k : G::T_STKP + k - 3, v);
+        } else {
+            double *sp = sbase + (size_t)((lev - 2) * 5 + k) * DP;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[4 * r] = v[r];
+        }
     };
     auto sum4 = [](const double (&v)[4]) -> double { return (v[0] + v[1]) + (v[2] + v[3]); };
     auto sumw = [](const double *rp, int st) -> double { return (rp[0] + rp[st]) + (rp[2 * st] + rp[3 * st]); };
@@ -106,6 +133,11 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         for (int w2 = 1; w2 < W; ++w2) r2 += PB[w2 * 16 + c];
         const bool inside = !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven)
         return !bf_any(!inside);
+    };
+    // merge levels of leaf number i_leaf of a doubling of 2^depth leaves: its trailing one bits
+    auto merge_levels = [](int i_leaf, int depth) -> int {
+        const int t1 = __builtin_ctz(~(unsigned)i_leaf);
+        return t1 < depth ? t1 : depth;
     };
 
 #if defined(BF_SPLIT_ONLY) && !defined(BF_HOST_EMU)  // tuning builds: one role's register needs on its own (the kernel hangs)
@@ -122,40 +154,103 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             afH[s] = m.Hf[(j * NS + s) * 64 + lane];
         }
         double c_lin[4], c_mu[4], q[4], p[4], g[4], var[4];
+        double L0p[4], PSUM[4], pdbl[4];   // the waiting leaf's momentum, the tree's p_sum, the momentum this doubling started from
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             c_lin[r] = m.pd[PD_LIN * DP + dbase + 4 * r];
             c_mu[r] = m.pd[PD_MU * DP + dbase + 4 * r];
-            q[r] = p[r] = g[r] = 0.;
+            q[r] = p[r] = g[r] = L0p[r] = PSUM[r] = pdbl[r] = 0.;
             var[r] = 1.;
         }
         enum { I_IDLE = 0, I_EVAL = 1, I_OOB = 2, I_FIN = 4 };
-        int imode = I_IDLE, epoch_i = 0;
+        int imode = I_IDLE, epoch_i = 0, i_leaf = 0, depth = 0, dir = 1;
+        bool init_eval = false;
         double eps_t = 0., beta = 1., coef2 = 0., logp_keep = 0.;
         unsigned int n_trip = 0, n_trip_h = 0;
+        auto post = [&](int vi, double part) {
+            const double t = bf_xor32_add(bf_xor16_add(part));
+            if (gq == 0) RBE[(vi * W + j) * 16 + c] = t;
+        };
+        auto post_n = [&](int vi0, auto &part) {   // as in the group kernel: N sums reduced over the rows side by side
+            constexpr int N = sizeof(part) / sizeof(double);
+            constexpr int NQ = N / 4, NP = (N % 4) / 2, N1 = N % 2;
+            double sq[NQ > 0 ? 2 * NQ : 1], sp[NP > 0 ? NP : 1], s1[N1 > 0 ? N1 : 1];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                sq[2 * k] = bf_pair16_add(part[4 * k], part[4 * k + 1]);
+                sq[2 * k + 1] = bf_pair16_add(part[4 * k + 2], part[4 * k + 3]);
+            }
+            if constexpr (NP > 0) sp[0] = bf_pair16_add(part[4 * NQ], part[4 * NQ + 1]);
+            if constexpr (N1 > 0) s1[0] = bf_xor16_add(part[N - 1]);
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) sq[k] = bf_pair32_add(sq[2 * k], sq[2 * k + 1]);
+            if constexpr (NP > 0) sp[0] = bf_xor32_add(sp[0]);
+            if constexpr (N1 > 0) s1[0] = bf_xor32_add(s1[0]);
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) RBE[((vi0 + 4 * k + gq) * W + j) * 16 + c] = sq[k];
+            if constexpr (NP > 0) { if (gq < 2) RBE[((vi0 + 4 * NQ + gq) * W + j) * 16 + c] = sp[0]; }
+            if constexpr (N1 > 0) { if (gq == 0) RBE[((vi0 + N - 1) * W + j) * 16 + c] = s1[0]; }
+        };
+        auto post_lv = [&](int lev, int k, double part) {
+            if (lev <= G::LSH) {
+                post(G::U_LV + 6 * (lev - 1) + k, part);
+            } else {
+                const double t = bf_xor32_add(bf_xor16_add(part));
+                if (gq == 0 && real) rbg[(6 * (lev - 1 - G::LSH) + k) * W + j] = t;
+            }
+        };
         bf_sync();  // P0: the bookkeepers' first commands are posted
         int trip_no = -1;
         (void)trip_no;
         for (;;) {
             ++trip_no;
             STRACE(0, 0);
-            // ---- commands of the bookkeepers (posted before the barrier that ended the previous trip) ----
             if (FLG[0] == 0.) break;
+            // ---- commands of the bookkeepers (posted before the barrier that ended the previous trip) ----
             {
                 const int cmd = (int)XC[G::X_CMD * 16 + c];
-                if ((cmd & 3) == SC_STOP) {
+                const int op = cmd & 7;
+                if (op == SC_STOP) {
                     imode = I_IDLE;
-                } else if ((cmd & 3) != SC_CONT) {
-                    const int eo = (cmd & 3) == SC_RIGHT ? G::T_RIGHT : G::T_LEFT;
-                    vec_ld(tvb, eo + 0, q); vec_ld(tvb, eo + 1, p); vec_ld(tvb, eo + 2, g);
-                    if (cmd & 4) vec_ld(vxb, 0, var);
+                } else if (op == SC_NEW || op == SC_INIT) {
+                    // an iteration starts at T_START: Tree.__init__ (nuts.py:24-43) -- both ends and p_sum are the start point
+                    tv_ld(G::T_START + 0, q); tv_ld(G::T_START + 1, p); tv_ld(G::T_START + 2, g);
+                    if (cmd & 8) { const double *sp = vxb; for (int r = 0; r < 4; ++r) var[r] = sp[64 * r]; }
+                    tv_st(G::T_OEND + 0, q); tv_st(G::T_OEND + 1, p); tv_st(G::T_OEND + 2, g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { PSUM[r] = p[r]; pdbl[r] = p[r]; }
                     epoch_i = (int)XC[G::X_EPOCH * 16 + c];
                     eps_t = XC[G::X_EPS * 16 + c];
+                    dir = eps_t < 0. ? -1 : 1;
+                    depth = 0;
+                    i_leaf = 0;
+                    init_eval = op == SC_INIT;
+                    imode = I_EVAL;
+                } else if (op == SC_DBL) {
+                    // the next doubling (nuts.py:71-103 went on): extend the end the new direction points to.  This wave's
+                    // state is the end of the direction just extended (it paused there); the other end waits in T_OEND
+                    const double es = XC[G::X_EPS * 16 + c];
+                    const int nd = es < 0. ? -1 : 1;
+                    if (nd != dir) {
+                        double oq[4], op_[4], og[4];
+                        tv_ld(G::T_OEND + 0, oq); tv_ld(G::T_OEND + 1, op_); tv_ld(G::T_OEND + 2, og);
+                        tv_st(G::T_OEND + 0, q); tv_st(G::T_OEND + 1, p); tv_st(G::T_OEND + 2, g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { q[r] = oq[r]; p[r] = op_[r]; g[r] = og[r]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pdbl[r] = p[r];
+                    epoch_i = (int)XC[G::X_EPOCH * 16 + c];
+                    eps_t = es;
+                    dir = nd;
+                    depth = (int)XC[G::X_DEPTH * 16 + c];
+                    i_leaf = 0;
                     imode = I_EVAL;
                 }
             }
             // ---- phase A: first half of the leapfrog step (integration.py:80-85), B operands, the proof's partial ----
             const bool ev = imode != I_IDLE;
+            const bool any_ev = bf_any(ev);   // (a trip in which every chain waits for its bookkeeper: barriers only)
             double xs[4], xev[4];
             if (imode == I_EVAL) {
                 const double dt = 0.5 * eps_t;
@@ -165,7 +260,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     q[r] = bf_fma(eps_t, var[r] * p[r], q[r]);
                 }
             }
-            {
+            if (any_ev) {
                 double t_r2[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -181,6 +276,12 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
                 if (imode & (I_OOB | I_FIN)) r2p = __builtin_inf();  // passes that need H (x - mu) itself
                 if (gq == 0) PB[j * 16 + c] = r2p;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { xs[r] = 0.; xev[r] = 0.; }
+                if (gq == 0) PB[j * 16 + c] = 0.;
+            }
+            {
                 const bool second = bf_any(imode & (I_OOB | I_FIN));
                 if (tid == 0) FLG[1] = second ? 1. : 0.;   // (every integrator wave holds all 16 chains' modes: wave 0 posts)
             }
@@ -188,10 +289,10 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             bf_sync();  // B1
             STRACE(0, 2);
             // ---- phase B: row tile j of S x and H (x - mu) ----
-            double sx[4], hv[4];
+            double sx[4] = {0., 0., 0., 0.}, hv[4] = {0., 0., 0., 0.};
             const bool skipH = proof_holds();
             const bool extra = !skipH || FLG[1] != 0.;
-            {
+            if (any_ev) {
                 bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
                 constexpr int KH = NS / 2;
 #pragma unroll
@@ -213,37 +314,38 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             STRACE(0, 3);
             // ---- phase C: gradient, second half step, the evaluation's partial sums ----
-            double gn[4], ge[4], pn[4];
+            double ge[4], pn[4];
             const double dt_c = (imode == I_IDLE) ? 0. : 0.5 * eps_t;
-            {
+            bool fin = false, have_lp = false;
+            double logp_new = 0.;
+            if (any_ev) {
                 double t_val[4], t_b2[4], t_kin[4], t_dotj[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    gn[r] = sx[r] + c_lin[r];
+                    const double gn = sx[r] + c_lin[r];
                     t_val[r] = bf_fma(0.5 * xev[r], sx[r], c_lin[r] * xev[r]);
                     const double xm = xs[r] - c_mu[r];
                     t_b2[r] = xm * hv[r];
-                    t_dotj[r] = gn[r] * xm;  // dot(jj_0, x - mu), poly.py:496
-                    double t = gn[r];
+                    t_dotj[r] = gn * xm;  // dot(jj_0, x - mu), poly.py:496
+                    double t = gn;
                     if (imode == (I_FIN | I_OOB)) t = t + coef2 * (hv[r] / beta);  // poly.py:496-503
                     ge[r] = t;
                     pn[r] = bf_fma(dt_c, ge[r], p[r]);
                     t_kin[r] = pn[r] * (var[r] * pn[r]);
                 }
-                const double s_kin = bf_xor32_add(bf_xor16_add(sum4(t_kin)));
-                const double s_val = bf_xor32_add(bf_xor16_add(sum4(t_val)));
-                if (gq == 0) { RBE[(G::E_KIN * W + j) * 16 + c] = s_kin; RBE[(G::E_VAL * W + j) * 16 + c] = s_val; }
-                if (extra) {
-                    const double s_b2 = bf_xor32_add(bf_xor16_add(sum4(t_b2)));
-                    const double s_dj = bf_xor32_add(bf_xor16_add(sum4(t_dotj)));
-                    if (gq == 0) { RBE[(G::E_B2 * W + j) * 16 + c] = s_b2; RBE[(G::E_DOTJ * W + j) * 16 + c] = s_dj; }
+                if (!extra) {
+                    double e2[2] = {sum4(t_kin), sum4(t_val)};
+                    post_n(G::E_KIN, e2);
+                    fin = ev;  // first pass, inside the bound (proven): the value is complete (the bookkeepers add it up)
+                } else {
+                    double e4[4] = {sum4(t_kin), sum4(t_val), sum4(t_b2), sum4(t_dotj)};
+                    post_n(G::E_KIN, e4);
                 }
-            }
-            bool fin = false, have_lp = false;
-            double logp_new = 0.;
-            if (!extra) {
-                fin = ev;  // first pass, inside the bound (proven): the value is complete (the bookkeeper adds it up itself)
             } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ge[r] = 0.; pn[r] = 0.; }
+            }
+            if (extra) {
                 bf_sync();  // B2a: this trip's sums
                 if (ev) {
                     if (imode & I_FIN) {
@@ -276,11 +378,101 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     }
                 }
             }
+            // ---- the finished leaf: its state, the U-turn sums of the subtrees it completes (nuts.py:146-161 per merge,
+            // :88-101 per doubling), the momentum part of the subtree stack.  None of it depends on a random draw. ----
+            const bool leafy = fin && !init_eval;
+            int nm = 0;
             if (fin) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { p[r] = pn[r]; g[r] = ge[r]; }  // integration.py:90
-                vec_st(lvb, 0, q); vec_st(lvb, 1, p); vec_st(lvb, 2, g);
+                tv_st(G::T_LEAF + 0, q); tv_st(G::T_LEAF + 1, g);
                 imode = I_EVAL;
+            }
+            nm = leafy ? merge_levels(i_leaf, depth) : 0;
+            {
+                double tTL[4], tTPs[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { tTL[r] = p[r]; tTPs[r] = p[r]; }
+                if (bf_any(leafy && nm >= 1)) {  // level 0: the waiting leaf L0 and the new one (nuts.py:150-151)
+                    double t0[4], t1[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double ps0 = L0p[r] + p[r];
+                        t0[r] = ps0 * (var[r] * L0p[r]);
+                        t1[r] = ps0 * (var[r] * p[r]);
+                        if (leafy && nm >= 1) { tTPs[r] = ps0; tTL[r] = L0p[r]; }
+                    }
+                    double m2[2] = {sum4(t0), sum4(t1)};
+                    post_n(G::U_M0, m2);
+                }
+                for (int lev = 1; bf_any(leafy && lev < nm); ++lev) {
+                    const bool on = leafy && lev < nm;
+                    double A[4] = {0., 0., 0., 0.}, B[4] = {0., 0., 0., 0.}, S1[4] = {0., 0., 0., 0.};
+                    if (on) { stk_ld(lev, 0, A); stk_ld(lev, 1, B); stk_ld(lev, 2, S1); }
+                    double t[6][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double psum = S1[r] + tTPs[r];
+                        const double vA = var[r] * A[r], vB = var[r] * B[r], vC = var[r] * tTL[r], vD = var[r] * p[r];
+                        const double ps1 = S1[r] + tTL[r];   // :155-157
+                        const double ps2 = B[r] + tTPs[r];   // :158-160
+                        t[0][r] = psum * vA; t[1][r] = psum * vD; t[2][r] = ps1 * vA; t[3][r] = ps1 * vC;
+                        t[4][r] = ps2 * vB; t[5][r] = ps2 * vD;
+                        if (on) { tTL[r] = A[r]; tTPs[r] = psum; }
+                    }
+                    if (lev <= G::LSH) {
+                        double s6[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) s6[k] = sum4(t[k]);
+                        post_n(G::U_LV + 6 * (lev - 1), s6);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) post_lv(lev, k, sum4(t[k]));
+                    }
+                }
+                const bool dbl_end = leafy && nm == depth;
+                if (bf_any(dbl_end)) {  // the doubling completes: Tree.extend's checks, nuts.py:86-101
+                    double Oe[4] = {0., 0., 0., 0.};
+                    if (dbl_end) tv_ld(G::T_OEND + 1, Oe);
+                    double t[6][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double Lp = dir > 0 ? Oe[r] : pdbl[r], Rp = dir > 0 ? pdbl[r] : Oe[r];   // the tree's ends before this doubling
+                        const double ps = PSUM[r] + tTPs[r];  // :86 (in place)
+                        const double vN = var[r] * p[r], vT = var[r] * tTL[r], vL = var[r] * Lp, vR = var[r] * Rp;
+                        // (reference behaviour, kept on purpose: leftmost_p_sum / rightmost_p_sum alias the updated p_sum)
+                        if (dir > 0) {
+                            const double ps1 = ps + tTL[r], ps2 = Rp + tTPs[r];
+                            t[0][r] = ps * vL; t[1][r] = ps * vN; t[2][r] = ps1 * vL; t[3][r] = ps1 * vT;
+                            t[4][r] = ps2 * vR; t[5][r] = ps2 * vN;
+                        } else {
+                            const double ps1 = tTPs[r] + Lp, ps2 = tTL[r] + ps;
+                            t[0][r] = ps * vN; t[1][r] = ps * vR; t[2][r] = ps1 * vN; t[3][r] = ps1 * vL;
+                            t[4][r] = ps2 * vT; t[5][r] = ps2 * vR;
+                        }
+                        if (dbl_end) PSUM[r] = ps;
+                    }
+                    double s6[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s6[k] = sum4(t[k]);
+                    post_n(G::U_EXT, s6);
+                }
+                // the momentum part of what the tree does with this leaf (the bookkeepers do the rest when they get to it)
+                if (leafy) {
+                    if (dbl_end) {
+                        imode = I_IDLE;   // this state is the tree's new end; the bookkeepers say where the next doubling goes
+                    } else {
+                        if (nm == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) L0p[r] = p[r];
+                        } else {
+                            stk_st(nm, 0, tTL); stk_st(nm, 1, p); stk_st(nm, 2, tTPs);
+                        }
+                        i_leaf += 1;
+                    }
+                } else if (fin) {
+                    imode = I_IDLE;       // the launch's first evaluation: the bookkeepers start the iteration
+                }
             }
             if (wv == 0 && gq == 0) {
                 XC[G::X_TAG * 16 + c] = fin ? (double)epoch_i : -1.;
@@ -303,11 +495,11 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     // =========================================================================================================
     const bool writer = j == 0 && gq == 0;
     const int nw = a.cfg.n_warmup;
-    double var[4], L0p[4], L0q[4], L0g[4], PSUM[4], PRq[4], PRg[4];
+    double var[4], L0q[4], L0g[4], PRq[4], PRg[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         var[r] = 1.;
-        L0p[r] = L0q[r] = L0g[r] = PSUM[r] = PRq[r] = PRg[r] = 0.;
+        L0q[r] = L0g[r] = PRq[r] = PRg[r] = 0.;
     }
     uint64_t rs[4] = {0, 0, 0, 0};
     int mode = M_DONE, i_iter = 0, err = 0, epoch = 0;
@@ -322,13 +514,10 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     static_assert(K_ADAPT_WINDOW + 1 == G::NCOLD, "cold scalars");
     auto cold = [&](int it) -> double * { return COLD + (it & 1) * (G::NCOLD * 16) + c; };
     bool need_E0 = false;
-    double kin0_part = 0.;
     unsigned long long nlf = 0;
 
     double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
     double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
-    double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + dbase;
-    double *rbg = a.scratch + ((size_t)(real ? chain : 0) * a.nslot + G::S_DEEP) * DP;
     double *lsc = LS + c * LSS;
 
     auto load_vec = [&](int field, double (&v)[4], double pad) {
@@ -345,70 +534,18 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             if (dim < d) vecp[field * d + dim] = v[r];
         }
     };
-    auto tv_ld = [&](int slot, double (&v)[4]) { vec_ld(tvb, slot, v); };
-    auto tv_st = [&](int slot, const double (&v)[4]) { vec_st(tvb, slot, v); };
-    auto stk_ld = [&](int lev, int k, double (&v)[4]) {
-        if (lev == 1) {
-            tv_ld(G::T_STK1 + k, v);
-        } else {
-            const double *sp = sbase + (size_t)((lev - 2) * 5 + k) * DP;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = sp[4 * r];
-        }
-    };
-    auto stk_st = [&](int lev, int k, const double (&v)[4]) {
-        if (lev == 1) {
-            tv_st(G::T_STK1 + k, v);
-        } else {
-            double *sp = sbase + (size_t)((lev - 2) * 5 + k) * DP;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sp[4 * r] = v[r];
-        }
-    };
-    auto post = [&](int vi, double part) {
-        const double t = bf_xor32_add(bf_xor16_add(part));
-        if (gq == 0) RBU[(vi * W + j) * 16 + c] = t;
-    };
-    auto post_n = [&](int vi0, auto &part) {   // as in the group kernel: N sums reduced over the rows side by side
-        constexpr int N = sizeof(part) / sizeof(double);
-        constexpr int NQ = N / 4, NP = (N % 4) / 2, N1 = N % 2;
-        double sq[NQ > 0 ? 2 * NQ : 1], sp[NP > 0 ? NP : 1], s1[N1 > 0 ? N1 : 1];
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) {
-            sq[2 * k] = bf_pair16_add(part[4 * k], part[4 * k + 1]);
-            sq[2 * k + 1] = bf_pair16_add(part[4 * k + 2], part[4 * k + 3]);
-        }
-        if constexpr (NP > 0) sp[0] = bf_pair16_add(part[4 * NQ], part[4 * NQ + 1]);
-        if constexpr (N1 > 0) s1[0] = bf_xor16_add(part[N - 1]);
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) sq[k] = bf_pair32_add(sq[2 * k], sq[2 * k + 1]);
-        if constexpr (NP > 0) sp[0] = bf_xor32_add(sp[0]);
-        if constexpr (N1 > 0) s1[0] = bf_xor32_add(s1[0]);
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) RBU[((vi0 + 4 * k + gq) * W + j) * 16 + c] = sq[k];
-        if constexpr (NP > 0) { if (gq < 2) RBU[((vi0 + 4 * NQ + gq) * W + j) * 16 + c] = sp[0]; }
-        if constexpr (N1 > 0) { if (gq == 0) RBU[((vi0 + N - 1) * W + j) * 16 + c] = s1[0]; }
-    };
-    auto rd_n = [&](const double *RB, int vi0, auto &out) {
+    auto rd_n = [&](int vi0, auto &out) {
         constexpr int N = sizeof(out) / sizeof(double);
         double t[N][W];
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int w2 = 0; w2 < W; ++w2) t[i][w2] = RB[((vi0 + i) * W + w2) * 16 + c];
+            for (int w2 = 0; w2 < W; ++w2) t[i][w2] = RBE[((vi0 + i) * W + w2) * 16 + c];
 #pragma unroll
         for (int i = 0; i < N; ++i) out[i] = (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
     };
-    auto post_lv = [&](int lev, int k, double part) {
-        if (lev <= G::LSH) {
-            post(G::U_LV + 6 * (lev - 1) + k, part);
-        } else {
-            const double t = bf_xor32_add(bf_xor16_add(part));
-            if (gq == 0 && real) rbg[(6 * (lev - 1 - G::LSH) + k) * W + j] = t;
-        }
-    };
     auto rd_lv = [&](int lev, int k) -> double {
-        if (lev <= G::LSH) return sumw(RBU + ((G::U_LV + 6 * (lev - 1) + k) * W) * 16 + c, 16);
+        if (lev <= G::LSH) return sumw(RBE + ((G::U_LV + 6 * (lev - 1) + k) * W) * 16 + c, 16);
         return sumw(rbg + (6 * (lev - 1 - G::LSH) + k) * W, 1);
     };
     // metric.random (metrics.py:83-86), the group kernel's stream: one xoshiro draw keys a SplitMix64 counter stream,
@@ -432,24 +569,23 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
         theirs[0] = bf_xor16_get(theirs[0]);
         theirs[1] = bf_xor16_get(theirs[1]);
-        if (on) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double z = ((r >> 1) == godd) ? mine[r & 1] : theirs[r & 1];
-                pnew[r] = (dbase + 4 * r < d) ? (1. / bf_sqrt(var[r])) * z : 0.;  // var^-1/2 z, metrics.py:83-86
-            }
+        for (int r = 0; r < 4; ++r) {
+            const double z = ((r >> 1) == godd) ? mine[r & 1] : theirs[r & 1];
+            pnew[r] = (on && dbase + 4 * r < d) ? (1. / bf_sqrt(var[r])) * z : 0.;  // var^-1/2 z, metrics.py:83-86
         }
     };
-    // command to the integrators: restart this chain from an end of the tree with the signed step eps_s (a new epoch)
-    auto command = [&](int cmd, double eps_s) {
+    // command to the integrators (a new epoch): cmd, the signed step, the depth of the tree
+    auto command = [&](int cmd, double eps_s, int dep) {
         epoch += 1;
         if (writer) {
             XC[G::X_CMD * 16 + c] = (double)cmd;
             XC[G::X_EPOCH * 16 + c] = (double)epoch;
             XC[G::X_EPS * 16 + c] = eps_s;
+            XC[G::X_DEPTH * 16 + c] = (double)dep;
         }
     };
-    // Tree.__init__ (nuts.py:24-43) at (sq, pnew, sg): the proposal is the starting point; the integrators restart there
+    // Tree.__init__ (nuts.py:24-43) at (sq, pnew, sg): the proposal is the starting point; the integrators start there
     auto tree_reset = [&](const double (&sq)[4], const double (&pnew)[4], const double (&sg)[4], bool reload_var) {
         tree_W = 1.;
         w_off = 0.;
@@ -457,18 +593,19 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
         eps = bf_exp(cold(i_iter)[((i_iter < nw) ? K_LOG_STEP : K_LOG_BAR) * 16]);  // step_size.py:25-29: exp(log_step) / exp(log_bar)
         dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
-        tv_st(G::T_LEFT + 0, sq); tv_st(G::T_LEFT + 1, pnew); tv_st(G::T_LEFT + 2, sg);
-        tv_st(G::T_RIGHT + 0, sq); tv_st(G::T_RIGHT + 1, pnew); tv_st(G::T_RIGHT + 2, sg);
+        tv_st(G::T_START + 0, sq); tv_st(G::T_START + 1, pnew); tv_st(G::T_START + 2, sg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { PRq[r] = sq[r]; PRg[r] = sg[r]; PSUM[r] = pnew[r]; }
-        if (reload_var) vec_st(vxb, 0, var);
-        command((dir > 0 ? SC_RIGHT : SC_LEFT) | (reload_var ? 4 : 0), eps * (double)dir);
+        for (int r = 0; r < 4; ++r) { PRq[r] = sq[r]; PRg[r] = sg[r]; }
+        if (reload_var) { double *sp = vxb; for (int r = 0; r < 4; ++r) sp[64 * r] = var[r]; }
+        command(SC_NEW | (reload_var ? 8 : 0), eps * (double)dir, 0);
         mode = M_LEAF;
+        // the start energy needs the kinetic energy of the new momentum: its partial sums cross the next barrier
         double t_k0[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t_k0[r] = pnew[r] * (var[r] * pnew[r]);  // metrics.py:88-91
-        kin0_part = sum4(t_k0);
+        const double kp = sum4(t_k0);
         need_E0 = true;
+        return kp;
     };
 
     double q0[4];
@@ -503,13 +640,15 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // the launch's first iteration evaluates its starting point: a step of length 0 from (q0, 0, 0) (base_hmc.py:70)
         double z4[4] = {0., 0., 0., 0.};
         if (mode == M_INIT) {
-            tv_st(G::T_LEFT + 0, q0); tv_st(G::T_LEFT + 1, z4); tv_st(G::T_LEFT + 2, z4);
-            vec_st(vxb, 0, var);
-            command(SC_LEFT | 4, 0.);
+            tv_st(G::T_START + 0, q0); tv_st(G::T_START + 1, z4); tv_st(G::T_START + 2, z4);
+            double *sp = vxb;
+            for (int r = 0; r < 4; ++r) sp[64 * r] = var[r];
+            command(SC_INIT | 8, 0., 0);
         } else if (writer) {
             XC[G::X_CMD * 16 + c] = (double)SC_STOP;
             XC[G::X_EPOCH * 16 + c] = 0.;
             XC[G::X_EPS * 16 + c] = 0.;
+            XC[G::X_DEPTH * 16 + c] = 0.;
         }
         if (writer) XC[G::X_TAG * 16 + c] = -1.;
         const bool alive = bf_any(mode != M_DONE);
@@ -523,133 +662,72 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         ++trip_no;
         STRACE(1, 0);
         if (FLG[0] == 0.) break;
-        // ---- the leaf the integrators finished in the previous trip (if it belongs to this epoch) ----
+        // ---- the leaf the integrators finished in the previous trip (if it belongs to this epoch) and ALL its sums: nothing
+        // of this trip is needed, so everything is read before the first barrier ----
         const bool have = mode != M_DONE && (int)XC[G::X_TAG * 16 + c] == epoch;
-        double lq[4], lp[4], lg[4];
-        vec_ld(lvb, 0, lq); vec_ld(lvb, 1, lp); vec_ld(lvb, 2, lg);
-        double sv_e[2];
-        rd_n(RBE, G::E_KIN, sv_e);
-        const double logp_new = (XC[G::X_HASLP * 16 + c] != 0.) ? XC[G::X_LOGP * 16 + c] : (m.c0 + sv_e[1]) + 0.;
-        const double kin = sv_e[0];
-        // ---- U-turn sums of the subtrees this leaf completes (nuts.py:146-161 per merge, :88-101 per doubling) ----
-        double tTL[4], tTPs[4], tPS[4];
-        int nm = 0;
         const bool is_leaf = have && mode == M_LEAF;
-        {
-            const int t1 = __builtin_ctz(~(unsigned)i_leaf);
-            nm = is_leaf ? (t1 < depth ? t1 : depth) : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { tTL[r] = lp[r]; tTPs[r] = lp[r]; tPS[r] = 0.; }
+        const int nm = is_leaf ? merge_levels(i_leaf, depth) : 0;
         const bool any_m0 = bf_any(is_leaf && nm >= 1);
         const bool any_lv1 = bf_any(is_leaf && nm >= 2);
         const bool any_ext = bf_any(is_leaf && nm == depth);
-        if (any_m0) {  // level 0: the waiting leaf L0 and the new one (nuts.py:150-151)
-            double t0[4], t1[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double ps0 = L0p[r] + lp[r];
-                t0[r] = ps0 * (var[r] * L0p[r]);
-                t1[r] = ps0 * (var[r] * lp[r]);
-                if (is_leaf && nm >= 1) { tTPs[r] = ps0; tTL[r] = L0p[r]; }
-            }
-            double m2[2] = {sum4(t0), sum4(t1)};
-            post_n(G::U_M0, m2);
-        }
-        for (int lev = 1; bf_any(is_leaf && lev < nm); ++lev) {
-            const bool on = is_leaf && lev < nm;
-            double A[4] = {0., 0., 0., 0.}, B[4] = {0., 0., 0., 0.}, S1[4] = {0., 0., 0., 0.};
-            if (on) { stk_ld(lev, 0, A); stk_ld(lev, 1, B); stk_ld(lev, 2, S1); }
-            double t[6][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double psum = S1[r] + tTPs[r];
-                const double vA = var[r] * A[r], vB = var[r] * B[r], vC = var[r] * tTL[r], vD = var[r] * lp[r];
-                const double ps1 = S1[r] + tTL[r];   // :155-157
-                const double ps2 = B[r] + tTPs[r];   // :158-160
-                t[0][r] = psum * vA; t[1][r] = psum * vD; t[2][r] = ps1 * vA; t[3][r] = ps1 * vC;
-                t[4][r] = ps2 * vB; t[5][r] = ps2 * vD;
-                if (on) { tTL[r] = A[r]; tTPs[r] = psum; }
-            }
-            if (lev <= G::LSH) {
-                double s6[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s6[k] = sum4(t[k]);
-                post_n(G::U_LV + 6 * (lev - 1), s6);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) post_lv(lev, k, sum4(t[k]));
-            }
-        }
-        if (any_ext) {  // the doubling completes: Tree.extend's checks, nuts.py:86-101
-            const bool on = is_leaf && nm == depth;
-            double Lp[4] = {0., 0., 0., 0.}, Rp[4] = {0., 0., 0., 0.};
-            if (on) { tv_ld(G::T_LEFT + 1, Lp); tv_ld(G::T_RIGHT + 1, Rp); }
-            double t[6][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double ps = PSUM[r] + tTPs[r];  // :86 (in place)
-                const double vN = var[r] * lp[r], vT = var[r] * tTL[r], vL = var[r] * Lp[r], vR = var[r] * Rp[r];
-                // (reference behaviour, kept on purpose: leftmost_p_sum / rightmost_p_sum alias the updated p_sum)
-                if (dir > 0) {
-                    const double ps1 = ps + tTL[r], ps2 = Rp[r] + tTPs[r];
-                    t[0][r] = ps * vL; t[1][r] = ps * vN; t[2][r] = ps1 * vL; t[3][r] = ps1 * vT;
-                    t[4][r] = ps2 * vR; t[5][r] = ps2 * vN;
-                } else {
-                    const double ps1 = tTPs[r] + Lp[r], ps2 = tTL[r] + ps;
-                    t[0][r] = ps * vN; t[1][r] = ps * vR; t[2][r] = ps1 * vN; t[3][r] = ps1 * vL;
-                    t[4][r] = ps2 * vT; t[5][r] = ps2 * vR;
-                }
-                if (on) tPS[r] = ps;
-            }
-            double s6[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s6[k] = sum4(t[k]);
-            post_n(G::U_EXT, s6);
-        }
         const bool any_e0 = bf_any(need_E0);
-        if (any_e0) post(G::U_KIN0, kin0_part);
+        double lq[4], lg[4];
+        tv_ld(G::T_LEAF + 0, lq); tv_ld(G::T_LEAF + 1, lg);
+        double sv_e[2], sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
+        rd_n(G::E_KIN, sv_e);
+        if (any_m0) rd_n(G::U_M0, sv_m0);
+        if (any_lv1) rd_n(G::U_LV, sv_l1);
+        if (any_ext) rd_n(G::U_EXT, sv_x);
+        bool turn_deep = false;   // U-turn checks of the merge levels above 1, in the order the merges take them
+        int lev_turn = 1 << 30;   // the first level >= 2 whose check says turning
+        if (bf_any(is_leaf && nm >= 3)) {
+            for (int lev = 2; lev < nm; ++lev) {
+                bool t = false;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t = t || (rd_lv(lev, k) <= 0.);
+                if (t && !turn_deep) { turn_deep = true; lev_turn = lev; }
+            }
+        }
+        const double logp_new = (XC[G::X_HASLP * 16 + c] != 0.) ? XC[G::X_LOGP * 16 + c] : (m.c0 + sv_e[1]) + 0.;
+        const double kin = sv_e[0];
+        double kin0 = 0.;
+        if (any_e0) kin0 = sumw(RBK + c, 16);
         STRACE(1, 1);
         bf_sync();  // B1
         STRACE(1, 2);
         const bool extra = !proof_holds() || FLG[1] != 0.;
         if (writer) XC[G::X_CMD * 16 + c] = (double)SC_CONT;   // (the integrators took the previous trip's command before B1)
 
-        // ---- this trip's sums ----
-        double sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
-        if (any_e0) rd_n(RBU, G::U_KIN0, sv_k0);
-        if (any_m0) rd_n(RBU, G::U_M0, sv_m0);
-        if (any_lv1) rd_n(RBU, G::U_LV, sv_l1);
-        if (any_ext) rd_n(RBU, G::U_EXT, sv_x);
         const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93
         // the start energy of an iteration that began at the end of the previous trip
-        if (any_e0 && need_E0 && mode != M_DONE) {
-            const double E0 = 0.5 * sv_k0[0] - prop_logp;  // integration.py:28-34
+        if (need_E0 && mode != M_DONE) {
+            const double E0 = 0.5 * kin0 - prop_logp;  // integration.py:28-34
             if (!(bf_fabs(E0) <= BF_DBL_MAX)) err = 1;           // base_hmc.py:72-76
             start_energy = E0;
             prop_E = E0;
             need_E0 = false;
         }
-
         STRACE(1, 3);
         // ---- per-chain state machine (bfhip_group.h) ----
         enum { S_NONE, S_MERGE, S_ABORT, S_DBL_END, S_END };
         int st = S_NONE, lev = 0, src = -1;
-        double dE = 0., aw = 0., sc_ = 1.;
+        double dE = 0., aw = 0.;
         double T_W = 0., T_acc = 0., T_E = 0., T_logp = 0.;   // the finished subtree: weight, accept sum, its proposal's energy and logp
         bool resc = false;
         const bool ok = have && err == 0;
         const bool is_init = ok && mode == M_INIT, leaf = ok && mode == M_LEAF;
+        double kin0_part = 0.;
+        bool post_k0 = false;
         if (bf_any(is_init)) {
             if (is_init) {
                 // BaseHMC.astep start (base_hmc.py:70-76): the value and gradient at the chain's position; the start energy
-                // follows with the kinetic energy of the momentum drawn at the launch's start
+                // follows with the kinetic energy of the momentum drawn now
                 prop_logp = logp_new;
                 if (!(bf_fabs(logp_new) <= BF_DBL_MAX)) err = 1;
             }
             double pnew[4];
             draw_momentum(is_init, pnew);   // metric.random (the first draw of the chain's stream in this launch)
-            if (is_init && err == 0) tree_reset(lq, pnew, lg, false);
+            if (is_init && err == 0) { kin0_part = tree_reset(lq, pnew, lg, false); post_k0 = true; }
         }
         if (leaf) {
             nlf += 1;
@@ -667,7 +745,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             resc = aw > 600.;
         }
         if (resc) {  // (rare) the weights follow a new offset; the stacked subtrees' weights are rescaled when they are read
-            sc_ = bf_exp(-aw);
+            const double sc_ = bf_exp(-aw);
             tree_W = tree_W * sc_;
             L0_W *= sc_;
             w_off = w_off + aw;
@@ -698,8 +776,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
                     for (int k = 0; k < 6; ++k) turning = turning || (sv_l1[k] <= 0.);
                 } else {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) turning = turning || (rd_lv(lev, k) <= 0.);
+                    turning = lev == lev_turn;   // (read before the barrier; levels above a turning one are never reached)
                 }
                 const double *lsp = lsc + lev * SS_N;
                 double lw = lsp[SS_W];
@@ -719,10 +796,10 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             if (st == S_MERGE) {
                 if (lev < depth) {
-                    // the subtree waits for its right sibling
+                    // the subtree waits for its right sibling: the proposal part (the integrators keep the momenta)
                     if (lev == 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { L0p[r] = lp[r]; L0q[r] = lq[r]; L0g[r] = lg[r]; }
+                        for (int r = 0; r < 4; ++r) { L0q[r] = lq[r]; L0g[r] = lg[r]; }
                         L0_W = T_W; L0_acc = T_acc; L0_E = E_new; L0_logp = logp_new;
                     } else {
                         double tq[4], tg[4];
@@ -736,7 +813,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                             stk_ld(src, 3, tq);
                             stk_ld(src, 4, tg);
                         }
-                        stk_st(lev, 0, tTL); stk_st(lev, 1, lp); stk_st(lev, 2, tTPs); stk_st(lev, 3, tq); stk_st(lev, 4, tg);
+                        stk_st(lev, 3, tq); stk_st(lev, 4, tg);
                         if (writer) {
                             double *lsp = lsc + lev * SS_N;
                             lsp[SS_W] = T_W; lsp[SS_ACC] = T_acc; lsp[SS_E] = T_E; lsp[SS_LOGP] = T_logp; lsp[SS_OFF] = w_off;
@@ -784,19 +861,13 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 bool turning = false;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) turning = turning || (sv_x[k] <= 0.);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) PSUM[r] = tPS[r];
-                {
-                    const int eo = (dir > 0) ? G::T_RIGHT : G::T_LEFT;
-                    tv_st(eo + 0, lq); tv_st(eo + 1, lp); tv_st(eo + 2, lg);
-                }
                 if (turning || depth >= a.cfg.max_treedepth) {
                     st = S_END;
                 } else {
                     const int nd = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
                     dir = nd;
                     i_leaf = 0;
-                    command(nd > 0 ? SC_RIGHT : SC_LEFT, eps * (double)nd);   // the integrators go on from that end
+                    command(SC_DBL, eps * (double)nd, depth);   // the integrators extend that end
                     st = S_NONE;
                 }
             }
@@ -893,10 +964,10 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
                 if (i_iter < a.iter_end) {
                     new_iter = true;
-                    reload = var_changed;   // (travels with the new iteration's restart command)
+                    reload = var_changed;   // (travels with the new iteration's command)
                 } else {
                     mode = M_DONE;
-                    command(SC_STOP, 0.);
+                    command(SC_STOP, 0., 0);
                 }
             }
             // next iteration: metric.random, then the tree starts at the proposal with its value and gradient
@@ -907,13 +978,18 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     double sq[4], sg[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { sq[r] = PRq[r]; sg[r] = PRg[r]; }
-                    tree_reset(sq, pnew, sg, reload);
+                    kin0_part = tree_reset(sq, pnew, sg, reload);
+                    post_k0 = true;
                 }
             }
         }
+        if (bf_any(post_k0)) {   // the new momentum's kinetic energy, summed over the bookkeeper waves across the next barrier
+            const double t = bf_xor32_add(bf_xor16_add(post_k0 ? kin0_part : 0.));
+            if (gq == 0 && post_k0) RBK[j * 16 + c] = t;
+        }
         if (err != 0 && mode != M_DONE) {
             mode = M_DONE;
-            command(SC_STOP, 0.);
+            command(SC_STOP, 0., 0);
         }
         STRACE(1, 4);
         if (extra) bf_sync();  // B2a (the integrators read their sums)
