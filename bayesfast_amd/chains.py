@@ -8,10 +8,10 @@ from .device import DeviceDensity, _ptr
 
 __all__ = ['DeviceChains']
 
-# what 'auto' runs while the trees of a group are in step: 'group', or 'split' (eight waves per 16 chains, two per SIMD with
-# disjoint work; NUTS on the plain surrogate at 33 <= d <= 64, the library runs everything else as 'group').  Same results
-# either way, bit for bit; 'split' is the slower one today (8.3 against 11.1 x 10^8 on the headline)
-IN_STEP_LAYOUT = __import__('os').environ.get('BFHIP_IN_STEP_LAYOUT', 'group')
+# what 'auto' runs while the trees of a group are in step: 'split' (eight waves per 16 chains, two per SIMD with disjoint work:
+# integrator and bookkeeper waves; NUTS on the plain surrogate at 33 <= d <= 64 -- the library runs everything else as 'group')
+# or 'group'.  Same results either way, bit for bit; 'split' is 3 % (7-leaf trees) to 13 % (15-leaf trees) faster
+IN_STEP_LAYOUT = __import__('os').environ.get('BFHIP_IN_STEP_LAYOUT', 'split')
 
 
 def _torch():

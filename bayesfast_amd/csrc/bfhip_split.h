@@ -13,9 +13,12 @@
 //                           the momentum draw, output rows.  They run ONE LEAF BEHIND the integrators.
 //
 // The integrator does not wait for the verdict on leaf n: it goes on with leaf n + 1 of the same subtree, which is what
-// happens unless the tree ends; at the end of a doubling (which it recognises by itself) it pauses.  The bookkeeper's
-// command (next doubling with a signed step, new iteration, stop) bumps the chain's EPOCH, and a leaf computed under an
-// older epoch is dropped.  A doubling's end therefore costs one trip in which only the bookkeepers work -- a short one.
+// happens unless the tree ends.  At the end of a doubling (which it recognises by itself) it needs the next direction: the
+// bookkeeper ANNOUNCES it one leaf early, read ahead from the chain's random stream -- the number of draws the pending
+// bookkeeping will consume is fixed by the tree's structure (one per merge level, one for the proposal swap, then the
+// direction: nuts.py:163-167,81-83,210) as long as the tree goes on, and if it does not the announced doubling is never used.
+// Every real command (new iteration, stop) bumps the chain's EPOCH past the announced one, and a leaf computed under an
+// epoch the bookkeeper did not reach is dropped: one wasted evaluation per iteration, in a trip the bookkeepers need anyway.
 // Every leaf that is used is computed from exactly the state the group kernel computes it from, with the same arithmetic
 // in the same order, and the bookkeeper's logic is the group kernel's: samples, statistics, adapted state and random
 // streams are BIT-IDENTICAL to bf_group_kernel's (tests/test_gpu_sampler.py, tests/test_group_emu.py).
@@ -40,9 +43,9 @@ struct SplitGeo {
     static constexpr int E_KIN = 0, E_VAL = 1, E_B2 = 2, E_DOTJ = 3, U_M0 = 4, U_LV = 6, U_EXT = U_LV + 6 * LSH, NE = U_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);
     // per-chain words exchanged between the roles (doubles): command, epoch, signed step, depth | leaf tag, provided logp
-    static constexpr int X_CMD = 0, X_EPOCH = 1, X_EPS = 2, X_DEPTH = 3, X_TAG = 4, X_LOGP = 5, X_HASLP = 6, NX = 7;
+    static constexpr int X_CMD = 0, X_EPOCH = 1, X_EPS = 2, X_DEPTH = 3, X_ANN = 4, X_TAG = 5, X_LOGP = 6, X_HASLP = 7, NX = 8;
     // per-chain scalars that only the end of an iteration touches (step-size and metric adaptation), parked in LDS
-    static constexpr int NCOLD = 10;   // two copies, read / written alternately by iteration parity
+    static constexpr int NCOLD = 12;   // two copies, read / written alternately by iteration parity
     static constexpr size_t lds_doubles() {
         return (size_t)2 * NS * 64 + 4 * 16 + (size_t)NE * W * 16 + (size_t)W * 16 + (size_t)NTV * DP * 16 + (size_t)16 * LSS +
                (size_t)DP * 16 + (size_t)NX * 16 + 16 + (size_t)2 * NCOLD * 16;
@@ -55,7 +58,8 @@ struct SplitGeo {
 
 // commands of the bookkeepers: go on | start an iteration at T_START (signed step, depth 0) | evaluate T_START's point with a
 // step of length 0 (the launch's first iteration) | next doubling (signed step, depth) | stop; + 8: reload the metric's variances
-enum { SC_CONT = 0, SC_NEW = 1, SC_INIT = 2, SC_DBL = 3, SC_STOP = 4 };
+// SC_ANN / X_ANN: the signed step of the doubling AFTER the one in flight, read ahead from the random stream (below)
+enum { SC_CONT = 0, SC_NEW = 1, SC_INIT = 2, SC_DBL = 3, SC_STOP = 4, SC_ANN = 5 };
 // stacked subtree scalars per level: weight (relative to the offset SS_OFF it was stored under), energy and logp of its
 // proposal, accept sum
 enum { SS_W = 0, SS_E, SS_LOGP, SS_ACC, SS_OFF, SS_N };
@@ -164,8 +168,8 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
         enum { I_IDLE = 0, I_EVAL = 1, I_OOB = 2, I_FIN = 4 };
         int imode = I_IDLE, epoch_i = 0, i_leaf = 0, depth = 0, dir = 1;
-        bool init_eval = false;
-        double eps_t = 0., beta = 1., coef2 = 0., logp_keep = 0.;
+        bool init_eval = false, paused_end = false;   // paused_end: this state is the end of a finished doubling, direction unknown
+        double eps_t = 0., ann_eps = 0., beta = 1., coef2 = 0., logp_keep = 0.;   // ann_eps: the announced next doubling's step (0: none)
         unsigned int n_trip = 0, n_trip_h = 0;
         auto post = [&](int vi, double part) {
             const double t = bf_xor32_add(bf_xor16_add(part));
@@ -199,6 +203,26 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 if (gq == 0 && real) rbg[(6 * (lev - 1 - G::LSH) + k) * W + j] = t;
             }
         };
+        // the next doubling (nuts.py:71-103 went on), signed step es: extend the end the new direction points to.  This wave's
+        // state is the end of the direction just extended; the other end waits in T_OEND
+        auto next_doubling = [&](double es) {
+            const int nd = es < 0. ? -1 : 1;
+            if (nd != dir) {
+                double oq[4], op_[4], og[4];
+                tv_ld(G::T_OEND + 0, oq); tv_ld(G::T_OEND + 1, op_); tv_ld(G::T_OEND + 2, og);
+                tv_st(G::T_OEND + 0, q); tv_st(G::T_OEND + 1, p); tv_st(G::T_OEND + 2, g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { q[r] = oq[r]; p[r] = op_[r]; g[r] = og[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pdbl[r] = p[r];
+            eps_t = es;
+            dir = nd;
+            i_leaf = 0;
+            ann_eps = 0.;
+            paused_end = false;
+            imode = I_EVAL;
+        };
         bf_sync();  // P0: the bookkeepers' first commands are posted
         int trip_no = -1;
         (void)trip_no;
@@ -212,6 +236,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 const int op = cmd & 7;
                 if (op == SC_STOP) {
                     imode = I_IDLE;
+                    paused_end = false;
                 } else if (op == SC_NEW || op == SC_INIT) {
                     // an iteration starts at T_START: Tree.__init__ (nuts.py:24-43) -- both ends and p_sum are the start point
                     tv_ld(G::T_START + 0, q); tv_ld(G::T_START + 1, p); tv_ld(G::T_START + 2, g);
@@ -221,31 +246,24 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     for (int r = 0; r < 4; ++r) { PSUM[r] = p[r]; pdbl[r] = p[r]; }
                     epoch_i = (int)XC[G::X_EPOCH * 16 + c];
                     eps_t = XC[G::X_EPS * 16 + c];
+                    ann_eps = XC[G::X_ANN * 16 + c];
                     dir = eps_t < 0. ? -1 : 1;
                     depth = 0;
                     i_leaf = 0;
                     init_eval = op == SC_INIT;
+                    paused_end = false;
                     imode = I_EVAL;
                 } else if (op == SC_DBL) {
-                    // the next doubling (nuts.py:71-103 went on): extend the end the new direction points to.  This wave's
-                    // state is the end of the direction just extended (it paused there); the other end waits in T_OEND
-                    const double es = XC[G::X_EPS * 16 + c];
-                    const int nd = es < 0. ? -1 : 1;
-                    if (nd != dir) {
-                        double oq[4], op_[4], og[4];
-                        tv_ld(G::T_OEND + 0, oq); tv_ld(G::T_OEND + 1, op_); tv_ld(G::T_OEND + 2, og);
-                        tv_st(G::T_OEND + 0, q); tv_st(G::T_OEND + 1, p); tv_st(G::T_OEND + 2, g);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { q[r] = oq[r]; p[r] = op_[r]; g[r] = og[r]; }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pdbl[r] = p[r];
                     epoch_i = (int)XC[G::X_EPOCH * 16 + c];
-                    eps_t = es;
-                    dir = nd;
                     depth = (int)XC[G::X_DEPTH * 16 + c];
-                    i_leaf = 0;
-                    imode = I_EVAL;
+                    next_doubling(XC[G::X_EPS * 16 + c]);
+                } else if (op == SC_ANN) {
+                    ann_eps = XC[G::X_ANN * 16 + c];
+                }
+                if (paused_end && ann_eps != 0.) {   // the announcement arrived after this chain reached the doubling's end
+                    depth += 1;
+                    epoch_i += 1;
+                    next_doubling(ann_eps);
                 }
             }
             // ---- phase A: first half of the leapfrog step (integration.py:80-85), B operands, the proof's partial ----
@@ -381,6 +399,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             // ---- the finished leaf: its state, the U-turn sums of the subtrees it completes (nuts.py:146-161 per merge,
             // :88-101 per doubling), the momentum part of the subtree stack.  None of it depends on a random draw. ----
             const bool leafy = fin && !init_eval;
+            const int leaf_epoch = epoch_i;   // (the epoch this leaf belongs to: an announced doubling starts the next one below)
             int nm = 0;
             if (fin) {
 #pragma unroll
@@ -460,7 +479,15 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 // the momentum part of what the tree does with this leaf (the bookkeepers do the rest when they get to it)
                 if (leafy) {
                     if (dbl_end) {
-                        imode = I_IDLE;   // this state is the tree's new end; the bookkeepers say where the next doubling goes
+                        // this state is the tree's new end; the next doubling goes where the bookkeepers announced, or waits
+                        if (ann_eps != 0.) {
+                            depth += 1;
+                            epoch_i += 1;
+                            next_doubling(ann_eps);
+                        } else {
+                            imode = I_IDLE;
+                            paused_end = true;
+                        }
                     } else {
                         if (nm == 0) {
 #pragma unroll
@@ -475,7 +502,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
             if (wv == 0 && gq == 0) {
-                XC[G::X_TAG * 16 + c] = fin ? (double)epoch_i : -1.;
+                XC[G::X_TAG * 16 + c] = fin ? (double)leaf_epoch : -1.;
                 XC[G::X_HASLP * 16 + c] = have_lp ? 1. : 0.;
                 XC[G::X_LOGP * 16 + c] = logp_new;
             }
@@ -503,6 +530,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     }
     uint64_t rs[4] = {0, 0, 0, 0};
     int mode = M_DONE, i_iter = 0, err = 0, epoch = 0;
+    bool ann_pending = false;   // a doubling was announced to the integrators under epoch + 1 and is not confirmed yet
     int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0;
     double eps = 0., start_energy = 0., acc_sum = 0.;
     double max_de = 0., w_off = 0., tree_W = 1.;
@@ -510,8 +538,9 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     double prop_E = 0., prop_logp = 0.;
     // cold scalars in LDS.  All four bookkeeper waves need them at the end of an iteration and there is no barrier inside that
     // code, so the copy of parity (i_iter & 1) is only READ and the other one only WRITTEN (by every wave, with the same values)
-    enum { K_LOG_STEP = 0, K_LOG_BAR, K_HBAR, K_SMU, K_COUNT, K_FG_N, K_BG_N, K_N_SAMPLES, K_PREV_UPD, K_ADAPT_WINDOW };
-    static_assert(K_ADAPT_WINDOW + 1 == G::NCOLD, "cold scalars");
+    enum { K_LOG_STEP = 0, K_LOG_BAR, K_HBAR, K_SMU, K_COUNT, K_FG_N, K_BG_N, K_N_SAMPLES, K_PREV_UPD, K_ADAPT_WINDOW,
+           K_STEP_NOW, K_STEP_BAR };   // (exp(log_step), exp(log_bar): what the tree steps with and the statistics report)
+    static_assert(K_STEP_BAR + 1 == G::NCOLD, "cold scalars");
     auto cold = [&](int it) -> double * { return COLD + (it & 1) * (G::NCOLD * 16) + c; };
     bool need_E0 = false;
     unsigned long long nlf = 0;
@@ -576,14 +605,24 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
     };
     // command to the integrators (a new epoch): cmd, the signed step, the depth of the tree
-    auto command = [&](int cmd, double eps_s, int dep) {
-        epoch += 1;
+    auto command = [&](int cmd, double eps_s, int dep, double ann = 0.) {
+        epoch += ann_pending ? 2 : 1;   // (past an announced epoch: what the integrators computed under it is dropped)
+        ann_pending = ann != 0.;
         if (writer) {
             XC[G::X_CMD * 16 + c] = (double)cmd;
             XC[G::X_EPOCH * 16 + c] = (double)epoch;
             XC[G::X_EPS * 16 + c] = eps_s;
             XC[G::X_DEPTH * 16 + c] = (double)dep;
+            XC[G::X_ANN * 16 + c] = ann;
         }
+    };
+    // The direction of the doubling after the one that ends with the next leaf, read ahead: processing that leaf will draw once
+    // per merge level (`dep` of them), once for the proposal swap (nuts.py:81-83), then the direction (:210).  0: no next doubling.
+    auto look_ahead = [&](int dep) -> int {
+        if (dep + 1 >= a.cfg.max_treedepth) return 0;
+        uint64_t r2[4] = {rs[0], rs[1], rs[2], rs[3]};
+        for (int k = 0; k < dep + 1; ++k) (void)bf_xoshiro_next(r2);
+        return (bf_u01(bf_xoshiro_next(r2)) < 0.5) ? 1 : -1;
     };
     // Tree.__init__ (nuts.py:24-43) at (sq, pnew, sg): the proposal is the starting point; the integrators start there
     auto tree_reset = [&](const double (&sq)[4], const double (&pnew)[4], const double (&sg)[4], bool reload_var) {
@@ -591,13 +630,14 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         w_off = 0.;
         max_de = 0.;
         depth = 0; acc_sum = 0.; n_prop = 0; diverged = 0; i_leaf = 0;
-        eps = bf_exp(cold(i_iter)[((i_iter < nw) ? K_LOG_STEP : K_LOG_BAR) * 16]);  // step_size.py:25-29: exp(log_step) / exp(log_bar)
+        eps = cold(i_iter)[((i_iter < nw) ? K_STEP_NOW : K_STEP_BAR) * 16];  // step_size.py:25-29: exp(log_step) / exp(log_bar)
         dir = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210, log(U) < log(1/2)
         tv_st(G::T_START + 0, sq); tv_st(G::T_START + 1, pnew); tv_st(G::T_START + 2, sg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { PRq[r] = sq[r]; PRg[r] = sg[r]; }
         if (reload_var) { double *sp = vxb; for (int r = 0; r < 4; ++r) sp[64 * r] = var[r]; }
-        command(SC_NEW | (reload_var ? 8 : 0), eps * (double)dir, 0);
+        // (the first doubling is one leaf: the direction of the second travels with this command)
+        command(SC_NEW | (reload_var ? 8 : 0), eps * (double)dir, 0, eps * (double)look_ahead(0));
         mode = M_LEAF;
         // the start energy needs the kinetic energy of the new momentum: its partial sums cross the next barrier
         double t_k0[4];
@@ -625,6 +665,8 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             cw[K_N_SAMPLES * 16] = scp[BFHIP_SC_N_SAMPLES];
             cw[K_PREV_UPD * 16] = scp[BFHIP_SC_PREV_UPDATE];
             cw[K_ADAPT_WINDOW * 16] = scp[BFHIP_SC_ADAPT_WINDOW];
+            cw[K_STEP_NOW * 16] = bf_exp(scp[BFHIP_SC_LOG_STEP]);
+            cw[K_STEP_BAR * 16] = bf_exp(scp[BFHIP_SC_LOG_BAR]);
         }
         err = (int)scp[BFHIP_SC_ERROR];
         load_vec(BFHIP_VEC_Q, q0, 0.);
@@ -649,6 +691,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             XC[G::X_EPOCH * 16 + c] = 0.;
             XC[G::X_EPS * 16 + c] = 0.;
             XC[G::X_DEPTH * 16 + c] = 0.;
+            XC[G::X_ANN * 16 + c] = 0.;
         }
         if (writer) XC[G::X_TAG * 16 + c] = -1.;
         const bool alive = bf_any(mode != M_DONE);
@@ -821,6 +864,13 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     }
                     i_leaf += 1;
                     st = S_NONE;
+                    if (merge_levels(i_leaf, depth) == depth) {   // the next leaf completes this doubling: announce the one after
+                        const int nd = look_ahead(depth);
+                        if (nd != 0) {
+                            ann_pending = true;
+                            if (writer) { XC[G::X_CMD * 16 + c] = (double)SC_ANN; XC[G::X_ANN * 16 + c] = eps * (double)nd; }
+                        }
+                    }
                 } else {
                     st = S_DBL_END;
                 }
@@ -867,7 +917,12 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     const int nd = (bf_u01(bf_xoshiro_next(rs)) < 0.5) ? 1 : -1;  // nuts.py:210
                     dir = nd;
                     i_leaf = 0;
-                    command(SC_DBL, eps * (double)nd, depth);   // the integrators extend that end
+                    if (ann_pending) {      // announced (the same draw, read ahead): the integrators are already there
+                        epoch += 1;
+                        ann_pending = false;
+                    } else {
+                        command(SC_DBL, eps * (double)nd, depth);   // the integrators extend that end
+                    }
                     st = S_NONE;
                 }
             }
@@ -881,7 +936,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 const double smu = cr[K_SMU * 16];
                 double fg_n = cr[K_FG_N * 16], bg_n = cr[K_BG_N * 16], n_samples = cr[K_N_SAMPLES * 16], prev_upd = cr[K_PREV_UPD * 16];
                 double adapt_window = cr[K_ADAPT_WINDOW * 16];
-                double step_now = bf_exp(log_step), step_bar = bf_exp(log_bar);
+                double step_now = cr[K_STEP_NOW * 16], step_bar = cr[K_STEP_BAR * 16];
                 if (warm && a.cfg.adapt_step_size) {  // step_size.py:31-45
                     const double wgt = 1. / (count + a.cfg.t_0);
                     hbar = ((1. - wgt) * hbar + wgt * (a.cfg.target_accept - accept_stat));
@@ -961,6 +1016,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     cw[K_LOG_STEP * 16] = log_step; cw[K_LOG_BAR * 16] = log_bar; cw[K_HBAR * 16] = hbar; cw[K_SMU * 16] = smu;
                     cw[K_COUNT * 16] = count; cw[K_FG_N * 16] = fg_n; cw[K_BG_N * 16] = bg_n; cw[K_N_SAMPLES * 16] = n_samples;
                     cw[K_PREV_UPD * 16] = prev_upd; cw[K_ADAPT_WINDOW * 16] = adapt_window;
+                    cw[K_STEP_NOW * 16] = step_now; cw[K_STEP_BAR * 16] = step_bar;
                 }
                 if (i_iter < a.iter_end) {
                     new_iter = true;

@@ -1,0 +1,30 @@
+"""Tuning: the in-step layouts ('group', 'split') and 'wave' on the headline surrogate at a given target_accept (tree size) and
+chain count: post-adaptation launches, leapfrog steps/s.  usage: python tools/layout_ab.py [target_accept] [chains]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bayesfast_amd.device import get_context, DeviceDensity
+from bayesfast_amd.chains import DeviceChains
+from bayesfast_amd.workloads import correlated_gaussian_spec
+from bayesfast_amd import _lib
+ta = float(sys.argv[1]) if len(sys.argv) > 1 else 0.8
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+ctx = get_context(0)
+spec, _ = correlated_gaussian_spec(64)
+dens = DeviceDensity(spec, ctx)
+x0 = np.random.default_rng(1).normal(size=(C, 64))
+for layout in ('group', 'split', 'wave'):
+    ch = DeviceChains(dens, x0, seed=3)
+    kw = dict(n_warmup=750, target_accept=ta, check=False, layout=layout)
+    ch.run(750, 'NUTS', **kw)
+    s, st = ch.run(250, 'NUTS', **kw)
+    lf0 = ch.total_leapfrog
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(ctx.stream)
+    for _ in range(4):
+        s, st = ch.run(250, 'NUTS', **kw)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    ts = st[:, :, _lib.NSTATS.index('tree_size')].mean().item()
+    print('target_accept %.2f chains %d layout %-5s: %.4g leapfrog steps/s, mean tree size %.1f' % (
+        ta, C, layout, (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), ts))
