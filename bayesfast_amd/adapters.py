@@ -37,7 +37,7 @@ def density_spec_from_reference(den):
     su = surrogates[0]
     d = int(den.input_size)
     spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=poly_spec_from_reference(su),
-                use_decay=bool(den._use_decay))
+                use_decay=bool(den._use_decay), link=None)  # (a density with a likelihood module: integrate.as_surrogate_density)
     if den._input_scales is not None:
         spec['ranges'] = np.array(den._input_scales, dtype=np.float64)
         hb = den._hard_bounds

@@ -250,7 +250,8 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
            'nuts_iterations_timed': steps * iters, 'nuts_adaptation_iterations': n_adapt, 'ms_per_launch': ms / steps,
            'target_accept': target_accept, 'mean_tree_size': float(ts.mean()), 'max_tree_depth': int(stn[:, :, _lib.NSTATS.index('tree_depth')].max()),
            'divergence_rate': float(stn[:, :, _lib.NSTATS.index('diverging')].mean()),
-           'mean_accept': float(stn[:, :, _lib.NSTATS.index('mean_tree_accept')].mean()), 'chain_layout': ch.last_layout,
+           'mean_accept': float(stn[:, :, _lib.NSTATS.index('mean_tree_accept')].mean()),
+           'chain_layout': _layout_of(kname().decode(), ch.last_layout),
            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': ach / 78.6, 'traffic': None,
                         'kernel': kname().decode(), 'kernel_ms_per_launch': ms / steps, 'flops_per_leapfrog': fl},
            'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9, 'peak': 8000.,
@@ -263,6 +264,14 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
         except Exception as ex:
             out['cpu_baseline'] = {'error': repr(ex)}
     return out, s, st
+
+
+def _layout_of(kernel, requested):
+    """The layout that RAN (a requested 'split' runs the group kernel where bf_split_kernel has no instantiation)."""
+    for key, lay in (('bf_split_kernel', 'split'), ('bf_group_kernel', 'group'), ('bf_nuts_pipe_kernel', 'wave'), ('bf_sampler_kernel', 'wave')):
+        if kernel.startswith(key):
+            return lay
+    return requested
 
 
 def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps=2, n_adapt=None):
