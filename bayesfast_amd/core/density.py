@@ -197,7 +197,8 @@ class SurrogateDensity:
         self._mu = np.mean(x, axis=0)
         self._hess = np.linalg.inv(np.cov(x, rowvar=False))
         if self._alpha_p is not None:
-            beta = np.einsum('ij,jk,ik->i', x - self._mu, self._hess, x - self._mu)**0.5
+            dx = x - self._mu
+            beta = np.sum((dx @ self._hess) * dx, axis=1)**0.5  # (the three-operand einsum as one matrix product)
             self._alpha = float(np.percentile(beta, self._alpha_p) if self._alpha_p < 100 else
                                 np.max(beta) * self._alpha_p / 100)
             self._alpha_2 = self._alpha**2

@@ -54,6 +54,8 @@ struct bfhip_ctx {
     void *scratch;        // sampler tree scratch (grow-only)
     size_t scratch_bytes;
     int n_cu;
+    void *flow;           // counters and exchange buffers of the triangular solves (bfhip_fit.hip: ensure_flow)
+    int flow_cap;         // in 64-row blocks
 };
 
 // Every entry point that launches or allocates runs on its context's device, whatever the caller's current device is

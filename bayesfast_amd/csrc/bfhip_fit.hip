@@ -233,136 +233,199 @@ __global__ void bf_unscale_kernel(int P, int m, double *__restrict__ r, const do
         for (int c = 0; c < m; ++c) r[(size_t)i * m + c] *= dsc[i];
 }
 
-// Cholesky of the NB x NB diagonal block at (k0, k0) by ONE wave (lane = row, left-looking, block in LDS), followed
-// by the inverse of the factor (forward substitution on the identity, lane = column), which turns the panel solve
-// below into a small matrix product.  info = first pivot below the threshold (1-based).
-__global__ __launch_bounds__(64) void bf_chol_diag_kernel(int P, int k0, double *__restrict__ G, double *__restrict__ Linv,
-                                                         int *__restrict__ info) {
-    __shared__ double L[NB_][NB_ + 1];
-    __shared__ double X[NB_][NB_ + 1];
-    const int nbk = min(NB_, P - k0);
-    const int t = threadIdx.x;
-    for (int i = 0; i < NB_; ++i)  // row i: one coalesced 512-byte read
-        L[i][t] = (i < nbk && t < nbk) ? G[(size_t)(k0 + i) * P + k0 + t] : (i == t ? 1. : 0.);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < nbk; ++j) {
-        // lane i >= j: a[i][j] - sum_{k<j} L[i][k] L[j][k]
-        double acc = L[t][j];
-#pragma unroll 8
-        for (int k = 0; k < j; ++k) acc -= L[t][k] * L[j][k];
-        double djj = bf_readlane(acc, j);
-        // the matrix is equilibrated (unit diagonal): a pivot below 1e-11 puts the condition number of the normal
-        // equations beyond the range in which the refinement of bfhip_lstsq_refine contracts quickly (its factor is
-        // ~ P eps cond(G)): the design matrix is reported as numerically rank deficient
-        if (!(djj > 1e-11)) {
-            if (t == 0 && *info == 0) *info = k0 + j + 1;
-            djj = 1.;
+// ---------------------------------------------------------------------------------------------------
+// The factorisation: one launch per 64-column panel.  Panel k's launch has one workgroup per 64 x 64 tile (i >= j > k)
+// of the trailing matrix; a workgroup forms the two blocks of the panel it needs itself, L_ik = A_ik L_kk^-T and
+// L_jk, as products with the kept inverse of the diagonal block (MFMA), takes L_ik L_jk^T out of its tile, and -- the
+// workgroup of tile (k+1, k+1) only -- factors the next diagonal block and inverts the factor, so that the next
+// launch starts from L_kk^-1.  Nothing a launch reads is written by it: L_ik goes, transposed, into the UPPER triangle
+// of G (block (k, i)), which the factorisation never reads; the triangular solves take it from there.
+// The chain per panel is (update, factor 64 x 64, invert): the 64 x 64 step is what bounds the whole factorisation, so
+// it runs in registers (lane = row, 64 columns in 64 registers, rank-1 updates through v_readlane) on two waves:
+// wave 0 factors, wave 1 inverts one column behind it, fed through LDS.
+// ---------------------------------------------------------------------------------------------------
+#define LDP_ (NB_ + 2)  // (even: pairs of a row are 16-byte aligned)
+
+// S[64][66]: the block (lower triangle; identity beyond nbk); overwritten by the factor, row-major.  Lc[64][66]: the
+// factor by columns (Lc[j][t] = L[t][j]).  Called by waves 0 and 1 of the workgroup; G gets L_kk (zeros above the
+// diagonal), Linv its inverse.
+//   wave 0, lane = row t, a[c] = A[t][c]: at step j the column is scaled, written to LDS in both layouts, and taken
+//           out of the columns to its right with its own entries L[c][j] read back as LDS broadcasts (two per read);
+//   wave 1, lane = column c of X = L^-1, x[j] = X[j][c]: row j of L X = I as soon as row j of L is complete (after
+//           wave 0's step j): x[j] = (delta_jc - sum_{k<j} L[j][k] x[k]) / L[j][j], the row read as LDS broadcasts.
+__device__ __forceinline__ void bf_chol64_two_waves(double (*S)[LDP_], double (*Lc)[LDP_], int *ready, int P, int k0, int nbk,
+                                                    double *__restrict__ G, double *__restrict__ Linv, int *__restrict__ info) {
+    const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv == 0) {
+        double a[NB_];
+#pragma unroll
+        for (int c = 0; c < NB_; ++c) a[c] = S[t][c];
+        int bad = 0;
+        // one basic block for all 64 steps (no branch inside): the pivot chain of step j+1 -- v_readlane, 1 / sqrt, the
+        // scaled column -- only needs column j+1, which is updated first and through v_readlane (no LDS round trip), so
+        // the scheduler can run it under the rest of step j's updates
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) {
+            double djj = bf_readlane(a[j], j);
+            // the matrix is equilibrated (unit diagonal): a pivot below 1e-11 puts the condition number of the normal
+            // equations beyond the range in which the refinement of bfhip_lstsq contracts quickly (its factor is
+            // ~ P eps cond(G)): the design matrix is reported as numerically rank deficient (first such pivot, 1-based)
+            const bool ok = djj > 1e-11;
+            bad = (!ok && bad == 0) ? j + 1 : bad;
+            djj = ok ? djj : 1.;
+            const double rl = rsqrt(djj), ljj = djj * rl;
+            int tt = t;
+            asm volatile("" : "+v"(tt));  // (or the lane masks of all 64 steps are formed up front and spilled)
+            const double lj = tt == j ? ljj : (tt > j ? a[j] * rl : 0.);
+            Lc[j][t] = lj;
+            S[t][j] = lj;
+            if (t == 0) Lc[j][NB_] = rl;  // (the padding column: 1 / L_jj for wave 1)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (t == 0) __hip_atomic_store(ready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            // (the pins keep the compiler from deferring the updates of the columns it does not need yet: it would
+            // hold every broadcast of every step in registers and spill 2000 of them)
+            if (j + 1 < NB_) {
+                a[j + 1] -= lj * bf_readlane(lj, j + 1);
+                asm volatile("" : "+v"(a[j + 1]));
+            }
+            if ((j & 1) && j + 2 < NB_) a[j + 2] -= lj * Lc[j][j + 2];  // (pairs start at an even column)
+#pragma unroll
+            for (int c = (j + 3) & ~1; c < NB_; c += 2) {
+                const d2_t l2 = *(const d2_t *)&Lc[j][c];
+                a[c] -= lj * l2.x;
+                a[c + 1] -= lj * l2.y;
+                if ((c & 15) == 14) {
+#pragma unroll
+                    for (int cc = c & ~15; cc <= c; cc += 2)
+                        if (cc > j + 1) asm volatile("" : "+v"(a[cc]), "+v"(a[cc + 1]));
+                }
+            }
         }
-        const double ljj = sqrt(djj);
-        __builtin_amdgcn_wave_barrier();
-        if (t == j) L[t][j] = ljj;
-        else if (t > j) L[t][j] = acc / ljj;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    for (int i = 0; i < NB_; ++i)
-        if (i < nbk && t < nbk) G[(size_t)(k0 + i) * P + k0 + t] = t <= i ? L[i][t] : 0.;
-    // X = L^-1: lane c solves L x = e_c
-    for (int j = 0; j < NB_; ++j) {
-        double sacc = (j == t) ? 1. : 0.;
-        if (j >= t) {
-#pragma unroll 8
-            for (int k = t; k < j; ++k) sacc -= L[j][k] * X[k][t];
-            sacc /= L[j][j];
-        } else {
-            sacc = 0.;
+        if (bad && t == 0) atomicCAS(info, 0, k0 + bad);
+        for (int i = 0; i < nbk; ++i)
+            if (t < nbk) G[(size_t)(k0 + i) * P + k0 + t] = S[i][t];  // (zeros above the diagonal: lj of the lanes t < j)
+    } else if (wv == 1) {
+        double x[NB_];
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) {
+            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            int tt = t;
+            asm volatile("" : "+v"(tt));
+            double sm[4] = {tt == j ? 1. : 0., 0., 0., 0.};
+#pragma unroll
+            for (int k = 0; k + 1 < j; k += 2) {
+                const d2_t l2 = *(const d2_t *)&S[j][k];
+                sm[(k >> 1) & 1] -= l2.x * x[k];
+                sm[2 + ((k >> 1) & 1)] -= l2.y * x[k + 1];
+            }
+            if (j & 1) sm[0] -= S[j][j - 1] * x[j - 1];
+            x[j] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * Lc[j][NB_];
+            Linv[j * NB_ + t] = x[j];
         }
-        X[j][t] = sacc;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i < NB_; ++i) Linv[i * NB_ + t] = X[i][t];
 }
 
-// panel: rows below the diagonal block, X = A21 L11^-T = A21 (L11^-1)^T: 64-row tiles, each thread 16 outputs
-__global__ __launch_bounds__(256) void bf_chol_trsm_kernel(int P, int k0, double *__restrict__ G, const double *__restrict__ Linv) {
-    __shared__ double Li[NB_][NB_ + 1];
-    __shared__ double At[NB_][NB_ + 1];
-    const int nbk = min(NB_, P - k0);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int r0 = k0 + nbk + blockIdx.x * NB_;
-    for (int i = wv; i < NB_; i += 4) {
-        Li[i][lane] = Linv[i * NB_ + lane];
-        const int row = r0 + i;
-        At[i][lane] = (row < P && lane < nbk) ? G[(size_t)row * P + k0 + lane] : 0.;
-    }
+// the first diagonal block (no panel before it)
+__global__ __launch_bounds__(256) void bf_chol_first_kernel(int P, double *__restrict__ G, double *__restrict__ Linv,
+                                                          int *__restrict__ info) {
+    __shared__ double R0[NB_][LDP_], R1[NB_][LDP_];
+    __shared__ int ready;
+    const int nbk = min(NB_, P);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < NB_; i += 4) R1[i][lane] = (i < nbk && lane < nbk) ? G[(size_t)i * P + lane] : (i == lane ? 1. : 0.);
+    if (threadIdx.x == 0) ready = 0;
     __syncthreads();
-    // thread (row = lane, columns wv*16 .. wv*16+15):  X[row][j] = sum_{k <= j} A[row][k] Linv[j][k]
-    const int row = r0 + lane;
-    double out[16];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = wv * 16 + jj;
-        double sacc = 0.;
-        for (int k = 0; k <= j; ++k) sacc += At[lane][k] * Li[j][k];
-        out[jj] = sacc;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) At[lane][wv * 16 + jj] = out[jj];
-    __syncthreads();
-    for (int i = wv; i < NB_; i += 4) {
-        const int rr = r0 + i;
-        if (rr < P && lane < nbk) G[(size_t)rr * P + k0 + lane] = At[i][lane];
-    }
-    (void)row;
+    bf_chol64_two_waves(R1, R0, &ready, P, 0, nbk, G, Linv, info);
 }
 
-// trailing update A22 -= L21 L21^T on MFMA, lower-triangular 64 x 64 blocks, one wave per block
-__global__ __launch_bounds__(256) void bf_chol_syrk_kernel(int P, int k0, double *__restrict__ G) {
-    const int nbk = min(NB_, P - k0);
-    const int t0 = k0 + nbk;  // first trailing row
-    const int nt = P - t0;
-    const int nb = (nt + GB_ - 1) / GB_;
-    const int n_blk = nb * (nb + 1) / 2;
-    const int lane = threadIdx.x & 63;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= n_blk) return;
-    int bj = 0, rem = blk;  // lower triangle: bi >= bj
+// panel k0 (a full 64 columns: there are rows below it): see above
+__global__ __launch_bounds__(256) void bf_chol_panel_kernel(int P, int k0, double *__restrict__ G, double *__restrict__ LinvAll,
+                                                          int *__restrict__ info) {
+    __shared__ double R0[NB_][LDP_], R1[NB_][LDP_];
+    __shared__ int ready;
+    const int t0 = k0 + NB_;  // first trailing row
+    const int nb = (P - t0 + NB_ - 1) / NB_;
+    int bj = 0, rem = blockIdx.x;  // lower triangle of the trailing blocks, by columns: bi >= bj
     while (rem >= nb - bj) { rem -= nb - bj; ++bj; }
     const int bi = bj + rem;
-    const int I0 = t0 + bi * GB_, J0 = t0 + bj * GB_;
+    const int I0 = t0 + bi * NB_, J0 = t0 + bj * NB_;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ci = lane & 15, kr = lane >> 4;
-    d4_t acc[4][4];
+    const bool diag = bi == bj;
+    const double *Linv = LinvAll + (size_t)(k0 / NB_) * NB_ * NB_;
+    for (int i = wv; i < NB_; i += 4) R0[i][lane] = Linv[i * NB_ + lane];
+    if (threadIdx.x == 0) ready = 0;
+    __syncthreads();
+    // rows 16 wv .. 16 wv + 15 of L_ik = A_ik Linv^T and of L_jk: D[r][c] = sum_m A[r][m] Linv[c][m] (m <= c)
+    d4_t li[4], lj[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) li[b] = lj[b] = (d4_t){0., 0., 0., 0.};
+    {
+        const int ra = I0 + 16 * wv + ci, rb = J0 + 16 * wv + ci;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0., 0., 0., 0.};
-    for (int kk = 0; kk < nbk; kk += 4) {
-        const int col = k0 + kk + kr;
-        const bool cok = kk + kr < nbk;
-        double fa[4], fb[4];
+        for (int s = 0; s < 16; ++s) {
+            const int col = k0 + 4 * s + kr;
+            const double fa = ra < P ? G[(size_t)ra * P + col] : 0.;
+            const double fb = (!diag && rb < P) ? G[(size_t)rb * P + col] : 0.;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ra = I0 + 16 * t + ci, rb = J0 + 16 * t + ci;
-            fa[t] = (cok && ra < P) ? G[(size_t)ra * P + col] : 0.;  // A operand: L21[I + i][k]
-            fb[t] = (cok && rb < P) ? G[(size_t)rb * P + col] : 0.;  // B operand: L21[J + j][k]
+            for (int b = 0; b < 4; ++b)
+                if (s <= 4 * b + 3) {  // (Linv is lower triangular: columns 16 b .. 16 b + 15 end at m = 16 b + 15)
+                    const double fl = R0[16 * b + ci][4 * s + kr];
+                    li[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fl, li[b], 0, 0, 0);
+                    if (!diag) lj[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fl, lj[b], 0, 0, 0);
+                }
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
+    __syncthreads();  // every wave is through with Linv: R0 <- L_ik, R1 <- L_jk
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int r = 0; r < 4; ++r) {
+            R0[16 * wv + kr + 4 * r][16 * b + ci] = li[b][r];
+            if (!diag) R1[16 * wv + kr + 4 * r][16 * b + ci] = lj[b][r];
+        }
+    __syncthreads();
+    double (*RJ)[LDP_] = diag ? R0 : R1;
+    d4_t acc[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = I0 + 16 * a + kr + 4 * r, j = J0 + 16 * b + ci;
-                if (i < P && j < P && j <= i) G[(size_t)i * P + j] -= acc[a][b][r];
+    for (int b = 0; b < 4; ++b) acc[b] = (d4_t){0., 0., 0., 0.};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const double fa = R0[16 * wv + ci][4 * s + kr];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, RJ[16 * b + ci][4 * s + kr], acc[b], 0, 0, 0);
+    }
+    const bool next_diag = diag && bi == 0;  // tile (k+1, k+1): factored here
+    double nv[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = I0 + 16 * wv + kr + 4 * r, j = J0 + 16 * b + ci;
+            nv[b][r] = 0.;
+            if (i < P && j < P && (!diag || j <= i)) {
+                nv[b][r] = G[(size_t)i * P + j] - acc[b][r];
+                G[(size_t)i * P + j] = nv[b][r];
             }
+        }
+    if (bj == 0) {  // L_ik, transposed, into block (k, i) of the upper triangle
+        for (int m = wv; m < NB_; m += 4)
+            if (I0 + lane < P) G[(size_t)(k0 + m) * P + I0 + lane] = R0[lane][m];
+    }
+    if (!next_diag) return;
+    __syncthreads();  // (uniform: the whole workgroup is here) R0 and R1 are free
+    const int nbk = min(NB_, P - t0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * wv + kr + 4 * r, j = 16 * b + ci;
+            R1[i][j] = (i < nbk && j < nbk) ? nv[b][r] : (i == j ? 1. : 0.);
+        }
+    __syncthreads();
+    bf_chol64_two_waves(R1, R0, &ready, P, t0, nbk, G, LinvAll + (size_t)(t0 / NB_) * NB_ * NB_, info);
 }
 
 // (wave-level sums used by the residual kernel of bfhip_lstsq)
@@ -392,109 +455,166 @@ static int solve_spd_impl(bfhip_ctx *ctx, int P, int m, double *G, double *r, in
     BF_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int), st));
     hipLaunchKernelGGL(bf_diag_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, G, dsc);
     hipLaunchKernelGGL(bf_scale_kernel, dim3(P), dim3(256), 0, st, P, m, G, r, dsc);
-    for (int k0 = 0; k0 < P; k0 += NB_) {
-        const int nbk = P - k0 < NB_ ? P - k0 : NB_;
-        double *Linv = LinvAll + (size_t)(k0 / NB_) * NB_ * NB_;  // kept: the triangular solves multiply by it
-        hipLaunchKernelGGL(bf_chol_diag_kernel, dim3(1), dim3(64), 0, st, P, k0, G, Linv, info);
-        const int below = P - k0 - nbk;
-        if (below > 0) {
-            hipLaunchKernelGGL(bf_chol_trsm_kernel, dim3((below + NB_ - 1) / NB_), dim3(256), 0, st, P, k0, G, Linv);
-            const int nb = (below + GB_ - 1) / GB_;
-            const int n_blk = nb * (nb + 1) / 2;
-            hipLaunchKernelGGL(bf_chol_syrk_kernel, dim3((n_blk + 3) / 4), dim3(256), 0, st, P, k0, G);
-        }
+    hipLaunchKernelGGL(bf_chol_first_kernel, dim3(1), dim3(256), 0, st, P, G, LinvAll, info);
+    for (int k0 = 0; k0 + NB_ < P; k0 += NB_) {
+        const int nb = (P - k0 - NB_ + NB_ - 1) / NB_;
+        hipLaunchKernelGGL(bf_chol_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, P, k0, G, LinvAll, info);
     }
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Triangular solves by block columns, one launch per 64-column panel and sweep (the single-workgroup sweep this
-// replaces read the whole factor through one CU: 1.1 ms per sweep at P = 2145).  Every workgroup of a launch forms the
-// panel's 64 unknowns itself, by a product with the inverse of the diagonal block kept from the factorisation, and
-// then takes the panel's contribution out of its own 64 rows (forward) or columns (backward) of the right-hand side.
-// Sums run in index order: the result does not depend on the grid.
+// Triangular solves: ONE launch per sweep, one workgroup per 64-row block, the blocks of the solution handed from
+// workgroup to workgroup as they become final (round 2 had one launch per panel and sweep: 68 dependent launches per
+// solve, 2.65 ms of the fit).  Workgroup b of the forward sweep takes L_bk y_k out of its rows for k = 0 .. b-1 in
+// order, as soon as block k is there, then forms y_b = L_bb^-1 r_b with the kept inverse and publishes it; the
+// backward sweep runs the same way from the last block up, on the transposed factor.  The factor is read-only here;
+// what is exchanged -- 64 doubles per block and right-hand side -- goes through an exchange buffer with agent-scope
+// atomics (sc1 loads and stores: the eight XCDs' L2 caches are not coherent for plain accesses inside a launch), and
+// the data is its own flag: the buffer holds a NaN with a payload no computation produces until the value is written,
+// and a reader spins on the value it needs (one trip to memory per hop instead of flag-then-data).  Each sweep clears
+// the OTHER sweep's buffer for the launch after it.  A workgroup takes its block from a ticket counter, so it only
+// ever waits for workgroups that started before it: no assumption on how many are resident or in which order they
+// are dispatched.  Every sum runs in a fixed order: the result does not depend on timing.
+// Up to 4 right-hand sides per launch (columns q0 .. q0+mq-1 of r (P, m)), solved in place.
 // ---------------------------------------------------------------------------------------------------
-// forward, panel at k0: y_k = L_kk^-1 r_k;  r_i -= L_ik y_k for the rows i below the panel
-__global__ __launch_bounds__(256) void bf_trsv_fwd_kernel(int P, int m, int k0, const double *__restrict__ L,
-                                                          const double *__restrict__ Linv, double *__restrict__ r,
-                                                          double *__restrict__ y) {
-    __shared__ double T[NB_][NB_ + 1];
-    __shared__ double rk[NB_], yk[NB_];
+#define TRSV_MQ_ 4
+#define BF_UNSET_ 0x7FF8DEAD7FF8DEADll  // (both halves equal: set with hipMemsetD32Async)
+__device__ inline double bf_ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void bf_st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sync: [0] ticket counter, [1] finished workgroups.  xch: this sweep's exchange buffer [block][4][64]; xch_next: the
+// other sweep's, cleared here
+template <bool BWD>
+__global__ __launch_bounds__(256) void bf_trsv_flow_kernel(int P, int m, int q0, int mq, const double *__restrict__ G,
+                                                         const double *__restrict__ LinvAll, const double *__restrict__ dsc,
+                                                         int scale, double *__restrict__ r, int *sync, double *xch,
+                                                         double *__restrict__ xch_next) {
+    __shared__ double T[NB_][LDP_];
+    __shared__ double Li[NB_][LDP_];
+    __shared__ double vk[TRSV_MQ_][NB_];
+    __shared__ double part[4][TRSV_MQ_][NB_];
+    __shared__ int s_ticket;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int nbk = min(NB_, P - k0);
-    const int i0 = k0 + nbk + blockIdx.x * NB_;
-    for (int q = 0; q < m; ++q) {
-        for (int i = wv; i < NB_; i += 4) T[i][lane] = Linv[i * NB_ + lane];
-        if (t < NB_) rk[t] = t < nbk ? r[(size_t)(k0 + t) * m + q] : 0.;
-        __syncthreads();
-        if (t < NB_) {
-            double acc = 0.;
-            for (int c = 0; c <= t; ++c) acc += T[t][c] * rk[c];
-            yk[t] = acc;
-            if (blockIdx.x == 0 && t < nbk) y[(size_t)(k0 + t) * m + q] = acc;
-        }
-        __syncthreads();
-        if (i0 < P) {
-            for (int i = wv; i < NB_; i += 4) T[i][lane] = (i0 + i < P && lane < nbk) ? L[(size_t)(i0 + i) * P + k0 + lane] : 0.;
-            __syncthreads();
-            if (t < NB_ && i0 + t < P) {
-                double acc = 0.;
-                for (int c = 0; c < nbk; ++c) acc += T[t][c] * yk[c];
-                r[(size_t)(i0 + t) * m + q] -= acc;
-            }
-        }
-        __syncthreads();
+    const int nb = (P + NB_ - 1) / NB_;
+    if (t == 0) s_ticket = atomicAdd(&sync[0], 1);
+    __syncthreads();
+    const int b = BWD ? nb - 1 - s_ticket : s_ticket;
+    const int b0 = b * NB_;
+    xch_next[(size_t)b * (TRSV_MQ_ * NB_) + t] = __longlong_as_double(BF_UNSET_);
+    // the block's own inverse and right-hand side: on their way while the blocks before it are taken out
+    const double *Linv = LinvAll + (size_t)b * NB_ * NB_;
+    double lpre[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lpre[e] = Linv[(wv + 4 * e) * NB_ + lane];
+    double own = 0.;
+    if (wv < mq && b0 + lane < P) {
+        own = r[(size_t)(b0 + lane) * m + q0 + wv];
+        if (!BWD && scale) own *= dsc[b0 + lane];  // (forward sweep of a refinement step: the residual comes unscaled)
     }
-}
-// backward, panel at k0: x_k = L_kk^-T y_k;  y_j -= L_kj^T x_k for the columns j left of the panel
-__global__ __launch_bounds__(256) void bf_trsv_bwd_kernel(int P, int m, int k0, const double *__restrict__ L,
-                                                          const double *__restrict__ Linv, double *__restrict__ y,
-                                                          double *__restrict__ x) {
-    __shared__ double T[NB_][NB_ + 1];
-    __shared__ double yk[NB_], xk[NB_];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int nbk = min(NB_, P - k0);
-    const int j0 = blockIdx.x * NB_;
-    for (int q = 0; q < m; ++q) {
-        for (int i = wv; i < NB_; i += 4) T[i][lane] = Linv[i * NB_ + lane];
-        if (t < NB_) yk[t] = t < nbk ? y[(size_t)(k0 + t) * m + q] : 0.;
-        __syncthreads();
-        if (t < NB_) {
-            double acc = 0.;
-            for (int i = t; i < NB_; ++i) acc += T[i][t] * yk[i];
-            xk[t] = acc;
-            if (blockIdx.x == 0 && t < nbk) x[(size_t)(k0 + t) * m + q] = acc;
+    // tile (b, k) of the sweep's operator, element (e, lane) for e = wv, wv + 4, ..:
+    //   forward  L_bk   = (block (k, b) of the upper triangle)^T:  T[c][row] = G[(k0 + c) P + b0 + row]
+    //   backward L_kb^T =  block (b, k) of the upper triangle:     T[row][c] = G[(b0 + row) P + k0 + c]
+    double pre[16];
+    auto fetch = [&](int k) {
+        const int k0 = k * NB_;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int a = wv + 4 * e;
+            const int row = BWD ? b0 + a : k0 + a, col = BWD ? k0 + lane : b0 + lane;
+            pre[e] = (row < P && col < P) ? G[(size_t)row * P + col] : 0.;
         }
-        __syncthreads();
-        if (j0 < k0) {
-            for (int i = wv; i < NB_; i += 4) T[i][lane] = i < nbk ? L[(size_t)(k0 + i) * P + j0 + lane] : 0.;
-            __syncthreads();
-            if (t < NB_) {
-                double acc = 0.;
-                for (int i = 0; i < nbk; ++i) acc += T[i][t] * xk[i];
-                y[(size_t)(j0 + t) * m + q] -= acc;
+    };
+    double accq[TRSV_MQ_];  // thread (lane = row of the block, wave = 16 of a tile's 64 columns)
+#pragma unroll
+    for (int q = 0; q < TRSV_MQ_; ++q) accq[q] = 0.;
+    const int n_k = BWD ? nb - 1 - b : b;
+    if (n_k > 0) fetch(BWD ? nb - 1 : 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Li[wv + 4 * e][lane] = lpre[e];
+    for (int kk = 0; kk < n_k; ++kk) {
+        const int k = BWD ? nb - 1 - kk : kk;
+        __syncthreads();  // the tile and the block before this one have been used
+#pragma unroll
+        for (int e = 0; e < 16; ++e) T[wv + 4 * e][lane] = pre[e];
+        if (kk + 1 < n_k) fetch(BWD ? k - 1 : k + 1);  // (in flight across the wait below)
+        if (wv < mq) {
+            const double *src = xch + (size_t)k * (TRSV_MQ_ * NB_) + t;
+            double v = bf_ld_agent(src);
+            while (__double_as_longlong(v) == BF_UNSET_) {
+                __builtin_amdgcn_s_sleep(1);
+                v = bf_ld_agent(src);
             }
+            vk[wv][lane] = v;
         }
         __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int c = 16 * wv + cc;
+            const double tv = BWD ? T[lane][c] : T[c][lane];
+#pragma unroll
+            for (int q = 0; q < TRSV_MQ_; ++q)
+                if (q < mq) accq[q] += tv * vk[q][c];
+        }
+    }
+    // the four waves' partial sums in wave order, then the product with the block's inverse
+#pragma unroll
+    for (int q = 0; q < TRSV_MQ_; ++q)
+        if (q < mq) part[wv][q][lane] = accq[q];
+    __syncthreads();
+    if (wv < mq) vk[wv][lane] = own - (((part[0][wv][lane] + part[1][wv][lane]) + part[2][wv][lane]) + part[3][wv][lane]);
+    __syncthreads();
+    if (wv < mq) {
+        const int q = wv, c = lane;
+        double s = 0.;
+        if (BWD) {
+            for (int i = c; i < NB_; ++i) s += Li[i][c] * vk[q][i];  // x = L_bb^-T y
+        } else {
+            for (int i = 0; i <= c; ++i) s += Li[c][i] * vk[q][i];  // y = L_bb^-1 r
+        }
+        bf_st_agent(xch + (size_t)b * (TRSV_MQ_ * NB_) + t, s);  // (rows beyond P: zeros, the padding of the inverse is the identity)
+        if (b0 + c < P) r[(size_t)(b0 + c) * m + q0 + q] = s;
+    }
+    if (t == 0) {
+        if (atomicAdd(&sync[1], 1) == nb - 1) {  // the last one out resets the counters for the next launch
+            __hip_atomic_store(&sync[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
-// x = (D L L^T D)^-1 r with the kept factor L, the inverses of its diagonal blocks and the scales D = diag(dsc): r is
-// overwritten by x; ybuf (P, m) is work space
-static int chol_apply(bfhip_ctx *ctx, int P, int m, const double *L, const double *dsc, const double *LinvAll, double *ybuf,
-                      double *r, bool scale_in) {
-    hipStream_t st = ctx->stream;
-    if (scale_in) hipLaunchKernelGGL(bf_unscale_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, m, r, dsc);
-    const int nblk = (P + NB_ - 1) / NB_;
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int k0 = kb * NB_, nbk = P - k0 < NB_ ? P - k0 : NB_, below = P - k0 - nbk;
-        const int grid = below > 0 ? (below + NB_ - 1) / NB_ : 1;
-        hipLaunchKernelGGL(bf_trsv_fwd_kernel, dim3(grid), dim3(256), 0, st, P, m, k0, L, LinvAll + (size_t)kb * NB_ * NB_, r, ybuf);
+static int ensure_flow(bfhip_ctx *ctx, int nb) {
+    if (ctx->flow_cap < nb) {
+        BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->flow) BF_HIP_CHECK(hipFree(ctx->flow));
+        ctx->flow = NULL;
+        ctx->flow_cap = 0;
+        const int cap = nb < 256 ? 256 : 2 * nb;
+        // [2 ints of counters, padded to 64 bytes][forward exchange buffer][backward exchange buffer]
+        const size_t n_x = (size_t)cap * TRSV_MQ_ * NB_;
+        BF_HIP_CHECK(hipMalloc((void **)&ctx->flow, 64 + 2 * n_x * sizeof(double)));
+        BF_HIP_CHECK(hipMemsetAsync(ctx->flow, 0, 64, ctx->stream));
+        BF_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)((char *)ctx->flow + 64), 0x7FF8DEAD, 4 * n_x, ctx->stream));
+        ctx->flow_cap = cap;
     }
-    for (int kb = nblk - 1; kb >= 0; --kb) {
-        const int k0 = kb * NB_;
-        const int grid = kb > 0 ? kb : 1;
-        hipLaunchKernelGGL(bf_trsv_bwd_kernel, dim3(grid), dim3(256), 0, st, P, m, k0, L, LinvAll + (size_t)kb * NB_ * NB_, ybuf, r);
+    return 0;
+}
+
+// x = (D L L^T D)^-1 r with the kept factor (the transposed blocks in the upper triangle of G), the inverses of its
+// diagonal blocks and the scales D = diag(dsc): r is overwritten by x.  scale_in: r comes unscaled (a refinement
+// step's A^T S); otherwise the caller has scaled it already (bf_scale_kernel)
+static int chol_apply(bfhip_ctx *ctx, int P, int m, const double *L, const double *dsc, const double *LinvAll, double *r,
+                      bool scale_in) {
+    hipStream_t st = ctx->stream;
+    const int nb = (P + NB_ - 1) / NB_;
+    if (int rc = ensure_flow(ctx, nb)) return rc;
+    int *sync = (int *)ctx->flow;
+    double *xf = (double *)((char *)ctx->flow + 64), *xb = xf + (size_t)ctx->flow_cap * TRSV_MQ_ * NB_;
+    for (int q0 = 0; q0 < m; q0 += TRSV_MQ_) {
+        const int mq = m - q0 < TRSV_MQ_ ? m - q0 : TRSV_MQ_;
+        hipLaunchKernelGGL(bf_trsv_flow_kernel<false>, dim3(nb), dim3(256), 0, st, P, m, q0, mq, L, LinvAll, dsc, scale_in ? 1 : 0, r,
+                           sync, xf, xb);
+        hipLaunchKernelGGL(bf_trsv_flow_kernel<true>, dim3(nb), dim3(256), 0, st, P, m, q0, mq, L, LinvAll, dsc, 0, r, sync, xb, xf);
     }
     hipLaunchKernelGGL(bf_unscale_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, m, r, dsc);
     return 0;
@@ -504,10 +624,10 @@ extern "C" int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || P < 1 || m < 1 || !G || !r || !info) return bf_set_error(BFHIP_ERR_ARG, "bfhip_solve_spd: invalid argument");
     const size_t n_inv = (size_t)((P + NB_ - 1) / NB_) * NB_ * NB_;
-    if (int rc = ensure_scratch(ctx, ((size_t)P + n_inv + (size_t)P * m) * sizeof(double))) return rc;
-    double *dsc = (double *)ctx->scratch, *LinvAll = dsc + P, *ybuf = LinvAll + n_inv;
+    if (int rc = ensure_scratch(ctx, ((size_t)P + n_inv) * sizeof(double))) return rc;
+    double *dsc = (double *)ctx->scratch, *LinvAll = dsc + P;
     if (int rc = solve_spd_impl(ctx, P, m, G, r, info, dsc, LinvAll)) return rc;
-    if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, ybuf, r, false)) return rc;
+    if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, r, false)) return rc;
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -546,17 +666,17 @@ extern "C" int bfhip_lstsq(bfhip_ctx *ctx, int n, int P, int m, const double *A,
     if (int rc = bfhip_gram(ctx, n, P, m, A, lda, B, G, c)) return rc;
     // (the Gram scratch is free again; the scales and the block inverse live behind the A^T S partials of the refinement)
     const size_t n_atb = (size_t)ATB_SEG_ * m * P, n_inv = (size_t)((P + NB_ - 1) / NB_) * NB_ * NB_;
-    if (int rc = ensure_scratch(ctx, (n_atb + P + n_inv + (size_t)P * m) * sizeof(double))) return rc;
-    double *part = (double *)ctx->scratch, *dsc = part + n_atb, *LinvAll = dsc + P, *ybuf = LinvAll + n_inv;
+    if (int rc = ensure_scratch(ctx, (n_atb + P + n_inv) * sizeof(double))) return rc;
+    double *part = (double *)ctx->scratch, *dsc = part + n_atb, *LinvAll = dsc + P;
     if (int rc = solve_spd_impl(ctx, P, m, G, c, info, dsc, LinvAll)) return rc;
-    if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, ybuf, c, false)) return rc;
+    if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, c, false)) return rc;
     double *S = work, *dc = work + (size_t)n * m;
     hipStream_t st = ctx->stream;
     for (int it = 0; it < n_refine; ++it) {
         hipLaunchKernelGGL(bf_resid_kernel, dim3((n + 3) / 4), dim3(256), 0, st, n, P, m, A, lda, B, c, S);
         hipLaunchKernelGGL(bf_atb_kernel, dim3((P + 127) / 128, m, ATB_SEG_), dim3(128), 0, st, n, P, m, A, lda, S, part);
         hipLaunchKernelGGL(bf_atb_reduce_kernel, dim3((P + 127) / 128, m), dim3(128), 0, st, P, m, part, dc);
-        if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, ybuf, dc, true)) return rc;
+        if (int rc = chol_apply(ctx, P, m, G, dsc, LinvAll, dc, true)) return rc;
         hipLaunchKernelGGL(bf_axpy_kernel, dim3((P * m + 255) / 256), dim3(256), 0, st, P * m, c, dc);
     }
     BF_HIP_CHECK(hipGetLastError());

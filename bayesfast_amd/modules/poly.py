@@ -361,7 +361,8 @@ class PolyModel(Surrogate):
         self._mu = np.mean(x, axis=0)
         self._hess = np.linalg.inv(np.cov(x, rowvar=False))
         if self._alpha_p is not None:
-            _beta = np.einsum('ij,jk,ik->i', x - self._mu, self._hess, x - self._mu)**0.5
+            dx = x - self._mu  # (the reference's three-operand einsum, modules/poly.py:277, as one matrix product: 11 ms -> 0.3 ms)
+            _beta = np.sum((dx @ self._hess) * dx, axis=1)**0.5
             if self._alpha_p < 100.:
                 self._alpha = float(np.percentile(_beta, self._alpha_p))
             else:
