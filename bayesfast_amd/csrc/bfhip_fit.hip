@@ -322,8 +322,11 @@ __device__ __forceinline__ void bf_chol64_two_waves(double (*S)[LDP_], double (*
             }
             if (j & 1) sm[0] -= S[j][j - 1] * x[j - 1];
             x[j] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * Lc[j][NB_];
-            Linv[j * NB_ + t] = x[j];
+            asm volatile("" : "+v"(x[j]));
         }
+        // (stored at the end: a store inside the loop would make every step's acquire fence wait for it)
+#pragma unroll
+        for (int j = 0; j < NB_; ++j) Linv[j * NB_ + t] = x[j];
     }
 }
 

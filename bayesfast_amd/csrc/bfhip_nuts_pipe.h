@@ -69,8 +69,9 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
-    const int chain = blockIdx.x * 16 + w;
-    const bool real = chain < a.n_chain;
+    const int cpg = a.cpg > 0 ? a.cpg : 16;  // chains of this workgroup (wave_layout_cpg; the other waves only run matvec jobs)
+    const int chain = blockIdx.x * cpg + w;
+    const bool real = w < cpg && chain < a.n_chain;
     const int d = m.d;
     const bool lane_ok = lane < DP;
 

@@ -198,8 +198,9 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
-    const int chain = blockIdx.x * NWV + w;
-    const bool real = chain < a.n_chain;
+    const int cpg = a.cpg > 0 ? a.cpg : NWV;  // chains of this workgroup (the other waves only run matvec jobs)
+    const int chain = blockIdx.x * cpg + w;
+    const bool real = w < cpg && chain < a.n_chain;
     const int d = m.d;
 
     // ---- stage the coefficient matrices (A-operand fragments) in LDS ----
@@ -1298,14 +1299,29 @@ static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
     return dbl * sizeof(double);
 }
 
+// Chains per workgroup of the wave-per-chain kernels.  A launch lasts (trips of its longest chain) x (time of a trip), and a
+// trip is its matvec jobs -- the same MFMAs whatever the number of columns in use -- plus the bookkeeping of the chains'
+// waves, which share four SIMDs.  When the chains do not fill the chip at 16 per workgroup, fewer chains per workgroup
+// on more CUs shorten the trip: the waves without a chain still take their share of the jobs.  (Results do not depend on
+// it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG overrides (tuning).
+static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
+    static const int forced = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced < nwv ? forced : nwv;
+    int cpg = nwv;
+    while (cpg > 1 && (n_chain + cpg / 2 - 1) / (cpg / 2) <= ctx->n_cu) cpg /= 2;
+    return cpg;
+}
+
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM = false>
-static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args) {
+static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = bf_sampler_kernel<W, NUTS, STAMPS, FS, FULLM>;
     const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int NWV = BF_SAMPLER_WAVES(W);
-    const int groups = (args.n_chain + NWV - 1) / NWV;
+    SamplerArgs args = args_in;
+    args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
+    const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
     hipLaunchKernelGGL(k, dim3(groups), dim3(NWV * 64), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1317,12 +1333,14 @@ static bool g_no_pipe = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return
 extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 
 template <int W, bool TR = false>
-static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args) {
+static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = bf_nuts_pipe_kernel<W, TR>;
     const size_t lds = PipeGeo<W>::lds_doubles() * sizeof(double);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int groups = (args.n_chain + 15) / 16;
+    SamplerArgs args = args_in;
+    args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
+    const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
     hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1393,6 +1411,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     const DevModel &m = ctx->model;
     const int W = m.DP / 16;
     SamplerArgs args;
+    args.cpg = 0;
     args.cfg = *cfg;
     args.n_chain = n_chain;
     args.iter_end = iter_end;

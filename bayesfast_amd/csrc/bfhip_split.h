@@ -147,6 +147,12 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #if defined(BF_SPLIT_ONLY) && !defined(BF_HOST_EMU)  // tuning builds: one role's register needs on its own (the kernel hangs)
     if ((BF_SPLIT_ONLY == 1) != integ) return;
 #endif
+#if defined(BF_K_PRIO) && !defined(BF_HOST_EMU)  // tuning: issue priority of the bookkeepers over the integrators of their SIMD
+    if (!integ) __builtin_amdgcn_s_setprio(BF_K_PRIO);
+#endif
+#if defined(BF_I_PRIO) && !defined(BF_HOST_EMU)
+    if (integ) __builtin_amdgcn_s_setprio(BF_I_PRIO);
+#endif
     if (integ) {
         // =====================================================================================================
         // INTEGRATOR
@@ -877,6 +883,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
         }
         const bool any_end = bf_any(st != S_NONE);
+        STRACE(1, 6);
         if (any_end) {
             if (st == S_ABORT) {
                 // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
@@ -1026,6 +1033,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     command(SC_STOP, 0., 0);
                 }
             }
+            STRACE(1, 7);
             // next iteration: metric.random, then the tree starts at the proposal with its value and gradient
             if (bf_any(new_iter)) {
                 double pnew[4];

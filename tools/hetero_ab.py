@@ -7,5 +7,6 @@ import bench
 from bayesfast_amd.device import get_context
 ctx = get_context(0)
 lay = os.environ.get('LAYOUT', 'auto')
-r = bench.hetero_rate(ctx, 64, 4096, 2024, 250, layout=lay)
-print('layout', lay, 'BFHIP_NUTS_KERNEL', os.environ.get('BFHIP_NUTS_KERNEL', '-'), 'hetero %.4g' % r['value'], 'mean tree', r['mean_tree_size'])
+C = int(os.environ.get('CHAINS', 4096))
+r = bench.hetero_rate(ctx, 64, C, 2024, 250, layout=lay)
+print('chains', C, 'BFHIP_WAVE_CPG', os.environ.get('BFHIP_WAVE_CPG', 'auto'), 'layout', lay, 'BFHIP_NUTS_KERNEL', os.environ.get('BFHIP_NUTS_KERNEL', '-'), 'hetero %.4g' % r['value'], 'mean tree', r['mean_tree_size'])

@@ -19,10 +19,10 @@ L.bfhip_debug_gstamps(C.c_void_p(buf.data_ptr()))
 dc.run(20, 'NUTS', n_warmup=750, layout='split')
 L.bfhip_debug_gstamps(None)
 t = buf.cpu().numpy().reshape(N, 2, 8).astype(np.int64)
-print('integrator: top | ->B1 | B1 | tiles | posted | B2      bookkeeper: top | ->B1 | B1 | sums read | machine done | B2   (cycles from the integrator\'s top)')
+print('integrator: top | ->B1 | B1 | tiles | posted | B2      bookkeeper: top | ->B1 | B1 | sums read | machine done | B2 || leaf and merges done | iteration end done (rows, adaptation)   (cycles from the integrator\'s top)')
 for i in range(2, N - 1):
     t0 = t[i, 0, 0]
     if t0 == 0 or t[i + 1, 0, 0] == 0: continue
     a = ' '.join('%5d' % int(t[i, 0, k] - t0) for k in range(1, 6))
-    b = ' '.join('%5d' % int(t[i, 1, k] - t0) for k in range(0, 6))
+    b = ' '.join('%5d' % int(t[i, 1, k] - t0) for k in range(0, 6)) + ' || ' + ' '.join('%5d' % (int(t[i, 1, k] - t0) if t[i, 1, k] else 0) for k in (6, 7))
     print('  trip %3d total %6d | I %s | K %s' % (i, int(t[i + 1, 0, 0] - t0), a, b))
