@@ -233,6 +233,26 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
     }
     if (tid < 6) alive[tid] = 0;
     for (int i = tid; i < PD_N * DP; i += NTH) PDL[i] = m.pd[i];
+    // cubic configs: the coefficient tables behind the matvec results when they fit (sampler_cubic_lds: config 5's 16
+    // masked inputs are 36 KB), the masks of this lane in registers
+    const bool cub_l = f_cubic && a.cub_lds != 0;
+    double *CUB = GB + (((size_t)a.gbn * 16 * GS + 1) & ~(size_t)1);  // [n2 n2] A2t | [n2 n2] A2 | [n3 n3 n3] T3t
+    int mk2 = 0, mk3 = 0, pj2[E], pj3[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) pj2[e] = pj3[e] = -1;
+    if (cub_l) {
+        const int n22 = m.n2 * m.n2, n33 = m.n3 * m.n3 * m.n3;
+        for (int i = tid; i < n22; i += NTH) { CUB[i] = m.A2t[i]; CUB[n22 + i] = m.A2[i]; }
+        for (int i = tid; i < n33; i += NTH) CUB[2 * n22 + i] = m.T3t[i];
+        mk2 = lane < m.n2 ? m.mask2[lane] : 0;
+        mk3 = lane < m.n3 ? m.mask3[lane] : 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
+            pj2[e] = (dim < m.DP && m.n2 > 0) ? m.pos2[dim] : -1;
+            pj3[e] = (dim < m.DP && m.n3 > 0) ? m.pos3[dim] : -1;
+        }
+    }
 
     // ---- per-lane constants: the per-dimension table rows of this lane's dimensions ----
     double c_lin[E], c_mu[E];
@@ -1082,6 +1102,58 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                     (void)add_value; (void)fval;
                 };
                 double fsum = 0.;
+                if (cub_l) {
+                    // the same sums in the same order with the tables in LDS, the masked inputs gathered once (lane k
+                    // holds x[mask[k]]) and the masks and positions of this lane in registers: nothing of the loops below
+                    // goes to global memory (the 64 dependent global loads of the cubic-3 contraction were 2/3 of config 5's trip)
+                    const int n2 = m.n2, n3 = m.n3;
+                    const double *A2t_l = CUB, *A2_l = CUB + n2 * n2, *T3_l = CUB + 2 * n2 * n2;
+                    const double xm2 = xl(mk2), xm3 = xl(mk3);
+                    auto fetch_l = [&](const int (&pj)[E], int jb, double val, double (&dst)[E]) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const bool mine = pj[e] >= jb && pj[e] < jb + 16;
+                            const double gv = __shfl(val, mine ? pj[e] - jb : 0, 64);
+                            if (mine) dst[e] += gv;
+                        }
+                    };
+                    for (int jb = 0; jb < n2; jb += 16) {
+                        const int j = jb + jl;
+                        const bool on = j < n2;
+                        double v1 = 0., v2 = 0.;
+                        for (int kk = 0; kk < n2; kk += 4) {
+                            const int k = kk + kq;
+                            const bool ok = on && k < n2;
+                            const double xk = __shfl(xm2, ok ? k : 0, 64);
+                            v1 += (ok ? A2t_l[k * n2 + j] : 0.) * xk;
+                            v2 += (ok ? A2_l[k * n2 + j] : 0.) * (xk * xk);
+                        }
+                        v1 = swap32_add_f64(swap16_add_f64(v1));
+                        v2 = swap32_add_f64(swap16_add_f64(v2));
+                        const double xj = __shfl(xm2, on ? j : 0, 64);
+                        const double gj2 = 2. * xj * v1 + v2;
+                        if (on && kq == 0) fsum += xj * xj * v1;
+                        fetch_l(pj2, jb, gj2, gn);
+                    }
+                    for (int jb = 0; jb < n3; jb += 16) {
+                        const int j = jb + jl;
+                        const bool on = j < n3;
+                        double sacc = 0.;
+                        for (int kk = 0; kk < n3; kk += 4) {
+                            const int k = kk + kq;
+                            const bool ok = on && k < n3;
+                            double t = 0.;
+                            const double *Tk = T3_l + (ok ? k : 0) * n3 * n3 + (ok ? j : 0);
+#pragma unroll 4
+                            for (int l = 0; l < n3; ++l) t += (ok ? Tk[l * n3] : 0.) * readlane_f64(xm3, l);
+                            sacc += t * __shfl(xm3, ok ? k : 0, 64);
+                        }
+                        sacc = swap32_add_f64(swap16_add_f64(sacc));
+                        const double xj = __shfl(xm3, on ? j : 0, 64);
+                        if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
+                        fetch_l(pj3, jb, 0.5 * sacc, gn);
+                    }
+                } else {
                 for (int jb = 0; jb < m.n2; jb += 16) {   // cubic-2: f = sum_j x_j^2 v1_j, v1 = A x; df/dx_j = 2 x_j v1_j + (A^T x^2)_j
                     const int j = jb + jl;
                     const bool on = j < m.n2;
@@ -1116,6 +1188,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(De
                     const double xj = xl(on ? m.mask3[j] : 0);
                     if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
                     fetch(m.pos3, jb, 0.5 * sacc, gn, false, 0.);
+                }
                 }
                 r_cub = wave_sum(fsum);
             }
@@ -1288,7 +1361,7 @@ static int sampler_gb_slots(const DevModel &m) {
     return n_mat * sampler_ksplit(m) > 1 ? n_mat * sampler_ksplit(m) : 1;
 }
 
-static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
+static size_t sampler_lds_base(const DevModel &m, bool plain) {
     const int W = m.DP / 16, DP = m.DP, NS = 4 * W;
     size_t dbl = (size_t)3 * NS * 65 + (size_t)sampler_gb_slots(m) * 16 * (DP + 1) + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 4 +
                  (size_t)16 * CS_N + (size_t)PD_N * DP;
@@ -1296,7 +1369,18 @@ static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
         dbl += (size_t)2 * DP * (DP + 2) + (size_t)2 * 16 * DP;
     else if (DP <= 64)
         dbl += (size_t)DP * DP * ((m.has_quad ? 1 : 0) + (m.use_bound ? 1 : 0) + (m.use_decay ? 1 : 0));
-    return dbl * sizeof(double);
+    return dbl;
+}
+// cubic coefficient tables in LDS (bf_sampler_kernel: cub_l): when both masks fit a wave and the tables fit behind the rest
+static size_t sampler_cubic_doubles(const DevModel &m) {
+    return (size_t)2 * m.n2 * m.n2 + (size_t)m.n3 * m.n3 * m.n3 + 2;
+}
+static bool sampler_cubic_lds(const DevModel &m, bool plain) {
+    return m.has_cubic && m.n2 <= 64 && m.n3 <= 64 &&
+           (sampler_lds_base(m, plain) + sampler_cubic_doubles(m)) * sizeof(double) <= (size_t)160 * 1024;
+}
+static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
+    return (sampler_lds_base(m, plain) + (sampler_cubic_lds(m, plain) ? sampler_cubic_doubles(m) : 0)) * sizeof(double);
 }
 
 // Chains per workgroup of the wave-per-chain kernels.  A launch lasts (trips of its longest chain) x (time of a trip), and a
@@ -1321,6 +1405,7 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     constexpr int NWV = BF_SAMPLER_WAVES(W);
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
+    args.cub_lds = sampler_cubic_lds(ctx->model, FS == 1) ? 1 : 0;
     const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
     hipLaunchKernelGGL(k, dim3(groups), dim3(NWV * 64), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
@@ -1412,6 +1497,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     const int W = m.DP / 16;
     SamplerArgs args;
     args.cpg = 0;
+    args.cub_lds = 0;
     args.cfg = *cfg;
     args.n_chain = n_chain;
     args.iter_end = iter_end;
