@@ -194,11 +194,14 @@ class SurrogateDensity:
 
     def _set_decay(self, x):
         """core/density.py:796-811."""
-        self._mu = np.mean(x, axis=0)
-        self._hess = np.linalg.inv(np.cov(x, rowvar=False))
+        from ..utils.threads import blas_single_thread
+        with blas_single_thread():  # (utils/threads.py)
+            self._mu = np.mean(x, axis=0)
+            self._hess = np.linalg.inv(np.cov(x, rowvar=False))
+            if self._alpha_p is not None:
+                dx = x - self._mu
+                beta = np.sum((dx @ self._hess) * dx, axis=1)**0.5  # (the three-operand einsum as one matrix product)
         if self._alpha_p is not None:
-            dx = x - self._mu
-            beta = np.sum((dx @ self._hess) * dx, axis=1)**0.5  # (the three-operand einsum as one matrix product)
             self._alpha = float(np.percentile(beta, self._alpha_p) if self._alpha_p < 100 else
                                 np.max(beta) * self._alpha_p / 100)
             self._alpha_2 = self._alpha**2

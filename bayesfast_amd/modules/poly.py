@@ -305,6 +305,7 @@ class PolyModel(Surrogate):
         groups = {}
         for ii in range(self._output_size):
             groups.setdefault(tuple(int(v) for v in self._recipe[ii]), []).append(ii)
+        pending = []
         for key, outs in groups.items():
             confs = [self._configs[k] for k in key if k >= 0]
             widths = [c._a_shape[0] for c in confs]
@@ -326,6 +327,10 @@ class PolyModel(Surrogate):
             work = ctx.empty((n * len(outs) + P * len(outs),))
             _lib.check(lib.bfhip_lstsq(h, n, P, len(outs), _ptr(A), P, _ptr(B), _ptr(G), _ptr(r), self._N_REFINE, _ptr(work),
                                        _ptr(info)))
+            pending.append((outs, confs, widths, P, A, B, G, r, info, work))
+        # the bound's statistics are host work on x alone: they run while the device solves
+        bound = self._bound_stats(x, logp) if (self._use_bound and not self._all_linear) else None
+        for outs, confs, widths, P, A, B, G, r, info, work in pending:
             if int(info.item()) != 0:
                 # numerically rank-deficient design matrix: LAPACK gelsd (modules/poly.py:570) would return the
                 # minimum-norm solution; here the normal equations get a relative ridge of 1e-9 on the diagonal
@@ -346,28 +351,34 @@ class PolyModel(Surrogate):
                     qq = int(np.argwhere(c._output_mask == ii)[0, 0])
                     c._set(sol[k:k + wd, jo], qq)
                     k += wd
+        del pending
         self._dev_model_key = None  # the device copy of the module is stale now
-        if self._use_bound and not self._all_linear:
-            self._set_bound(x, logp)
+        if bound is not None:
+            self._apply_bound(*bound)
         self._dev_model_key = None
 
-    def _set_bound(self, x, logp=None):
-        """mu, H = inv(cov), alpha and f_mu of the extrapolation bound (modules/poly.py:262-292)."""
+    def _bound_stats(self, x, logp=None):
+        """The part of ``_set_bound`` that only needs the fit points: mu, H = inv(cov), alpha and the point f_mu is taken at
+        (modules/poly.py:262-276)."""
         try:
             x = np.ascontiguousarray(x, dtype=np.float64)
             assert x.shape[-1] == self._input_size and x.ndim == 2
         except Exception:
             raise ValueError('invalid value for x.')
-        self._mu = np.mean(x, axis=0)
-        self._hess = np.linalg.inv(np.cov(x, rowvar=False))
+        from ..utils.threads import blas_single_thread
+        with blas_single_thread():  # (spinning BLAS workers starve the GPU runtime's threads: utils/threads.py)
+            mu = np.mean(x, axis=0)
+            hess = np.linalg.inv(np.cov(x, rowvar=False))
+            if self._alpha_p is not None:
+                dx = x - mu  # (the reference's three-operand einsum, modules/poly.py:277, as one matrix product: 11 ms -> 1 ms)
+                _beta = np.sum((dx @ hess) * dx, axis=1)**0.5
+        alpha = None
         if self._alpha_p is not None:
-            dx = x - self._mu  # (the reference's three-operand einsum, modules/poly.py:277, as one matrix product: 11 ms -> 0.3 ms)
-            _beta = np.sum((dx @ self._hess) * dx, axis=1)**0.5
             if self._alpha_p < 100.:
-                self._alpha = float(np.percentile(_beta, self._alpha_p))
+                alpha = float(np.percentile(_beta, self._alpha_p))
             else:
-                self._alpha = float(np.max(_beta) * self._alpha_p / 100.)
-        mu_f = self._mu
+                alpha = float(np.max(_beta) * self._alpha_p / 100.)
+        mu_f = mu
         if self._center_max:
             try:
                 logp = np.asarray(logp)
@@ -375,4 +386,14 @@ class PolyModel(Surrogate):
                 mu_f = x[np.argmax(logp)]
             except Exception:
                 warnings.warn('invalid value for logp. Disabling center_max for now.', RuntimeWarning)
-        self._f_mu = self._device_eval(mu_f, use_bound=False)[0]
+        return mu, hess, alpha, mu_f
+
+    def _apply_bound(self, mu, hess, alpha, mu_f):
+        self._mu, self._hess = mu, hess
+        if alpha is not None:
+            self._alpha = alpha
+        self._f_mu = self._device_eval(mu_f, use_bound=False)[0]  # (modules/poly.py:277-292: the fitted model at mu_f)
+
+    def _set_bound(self, x, logp=None):
+        """mu, H = inv(cov), alpha and f_mu of the extrapolation bound (modules/poly.py:262-292)."""
+        self._apply_bound(*self._bound_stats(x, logp))

@@ -308,8 +308,10 @@ int bfhip_design_block(bfhip_ctx *ctx, int order, int n, int n_in, const double 
  * Stands in for the factorisation inside scipy.linalg.lstsq (modules/poly.py:570). */
 int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, int lda, const double *B, double *G, double *r);
 
-/* Solves G c = r for SPD G (P,P) in place by blocked Cholesky on device: G is overwritten by its factor,
- * r (P,m) by the solution.  info (1,) int32 device flag: 0 ok, k>0 pivot k not positive. */
+/* Solves G c = r for SPD G (P,P) in place by blocked Cholesky on device: r (P,m) is overwritten by the solution, G by
+ * the factor of the Jacobi-equilibrated matrix in the solver's own layout (64 x 64 diagonal blocks of L in place, the
+ * blocks below the diagonal TRANSPOSED in the upper triangle; the strict lower triangle holds work values).  info (1,)
+ * int32 device flag: 0 ok, k>0 pivot k of the equilibrated matrix below 1e-11 (1-based, the first one). */
 int bfhip_solve_spd(bfhip_ctx *ctx, int P, int m, double *G, double *r, int *info);
 
 /* The least-squares solve of PolyModel.fit in one call (scipy.linalg.lstsq(A, b), modules/poly.py:570): c (P,m) =
