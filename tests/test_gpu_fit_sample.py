@@ -56,7 +56,7 @@ def test_gram_and_solve_vs_numpy():
     from bayesfast_amd import _lib
     ctx = get_context(0)
     rng = np.random.default_rng(0)
-    for n, P, m in ((300, 70, 2), (1000, 333, 1), (130, 129, 3)):
+    for n, P, m in ((300, 70, 2), (1000, 333, 1), (130, 129, 3), (500, 200, 6), (60, 50, 1)):   # (m = 6: two passes of the sweeps)
         A = rng.normal(size=(n, P))
         B = rng.normal(size=(n, m))
         At, Bt = ctx.tensor(A, torch.float64), ctx.tensor(B, torch.float64)
