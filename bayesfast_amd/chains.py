@@ -46,6 +46,7 @@ class DeviceChains:
         if x_0.dim() != 2 or x_0.shape[1] != density.d:
             raise ValueError('x_0 should have shape (n_chain, {}).'.format(density.d))
         self.n_chain, self.d = x_0.shape
+        self._n_cu = None
         lib, h = self.ctx._lib, self.ctx.handle
         self.rng = torch.empty((self.n_chain, 4), dtype=torch.int64, device=self.ctx.device)
         self.sc = self.ctx.empty((self.n_chain, _lib.SC_N))
@@ -139,6 +140,8 @@ class DeviceChains:
             lay = layout
             if lay == 'auto':
                 lay = IN_STEP_LAYOUT if (sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)) else 'wave'
+                if sampler == 'NUTS' and self._small_problem():
+                    lay = 'wave'
             cfg.chain_layout = {'group': 1, 'wave': 2, 'split': 3}[lay]
             self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
@@ -153,6 +156,22 @@ class DeviceChains:
         if check:
             self.raise_on_error()
         return samples, stats
+
+    def _small_problem(self):
+        """NUTS at d <= 32 with fewer chains than fill the chip at 16 per workgroup (or d <= 16 at any size): the lane-per-chain
+        kernel has d / 16 waves per workgroup -- two of four SIMDs idle at d = 32 -- while the wave-per-chain kernel spreads
+        fewer chains per workgroup over more CUs (bfhip_sampler.hip: wave_layout_cpg).  Measured, in-step 7-leaf trees
+        (tools/layout_ab.py): 32-d x 1024 chains 3.2 against 2.2 x 10^8, x 2048 5.5 against 4.4, x 4096 8.2 against 8.7;
+        16-d x 1024 2.8 against 1.8, x 4096 7.5 against 7.2; 64-d: equal up to 1024 chains, the split layout ahead from 2048.
+        A function of the shapes only (never of timing); the layouts give identical results."""
+        if self._n_cu is None:
+            self._n_cu = int(_torch().cuda.get_device_properties(self.ctx.device).multi_processor_count)
+        sp = self.density.spec
+        plain = (not sp.get('use_decay') and sp.get('ranges') is None and sp.get('su_lo') is None and sp.get('link') is None and
+                 bool(sp['poly'].get('use_bound')) and sorted(c['order'] for c in sp['poly']['configs']) == ['linear', 'quadratic'])
+        if not plain or self.full_metric:   # (measured on the plain surrogate only: the pipelined wave-per-chain kernel)
+            return False
+        return self.d <= 16 or (self.d <= 32 and self.n_chain < 16 * self._n_cu)
 
     def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
                      target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,

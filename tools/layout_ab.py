@@ -1,5 +1,5 @@
 """Tuning: the in-step layouts ('group', 'split') and 'wave' on the headline surrogate at a given target_accept (tree size) and
-chain count: post-adaptation launches, leapfrog steps/s.  usage: python tools/layout_ab.py [target_accept] [chains]"""
+chain count: post-adaptation launches, leapfrog steps/s.  usage: python tools/layout_ab.py [target_accept] [chains] [dim]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,10 +9,13 @@ from bayesfast_amd.workloads import correlated_gaussian_spec
 from bayesfast_amd import _lib
 ta = float(sys.argv[1]) if len(sys.argv) > 1 else 0.8
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 ctx = get_context(0)
-spec, _ = correlated_gaussian_spec(64)
+spec, _ = correlated_gaussian_spec(D)
 dens = DeviceDensity(spec, ctx)
-x0 = np.random.default_rng(1).normal(size=(C, 64))
+x0 = np.random.default_rng(1).normal(size=(C, D))
+KN = _lib.lib().bfhip_debug_last_kernel
+KN.restype = __import__('ctypes').c_char_p
 for layout in ('group', 'split', 'wave'):
     ch = DeviceChains(dens, x0, seed=3)
     kw = dict(n_warmup=750, target_accept=ta, check=False, layout=layout)
@@ -26,5 +29,5 @@ for layout in ('group', 'split', 'wave'):
     e1.record(ctx.stream)
     torch.cuda.synchronize()
     ts = st[:, :, _lib.NSTATS.index('tree_size')].mean().item()
-    print('target_accept %.2f chains %d layout %-5s: %.4g leapfrog steps/s, mean tree size %.1f' % (
-        ta, C, layout, (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), ts))
+    print('d %d target_accept %.2f chains %d layout %-5s (%s): %.4g leapfrog steps/s, mean tree size %.1f' % (
+        D, ta, C, layout, KN().decode(), (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), ts))
