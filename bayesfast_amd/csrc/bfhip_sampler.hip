@@ -1387,9 +1387,11 @@ static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
 // trip is its matvec jobs -- the same MFMAs whatever the number of columns in use -- plus the bookkeeping of the chains'
 // waves, which share four SIMDs.  When the chains do not fill the chip at 16 per workgroup, fewer chains per workgroup
 // on more CUs shorten the trip: the waves without a chain still take their share of the jobs.  (Results do not depend on
-// it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG overrides (tuning).
+// it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG / bfhip_debug_wave_cpg override (tests, tuning).
+static int g_wave_cpg = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
+extern "C" void bfhip_debug_wave_cpg(int v) { g_wave_cpg = v; }  // test / tuning hook (0: automatic)
 static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
-    static const int forced = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
+    const int forced = g_wave_cpg;
     if (forced > 0) return forced < nwv ? forced : nwv;
     int cpg = nwv;
     while (cpg > 1 && (n_chain + cpg / 2 - 1) / (cpg / 2) <= ctx->n_cu) cpg /= 2;

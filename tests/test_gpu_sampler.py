@@ -188,6 +188,39 @@ def test_group_kernel_bound_proof_never_changes_results(ctx, case):
     assert out[0][-1] == out[1][-1]
 
 
+@pytest.mark.parametrize('kernel', ['pipe', 'sliced', 'sliced128'])
+def test_chains_per_workgroup_never_change_results(ctx, kernel):
+    """The wave-per-chain kernels with 16, 4 and 1 chains per workgroup (bfhip_sampler.hip: wave_layout_cpg; the waves without a
+    chain only run matvec jobs): samples, statistics, adapted state and random streams are EQUAL, for a chain count that
+    leaves every workgroup size a ragged last group."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = 128 if kernel == 'sliced128' else 48
+    dens = DeviceDensity(correlated_gaussian_spec(d)[0], ctx)
+    x0 = np.random.default_rng(5).normal(size=(37, d))
+    out = {}
+    L = _lib.lib()
+    try:
+        L.bfhip_debug_no_group(1)
+        L.bfhip_debug_no_pipe(0 if kernel == 'pipe' else 1)
+        for cpg in (16, 4, 1):
+            L.bfhip_debug_wave_cpg(cpg)
+            dc = DeviceChains(dens, x0, seed=4)
+            s1, st1 = dc.run(24, 'NUTS', n_warmup=16, layout='wave')
+            s2, st2 = dc.run(8, 'NUTS', n_warmup=16, layout='wave')
+            out[cpg] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
+    finally:
+        L.bfhip_debug_wave_cpg(0)
+        L.bfhip_debug_no_pipe(0)
+        L.bfhip_debug_no_group(0)
+    for cpg in (4, 1):
+        for a, b in zip(out[16][:-1], out[cpg][:-1]):
+            assert np.array_equal(a, b, equal_nan=True), cpg
+        assert out[16][-1] == out[cpg][-1]
+
+
 @pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40', 'd32', 'd10', 'bounded'])
 def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     """bf_nuts_pipe_kernel (deferred bookkeeping, speculative next step, tree vectors in LDS) performs the same
