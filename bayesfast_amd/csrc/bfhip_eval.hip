@@ -77,6 +77,202 @@ __global__ __launch_bounds__(256) void bf_logp_grad_kernel(DevModel m, int stage
     }
 }
 
+// d = 128, the common surrogate (linear + quadratic configs with the bound, nothing else: bf_model_plain): one WORKGROUP of
+// eight waves evaluates 16 points.  Wave w owns row tile w of S X^T and H (X - mu)^T and dimensions 16 w .. 16 w + 15 of
+// the 16 points -- lane (c, g) element r is dimension 16 w + 4 r + g of point c, so the MFMA result lands on the lane
+// that owns it, as in the wave-local layout -- keeps the 2 x 32 A fragments of its tile in registers for the whole
+// launch, and the points' coordinates cross the waves through LDS as B operands.  (The wave-local kernel above holds all
+// 128 dimensions of 16 points in ONE wave: 32 elements per lane for every vector of the evaluation and 256 operand loads
+// per matvec, 117-243 spilled VGPRs, 7 % of the FP64 MFMA rate.)  The sums over dimensions are taken per wave and then
+// over the eight waves in wave order: every wave holds the same totals and takes the same decisions.
+struct Coop128 {
+    static constexpr int NS = 32;
+    double afS[NS], afH[NS];   // A fragments of this wave's row tile
+    double c_lin[4], c_mu[4];
+    int lane, w, c, g;
+};
+__device__ __forceinline__ void bf_coop128_init(Coop128 &k, const DevModel &m) {
+    k.lane = threadIdx.x & 63;
+    k.w = threadIdx.x >> 6;
+    k.c = k.lane & 15;
+    k.g = k.lane >> 4;
+#pragma unroll
+    for (int s = 0; s < Coop128::NS; ++s) {
+        k.afS[s] = m.Sf[(size_t)(k.w * Coop128::NS + s) * 64 + k.lane];
+        k.afH[s] = m.Hf[(size_t)(k.w * Coop128::NS + s) * 64 + k.lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int dim = 16 * k.w + 4 * r + k.g;
+        k.c_lin[r] = m.pd[PD_LIN * 128 + dim];
+        k.c_mu[r] = m.pd[PD_MU * 128 + dim];
+    }
+}
+__device__ __forceinline__ d4_t bf_coop128_matvec(const double (&af)[Coop128::NS], const double (*xb)[64], int lane) {
+    d4_t acc = {0., 0., 0., 0.};
+#pragma unroll
+    for (int s = 0; s < Coop128::NS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], xb[s][lane], acc, 0, 0, 0);
+    return acc;
+}
+// the eight waves' partial sums of point c, in wave order
+__device__ __forceinline__ double bf_coop128_total(const double (*rb)[16], int c) {
+    double t = rb[0][c];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += rb[j][c];
+    return t;
+}
+// logp and gradient (this lane's four dimensions) of the workgroup's 16 points at xv; contains workgroup barriers: the
+// first one also separates this evaluation from whatever used XB / RB before it
+__device__ __forceinline__ void bf_coop128_eval(const Coop128 &k, const DevModel &m, double (*XB)[Coop128::NS][64],
+                                                double (*RB)[8][16], const double (&xv)[4], double &f, double (&gv)[4]) {
+    const int lane = k.lane, w = k.w, c = k.c, g = k.g;
+    double xm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xm[r] = xv[r] - k.c_mu[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        XB[0][4 * w + r][lane] = xv[r];
+        XB[1][4 * w + r][lane] = xm[r];
+    }
+    __syncthreads();
+    const d4_t gS = bf_coop128_matvec(k.afS, XB[0], lane), gH = bf_coop128_matvec(k.afH, XB[1], lane);
+    double quad = 0., lin = 0., b2 = 0.;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        quad += xv[r] * gS[r];
+        lin += k.c_lin[r] * xv[r];
+        b2 += xm[r] * gH[r];
+        gv[r] = gS[r] + k.c_lin[r];
+    }
+    quad = bf_sum_g(quad); lin = bf_sum_g(lin); b2 = bf_sum_g(b2);
+    if (g == 0) { RB[0][w][c] = quad; RB[1][w][c] = lin; RB[2][w][c] = b2; }
+    __syncthreads();
+    quad = bf_coop128_total(RB[0], c); lin = bf_coop128_total(RB[1], c); b2 = bf_coop128_total(RB[2], c);
+    f = (m.c0 + lin) + 0.5 * quad;
+    // linear extrapolation outside the alpha-ellipsoid (modules/poly.py:480-503); rare: one more S tile for the group
+    const double beta = sqrt(b2);
+    const bool oob = beta > m.alpha;
+    if (__any(oob)) {  // (the same in every wave: they hold the same totals)
+        double x0[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x0[r] = oob ? (m.alpha * xv[r] + (beta - m.alpha) * k.c_mu[r]) / beta : xv[r];
+        __syncthreads();  // (every wave has read RB and XB[0])
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XB[0][4 * w + r][lane] = x0[r];
+        __syncthreads();
+        const d4_t j0 = bf_coop128_matvec(k.afS, XB[0], lane);
+        double quad0 = 0., lin0 = 0., dotj = 0., j0v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            quad0 += x0[r] * j0[r];
+            lin0 += k.c_lin[r] * x0[r];
+            j0v[r] = j0[r] + k.c_lin[r];
+            dotj += j0v[r] * xm[r];
+        }
+        quad0 = bf_sum_g(quad0); lin0 = bf_sum_g(lin0); dotj = bf_sum_g(dotj);
+        if (g == 0) { RB[0][w][c] = quad0; RB[1][w][c] = lin0; RB[2][w][c] = dotj; }
+        __syncthreads();
+        quad0 = bf_coop128_total(RB[0], c); lin0 = bf_coop128_total(RB[1], c); dotj = bf_coop128_total(RB[2], c);
+        if (oob) {
+            const double f0 = (m.c0 + lin0) + 0.5 * quad0;
+            f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
+            const double coef = (f0 - m.f_mu) / m.alpha - dotj / beta;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[r] = j0v[r] + coef * (gH[r] / beta);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void bf_logp_grad_coop128_kernel(DevModel m, int n, const double *__restrict__ x,
+                                                                   double *__restrict__ logp, double *__restrict__ grad) {
+    __shared__ double XB[2][Coop128::NS][64];   // B operands of the 32 k-steps: x | x - mu
+    __shared__ double RB[4][8][16];             // per-wave partial sums of the 16 points
+    Coop128 k;
+    bf_coop128_init(k, m);
+    const int n_tiles = (n + 15) / 16;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int pt = tile * 16 + k.c;
+        double xv[4], gv[4], f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dim = 16 * k.w + 4 * r + k.g;
+            xv[r] = (pt < n && dim < m.d) ? x[(size_t)pt * m.d + dim] : 0.;
+        }
+        bf_coop128_eval(k, m, XB, RB, xv, f, gv);
+        if (pt < n) {
+            if (k.w == 0 && k.g == 0) logp[pt] = f;
+            if (grad) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dim = 16 * k.w + 4 * r + k.g;
+                    if (dim < m.d) grad[(size_t)pt * m.d + dim] = gv[r];
+                }
+            }
+        }
+    }
+}
+
+// CpuLeapfrogIntegrator._step (integration.py:68-95) in the same layout
+__global__ __launch_bounds__(512) void bf_leapfrog_coop128_kernel(DevModel m, int n, const double *__restrict__ eps,
+                                                                  const double *__restrict__ var, double *__restrict__ q,
+                                                                  double *__restrict__ p, double *__restrict__ grad,
+                                                                  double *__restrict__ logp, double *__restrict__ energy,
+                                                                  double *__restrict__ vel) {
+    __shared__ double XB[2][Coop128::NS][64];
+    __shared__ double RB[4][8][16];
+    Coop128 k;
+    bf_coop128_init(k, m);
+    const int n_tiles = (n + 15) / 16;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int ch = tile * 16 + k.c;
+        const bool live = ch < n;
+        const double ep = live ? eps[ch] : 0.;
+        const double dt = 0.5 * ep;
+        double qn[4], pn[4], vr[4], gn[4], lp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dim = 16 * k.w + 4 * r + k.g;
+            const bool ok = live && dim < m.d;
+            const size_t idx = (size_t)ch * m.d + dim;
+            vr[r] = ok ? var[idx] : 1.;
+            const double pp = ok ? p[idx] : 0., gg = ok ? grad[idx] : 0., qq = ok ? q[idx] : 0.;
+            pn[r] = pp + dt * gg;              // integration.py:80
+            qn[r] = qq + ep * (vr[r] * pn[r]); // :82-85
+        }
+        bf_coop128_eval(k, m, XB, RB, qn, lp, gn);  // :87
+        double kin = 0.;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pn[r] = pn[r] + dt * gn[r];  // :90
+            const double v = vr[r] * pn[r];
+            kin += pn[r] * v;            // metrics.py:88-91
+            vr[r] = v;
+        }
+        kin = bf_sum_g(kin);
+        if (k.g == 0) RB[3][k.w][k.c] = kin;   // (a slot of its own: slower waves may still be reading the evaluation's)
+        __syncthreads();
+        kin = bf_coop128_total(RB[3], k.c);
+        if (live) {
+            if (k.w == 0 && k.g == 0) {
+                logp[ch] = lp;
+                energy[ch] = 0.5 * kin - lp;  // :92-93
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dim = 16 * k.w + 4 * r + k.g;
+                if (dim < m.d) {
+                    const size_t idx = (size_t)ch * m.d + dim;
+                    q[idx] = qn[r];
+                    p[idx] = pn[r];
+                    grad[idx] = gn[r];
+                    if (vel) vel[idx] = vr[r];
+                }
+            }
+        }
+    }
+}
+
 // CpuLeapfrogIntegrator._step (samplers/hmc_utils/integration.py:68-95), diagonal metric, n chains.
 template <int T, bool STAGE, bool PL>
 __global__ __launch_bounds__(256) void bf_leapfrog_kernel(DevModel m, int stage_dbl, int n, const double *__restrict__ eps,
@@ -196,7 +392,15 @@ extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int origi
     case 1: return launch_logp_grad<1, true>(ctx, grid, lds, n, x, original_space, logp, grad);
     case 2: return launch_logp_grad<2, true>(ctx, grid, lds, n, x, original_space, logp, grad);
     case 4: return launch_logp_grad<4, true>(ctx, grid, lds, n, x, original_space, logp, grad);
-    case 8: return launch_logp_grad<8, false>(ctx, grid, lds, n, x, original_space, logp, grad);
+    case 8:
+        if (bf_model_plain(ctx->model)) {  // (no transform: original_space makes no difference)
+            const int n_tiles = (n + 15) / 16;
+            hipLaunchKernelGGL(bf_logp_grad_coop128_kernel, dim3(n_tiles < ctx->n_cu ? n_tiles : ctx->n_cu), dim3(512), 0, ctx->stream,
+                               ctx->model, n, x, logp, grad);
+            BF_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+        return launch_logp_grad<8, false>(ctx, grid, lds, n, x, original_space, logp, grad);
     }
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->model.DP);
 }
@@ -214,7 +418,15 @@ extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const do
     case 1: return launch_leapfrog<1, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
     case 2: return launch_leapfrog<2, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
     case 4: return launch_leapfrog<4, true>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
-    case 8: return launch_leapfrog<8, false>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
+    case 8:
+        if (bf_model_plain(ctx->model)) {
+            const int n_tiles = (n + 15) / 16;
+            hipLaunchKernelGGL(bf_leapfrog_coop128_kernel, dim3(n_tiles < ctx->n_cu ? n_tiles : ctx->n_cu), dim3(512), 0, ctx->stream,
+                               ctx->model, n, eps, var, q, p, grad, logp, energy, velocity_out);
+            BF_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+        return launch_leapfrog<8, false>(ctx, grid, lds, n, eps, var, q, p, grad, logp, energy, velocity_out);
     }
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->model.DP);
 }

@@ -57,6 +57,25 @@ def test_logp_grad_vs_oracle(ctx, case, n, scale):
     np.testing.assert_allclose(g, g0, rtol=1e-10, atol=1e-9)
 
 
+@pytest.mark.parametrize('d,n,scale', [(128, 4099, 1.0), (128, 300, 1.75), (100, 77, 1.8), (128, 5, 1.0)])
+def test_logp_grad_d128_cooperative_kernel_vs_oracle(ctx, d, n, scale):
+    """d > 64 on the common surrogate: bf_logp_grad_coop128_kernel (eight waves per 16 points, one row tile each) against
+    the C oracle -- points inside and outside the bound in the same tile, a padded dimension, ragged and tiny batches."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from oracle import oracle as orc
+    spec, _ = correlated_gaussian_spec(d)
+    x = np.random.default_rng(8).normal(size=(n, d)) * scale
+    lp0, g0 = orc.logp_and_grad(spec, x)
+    po = spec['poly']
+    beta = np.sqrt(np.einsum('ij,jk,ik->i', x - po['mu'], po['hess'], x - po['mu']))
+    if scale > 1.:
+        assert (beta > po['alpha']).any() and (beta < po['alpha']).any(), 'both branches in the batch'
+    lp, g = DeviceDensity(spec, ctx).logp_and_grad(x)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp0, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(g.cpu().numpy(), g0, rtol=1e-10, atol=1e-9)
+
+
 def test_logp_grad_empty_and_errors(ctx):
     import torch
     from bayesfast_amd.device import DeviceDensity
@@ -102,6 +121,38 @@ def test_leapfrog_golden_and_oracle(ctx, name):
         np.testing.assert_allclose(tp[i].cpu().numpy(), r['p'], rtol=1e-10, atol=1e-11)
         np.testing.assert_allclose(tg[i].cpu().numpy(), r['grad'], rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(energy[i].item(), r['energy'], rtol=1e-11, atol=1e-10)
+
+
+@pytest.mark.parametrize('d,n,scale', [(128, 333, 1.0), (100, 50, 1.9)])
+def test_leapfrog_d128_cooperative_kernel_vs_oracle(ctx, d, n, scale):
+    """CpuLeapfrogIntegrator._step at d > 64 on the common surrogate (bf_leapfrog_coop128_kernel) against the C oracle, end
+    points inside and outside the bound."""
+    import torch
+    from bayesfast_amd.device import DeviceDensity, _ptr
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    from oracle import oracle as orc
+    spec, _ = correlated_gaussian_spec(d)
+    rng = np.random.default_rng(6)
+    q = rng.normal(size=(n, d)) * scale
+    p = rng.normal(size=(n, d))
+    var = rng.uniform(0.5, 2., size=(n, d))
+    eps = rng.uniform(0.05, 0.15, size=n)
+    _, g_start = orc.logp_and_grad(spec, q)
+    ref = [orc.leapfrog(spec, var[i], eps[i], q[i], p[i], g_start[i]) for i in range(n)]
+    dd = DeviceDensity(spec, ctx)
+    qt, pt, gt = ctx.tensor(q, torch.float64), ctx.tensor(p, torch.float64), ctx.tensor(g_start, torch.float64)
+    lpt, et, vt = ctx.empty((n,)), ctx.empty((n,)), ctx.empty((n, d))
+    epst, vart = ctx.tensor(eps, torch.float64), ctx.tensor(var, torch.float64)
+    _lib.check(ctx._lib.bfhip_leapfrog(ctx.handle, n, _ptr(epst), _ptr(vart), _ptr(qt), _ptr(pt), _ptr(gt), _ptr(lpt), _ptr(et), _ptr(vt)))
+    for name, dev in (('q', qt), ('p', pt), ('grad', gt)):
+        np.testing.assert_allclose(dev.cpu().numpy(), np.stack([r[name] for r in ref]), rtol=1e-10, atol=1e-9, err_msg=name)
+    np.testing.assert_allclose(vt.cpu().numpy(), var * pt.cpu().numpy(), rtol=1e-14, atol=0)   # velocity = var p (metrics.py:88-91)
+    np.testing.assert_allclose(et.cpu().numpy(), np.array([r['energy'] for r in ref]), rtol=1e-11, atol=1e-9)
+    po = spec['poly']
+    beta = np.sqrt(np.einsum('ij,jk,ik->i', qt.cpu().numpy() - po['mu'], po['hess'], qt.cpu().numpy() - po['mu']))
+    if scale > 1.:
+        assert (beta > po['alpha']).any() and (beta < po['alpha']).any(), 'both branches in the batch'
 
 
 def test_constraint_transforms_golden(ctx):
