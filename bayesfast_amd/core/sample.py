@@ -70,8 +70,9 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
             torch.cuda.set_device(dev)
     b, e = parallel.shard_range(trace.n_chain, rank, ws)
     if prev is None:
-        if trace.x_0 is None:  # core/sample.py:106-113 (N(0, I) starts; the reference draws them from a Sobol sequence)
-            trace.x_0 = np.random.default_rng(trace.seed() ^ 0x5bd1e995).normal(size=(trace.n_chain, d))
+        if trace.x_0 is None:  # core/sample.py:106-113: Sobol-normal starts in the sampler's space, the reference's own points
+            from ..utils.sobol import multivariate_normal
+            trace.x_0 = multivariate_normal(np.zeros(d), np.eye(d), trace.n_chain)
             trace._x_0_transformed = True
         elif not trace.x_0_transformed:  # :114-116
             trace.x_0 = density.from_original(trace.x_0)

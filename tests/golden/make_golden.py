@@ -734,6 +734,22 @@ def gen_recipe(bf, out):
     np.savez_compressed(os.path.join(out, 'recipe.npz'), **z)
 
 
+def gen_sobol(bf, out):
+    """Default starting points of sample() (core/sample.py:106-113): Sobol-normal points, utils/sobol.py:49-61 (direction
+    numbers new-joe-kuo-6.21201, Gray-code order, the first point skipped)."""
+    from bayesfast.utils.sobol import multivariate_normal, uniform
+    z = {}
+    for d, n in ((2, 8), (5, 33), (64, 16), (128, 4)):
+        z['normal_%d_%d' % (d, n)] = multivariate_normal(np.zeros(d), np.eye(d), n)
+    z['uniform_3_10'] = uniform(np.zeros(3), np.ones(3), 10)
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(4, 4))
+    z['cov'] = a @ a.T + np.eye(4)
+    z['mean'] = rng.normal(size=4)
+    z['normal_cov_4_12'] = multivariate_normal(z['mean'], z['cov'], 12)
+    np.savez(os.path.join(out, 'sobol.npz'), **z)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -743,7 +759,7 @@ def main():
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
                 density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, tempered=gen_tempered,
-                fit_illcond=gen_fit_illcond, recipe=gen_recipe)
+                fit_illcond=gen_fit_illcond, recipe=gen_recipe, sobol=gen_sobol)
     for k, g in gens.items():
         if a.only and k != a.only:
             continue

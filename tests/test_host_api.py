@@ -340,3 +340,22 @@ def test_reference_timing_fixture_is_present_and_sane():
     assert 2e3 < rt['leapfrog_steps_per_sec_per_core'] < 1e5
     assert rt['quadratic_kernels_us'] < rt['polymodel_fun_and_jac_us'] < rt['logp_and_grad_us'] <= rt['leapfrog_step_us'] * 1.2
     assert rt['host']['logical_cpus'] >= 1 and rt['polymodel_fit_shape'] == [4290, 2145]
+
+
+def test_sobol_normal_points_equal_the_references():
+    """utils/sobol.py against fixtures of the reference's own generator (utils/sobol.py:12-61, utils/_sobol.pyx): the default
+    starting points of sample() (core/sample.py:106-113) are the reference's, bit for bit."""
+    import os
+    from bayesfast_amd.utils.sobol import multivariate_normal, uniform
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sobol.npz'))
+    for k in z.files:
+        if k.startswith('normal_') and 'cov' not in k:
+            d, n = (int(v) for v in k.split('_')[1:])
+            assert np.array_equal(multivariate_normal(np.zeros(d), np.eye(d), n), z[k]), k
+    assert np.array_equal(uniform(np.zeros(3), np.ones(3), 10), z['uniform_3_10'])
+    np.testing.assert_allclose(multivariate_normal(z['mean'], z['cov'], 12), z['normal_cov_4_12'], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(uniform(np.zeros(3), np.ones(3), 4, skip=7), z['uniform_3_10'][6:])
+    with pytest.raises(ValueError):
+        uniform(np.zeros(3), np.ones(2), 4)
+    with pytest.raises(ValueError):
+        multivariate_normal(np.zeros(3), np.eye(2), 4)
