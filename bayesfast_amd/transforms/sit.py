@@ -10,8 +10,8 @@ Each iteration rotates the data with FastICA and then Gaussianizes every rotated
   (``fit``'s update of the data, ``forward_transform`` / ``logq``, ``backward_transform`` / ``sample``):
   ``bfhip_spline_apply``.  The data stay on the GPU between iterations.
 
-Differences from the reference, on purpose: ``mvn_generator`` defaults to NumPy normals (the reference's Sobol generator
-is outside this build's scope); there is no plotting."""
+``mvn_generator`` defaults, as in the reference (transforms/sit.py:214-221), to its Sobol-normal points (``utils/sobol.py``).
+There is no plotting."""
 import warnings
 
 import numpy as np
@@ -19,13 +19,6 @@ import numpy as np
 from ..utils.spline import GaussianizingSpline, SplineTable
 
 __all__ = ['SIT']
-
-
-def _default_mvn(rng):
-    def gen(mean, cov, size):
-        a, w = np.linalg.eigh(np.atleast_2d(cov))
-        return np.atleast_1d(mean) + (rng.normal(size=(int(size), len(a))) * a**0.5) @ w.T
-    return gen
 
 
 class SIT:
@@ -53,7 +46,9 @@ class SIT:
         self.ica_options = dict(ica_options if ica_options is not None else {'max_iter': 100})
         if mvn_generator is not None and not callable(mvn_generator):
             raise ValueError('invalid value for mvn_generator.')
-        self.mvn_generator = mvn_generator or _default_mvn(self.random_generator)
+        if mvn_generator is None:  # transforms/sit.py:214-221
+            from ..utils.sobol import multivariate_normal as mvn_generator
+        self.mvn_generator = mvn_generator
         self._data = None
         self._tables = []
         self._A = self._B = self._m = self._logdetA = None
