@@ -1544,8 +1544,12 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
                  1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0));
         return bf_launch_group(ctx, args);
     }
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>",
-             (nuts && W <= 4 && !g_no_pipe && !args.mat && sampler_plain(m)) ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
+    {
+        // (the conditions of launch_sampler: the common surrogate, plain or behind the constraint transform)
+        const bool tr_only = m.has_quad && m.use_bound && m.has_transform && !m.use_decay && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
+        const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only);
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
+    }
     switch (W) {
 #ifndef BF_ONLY_HEADLINE  // tuning builds (-DBF_ONLY_HEADLINE) compile the 64-d instantiations only
     case 1: return nuts ? launch_sampler<1, true>(ctx, args) : launch_sampler<1, false>(ctx, args);

@@ -12,6 +12,9 @@ C = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 ctx = get_context(0)
 spec, _ = correlated_gaussian_spec(D)
+if os.environ.get('DECAY'):   # the decay term of core/density.py:740-746 around the bound's ellipsoid, never active here
+    po = spec['poly']
+    spec = dict(spec, use_decay=True, decay_mu=po['mu'], decay_hess=po['hess'], decay_alpha2=(float(os.environ['DECAY']) * po['alpha'])**2, decay_gamma=0.1)
 dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(1).normal(size=(C, D))
 KN = _lib.lib().bfhip_debug_last_kernel
@@ -29,5 +32,6 @@ for layout in ('group', 'split', 'wave'):
     e1.record(ctx.stream)
     torch.cuda.synchronize()
     ts = st[:, :, _lib.NSTATS.index('tree_size')].mean().item()
+    gc = torch.zeros(2, dtype=torch.int64, device='cuda')
     print('d %d target_accept %.2f chains %d layout %-5s (%s): %.4g leapfrog steps/s, mean tree size %.1f' % (
         D, ta, C, layout, KN().decode(), (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), ts))
