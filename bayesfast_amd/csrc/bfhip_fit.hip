@@ -333,7 +333,8 @@ __device__ __forceinline__ void bf_chol64_two_waves(double (*S)[LDP_], double (*
 // the first diagonal block (no panel before it)
 __global__ __launch_bounds__(256) void bf_chol_first_kernel(int P, double *__restrict__ G, double *__restrict__ Linv,
                                                           int *__restrict__ info) {
-    __shared__ double R0[NB_][LDP_], R1[NB_][LDP_];
+    __shared__ __attribute__((aligned(16))) double R0[NB_][LDP_];
+    __shared__ __attribute__((aligned(16))) double R1[NB_][LDP_];
     __shared__ int ready;
     const int nbk = min(NB_, P);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -346,7 +347,8 @@ __global__ __launch_bounds__(256) void bf_chol_first_kernel(int P, double *__res
 // panel k0 (a full 64 columns: there are rows below it): see above
 __global__ __launch_bounds__(256) void bf_chol_panel_kernel(int P, int k0, double *__restrict__ G, double *__restrict__ LinvAll,
                                                           int *__restrict__ info) {
-    __shared__ double R0[NB_][LDP_], R1[NB_][LDP_];
+    __shared__ __attribute__((aligned(16))) double R0[NB_][LDP_];
+    __shared__ __attribute__((aligned(16))) double R1[NB_][LDP_];
     __shared__ int ready;
     const int t0 = k0 + NB_;  // first trailing row
     const int nb = (P - t0 + NB_ - 1) / NB_;
