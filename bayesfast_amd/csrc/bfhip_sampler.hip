@@ -147,8 +147,10 @@ struct SamplerGeo {
 
 // Waves (= chains) per workgroup.  16 fills the 16 columns of the MFMA tiles; at d = 128 a chain's state takes two
 // registers per vector and lane, and 16 waves (128 VGPRs each) spill ~180 of them: there a workgroup is 8 waves with
-// 256 VGPRs each (half-empty tiles, twice as many workgroups).
-#define BF_SAMPLER_WAVES(W) ((W) == 8 ? 8 : 16)
+// 256 VGPRs each (half-empty tiles, twice as many workgroups).  The same for the full-rank metric at any d: its
+// matrix-vector products stream the chain's own d x d matrix in batches of 16 columns, and at 128 VGPRs the batches were
+// spilled -- 163 VGPRs of scratch -- so that every column's load was waited for on its own.
+#define BF_SAMPLER_WAVES(W, FULLM) (((W) == 8 || (FULLM)) ? 8 : 16)
 
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
 // extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
@@ -161,8 +163,8 @@ struct SamplerGeo {
 __device__ inline bool g_sliced_proof_on(const SamplerArgs &a) { return a.no_bound_proof == 0; }
 
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
-__global__ __launch_bounds__(BF_SAMPLER_WAVES(W) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
-    constexpr int NWV = BF_SAMPLER_WAVES(W), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
+__global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
+    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0;
     const bool f_quad = SPEC ? true : (bool)m.has_quad, f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
@@ -1404,7 +1406,7 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int NWV = BF_SAMPLER_WAVES(W);
+    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM);
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
     args.cub_lds = sampler_cubic_lds(ctx->model, FS == 1) ? 1 : 0;
