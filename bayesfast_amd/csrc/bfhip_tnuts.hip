@@ -401,8 +401,12 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     if (!bf_model_plain(m) || m.DP > 64 || cfg->full_metric)
         return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_tnuts_run: the tempered sampler covers the common surrogate (linear + quadratic "
                                                    "configs with the bound, no transform / scaling / decay / cubic) at d <= 64 with the diagonal metric");
-    constexpr int WPB = 8;
-    const size_t need = (size_t)((n_chain + WPB - 1) / WPB * WPB) * (4 * TN_MAXL) * 64 * sizeof(double);
+    // Waves (= chains) per workgroup.  The three staged matrices take 96 KB of LDS, so a CU holds ONE workgroup: with 8 waves
+    // of 256 registers 2048 chains run at a time and 4096 chains take two rounds; 16 waves of 128 registers (spilling ~50)
+    // keep all of them resident.  BFHIP_TNUTS_WPB overrides (tuning).
+    static const int forced = [] { const char *e = getenv("BFHIP_TNUTS_WPB"); return e ? atoi(e) : 0; }();
+    const int wpb = forced == 8 || forced == 16 ? forced : (n_chain > 8 * ctx->n_cu ? 16 : 8);
+    const size_t need = (size_t)((n_chain + 15) / 16 * 16) * (4 * TN_MAXL) * 64 * sizeof(double);
     if (ctx->scratch_bytes < need) {
         BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (ctx->scratch) BF_HIP_CHECK(hipFree(ctx->scratch));
@@ -418,10 +422,16 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     a.n_leapfrog = n_leapfrog;
     a.scratch = (double *)ctx->scratch;
     a.base_S = tp->base_S; a.base_lin = tp->base_lin; a.base_c0 = tp->base_c0; a.logxi = tp->logxi;
-    const size_t lds = ((size_t)3 * 4096 + WPB * 64 + WPB * TN_MAXL * TS_N) * sizeof(double);
-    auto k = bf_tnuts_kernel<WPB>;
-    BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((n_chain + WPB - 1) / WPB), dim3(64 * WPB), lds, ctx->stream, m, a);
+    const size_t lds = ((size_t)3 * 4096 + wpb * 64 + wpb * TN_MAXL * TS_N) * sizeof(double);
+    if (wpb == 16) {
+        auto k = bf_tnuts_kernel<16>;
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((n_chain + 15) / 16), dim3(64 * 16), lds, ctx->stream, m, a);
+    } else {
+        auto k = bf_tnuts_kernel<8>;
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((n_chain + 7) / 8), dim3(64 * 8), lds, ctx->stream, m, a);
+    }
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
