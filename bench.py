@@ -112,6 +112,50 @@ def hetero_rate(ctx, d, C, seed, iters, steps=3, layout='auto'):
                         '(adapt_metric off), target_accept 0.9, %d x %d post-adaptation iterations' % (C, d, steps, iters)}
 
 
+def other_samplers(ctx, d, cov, C, seed):
+    """Secondary figures: the two samplers of the path that are not the default -- NUTS with the full-rank metric
+    (QuadMetricFull, metrics.py:94-132; every chain streams its own d x d covariance twice per leapfrog step) after adaptation,
+    and tempered NUTS (samplers/tnuts.py, integration.py:98-222) with a Gaussian base density.  HIP events, one launch each."""
+    import torch
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    spec, _ = correlated_gaussian_spec(d)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(seed + 2).normal(size=(C, d))
+    out = {}
+
+    def timed(f):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(ctx.stream)
+        r = f()
+        e1.record(ctx.stream)
+        torch.cuda.synchronize()
+        return r, e0.elapsed_time(e1) * 1e-3
+
+    ch = DeviceChains(dens, x0, seed=seed + 2, metric='full')
+    ch.run(300, 'NUTS', n_warmup=300, check=False)
+    lf0 = ch.total_leapfrog
+    (_, st), t = timed(lambda: ch.run(100, 'NUTS', n_warmup=300, check=False))
+    ch.raise_on_error()
+    n_lf = ch.total_leapfrog - lf0
+    out['full_metric'] = {'value': n_lf / t, 'unit': 'leapfrog steps/sec', 'chains': C, 'dim': d,
+                          'mean_tree_size': float(st[:, :, _lib.NSTATS.index('tree_size')].mean().item()),
+                          'covariance_traffic_GBps': n_lf * 2 * 8 * d * d / t / 1e9,
+                          'note': 'per-chain adapted covariances (fixed in the timed launch); two cov p products per leapfrog step'}
+    ch = DeviceChains(dens, x0, seed=seed + 3)
+    ch.run_tempered(120, np.zeros(d), 1.3 * cov, n_warmup=100, check=False)
+    lf0 = ch.total_leapfrog
+    (_, st, _), t = timed(lambda: ch.run_tempered(60, np.zeros(d), 1.3 * cov, n_warmup=100, check=False))
+    ch.raise_on_error()
+    out['tempered'] = {'value': (ch.total_leapfrog - lf0) / t, 'unit': 'tempered leapfrog steps/sec', 'chains': C, 'dim': d,
+                       'mean_tree_size': float(st[:, :, _lib.NSTATS.index('tree_size')].mean().item()),
+                       'note': 'TNUTS, Gaussian base density 1.3 x the target covariance; each step evaluates both densities twice'}
+    return out
+
+
 def refit_cycle(d, cov, C, seed):
     """One refit cycle end to end through the package API (BASELINE config 3's shape: sample -> choose 2P points by
     logq -> true logp -> fit -> sample), wall-clock per stage.  The true model is the exactly quadratic target evaluated
@@ -561,6 +605,7 @@ def main():
                 with torch.cuda.device(ctx.device):
                     out['hetero'] = hetero_rate(ctx, d, C, a.seed, a.iters)
                     out['refit_cycle'] = refit_cycle(d, cov, C, a.seed)
+                    out.update(other_samplers(ctx, d, cov, C, a.seed))
             except Exception as ex:  # side measurements; the headline line must still print
                 out['extras_error'] = repr(ex)
         if not a.no_configs and world == 1:

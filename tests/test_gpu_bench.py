@@ -30,6 +30,10 @@ def test_bench_single_gpu_line():
     rf = j['roofline']
     assert rf['bound'] in ('hbm', 'mfma') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     assert 'workload' in j['config'] and 'model' not in j['config']
+    assert 'extras_error' not in j, j.get('extras_error')
+    for k in ('hetero', 'refit_cycle', 'full_metric', 'tempered'):   # the side blocks
+        assert k in j, k
+    assert j['full_metric']['value'] > 0 and j['tempered']['value'] > 0 and j['refit_cycle']['total_ms'] > 0
 
 
 def test_bench_two_ranks_on_one_gpu_gloo():
