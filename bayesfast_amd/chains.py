@@ -171,7 +171,8 @@ class DeviceChains:
                  bool(sp['poly'].get('use_bound')) and sorted(c['order'] for c in sp['poly']['configs']) == ['linear', 'quadratic'])
         if not plain or self.full_metric:   # (measured on the plain surrogate only: the pipelined wave-per-chain kernel)
             return False
-        return self.d <= 16 or (self.d <= 32 and self.n_chain < 16 * self._n_cu)
+        n = self.n_chain if self.n_chain_rule is None else self.n_chain_rule   # (sharded: the ranks' average, equal on all of them)
+        return self.d <= 16 or (self.d <= 32 and n < 16 * self._n_cu)
 
     def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
                      target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,
@@ -224,6 +225,7 @@ class DeviceChains:
     # ranks' chains -- a collective per launch, the same launches on every rank -- so that every rank picks the same
     # layout and results do not depend on the number of ranks.  Without it each DeviceChains decides from its own chains.
     hist_reduce = None
+    n_chain_rule = None   # set by sample() under torch.distributed: chains per rank on average (``_small_problem``)
 
     def _note_trees(self, stats, row0, row1, sampler, n_last=32, share=0.98):
         """Queue, behind the launch that wrote rows [row0, row1) of ``stats``, the answer to "did the chains run in step?":

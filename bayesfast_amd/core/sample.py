@@ -101,8 +101,9 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     if done + n_run > trace.n_iter:
         trace.n_iter = done + n_run
     step = n_run if not iters_per_launch else int(iters_per_launch)
-    if ws > 1:  # the 'auto' layout is decided from every rank's trees (DeviceChains.hist_reduce)
+    if ws > 1:  # the 'auto' layout is decided from every rank's trees (DeviceChains.hist_reduce) and from the average shard size
         chains.hist_reduce = parallel.all_reduce_sum
+        chains.n_chain_rule = trace.n_chain / float(ws)   # (the same number on every rank: shards differ by at most one chain)
     ss, sts, stts = [], [], []
     left = n_run
     while left > 0:
