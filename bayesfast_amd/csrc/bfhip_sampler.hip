@@ -176,6 +176,13 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     // the coefficient matrices are not staged in LDS at all.
     constexpr bool AREG = PLAIN && W <= 4;
     constexpr bool TAIL = AREG;
+    // FUSE (the decay instantiation, FS = 3): a leaf outside the bound's ellipsoid takes its second pass -- the surrogate at
+    // the projected point, modules/poly.py:480-503 -- INSIDE the trip of the first (one more pair of barriers and a round of
+    // S tiles) instead of a trip of its own in mode M_OOB.  The workloads that use the decay term run outside the bound all
+    // the time (100 % of config 3's and config 4's leaves), so for them every leaf was two trips.  Same
+    // expressions in the same order as the M_OOB pass (bfhip_debug_no_fuse selects that one: tests compare the two).
+    constexpr bool FUSE = FS == 3 && !FULLM && !STAMPS;
+    const bool fuse = FUSE && a.no_fuse == 0;
     constexpr int KS_P = (W == 2 || W == 4) ? 2 : 1, KPJ_P = (4 * W) / KS_P, NJOB_P = 2 * W * KS_P;
     using G = SamplerGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             RM[(1 * DP + row) * RS + col] = m.Hf[i];
         }
     }
-    if (tid < 6) alive[tid] = 0;
+    if (tid < 8) alive[tid] = 0;
     for (int i = tid; i < PD_N * DP; i += NTH) PDL[i] = m.pd[i];
     // cubic configs: the coefficient tables behind the matvec results when they fit (sampler_cubic_lds: config 5's 16
     // masked inputs are 36 KB), the masks of this lane in registers
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         if (rfl(alive[trip & 1]) == 0) break;  // every chain of the group is done (uniform)
         const unsigned ev_mask = TAIL ? (unsigned)rfl(alive[2 + (trip & 1)]) : 0u;
         const bool skip_h = PROOF && f_bound && f_quad && !f_decay && rfl(alive[4 + (trip & 1)]) == 0;  // (uniform over the workgroup)
-        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; }
+        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; alive[6 + ((trip + 1) & 1)] = 0; }
         TRACE(3);
 
         // ================= phase B: gradient tiles on MFMA =================
@@ -974,13 +981,13 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         // partial results land in separate GB slots and are added by the chain's own wave in phase C.
         // All operands of a job (at most 8 k-steps at a time) are fetched from LDS before the first MFMA so
         // that the LDS latency is paid once per job, not once per k-step.
-        auto run_jobs = [&](auto ks_tag) {
+        auto run_jobs = [&](auto ks_tag, bool only_s = false) {
             constexpr int KS = decltype(ks_tag)::value;
             constexpr int KPJ = NS / KS;                        // k-steps per job
             constexpr int CH = KPJ < 8 ? KPJ : 8;               // k-steps fetched together
             const int mc = lane & 15, mg = lane >> 4;
             // (skip_h: S and H are the only matrices and the H jobs, the second half of the list, are left out)
-            const int n_job = (skip_h && n_mat == 2 && mat0 == 0 && mat1 == 1) ? W * KS : n_mat * (W * KS);
+            const int n_job = (only_s || (skip_h && n_mat == 2 && mat0 == 0 && mat1 == 1)) ? W * KS : n_mat * (W * KS);
             for (int job = w; job < n_job; job += NWV) {
                 const int slot_m = job / (W * KS), rem = job % (W * KS);
                 const int t = rem / KS, kp = rem % KS;
@@ -1056,6 +1063,9 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         double logp_new = 0., E_new = 0.;
         bool have_eval = false, kin_ready = false;
         double kin_fast = 0.;
+        // (hoisted for the fused second pass: what its first half leaves for the second)
+        double f_keep = 0., beta_keep = 0., bd2_keep = 0.;
+        bool oob_fused = false;
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
             const bool fast_kin = !FULLM && !f_decay && !f_link && mode != M_OOB;
@@ -1245,7 +1255,18 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             }
             kin_ready = fast_kin && !oob_now;
             kin_fast = r_kin;
-            if (oob_now) {
+            if (oob_now && fuse) {
+                // the projected point x_0 (poly.py:482) into this chain's column of the S operand, the second round is on
+                oob_fused = true;
+                beta_keep = beta;
+                bd2_keep = r_bd2;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int dim = lane * E + e;
+                    if (dim < DP) XB[(dim >> 2) * XS + w + 16 * (dim & 3)] = (m.alpha * xs[e] + (beta - m.alpha) * c_mu[e]) / beta;
+                }
+                if (lane == 0) alive[6 + (trip & 1)] = 1;
+            } else if (oob_now) {
                 // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
                 cs_set(CS_BETA, beta);
                 prev_mode = mode;
@@ -1280,6 +1301,53 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                 have_eval = true;
             }
         }
+        if constexpr (FUSE) {
+            if (fuse) {  // (uniform over the workgroup)
+                __syncthreads();  // X: the projected points are in the S operand, the flag of the second round is set
+                if (rfl(alive[6 + (trip & 1)]) != 0) {
+                    // the S tiles again (the other matrices' results do not change: the chain keeps them), same K-split
+                    if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>(), true);
+                    else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>(), true);
+                    else run_jobs(std::integral_constant<int, 1>(), true);
+                    __syncthreads();  // Y
+                    if (oob_fused) {
+                        // modules/poly.py:484-496 at x_0, then what follows an in-bound evaluation
+                        const double beta = beta_keep;
+                        double r_lin = 0., r_dotj = 0.;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int dim = lane * E + e;
+                            const double sx = lane_ok ? gb_read(slot_S, dim) : 0.;
+                            const double xev = (m.alpha * xs[e] + (beta - m.alpha) * c_mu[e]) / beta;
+                            r_lin += __builtin_fma(0.5 * xev, sx, c_lin[e] * xev);
+                            gn[e] = sx + c_lin[e];
+                            r_dotj += gn[e] * (xs[e] - c_mu[e]);
+                        }
+                        double r3[3] = {0., r_lin, 0.};
+                        wave_sum_n<3>(r3);
+                        r_lin = r3[1];
+                        r_dotj = wave_sum(r_dotj);
+                        const double f0 = (m.c0 + r_lin) + 0.;
+                        double f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
+                        const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            gn[e] = gn[e] + coef * (hv[e] / beta);
+                            gn[e] = gn[e] * jac[e];
+                        }
+                        f -= m.decay_gamma * bf_clip0(bd2_keep - m.decay_alpha2);
+                        if (bd2_keep > m.decay_alpha2) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
+                        }
+                        logp_new = f;
+                        have_eval = true;
+                        kin_ready = false;
+                    }
+                }
+            }
+        }
+        (void)f_keep;
         if (have_eval) {
             // second half of the leapfrog and the kinetic energy
             double kin = 0.;
@@ -1390,6 +1458,8 @@ static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
 // waves, which share four SIMDs.  When the chains do not fill the chip at 16 per workgroup, fewer chains per workgroup
 // on more CUs shorten the trip: the waves without a chain still take their share of the jobs.  (Results do not depend on
 // it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG / bfhip_debug_wave_cpg override (tests, tuning).
+static int g_no_fuse = [] { const char *e = getenv("BFHIP_NO_FUSE"); return e ? atoi(e) : 0; }();
+extern "C" void bfhip_debug_no_fuse(int v) { g_no_fuse = v; }  // test / tuning hook: the decay kernel's second passes in trips of their own
 static int g_wave_cpg = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
 extern "C" void bfhip_debug_wave_cpg(int v) { g_wave_cpg = v; }  // test / tuning hook (0: automatic)
 static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
@@ -1502,6 +1572,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     SamplerArgs args;
     args.cpg = 0;
     args.cub_lds = 0;
+    args.no_fuse = g_no_fuse;
     args.cfg = *cfg;
     args.n_chain = n_chain;
     args.iter_end = iter_end;
