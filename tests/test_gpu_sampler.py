@@ -188,6 +188,48 @@ def test_group_kernel_bound_proof_never_changes_results(ctx, case):
     assert out[0][-1] == out[1][-1]
 
 
+@pytest.mark.parametrize('case', ['outside', 'mixed', 'inside'])
+def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, case):
+    """bf_sampler_kernel's decay instantiation takes the second pass of a leaf outside the bound (modules/poly.py:480-503) inside
+    the trip of the first; with bfhip_debug_no_fuse(1) the pass is a trip of its own (mode M_OOB), as in every other
+    instantiation.  The two are the same expressions in different places of the kernel -- the compiler contracts them into
+    fused multiply-adds differently, so they agree to rounding, not bit for bit: the first iterations to 1e-10 with equal trees
+    and statistics, the runs' distributions after that -- with every leaf outside the bound (the regime of BASELINE configs 3 and
+    4), with chains crossing it, and with none outside."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    spec, _ = correlated_gaussian_spec(64, fit_scale={'outside': 0.3, 'mixed': 1.0, 'inside': 1.5}[case])
+    po = spec['poly']
+    spec = dict(spec, use_decay=True, decay_mu=po['mu'] + 0.05, decay_hess=po['hess'], decay_alpha2=(1.5 * po['alpha'])**2, decay_gamma=0.1)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(2).normal(size=(150, 64))
+    L = _lib.lib()
+    out = {}
+    try:
+        for nf in (0, 1):
+            L.bfhip_debug_no_fuse(nf)
+            dc = DeviceChains(dens, x0, seed=11)
+            s1, st1 = dc.run(45, 'NUTS', n_warmup=30, layout='wave')
+            out[nf] = [s1.cpu().numpy(), st1.cpu().numpy(), dc.total_leapfrog]
+    finally:
+        L.bfhip_debug_no_fuse(0)
+    (sa, sta, _), (sb, stb, _) = out[0], out[1]
+    n = 4
+    np.testing.assert_allclose(sa[:, :n], sb[:, :n], rtol=1e-10, atol=1e-10)
+    for f in ('tree_size', 'tree_depth', 'diverging'):
+        k = _lib.NSTATS.index(f)
+        assert np.array_equal(sta[:, :n, k], stb[:, :n, k]), f
+    np.testing.assert_allclose(sta[:, :n, _lib.NSTATS.index('energy')], stb[:, :n, _lib.NSTATS.index('energy')], rtol=1e-9, atol=1e-9)
+    ts = _lib.NSTATS.index('tree_size')
+    assert abs(sta[:, :, ts].mean() - stb[:, :, ts].mean()) < 0.05 * stb[:, :, ts].mean()
+    x = sa.reshape(-1, 64)
+    beta = np.sqrt(np.einsum('ij,jk,ik->i', x - po['mu'], po['hess'], x - po['mu']))
+    frac = float(np.mean(beta > po['alpha']))
+    assert {'outside': frac > 0.99, 'mixed': 0.02 < frac < 0.98, 'inside': frac < 0.01}[case], frac
+
+
 @pytest.mark.parametrize('kernel', ['pipe', 'sliced', 'sliced128'])
 def test_chains_per_workgroup_never_change_results(ctx, kernel):
     """The wave-per-chain kernels with 16, 4 and 1 chains per workgroup (bfhip_sampler.hip: wave_layout_cpg; the waves without a
