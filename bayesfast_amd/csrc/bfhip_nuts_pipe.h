@@ -37,35 +37,41 @@
 // (levels >= 1); they let an iteration start from its predecessor's proposal without evaluating it again
 enum { SL_PROPG = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH, SL_PG = SL_PROPG + 1, SL_PIPE_N = SL_PG + BFHIP_MAX_TREEDEPTH };
 
-template <int W>
+// DEC: a third matrix, the decay term's (density.py:740-746).  The K-split is the sliced kernel's for the same model
+// (sampler_ksplit: at most 16 jobs), so that the sums associate the same way: at W = 4 twelve jobs of 16 k-steps.
+template <int W, bool DEC = false>
 struct PipeGeo {
-    static constexpr int KS = (W == 2 || W == 4) ? 2 : 1;  // K-split of the matvec jobs: every wave owns one job
-    static constexpr int KPJ = (4 * W) / KS, NJOB = 2 * W * KS, NTL = 12;
+    static constexpr int NMAT = DEC ? 3 : 2;
+    static constexpr int KS = DEC ? (W == 2 ? 2 : 1) : ((W == 2 || W == 4) ? 2 : 1);  // K-split of the matvec jobs: every wave owns at most one job
+    static constexpr int KPJ = (4 * W) / KS, NJOB = NMAT * W * KS, NTL = 12;
+    static constexpr int MPS = KPJ > 8 ? 2 : 1;  // MFMAs at each of the eight points of phase B the chain is spread over
+    static_assert(NJOB <= 16 && KPJ <= 8 * MPS, "one job per wave, eight MFMA sites");
     static constexpr size_t lds_doubles() {
         using G = SamplerGeo<W>;
-        return (size_t)2 * G::NS * G::XS + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 2 + (size_t)16 * CS_N +
-               (size_t)16 * NTL * G::DP + (size_t)2 * KS * 16 * G::GS;
+        return (size_t)NMAT * G::NS * G::XS + (size_t)16 * BFHIP_MAX_TREEDEPTH * LS_N + 4 + (size_t)16 * CS_N +
+               (size_t)16 * NTL * G::DP + (size_t)NMAT * KS * 16 * G::GS;
     }
 };
 
 // TR: the density lives behind the constraint transform (Density.input_scales / hard_bounds: density.py:92-140,
 // 747-750): the surrogate is evaluated at x(q), its gradient gets the chain-rule factor dx/dq and the log-Jacobian
 // term; same arithmetic as the FS = 5 instantiation of bf_sampler_kernel.
-template <int W, bool TR>
+template <int W, bool TR, bool DEC = false>
 __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
     using G = SamplerGeo<W>;
-    using PG = PipeGeo<W>;
+    using PG = PipeGeo<W, DEC>;
     constexpr int DP = G::DP, NS = G::NS, XS = G::XS, GS = G::GS;
-    constexpr int KS_P = PG::KS, KPJ_P = PG::KPJ, NJOB_P = PG::NJOB, NTL = PG::NTL;
+    constexpr int KS_P = PG::KS, KPJ_P = PG::KPJ, NJOB_P = PG::NJOB, NTL = PG::NTL, NMAT = PG::NMAT, MPS = PG::MPS;
     constexpr int MAXL = BFHIP_MAX_TREEDEPTH;
     static_assert(DP <= 64, "one dimension per lane");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *XB = lds;                             // [2][NS][XS]   B operands: x | x - mu
-    double *LS = XB + 2 * NS * XS;                // [16][MAXL][LS_N] per-chain stack scalars
-    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity)
-    double *CS = LS + 16 * MAXL * LS_N + 2;       // [16][CS_N]    cold per-chain scalars
+    double *XB = lds;                             // [NMAT][NS][XS] B operands: x | x - mu | x - mu_decay
+    double *LS = XB + NMAT * NS * XS;             // [16][MAXL][LS_N] per-chain stack scalars
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating | [2] (DEC) some
+                                                  // chain takes its second pass in this trip (all by trip parity)
+    double *CS = LS + 16 * MAXL * LS_N + 4;       // [16][CS_N]    cold per-chain scalars
     double *TB = CS + 16 * CS_N;                  // [16][NTL][DP] tree vectors: slots 0-7, stack level 1
-    double *GB = TB + 16 * NTL * DP;              // [2 KS][16][GS] matvec results
+    double *GB = TB + 16 * NTL * DP;              // [NMAT KS][16][GS] matvec results
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
@@ -79,13 +85,14 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     double afr[KPJ_P];
     {
         const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
-        const double *Af = (slot_m == 0 ? m.Sf : m.Hf) + (t * NS + kp * KPJ_P) * 64 + lane;
+        const double *Af = (slot_m == 0 ? m.Sf : (slot_m == 1 ? m.Hf : m.Hdf)) + (t * NS + kp * KPJ_P) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KPJ_P; ++s) afr[s] = (w < NJOB_P) ? Af[s * 64] : 0.;
     }
-    if (tid < 4) alive[tid] = 0;
+    if (tid < 8) alive[tid] = 0;
     const double c_lin = lane_ok ? m.pd[PD_LIN * DP + lane] : 0.;
     const double c_mu = lane_ok ? m.pd[PD_MU * DP + lane] : 0.;
+    const double c_dmu = (DEC && lane_ok) ? m.pd[PD_DMU * DP + lane] : 0.;
     // constraint transform of this lane's dimension (TR) and what phase A leaves for phase C: x(q), dx/dq,
     // (d2x/dq2) / (dx/dq), log |dx/dq|
     const int c_kind = (TR && lane_ok) ? (int)m.pd[PD_KIND * DP + lane] : 0;
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 const int xi = (lane >> 2) * XS + w + 16 * (lane & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
                 XB[xi] = x_eval;
                 XB[NS * XS + xi] = xs - c_mu;
+                if constexpr (DEC) XB[2 * NS * XS + xi] = xs - c_dmu;   // (the decay term lives in the original space)
             }
         }
         if (lane == 0) {
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         TRACE(2);
         if (rfl(alive[trip & 1]) == 0) break;  // every chain of the group is done (uniform)
         const unsigned ev_mask = (unsigned)rfl(alive[2 + (trip & 1)]);
-        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; }
+        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; }
 
         // ================= phase B: gradient tiles on MFMA, the pending bookkeeping between them =================
         // A wave's MFMAs form one dependent chain (the accumulator); a dependent v_mfma_f64_16x16x4_f64 issues about
@@ -376,15 +384,21 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         const bool job = ev_mask != 0 && w < NJOB_P;
         d4_t acc = {0., 0., 0., 0.};
         const double *Xf = XB + ((w / (W * KS_P)) * NS + (w % KS_P) * KPJ_P) * XS + lane;
-        double x_next = job ? Xf[0] : 0.;
+        double x_pre[MPS];
+#pragma unroll
+        for (int u = 0; u < MPS; ++u) x_pre[u] = job ? Xf[u * XS] : 0.;
 #define BF_MF(K)                                                                                            \
         do {                                                                                                \
-            if ((K) < KPJ_P) {                                                                              \
-                const double x_cur = x_next;                                                                \
-                if ((K) + 1 < KPJ_P && job) x_next = Xf[((K) + 1 < KPJ_P ? (K) + 1 : 0) * XS];            \
-                asm volatile("" : "+v"(acc) : : "memory");                                                  \
-                if (job) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[(K) < KPJ_P ? (K) : 0], x_cur, acc, 0, 0, 0); \
-                asm volatile("" : "+v"(acc) : : "memory");                                                  \
+            if ((K) * MPS < KPJ_P) {                                                                        \
+                double x_cur[MPS];                                                                          \
+                _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_cur[u] = x_pre[u];                        \
+                if (((K) + 1) * MPS < KPJ_P && job)                                                         \
+                    _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_pre[u] = Xf[((((K) + 1) * MPS < KPJ_P ? ((K) + 1) * MPS : 0) + u) * XS]; \
+                _Pragma("unroll") for (int u = 0; u < MPS; ++u) {                                           \
+                    asm volatile("" : "+v"(acc) : : "memory");                                              \
+                    if (job) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cur[u], acc, 0, 0, 0); \
+                    asm volatile("" : "+v"(acc) : : "memory");                                              \
+                }                                                                                           \
             }                                                                                               \
         } while (0)
         int unit = pend ? U_EVAL : U_DONE, lev = 0;
@@ -600,14 +614,51 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         TRACE(6);
 
         // ================= phase C: finish the evaluation =================
+        // what follows a complete evaluation (f, gn: the surrogate's value and gradient in its own coordinates)
+        auto finish = [&](double f, double gn, bool kin_ready, double r_kin, double logdet, double r_bd2, double dgr) {
+            gn = gn * jac;  // chain rule (module.py:226, density.py:558); 1 without the transform
+            if constexpr (DEC) {  // density.py:740-746
+                f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
+                if (r_bd2 > m.decay_alpha2) gn -= 2. * m.decay_gamma * dgr;
+            }
+            if constexpr (TR) {  // density.py:747-750
+                f += logdet;
+                gn += gj;
+            }
+            const double logp_new = f;
+            // second half of the leapfrog and the kinetic energy
+            const double dt = 0.5 * eps_t;
+            p = p + dt * gn;        // integration.py:90
+            g = gn;
+            double kin = p * (var * p);   // metrics.py:88-91
+            kin = kin_ready ? r_kin : wave_sum(kin);
+            const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93
+            if (mode == M_INIT) {
+                init_tree(E_new, logp_new);
+            } else {
+                pend = true;
+                E_pend = E_new;
+                lp_pend = logp_new;
+                TRp = p;
+                TPq = q;
+                TPg = g;
+            }
+        };
+        // DEC: a leaf outside the bound takes its second pass (the surrogate at the projected point, poly.py:480-503) in THIS
+        // trip -- one more pair of barriers and the S tiles again -- as bf_sampler_kernel's decay instantiation does (FUSE): the
+        // densities that carry the decay term run outside the bound nearly all the time, and a second pass that was a trip of
+        // its own had nothing to overlap with in this kernel
+        bool oob_fused = false;
+        double beta_k = 0., hv_k = 0., dgr_k = 0., bd2_k = 0., logdet_k = 0.;
         if (evaluating && !ended) {
             const double sx = lane_ok ? gb_read(0) : 0.;
             const double hv = lane_ok ? gb_read(1) : 0.;
+            const double dgr = (DEC && lane_ok) ? gb_read(2) : 0.;   // H_decay (x - mu_decay)
             double xev = xs;
             if (mode == M_OOB) xev = (m.alpha * xs + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
             double gn = sx + c_lin;
             const double xm = xs - c_mu;
-            const bool fast_kin = mode != M_OOB;
+            const bool fast_kin = !DEC && mode != M_OOB;   // (with the decay term the gradient is final only after its sum)
             // (the surrogate's value, linear + quadratic term, summed per lane: one reduction for both)
             double r3[3] = {0., __builtin_fma(0.5 * xev, sx, c_lin * xev), xm * hv};
             double r_dotj = gn * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
@@ -622,6 +673,8 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             TRACE(8);
             const double r_kin = r3[0], r_val = r3[1], r_b2 = r3[2];
             if (mode == M_OOB) r_dotj = wave_sum(r_dotj);
+            double r_bd2 = 0.;
+            if constexpr (DEC) r_bd2 = wave_sum((xs - c_dmu) * dgr);
             double logdet = 0.;
             if constexpr (TR) logdet = wave_sum(logdet_l);
             double f = (m.c0 + r_val) + 0.;
@@ -639,36 +692,52 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                     oob_now = true;
                 }
             }
-            if (oob_now) {
+            if (oob_now && DEC) {
+                oob_fused = true;
+                beta_k = beta; hv_k = hv; dgr_k = dgr; bd2_k = r_bd2; logdet_k = logdet;
+                if (lane_ok) XB[(lane >> 2) * XS + w + 16 * (lane & 3)] = (m.alpha * xs + (beta - m.alpha) * c_mu) / beta;
+                if (lane == 0) alive[4 + (trip & 1)] = 1;
+            } else if (oob_now) {
                 // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
                 cs_set(CS_BETA, beta);
                 prev_mode = mode;
                 mode = M_OOB;
             } else {
-                const bool kin_ready = fast_kin;
                 if (mode == M_OOB) mode = prev_mode;
-                gn = gn * jac;  // chain rule (module.py:226, density.py:558); 1 without the transform
-                if constexpr (TR) {  // density.py:747-750
-                    f += logdet;
-                    gn += gj;
+                finish(f, gn, fast_kin, r_kin, logdet, r_bd2, dgr);
+            }
+        }
+        if constexpr (DEC) {
+            __syncthreads();  // X: the projected points are in the S operand, the flag of the second round is set
+            if (rfl(alive[4 + (trip & 1)]) != 0) {
+                if (w < W * KS_P) {  // the waves with an S job: the same chain of MFMAs on the new operand
+                    d4_t acc2 = {0., 0., 0., 0.};
+                    const double *Xf0 = XB + ((w % KS_P) * KPJ_P) * XS + lane;
+                    double xv[KPJ_P];
+#pragma unroll
+                    for (int k2 = 0; k2 < KPJ_P; ++k2) xv[k2] = Xf0[k2 * XS];
+#pragma unroll
+                    for (int k2 = 0; k2 < KPJ_P; ++k2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[k2], xv[k2], acc2, 0, 0, 0);
+                    const int mc = lane & 15, mg = lane >> 4;
+                    const int t = w / KS_P, kp = w % KS_P;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) GB[(kp * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc2[r4];
                 }
-                const double logp_new = f;
-                // second half of the leapfrog and the kinetic energy
-                const double dt = 0.5 * eps_t;
-                p = p + dt * gn;        // integration.py:90
-                g = gn;
-                double kin = p * (var * p);   // metrics.py:88-91
-                kin = kin_ready ? r_kin : wave_sum(kin);
-                const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93
-                if (mode == M_INIT) {
-                    init_tree(E_new, logp_new);
-                } else {
-                    pend = true;
-                    E_pend = E_new;
-                    lp_pend = logp_new;
-                    TRp = p;
-                    TPq = q;
-                    TPg = g;
+                __syncthreads();  // Y
+                if (oob_fused) {  // poly.py:484-496 at x_0
+                    const double beta = beta_k;
+                    const double sx = lane_ok ? gb_read(0) : 0.;
+                    const double xev = (m.alpha * xs + (beta - m.alpha) * c_mu) / beta;
+                    double gn = sx + c_lin;
+                    double r3[3] = {0., __builtin_fma(0.5 * xev, sx, c_lin * xev), 0.};
+                    double r_dotj = gn * (xs - c_mu);
+                    wave_sum_n<3>(r3);
+                    r_dotj = wave_sum(r_dotj);
+                    const double f0 = (m.c0 + r3[1]) + 0.;
+                    const double f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
+                    const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
+                    gn = gn + coef * (hv_k / beta);
+                    finish(f, gn, false, 0., logdet_k, bd2_k, dgr_k);
                 }
             }
         }

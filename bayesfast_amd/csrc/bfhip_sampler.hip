@@ -1493,10 +1493,10 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
 static bool g_no_pipe = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && !strcmp(e, "sliced"); }();
 extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 
-template <int W, bool TR = false>
+template <int W, bool TR = false, bool DEC = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
-    auto k = bf_nuts_pipe_kernel<W, TR>;
-    const size_t lds = PipeGeo<W>::lds_doubles() * sizeof(double);
+    auto k = bf_nuts_pipe_kernel<W, TR, DEC>;
+    const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SamplerArgs args = args_in;
@@ -1541,6 +1541,10 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
         !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
+    // ... and with the decay penalty (the GBS recipes' densities: configs 3 and 4); BFHIP_NO_FUSE keeps those on the sliced kernel
+    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && !args.no_fuse && m.has_quad && m.use_bound && m.use_decay &&
+        !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link)
+        return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
     // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)
@@ -1621,8 +1625,9 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     }
     {
         // (the conditions of launch_sampler: the common surrogate, plain or behind the constraint transform)
-        const bool tr_only = m.has_quad && m.use_bound && m.has_transform && !m.use_decay && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
-        const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only);
+        const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
+        const bool tr_only = common && m.has_transform && !m.use_decay, dec_only = common && m.use_decay && !m.has_transform && !args.no_fuse;
+        const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only || dec_only);
         snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
     }
     switch (W) {
