@@ -176,12 +176,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     // the coefficient matrices are not staged in LDS at all.
     constexpr bool AREG = PLAIN && W <= 4;
     constexpr bool TAIL = AREG;
-    // FUSE (the decay instantiation, FS = 3): a leaf outside the bound's ellipsoid takes its second pass -- the surrogate at
+    // FUSE (the decay instantiations, FS = 3 and 7): a leaf outside the bound's ellipsoid takes its second pass -- the surrogate at
     // the projected point, modules/poly.py:480-503 -- INSIDE the trip of the first (one more pair of barriers and a round of
     // S tiles) instead of a trip of its own in mode M_OOB.  The workloads that use the decay term run outside the bound all
     // the time (100 % of config 3's and config 4's leaves), so for them every leaf was two trips.  Same
     // expressions in the same order as the M_OOB pass (bfhip_debug_no_fuse selects that one: tests compare the two).
-    constexpr bool FUSE = FS == 3 && !FULLM && !STAMPS;
+    constexpr bool FUSE = (FS == 3 || FS == 7) && !FULLM && !STAMPS;   // (decay; decay + constraint transform)
     const bool fuse = FUSE && a.no_fuse == 0;
     constexpr int KS_P = (W == 2 || W == 4) ? 2 : 1, KPJ_P = (4 * W) / KS_P, NJOB_P = 2 * W * KS_P;
     using G = SamplerGeo<W>;
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         bool have_eval = false, kin_ready = false;
         double kin_fast = 0.;
         // (hoisted for the fused second pass: what its first half leaves for the second)
-        double f_keep = 0., beta_keep = 0., bd2_keep = 0.;
+        double f_keep = 0., beta_keep = 0., bd2_keep = 0., logdet_keep = 0.;
         bool oob_fused = false;
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
@@ -1260,6 +1260,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                 oob_fused = true;
                 beta_keep = beta;
                 bd2_keep = r_bd2;
+                logdet_keep = logdet;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const int dim = lane * E + e;
@@ -1341,6 +1342,11 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                         if (bd2_keep > m.decay_alpha2) {
 #pragma unroll
                             for (int e = 0; e < E; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
+                        }
+                        if (f_tr) {  // density.py:747-750
+                            f += logdet_keep;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) gn[e] += gj[e];
                         }
                         logp_new = f;
                         have_eval = true;

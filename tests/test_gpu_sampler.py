@@ -188,7 +188,7 @@ def test_group_kernel_bound_proof_never_changes_results(ctx, case):
     assert out[0][-1] == out[1][-1]
 
 
-@pytest.mark.parametrize('case', ['outside', 'mixed', 'inside'])
+@pytest.mark.parametrize('case', ['outside', 'mixed', 'inside', 'bounded'])
 def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, case):
     """bf_sampler_kernel's decay instantiation takes the second pass of a leaf outside the bound (modules/poly.py:480-503) inside
     the trip of the first; with bfhip_debug_no_fuse(1) the pass is a trip of its own (mode M_OOB), as in every other
@@ -200,11 +200,14 @@ def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, cas
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
     from bayesfast_amd import _lib
-    spec, _ = correlated_gaussian_spec(64, fit_scale={'outside': 0.3, 'mixed': 1.0, 'inside': 1.5}[case])
+    spec, _ = correlated_gaussian_spec(64, fit_scale={'outside': 0.3, 'mixed': 1.0, 'inside': 1.5, 'bounded': 0.8}[case])
     po = spec['poly']
     spec = dict(spec, use_decay=True, decay_mu=po['mu'] + 0.05, decay_hess=po['hess'], decay_alpha2=(1.5 * po['alpha'])**2, decay_gamma=0.1)
+    if case == 'bounded':  # behind the constraint transform as well (FS = 7): all four kinds of bounds (density.py:92-140)
+        lo = np.full(64, -9.) + np.arange(64) * 0.01
+        spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * 16, dtype=np.uint8))
     dens = DeviceDensity(spec, ctx)
-    x0 = np.random.default_rng(2).normal(size=(150, 64))
+    x0 = np.random.default_rng(2).normal(size=(150, 64)) * (0.3 if case == 'bounded' else 1.)
     L = _lib.lib()
     out = {}
     try:
@@ -224,10 +227,11 @@ def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, cas
     np.testing.assert_allclose(sta[:, :n, _lib.NSTATS.index('energy')], stb[:, :n, _lib.NSTATS.index('energy')], rtol=1e-9, atol=1e-9)
     ts = _lib.NSTATS.index('tree_size')
     assert abs(sta[:, :, ts].mean() - stb[:, :, ts].mean()) < 0.05 * stb[:, :, ts].mean()
-    x = sa.reshape(-1, 64)
-    beta = np.sqrt(np.einsum('ij,jk,ik->i', x - po['mu'], po['hess'], x - po['mu']))
-    frac = float(np.mean(beta > po['alpha']))
-    assert {'outside': frac > 0.99, 'mixed': 0.02 < frac < 0.98, 'inside': frac < 0.01}[case], frac
+    if case != 'bounded':   # (there the samples live in the transformed space)
+        x = sa.reshape(-1, 64)
+        beta = np.sqrt(np.einsum('ij,jk,ik->i', x - po['mu'], po['hess'], x - po['mu']))
+        frac = float(np.mean(beta > po['alpha']))
+        assert {'outside': frac > 0.99, 'mixed': 0.02 < frac < 0.98, 'inside': frac < 0.01}[case], frac
 
 
 @pytest.mark.parametrize('kernel', ['pipe', 'sliced', 'sliced128'])
