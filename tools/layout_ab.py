@@ -15,8 +15,11 @@ spec, _ = correlated_gaussian_spec(D)
 if os.environ.get('DECAY'):   # the decay term of core/density.py:740-746 around the bound's ellipsoid, never active here
     po = spec['poly']
     spec = dict(spec, use_decay=True, decay_mu=po['mu'], decay_hess=po['hess'], decay_alpha2=(float(os.environ['DECAY']) * po['alpha'])**2, decay_gamma=0.1)
+if os.environ.get('BOUNDED'):  # behind the constraint transform: all four kinds of bounds (density.py:92-140)
+    lo = np.full(D, -9.) + np.arange(D) * 0.01
+    spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * (D // 4), dtype=np.uint8))
 dens = DeviceDensity(spec, ctx)
-x0 = np.random.default_rng(1).normal(size=(C, D))
+x0 = np.random.default_rng(1).normal(size=(C, D)) * (0.3 if os.environ.get('BOUNDED') else 1.)
 KN = _lib.lib().bfhip_debug_last_kernel
 KN.restype = __import__('ctypes').c_char_p
 for layout in ('group', 'split', 'wave'):
