@@ -359,3 +359,17 @@ def test_sobol_normal_points_equal_the_references():
         uniform(np.zeros(3), np.ones(2), 4)
     with pytest.raises(ValueError):
         multivariate_normal(np.zeros(3), np.eye(2), 4)
+
+
+def test_blas_single_thread_context_limits_and_restores():
+    """utils/threads.blas_single_thread: BLAS calls inside run on one thread, the pool's size comes back after (the host
+    linear algebra of the fit must not leave spinning workers beside the GPU runtime's threads)."""
+    from bayesfast_amd.utils.threads import blas_single_thread
+    threadpoolctl = pytest.importorskip('threadpoolctl')
+    before = [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']
+    with blas_single_thread():
+        inside = [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']
+        a = np.random.default_rng(0).normal(size=(300, 40))
+        assert np.allclose(a.T @ a, np.einsum('ij,ik->jk', a, a))
+    after = [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']
+    assert inside and all(n == 1 for n in inside) and after == before
