@@ -11,43 +11,49 @@ import numpy as np
 
 __all__ = ['uniform', 'multivariate_normal']
 
+_D_MAX = 21201  # dimensions the direction numbers cover
 
-def uniform(low, high, size, skip=1):
-    """utils/sobol.py:12-46: ``size`` points of the d-dimensional Sobol sequence after ``skip`` points, scaled to [low, high)."""
+
+def _counts(size, skip):
+    ok = isinstance(size, (int, np.integer)) or (isinstance(size, float) and size.is_integer())
+    if not ok or int(size) < 1:
+        raise ValueError('size: a positive number of points is needed, got {!r}.'.format(size))
+    ok = isinstance(skip, (int, np.integer)) or (isinstance(skip, float) and skip.is_integer())
+    if not ok or int(skip) < 0:
+        raise ValueError('skip: a count of leading points to drop (>= 0) is needed, got {!r}.'.format(skip))
+    return int(size), int(skip)
+
+
+def _unit_points(d, size, skip):
+    """Points skip .. skip + size - 1 of the d-dimensional sequence, in the unit cube."""
     from scipy.stats import qmc
-    low, high = np.atleast_1d(low), np.atleast_1d(high)
-    if not (low.ndim == 1 and low.shape == high.shape):
-        raise ValueError('low and high should be 1-d arraies with the same shape, but you give me low.shape = {}, '
-                         'high.shape = {}.'.format(low.shape, high.shape))
-    try:
-        size = int(size)
-        assert size > 0
-    except Exception:
-        raise ValueError('size should be a positive int, instead of {}.'.format(size))
-    try:
-        skip = int(skip)
-        assert skip >= 0
-    except Exception:
-        raise ValueError('skip should be a non-negative int, instead of {}.'.format(skip))
-    d = low.shape[0]
-    if d > 21201:
-        raise NotImplementedError('d = {} is not supported, as the direction numbers end at d_max = 21201.'.format(d))
+    if d > _D_MAX:
+        raise NotImplementedError('the Sobol direction numbers end at dimension {}; d = {}.'.format(_D_MAX, d))
     with warnings.catch_warnings():
         warnings.simplefilter('ignore', UserWarning)  # (scipy: "balance properties require n to be a power of 2")
-        points = qmc.Sobol(d, scramble=False).random(size + skip)[skip:]
-    return low + (high - low) * points
+        return qmc.Sobol(d, scramble=False).random(size + skip)[skip:]
+
+
+def uniform(low, high, size, skip=1):
+    """``size`` Sobol points after the first ``skip``, stretched to the box [low, high) (utils/sobol.py:12-46)."""
+    lo, hi = np.atleast_1d(low).astype(float), np.atleast_1d(high).astype(float)
+    if lo.ndim != 1 or lo.shape != hi.shape:
+        raise ValueError('low and high: two 1-d arrays of one length are needed, got shapes {} and {}.'.format(lo.shape, hi.shape))
+    size, skip = _counts(size, skip)
+    return lo + (hi - lo) * _unit_points(lo.shape[0], size, skip)
 
 
 def multivariate_normal(mean, cov, size, skip=1):
-    """utils/sobol.py:49-61: Sobol points through the normal quantile function and the eigen-decomposition of ``cov``."""
+    """Sobol points through the normal quantile function and the eigen-decomposition of ``cov`` (utils/sobol.py:49-61)."""
     from scipy.special import ndtri
     from .threads import blas_single_thread
     mean, cov = np.atleast_1d(mean), np.atleast_2d(cov)
     d = mean.shape[0]
-    if not (mean.shape == (d,) and cov.shape == (d, d)):
-        raise ValueError('the shape of mean is not consistent with the shape of cov.')
+    if mean.ndim != 1 or cov.shape != (d, d):
+        raise ValueError('mean {} and cov {} do not describe one normal distribution.'.format(mean.shape, cov.shape))
+    size, skip = _counts(size, skip)
     # (scipy.stats.norm.ppf is ndtri behind 50 ms of argument handling at 4096 x 64; the points are inside (0, 1))
-    points = ndtri(uniform(np.zeros(d), np.ones(d), size, skip))
+    points = ndtri(_unit_points(d, size, skip))
     if np.array_equal(cov, np.eye(d)):
         # eigh(I) = (ones, I) and a product with the exact identity leaves every entry as it is: the same bits without the
         # product (sample()'s default starts are this case)
