@@ -386,6 +386,9 @@ __global__ __launch_bounds__(64 * WPB) void bf_tnuts_kernel(DevModel m, TnutsArg
     }
 }
 
+static int g_tnuts_wpb = [] { const char *e = getenv("BFHIP_TNUTS_WPB"); return e ? atoi(e) : 0; }();
+extern "C" void bfhip_debug_tnuts_wpb(int v) { g_tnuts_wpb = v; }  // test / tuning hook: waves per workgroup (8, 16; 0: automatic)
+
 extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, const bfhip_tempering *tp, int n_chain, int iter_end,
                                uint64_t *rng, double *sc, double *vec, double *u, int iter_out0, int n_out, double *samples,
                                double *stats, double *stats_t, unsigned long long *n_leapfrog) {
@@ -404,7 +407,7 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     // Waves (= chains) per workgroup.  The three staged matrices take 96 KB of LDS, so a CU holds ONE workgroup: with 8 waves
     // of 256 registers 2048 chains run at a time and 4096 chains take two rounds; 16 waves of 128 registers (spilling ~50)
     // keep all of them resident.  BFHIP_TNUTS_WPB overrides (tuning).
-    static const int forced = [] { const char *e = getenv("BFHIP_TNUTS_WPB"); return e ? atoi(e) : 0; }();
+    const int forced = g_tnuts_wpb;
     const int wpb = forced == 8 || forced == 16 ? forced : (n_chain > 8 * ctx->n_cu ? 16 : 8);
     const size_t need = (size_t)((n_chain + 15) / 16 * 16) * (4 * TN_MAXL) * 64 * sizeof(double);
     if (ctx->scratch_bytes < need) {

@@ -87,6 +87,29 @@ def test_device_tnuts_matches_oracle_on_shared_streams(fx):
 
 
 @pytest.mark.gpu
+def test_device_tnuts_workgroup_size_never_changes_results(fx):
+    """bf_tnuts_kernel with 8 and with 16 chains per workgroup (the library takes 16 above 2048 chains, where 8 would take two
+    rounds of workgroups): samples, statistics, tempering coordinate and weights are EQUAL -- 37 chains, ragged for both."""
+    from bayesfast_amd.device import get_context, DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd import _lib
+    spec, base, logxi = _specs(fx)
+    ctx = get_context(0)
+    rng = np.random.default_rng(22)
+    x0, u0 = rng.normal(size=(37, spec['d'])) * 0.5, rng.normal(size=37)
+    out = {}
+    try:
+        for wpb in (8, 16):
+            _lib.lib().bfhip_debug_tnuts_wpb(wpb)
+            dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=98)
+            out[wpb] = [t.cpu().numpy() for t in dc.run_tempered(24, fx['t6.base_mean'], fx['t6.base_cov'], logxi=logxi, u_0=u0, n_warmup=16)]
+    finally:
+        _lib.lib().bfhip_debug_tnuts_wpb(0)
+    for a, b in zip(out[8], out[16]):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_sample_entry_point_runs_tnuts_and_tempering_brings_base_mass(fx):
     """bayesfast_amd.sample(..., sampler='TNUTS'): TraceTuple with the (u, weight) statistics; continuing a run; 'THMC' is
     refused (the reference's THTrace cannot be constructed, samplers/sample_trace.py:600)."""
