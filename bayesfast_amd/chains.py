@@ -158,12 +158,13 @@ class DeviceChains:
         return samples, stats
 
     def _small_problem(self):
-        """NUTS at d <= 32 with fewer chains than fill the chip at 16 per workgroup (or d <= 16 at any size): the lane-per-chain
-        kernel has d / 16 waves per workgroup -- two of four SIMDs idle at d = 32 -- while the wave-per-chain kernel spreads
-        fewer chains per workgroup over more CUs (bfhip_sampler.hip: wave_layout_cpg).  Measured, in-step 7-leaf trees
-        (tools/layout_ab.py): 32-d x 1024 chains 3.2 against 2.2 x 10^8, x 2048 5.5 against 4.4, x 4096 8.2 against 8.7;
-        16-d x 1024 2.8 against 1.8, x 4096 7.5 against 7.2; 64-d: equal up to 1024 chains, the split layout ahead from 2048.
-        A function of the shapes only (never of timing); the layouts give identical results."""
+        """NUTS on the plain surrogate where the wave-per-chain kernel beats the lane-per-chain layouts although the trees are in
+        step: the latter have d / 16 (group) or 2 d / 16 (split) waves per workgroup of 16 chains, so few chains leave most of a
+        CU idle, while the wave-per-chain kernel spreads fewer chains per workgroup over more CUs (bfhip_sampler.hip:
+        wave_layout_cpg).  Measured, in-step 7-leaf trees (tools/layout_ab.py, profiles/r03n_layout_ab.log), wave against the
+        best lane-per-chain layout: d = 32 (split, two + two waves): 1024 chains 3.2 against 3.0 x 10^8, 2048 5.5 against 6.0, 4096
+        8.2 against 12.1; d = 16 (split, one + one wave): 1024 2.75 against 2.80, 4096 7.5 against 11.0; d = 64: equal up to 1024
+        chains, the split layout ahead from 2048.  A function of the shapes only (never of timing)."""
         if self._n_cu is None:
             self._n_cu = int(_torch().cuda.get_device_properties(self.ctx.device).multi_processor_count)
         sp = self.density.spec
@@ -172,7 +173,7 @@ class DeviceChains:
         if not plain or self.full_metric:   # (measured on the plain surrogate only: the pipelined wave-per-chain kernel)
             return False
         n = self.n_chain if self.n_chain_rule is None else self.n_chain_rule   # (sharded: the ranks' average, equal on all of them)
-        return self.d <= 16 or (self.d <= 32 and n < 16 * self._n_cu)
+        return (self.d <= 16 and n < 4 * self._n_cu) or (16 < self.d <= 32 and n < 6 * self._n_cu)
 
     def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
                      target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,

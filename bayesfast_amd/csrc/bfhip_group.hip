@@ -55,15 +55,21 @@ static int launch_w(bfhip_ctx *ctx, const SamplerArgs &args, bool nuts, int fs) 
 #endif
 }
 
-// the split layout (bfhip_split.h): 8 waves per 16 chains, integrator and bookkeeper waves two per SIMD
-__global__ __launch_bounds__(512) void bf_split_kernel(DevModel m, SamplerArgs a) {
+// the split layout (bfhip_split.h): 2 W waves per 16 chains, W integrator and W bookkeeper waves -- two per SIMD at W = 4 (33 <= d
+// <= 64), one per SIMD at W = 2 (17 <= d <= 32)
+template <int W>
+__global__ __launch_bounds__(128 * W) void bf_split_kernel(DevModel m, SamplerArgs a) {
     extern __shared__ __attribute__((aligned(16))) double bf_split_lds[];
-    bf_split_body<true>(m, a, bf_split_lds);
+    bf_split_body<true, W>(m, a, bf_split_lds);
 }
 
 bool bf_split_supports(const DevModel &m, const SamplerArgs &args) {
-    return m.DP == 64 && args.cfg.sampler == 0 && m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su &&
-           !m.has_cubic && !m.has_link && !args.mat && args.nslot >= SplitGeo::scratch_slots();
+#ifdef BF_ONLY_HEADLINE
+    if (m.DP != 64) return false;
+#endif
+    return m.DP <= 64 && args.cfg.sampler == 0 && m.has_quad && m.use_bound && !m.use_decay && !m.has_transform &&
+           !m.has_su && !m.has_cubic && !m.has_link && !args.mat &&
+           args.nslot >= (m.DP == 64 ? SplitGeoT<4>::scratch_slots() : (m.DP == 32 ? SplitGeoT<2>::scratch_slots() : SplitGeoT<1>::scratch_slots()));
 }
 
 int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args_in) {
@@ -71,10 +77,26 @@ int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     args.gcount = g_gcount_ptr();
     args.no_bound_proof = bf_no_bound_proof();
     args.stamps = g_gstamps_ptr();
-    const size_t lds = SplitGeo::lds_doubles() * sizeof(double);
-    BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + 15) / 16;
-    hipLaunchKernelGGL(bf_split_kernel, dim3(groups), dim3(512), lds, ctx->stream, ctx->model, args);
+#ifndef BF_ONLY_HEADLINE
+    if (ctx->model.DP == 32) {
+        const size_t lds = SplitGeoT<2>::lds_doubles() * sizeof(double);
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_split_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bf_split_kernel<2>, dim3(groups), dim3(256), lds, ctx->stream, ctx->model, args);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (ctx->model.DP == 16) {
+        const size_t lds = SplitGeoT<1>::lds_doubles() * sizeof(double);
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bf_split_kernel<1>, dim3(groups), dim3(128), lds, ctx->stream, ctx->model, args);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+#endif
+    const size_t lds = SplitGeoT<4>::lds_doubles() * sizeof(double);
+    BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_split_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bf_split_kernel<4>, dim3(groups), dim3(512), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1620,7 +1620,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     // d <= 64 with the diagonal metric: the group kernel
     if (cfg->chain_layout < 0 || cfg->chain_layout > 3) return bf_set_error(BFHIP_ERR_ARG, "chain_layout should be 0, 1, 2 or 3");
     if (cfg->chain_layout == 3 && !g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_split_supports(m, args)) {
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_split_kernel");
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_split_kernel<%d>", W);
         return bf_launch_split(ctx, args);
     }
     const bool want_group = cfg->chain_layout == 1 || cfg->chain_layout == 3 || (cfg->chain_layout == 0 && !nuts);

@@ -31,8 +31,11 @@
 #pragma once
 #include "bfhip_group.h"
 
-struct SplitGeo {
-    static constexpr int W = 4, DP = 64, NS = 16, MAXL = BFHIP_MAX_TREEDEPTH, LSS = 5 * MAXL + 1, LSH = 2;
+// W_ = 4: 33 <= d <= 64, eight waves, two per SIMD.  W_ = 2: 17 <= d <= 32, two integrator and two bookkeeper waves -- one per
+// SIMD, where the group kernel has two waves and two idle SIMDs.  W_ = 1: d <= 16, one of each.
+template <int W_>
+struct SplitGeoT {
+    static constexpr int W = W_, DP = 16 * W_, NS = 4 * W_, MAXL = BFHIP_MAX_TREEDEPTH, LSS = 5 * MAXL + 1, LSH = 2;
     // vectors in LDS, [slot][dimension][chain]
     //   integrators: stack level 1's momenta (left p, right p, p_sum), the tree's OTHER end (q, p, grad) -- the end being
     //                extended is the integrators' own state
@@ -55,6 +58,7 @@ struct SplitGeo {
     static constexpr int S_DEEP = 5 * (MAXL - 2);
     static constexpr int scratch_slots() { return S_DEEP + (NDEEP * W + DP - 1) / DP; }
 };
+using SplitGeo = SplitGeoT<4>;
 
 // commands of the bookkeepers: go on | start an iteration at T_START (signed step, depth 0) | evaluate T_START's point with a
 // step of length 0 (the launch's first iteration) | next doubling (signed step, depth) | stop; + 8: reload the metric's variances
@@ -72,9 +76,9 @@ enum { SS_W = 0, SS_E, SS_LOGP, SS_ACC, SS_OFF, SS_N };
 #define STRACE(role, k) do { } while (0)
 #endif
 
-template <bool NUTS_ONLY = true>
+template <bool NUTS_ONLY = true, int WW = 4>
 BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) {
-    using G = SplitGeo;
+    using G = SplitGeoT<WW>;
     constexpr int W = G::W, DP = G::DP, NS = G::NS, LSS = G::LSS;
     double *XB = lds;                          // [2][NS][64]   B operands: x | x - mu
     double *PB = XB + 2 * NS * 64;             // [W][16]       per-wave |x - mu|^2 (bound proof)
@@ -129,7 +133,11 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
     };
     auto sum4 = [](const double (&v)[4]) -> double { return (v[0] + v[1]) + (v[2] + v[3]); };
-    auto sumw = [](const double *rp, int st) -> double { return (rp[0] + rp[st]) + (rp[2 * st] + rp[3 * st]); };
+    auto sumw = [](const double *rp, int st) -> double {   // (the group kernel's association)
+        if constexpr (W == 4) return (rp[0] + rp[st]) + (rp[2 * st] + rp[3 * st]);
+        else if constexpr (W == 2) return rp[0] + rp[st];
+        else return rp[0];
+    };
     // the proof's verdict for the point in flight, the same arithmetic in both roles (read after B1)
     auto proof_holds = [&]() -> bool {
         double r2 = PB[c];
@@ -318,11 +326,11 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             const bool extra = !skipH || FLG[1] != 0.;
             if (any_ev) {
                 bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
-                constexpr int KH = NS / 2;
+                constexpr int KS = W == 1 ? 1 : 2, KH = NS / KS;   // K halves of a matvec: the group kernel's association
 #pragma unroll
                 for (int s = 0; s < KH; ++s) {
                     aS0 = bf_mfma(afS[s], XB[(0 * NS + s) * 64 + lane], aS0);
-                    aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
+                    if constexpr (KS == 2) aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
                 }
                 n_trip += 1;
                 n_trip_h += skipH ? 0 : 1;
@@ -330,11 +338,14 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
                     for (int s = 0; s < KH; ++s) {
                         aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
-                        aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
+                        if constexpr (KS == 2) aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { sx[r] = aS0[r] + aS1[r]; hv[r] = aH0[r] + aH1[r]; }
+                for (int r = 0; r < 4; ++r) {
+                    sx[r] = (KS == 2) ? aS0[r] + aS1[r] : aS0[r];
+                    hv[r] = (KS == 2) ? aH0[r] + aH1[r] : aH0[r];
+                }
             }
             STRACE(0, 3);
             // ---- phase C: gradient, second half step, the evaluation's partial sums ----
@@ -577,7 +588,11 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
             for (int w2 = 0; w2 < W; ++w2) t[i][w2] = RBE[((vi0 + i) * W + w2) * 16 + c];
 #pragma unroll
-        for (int i = 0; i < N; ++i) out[i] = (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+        for (int i = 0; i < N; ++i) {
+            if constexpr (W == 4) out[i] = (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+            else if constexpr (W == 2) out[i] = t[i][0] + t[i][1];
+            else out[i] = t[i][0];
+        }
     };
     auto rd_lv = [&](int lev, int k) -> double {
         if (lev <= G::LSH) return sumw(RBE + ((G::U_LV + 6 * (lev - 1) + k) * W) * 16 + c, 16);

@@ -180,7 +180,8 @@ struct Launch {
 
 template <int W, bool NUTS, int FS>
 void body_t() { bf_group_body<W, NUTS, FS>(L.m, L.a, L.lds); }
-void body_split() { bf_split_body<true>(L.m, L.a, L.lds); }
+template <int W>
+void body_split() { bf_split_body<true, W>(L.m, L.a, L.lds); }
 
 template <int W>
 void (*pick_body())() {
@@ -297,20 +298,21 @@ extern "C" int bfemu_sampler_run(const bfhip_density_desc *ds, const bfhip_sampl
     const int groups = (n_chain + 15) / 16;
     a.nslot = W == 4 ? GroupGeo<4>::scratch_slots() : (W == 2 ? GroupGeo<2>::scratch_slots() : GroupGeo<1>::scratch_slots());
     // chain_layout 3: the split layout (bfhip_split.h), eight waves per group, where it applies
-    const bool split = cfg->chain_layout == 3 && W == 4 && L.nuts && L.fs == 1;
-    if (split && SplitGeo::scratch_slots() > a.nslot) a.nslot = SplitGeo::scratch_slots();
+    const bool split = cfg->chain_layout == 3 && L.nuts && L.fs == 1;
+    const int split_slots = W == 4 ? SplitGeoT<4>::scratch_slots() : (W == 2 ? SplitGeoT<2>::scratch_slots() : SplitGeoT<1>::scratch_slots());
+    if (split && split_slots > a.nslot) a.nslot = split_slots;
     std::vector<double> scratch((size_t)groups * 16 * a.nslot * DP, 0.);
     a.scratch = scratch.data();
-    const size_t lds_n = split ? SplitGeo::lds_doubles()
+    const size_t lds_n = split ? (W == 4 ? SplitGeoT<4>::lds_doubles() : (W == 2 ? SplitGeoT<2>::lds_doubles() : SplitGeoT<1>::lds_doubles()))
                                : (W == 4 ? GroupGeo<4>::lds_doubles(3) : (W == 2 ? GroupGeo<2>::lds_doubles(3) : GroupGeo<1>::lds_doubles(3)));
     std::vector<double> lds(lds_n);
-    void (*body)() = split ? body_split : (W == 4 ? pick_body<4>() : (W == 2 ? pick_body<2>() : pick_body<1>()));
+    void (*body)() = split ? (W == 4 ? body_split<4> : (W == 2 ? body_split<2> : body_split<1>)) : (W == 4 ? pick_body<4>() : (W == 2 ? pick_body<2>() : pick_body<1>()));
     if (!body) return -1;
     for (int g = 0; g < groups; ++g) {
         // uninitialised shared memory: NaN patterns, so that a read of a never-written slot shows up
         for (size_t i = 0; i < lds_n; ++i) lds[i] = __builtin_nan("");
         L.lds = lds.data();
-        if (!emu_run_group(split ? 512 : 64 * W, g, body)) return -2;
+        if (!emu_run_group(split ? 128 * W : 64 * W, g, body)) return -2;
     }
     return 0;
 }

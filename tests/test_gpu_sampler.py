@@ -433,23 +433,24 @@ def test_nuts_posterior_moments_quadratic_target(ctx):
     assert np.max(np.abs(emp - cov) / np.sqrt(np.outer(np.diag(cov), np.diag(cov)))) < 0.03
 
 
-def test_split_layout_is_bit_identical_to_group_layout_on_the_device(ctx):
-    """chain_layout 3 (bfhip_split.h: integrator and bookkeeper waves, two per SIMD, the bookkeepers one leaf behind) against
-    chain_layout 1 on the GPU: equal samples, statistics, chain state and random streams -- ragged groups through warm-up,
-    starts far outside the bound (second passes, the third barrier), launch cuts.  (The CPU emulation checks the same and
-    more: tests/test_group_emu.py.)"""
+@pytest.mark.parametrize('d', [64, 40, 32, 20, 16, 7])
+def test_split_layout_is_bit_identical_to_group_layout_on_the_device(ctx, d):
+    """chain_layout 3 (bfhip_split.h: integrator and bookkeeper waves, the bookkeepers one leaf behind; four + four waves at d > 32,
+    two + two at d > 16, one + one below) against chain_layout 1 on the GPU: equal samples, statistics, chain state and random
+    streams -- ragged groups through warm-up, starts far outside the bound (second passes, the third barrier), launch cuts,
+    padded dimensions.  (The CPU emulation checks the same and more: tests/test_group_emu.py.)"""
     from bayesfast_amd.device import DeviceDensity
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
     from bayesfast_amd import _lib
     import ctypes as C
-    spec, _ = correlated_gaussian_spec(64)
+    spec, _ = correlated_gaussian_spec(d)
     dens = DeviceDensity(spec, ctx)
     rng = np.random.default_rng(3)
     kname = _lib.lib().bfhip_debug_last_kernel
     kname.restype = C.c_char_p
-    for x0, n, nw, kw in ((rng.normal(size=(37, 64)), 60, 40, {}), (rng.normal(size=(20, 64)) * 6., 30, 20, {}),
-                          (rng.normal(size=(300, 64)), 90, 50, dict(launch_iters=17))):
+    for x0, n, nw, kw in ((rng.normal(size=(37, d)), 60, 40, {}), (rng.normal(size=(20, d)) * 6., 30, 20, {}),
+                          (rng.normal(size=(300, d)), 90, 50, dict(launch_iters=17))):
         out = []
         for layout in ('group', 'split'):
             ch = DeviceChains(dens, x0, seed=5)

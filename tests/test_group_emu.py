@@ -161,6 +161,15 @@ def test_split_layout_is_bit_identical_to_the_group_layout(samp):
     spec40 = correlated_gaussian_spec(40)[0]                              # d = 40 in the 64-wide layout
     x40 = np.random.default_rng(9).normal(size=(5, 40))
     _same(_emu(spec40, x40, 6, 4, layout='group'), _emu(spec40, x40, 6, 4, layout='split'))
+    spec32 = correlated_gaussian_spec(32)[0]                              # W = 2: two integrator and two bookkeeper waves
+    x32 = np.random.default_rng(10).normal(size=(18, 32))
+    _same(_emu(spec32, x32, 8, 5, layout='group'), _emu(spec32, x32, 8, 5, layout='split'))
+    spec20 = correlated_gaussian_spec(20)[0]                              # d = 20 in the 32-wide layout, a resumed run
+    x20 = np.random.default_rng(11).normal(size=(5, 20)) * 2.
+    _same(_emu(spec20, x20, 6, 4, layout='group'), _emu(spec20, x20, 6, 4, layout='split', split=3))
+    spec10 = correlated_gaussian_spec(10)[0]                              # W = 1: one integrator and one bookkeeper wave, d = 10 of 16
+    x10 = np.random.default_rng(12).normal(size=(19, 10))
+    _same(_emu(spec10, x10, 10, 6, layout='group'), _emu(spec10, x10, 10, 6, layout='split'))
     bad = x0[:3].copy()
     bad[1, 0] = np.inf                                                   # bad initial energy: error flag, chain stops
     a, b = _emu(spec, bad, 3, 2, layout='group'), _emu(spec, bad, 3, 2, layout='split')
