@@ -245,14 +245,22 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     // cubic configs: the coefficient tables behind the matvec results when they fit (sampler_cubic_lds: config 5's 16
     // masked inputs are 36 KB), the masks of this lane in registers
     const bool cub_l = f_cubic && a.cub_lds != 0;
-    double *CUB = GB + (((size_t)a.gbn * 16 * GS + 1) & ~(size_t)1);  // [n2 n2] A2t | [n2 n2] A2 | [n3 n3 n3] T3t
+    double *CUB = GB + (((size_t)a.gbn * 16 * GS + 1) & ~(size_t)1);  // [n2 n2] A2t | [n2 n2] A2 | [nc3 n3 n3 16] T3x
     int mk2 = 0, mk3 = 0, pj2[E], pj3[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) pj2[e] = pj3[e] = -1;
     if (cub_l) {
         const int n22 = m.n2 * m.n2, n33 = m.n3 * m.n3 * m.n3;
         for (int i = tid; i < n22; i += NTH) { CUB[i] = m.A2t[i]; CUB[n22 + i] = m.A2[i]; }
-        for (int i = tid; i < n33; i += NTH) CUB[2 * n22 + i] = m.T3t[i];
+        // T3t is [k][l][j]; in LDS it is [c][k][j][lq][i] with l = 16 c + lq + 4 i (zero where l >= n3): lane (j, lq) of the
+        // contraction reads its four l of a chunk as two 16-byte pairs, and a wave's 64 lanes read 2 KB in a row
+        const int n3 = m.n3, nc3 = (n3 + 15) >> 4;
+        double *T3x = lds + (((size_t)(CUB + 2 * n22 - lds) + 1) & ~(size_t)1);
+        for (int i = tid; i < nc3 * n3 * n3 * 16; i += NTH) {
+            const int q = i & 15, jj = (i >> 4) % n3, k = ((i >> 4) / n3) % n3, c = (i >> 4) / (n3 * n3);
+            const int l = 16 * c + (q >> 2) + 4 * (q & 3);
+            T3x[i] = l < n3 ? m.T3t[((size_t)k * n3 + l) * n3 + jj] : 0.;
+        }
         mk2 = lane < m.n2 ? m.mask2[lane] : 0;
         mk3 = lane < m.n3 ? m.mask3[lane] : 0;
 #pragma unroll
@@ -1119,7 +1127,9 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                     // holds x[mask[k]]) and the masks and positions of this lane in registers: nothing of the loops below
                     // goes to global memory (the 64 dependent global loads of the cubic-3 contraction were 2/3 of config 5's trip)
                     const int n2 = m.n2, n3 = m.n3;
-                    const double *A2t_l = CUB, *A2_l = CUB + n2 * n2, *T3_l = CUB + 2 * n2 * n2;
+                    const double *A2t_l = CUB, *A2_l = CUB + n2 * n2;
+                    const double *T3_l = lds + (((size_t)(CUB + 2 * n2 * n2 - lds) + 1) & ~(size_t)1);
+                    const int nc3 = (n3 + 15) >> 4;
                     const double xm2 = xl(mk2), xm3 = xl(mk3);
                     auto fetch_l = [&](const int (&pj)[E], int jb, double val, double (&dst)[E]) {
 #pragma unroll
@@ -1129,39 +1139,87 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                             if (mine) dst[e] += gv;
                         }
                     };
+                    // (The loads of a batch are issued together, then the sums run in the original order: with one LDS
+                    // round trip per term the contraction was 13 k of config 5's 29 k cycles per trip,
+                    // tools/trace_sliced.py.  Terms past the tables' ends are +0 and leave the sums as they were.)
                     for (int jb = 0; jb < n2; jb += 16) {
                         const int j = jb + jl;
                         const bool on = j < n2;
+                        const int jc = on ? j : 0;
                         double v1 = 0., v2 = 0.;
-                        for (int kk = 0; kk < n2; kk += 4) {
-                            const int k = kk + kq;
-                            const bool ok = on && k < n2;
-                            const double xk = __shfl(xm2, ok ? k : 0, 64);
-                            v1 += (ok ? A2t_l[k * n2 + j] : 0.) * xk;
-                            v2 += (ok ? A2_l[k * n2 + j] : 0.) * (xk * xk);
+                        for (int kk = 0; kk < n2; kk += 16) {
+                            double a1[4], a2[4], xk[4];
+                            if (jb + 16 <= n2 && kk + 16 <= n2) {   // (wave-uniform: a full tile needs no guards)
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int k = kk + 4 * u + kq;
+                                    xk[u] = __shfl(xm2, k, 64);
+                                    a1[u] = A2t_l[k * n2 + j];
+                                    a2[u] = A2_l[k * n2 + j];
+                                }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int k = kk + 4 * u + kq;
+                                    const bool ok = on && k < n2;
+                                    const int kc = ok ? k : 0;
+                                    xk[u] = __shfl(xm2, kc, 64);
+                                    const double t1 = A2t_l[kc * n2 + jc], t2 = A2_l[kc * n2 + jc];
+                                    a1[u] = ok ? t1 : 0.;
+                                    a2[u] = ok ? t2 : 0.;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                v1 += a1[u] * xk[u];
+                                v2 += a2[u] * (xk[u] * xk[u]);
+                            }
                         }
                         v1 = swap32_add_f64(swap16_add_f64(v1));
                         v2 = swap32_add_f64(swap16_add_f64(v2));
-                        const double xj = __shfl(xm2, on ? j : 0, 64);
+                        const double xj = __shfl(xm2, jc, 64);
                         const double gj2 = 2. * xj * v1 + v2;
                         if (on && kq == 0) fsum += xj * xj * v1;
                         fetch_l(pj2, jb, gj2, gn);
                     }
+                    // cubic-3, lane (j, lq): sum_k x_k sum_{l = lq mod 4} T[j, k, l] x_l -- the lane's own four x_l of a chunk of 16
+                    // stay in registers, x_k is the only broadcast (a third of the instructions of the (j, kq) form,
+                    // which read every x_l through a readlane; the trip is its instruction count)
                     for (int jb = 0; jb < n3; jb += 16) {
                         const int j = jb + jl;
                         const bool on = j < n3;
+                        const int jc = on ? j : 0;
                         double sacc = 0.;
-                        for (int kk = 0; kk < n3; kk += 4) {
-                            const int k = kk + kq;
-                            const bool ok = on && k < n3;
-                            double t = 0.;
-                            const double *Tk = T3_l + (ok ? k : 0) * n3 * n3 + (ok ? j : 0);
-#pragma unroll 4
-                            for (int l = 0; l < n3; ++l) t += (ok ? Tk[l * n3] : 0.) * readlane_f64(xm3, l);
-                            sacc += t * __shfl(xm3, ok ? k : 0, 64);
+                        for (int c = 0; c < nc3; ++c) {
+                            double xq[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int l = 16 * c + kq + 4 * i;
+                                xq[i] = __shfl(xm3, l < n3 ? l : 0, 64);   // (the table is zero there)
+                            }
+                            const double *Tc = T3_l + ((size_t)c * n3 * n3 + jc) * 16 + kq * 4;
+                            for (int k = 0; k < n3; k += 4) {
+                                d2_t ta[4][2];
+                                const bool full = k + 4 <= n3;   // (wave-uniform)
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const double *pk = Tc + (size_t)((full || k + u < n3) ? k + u : 0) * n3 * 16;
+                                    ta[u][0] = *(const d2_t *)pk;
+                                    ta[u][1] = *(const d2_t *)(pk + 2);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);   // all eight loads on their way before the first product
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    double t = ta[u][0][0] * xq[0];
+                                    t += ta[u][0][1] * xq[1];
+                                    t += ta[u][1][0] * xq[2];
+                                    t += ta[u][1][1] * xq[3];
+                                    if (full || k + u < n3) sacc += t * readlane_f64(xm3, (k + u) & 63);
+                                }
+                            }
                         }
                         sacc = swap32_add_f64(swap16_add_f64(sacc));
-                        const double xj = __shfl(xm3, on ? j : 0, 64);
+                        const double xj = __shfl(xm3, jc, 64);
                         if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
                         fetch_l(pj3, jb, 0.5 * sacc, gn);
                     }
@@ -1451,7 +1509,7 @@ static size_t sampler_lds_base(const DevModel &m, bool plain) {
 }
 // cubic coefficient tables in LDS (bf_sampler_kernel: cub_l): when both masks fit a wave and the tables fit behind the rest
 static size_t sampler_cubic_doubles(const DevModel &m) {
-    return (size_t)2 * m.n2 * m.n2 + (size_t)m.n3 * m.n3 * m.n3 + 2;
+    return (size_t)2 * m.n2 * m.n2 + (size_t)((m.n3 + 15) >> 4) * m.n3 * m.n3 * 16 + 2;   // (bf_sampler_kernel: T3x and its alignment)
 }
 static bool sampler_cubic_lds(const DevModel &m, bool plain) {
     return m.has_cubic && m.n2 <= 64 && m.n3 <= 64 &&
