@@ -531,7 +531,7 @@ def test_headline_size_properties(ctx):
     assert np.array_equal(sb.cpu().numpy(), s[C // 2:, :60].cpu().numpy())
 
 
-def _cubic_spec(d=6, seed=3):
+def _cubic_spec(d=6, seed=3, m2=(1, 2, 4), m3=(0, 1, 3, 5), amp=1.):
     """Negative-definite quadratic + small masked cubic-2 / cubic-3 terms, bound on."""
     rng = np.random.default_rng(seed)
     L = np.eye(d) + 0.3 * np.tril(rng.normal(size=(d, d)), -1) / np.sqrt(d)
@@ -539,11 +539,12 @@ def _cubic_spec(d=6, seed=3):
     quad = np.zeros((d, d))
     iu = np.triu_indices(d)
     quad[iu] = A[iu] * np.where(iu[0] == iu[1], 1., 2.)
-    m2, m3 = np.array([1, 2, 4]), np.array([0, 1, 3, 5])
-    c2 = 0.02 * rng.normal(size=(1, 3, 3))
-    c3 = np.zeros((1, 4, 4, 4))
-    j, k, l = np.meshgrid(*[np.arange(4)] * 3, indexing='ij')
-    c3[0][(j < k) & (k < l)] = 0.03 * rng.normal(size=4)
+    m2, m3 = np.array(m2), np.array(m3)
+    n2, n3 = m2.size, m3.size
+    c2 = 0.02 * amp * rng.normal(size=(1, n2, n2))
+    c3 = np.zeros((1, n3, n3, n3))
+    j, k, l = np.meshgrid(*[np.arange(n3)] * 3, indexing='ij')
+    c3[0][(j < k) & (k < l)] = 0.03 * amp * rng.normal(size=int(((j < k) & (k < l)).sum()))
     x = rng.normal(size=(200, d))
     mu = x.mean(0)
     hess = np.linalg.inv(np.cov(x, rowvar=False))
@@ -569,6 +570,27 @@ def test_cubic_configs_eval_and_nuts(ctx):
     np.testing.assert_allclose(lp.cpu().numpy(), lp0, rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(g.cpu().numpy(), g0, rtol=1e-10, atol=1e-10)
     x0 = rng.normal(size=(5, 6)) * 0.5
+    dev = _device_chains(ctx, spec, x0, 25, 15)
+    orc_runs = _oracle_chains(spec, x0, 25, 15)
+    _compare_nuts(dev, orc_runs, 25)
+
+
+def test_cubic_configs_with_ragged_multi_chunk_masks(ctx):
+    """Cubic masks that are neither one 16-wide tile nor a multiple of it (20 cubic-2 inputs, 18 cubic-3 inputs of 24: two
+    chunks of the LDS-resident cubic-3 table, guarded tails in both contractions of bf_sampler_kernel) vs the oracle."""
+    from bayesfast_amd.device import DeviceDensity
+    from oracle import oracle as orc
+    d = 24
+    rng = np.random.default_rng(21)
+    m2 = np.sort(rng.choice(d, 20, replace=False))
+    m3 = np.sort(rng.choice(d, 18, replace=False))
+    spec = _cubic_spec(d=d, seed=5, m2=m2, m3=m3, amp=0.15)
+    x = np.concatenate([rng.normal(size=(40, d)) * 0.7, rng.normal(size=(9, d)) * 3.])
+    lp0, g0 = orc.logp_and_grad(spec, x)
+    lp, g = DeviceDensity(spec, ctx).logp_and_grad(x)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp0, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(g.cpu().numpy(), g0, rtol=1e-10, atol=1e-10)
+    x0 = rng.normal(size=(5, d)) * 0.5
     dev = _device_chains(ctx, spec, x0, 25, 15)
     orc_runs = _oracle_chains(spec, x0, 25, 15)
     _compare_nuts(dev, orc_runs, 25)
