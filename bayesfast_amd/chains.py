@@ -80,9 +80,11 @@ class DeviceChains:
 
     def run(self, n_run, sampler='NUTS', n_warmup=500, max_treedepth=10, n_int_step=32, max_change=1000.,
             target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,
-            update_window=1, doubling=True, samples=None, stats=None, check=True, launch_iters=250, layout='auto'):
+            update_window=1, doubling=True, samples=None, stats=None, check=True, launch_iters='auto', layout='auto'):
         """Advance every chain by ``n_run`` iterations, in kernel launches of at most ``launch_iters`` iterations
-        (None: one launch) queued back to back on the context's stream.
+        (None: one launch; a sequence: these lengths, the last one repeating; 'auto': launches of 100 while the chains adapt,
+        then of 250 -- measured on the default 1500-iteration run of 4096 chains: 64.5 ms in launches of 250, 61.6 ms with the
+        warm-up in launches of 100, 72.8 ms with the warm-up in one launch) queued back to back on the context's stream.
 
         The chains of a workgroup share the gradient tiles of every trip, so they run fastest in step; chains whose
         trees differ drift apart inside a launch and every launch boundary lines them up again (measured on the
@@ -130,8 +132,18 @@ class DeviceChains:
             if (tuple(t.shape) != shape or t.dtype != torch.float64 or t.device != self.ctx.device or
                     not t.is_contiguous()):
                 raise ValueError('{} should be a contiguous float64 tensor of shape {} on {}.'.format(name, shape, self.ctx.device))
-        step = max(1, int(launch_iters) if launch_iters else n_run)
-        for i_launch, done in enumerate(range(step, n_run + step, step)):  # iter_end of each launch; output rows are relative to i_iter
+        # launch lengths: one number, or a sequence whose last entry repeats (sample(): the warm-up in one launch)
+        if isinstance(launch_iters, str):
+            if launch_iters != 'auto':
+                raise ValueError("launch_iters should be a number, a sequence of numbers, None or 'auto'.")
+            n_adapting = max(0, min(int(n_warmup) - self.i_iter, n_run))   # a function of the arguments only
+            launch_iters = [100] * (-(-n_adapting // 100)) + [250]
+        lens = [max(1, int(v)) for v in launch_iters] if isinstance(launch_iters, (list, tuple)) else [max(1, int(launch_iters) if launch_iters else n_run)]
+        ends, steps = [], []
+        while (ends[-1] if ends else 0) < n_run:
+            steps.append(lens[min(len(ends), len(lens) - 1)])
+            ends.append((ends[-1] if ends else 0) + steps[-1])
+        for i_launch, (done, step) in enumerate(zip(ends, steps)):  # iter_end of each launch; output rows are relative to i_iter
             # the layout is chosen per launch from the trees of an EARLIER launch, as a pure function of the sequence of
             # launches (never of host timing): inside a run, the launch just before (the host waits for its answer: it has
             # nothing else to queue, and the gap is a launch latency); the first launch of a run, the launch before the
