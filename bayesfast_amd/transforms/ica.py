@@ -44,6 +44,21 @@ def _gram(ctx, xc):
     return gram
 
 
+def _tn_product(a, b, rows=400):
+    """a^T b for tall a, b (n, d): the sum over the n rows split into batches of ``rows`` (one batched product and a sum over
+    the batches).  rocBLAS runs the plain (d x n)(n x d) product at 20 000 x 64 on a handful of workgroups: 1.07 ms against
+    21 us this way -- it was 70 % of a FastICA iteration."""
+    import torch
+    n, d = a.shape
+    m = (n // rows) * rows
+    if m == 0:
+        return a.T @ b
+    out = torch.bmm(a[:m].view(m // rows, rows, d).transpose(1, 2), b[:m].view(m // rows, rows, b.shape[1])).sum(0)
+    if m < n:
+        out = out + a[m:].T @ b[m:]
+    return out
+
+
 def fastica_device(x, random_state=None, max_iter=200, tol=1e-4, w_init=None, ctx=None):
     """``FastICA(max_iter=..., tol=..., random_state=...).fit(x)`` for x (n, d) (array or device tensor).
 
@@ -84,7 +99,7 @@ def fastica_device(x, random_state=None, max_iter=200, tol=1e-4, w_init=None, ct
         wt = ctx.tensor(W.T.copy())
         gwtx = torch.tanh(x1 @ wt)                                   # (n, d) = g(W X1)^T, alpha = 1
         g_wtx = (1. - gwtx * gwtx).mean(0)                           # (d,)   mean of g'(W X1) over the samples
-        both = torch.cat([(gwtx.T @ x1) / p_, g_wtx[None]], 0).cpu().numpy()   # one copy to the host
+        both = torch.cat([_tn_product(gwtx, x1) / p_, g_wtx[None]], 0).cpu().numpy()   # one copy to the host
         W1 = _sym_decorrelation(both[:d] - both[d][:, None] * W)
         lim = np.max(np.abs(np.abs(np.einsum('ij,ij->i', W1, W)) - 1))
         W = W1

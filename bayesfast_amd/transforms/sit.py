@@ -113,7 +113,7 @@ class SIT:
     def _gaussianize(self, y):
         """Splines of all coordinates of y (n, d) device tensor: knots and edge points on the host, KDE cdfs on the device."""
         import torch
-        from scipy.stats import norm
+        from scipy.special import ndtri
         from .. import _lib
         from ..device import _ptr
         ctx = self._ctx()
@@ -126,20 +126,27 @@ class SIT:
         mean = (yT * w).sum(1) / w.sum()
         var = (((yT - mean[:, None])**2) * w).sum(1) / w.sum() / (1. - float(np.sum(wn**2)))  # np.cov(aweights=w, bias=False)
         h = torch.sqrt(var) * (neff**(-1. / 5)) * self.bw_factor
-        y_host = yT.cpu().numpy()
-        splines = []
-        for j in range(d):
-            hj = h[j:j + 1].contiguous()
-            dj = yT[j:j + 1].contiguous()
+        # the sorted coordinates (percentiles of the knots and edge points): one device sort, one copy to the host
+        y_sorted = torch.sort(yT, dim=1).values.cpu().numpy()
+        hd = h.contiguous()
 
-            def fun(pts, dj=dj, hj=hj):
-                pts = np.ascontiguousarray(np.atleast_1d(pts), dtype=np.float64)
-                p = ctx.tensor(pts.reshape(1, -1))
-                out = torch.empty_like(p)
-                _lib.check(ctx._lib.bfhip_kde_cdf(ctx.handle, 1, n, _ptr(dj), _ptr(w), _ptr(hj), p.shape[1], _ptr(p), _ptr(out)))
-                return norm.ppf(out.cpu().numpy().reshape(-1))
+        def batch_fun(requests):
+            # the requests of one round of all d splines in ONE kde-cdf call (rows padded with their last point)
+            m = max(r.size for r in requests if r is not None)
+            pts = np.empty((d, m))
+            for j, r in enumerate(requests):
+                if r is None:
+                    pts[j] = y_sorted[j, 0]
+                else:
+                    pts[j, :r.size] = r
+                    pts[j, r.size:] = r[-1]
+            p = ctx.tensor(pts)
+            out = torch.empty_like(p)
+            _lib.check(ctx._lib.bfhip_kde_cdf(ctx.handle, d, n, _ptr(yT), _ptr(w), _ptr(hd), m, _ptr(p), _ptr(out)))
+            vals = ndtri(out.cpu().numpy())          # (scipy's norm.ppf is this function)
+            return [None if r is None else vals[j, :r.size] for j, r in enumerate(requests)]
 
-            splines.append(GaussianizingSpline(y_host[j], fun, **self.cubic_options))
+        splines = GaussianizingSpline.build_many(y_sorted, batch_fun, presorted=True, **self.cubic_options)
         return SplineTable(splines, ctx)
 
     def fit(self, data=None, weights=None, n_run=None):

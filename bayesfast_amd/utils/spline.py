@@ -68,24 +68,64 @@ def percentile_sorted(xs, q):
 class GaussianizingSpline:
     """``cubic_spline(x_all, fun, **options)``: knots ``x``, values ``y`` and coefficient rows ``c`` (n + 1, 4)."""
 
-    def __init__(self, x_all, fun, bins=100, edge_bins=1, edge_points=10, max_width=5, split=4, max_add=5):
-        xs = np.sort(np.asarray(x_all, dtype=np.float64).reshape(-1))  # one sort serves the three percentile sets below
+    def __init__(self, x_all, fun, bins=100, edge_bins=1, edge_points=10, max_width=5, split=4, max_add=5, presorted=False):
+        steps = self._build(x_all, presorted, bins, edge_bins, edge_points, max_width, split, max_add)
+        try:
+            pts = next(steps)
+            while True:
+                pts = steps.send(np.asarray(fun(pts), dtype=np.float64))
+        except StopIteration:
+            pass
+
+    @classmethod
+    def build_many(cls, rows, batch_fun, presorted=False, **options):
+        """One spline per row of ``rows``, built side by side: every spline asks for function values at a few points
+        several times on its way (knots, edge points, extra knots); ``batch_fun(requests)`` gets the requests of one round
+        -- a list with a point array or None per row -- and returns the list of value arrays, so that the d coordinates of a
+        SIT iteration cost a handful of device calls instead of eight per coordinate."""
+        out = [cls.__new__(cls) for _ in rows]
+        steps = [o._build(r, presorted, **options) for o, r in zip(out, rows)]
+        req = []
+        for g in steps:
+            try:
+                req.append(next(g))
+            except StopIteration:
+                req.append(None)
+        while any(r is not None for r in req):
+            vals = batch_fun(req)
+            nxt = []
+            for g, r, v in zip(steps, req, vals):
+                if r is None:
+                    nxt.append(None)
+                    continue
+                try:
+                    nxt.append(g.send(np.asarray(v, dtype=np.float64)))
+                except StopIteration:
+                    nxt.append(None)
+            req = nxt
+        return out
+
+    def _build(self, x_all, presorted=False, bins=100, edge_bins=1, edge_points=10, max_width=5, split=4, max_add=5):
+        """The construction as a generator: yields the points it needs ``fun`` at, is sent the values."""
+        xs = np.asarray(x_all, dtype=np.float64).reshape(-1)
+        if not presorted:
+            xs = np.sort(xs)  # one sort serves the three percentile sets below
         edge_bins = int(min(edge_bins, bins // 4))
         grid = np.linspace(0, 100, bins + 1)[edge_bins:-edge_bins]
         self.x = np.unique(percentile_sorted(xs, grid))
-        self.y = np.asarray(fun(self.x), dtype=np.float64)
+        self.y = np.asarray((yield self.x), dtype=np.float64)
         inner = np.linspace(0, 100, edge_points + 2)[1:-1]
         below = xs[:np.searchsorted(xs, self.x[edge_bins], 'left')]            # x_all[x_all < knot], sorted
         above = xs[np.searchsorted(xs, self.x[-edge_bins - 1], 'right'):]      # x_all[x_all > knot], sorted
-        self._k_left = self._edge_slope(below, self.x[0], self.y[0], fun, inner)
-        self._k_right = self._edge_slope(above, self.x[-1], self.y[-1], fun, inner)
-        self._fill_wide_gaps(fun, max_width, split)
+        self._k_left = yield from self._edge_slope(below, self.x[0], self.y[0], inner)
+        self._k_right = yield from self._edge_slope(above, self.x[-1], self.y[-1], inner)
+        yield from self._fill_wide_gaps(max_width, split)
         self._fit()
         good = _monotone_flags(self.c, self.x)
         rounds = 0
         while not good.all() and rounds < max_add:
             new = np.concatenate([np.linspace(self.x[j], self.x[j + 1], split + 1)[1:-1] for j in np.flatnonzero(~good)])
-            self._insert(new, fun)
+            yield from self._insert(new)
             if rounds == max_add - 1:
                 self._straighten_flat_values()
             self._fit()
@@ -98,17 +138,18 @@ class GaussianizingSpline:
                 warnings.warn(RuntimeWarning('Not all the intervals are monotone.'))
 
     @staticmethod
-    def _edge_slope(outside, knot, value, fun, inner):
+    def _edge_slope(outside, knot, value, inner):
         t = percentile_sorted(outside - knot, inner)  # (outside is sorted, and stays so under the shift)
-        f = np.asarray(fun(t + knot)) - value
+        f = np.asarray((yield t + knot)) - value
         return np.sum(t * f) / np.sum(t * t)
 
-    def _insert(self, new, fun):
+    def _insert(self, new):
         at = np.searchsorted(self.x, new)
+        vals = np.asarray((yield new), dtype=np.float64)
         self.x = np.insert(self.x, at, new)
-        self.y = np.insert(self.y, at, np.asarray(fun(new), dtype=np.float64))
+        self.y = np.insert(self.y, at, vals)
 
-    def _fill_wide_gaps(self, fun, max_width, split):
+    def _fill_wide_gaps(self, max_width, split):
         rel = np.diff(self.x)
         rel = rel / np.mean(rel)
         n = self.x.size
@@ -127,7 +168,7 @@ class GaussianizingSpline:
         wide = np.flatnonzero(rel[first:last + 1] > max_width) + first
         if wide.size:
             new = np.concatenate([np.linspace(self.x[j], self.x[j + 1], int(np.ceil(rel[j] / split)) + 1)[1:-1] for j in wide])
-            self._insert(new, fun)
+            yield from self._insert(new)
 
     def _fit(self):
         """Clamped C2 cubic spline: slopes s at the knots from the tridiagonal continuity system, then the local
