@@ -124,7 +124,11 @@ class GaussianizingSpline:
         good = _monotone_flags(self.c, self.x)
         rounds = 0
         while not good.all() and rounds < max_add:
-            new = np.concatenate([np.linspace(self.x[j], self.x[j + 1], split + 1)[1:-1] for j in np.flatnonzero(~good)])
+            # np.linspace(x[j], x[j + 1], split + 1)[1:-1] of every offending interval at once (linspace's own arithmetic:
+            # k * ((b - a) / split) + a; a call per interval was 0.15 s of a ten-iteration SIT fit)
+            bad = np.flatnonzero(~good)
+            lo, hi = self.x[bad], self.x[bad + 1]
+            new = (np.arange(1, split, dtype=np.float64)[None, :] * ((hi - lo) / split)[:, None] + lo[:, None]).reshape(-1)
             yield from self._insert(new)
             if rounds == max_add - 1:
                 self._straighten_flat_values()
