@@ -163,7 +163,10 @@ class DeviceChains:
                 # a launch that ends the warm-up is judged more leniently: its last iterations still adapt the step size
                 # (a few trees of another size), the launch after it runs with the frozen, averaged one
                 i0, i1 = self.i_iter + done - step, self.i_iter + min(done, n_run)
-                self._note_trees(stats, done - step, min(done, n_run), sampler, share=0.85 if i0 < n_warmup <= i1 else 0.98)
+                # (launches inside the warm-up: 7-leaf trees with one 15-leaf tree in ten already run faster in step -- the late
+                # warm-up launches of the default run 5.5 against 6.0 ms, tools/launch_times.py)
+                self._note_trees(stats, done - step, min(done, n_run), sampler,
+                                 share=0.85 if i0 < n_warmup <= i1 else (0.8 if i1 < n_warmup else 0.98))
         self.i_iter += n_run
         if check:
             self.raise_on_error()
