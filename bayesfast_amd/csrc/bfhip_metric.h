@@ -127,6 +127,54 @@ __device__ inline void bf_velocity_full(const double *covT, const double (&pv)[E
     }
 }
 
+// Three velocities in ONE pass over the matrix (the U-turn checks of a merge level and of a doubling's end need cov p of three
+// stored momenta: nuts.py:150-160, 88-100): each vector's sum is the one bf_velocity_full makes, term by term; the 32 KB of a
+// chain's covariance are read once instead of three times.
+template <int E>
+__device__ inline void bf_velocity_full3(const double *covT, const double (&p0)[E], const double (&p1)[E], const double (&p2)[E],
+                                         double (&o0)[E], double (&o1)[E], double (&o2)[E], int d, int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) o0[e] = o1[e] = o2[e] = 0.;
+    constexpr int B = 16;
+    int k = 0;
+    for (; k + B <= d; k += B) {
+        double c[B][E];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                c[u][e] = (i < d) ? covT[(size_t)(k + u) * d + i] : 0.;
+            }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const double a0 = bf_pick<E>(p0, k + u), a1 = bf_pick<E>(p1, k + u), a2 = bf_pick<E>(p2, k + u);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < d) {
+                    o0[e] = __dadd_rn(o0[e], __dmul_rn(c[u][e], a0));
+                    o1[e] = __dadd_rn(o1[e], __dmul_rn(c[u][e], a1));
+                    o2[e] = __dadd_rn(o2[e], __dmul_rn(c[u][e], a2));
+                }
+            }
+        }
+    }
+    for (; k < d; ++k) {
+        const double a0 = bf_pick<E>(p0, k), a1 = bf_pick<E>(p1, k), a2 = bf_pick<E>(p2, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) {
+                const double cv = covT[(size_t)k * d + i];
+                o0[e] = __dadd_rn(o0[e], __dmul_rn(cv, a0));
+                o1[e] = __dadd_rn(o1[e], __dmul_rn(cv, a1));
+                o2[e] = __dadd_rn(o2[e], __dmul_rn(cv, a2));
+            }
+        }
+    }
+}
+
 // metric.random for the full metric: solve L^T p = z (scipy.linalg.solve_triangular(chol.T, z), metrics.py:123-127)
 // by the column sweep of BLAS dtrsv: j = d-1 .. 0: p_j = z_j / L[j][j]; z_i -= L[j][i] p_j for i < j.
 template <int E>

@@ -323,6 +323,15 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         }
     };
 
+    auto velocity3 = [&](const double (&a0)[E], const double (&a1)[E], const double (&a2)[E], double (&o0)[E], double (&o1)[E], double (&o2)[E]) {
+        if constexpr (FULLM) {
+            bf_velocity_full3<E>(matp + BF_MAT_COV * msz, a0, a1, a2, o0, o1, o2, d, lane);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { o0[e] = var[e] * a0[e]; o1[e] = var[e] * a1[e]; o2[e] = var[e] * a2[e]; }
+        }
+    };
+
     auto load_vec = [&](int field, double (&v)[E], double pad) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             for (int e = 0; e < E; ++e) { A[e] = PF0[e]; B[e] = PF1[e]; S1[e] = PF2[e]; }  // prefetched when this unit was scheduled
             double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
             double vAa[E], vBa[E], vCa[E];
-            velocity(A, vAa); velocity(B, vBa); velocity(TLp, vCa);
+            velocity3(A, B, TLp, vAa, vBa, vCa);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 psum[e] = S1[e] + TPs[e];
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             }
             double d0 = 0., d1 = 0., d2 = 0., d3 = 0., d4 = 0., d5 = 0.;
             double vTa[E], vLa[E], vRa[E];
-            velocity(TLp, vTa); velocity(oldL, vLa); velocity(oldR, vRa);
+            velocity3(TLp, oldL, oldR, vTa, vLa, vRa);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 ps[e] += TPs[e];  // :86 (in place)

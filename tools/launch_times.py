@@ -27,9 +27,13 @@ for rep in range(2):
         e1.record(ctx.stream)
         torch.cuda.synchronize()
         ts = st[:, :, _lib.NSTATS.index('tree_size')]
-        rows.append((n, e0.elapsed_time(e1), ch.total_leapfrog - lf0, ch.last_layout, kname().decode(), float(ts.mean()), float(ts.max())))
+        tot = ts.sum(1)                                   # leapfrog steps per chain in this launch
+        wg = tot.view(-1, 16).max(1).values               # ... of the slowest chain of every 16-chain workgroup
+        rows.append((n, e0.elapsed_time(e1), ch.total_leapfrog - lf0, ch.last_layout, kname().decode(), float(ts.mean()), float(ts.max()),
+                     float(tot.mean() / wg.mean()), float(tot.mean() / tot.max())))
 tot = 0.
-for n, ms, lf, lay, kn, tm, tx in rows:
+for n, ms, lf, lay, kn, tm, tx, e16, eall in rows:
     tot += ms
-    print('%4d iterations: %6.2f ms  %.3g leapfrogs  %.3g /s  layout %-5s %-28s tree mean %.1f max %d' % (n, ms, lf, lf / ms * 1e3, lay, kn, tm, tx))
+    print('%4d iterations: %6.2f ms  %.3g leapfrogs  %.3g /s  layout %-5s %-28s tree mean %.1f max %d  chain totals: mean / mean of 16-chain maxima %.2f, mean / max %.2f' % (
+        n, ms, lf, lf / ms * 1e3, lay, kn, tm, tx, e16, eall))
 print('total %.1f ms' % tot)
