@@ -11,6 +11,7 @@
 #include "bfhip_common.h"
 
 enum { BF_MAT_COV = 0, BF_MAT_CHOL, BF_MAT_CHOL_ROWS, BF_MAT_FG, BF_MAT_BG, BF_MAT_WORK, BF_MAT_N };
+static_assert(BF_MAT_N == BFHIP_MAT_N, "include/bfhip.h");
 
 __device__ inline double bf_readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
@@ -25,49 +26,62 @@ __device__ inline double bf_pick(const double (&x)[E], int k) {
 // Returns false when a pivot is not positive (the reference keeps its previous factor then, metrics.py:287-292).
 template <int E>
 __device__ inline bool bf_chol_rows(const double *aT, double *lT, int d, int lane) {
-    for (int j = 0; j < d; ++j) {
-        double acc[E];
+    // Columns in blocks of JB: the finished columns k < j0 are read ONCE per block and applied to all its columns (column by
+    // column every one of them was read again for every later column: 1 MB per factorisation at d = 64, the largest part of
+    // a warm-up iteration with the full-rank metric), the block's own columns stay in registers.  For every column j the
+    // terms L[i][k] L[j][k] are subtracted for k = 0 .. j - 1 in this order, as before (oracle/bf_oracle.c rounds the same).
+    // (Writing the row-major copy from the block's registers, whole cache lines into a second work matrix, and publishing by
+    // two straight copies was measured slower than bf_chol_publish's scattered stores: 262 against 219 ms per 100 iterations.)
+    constexpr int JB = E == 1 ? 16 : 8, KB = 8;
+    for (int j0 = 0; j0 < d; j0 += JB) {
+        const int nj = d - j0 < JB ? d - j0 : JB;
+        double acc[JB][E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = lane * E + e;
-            acc[e] = (i < d) ? aT[(size_t)j * d + i] : 0.;  // a[i][j]
-        }
-        constexpr int B = 16;  // (loads of a block of columns in flight together, as in bf_velocity_full; same order of sums)
-        int k = 0;
-        for (; k + B <= j; k += B) {
-            double lb[B][E];
-#pragma unroll
-            for (int u = 0; u < B; ++u)
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = lane * E + e;
-                    lb[u][e] = (i < d) ? lT[(size_t)(k + u) * d + i] : 0.;  // L[i][k + u], written by this lane earlier
-                }
-#pragma unroll
-            for (int u = 0; u < B; ++u) {
-                const double ljk = bf_pick<E>(lb[u], j);
-#pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] = __dsub_rn(acc[e], __dmul_rn(lb[u][e], ljk));
-            }
-        }
-        for (; k < j; ++k) {
-            double lik[E];
+        for (int u = 0; u < JB; ++u)
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int i = lane * E + e;
-                lik[e] = (i < d) ? lT[(size_t)k * d + i] : 0.;  // L[i][k], written by this lane at step k
+                acc[u][e] = (u < nj && i < d) ? aT[(size_t)(j0 + u) * d + i] : 0.;  // a[i][j0 + u]
             }
-            const double ljk = bf_pick<E>(lik, j);              // L[j][k]
+        for (int k = 0; k < j0; k += KB) {  // (j0 is a multiple of JB, JB of KB)
+            double lb[KB][E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = __dsub_rn(acc[e], __dmul_rn(lik[e], ljk));
+            for (int v = 0; v < KB; ++v)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = lane * E + e;
+                    lb[v][e] = (i < d) ? lT[(size_t)(k + v) * d + i] : 0.;  // L[i][k + v], written by this lane earlier
+                }
+#pragma unroll
+            for (int v = 0; v < KB; ++v)
+#pragma unroll
+                for (int u = 0; u < JB; ++u)
+                    if (u < nj) {
+                        const double ljk = bf_pick<E>(lb[v], j0 + u);              // L[j0 + u][k + v]
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[u][e] = __dsub_rn(acc[u][e], __dmul_rn(lb[v][e], ljk));
+                    }
         }
-        const double s = bf_pick<E>(acc, j);
-        if (!(s > 0.)) return false;
-        const double ljj = __dsqrt_rn(s);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = lane * E + e;
-            if (i < d) lT[(size_t)j * d + i] = i > j ? __ddiv_rn(acc[e], ljj) : (i == j ? ljj : 0.);
+        for (int u = 0; u < JB; ++u) {
+            if (u < nj) {
+                const int j = j0 + u;
+#pragma unroll
+                for (int v = 0; v < u; ++v) {   // the block's own finished columns, from registers
+                    const double ljk = bf_pick<E>(acc[v], j);                      // L[j][j0 + v]
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[u][e] = __dsub_rn(acc[u][e], __dmul_rn(acc[v][e], ljk));
+                }
+                const double s = bf_pick<E>(acc[u], j);
+                if (!(s > 0.)) return false;
+                const double ljj = __dsqrt_rn(s);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = lane * E + e;
+                    acc[u][e] = i > j ? __ddiv_rn(acc[u][e], ljj) : (i == j ? ljj : 0.);
+                    if (i < d) lT[(size_t)j * d + i] = acc[u][e];
+                }
+            }
         }
     }
     return true;
