@@ -90,14 +90,38 @@ __device__ inline bool bf_chol_rows(const double *aT, double *lT, int d, int lan
 // lT -> the two stored copies of the factor
 template <int E>
 __device__ inline void bf_chol_publish(const double *lT, double *cholT, double *cholR, int d, int lane) {
-    for (int j = 0; j < d; ++j) {
+    // columns in batches: the loads of a batch before its stores (the matrices of a chain may alias for all the compiler
+    // knows, so a load -> store loop waits a memory latency per column)
+    constexpr int B = 16;
+    int j = 0;
+    for (; j + B <= d; j += B) {
+        double v[B][E];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                v[u][e] = (i < d) ? lT[(size_t)(j + u) * d + i] : 0.;
+            }
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < d) {
+                    cholT[(size_t)(j + u) * d + i] = v[u][e];
+                    cholR[(size_t)i * d + j + u] = v[u][e];  // row-major: L[i][j + u]
+                }
+            }
+    }
+    for (; j < d; ++j) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = lane * E + e;
             if (i < d) {
                 const double v = lT[(size_t)j * d + i];
                 cholT[(size_t)j * d + i] = v;
-                cholR[(size_t)i * d + j] = v;  // row-major: L[i][j]
+                cholR[(size_t)i * d + j] = v;
             }
         }
     }
@@ -235,7 +259,10 @@ __device__ inline void bf_solve_lt(const double *cholR, double (&z)[E], int d, i
 
 // _WeightedCovariance.add_sample (metrics.py:401-407) on the transposed accumulator: raw[i][j] += new_i * old_j
 template <int E>
-__device__ inline void bf_welford_cov(double *rawT, const double (&new_diff)[E], const double (&old_diff)[E], int d, int lane) {
+// (scaledT: when not NULL also scaledT = updated raw / n -- _update_from_weightvar's covariance, metrics.py:287-292, taken
+// while the accumulator passes through registers instead of in a second sweep over it)
+__device__ inline void bf_welford_cov(double *rawT, const double (&new_diff)[E], const double (&old_diff)[E], int d, int lane,
+                                      double *scaledT = nullptr, double n = 1.) {
     constexpr int B = 8;
     int j = 0;
     for (; j + B <= d; j += B) {
@@ -253,7 +280,11 @@ __device__ inline void bf_welford_cov(double *rawT, const double (&new_diff)[E],
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int i = lane * E + e;
-                if (i < d) rawT[(size_t)(j + u) * d + i] = __dadd_rn(rb[u][e], __dmul_rn(__dmul_rn(1., new_diff[e]), oj));
+                if (i < d) {
+                    const double r = __dadd_rn(rb[u][e], __dmul_rn(__dmul_rn(1., new_diff[e]), oj));
+                    rawT[(size_t)(j + u) * d + i] = r;
+                    if (scaledT) scaledT[(size_t)(j + u) * d + i] = r / n;
+                }
             }
         }
     }
@@ -262,7 +293,11 @@ __device__ inline void bf_welford_cov(double *rawT, const double (&new_diff)[E],
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = lane * E + e;
-            if (i < d) rawT[(size_t)j * d + i] = __dadd_rn(rawT[(size_t)j * d + i], __dmul_rn(__dmul_rn(1., new_diff[e]), oj));
+            if (i < d) {
+                const double r = __dadd_rn(rawT[(size_t)j * d + i], __dmul_rn(__dmul_rn(1., new_diff[e]), oj));
+                rawT[(size_t)j * d + i] = r;
+                if (scaledT) scaledT[(size_t)j * d + i] = r / n;
+            }
         }
     }
 }

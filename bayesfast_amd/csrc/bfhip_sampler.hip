@@ -730,19 +730,13 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                 fg_n += 1.;
 #pragma unroll
                 for (int e = 0; e < E; ++e) { od[e] = q[e] - fm[e]; fm[e] += od[e] / fg_n; nd[e] = q[e] - fm[e]; }
-                bf_welford_cov<E>(fgT, nd, od, d, lane);
+                const bool refresh = (delta + 1) % (long)a.cfg.update_window == 0;   // _update_from_weightvar: :287-292
+                bf_welford_cov<E>(fgT, nd, od, d, lane, refresh ? covT : nullptr, fg_n);
                 bg_n += 1.;
 #pragma unroll
                 for (int e = 0; e < E; ++e) { od[e] = q[e] - bm[e]; bm[e] += od[e] / bg_n; nd[e] = q[e] - bm[e]; }
                 bf_welford_cov<E>(bgT, nd, od, d, lane);
-                if ((delta + 1) % (long)a.cfg.update_window == 0) {  // _update_from_weightvar: :287-292
-                    for (int j = 0; j < d; ++j) {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            const int i = lane * E + e;
-                            if (i < d) covT[(size_t)j * d + i] = fgT[(size_t)j * d + i] / fg_n;
-                        }
-                    }
+                if (refresh) {  // (covT = fgT / fg_n was written by the foreground update above)
                     double *wT = matp + BF_MAT_WORK * msz;
                     if (bf_chol_rows<E>(covT, wT, d, lane))
                         bf_chol_publish<E>(wT, matp + BF_MAT_CHOL * msz, matp + BF_MAT_CHOL_ROWS * msz, d, lane);
