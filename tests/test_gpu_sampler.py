@@ -332,13 +332,15 @@ def test_launch_cuts_do_not_change_results(ctx):
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(3).normal(size=(40, 64))
     out = []
-    for li in (None, 7, 250):
+    for li in (None, 7, 250, [3, 11], 'auto'):   # (a sequence: its last length repeats; 'auto': 100 while adapting, then 250)
         dc = DeviceChains(dens, x0, seed=3)
         s, st = dc.run(50, 'NUTS', n_warmup=30, launch_iters=li, layout=_LAYOUT['v'])
         out.append((s.cpu().numpy(), st.cpu().numpy(), dc.sc.cpu().numpy(), dc.total_leapfrog))
     for o in out[1:]:
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1], equal_nan=True)
         assert np.array_equal(o[2], out[0][2], equal_nan=True) and o[3] == out[0][3]
+    with pytest.raises(ValueError):
+        DeviceChains(dens, x0, seed=3).run(5, 'NUTS', n_warmup=3, launch_iters='sometimes')
 
 
 def test_nuts_divergences_and_max_treedepth(ctx, samp):
