@@ -907,12 +907,131 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         }
     };
 
+    // The cubic configs of this wave's chain with the tables in LDS (cub_l): the contributions to the gradient entries this lane
+    // owns (gc2: cubic-2, gc3: cubic-3; a dimension gets at most one of each) and the lane's part of the value.  xe: the
+    // evaluation point, element e of lane l is dimension l E + e.  Called in phase C -- or, when the workgroup has at least as
+    // many chain-less waves as chains (wave_layout_cpg: config 5's shard, 4 chains on 8 waves), right after barrier B1 by the
+    // chain's wave while the chain-less waves take ALL the matvec jobs: the contraction (a third of the trip) then runs beside
+    // the jobs, which wait for their A operands from L2 most of the time, instead of behind them.
+    auto cubic_lds = [&](const double (&xe)[E], double (&gc2)[E], double (&gc3)[E]) -> double {
+        const int jl = lane & 15, kq = lane >> 4;
+        auto xl_ = [&](int dim) {
+            const double a0 = __shfl(xe[0], dim / E, 64);
+            if constexpr (E > 1) { const double a1 = __shfl(xe[E - 1], dim / E, 64); return (dim % E) ? a1 : a0; }
+            return a0;
+        };
+        const double xm2 = xl_(mk2), xm3 = xl_(mk3);
+        double fsum = 0.;
+#pragma unroll
+        for (int e = 0; e < E; ++e) gc2[e] = gc3[e] = 0.;
+        auto fetch_l = [&](const int (&pj)[E], int jb, double val, double (&dst)[E]) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool mine = pj[e] >= jb && pj[e] < jb + 16;
+                const double gv = __shfl(val, mine ? pj[e] - jb : 0, 64);
+                if (mine) dst[e] += gv;
+            }
+        };
+        const int n2 = m.n2, n3 = m.n3;
+        const double *A2t_l = CUB, *A2_l = CUB + n2 * n2;
+        const double *T3_l = lds + (((size_t)(CUB + 2 * n2 * n2 - lds) + 1) & ~(size_t)1);
+        const int nc3 = (n3 + 15) >> 4;
+        // (The loads of a batch are issued together, then the sums run in the original order: with one LDS
+        // round trip per term the contraction was 13 k of config 5's 29 k cycles per trip,
+        // tools/trace_sliced.py.  Terms past the tables' ends are +0 and leave the sums as they were.)
+        for (int jb = 0; jb < n2; jb += 16) {
+            const int j = jb + jl;
+            const bool on = j < n2;
+            const int jc = on ? j : 0;
+            double v1 = 0., v2 = 0.;
+            for (int kk = 0; kk < n2; kk += 16) {
+                double a1[4], a2[4], xk[4];
+                if (jb + 16 <= n2 && kk + 16 <= n2) {   // (wave-uniform: a full tile needs no guards)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kk + 4 * u + kq;
+                        xk[u] = __shfl(xm2, k, 64);
+                        a1[u] = A2t_l[k * n2 + j];
+                        a2[u] = A2_l[k * n2 + j];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kk + 4 * u + kq;
+                        const bool ok = on && k < n2;
+                        const int kc = ok ? k : 0;
+                        xk[u] = __shfl(xm2, kc, 64);
+                        const double t1 = A2t_l[kc * n2 + jc], t2 = A2_l[kc * n2 + jc];
+                        a1[u] = ok ? t1 : 0.;
+                        a2[u] = ok ? t2 : 0.;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v1 += a1[u] * xk[u];
+                    v2 += a2[u] * (xk[u] * xk[u]);
+                }
+            }
+            v1 = swap32_add_f64(swap16_add_f64(v1));
+            v2 = swap32_add_f64(swap16_add_f64(v2));
+            const double xj = __shfl(xm2, jc, 64);
+            const double gj2 = 2. * xj * v1 + v2;
+            if (on && kq == 0) fsum += xj * xj * v1;
+            fetch_l(pj2, jb, gj2, gc2);
+        }
+        // cubic-3, lane (j, lq): sum_k x_k sum_{l = lq mod 4} T[j, k, l] x_l -- the lane's own four x_l of a chunk of 16
+        // stay in registers, x_k is the only broadcast (a third of the instructions of the (j, kq) form,
+        // which read every x_l through a readlane; the trip is its instruction count)
+        for (int jb = 0; jb < n3; jb += 16) {
+            const int j = jb + jl;
+            const bool on = j < n3;
+            const int jc = on ? j : 0;
+            double sacc = 0.;
+            for (int c = 0; c < nc3; ++c) {
+                double xq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int l = 16 * c + kq + 4 * i;
+                    xq[i] = __shfl(xm3, l < n3 ? l : 0, 64);   // (the table is zero there)
+                }
+                const double *Tc = T3_l + ((size_t)c * n3 * n3 + jc) * 16 + kq * 4;
+                for (int k = 0; k < n3; k += 4) {
+                    d2_t ta[4][2];
+                    const bool full = k + 4 <= n3;   // (wave-uniform)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double *pk = Tc + (size_t)((full || k + u < n3) ? k + u : 0) * n3 * 16;
+                        ta[u][0] = *(const d2_t *)pk;
+                        ta[u][1] = *(const d2_t *)(pk + 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // all eight loads on their way before the first product
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        double t = ta[u][0][0] * xq[0];
+                        t += ta[u][0][1] * xq[1];
+                        t += ta[u][1][0] * xq[2];
+                        t += ta[u][1][1] * xq[3];
+                        if (full || k + u < n3) sacc += t * readlane_f64(xm3, (k + u) & 63);
+                    }
+                }
+            }
+            sacc = swap32_add_f64(swap16_add_f64(sacc));
+            const double xj = __shfl(xm3, jc, 64);
+            if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
+            fetch_l(pj3, jb, 0.5 * sacc, gc3);
+        }
+        return fsum;
+    };
+    const bool cub_early = cub_l && 2 * cpg <= NWV;   // (fixed for the launch, the same in every wave)
     for (int trip = 0;; ++trip) {
         trip_no = trip;
         TRACE(0);
         // ================= phase A: first half of the leapfrog, B operands =================
-        double xs[E], jac[E], gj[E], xo[E];
+        double xs[E], jac[E], gj[E], xo[E], xea[E];
         double logdet = 0.;
+        double gc2_c[E], gc3_c[E], fs_c = 0.;   // (cubic configs, taken early: cub_early)
+#pragma unroll
+        for (int e = 0; e < E; ++e) xea[e] = gc2_c[e] = gc3_c[e] = 0.;
         const bool evaluating = unit == U_EVAL;
         if (evaluating) {
             if (mode != M_OOB) {
@@ -942,6 +1061,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                 double x_eval = xs[e];
                 if (mode == M_OOB)  // modules/poly.py:482
                     x_eval = (m.alpha * xs[e] + (cs_get(CS_BETA) - m.alpha) * c_mu[e]) / cs_get(CS_BETA);
+                xea[e] = x_eval;
                 if (dim < DP) {
                     const int xi = (dim >> 2) * XS + w + 16 * (dim & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
                     XB[0 * NS * XS + xi] = x_eval;
@@ -999,6 +1119,42 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             const int mc = lane & 15, mg = lane >> 4;
             // (skip_h: S and H are the only matrices and the H jobs, the second half of the list, are left out)
             const int n_job = (only_s || (skip_h && n_mat == 2 && mat0 == 0 && mat1 == 1)) ? W * KS : n_mat * (W * KS);
+            if (cub_early) {
+                // the chains' waves are busy with the cubic configs; the chain-less waves share the jobs, TWO at a time: two
+                // independent chains of MFMAs whose operand loads (A from L2 at d = 128) are in flight together
+                const int st = NWV - cpg;
+                constexpr int C2 = KPJ < 4 ? KPJ : 4;
+                for (int job = w - cpg; job >= 0 && job < n_job; job += 2 * st) {
+                    const bool two = job + st < n_job;
+                    const int jb2 = two ? job + st : job;
+                    const int sm1 = job / (W * KS), r1 = job % (W * KS), t1 = r1 / KS, kp1 = r1 % KS;
+                    const int sm2 = jb2 / (W * KS), r2 = jb2 % (W * KS), t2 = r2 / KS, kp2 = r2 % KS;
+                    const int b1 = sm1 == 0 ? mat0 : (sm1 == 1 ? mat1 : 2), b2 = sm2 == 0 ? mat0 : (sm2 == 1 ? mat1 : 2);
+                    const double *Af1 = (b1 == 0 ? Sf : (b1 == 1 ? Hf : Hdf)) + (t1 * NS + kp1 * KPJ) * 64 + lane;
+                    const double *Af2 = (b2 == 0 ? Sf : (b2 == 1 ? Hf : Hdf)) + (t2 * NS + kp2 * KPJ) * 64 + lane;
+                    const double *Xf1 = XB + (b1 * NS + kp1 * KPJ) * XS + lane, *Xf2 = XB + (b2 * NS + kp2 * KPJ) * XS + lane;
+                    d4_t acc1 = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};
+#pragma unroll
+                    for (int c0 = 0; c0 < KPJ; c0 += C2) {
+                        double a1[C2], x1[C2], a2[C2], x2[C2];
+#pragma unroll
+                        for (int q2 = 0; q2 < C2; ++q2) {
+                            a1[q2] = Af1[(c0 + q2) * 64]; x1[q2] = Xf1[(c0 + q2) * XS];
+                            a2[q2] = Af2[(c0 + q2) * 64]; x2[q2] = Xf2[(c0 + q2) * XS];
+                        }
+#pragma unroll
+                        for (int q2 = 0; q2 < C2; ++q2) {
+                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q2], x1[q2], acc1, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q2], x2[q2], acc2, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        GB[((sm1 * KS + kp1) * 16 + mc) * GS + 16 * t1 + 4 * r4 + mg] = acc1[r4];
+                        if (two) GB[((sm2 * KS + kp2) * 16 + mc) * GS + 16 * t2 + 4 * r4 + mg] = acc2[r4];
+                    }
+                }
+            } else
             for (int job = w; job < n_job; job += NWV) {
                 const int slot_m = job / (W * KS), rem = job % (W * KS);
                 const int t = rem / KS, kp = rem % KS;
@@ -1063,6 +1219,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         } else if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>());
         else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>());
         else run_jobs(std::integral_constant<int, 1>());
+        if (cub_early && evaluating) fs_c = cubic_lds(xea, gc2_c, gc3_c);   // (this wave had no job: see run_jobs)
         const int unit_in = unit;
         stamp(2);
         __syncthreads();  // B2
@@ -1129,103 +1286,11 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                     // the same sums in the same order with the tables in LDS, the masked inputs gathered once (lane k
                     // holds x[mask[k]]) and the masks and positions of this lane in registers: nothing of the loops below
                     // goes to global memory (the 64 dependent global loads of the cubic-3 contraction were 2/3 of config 5's trip)
-                    const int n2 = m.n2, n3 = m.n3;
-                    const double *A2t_l = CUB, *A2_l = CUB + n2 * n2;
-                    const double *T3_l = lds + (((size_t)(CUB + 2 * n2 * n2 - lds) + 1) & ~(size_t)1);
-                    const int nc3 = (n3 + 15) >> 4;
-                    const double xm2 = xl(mk2), xm3 = xl(mk3);
-                    auto fetch_l = [&](const int (&pj)[E], int jb, double val, double (&dst)[E]) {
+                    // (cubic_lds above: the sums and their order are those of the separate loops below)
+                    if (!cub_early) fs_c = cubic_lds(xev, gc2_c, gc3_c);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            const bool mine = pj[e] >= jb && pj[e] < jb + 16;
-                            const double gv = __shfl(val, mine ? pj[e] - jb : 0, 64);
-                            if (mine) dst[e] += gv;
-                        }
-                    };
-                    // (The loads of a batch are issued together, then the sums run in the original order: with one LDS
-                    // round trip per term the contraction was 13 k of config 5's 29 k cycles per trip,
-                    // tools/trace_sliced.py.  Terms past the tables' ends are +0 and leave the sums as they were.)
-                    for (int jb = 0; jb < n2; jb += 16) {
-                        const int j = jb + jl;
-                        const bool on = j < n2;
-                        const int jc = on ? j : 0;
-                        double v1 = 0., v2 = 0.;
-                        for (int kk = 0; kk < n2; kk += 16) {
-                            double a1[4], a2[4], xk[4];
-                            if (jb + 16 <= n2 && kk + 16 <= n2) {   // (wave-uniform: a full tile needs no guards)
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int k = kk + 4 * u + kq;
-                                    xk[u] = __shfl(xm2, k, 64);
-                                    a1[u] = A2t_l[k * n2 + j];
-                                    a2[u] = A2_l[k * n2 + j];
-                                }
-                            } else {
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int k = kk + 4 * u + kq;
-                                    const bool ok = on && k < n2;
-                                    const int kc = ok ? k : 0;
-                                    xk[u] = __shfl(xm2, kc, 64);
-                                    const double t1 = A2t_l[kc * n2 + jc], t2 = A2_l[kc * n2 + jc];
-                                    a1[u] = ok ? t1 : 0.;
-                                    a2[u] = ok ? t2 : 0.;
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                v1 += a1[u] * xk[u];
-                                v2 += a2[u] * (xk[u] * xk[u]);
-                            }
-                        }
-                        v1 = swap32_add_f64(swap16_add_f64(v1));
-                        v2 = swap32_add_f64(swap16_add_f64(v2));
-                        const double xj = __shfl(xm2, jc, 64);
-                        const double gj2 = 2. * xj * v1 + v2;
-                        if (on && kq == 0) fsum += xj * xj * v1;
-                        fetch_l(pj2, jb, gj2, gn);
-                    }
-                    // cubic-3, lane (j, lq): sum_k x_k sum_{l = lq mod 4} T[j, k, l] x_l -- the lane's own four x_l of a chunk of 16
-                    // stay in registers, x_k is the only broadcast (a third of the instructions of the (j, kq) form,
-                    // which read every x_l through a readlane; the trip is its instruction count)
-                    for (int jb = 0; jb < n3; jb += 16) {
-                        const int j = jb + jl;
-                        const bool on = j < n3;
-                        const int jc = on ? j : 0;
-                        double sacc = 0.;
-                        for (int c = 0; c < nc3; ++c) {
-                            double xq[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int l = 16 * c + kq + 4 * i;
-                                xq[i] = __shfl(xm3, l < n3 ? l : 0, 64);   // (the table is zero there)
-                            }
-                            const double *Tc = T3_l + ((size_t)c * n3 * n3 + jc) * 16 + kq * 4;
-                            for (int k = 0; k < n3; k += 4) {
-                                d2_t ta[4][2];
-                                const bool full = k + 4 <= n3;   // (wave-uniform)
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const double *pk = Tc + (size_t)((full || k + u < n3) ? k + u : 0) * n3 * 16;
-                                    ta[u][0] = *(const d2_t *)pk;
-                                    ta[u][1] = *(const d2_t *)(pk + 2);
-                                }
-                                __builtin_amdgcn_sched_barrier(0);   // all eight loads on their way before the first product
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    double t = ta[u][0][0] * xq[0];
-                                    t += ta[u][0][1] * xq[1];
-                                    t += ta[u][1][0] * xq[2];
-                                    t += ta[u][1][1] * xq[3];
-                                    if (full || k + u < n3) sacc += t * readlane_f64(xm3, (k + u) & 63);
-                                }
-                            }
-                        }
-                        sacc = swap32_add_f64(swap16_add_f64(sacc));
-                        const double xj = __shfl(xm3, jc, 64);
-                        if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
-                        fetch_l(pj3, jb, 0.5 * sacc, gn);
-                    }
+                    for (int e = 0; e < E; ++e) { gn[e] += gc2_c[e]; gn[e] += gc3_c[e]; }
+                    fsum = fs_c;
                 } else {
                 for (int jb = 0; jb < m.n2; jb += 16) {   // cubic-2: f = sum_j x_j^2 v1_j, v1 = A x; df/dx_j = 2 x_j v1_j + (A^T x^2)_j
                     const int j = jb + jl;
