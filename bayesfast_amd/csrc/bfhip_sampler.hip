@@ -161,6 +161,7 @@ struct SamplerGeo {
 // scaling, no cubic configs, and bit 1 (value 2) = decay penalty on, bit 2 (value 4) = constraint transform on.
 // FS == 1 is the PLAIN instantiation with its register-resident A operands and tail path.
 __device__ inline bool g_sliced_proof_on(const SamplerArgs &a) { return a.no_bound_proof == 0; }
+__device__ inline bool g_no_quad_tiles(const SamplerArgs &a) { return a.no_quad != 0; }
 
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
 __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
@@ -1117,6 +1118,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             constexpr int KPJ = NS / KS;                        // k-steps per job
             constexpr int CH = KPJ < 8 ? KPJ : 8;               // k-steps fetched together
             const int mc = lane & 15, mg = lane >> 4;
+            const bool quad = cpg <= 4 && !g_no_quad_tiles(a);   // (fixed for the launch)
             // (skip_h: S and H are the only matrices and the H jobs, the second half of the list, are left out)
             const int n_job = (only_s || (skip_h && n_mat == 2 && mat0 == 0 && mat1 == 1)) ? W * KS : n_mat * (W * KS);
             if (cub_early) {
@@ -1133,6 +1135,32 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                     const double *Af1 = (b1 == 0 ? Sf : (b1 == 1 ? Hf : Hdf)) + (t1 * NS + kp1 * KPJ) * 64 + lane;
                     const double *Af2 = (b2 == 0 ? Sf : (b2 == 1 ? Hf : Hdf)) + (t2 * NS + kp2 * KPJ) * 64 + lane;
                     const double *Xf1 = XB + (b1 * NS + kp1 * KPJ) * XS + lane, *Xf2 = XB + (b2 * NS + kp2 * KPJ) * XS + lane;
+                    if (quad) {
+                        // at most four chains in the workgroup: v_mfma_f64_4x4x4_4b -- four 4-row blocks of the tile against the
+                        // SAME four columns (A lane 16 k + m as for the 16 x 16 x 4 tile, B lane 16 k + 4 b + n reads column n,
+                        // D lane 16 i + 4 b + n is row 4 b + i of chain n) -- a quarter of the 16-column tile's time in the pipe
+                        const int qo = (lane & ~15) + (lane & 3);
+                        const double *Xq1 = Xf1 - lane + qo, *Xq2 = Xf2 - lane + qo;
+                        double q1 = 0., q2 = 0.;
+#pragma unroll
+                        for (int c0 = 0; c0 < KPJ; c0 += C2) {
+                            double a1[C2], x1[C2], a2[C2], x2[C2];
+#pragma unroll
+                            for (int q3 = 0; q3 < C2; ++q3) {
+                                a1[q3] = Af1[(c0 + q3) * 64]; x1[q3] = Xq1[(c0 + q3) * XS];
+                                a2[q3] = Af2[(c0 + q3) * 64]; x2[q3] = Xq2[(c0 + q3) * XS];
+                            }
+#pragma unroll
+                            for (int q3 = 0; q3 < C2; ++q3) {
+                                q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[q3], x1[q3], q1, 0, 0, 0);
+                                q2 = __builtin_amdgcn_mfma_f64_4x4x4f64(a2[q3], x2[q3], q2, 0, 0, 0);
+                            }
+                        }
+                        const int qr = 4 * ((lane >> 2) & 3) + (lane >> 4), qn = lane & 3;
+                        GB[((sm1 * KS + kp1) * 16 + qn) * GS + 16 * t1 + qr] = q1;
+                        if (two) GB[((sm2 * KS + kp2) * 16 + qn) * GS + 16 * t2 + qr] = q2;
+                        continue;
+                    }
                     d4_t acc1 = {0., 0., 0., 0.}, acc2 = {0., 0., 0., 0.};
 #pragma unroll
                     for (int c0 = 0; c0 < KPJ; c0 += C2) {
@@ -1161,6 +1189,20 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                 const int b = slot_m == 0 ? mat0 : (slot_m == 1 ? mat1 : 2);  // 0 S, 1 H, 2 H_decay
                 const double *Af = (b == 0 ? Sf : (b == 1 ? Hf : Hdf)) + (t * NS + kp * KPJ) * 64 + lane;
                 const double *Xf = XB + (b * NS + kp * KPJ) * XS + lane;
+                if (quad) {   // (see above)
+                    const double *Xq = Xf - lane + (lane & ~15) + (lane & 3);
+                    double q1 = 0.;
+#pragma unroll
+                    for (int c0 = 0; c0 < KPJ; c0 += CH) {
+                        double av[CH], xv[CH];
+#pragma unroll
+                        for (int s = 0; s < CH; ++s) { av[s] = Af[(c0 + s) * 64]; xv[s] = Xq[(c0 + s) * XS]; }
+#pragma unroll
+                        for (int s = 0; s < CH; ++s) q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s], xv[s], q1, 0, 0, 0);
+                    }
+                    GB[((slot_m * KS + kp) * 16 + (lane & 3)) * GS + 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4)] = q1;
+                    continue;
+                }
                 d4_t acc = {0., 0., 0., 0.};
 #pragma unroll
                 for (int c0 = 0; c0 < KPJ; c0 += CH) {
@@ -1594,6 +1636,8 @@ static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
 // it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG / bfhip_debug_wave_cpg override (tests, tuning).
 static int g_no_fuse = [] { const char *e = getenv("BFHIP_NO_FUSE"); return e ? atoi(e) : 0; }();
 extern "C" void bfhip_debug_no_fuse(int v) { g_no_fuse = v; }  // test / tuning hook: the decay kernel's second passes in trips of their own
+static int g_no_quad = [] { const char *e = getenv("BFHIP_NO_QUAD"); return e ? atoi(e) : 0; }();
+extern "C" void bfhip_debug_no_quad_tiles(int v) { g_no_quad = v; }  // test / tuning hook: 16-column tiles whatever the number of chains
 static int g_wave_cpg = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
 extern "C" void bfhip_debug_wave_cpg(int v) { g_wave_cpg = v; }  // test / tuning hook (0: automatic)
 static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
@@ -1711,6 +1755,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.cpg = 0;
     args.cub_lds = 0;
     args.no_fuse = g_no_fuse;
+    args.no_quad = g_no_quad;
     args.cfg = *cfg;
     args.n_chain = n_chain;
     args.iter_end = iter_end;
