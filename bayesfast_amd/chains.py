@@ -176,10 +176,10 @@ class DeviceChains:
         """NUTS on the plain surrogate where the wave-per-chain kernel beats the lane-per-chain layouts although the trees are in
         step: the latter have d / 16 (group) or 2 d / 16 (split) waves per workgroup of 16 chains, so few chains leave most of a
         CU idle, while the wave-per-chain kernel spreads fewer chains per workgroup over more CUs (bfhip_sampler.hip:
-        wave_layout_cpg).  Measured, in-step 7-leaf trees (tools/layout_ab.py, profiles/r03n_layout_ab.log), wave against the
+        wave_layout_cpg).  Measured, in-step 7-leaf trees (tools/layout_ab.py, profiles/r03s_layout_ab.log), wave against the
         best lane-per-chain layout: d = 32 (split, two + two waves): 1024 chains 3.2 against 3.0 x 10^8, 2048 5.5 against 6.0, 4096
-        8.2 against 12.1; d = 16 (split, one + one wave): 1024 2.75 against 2.80, 4096 7.5 against 11.0; d = 64: equal up to 1024
-        chains, the split layout ahead from 2048.  A function of the shapes only (never of timing)."""
+        8.2 against 12.1; d = 16 (split, one + one wave): 1024 2.75 against 2.80, 4096 7.5 against 11.0; d = 64: the split layout
+        ahead from 2048 chains.  A function of the shapes only (never of timing)."""
         if self._n_cu is None:
             self._n_cu = int(_torch().cuda.get_device_properties(self.ctx.device).multi_processor_count)
         sp = self.density.spec
@@ -188,7 +188,10 @@ class DeviceChains:
         if not plain or self.full_metric:   # (measured on the plain surrogate only: the pipelined wave-per-chain kernel)
             return False
         n = self.n_chain if self.n_chain_rule is None else self.n_chain_rule   # (sharded: the ranks' average, equal on all of them)
-        return (self.d <= 16 and n < 4 * self._n_cu) or (16 < self.d <= 32 and n < 6 * self._n_cu)
+        # (32 < d <= 64: with at most four chains per workgroup -- n <= 4 x CUs, wave_layout_cpg -- the pipelined kernel's jobs run
+        # on 4 x 4 x 4 MFMA tiles: 1024 chains 3.7 against the split layout's 2.9 x 10^8, 512 chains 1.9 against 1.5)
+        return ((self.d <= 16 and n < 4 * self._n_cu) or (16 < self.d <= 32 and n < 6 * self._n_cu) or
+                (32 < self.d <= 64 and n <= 4 * self._n_cu))
 
     def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
                      target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,

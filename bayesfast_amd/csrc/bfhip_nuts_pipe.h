@@ -56,8 +56,17 @@ struct PipeGeo {
 // TR: the density lives behind the constraint transform (Density.input_scales / hard_bounds: density.py:92-140,
 // 747-750): the surrogate is evaluated at x(q), its gradient gets the chain-rule factor dx/dq and the log-Jacobian
 // term; same arithmetic as the FS = 5 instantiation of bf_sampler_kernel.
-template <int W, bool TR, bool DEC = false>
+// QUAD: at most four chains in the workgroup (wave_layout_cpg) -- the jobs run on v_mfma_f64_4x4x4_4b, four 4-row blocks of
+// the tile against the same four columns (lane maps: bf_sampler_kernel's run_jobs), a quarter of the 16-column tile's time
+// in the FP64 pipe that the bookkeeping's own FP64 instructions share; the same sequential sum per entry.
+template <bool QUAD> struct PipeAcc { typedef d4_t type; };
+template <> struct PipeAcc<true> { typedef double type; };
+__device__ inline d4_t bf_pipe_mfma(double a_, double b_, d4_t c_) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0); }
+__device__ inline double bf_pipe_mfma(double a_, double b_, double c_) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0); }
+
+template <int W, bool TR, bool DEC = false, bool QUAD = false>
 __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
+    static_assert(!(QUAD && DEC), "the fused second pass keeps the 16-column tiles");
     using G = SamplerGeo<W>;
     using PG = PipeGeo<W, DEC>;
     constexpr int DP = G::DP, NS = G::NS, XS = G::XS, GS = G::GS;
@@ -382,8 +391,8 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         // (Stages that have nothing to do fall through; the MFMAs then simply queue up.  The FP64 VALU work does not
         // overlap with the MFMAs themselves: they share the pipe.)
         const bool job = ev_mask != 0 && w < NJOB_P;
-        d4_t acc = {0., 0., 0., 0.};
-        const double *Xf = XB + ((w / (W * KS_P)) * NS + (w % KS_P) * KPJ_P) * XS + lane;
+        typename PipeAcc<QUAD>::type acc = {};
+        const double *Xf = XB + ((w / (W * KS_P)) * NS + (w % KS_P) * KPJ_P) * XS + (QUAD ? (lane & ~15) + (lane & 3) : lane);
         double x_pre[MPS];
 #pragma unroll
         for (int u = 0; u < MPS; ++u) x_pre[u] = job ? Xf[u * XS] : 0.;
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                     _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_pre[u] = Xf[((((K) + 1) * MPS < KPJ_P ? ((K) + 1) * MPS : 0) + u) * XS]; \
                 _Pragma("unroll") for (int u = 0; u < MPS; ++u) {                                           \
                     asm volatile("" : "+v"(acc) : : "memory");                                              \
-                    if (job) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cur[u], acc, 0, 0, 0); \
+                    if (job) acc = bf_pipe_mfma(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cur[u], acc); \
                     asm volatile("" : "+v"(acc) : : "memory");                                              \
                 }                                                                                           \
             }                                                                                               \
@@ -606,8 +615,12 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         if (job) {
             const int mc = lane & 15, mg = lane >> 4;
             const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
+            if constexpr (QUAD) {
+                GB[((slot_m * KS_P + kp) * 16 + (lane & 3)) * GS + 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4)] = acc;
+            } else {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
+                for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
+            }
         }
         TRACE(5);
         __syncthreads();  // B2

@@ -1671,12 +1671,14 @@ extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 
 template <int W, bool TR = false, bool DEC = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
-    auto k = bf_nuts_pipe_kernel<W, TR, DEC>;
+    SamplerArgs args = args_in;
+    args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
+    // (at most four chains in a workgroup: 4 x 4 x 4 MFMA tiles; the plain instantiation only)
+    constexpr bool CANQ = !TR && !DEC;
+    auto k = (CANQ && args.cpg <= 4 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ> : bf_nuts_pipe_kernel<W, TR, DEC>;
     const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SamplerArgs args = args_in;
-    args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
     const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
     hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());

@@ -2,7 +2,7 @@
 //
 // (The text below describes the W = 4 instantiation, 33 <= d <= 64.  bf_split_body<NUTS_ONLY, W> is the same kernel with W
 // integrator and W bookkeeper waves for d <= 16 W: W = 2 at 17 <= d <= 32, W = 1 below, where every wave has a SIMD of its
-// own -- the group kernel's d / 16 waves left two or three SIMDs of the CU idle there, profiles/r03n_layout_ab.log.)
+// own -- the group kernel's d / 16 waves left two or three SIMDs of the CU idle there, profiles/r03s_layout_ab.log.)
 //
 // The group kernel (bfhip_group.h) runs one wave per SIMD, and a lone wave issues an instruction every 7.7 cycles on
 // average whatever it is (profiles/r03_knockouts.log, r03b_debranch_*.log: a trip's time is its instruction count; the
