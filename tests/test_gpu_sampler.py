@@ -238,7 +238,8 @@ def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, cas
 def test_chains_per_workgroup_never_change_results(ctx, kernel):
     """The wave-per-chain kernels with 16, 4 and 1 chains per workgroup (bfhip_sampler.hip: wave_layout_cpg; the waves without a
     chain only run matvec jobs): samples, statistics, adapted state and random streams are EQUAL, for a chain count that
-    leaves every workgroup size a ragged last group."""
+    leaves every workgroup size a ragged last group.  With at most four chains in a workgroup the gradient tiles run on
+    v_mfma_f64_4x4x4_4b instead of v_mfma_f64_16x16x4_f64: this is also the test that the two give the same bits."""
     from bayesfast_amd.device import DeviceDensity
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
