@@ -234,19 +234,28 @@ def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, cas
         assert {'outside': frac > 0.99, 'mixed': 0.02 < frac < 0.98, 'inside': frac < 0.01}[case], frac
 
 
-@pytest.mark.parametrize('kernel', ['pipe', 'sliced', 'sliced128'])
+@pytest.mark.parametrize('kernel', ['pipe', 'sliced', 'sliced128', 'cubic24', 'cubic128'])
 def test_chains_per_workgroup_never_change_results(ctx, kernel):
     """The wave-per-chain kernels with 16, 4 and 1 chains per workgroup (bfhip_sampler.hip: wave_layout_cpg; the waves without a
     chain only run matvec jobs): samples, statistics, adapted state and random streams are EQUAL, for a chain count that
     leaves every workgroup size a ragged last group.  With at most four chains in a workgroup the gradient tiles run on
-    v_mfma_f64_4x4x4_4b instead of v_mfma_f64_16x16x4_f64: this is also the test that the two give the same bits."""
+    v_mfma_f64_4x4x4_4b instead of v_mfma_f64_16x16x4_f64: this is also the test that the two give the same bits.  The cubic
+    cases: with chain-less waves in the workgroup the chains' waves take the cubic configs beside the matvec jobs (which the
+    chain-less waves run two at a time), with 16 chains per workgroup they take them in phase C: the same numbers."""
     from bayesfast_amd.device import DeviceDensity
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
     from bayesfast_amd import _lib
-    d = 128 if kernel == 'sliced128' else 48
-    dens = DeviceDensity(correlated_gaussian_spec(d)[0], ctx)
-    x0 = np.random.default_rng(5).normal(size=(37, d))
+    if kernel.startswith('cubic'):
+        d = int(kernel[5:])
+        rng = np.random.default_rng(21)
+        spec = _cubic_spec(d=d, seed=5, m2=np.sort(rng.choice(d, 20, replace=False)), m3=np.sort(rng.choice(d, 16, replace=False)),
+                           amp=0.15 if d == 24 else 0.05)
+    else:
+        d = 128 if kernel == 'sliced128' else 48
+        spec = correlated_gaussian_spec(d)[0]
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(5).normal(size=(37, d)) * (0.5 if kernel.startswith('cubic') else 1.)
     out = {}
     L = _lib.lib()
     try:
