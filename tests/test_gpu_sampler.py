@@ -234,7 +234,7 @@ def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, cas
         assert {'outside': frac > 0.99, 'mixed': 0.02 < frac < 0.98, 'inside': frac < 0.01}[case], frac
 
 
-@pytest.mark.parametrize('kernel', ['pipe', 'sliced', 'sliced128', 'cubic24', 'cubic128'])
+@pytest.mark.parametrize('kernel', ['pipe', 'pipe20', 'pipe10', 'sliced', 'sliced128', 'cubic24', 'cubic128'])
 def test_chains_per_workgroup_never_change_results(ctx, kernel):
     """The wave-per-chain kernels with 16, 4 and 1 chains per workgroup (bfhip_sampler.hip: wave_layout_cpg; the waves without a
     chain only run matvec jobs): samples, statistics, adapted state and random streams are EQUAL, for a chain count that
@@ -252,7 +252,7 @@ def test_chains_per_workgroup_never_change_results(ctx, kernel):
         spec = _cubic_spec(d=d, seed=5, m2=np.sort(rng.choice(d, 20, replace=False)), m3=np.sort(rng.choice(d, 16, replace=False)),
                            amp=0.15 if d == 24 else 0.05)
     else:
-        d = 128 if kernel == 'sliced128' else 48
+        d = 128 if kernel == 'sliced128' else (int(kernel[4:]) if kernel[4:] else 48) if kernel.startswith('pipe') else 48
         spec = correlated_gaussian_spec(d)[0]
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(5).normal(size=(37, d)) * (0.5 if kernel.startswith('cubic') else 1.)
@@ -260,7 +260,7 @@ def test_chains_per_workgroup_never_change_results(ctx, kernel):
     L = _lib.lib()
     try:
         L.bfhip_debug_no_group(1)
-        L.bfhip_debug_no_pipe(0 if kernel == 'pipe' else 1)
+        L.bfhip_debug_no_pipe(0 if kernel.startswith('pipe') else 1)
         for cpg in (16, 4, 1):
             L.bfhip_debug_wave_cpg(cpg)
             dc = DeviceChains(dens, x0, seed=4)
