@@ -59,12 +59,14 @@ struct PipeGeo {
 // QUAD: at most four chains in the workgroup (wave_layout_cpg) -- the jobs run on v_mfma_f64_4x4x4_4b, four 4-row blocks of
 // the tile against the same four columns (lane maps: bf_sampler_kernel's run_jobs), a quarter of the 16-column tile's time
 // in the FP64 pipe that the bookkeeping's own FP64 instructions share; the same sequential sum per entry.
-template <bool QUAD> struct PipeAcc { typedef d4_t type; };
-template <> struct PipeAcc<true> { typedef double type; };
+// (QUAD = 2: at most eight chains -- two such instructions per k-step, columns 0-3 and 4-7: 35 against 64 cycles of the pipe)
+template <int QUAD> struct PipeAcc { typedef d4_t type; };
+template <> struct PipeAcc<1> { typedef double type; };
+template <> struct PipeAcc<2> { typedef d2_t type; };
 __device__ inline d4_t bf_pipe_mfma(double a_, double b_, d4_t c_) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0); }
 __device__ inline double bf_pipe_mfma(double a_, double b_, double c_) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0); }
 
-template <int W, bool TR, bool DEC = false, bool QUAD = false>
+template <int W, bool TR, bool DEC = false, int QUAD = 0>
 __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
     static_assert(!(QUAD && DEC), "the fused second pass keeps the 16-column tiles");
     using G = SamplerGeo<W>;
@@ -393,19 +395,33 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         const bool job = ev_mask != 0 && w < NJOB_P;
         typename PipeAcc<QUAD>::type acc = {};
         const double *Xf = XB + ((w / (W * KS_P)) * NS + (w % KS_P) * KPJ_P) * XS + (QUAD ? (lane & ~15) + (lane & 3) : lane);
-        double x_pre[MPS];
+        double x_pre[MPS], x_pr2[QUAD == 2 ? MPS : 1];
 #pragma unroll
         for (int u = 0; u < MPS; ++u) x_pre[u] = job ? Xf[u * XS] : 0.;
+        if constexpr (QUAD == 2) {
+#pragma unroll
+            for (int u = 0; u < MPS; ++u) x_pr2[u] = job ? Xf[u * XS + 4] : 0.;
+        }
 #define BF_MF(K)                                                                                            \
         do {                                                                                                \
             if ((K) * MPS < KPJ_P) {                                                                        \
-                double x_cur[MPS];                                                                          \
+                double x_cur[MPS], x_cu2[QUAD == 2 ? MPS : 1];                                             \
                 _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_cur[u] = x_pre[u];                        \
-                if (((K) + 1) * MPS < KPJ_P && job)                                                         \
+                if constexpr (QUAD == 2) { _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_cu2[u] = x_pr2[u]; } \
+                if (((K) + 1) * MPS < KPJ_P && job) {                                                       \
                     _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_pre[u] = Xf[((((K) + 1) * MPS < KPJ_P ? ((K) + 1) * MPS : 0) + u) * XS]; \
+                    if constexpr (QUAD == 2) { _Pragma("unroll") for (int u = 0; u < MPS; ++u) x_pr2[u] = Xf[((((K) + 1) * MPS < KPJ_P ? ((K) + 1) * MPS : 0) + u) * XS + 4]; } \
+                }                                                                                           \
                 _Pragma("unroll") for (int u = 0; u < MPS; ++u) {                                           \
                     asm volatile("" : "+v"(acc) : : "memory");                                              \
-                    if (job) acc = bf_pipe_mfma(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cur[u], acc); \
+                    if constexpr (QUAD == 2) {                                                              \
+                        if (job) {                                                                          \
+                            acc[0] = bf_pipe_mfma(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cur[u], acc[0]); \
+                            acc[1] = bf_pipe_mfma(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cu2[u], acc[1]); \
+                        }                                                                                   \
+                    } else {                                                                                \
+                        if (job) acc = bf_pipe_mfma(afr[((K) * MPS < KPJ_P ? (K) * MPS : 0) + u], x_cur[u], acc); \
+                    }                                                                                       \
                     asm volatile("" : "+v"(acc) : : "memory");                                              \
                 }                                                                                           \
             }                                                                                               \
@@ -615,8 +631,11 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         if (job) {
             const int mc = lane & 15, mg = lane >> 4;
             const int slot_m = w / (W * KS_P), rem = w % (W * KS_P), t = rem / KS_P, kp = rem % KS_P;
-            if constexpr (QUAD) {
+            if constexpr (QUAD == 1) {
                 GB[((slot_m * KS_P + kp) * 16 + (lane & 3)) * GS + 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4)] = acc;
+            } else if constexpr (QUAD == 2) {
+                GB[((slot_m * KS_P + kp) * 16 + (lane & 3)) * GS + 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4)] = acc[0];
+                GB[((slot_m * KS_P + kp) * 16 + 4 + (lane & 3)) * GS + 16 * t + 4 * ((lane >> 2) & 3) + (lane >> 4)] = acc[1];
             } else {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];

@@ -261,7 +261,7 @@ def test_chains_per_workgroup_never_change_results(ctx, kernel):
     try:
         L.bfhip_debug_no_group(1)
         L.bfhip_debug_no_pipe(0 if kernel.startswith('pipe') else 1)
-        for cpg in (16, 4, 1):
+        for cpg in (16, 8, 4, 1):   # (8: the pipelined kernel takes two 4 x 4 x 4 instructions per k-step)
             L.bfhip_debug_wave_cpg(cpg)
             dc = DeviceChains(dens, x0, seed=4)
             s1, st1 = dc.run(24, 'NUTS', n_warmup=16, layout='wave')
@@ -271,7 +271,7 @@ def test_chains_per_workgroup_never_change_results(ctx, kernel):
         L.bfhip_debug_wave_cpg(0)
         L.bfhip_debug_no_pipe(0)
         L.bfhip_debug_no_group(0)
-    for cpg in (4, 1):
+    for cpg in (8, 4, 1):
         for a, b in zip(out[16][:-1], out[cpg][:-1]):
             assert np.array_equal(a, b, equal_nan=True), cpg
         assert out[16][-1] == out[cpg][-1]
