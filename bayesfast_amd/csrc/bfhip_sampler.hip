@@ -1023,8 +1023,10 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         }
         return fsum;
     };
-    // (not in the full-rank instantiation: it has no register to spare -- with these paths compiled in it spilled 135 VGPRs)
-    const bool cub_early = !FULLM && cub_l && 2 * cpg <= NWV;   // (fixed for the launch, the same in every wave)
+    // (d = 128 only, where they were measured: the 128-register instantiations of d <= 64 and the full-rank one have no
+    // register to spare -- with these paths compiled in they spilled 25 % more VGPRs, the full-rank one 135 instead of 90)
+    constexpr bool XT = W == 8 && !FULLM;
+    const bool cub_early = XT && cub_l && 2 * cpg <= NWV;   // (fixed for the launch, the same in every wave)
     for (int trip = 0;; ++trip) {
         trip_no = trip;
         TRACE(0);
@@ -1119,7 +1121,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             constexpr int KPJ = NS / KS;                        // k-steps per job
             constexpr int CH = KPJ < 8 ? KPJ : 8;               // k-steps fetched together
             const int mc = lane & 15, mg = lane >> 4;
-            const bool quad = !FULLM && cpg <= 4 && !g_no_quad_tiles(a);   // (fixed for the launch)
+            const bool quad = XT && cpg <= 4 && !g_no_quad_tiles(a);   // (fixed for the launch)
             // (skip_h: S and H are the only matrices and the H jobs, the second half of the list, are left out)
             const int n_job = (only_s || (skip_h && n_mat == 2 && mat0 == 0 && mat1 == 1)) ? W * KS : n_mat * (W * KS);
             if (cub_early) {
