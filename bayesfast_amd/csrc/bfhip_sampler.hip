@@ -1676,8 +1676,8 @@ template <int W, bool TR = false, bool DEC = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
-    // (at most four chains in a workgroup: 4 x 4 x 4 MFMA tiles; the plain instantiation only)
-    constexpr bool CANQ = !TR && !DEC;
+    // (at most four / eight chains in a workgroup: 4 x 4 x 4 MFMA tiles; not with the decay term's fused second pass)
+    constexpr bool CANQ = !DEC;
     auto k = (CANQ && args.cpg <= 4 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
              : ((CANQ && args.cpg <= 8 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
     const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);

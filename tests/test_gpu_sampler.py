@@ -234,7 +234,7 @@ def test_fused_second_pass_of_the_decay_kernel_equals_the_separate_pass(ctx, cas
         assert {'outside': frac > 0.99, 'mixed': 0.02 < frac < 0.98, 'inside': frac < 0.01}[case], frac
 
 
-@pytest.mark.parametrize('kernel', ['pipe', 'pipe20', 'pipe10', 'sliced', 'sliced128', 'cubic24', 'cubic128'])
+@pytest.mark.parametrize('kernel', ['pipe', 'pipe20', 'pipe10', 'pipebounded', 'sliced', 'sliced128', 'cubic24', 'cubic128'])
 def test_chains_per_workgroup_never_change_results(ctx, kernel):
     """The wave-per-chain kernels with 16, 4 and 1 chains per workgroup (bfhip_sampler.hip: wave_layout_cpg; the waves without a
     chain only run matvec jobs): samples, statistics, adapted state and random streams are EQUAL, for a chain count that
@@ -252,10 +252,13 @@ def test_chains_per_workgroup_never_change_results(ctx, kernel):
         spec = _cubic_spec(d=d, seed=5, m2=np.sort(rng.choice(d, 20, replace=False)), m3=np.sort(rng.choice(d, 16, replace=False)),
                            amp=0.15 if d == 24 else 0.05)
     else:
-        d = 128 if kernel == 'sliced128' else (int(kernel[4:]) if kernel[4:] else 48) if kernel.startswith('pipe') else 48
+        d = 128 if kernel == 'sliced128' else (int(kernel[4:]) if kernel[4:].isdigit() else 48) if kernel.startswith('pipe') else 48
         spec = correlated_gaussian_spec(d)[0]
+        if kernel == 'pipebounded':   # behind the constraint transform (bf_nuts_pipe_kernel<W, true>): all four kinds of bounds
+            lo = np.full(d, -9.) + np.arange(d) * 0.01
+            spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * (d // 4), dtype=np.uint8))
     dens = DeviceDensity(spec, ctx)
-    x0 = np.random.default_rng(5).normal(size=(37, d)) * (0.5 if kernel.startswith('cubic') else 1.)
+    x0 = np.random.default_rng(5).normal(size=(37, d)) * (0.5 if kernel.startswith('cubic') else (0.3 if kernel == 'pipebounded' else 1.))
     out = {}
     L = _lib.lib()
     try:
