@@ -12,6 +12,8 @@ __all__ = ['DeviceChains']
 # integrator and bookkeeper waves; NUTS on the plain surrogate at 33 <= d <= 64 -- the library runs everything else as 'group')
 # or 'group'.  Same results either way, bit for bit; 'split' is 3 % (7-leaf trees) to 13 % (15-leaf trees) faster
 IN_STEP_LAYOUT = __import__('os').environ.get('BFHIP_IN_STEP_LAYOUT', 'split')
+if IN_STEP_LAYOUT not in ('group', 'split'):
+    raise ValueError("BFHIP_IN_STEP_LAYOUT should be 'group' or 'split', not {!r}.".format(IN_STEP_LAYOUT))
 
 
 def _torch():
@@ -117,9 +119,13 @@ class DeviceChains:
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
         cfg.full_metric = int(self.full_metric)
         cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
-        layout = __import__('os').environ.get('BFHIP_FORCE_LAYOUT') or layout   # (tuning: one layout for every launch)
         if layout not in ('auto', 'group', 'wave', 'split'):
             raise ValueError("layout should be 'auto', 'group', 'split' or 'wave'.")
+        if layout == 'auto':   # (tuning: one layout for every launch the dispatch would have chosen; an explicit layout wins)
+            layout = __import__('os').environ.get('BFHIP_FORCE_LAYOUT') or layout
+            if layout not in ('auto', 'group', 'wave', 'split'):
+                raise ValueError("BFHIP_FORCE_LAYOUT should be 'group', 'split' or 'wave'.")
+        judged = layout == 'auto'
         n_run = int(n_run)
         if samples is None:
             samples = self.ctx.empty((self.n_chain, n_run, self.d))
@@ -159,7 +165,10 @@ class DeviceChains:
             _lib.check(self.ctx._lib.bfhip_sampler_run(
                 self.ctx.handle, C.byref(cfg), self.n_chain, self.i_iter + min(done, n_run), _ptr(self.rng), _ptr(self.sc),
                 _ptr(self.vec), self.i_iter, n_run, _ptr(samples), _ptr(stats), _ptr(self.n_leapfrog)))
-            if layout == 'auto':
+            if not judged:
+                self._answers = getattr(self, '_answers', []) + [None]   # (a launch that was not judged: no stale answer later)
+                del self._answers[:-4]
+            if judged:
                 # a launch that ends the warm-up is judged more leniently: its last iterations still adapt the step size
                 # (a few trees of another size), the launch after it runs with the frozen, averaged one
                 i0, i1 = self.i_iter + done - step, self.i_iter + min(done, n_run)
@@ -260,7 +269,9 @@ class DeviceChains:
         r0 = max(row0, row1 - n_last)
         if self.hist_reduce is not None:
             with torch.cuda.stream(self.ctx.stream):
-                ts = stats[:, r0:row1, _lib.NSTATS.index('tree_size')].reshape(-1).clamp(0., 4095.).to(torch.int64)
+                ts = stats[:, r0:row1, _lib.NSTATS.index('tree_size')].reshape(-1)
+                # (binned as bf_tree_mode_kernel bins them: negative and NaN sizes go to bucket 4095)
+                ts = torch.where((ts >= 0.) & (ts < 4095.), ts, torch.full_like(ts, 4095.)).to(torch.int64)
                 hist = torch.zeros(4096, dtype=torch.int64, device=self.ctx.device)
                 hist.scatter_add_(0, ts, torch.ones_like(ts))
             self.ctx.stream.synchronize()

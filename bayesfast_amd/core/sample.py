@@ -21,7 +21,7 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     n_run : number of iterations to run now (default: up to ``n_iter``)
     parallel_backend : accepted for signature compatibility and ignored; chains shard over the ranks of the
         default ``torch.distributed`` process group instead (one process per GPU)
-    layout : 'auto' | 'group' | 'wave', the chain layout of the kernel (``DeviceChains.run``).  'auto' switches per launch
+    layout : 'auto' | 'group' | 'split' | 'wave', the chain layout of the kernel (``DeviceChains.run``).  'auto' switches per launch
         by how uniform the trees of ALL ranks' chains were in the launches before (a pure function of the launch sequence,
         the same on every rank); results are bit-reproducible for a fixed layout and agree to rounding between them
     gather : also materialise the host arrays of all chains before returning (``TraceTuple.gather()``)

@@ -577,7 +577,10 @@ __global__ __launch_bounds__(256) void bf_trsv_flow_kernel(int P, int m, int q0,
         } else {
             for (int i = 0; i <= c; ++i) s += Li[c][i] * vk[q][i];  // y = L_bb^-1 r
         }
-        bf_st_agent(xch + (size_t)b * (TRSV_MQ_ * NB_) + t, s);  // (rows beyond P: zeros, the padding of the inverse is the identity)
+        // (rows beyond P: zeros, the padding of the inverse is the identity.  A NaN that reaches here -- from the inputs or
+        // from the blocks of a failed factorisation -- is published as the canonical quiet NaN: a payload can never be the
+        // "not yet" marker, so a reader's spin always ends)
+        bf_st_agent(xch + (size_t)b * (TRSV_MQ_ * NB_) + t, (s != s) ? __longlong_as_double(0x7FF8000000000000ll) : s);
         if (b0 + c < P) r[(size_t)(b0 + c) * m + q0 + q] = s;
     }
     if (t == 0) {

@@ -184,6 +184,12 @@ def reference_classes(bayesfast=None):
             inner.gather()  # (host arrays of all chains; a plain copy without a process group)
             adapted = inner._adapted_state()
             t = copy.copy(self._template)
+            # (a template that already carries adaptation / metric INSTANCES: _set_*_2 leave them alone, so each chain
+            # gets its own copy -- otherwise every chain's adapted state would land in the caller's one object)
+            if isinstance(getattr(t, '_step_size', None), DualAverageAdaptation):
+                t._step_size = copy.copy(t._step_size)
+            if hasattr(getattr(t, '_metric', None), 'velocity'):
+                t._metric = copy.copy(t._metric)
             t._chain_id = i
             t._x_0 = np.array(adapted['x_0'][i])
             t._x_0_transformed = True
@@ -197,14 +203,14 @@ def reference_classes(bayesfast=None):
                 ss._hbar = float(adapted['hbar'][i])
                 ss._count = int(adapted['count'][i])
             m = t._metric
-            if hasattr(m, '_cov'):
+            if hasattr(m, '_cov'):   # QuadMetricFull(Adapt), samplers/hmc_utils/metrics.py:103-111
+                import scipy.linalg
                 m._cov = np.array(adapted['cov'][i])
-                if hasattr(m, '_chol'):
-                    m._chol = np.linalg.cholesky(m._cov)
-            elif hasattr(m, '_var'):
+                m._chol = scipy.linalg.cholesky(m._cov, lower=True)
+            elif hasattr(m, '_var'):   # QuadMetricDiag(Adapt), :60-71: random() reads _inv_std, velocity() reads _var
                 m._var = np.array(adapted['var'][i])
-                if hasattr(m, '_stds'):
-                    m._stds = np.sqrt(m._var)
+                m._std = m._var**0.5
+                m._inv_std = 1. / m._std
             t._samples = inner._samples[i]
             t._samples_original = inner._samples_original[i]
             t._logp_original = inner._logp_original[i]
@@ -270,12 +276,40 @@ def _our_trace(ns, ref_trace, sampler):
     """The reference's trace object -> this package's option object of the same meaning (fields read by duck typing:
     samplers/sample_trace.py:159-172,460-512)."""
     st = ns._our_st
+    bf = ns.bayesfast
+    from bayesfast.samplers.hmc_utils.step_size import DualAverageAdaptation
+    mt = bf.samplers.hmc_utils.metrics
     kw = dict(n_chain=ref_trace._n_chain, n_iter=ref_trace._n_iter, n_warmup=ref_trace._n_warmup, x_0=ref_trace._x_0,
-              step_size=ref_trace._step_size, adapt_step_size=ref_trace._adapt_step_size, metric=ref_trace._metric,
-              adapt_metric=ref_trace._adapt_metric, max_change=ref_trace._max_change, target_accept=ref_trace._target_accept,
-              gamma=ref_trace._gamma, k=ref_trace._k, t_0=ref_trace._t_0, initial_mean=ref_trace._initial_mean,
-              initial_weight=ref_trace._initial_weight, adapt_window=ref_trace._adapt_window,
-              update_window=ref_trace._update_window, doubling=ref_trace._doubling)
+              max_change=ref_trace._max_change)
+    # step size: a number with the adaptation options, or a DualAverageAdaptation INSTANCE (then the option fields do not
+    # exist on the trace, samplers/sample_trace.py:318-322); a fresh instance is read back into the same options
+    ss = ref_trace._step_size
+    if isinstance(ss, DualAverageAdaptation):
+        if ss._count != 1 or ss._hbar != 0. or ss._log_bar != ss._log_step:
+            raise NotImplementedError('a DualAverageAdaptation that has already adapted cannot seed the device chains; '
+                                      'continue from the TraceTuple of the device sampler instead.')
+        d = np.asarray(ref_trace._x_0).shape[-1] if ref_trace._x_0 is not None else ref_trace.input_size
+        kw.update(step_size=float(np.exp(ss._log_step)) * d**0.25, adapt_step_size=bool(ss._adapt), target_accept=float(ss._target),
+                  gamma=float(ss._gamma), k=float(ss._k), t_0=float(ss._t_0))
+    else:
+        kw.update(step_size=ss, adapt_step_size=ref_trace._adapt_step_size, target_accept=ref_trace._target_accept,
+                  gamma=ref_trace._gamma, k=ref_trace._k, t_0=ref_trace._t_0)
+    # metric: 'diag' / 'full' / an array with the adaptation options, or a QuadMetric INSTANCE (samplers/sample_trace.py:377-379)
+    m = ref_trace._metric
+    if isinstance(m, mt.QuadMetric):
+        adapting = isinstance(m, (mt.QuadMetricDiagAdapt, mt.QuadMetricFullAdapt))
+        if adapting and (m._n_samples != 0 or m._previous_update != 0):
+            raise NotImplementedError('a metric that has already adapted cannot seed the device chains; continue from the '
+                                      'TraceTuple of the device sampler instead.')
+        kw.update(metric=np.array(m._cov if hasattr(m, '_cov') else m._var), adapt_metric=adapting)
+        if adapting:
+            fg = m._foreground_cov if hasattr(m, '_foreground_cov') else m._foreground_var
+            kw.update(initial_mean=np.array(fg.mean), initial_weight=float(fg.n_samples), adapt_window=int(m._adapt_window),
+                      update_window=int(m._update_window), doubling=bool(m._doubling))
+    else:
+        kw.update(metric=m, adapt_metric=ref_trace._adapt_metric, initial_mean=ref_trace._initial_mean,
+                  initial_weight=ref_trace._initial_weight, adapt_window=ref_trace._adapt_window,
+                  update_window=ref_trace._update_window, doubling=ref_trace._doubling)
     # one integer from the trace's generator seeds the per-chain xoshiro streams (the reference spawns one PCG64 per chain
     # from the same generator, samplers/sample_trace.py:192-193)
     kw['random_generator'] = int(ref_trace.random_generator.integers(0, 2**63 - 1))

@@ -31,48 +31,63 @@ sys.path.insert(0, ROOT)
 N_ADAPT = 750  # NUTS adaptation iterations before anything is timed (GPU path and CPU baseline alike)
 
 
-def cpu_baseline(spec, d, n_warm_iter, seed, target_seconds=15.):
-    """Leapfrog steps/sec of the CPU port on all host cores, post-warm-up, on a bounded sample.  The NUTS driver is the
-    oracle's; the density evaluation is its tuned form (oracle/bf_cpu_tuned.c: one symmetrised dense matvec pair per
-    gradient, AVX2 + FMA, no allocation -- ~18x the statement-by-statement checker), i.e. the stronger baseline."""
+def _host():
+    from bayesfast_amd.utils.hostinfo import host_cpu_facts
+    h = host_cpu_facts()
+    h.pop('one_cpu_per_core', None)
+    return h
+
+
+def _timed_slices(cs, n_warm_iter, n_thr, target_seconds, first_slice=50):
+    """Leapfrogs and seconds of post-warm-up slices of the chain set, each slice long enough (>= ~1 s) for the parallel
+    region's start-up and the output arrays' page faults not to count."""
+    nl, dt, n_it, it = 0, 0., 0, first_slice
+    while dt < target_seconds:
+        t0 = time.perf_counter()
+        _, _, k = cs.run(it, n_warm_iter, n_threads=n_thr)
+        t1 = time.perf_counter() - t0
+        dt += t1
+        nl += k
+        n_it += it
+        if t1 < 1.:
+            it = min(2 * it, 4000)
+    return nl, dt, n_it
+
+
+def _cpu_baseline_here(spec, d, n_warm_iter, seed, target_seconds=12.):
+    """Leapfrog steps/sec of the CPU port on the host cores THIS PROCESS MAY USE, post-warm-up, on a bounded sample.  The NUTS
+    driver is the oracle's; the density evaluation is its tuned form (oracle/bf_cpu_tuned.c: one symmetrised dense matvec pair
+    per gradient, AVX2 + FMA, no allocation -- ~18x the statement-by-statement checker), i.e. the stronger baseline.
+
+    /proc/cpuinfo lists every CPU of the machine; the affinity mask and the cgroup's cpu.max say what the process gets (the
+    round-3 line ran 128 threads inside a 16-CPU quota: 34 k steps/s/thread instead of 850 k).  `threads` = min(CPUs in the
+    affinity mask, cgroup quota), one chain per thread, threads bound to cores (OMP_PROC_BIND=close, OMP_PLACES=cores); the
+    1-thread rate of the same code is measured beside it so that the per-thread efficiency is on the line."""
     from oracle import oracle as orc  # the checker, timed as a baseline only
-    n_thr = orc.max_threads()
+    host = _host()
+    n_thr = max(1, min(host['usable_threads'], orc.max_threads()))
+    # one thread, four chains
+    x1 = np.random.default_rng(seed).normal(size=(4, d))
+    c1 = orc.ChainSet(spec, x1, seed, tuned=True)
+    c1.run(n_warm_iter, n_warm_iter, n_threads=1)
+    nl1, dt1, _ = _timed_slices(c1, n_warm_iter, 1, min(3., target_seconds / 4))
+    c1.close()
     n_chain = 4 * n_thr
     x0 = np.random.default_rng(seed).normal(size=(n_chain, d))
     cs = orc.ChainSet(spec, x0, seed, tuned=True)
     cs.run(n_warm_iter, n_warm_iter, n_threads=n_thr)  # untimed adaptation, same as the GPU path
-    nl, dt, n_it = 0, 0., 0
-    while dt < target_seconds:  # bounded sample, in slices so the recorded draws stay small
-        t0 = time.perf_counter()
-        _, _, k = cs.run(250, n_warm_iter, n_threads=n_thr)
-        dt += time.perf_counter() - t0
-        nl += k
-        n_it += 250
+    nl, dt, n_it = _timed_slices(cs, n_warm_iter, n_thr, target_seconds)
     tuned = cs.tuned
     cs.close()
-    try:
-        model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
-    except Exception:
-        model = 'unknown'
-    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': physical_cores(n_thr), 'threads': n_thr, 'kind': 'port',
-            'sample': '%d chains x %d post-warm-up NUTS iterations (%d leapfrogs in %.1f s) of the same 64-d workload, '
-                      'one chain per OpenMP thread, %s density evaluation, %s' % (
-                          n_chain, n_it, nl, dt, 'tuned (dense symmetric matvec, AVX2+FMA)' if tuned else 'statement-by-statement', model)}
-
-
-def physical_cores(default):
-    """Physical cores of the host (distinct (package, core id) pairs of /proc/cpuinfo); the baseline runs one chain per
-    hardware THREAD, which is reported separately."""
-    try:
-        seen, pkg = set(), None
-        for l in open('/proc/cpuinfo'):
-            if l.startswith('physical id'):
-                pkg = l.split(':')[1].strip()
-            elif l.startswith('core id'):
-                seen.add((pkg, l.split(':')[1].strip()))
-        return len(seen) or default
-    except Exception:
-        return default
+    one = nl1 / dt1
+    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': host['usable_cores'], 'threads': n_thr, 'kind': 'port',
+            'one_thread_value': one, 'per_thread_efficiency': (nl / dt) / (n_thr * one), 'host': host,
+            'omp': {k: os.environ.get(k) for k in ('OMP_PROC_BIND', 'OMP_PLACES', 'OMP_NUM_THREADS')},
+            'sample': '%d chains x %d post-warm-up NUTS iterations (%d leapfrogs in %.1f s) of the same %d-d workload, '
+                      'one chain per OpenMP thread on the %d CPUs the process may use (affinity %d, cgroup quota %s), %s density '
+                      'evaluation, %s' % (n_chain, n_it, nl, dt, d, n_thr, host['affinity_cpus'], host['cgroup_cpu_quota'],
+                                          'tuned (dense symmetric matvec, AVX2+FMA)' if tuned else 'statement-by-statement',
+                                          host['model'])}
 
 
 def hetero_rate(ctx, d, C, seed, iters, steps=3, layout='auto'):
@@ -232,12 +247,13 @@ def fit_timing(d, cov, seed=7):
             'note': 'host arrays in, coefficients out: upload, design blocks, split-K MFMA Gram, blocked Cholesky solve, bound statistics'}
 
 
-def _cpu_rate(spec, x_start, step_size, var, seed, target_accept, target_seconds):
+def _cpu_rate_here(spec, x_start, step_size, var, seed, target_accept, target_seconds):
     """The CPU port on the same density: the oracle's NUTS driver, one chain per OpenMP thread, bounded.  The chains start
     where the device chains are after their adaptation, with the device's adapted step size and diagonal metric (means over
     the chains) held fixed -- the CPU pays for sampling, not for a second adaptation (minutes on the deep-tree configs)."""
     from oracle import oracle as orc
-    n_thr = orc.max_threads()
+    host = _host()
+    n_thr = max(1, min(host['usable_threads'], orc.max_threads()))   # (what the process may use: cpu_baseline)
     n_chain = min(n_thr, x_start.shape[0])
     cs = orc.ChainSet(spec, x_start[:n_chain], seed, step_size=step_size, metric=var, adapt_step_size=False, adapt_metric=False,
                       target_accept=target_accept)
@@ -252,10 +268,57 @@ def _cpu_rate(spec, x_start, step_size, var, seed, target_accept, target_seconds
         n_it += slice_it
         if t1 < 0.3:
             slice_it = min(4 * slice_it, 200)
-    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': physical_cores(n_thr), 'threads': n_thr, 'kind': 'port',
+    return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': host['usable_cores'], 'threads': n_thr, 'kind': 'port',
+            'omp': {k: os.environ.get(k) for k in ('OMP_PROC_BIND', 'OMP_PLACES', 'OMP_NUM_THREADS')},
             'sample': '%d chains x %d NUTS iterations (%d leapfrogs in %.1f s) of the same density from the device chains\' '
                       'post-adaptation positions, with their adapted step size and diagonal metric (chain means) held fixed; one '
                       'chain per OpenMP thread' % (n_chain, n_it, nl, dt)}
+
+
+def _cpu_child(job):
+    """The CPU baseline runs in a CHILD process that never touches the GPU: libgomp reads its thread placement when it loads,
+    so OMP_PROC_BIND=close / OMP_PLACES=cores / OMP_NUM_THREADS are set for the child only and the benchmark's own process
+    (HIP runtime threads, launch path) keeps the scheduler's placement.  The job travels as a pickle, the answer as one JSON
+    line."""
+    import pickle
+    import subprocess
+    import tempfile
+    host = _host()
+    env = dict(os.environ)
+    env.setdefault('OMP_PROC_BIND', 'close')
+    env.setdefault('OMP_PLACES', 'cores')
+    env.setdefault('OMP_NUM_THREADS', str(host['usable_threads']))
+    with tempfile.NamedTemporaryFile(suffix='.pkl', delete=False) as f:
+        pickle.dump(job, f)
+        path = f.name
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', path], env=env, capture_output=True, text=True)
+    finally:
+        os.unlink(path)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'error': 'cpu baseline child failed (rc %d): %s' % (r.returncode, r.stderr[-400:])}
+    return json.loads(lines[-1])
+
+
+def cpu_baseline(spec, d, n_warm_iter, seed, target_seconds=12.):
+    return _cpu_child(dict(kind='headline', spec=spec, d=d, n_warm_iter=n_warm_iter, seed=seed, target_seconds=target_seconds))
+
+
+def _cpu_rate(spec, x_start, step_size, var, seed, target_accept, target_seconds):
+    return _cpu_child(dict(kind='config', spec=spec, x_start=x_start, step_size=step_size, var=var, seed=seed,
+                           target_accept=target_accept, target_seconds=target_seconds))
+
+
+def _cpu_child_main(path):
+    import pickle
+    with open(path, 'rb') as f:
+        job = pickle.load(f)
+    if job.pop('kind') == 'headline':
+        out = _cpu_baseline_here(**job)
+    else:
+        out = _cpu_rate_here(**job)
+    print(json.dumps(out))
 
 
 def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu_seconds, what, first_stream=0):
@@ -336,8 +399,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
     t_fit = {}
     # launch lengths that keep a block within seconds: the banana's refitted surrogate and config 5 run every tree to the
     # depth limit (1023 leapfrogs per iteration)
-    iters = iters or {'banana_decay': 50, 'funnel': 100, 'cubic128': 20}[name]
-    n_adapt = n_adapt or {'banana_decay': 200, 'funnel': 300, 'cubic128': 150}[name]
+    iters = iters or {'gauss32': 250, 'banana_decay': 50, 'funnel': 100, 'cubic128': 20}[name]
+    n_adapt = n_adapt or {'gauss32': 500, 'banana_decay': 200, 'funnel': 300, 'cubic128': 150}[name]
 
     def fit(den, x, lp, key):
         torch.cuda.synchronize()
@@ -346,6 +409,22 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         torch.cuda.synchronize()
         t_fit[key] = (time.perf_counter() - t0) * 1e3
 
+    if name == 'gauss32':
+        from bayesfast_amd.workloads import correlated_gaussian_spec, sobol_normal
+        d, C = 32, chains or 1024
+        _, cov = correlated_gaussian_spec(d)       # (its precision matrix is SURVEY 8d's P = L L^T, seed 123)
+        prec = np.linalg.inv(cov)
+        logp = lambda x: -0.5 * np.sum((x @ prec) * x, axis=1)
+        su = bfa.PolyModel('quadratic', input_size=d, output_size=1)
+        den = bfa.SurrogateDensity(su)
+        x_fit = 1.5 * sobol_normal(2 * su.n_param, d, seed=seed)   # (broader than the posterior: DESIGN.md section 5)
+        fit(den, x_fit, logp(x_fit), 'fit_ms')
+        x0 = sobol_normal(C, d, seed=seed + 1)
+        what = ('config 2: %d chains x 32-d correlated Gaussian (P = L L^T, SURVEY 8d), quadratic PolyModel P = %d fitted on 2 P '
+                'Sobol-normal points, bound on; NUTS defaults' % (C, su.n_param))
+        r, s_, _ = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what)
+        var_ratio = float(np.mean(s_.reshape(-1, d).var(0).cpu().numpy() / np.diag(cov)))
+        return dict(r, posterior_variance_ratio=var_ratio, **t_fit)
     if name == 'banana_decay':
         d, C = 64, chains or 4096
         logp = banana_logp(d)
@@ -398,10 +477,31 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
     raise ValueError(name)
 
 
-CONFIG_BLOCKS = ('banana_decay', 'funnel', 'cubic128')
+CONFIG_BLOCKS = ('gauss32', 'banana_decay', 'funnel', 'cubic128')
+CONFIG_KEYS = ('config2', 'config3', 'config4', 'config5')
+
+
+def _spawn_ranks(n, backend):
+    """One process per GPU over torch.distributed.run, as the driver launches them; exits with the launcher's code."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if backend == 'nccl' and n_dev < n:
+        print('bench.py: --gpus %d needs %d GPUs for RCCL, %d visible (plumbing runs on fewer GPUs: --backend gloo)' % (n, n, n_dev),
+              file=sys.stderr)
+        sys.exit(3)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == '--cpu-child':
+        return _cpu_child_main(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -414,12 +514,23 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fit', action='store_true', help='skip the (untimed, separately reported) surrogate fit')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary figures (hetero workload, refit cycle)')
-    ap.add_argument('--no-configs', action='store_true', help="skip the blocks on the BASELINE configs' own targets (config3/4/5)")
+    ap.add_argument('--no-configs', action='store_true', help="skip the blocks on the BASELINE configs' own targets (config2/3/4/5)")
     ap.add_argument('--workload', default=None, choices=CONFIG_BLOCKS,
                     help='run ONE config block only and print it (profiling: rocprofv3 -- python3 bench.py --workload funnel)')
     a = ap.parse_args()
     if a.no_extras:
         a.no_configs = True
+    if a.gpus < 1:
+        ap.error('--gpus should be a positive int')
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, BEFORE anything here touches the GPU
+        # (fresh children through torch.distributed.run; this process only relays their output and exit code)
+        return _spawn_ranks(a.gpus, a.backend)
+    if int(os.environ.get('WORLD_SIZE', '1')) != a.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node '
+              '%d ... bench.py --gpus %d), or run `python bench.py --gpus %d` without a launcher'
+              % (a.gpus, os.environ.get('WORLD_SIZE'), a.gpus, a.gpus, a.gpus), file=sys.stderr)
+        sys.exit(2)
 
     import torch
     from bayesfast_amd.device import DeviceContext, DeviceDensity
@@ -440,8 +551,6 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
         else:
             dist.init_process_group(a.backend)
-    if a.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (a.gpus, world), file=sys.stderr)
 
     d, C = a.dim, a.chains
     spec, cov = correlated_gaussian_spec(d)
@@ -557,6 +666,8 @@ def main():
                     traffic = tj['hbm_bytes_per_leapfrog'] * lf_per_launch
             except Exception:
                 traffic = None
+        exec_share = 0.5 * (1. + g_trips_h / g_trips) if (g_trips and use_bound) else 1.
+        ts_last = st_last[:, :, _lib.NSTATS.index('tree_size')]
         out = {
             'metric': 'leapfrog steps/sec (all chains), %d chains x %d-d quadratic surrogate' % (C, d),
             'value': value, 'unit': 'leapfrog steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -564,24 +675,29 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%d chains/GPU x %d-d correlated Gaussian (SURVEY 8d config-2 family), '
                                    "PolyModel('quadratic') surrogate = linear+quadratic, bound on; NUTS defaults "
-                                   '(diag-adapt metric, target_accept 0.8, max_treedepth 10)' % (C, d),
+                                   '(diag-adapt metric, target_accept 0.8, max_treedepth 10).  The surrogate is exact for this '
+                                   'target and no sample leaves the bound: %.1f %% of the trees have %d leaves, so the chains of a '
+                                   'workgroup run in step -- the best case of the path; the BASELINE configs\' own targets '
+                                   '(banana round 0 / round 1, funnel, cubic-cross) are the config2..config5 blocks and the '
+                                   'config3_round*_value keys of this line' % (
+                                       C, d, 100. * float(np.mean(ts_last == np.median(ts_last))), int(np.median(ts_last))),
                        'chains_per_gpu': C, 'dim': d, 'nuts_iterations_per_step': a.iters,
                        'nuts_warmup_iterations': n_warm_iter,
-                       'mean_tree_size': float(st_last[:, :, _lib.NSTATS.index('tree_size')].mean()),
+                       'mean_tree_size': float(ts_last.mean()),
                        'parallelism': 'chains sharded over %d rank(s), no data-path collective' % world},
-            'roofline': {'bound': 'mfma', 'achieved': ach_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
-                         'frac': ach_tf / peak_tf, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'achieved': ach_tf * exec_share, 'peak': peak_tf, 'unit': 'TFLOP/s',
+                         'frac': ach_tf * exec_share / peak_tf, 'traffic': traffic,
+                         'achieved_algorithmic': ach_tf, 'frac_algorithmic': ach_tf / peak_tf,
                          'kernel': kernel_name, 'kernel_ms_per_launch': kernel_ms,
                          'traffic_source': None if traffic is None else 'stored profile (profiles/hbm_traffic.json), not this run',
                          'flops_per_leapfrog': flops_per_leapfrog(d, use_bound),
                          'group_trips': g_trips, 'group_trips_with_bound_tiles': g_trips_h,
-                         'frac_executed': (None if not g_trips or not use_bound else
-                                           (ach_tf / peak_tf) * 0.5 * (1. + g_trips_h / g_trips)),
-                         'flops_note': 'algorithmic: S x and H (x - mu) per step (4 d^2). bf_group_kernel leaves the H tiles out of a '
+                         'executed_share_of_algorithmic_flops': exec_share,
+                         'flops_note': 'achieved / frac count the flops the kernel EXECUTED; *_algorithmic count S x and H (x - mu) per '
+                                       'step (4 d^2) whether executed or not.  The lane-per-chain kernels leave the H tiles out of a '
                                        'trip when lam_max(H) |x - mu|^2 < alpha^2 proves all 16 chains of the group inside the bound '
-                                       '(identical results); on this workload that is nearly every trip, so about half of the '
-                                       'algorithmic flops are decided, not executed (frac_executed: the same fraction counting the H tiles only '
-                                       'for the group_trips_with_bound_tiles of group_trips trips that ran them)'},
+                                       '(identical results); on this workload that is nearly every trip (group_trips_with_bound_tiles of '
+                                       'group_trips ran them), so about half of the algorithmic flops are decided, not executed'},
             'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': bytes_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.,
                                          'peak': 8000., 'unit': 'GB/s',
                                          'frac': (bytes_alg / (kernel_ms * 1e-3) / 1e9 / 8000.) if kernel_ms else 0.,
@@ -611,12 +727,15 @@ def main():
             except Exception as ex:  # side measurements; the headline line must still print
                 out['extras_error'] = repr(ex)
         if not a.no_configs and world == 1:
-            for name, key in zip(CONFIG_BLOCKS, ('config3', 'config4', 'config5')):
+            for name, key in zip(CONFIG_BLOCKS, CONFIG_KEYS):
                 try:
                     with torch.cuda.device(ctx.device):
                         out[key] = config_block(name, ctx, a.seed, cpu_seconds=0. if a.no_cpu_baseline else 4.)
                 except Exception as ex:  # side measurements; the headline line must still print
                     out[key] = {'error': repr(ex)}
+            c3 = out.get('config3', {})   # SURVEY 8d's headline config, beside the benign-target `value`
+            out['config3_round0_value'] = c3.get('value')
+            out['config3_round1_value'] = (c3.get('round_1') or {}).get('value')
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(spec, d, n_warm_iter, a.seed)
         elif not a.no_cpu_baseline:

@@ -31,6 +31,7 @@ def test_bench_single_gpu_line():
     assert rf['bound'] in ('hbm', 'mfma') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     assert 'workload' in j['config'] and 'model' not in j['config']
     assert 'extras_error' not in j, j.get('extras_error')
+    assert rf['frac'] <= rf['frac_algorithmic'] and 'trees have' in j['config']['workload']
     for k in ('hetero', 'refit_cycle', 'full_metric', 'tempered'):   # the side blocks
         assert k in j, k
     assert j['full_metric']['value'] > 0 and j['tempered']['value'] > 0 and j['refit_cycle']['total_ms'] > 0
@@ -51,7 +52,27 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert ex['wire_bytes_per_rank'] < 256 * 250 * 65 * 8 / 4   # far below the shard's samples
 
 
-@pytest.mark.parametrize('name', ['banana_decay', 'funnel', 'cubic128'])
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher starts two ranks (never one rank labelled n_gpus 1), and refuses RCCL when the
+    box has fewer GPUs than ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--chains', '256', '--backend', 'gloo',
+                        '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert j['n_gpus'] == 2 and j['refit_exchange']['collectives'] == 4 and j['refit_exchange']['identical_on_all_ranks']
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1'], cwd=ROOT, capture_output=True,
+                           text=True, timeout=300, env=env)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    # a launcher whose world size disagrees with --gpus is an error, not a mislabelled line
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '1', '--steps', '1', '--warmup', '1'], cwd=ROOT, capture_output=True,
+                       text=True, timeout=300, env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'))
+    assert r.returncode != 0
+
+
+@pytest.mark.parametrize('name', ['gauss32', 'banana_decay', 'funnel', 'cubic128'])
 def test_bench_config_blocks(name):
     """The blocks on the BASELINE configs' own targets (bench.py: config_block), at a reduced chain count: each prints its
     rate, tree statistics, divergence rate and its own roofline."""

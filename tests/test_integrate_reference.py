@@ -136,6 +136,24 @@ def test_sample_on_the_seam_takes_reference_traces_and_continues(bf, seam):
     assert np.array_equal(tt2.samples[:, :60], tt.samples)
     assert tt2.get().shape == (3 * 30, 2) and tt2.get(return_type='logp', flatten=False).shape == (3, 30)
     assert np.isfinite(bf.samplers._get_step_size(tt2))
+    # the per-chain traces carry a CONSISTENT adapted metric (random() reads _inv_std, velocity() reads _var:
+    # samplers/hmc_utils/metrics.py:60-86), one object per chain
+    for t in tt2:
+        np.testing.assert_allclose(t._metric._inv_std**-2, t._metric._var, rtol=1e-14)
+        np.testing.assert_allclose(t._metric._std**2, t._metric._var, rtol=1e-14)
+    assert len({id(t._metric) for t in tt2}) == 3 and len({id(t._step_size) for t in tt2}) == 3
+    # a template that already carries INSTANCES (a warm start built by hand): every chain gets its own copy, the caller's
+    # objects are not written to
+    from bayesfast.samplers.hmc_utils.metrics import QuadMetricDiagAdapt
+    from bayesfast.samplers.hmc_utils.step_size import DualAverageAdaptation
+    met = QuadMetricDiagAdapt(2, np.zeros(2), np.ones(2), 10)
+    ssz = DualAverageAdaptation(0.7, 0.8, 0.05, 0.75, 10., True)
+    tr3 = bf.samplers.NTrace(n_chain=3, n_iter=40, n_warmup=30, random_generator=5, metric=met, step_size=ssz)
+    tt3 = bf.sample(den, tr3, verbose=False)
+    assert len({id(t._metric) for t in tt3}) == 3 and all(t._metric is not met for t in tt3)
+    assert len({id(t._step_size) for t in tt3}) == 3 and all(t._step_size is not ssz for t in tt3)
+    np.testing.assert_array_equal(met._var, np.ones(2))
+    assert len({float(t._step_size._log_step) for t in tt3}) == 3
     den.use_surrogate = False
     with pytest.raises(NotImplementedError):
         integrate.sample(den, {'n_chain': 2, 'n_iter': 20, 'n_warmup': 10})
