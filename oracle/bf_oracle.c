@@ -399,6 +399,44 @@ void bfo_logp_and_grad(const bfo_density *dn, const double *x, int original_spac
     /* core/module.py:76-83: surrogate input scaling */
     for (int i = 0; i < d; ++i) xs[i] = dn->su_lo ? (xo[i] - dn->su_lo[i]) / dn->su_diff[i] : xo[i];
     double f;
+    if (dn->link_kind == 2) {
+        /* [surrogate (m outputs), Gaussian likelihood, optional prior module]: density.py:527-560 */
+        int m = dn->poly.output_size;
+        double *fm = (double *)malloc(sizeof(double) * ((size_t)m * 2 + (size_t)m * d));
+        double *r = fm + m, *J = fm + 2 * m;
+        bfo_poly_fun_and_jac(&dn->poly, xs, fm, J);
+        /* module.py:226 on every row of the surrogate's Jacobian, then density.py:558 with the diagonal input Jacobian */
+        for (int k = 0; k < m; ++k)
+            for (int i = 0; i < d; ++i) {
+                double v = J[(size_t)k * d + i];
+                if (dn->su_diff) v = v / dn->su_diff[i];
+                J[(size_t)k * d + i] = v * jd[i];
+            }
+        double q = 0.;
+        for (int k = 0; k < m; ++k) {
+            double acc = 0.;
+            if (dn->chi2_prec) for (int l = 0; l < m; ++l) acc += dn->chi2_prec[(size_t)k * m + l] * (fm[l] - dn->chi2_y[l]);
+            else acc = dn->chi2_prec_diag[k] * (fm[k] - dn->chi2_y[k]);
+            r[k] = acc;
+        }
+        for (int k = 0; k < m; ++k) q += (fm[k] - dn->chi2_y[k]) * r[k];
+        f = dn->link_logp0 - 0.5 * q;
+        for (int i = 0; i < d; ++i) {
+            double acc = 0.;
+            for (int k = 0; k < m; ++k) acc += -r[k] * J[(size_t)k * d + i];   /* dot(J_out (1,m), J_in (m,d)) */
+            g[i] = acc;
+        }
+        if (dn->prior_mu) {
+            double pr = 0.;
+            for (int i = 0; i < d; ++i) {
+                double dx = xo[i] - dn->prior_mu[i];
+                pr += dn->prior_prec[i] * dx * dx;
+                g[i] += -(dn->prior_prec[i] * dx) * jd[i];   /* the 'x' rows of the module's input Jacobian are diag(jd) */
+            }
+            f += dn->prior_c0 - 0.5 * pr;
+        }
+        free(fm);
+    } else {
     bfo_poly_fun_and_jac(&dn->poly, xs, &f, g);
     /* core/module.py:226 (jac / input_scales_diff) then density.py:558 (chain rule with diag j) */
     for (int i = 0; i < d; ++i) {
@@ -409,6 +447,7 @@ void bfo_logp_and_grad(const bfo_density *dn, const double *x, int original_spac
         double r = f - dn->link_y, dphi = -(dn->link_prec * r);
         f = dn->link_logp0 - 0.5 * (r * (dn->link_prec * r));
         for (int i = 0; i < d; ++i) g[i] = dphi * g[i];
+    }
     }
     if (dn->use_decay) { /* density.py:740-746 */
         double beta2 = mahalanobis2(xo, dn->decay_mu, dn->decay_hess, d, hv);

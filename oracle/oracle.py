@@ -53,7 +53,9 @@ class _Density(C.Structure):
     _fields_ = [('d', C.c_int), ('ranges', _dp), ('hard_bounds', _u8p), ('su_lo', _dp), ('su_diff', _dp),
                 ('poly', _PolyModel), ('use_decay', C.c_int), ('decay_mu', _dp), ('decay_hess', _dp),
                 ('decay_alpha2', C.c_double), ('decay_gamma', C.c_double),
-                ('link_kind', C.c_int), ('link_y', C.c_double), ('link_prec', C.c_double), ('link_logp0', C.c_double)]
+                ('link_kind', C.c_int), ('link_y', C.c_double), ('link_prec', C.c_double), ('link_logp0', C.c_double),
+                ('chi2_y', _dp), ('chi2_prec', _dp), ('chi2_prec_diag', _dp), ('prior_mu', _dp), ('prior_prec', _dp),
+                ('prior_c0', C.c_double)]
 
 
 class _Rng(C.Structure):
@@ -204,8 +206,29 @@ def density_struct(spec):
         dn.su_lo = keep.f64(spec['su_lo'])
         dn.su_diff = keep.f64(spec['su_diff'])
     dn.poly = _poly_struct(spec['poly'], keep)
-    if dn.poly.output_size != 1:
-        raise ValueError('the density surrogate must have output_size 1.')
+    chi2 = spec.get('chi2')
+    if chi2 is None and dn.poly.output_size != 1:
+        raise ValueError('the density surrogate must have output_size 1 (or a chi2 stage for its outputs).')
+    if chi2 is not None:   # {'y' (m,), 'prec' (m,m) | 'prec_diag' (m,), 'logp0'}; optional spec['prior'] = {'mu', 'prec_diag' (d,), 'c0'}
+        if spec.get('link') is not None:
+            raise ValueError('a density has a link or a chi2 stage, not both.')
+        m = dn.poly.output_size
+        dn.link_kind = 2
+        dn.chi2_y = keep.f64(np.asarray(chi2['y'], dtype=np.float64).reshape(m))
+        if (chi2.get('prec') is None) == (chi2.get('prec_diag') is None):
+            raise ValueError('give me exactly one of prec and prec_diag.')
+        if chi2.get('prec') is not None:
+            dn.chi2_prec = keep.f64(np.asarray(chi2['prec'], dtype=np.float64).reshape(m, m))
+        else:
+            dn.chi2_prec_diag = keep.f64(np.asarray(chi2['prec_diag'], dtype=np.float64).reshape(m))
+        dn.link_logp0 = float(chi2.get('logp0', 0.))
+        prior = spec.get('prior')
+        if prior is not None:
+            dn.prior_mu = keep.f64(np.asarray(prior['mu'], dtype=np.float64).reshape(dn.d))
+            dn.prior_prec = keep.f64(np.asarray(prior['prec_diag'], dtype=np.float64).reshape(dn.d))
+            dn.prior_c0 = float(prior.get('c0', 0.))
+    elif spec.get('prior') is not None:
+        raise ValueError('a prior stage needs a chi2 stage before it.')
     dn.use_decay = int(bool(spec.get('use_decay', False)))
     if dn.use_decay:
         dn.decay_mu = keep.f64(spec['decay_mu'])

@@ -576,6 +576,110 @@ def gen_pipeline(bf, out):
     np.savez_compressed(os.path.join(out, 'pipeline.npz'), **z)
 
 
+def gen_pipeline_des(bf, out):
+    """SURVEY 8f-1 in the shape of examples/des-y1-w-cosmosis.ipynb (cells 12-18), scaled down: a THREE-module pipeline
+    x -> m (multi-output model, replaced by a PolyModel surrogate = linear on all inputs + quadratic on a masked subset, with
+    surrogate input_scales) -> like = -|m - d|^2 / 2 + norm (whitened chi-square) -> logp = like + Gaussian prior on some of
+    the x, in a Density with input_scales and hard bounds and the decay term.  Recorded: the fitted surrogate, the density's
+    state, Density.logp_and_grad(use_surrogate=True) in both spaces inside and outside the bound (core/density.py:487-566,
+    724-754; modules/poly.py:466-503), and NUTS trajectories of the reference's own sampler on it with logged draws."""
+    from bayesfast.samplers import NUTS, NTrace
+    rng = np.random.default_rng(457)
+    d, m = 9, 22
+    lo = -1. - rng.uniform(size=d)
+    hi = 1.5 + rng.uniform(size=d)
+    para_range = np.stack([lo, hi], 1)
+    nonlinear = np.array([0, 1, 2, 5])
+    prior_idx = np.array([3, 4, 6, 7, 8])
+    prior_mu = rng.normal(size=prior_idx.size) * 0.1
+    prior_sig = rng.uniform(0.2, 0.5, size=prior_idx.size)
+    prior_norm = -0.5 * np.sum(np.log(2 * np.pi * prior_sig**2))
+    W1 = rng.normal(size=(m, d)) * 0.6
+    W2 = rng.normal(size=(m, nonlinear.size, nonlinear.size)) * 0.25
+    dvec = rng.normal(size=m) * 0.3
+    norm_c = -3.21
+
+    def model(x):
+        z = x[nonlinear]
+        return W1 @ x + np.einsum('ojk,j,k->o', W2, z, z) + 0.05 * np.sin(2. * z[0]) * np.ones(m)
+
+    def chi2_f(mm):
+        return np.atleast_1d(-0.5 * np.sum((mm - dvec)**2) + norm_c)
+
+    def chi2_fj(mm):
+        return np.atleast_1d(-0.5 * np.sum((mm - dvec)**2) + norm_c), -(mm - dvec)[np.newaxis]
+
+    def prior_f(x):
+        return -0.5 * np.sum(((x[prior_idx] - prior_mu) / prior_sig)**2) + prior_norm
+
+    def post_f(like, x):
+        return like + prior_f(x)
+
+    def post_fj(like, x):
+        pj = np.zeros((1, d))
+        pj[0, prior_idx] = -(x[prior_idx] - prior_mu) / prior_sig**2
+        return like + prior_f(x), np.concatenate((np.ones((1, 1)), pj), axis=-1)
+
+    mod0 = bf.Module(fun=model, input_vars='x', output_vars='m')
+    mod1 = bf.Module(fun=chi2_f, fun_and_jac=chi2_fj, input_vars='m', output_vars='like')
+    mod2 = bf.Module(fun=post_f, fun_and_jac=post_fj, input_vars=['like', 'x'], output_vars='logp')
+    su = bf.modules.PolyModel([bf.modules.PolyConfig('linear'), bf.modules.PolyConfig('quadratic', input_mask=nonlinear)],
+                              input_size=d, output_size=m, input_vars='x', output_vars='m', input_scales=para_range)
+    z = {}
+    for tag, decay in (('a', False), ('b', True)):
+        den = bf.Density(density_name='logp', module_list=[mod0, mod1, mod2], surrogate_list=[su], input_vars='x', input_shapes=d,
+                         input_scales=para_range, hard_bounds=True, decay_options=dict(use_decay=decay))
+        xf = lo + (hi - lo) * (0.5 + 0.22 * rng.normal(size=(3 * int(su.n_param), d))).clip(0.02, 0.98)
+        vds = [den.fun(x, original_space=True, use_surrogate=False) for x in xf]
+        den.fit(vds)
+        z.update(flatten_poly(poly_spec_from_reference(su), tag + '.poly.'))
+        z[tag + '.ranges'], z[tag + '.hard_bounds'] = para_range, np.ones((d, 2), np.uint8)
+        z[tag + '.su_lo'], z[tag + '.su_diff'] = np.array(su._input_scales[:, 0]), np.array(su._input_scales_diff)
+        z[tag + '.use_decay'] = np.asarray(decay)
+        if decay:
+            z[tag + '.decay_mu'], z[tag + '.decay_hess'] = np.array(den._mu), np.array(den._hess)
+            z[tag + '.decay_alpha2'], z[tag + '.decay_gamma'] = np.asarray(den._alpha_2), np.asarray(den._gamma)
+        z[tag + '.x_fit'] = xf
+        z[tag + '.y_fit'] = np.array([vd._fun['m'] for vd in vds])
+        z[tag + '.logp_fit'] = np.array([vd._fun['logp'][0] for vd in vds])
+        # evaluation points: original space inside the range (near and far from the fit cloud), and their transformed images
+        xo = lo + (hi - lo) * np.concatenate(((0.5 + 0.15 * rng.normal(size=(20, d))).clip(0.03, 0.97),
+                                              rng.uniform(0.02, 0.98, size=(14, d))))
+        xt = np.array([den.from_original(x) for x in xo])
+        z[tag + '.xo'], z[tag + '.xt'] = xo, xt
+        for sp, pts, key in ((True, xo, 'orig'), (False, xt, 'trans')):
+            lg = [den.logp_and_grad(x, original_space=sp, use_surrogate=True) for x in pts]
+            z['%s.logp_%s' % (tag, key)] = np.array([v[0] for v in lg])
+            z['%s.grad_%s' % (tag, key)] = np.array([v[1] for v in lg])
+        z[tag + '.su_f'] = np.array([su.fun((x - su._input_scales[:, 0]) / su._input_scales_diff)[0] for x in xo]).reshape(len(xo), m)
+        beta = np.array([np.dot(np.dot(xs - su._mu, su._hess), xs - su._mu)**0.5
+                         for xs in (xo - su._input_scales[:, 0]) / su._input_scales_diff])
+        z[tag + '.n_outside_bound'] = np.asarray(int(np.sum(beta > su._alpha)))
+
+        def lgt(x):
+            return den.logp_and_grad(x, original_space=False, use_surrogate=True)
+
+        n_chain, n_iter, n_warmup = 2, 36, 24
+        x0 = xt[:n_chain].copy()
+        z[tag + '.x0'] = x0
+        z[tag + '.n_iter'], z[tag + '.n_warmup'] = np.asarray(n_iter), np.asarray(n_warmup)
+        for c in range(n_chain):
+            t = NTrace(n_chain=n_chain, n_iter=n_iter, n_warmup=n_warmup, x_0=x0.copy(), random_generator=2718)
+            t._init_chain(c)
+            log = LoggingGenerator(t._random_generator)
+            t._random_generator = log
+            NUTS(logp_and_grad=lgt, sample_trace=t).run(verbose=False)
+            k = '%s.nuts%d.' % (tag, c)
+            z[k + 'samples'] = t.samples
+            z[k + 'normals'] = np.array(log.normals)
+            z[k + 'uniforms'] = np.array(log.uniforms)
+            for si in t.stats.stats_items:
+                z[k + si] = np.array(getattr(t.stats, '_' + si), dtype=float)
+    z['chi2.y'], z['chi2.logp0'] = dvec, np.asarray(norm_c)
+    z['prior.idx'], z['prior.mu'], z['prior.sig'], z['prior.c0'] = prior_idx, prior_mu, prior_sig, np.asarray(prior_norm)
+    np.savez_compressed(os.path.join(out, 'pipeline_des.npz'), **z)
+
+
 def gen_tempered(bf, out):
     """Tempered samplers: TCpuLeapfrogIntegrator states (integration.py:98-222) and TNUTS trajectories with
     logged draws (tnuts.py, base_hmc.py:220-262) on a surrogate target with a Gaussian base density.  (THMC is not
@@ -758,7 +862,7 @@ def main():
     a = ap.parse_args()
     bf = prepare_reference(a.ref, a.work)
     gens = dict(poly_kernels=gen_poly_kernels, constraint=gen_constraint, polymodel=gen_polymodel,
-                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, tempered=gen_tempered,
+                density=gen_density, sampler=gen_sampler, sampler_fullmetric=gen_sampler_fullmetric, refit=gen_refit, evidence=gen_evidence, pipeline=gen_pipeline, pipeline_des=gen_pipeline_des, tempered=gen_tempered,
                 fit_illcond=gen_fit_illcond, recipe=gen_recipe, sobol=gen_sobol)
     for k, g in gens.items():
         if a.only and k != a.only:

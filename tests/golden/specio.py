@@ -68,3 +68,30 @@ def rebuild_spec(z, prefix=''):
     for k in ('ranges', 'hard_bounds', 'su_lo', 'su_diff'):
         spec.setdefault(k, None)
     return spec
+
+
+def rebuild_pipeline(z):
+    """pipeline.npz (make_golden.gen_pipeline): [multi-output surrogate with cubic configs, chi-square with a full
+    precision matrix], no transforms -> density spec with a 'chi2' stage."""
+    poly = rebuild_poly(z, 'poly.')
+    return dict(d=poly['input_size'], ranges=None, hard_bounds=None, su_lo=None, su_diff=None, poly=poly, use_decay=False,
+                chi2=dict(y=np.asarray(z['ydat']), prec=np.asarray(z['prec']), logp0=0.))
+
+
+def rebuild_pipeline_des(z, tag):
+    """pipeline_des.npz (make_golden.gen_pipeline_des), case 'a' (no decay) or 'b' (decay): [surrogate, whitened chi-square,
+    like + Gaussian prior on some inputs] behind input scales and hard bounds -> density spec with 'chi2' and 'prior'."""
+    poly = rebuild_poly(z, tag + '.poly.')
+    d, m = poly['input_size'], poly['output_size']
+    pm, pp = np.zeros(d), np.zeros(d)
+    pm[z['prior.idx']] = z['prior.mu']
+    pp[z['prior.idx']] = 1. / np.asarray(z['prior.sig'])**2
+    spec = dict(d=d, ranges=np.asarray(z[tag + '.ranges']), hard_bounds=np.asarray(z[tag + '.hard_bounds']),
+                su_lo=np.asarray(z[tag + '.su_lo']), su_diff=np.asarray(z[tag + '.su_diff']), poly=poly,
+                use_decay=bool(z[tag + '.use_decay']),
+                chi2=dict(y=np.asarray(z['chi2.y']), prec_diag=np.ones(m), logp0=float(z['chi2.logp0'])),
+                prior=dict(mu=pm, prec_diag=pp, c0=float(z['prior.c0'])))
+    if spec['use_decay']:
+        spec.update(decay_mu=np.asarray(z[tag + '.decay_mu']), decay_hess=np.asarray(z[tag + '.decay_hess']),
+                    decay_alpha2=float(z[tag + '.decay_alpha2']), decay_gamma=float(z[tag + '.decay_gamma']))
+    return spec

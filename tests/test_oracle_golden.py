@@ -303,3 +303,50 @@ def test_tuned_baseline_evaluation_agrees_with_the_faithful_one():
     assert np.array_equal(f1[200:], f0[200:])  # outside the bound: the faithful path itself
     f2, _ = orc.logp_and_grad(spec, x)  # and the registration does not outlive the call
     assert np.array_equal(f2, f0)
+
+
+# ---- multi-output surrogate + chi-square (+ prior) pipelines, SURVEY 8f-1: fixtures pipeline.npz, pipeline_des.npz ----
+
+def test_pipeline_density_with_full_precision_and_cubic_configs():
+    """[surrogate with linear, quadratic, cubic-2, cubic-3 configs and output masks; chi-square with a full precision
+    matrix]: the oracle's chi2 stage equals the reference's Density.logp_and_grad(use_surrogate=True), inside and outside
+    the bound (core/density.py:552-560, modules/poly.py:480-503)."""
+    from specio import rebuild_pipeline
+    z = np.load(os.path.join(G, 'pipeline.npz'))
+    spec = rebuild_pipeline(z)
+    lp, g = orc.logp_and_grad(spec, z['xt'], original_space=True)
+    np.testing.assert_allclose(lp, z['logp'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g, z['grad'], rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_des_shaped_pipeline_density(tag):
+    """The three-module pipeline of examples/des-y1-w-cosmosis.ipynb in small: surrogate (linear + masked quadratic, with
+    surrogate input scales) -> whitened chi-square -> like + Gaussian prior of some inputs, behind the Density's input
+    scales and hard bounds, without ('a') and with ('b') the decay term; both spaces, points inside and outside the bound."""
+    from specio import rebuild_pipeline_des
+    z = np.load(os.path.join(G, 'pipeline_des.npz'))
+    spec = rebuild_pipeline_des(z, tag)
+    assert 0 < int(z[tag + '.n_outside_bound']) < z[tag + '.xo'].shape[0]
+    for sp, key, pts in ((True, 'orig', z[tag + '.xo']), (False, 'trans', z[tag + '.xt'])):
+        lp, g = orc.logp_and_grad(spec, pts, original_space=sp)
+        np.testing.assert_allclose(lp, z['%s.logp_%s' % (tag, key)], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(g, z['%s.grad_%s' % (tag, key)], rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize('tag,c', [('a', 0), ('a', 1), ('b', 0), ('b', 1)])
+def test_des_shaped_pipeline_nuts_replay(tag, c):
+    """The reference's NUTS on that density, replayed with its logged draws: exact tree statistics and draw counts."""
+    from specio import rebuild_pipeline_des
+    z = np.load(os.path.join(G, 'pipeline_des.npz'))
+    spec = rebuild_pipeline_des(z, tag)
+    k = '%s.nuts%d.' % (tag, c)
+    chain = orc.Chain(z[tag + '.x0'][c])
+    rng = orc.make_rng('replay', normals=z[k + 'normals'], uniforms=z[k + 'uniforms'])
+    samples, st = orc.nuts_run(spec, chain, rng, int(z[tag + '.n_iter']), int(z[tag + '.n_warmup']))
+    for f in ('tree_depth', 'tree_size', 'diverging', 'warmup'):
+        assert np.array_equal(st[f], z[k + f]), f
+    assert rng[0].i_uniform == z[k + 'uniforms'].size and rng[0].i_normal == z[k + 'normals'].size
+    np.testing.assert_allclose(samples, z[k + 'samples'], rtol=1e-8, atol=1e-8)
+    for f in ('logp', 'energy', 'step_size', 'step_size_bar'):
+        np.testing.assert_allclose(st[f], z[k + f], rtol=1e-7, atol=1e-7, err_msg=f)
