@@ -56,6 +56,14 @@ class PolymodelDesc(C.Structure):  # bfhip_polymodel_desc
                 ('n3', C.c_int), ('mask3', C.POINTER(C.c_int)), ('cubic3', C.POINTER(C.c_double))]
 
 
+class PipelineDesc(C.Structure):  # bfhip_pipeline_desc
+    _fields_ = [('d', C.c_int), ('m', C.c_int), ('ranges', _dp), ('hard_bounds', _u8p), ('su_lo', _dp), ('su_diff', _dp),
+                ('model', PolymodelDesc), ('y', _dp), ('prec', _dp), ('prec_diag', _dp), ('logp0', C.c_double),
+                ('prior_mu', _dp), ('prior_prec', _dp), ('prior_c0', C.c_double),
+                ('use_decay', C.c_int), ('decay_mu', _dp), ('decay_hess', _dp), ('decay_alpha2', C.c_double),
+                ('decay_gamma', C.c_double)]
+
+
 # every symbol include/bfhip.h declares: (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -79,6 +87,7 @@ SYMBOLS = {
     'bfhip_polymodel_upload': (C.c_int, [_vp, C.POINTER(PolymodelDesc)]),
     'bfhip_polymodel_eval': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_chi2_stage': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp]),
+    'bfhip_pipeline_upload': (C.c_int, [_vp, C.POINTER(PipelineDesc)]),
     'bfhip_design_block': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]),
     'bfhip_gram': (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp]),
     'bfhip_tree_size_mode_share': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_double, _vp]),

@@ -44,8 +44,10 @@ class SurrogateDensity:
         of a two-module pipeline; the link is the second)
     """
 
+    _multi_output = False   # (Chi2PipelineDensity: the surrogate's m outputs feed a likelihood module)
+
     def __init__(self, surrogate, input_scales=None, hard_bounds=False, decay_options=None, link=None):
-        if not isinstance(surrogate, PolyModel) or surrogate.output_size != 1:
+        if not isinstance(surrogate, PolyModel) or (surrogate.output_size != 1 and not self._multi_output):
             raise ValueError('surrogate should be a PolyModel with output_size 1.')
         if link is not None and not isinstance(link, GaussianLink):
             raise ValueError('link should be a GaussianLink or None.')
@@ -241,24 +243,33 @@ class SurrogateDensity:
         return self.logp_and_grad(x, original_space)[1]
 
 
-class Chi2PipelineDensity:
-    """A two-module pipeline evaluated on the device: a multi-output ``PolyModel`` surrogate (x -> m outputs) followed by
-    a Gaussian likelihood of those outputs, i.e. the reference's ``Density(module_list=[model, chi2],
-    surrogate_list=[PolyModel])`` with ``use_surrogate=True`` (core/density.py:487-566: the surrogate replaces the module
-    in its scope, :527-551; the Jacobians are chained, ``jac = np.dot(J_out, J_in)``, :552-560; ``logp`` and ``grad`` are
-    read from the density variable, :737-739).
+class Chi2PipelineDensity(SurrogateDensity):
+    """A pipeline evaluated AND sampled on the device: a multi-output ``PolyModel`` surrogate (x -> m outputs), a Gaussian
+    likelihood of those outputs and, optionally, a diagonal Gaussian prior of the inputs, i.e. the reference's
+    ``Density(module_list=[model, chi2(, post)], surrogate_list=[PolyModel])`` with ``use_surrogate=True``
+    (core/density.py:487-566: the surrogate replaces the module in its scope, :527-551; the Jacobians are chained,
+    ``jac = np.dot(J_out, J_in)``, :552-560; ``logp`` and ``grad`` are read from the density variable, :737-739;
+    examples/des-y1-w-cosmosis.ipynb cells 12-18 is this with d = 27, m = 457).
 
-    surrogate : PolyModel with output_size m (any config orders)
+        like = logp0 - (f(x) - y)^T prec (f(x) - y) / 2
+        logp = like + prior_c0 - sum_i prior_prec[i] (x_i - prior_mu[i])^2 / 2
+
+    surrogate : PolyModel with output_size m (any config orders, masks, bound, input_scales)
     y : (m,) data vector;  prec : (m, m) precision matrix, or  prec_diag : (m,) inverse variances
     logp0 : additive constant of the log-likelihood
+    prior_mu, prior_prec : (d,) each or None -- prior_prec[i] = 0 leaves input i without a prior; prior_c0 its constant
+    input_scales, hard_bounds, decay_options : as ``SurrogateDensity``
 
-    ``logp_and_grad(x)`` runs ``bfhip_polymodel_eval`` (f and the (n, m, d) Jacobians) and ``bfhip_chi2_stage``
-    (r = prec (f - y), logp = logp0 - (f - y).r / 2, grad = -J^T r) without leaving the GPU."""
+    ``sample(density, ...)`` runs NUTS / HMC on it inside the fused kernel (``bfhip_pipeline_upload``: the (m, d) Jacobian is
+    never formed; two FP64-MFMA contractions per gradient, bayesfast_amd/csrc/bfhip_pld.h).  ``logp_and_grad_device`` keeps
+    the first implementation -- ``bfhip_polymodel_eval`` (f and the (n, m, d) Jacobians) + ``bfhip_chi2_stage`` -- as an
+    independent second route the tests compare with."""
 
-    def __init__(self, surrogate, y, prec=None, prec_diag=None, logp0=0.):
-        if not isinstance(surrogate, PolyModel):
-            raise ValueError('surrogate should be a PolyModel.')
-        self.surrogate = surrogate
+    _multi_output = True
+
+    def __init__(self, surrogate, y, prec=None, prec_diag=None, logp0=0., prior_mu=None, prior_prec=None, prior_c0=0.,
+                 input_scales=None, hard_bounds=False, decay_options=None):
+        super().__init__(surrogate, input_scales=input_scales, hard_bounds=hard_bounds, decay_options=decay_options)
         m = surrogate.output_size
         self._y = np.ascontiguousarray(y, dtype=np.float64).reshape(m)
         if (prec is None) == (prec_diag is None):
@@ -266,14 +277,47 @@ class Chi2PipelineDensity:
         self._prec = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64).reshape(m, m)
         self._pdiag = None if prec_diag is None else np.ascontiguousarray(prec_diag, dtype=np.float64).reshape(m)
         self._logp0 = float(logp0)
+        if (prior_mu is None) != (prior_prec is None):
+            raise ValueError('prior_mu and prior_prec go together.')
+        self._prior_mu = None if prior_mu is None else np.ascontiguousarray(prior_mu, dtype=np.float64).reshape(self._d)
+        self._prior_prec = None if prior_prec is None else np.ascontiguousarray(prior_prec, dtype=np.float64).reshape(self._d)
+        if self._prior_prec is not None and not np.all(self._prior_prec >= 0):
+            raise ValueError('prior_prec should be non-negative.')
+        self._prior_c0 = float(prior_c0)
 
-    input_size = property(lambda self: self.surrogate.input_size)
+    def fit(self, x, logp, y=None):
+        """``Density.fit`` (core/density.py:813-830) for this pipeline: x (n, d) original-space points, y (n, m) the true
+        outputs of the module the surrogate replaces, logp (n,) the true log-densities (the bound's ``center_max`` and the
+        decay statistics use them)."""
+        if y is None:
+            raise ValueError('the surrogate of a pipeline density is fitted to the outputs y (n, m) of the module it replaces.')
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        logp = np.asarray(logp, dtype=np.float64).reshape(-1)
+        if x.ndim != 2 or x.shape != (logp.size, self._d) or y.shape != (logp.size, self.surrogate.output_size):
+            raise ValueError('x should have shape (n, d), y shape (n, m) and logp shape (n,).')
+        if self._use_decay:
+            self._set_decay(x)
+        su = self.surrogate
+        xs = x if su._input_scales is None else (x - su._input_scales[:, 0]) / su._input_scales_diff
+        su.fit(xs, y, logp)
+        self._device = None
+
+    def spec(self):
+        sp = super().spec()
+        sp['link'] = None
+        sp['chi2'] = dict(y=self._y, prec=self._prec, prec_diag=self._pdiag, logp0=self._logp0)
+        sp['prior'] = None if self._prior_mu is None else dict(mu=self._prior_mu, prec_diag=self._prior_prec, c0=self._prior_c0)
+        return sp
 
     def logp_and_grad_device(self, x, grad=True):
-        """x (n, d) array or device tensor -> logp (n,), grad (n, d) device tensors."""
+        """Second route (original-space x, no transforms / prior / decay): x (n, d) array or device tensor -> logp (n,),
+        grad (n, d) device tensors through ``bfhip_polymodel_eval`` + ``bfhip_chi2_stage``."""
         import torch
         from .. import _lib
         from ..device import _ptr
+        if self._input_scales is not None or self.surrogate._input_scales is not None or self._prior_mu is not None or self._use_decay:
+            raise NotImplementedError('the two-kernel route covers the plain [surrogate, chi-square] pipeline only.')
         dm = self.surrogate.device_model()
         ctx = dm.ctx
         xt = ctx.tensor(x, torch.float64).reshape(-1, self.input_size)
@@ -290,13 +334,14 @@ class Chi2PipelineDensity:
 
     def logp_and_grad(self, x, original_space=True):
         x = np.asarray(x, dtype=np.float64)
-        lp, g = self.logp_and_grad_device(x.reshape(-1, self.input_size))
+        lp, g = self.device().logp_and_grad(x.reshape(-1, self.input_size), original_space)
         lp, g = lp.cpu().numpy(), g.cpu().numpy()
         return (lp[0], g[0]) if x.ndim == 1 else (lp, g)
 
     def logp(self, x, original_space=True):
-        x = np.asarray(x, dtype=np.float64)
-        lp = self.logp_and_grad_device(x.reshape(-1, self.input_size), grad=False)[0].cpu().numpy()
-        return lp[0] if x.ndim == 1 else lp
+        return self.logp_and_grad(x, original_space)[0]
 
     __call__ = logp
+
+    def grad(self, x, original_space=True):
+        return self.logp_and_grad(x, original_space)[1]

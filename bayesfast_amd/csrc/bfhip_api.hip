@@ -45,6 +45,7 @@ extern "C" void bfhip_ctx_destroy(bfhip_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->cubic_buf) (void)hipFree(ctx->cubic_buf);
     if (ctx->pm_buf) (void)hipFree(ctx->pm_buf);
+    if (ctx->pld_buf) (void)hipFree(ctx->pld_buf);
     if (ctx->flow) (void)hipFree(ctx->flow);
     free(ctx);
 }

@@ -37,6 +37,8 @@ struct bfhip_ctx {
     void *pm_buf;         // multi-output polymodel (bfhip_polymodel_upload)
     size_t pm_bytes;
     int has_pm;
+    void *pld_buf;        // pipeline density (bfhip_pipeline_upload): fragments, tables
+    size_t pld_bytes;
     struct PolyDev {
         int d, DP, m, use_bound, has_quad;
         const double *Sf;    // [m][DP*DP] A fragments of S_o = A_o + A_o^T

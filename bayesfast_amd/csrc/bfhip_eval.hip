@@ -1,5 +1,6 @@
 // bfhip_eval.hip -- batched surrogate logp+grad and batched leapfrog step (wave-local MFMA layout).
 #include "bfhip_eval.h"
+#include "bfhip_sampler_defs.h"
 
 // Stages the model's fragments and per-dimension table into LDS (coefficient matrices are read by
 // every MFMA of every wave; 32 KB each at DP = 64).  Returns pointers valid after __syncthreads().
@@ -386,6 +387,7 @@ extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int origi
     if (!ctx || n < 0 || (n > 0 && (!x || !logp))) return bf_set_error(BFHIP_ERR_ARG, "bfhip_logp_grad: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_logp_grad: no density uploaded");
     if (n == 0) return 0;
+    if (ctx->model.pld.on) return bf_pld_logp_grad(ctx, n, x, original_space, logp, grad);
     const int grid = eval_grid(ctx, n);
     const size_t lds = bf_eval_lds_bytes(ctx->model);
     switch (ctx->model.DP / 16) {
@@ -412,6 +414,7 @@ extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const do
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_leapfrog: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_leapfrog: no density uploaded");
     if (n == 0) return 0;
+    if (ctx->model.pld.on) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_leapfrog: not implemented for the pipeline density (bfhip_sampler_run is)");
     const int grid = eval_grid(ctx, n);
     const size_t lds = bf_eval_lds_bytes(ctx->model);
     switch (ctx->model.DP / 16) {

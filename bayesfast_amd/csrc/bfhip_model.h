@@ -30,6 +30,23 @@ enum {
     PD_N
 };
 
+// ---- pipeline density (bfhip_pld.h): multi-output surrogate + Gaussian likelihood (+ prior), device-side description ----
+struct PldDev {
+    int on;                 // the uploaded density is a pipeline density
+    int m, MP, NT1, NS2;    // outputs; padded to 16; row tiles of GEMM1; k-steps of GEMM2
+    int nf, PP, NS1, NT2;   // monomials; padded to 16; k-steps of GEMM1; row tiles of GEMM2
+    int KS2, KPJ2;          // K-split of GEMM2 (partial sums in separate W slots) and k-steps per part
+    int n_ent;              // entries per dimension of the gradient table
+    int has_prior;
+    const double *CF, *CTF; // A fragments (see above)
+    const double *yw, *fmuw;    // (MP) whitened data vector and f_mu, zero padded
+    const unsigned *mono;       // (PP) i1 | i2 << 8 | i3 << 16; index DP = 1, DP + 1 = 0 (padding monomials)
+    const unsigned long long *gtab;   // [n_ent][DP]: low word = monomial p, high word = a | b << 8 | mult << 16 (padding: a = DP + 1)
+    const double *prior_mu, *prior_prec;   // (DP) original-space Gaussian prior, zero padded (prec 0 = no prior on that input)
+    double logp0, prior_c0;
+};
+
+
 // Device-resident surrogate density.  Matrices are stored as MFMA A-operand fragments:
 //   frag[(t * NS + s) * 64 + l] = M[16 t + (l & 15)][4 s + (l >> 4)],  t < T = DP/16, s < NS = DP/4
 // so that one wave-instruction reads 512 contiguous bytes (v_mfma_f64_16x16x4_f64, A[i=l&15][k=l>>4]).
@@ -52,6 +69,8 @@ struct DevModel {
     const double *A2t;   // [n2][n2] its transpose
     const double *T3t;   // [n3][n3][n3] symmetric fill of the j<k<l coefficients, zero where indices repeat,
                          // stored [k][l][j] so that consecutive lanes (j) read consecutive words
+    PldDev pld;          // pld.on: the density is [multi-output surrogate, Gaussian likelihood, optional prior] (bfhip_pld.h);
+                         // then has_quad = has_cubic = has_link = 0 and the fields above describe transforms, bound and decay
 };
 
 // ---- xoshiro256++ / splitmix64 --------------------------------------------------------------------

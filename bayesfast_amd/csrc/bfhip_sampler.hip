@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include "bfhip_eval.h"
 #include "bfhip_metric.h"
+#include "bfhip_pld.h"
 
 // The f64 libm expansions (exp, log, sincospi, sqrt) are long inline sequences whose constants get hoisted
 // out of the trip loop; inlined at every call site they push the kernel far over its 128-VGPR budget
@@ -166,11 +167,14 @@ __device__ inline bool g_no_quad_tiles(const SamplerArgs &a) { return a.no_quad 
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
 __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
     constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
-    constexpr bool PLAIN = FS == 1, SPEC = FS != 0;
-    const bool f_quad = SPEC ? true : (bool)m.has_quad, f_bound = SPEC ? true : (bool)m.use_bound;
+    // FS == 8: the pipeline density (bfhip_pld.h: multi-output surrogate + Gaussian likelihood + prior); transforms, input
+    // scaling, bound and decay are run-time features as in FS == 0, the polynomial itself is the two contractions of phase P
+    constexpr bool PLD = FS == 8;
+    constexpr bool PLAIN = FS == 1, SPEC = FS != 0 && !PLD;
+    const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
-    const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = SPEC ? false : (bool)m.has_cubic;
-    const bool f_link = SPEC ? false : (bool)m.has_link;  // Gaussian likelihood of the surrogate's output (density.py:552-560)
+    const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = (SPEC || PLD) ? false : (bool)m.has_cubic;
+    const bool f_link = (SPEC || PLD) ? false : (bool)m.has_link;  // Gaussian likelihood of the surrogate's output (density.py:552-560)
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
     // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
     // (matrix, row tile, K part) on every trip and keeps its A operands in registers for the whole launch:
@@ -247,6 +251,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     // masked inputs are 36 KB), the masks of this lane in registers
     const bool cub_l = f_cubic && a.cub_lds != 0;
     double *CUB = GB + (((size_t)a.gbn * 16 * GS + 1) & ~(size_t)1);  // [n2 n2] A2t | [n2 n2] A2 | [nc3 n3 n3 16] T3x
+    // pipeline density: its regions behind the matvec results (there are no cubic tables then)
+    PldLds PL;
+    if constexpr (PLD) {
+        PL = pld_lds(CUB, DP, m.pld);
+        pld_stage(m.pld, PL, tid, NTH);
+    }
     int mk2 = 0, mk3 = 0, pj2[E], pj3[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) pj2[e] = pj3[e] = -1;
@@ -409,10 +419,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     (void)trip_no;
 #ifdef BF_TRACE
     __shared__ unsigned long long TRC[BF_TRACE * 16];
-#define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
+#define TRACE(k) do { if ((!PLD || (k) <= 10) && w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
+#define TRACEP(k) do { if (PLD && w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
     for (int i = threadIdx.x; i < BF_TRACE * 16; i += NTH) TRC[i] = 0;
 #else
 #define TRACE(k) do { } while (0)
+#define TRACEP(k) do { } while (0)
 #endif
 
     auto run_unit = [&](bool have_ev, double E_new, double logp_new) {
@@ -1279,6 +1291,72 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
         // (hoisted for the fused second pass: what its first half leaves for the second)
         double f_keep = 0., beta_keep = 0., bd2_keep = 0., logdet_keep = 0.;
         bool oob_fused = false;
+        if constexpr (PLD) {
+            // ================= phase P: the pipeline density (bfhip_pld.h) =================
+            // Every wave of the workgroup takes part in the two contractions; a chain that evaluates owns column w of them.
+            // The bound is decided FIRST (its H (x - mu) tiles are this trip's phase B), so a point outside the ellipsoid is
+            // evaluated once, at its projection (modules/poly.py:480-503), never in a second trip.
+            static_assert(!PLD || E == 1, "the pipeline density is instantiated for d <= 64");
+            const PldDev &pl = m.pld;
+            double xm0 = 0., beta_o = 0., r_bd2 = 0.;
+            if (evaluating) {
+                double r_b2 = 0.;
+                hv[0] = (f_bound && lane_ok) ? gb_read(slot_H, lane) : 0.;
+                dgr[0] = (f_decay && lane_ok) ? gb_read(slot_D, lane) : 0.;
+                xm0 = xs[0] - c_mu[0];
+                r_b2 = xm0 * hv[0];
+                if (f_decay) r_bd2 = (xo[0] - pdl(PD_DMU, 0)) * dgr[0];
+                { double r2[2] = {r_b2, r_bd2}; wave_sum_n<2>(r2); r_b2 = r2[0]; r_bd2 = r2[1]; }
+                if (f_tr) logdet = wave_sum(logdet);
+                if (f_bound && !(r_b2 < m.alpha * m.alpha * (1. - 1e-12))) {   // modules/poly.py:467-469
+                    const double b = usqrt(r_b2);
+                    if (b > m.alpha) beta_o = b;
+                }
+                const double x_ev = beta_o > 0. ? (m.alpha * xs[0] + (beta_o - m.alpha) * c_mu[0]) / beta_o : xs[0];   // :482
+                pld_point(pl, PL, DP, w, lane, lane < d ? x_ev : 0., beta_o);
+            }
+            TRACEP(7);
+            __syncthreads();  // P1: monomials of every evaluating chain
+            TRACEP(8);
+            pld_gemm1(pl, PL, m.alpha, w, NWV, lane);
+            TRACEP(11);
+            __syncthreads();  // P2: residuals
+            TRACEP(12);
+            pld_gemm2(pl, PL, w, NWV, lane);
+            TRACEP(13);
+            __syncthreads();  // P3: W = C'^T r
+            TRACEP(14);
+            if (evaluating) {
+                double s2[2];
+                pld_sums(pl, PL, w, lane, s2[0], s2[1]);
+                wave_sum_n<2>(s2);
+                double gj0 = lane < DP ? pld_grad(pl, PL, DP, w, lane) : 0.;   // (J_0^T r)_lane
+                TRACEP(15);
+                if (beta_o > 0.) {   // modules/poly.py:494-496, contracted with r
+                    const double r_dotj = wave_sum(gj0 * xm0);
+                    gj0 += (s2[1] / m.alpha - r_dotj / beta_o) * (hv[0] / beta_o);
+                }
+                double f = pl.logp0 - 0.5 * s2[0];
+                gn[0] = -gj0;                                   // density.py:552-560: dot(J_like, J_surrogate)
+                if (f_su) gn[0] = gn[0] / pdl(PD_SU_DIFF, 0);   // module.py:226
+                gn[0] = gn[0] * jac[0];                         // density.py:558
+                if (pl.has_prior) {   // the last module: like + log prior of the original-space inputs
+                    const double dx = lane < d ? xo[0] - pl.prior_mu[lane] : 0., pp = lane < d ? pl.prior_prec[lane] : 0.;
+                    f += pl.prior_c0 - 0.5 * wave_sum(pp * dx * dx);
+                    gn[0] += -(pp * dx) * jac[0];
+                }
+                if (f_decay) {
+                    f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
+                    if (r_bd2 > m.decay_alpha2) gn[0] -= 2. * m.decay_gamma * dgr[0];
+                }
+                if (f_tr) {
+                    f += logdet;
+                    gn[0] += gj[0];
+                }
+                logp_new = f;
+                have_eval = true;
+            }
+        } else
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
             const bool fast_kin = !FULLM && !f_decay && !f_link && mode != M_OOB;
@@ -1586,6 +1664,10 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     }
 }
 
+#ifdef BF_TRACE   // (the macro above names PLD, a template constant of bf_sampler_kernel)
+#undef TRACE
+#define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
+#endif
 #include "bfhip_nuts_pipe.h"
 
 static int g_tail_max = 4;  // tuning / test hook: 0 disables the VALU matvec of the plain kernel
@@ -1629,8 +1711,12 @@ static bool sampler_cubic_lds(const DevModel &m, bool plain) {
            (sampler_lds_base(m, plain) + sampler_cubic_doubles(m)) * sizeof(double) <= (size_t)160 * 1024;
 }
 static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
+    if (m.pld.on)   // (the pipeline block sits where the cubic tables would: behind the matvec results, 16-byte aligned)
+        return (((sampler_lds_base(m, false) + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2)) * sizeof(double);
     return (sampler_lds_base(m, plain) + (sampler_cubic_lds(m, plain) ? sampler_cubic_doubles(m) : 0)) * sizeof(double);
 }
+// what the sampler's own regions take for a pipeline density (bfhip_pipeline_upload sizes the K-split of GEMM2 with it)
+size_t bf_sampler_lds_bytes_base(const DevModel &m) { return ((sampler_lds_base(m, false) + 1) & ~(size_t)1) * sizeof(double); }
 
 // Chains per workgroup of the wave-per-chain kernels.  A launch lasts (trips of its longest chain) x (time of a trip), and a
 // trip is its matvec jobs -- the same MFMAs whatever the number of columns in use -- plus the bookkeeping of the chains'
@@ -1706,6 +1792,12 @@ template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
     const bool plain = sampler_plain(m) && !args.mat;
+    if (m.pld.on) {   // pipeline density: the FS = 8 instantiation (d <= 64, diagonal metric)
+        if (args.mat) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density runs with the diagonal metric only");
+        constexpr int WP = W <= 4 ? W : 1;   // (keeps W = 8 from instantiating it)
+        if (W > 4) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density is implemented for d <= 64");
+        return launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
+    }
     if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);
 #ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
@@ -1811,7 +1903,8 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
         const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
         const bool tr_only = common && m.has_transform && !m.use_decay, dec_only = common && m.use_decay && !m.has_transform && !args.no_fuse;
         const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only || dec_only);
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
+        if (m.pld.on) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_sampler_kernel<%d, %s, false, 8>", W, nuts ? "true" : "false");
+        else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
     }
     switch (W) {
 #ifndef BF_ONLY_HEADLINE  // tuning builds (-DBF_ONLY_HEADLINE) compile the 64-d instantiations only

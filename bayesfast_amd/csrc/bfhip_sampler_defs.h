@@ -31,6 +31,10 @@ enum { CS_LOG_STEP = 0, CS_LOG_BAR, CS_HBAR, CS_SMU, CS_COUNT, CS_PROP_E, CS_PRO
        CS_W_OFF, CS_TREE_W, CS_BETA, CS_T_E, CS_T_LOGP, CS_STEP_NOW, CS_STEP_BAR, CS_N };
 
 
+// bfhip_sampler.hip: LDS bytes of bf_sampler_kernel's own regions for a pipeline density (bfhip_pld.hip sizes its block with it)
+size_t bf_sampler_lds_bytes_base(const DevModel &m);
+// bfhip_pld.hip: Density.logp_and_grad of the pipeline density
+int bf_pld_logp_grad(struct bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad);
 // bfhip_group.hip: NUTS / HMC for the common surrogate (optionally with decay / constraint transform) at d <= 64
 struct bfhip_ctx;
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args);

@@ -395,6 +395,7 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || !cfg || !tp || n_chain < 0) return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_tnuts_run: no density uploaded");
+    if (ctx->model.pld.on) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_tnuts_run: not implemented for the pipeline density");
     if (n_chain == 0) return 0;
     if (!rng || !sc || !vec || !u || !tp->base_S || !tp->base_lin || n_out < 0 || (n_out > 0 && (!samples || !stats || !stats_t)))
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: NULL array");

@@ -8,7 +8,8 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ['DeviceContext', 'DeviceDensity', 'DevicePolyModel', 'density_desc_from_spec', 'get_context']
+__all__ = ['DeviceContext', 'DeviceDensity', 'DevicePolyModel', 'density_desc_from_spec', 'pipeline_desc_from_spec',
+           'polymodel_desc_from_poly', 'get_context']
 
 _ORDERS = ('linear', 'quadratic', 'cubic-2', 'cubic-3')
 
@@ -199,6 +200,67 @@ def density_desc_from_spec(spec):
     return ds, keep
 
 
+def pipeline_desc_from_spec(spec):
+    """A density spec with a ``'chi2'`` stage -> ``bfhip_pipeline_desc`` + the arrays it points to.
+
+    spec = the keys of ``density_desc_from_spec`` with a MULTI-output ``poly`` and no ``link``, plus
+           'chi2': {'y' (m,), 'prec' (m, m) | 'prec_diag' (m,), 'logp0'} and optionally
+           'prior': {'mu' (d,), 'prec_diag' (d,), 'c0'}  (original-space inputs; prec_diag 0 = no prior on that input)"""
+    d = int(spec['d'])
+    poly, chi2 = spec['poly'], spec['chi2']
+    m = int(poly['output_size'])
+    if int(poly['input_size']) != d:
+        raise ValueError('the surrogate should have input_size d.')
+    if spec.get('link') is not None:
+        raise ValueError('a density has a link or a chi2 stage, not both.')
+    keep = []
+
+    def f64(a, shape=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if shape is not None and a.shape != shape:
+            raise ValueError('expected shape {}, got {}.'.format(shape, a.shape))
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    ds = _lib.PipelineDesc()
+    ds.d, ds.m = d, m
+    if spec.get('ranges') is not None:
+        ds.ranges = f64(spec['ranges'], (d, 2))
+        hb = spec.get('hard_bounds')
+        if hb is not None:
+            hb = np.ascontiguousarray(hb, dtype=np.uint8)
+            if hb.shape != (d, 2):
+                raise ValueError('hard_bounds should have shape (d, 2).')
+            keep.append(hb)
+            ds.hard_bounds = hb.ctypes.data_as(C.POINTER(C.c_uint8))
+    if spec.get('su_lo') is not None:
+        ds.su_lo = f64(spec['su_lo'], (d,))
+        ds.su_diff = f64(spec['su_diff'], (d,))
+    pmd, pkeep = polymodel_desc_from_poly(poly)
+    keep.append(pkeep)
+    ds.model = pmd
+    ds.y = f64(np.asarray(chi2['y'], dtype=np.float64).reshape(-1), (m,))
+    if (chi2.get('prec') is None) == (chi2.get('prec_diag') is None):
+        raise ValueError('give me exactly one of prec and prec_diag.')
+    if chi2.get('prec') is not None:
+        ds.prec = f64(chi2['prec'], (m, m))
+    else:
+        ds.prec_diag = f64(np.asarray(chi2['prec_diag'], dtype=np.float64).reshape(-1), (m,))
+    ds.logp0 = float(chi2.get('logp0', 0.))
+    prior = spec.get('prior')
+    if prior is not None:
+        ds.prior_mu = f64(np.asarray(prior['mu'], dtype=np.float64).reshape(-1), (d,))
+        ds.prior_prec = f64(np.asarray(prior['prec_diag'], dtype=np.float64).reshape(-1), (d,))
+        ds.prior_c0 = float(prior.get('c0', 0.))
+    if spec.get('use_decay', False):
+        ds.use_decay = 1
+        ds.decay_mu = f64(spec['decay_mu'], (d,))
+        ds.decay_hess = f64(spec['decay_hess'], (d, d))
+        ds.decay_alpha2 = float(spec['decay_alpha2'])
+        ds.decay_gamma = float(spec['decay_gamma'])
+    return ds, keep
+
+
 class DeviceDensity:
     """A surrogate log density resident on one GPU.
 
@@ -213,8 +275,12 @@ class DeviceDensity:
 
     def upload(self):
         """Make this density the context's current one (a context holds one density at a time)."""
-        ds, keep = density_desc_from_spec(self.spec)
-        _lib.check(self.ctx._lib.bfhip_density_upload(self.ctx.handle, C.byref(ds)))
+        if self.spec.get('chi2') is not None:   # [multi-output surrogate, Gaussian likelihood, optional prior]: bfhip_pipeline_upload
+            ds, keep = pipeline_desc_from_spec(self.spec)
+            _lib.check(self.ctx._lib.bfhip_pipeline_upload(self.ctx.handle, C.byref(ds)))
+        else:
+            ds, keep = density_desc_from_spec(self.spec)
+            _lib.check(self.ctx._lib.bfhip_density_upload(self.ctx.handle, C.byref(ds)))
         self.ctx._current_density = self
 
     def upload_if_needed(self):
@@ -269,6 +335,74 @@ class DeviceDensity:
         return logp, energy
 
 
+def polymodel_desc_from_poly(poly):
+    """``PolyModel.poly_spec()`` -> a filled ``bfhip_polymodel_desc`` + the arrays it points to: dense per-output coefficients
+    with the masks scattered, which is what ``_fun_and_jac`` does on every call (modules/poly.py:474-477)."""
+    d, m = int(poly['input_size']), int(poly['output_size'])
+    c0 = np.zeros(m)
+    lin = np.zeros((m, d))
+    quad = np.zeros((m, d, d))
+    has_quad = False
+    cubic = []
+    for cf in poly['configs']:
+        im = np.asarray(cf['input_mask'], dtype=np.int64)
+        om = np.asarray(cf['output_mask'], dtype=np.int64)
+        coef = np.asarray(cf['coef'], dtype=np.float64)
+        if cf['order'] == 'linear':
+            c0[om] += coef[:, 0]
+            lin[np.ix_(om, im)] += coef[:, 1:]
+        elif cf['order'] == 'quadratic':
+            has_quad = True
+            iu = np.triu_indices(im.size)
+            for q, o in enumerate(om):
+                quad[o, im[iu[0]], im[iu[1]]] += coef[q][iu]
+        elif cf['order'] in ('cubic-2', 'cubic-3'):
+            cubic.append((cf['order'], im, om, coef))
+        else:
+            raise ValueError('unexpected PolyConfig order "{}".'.format(cf['order']))
+    # cubic configs, compact over the union of the dimensions they touch (per order)
+    mask2 = np.unique(np.concatenate([c[1] for c in cubic if c[0] == 'cubic-2'] or [np.zeros(0, np.int64)])).astype(np.int32)
+    mask3 = np.unique(np.concatenate([c[1] for c in cubic if c[0] == 'cubic-3'] or [np.zeros(0, np.int64)])).astype(np.int32)
+    cub2 = np.zeros((m, mask2.size, mask2.size))
+    cub3 = np.zeros((m, mask3.size, mask3.size, mask3.size))
+    for order, im, om, coef in cubic:
+        if order == 'cubic-2':
+            pos = np.searchsorted(mask2, im)
+            for q, o in enumerate(om):
+                cub2[o][np.ix_(pos, pos)] += coef[q]
+        else:
+            pos = np.searchsorted(mask3, im)
+            n_ = im.size
+            jj, kk, ll = np.meshgrid(np.arange(n_), np.arange(n_), np.arange(n_), indexing='ij')
+            sel = (jj < kk) & (kk < ll)  # only j < k < l is defined (modules/_poly.pyx:86-137)
+            for q, o in enumerate(om):
+                cub3[o, pos[jj[sel]], pos[kk[sel]], pos[ll[sel]]] += coef[q][sel]
+    ds = _lib.PolymodelDesc()
+    keep = []
+
+    def f64(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    ds.d, ds.m = d, m
+    ds.c0, ds.lin = f64(c0), f64(lin)
+    if has_quad:
+        ds.quad = f64(quad)
+    if mask2.size:
+        keep.append(mask2)
+        ds.n2, ds.mask2, ds.cubic2 = int(mask2.size), mask2.ctypes.data_as(C.POINTER(C.c_int)), f64(cub2)
+    if mask3.size:
+        keep.append(mask3)
+        ds.n3, ds.mask3, ds.cubic3 = int(mask3.size), mask3.ctypes.data_as(C.POINTER(C.c_int)), f64(cub3)
+    if poly.get('use_bound', False) and (has_quad or cubic):  # (not for an all-linear model, modules/poly.py:467)
+        ds.use_bound = 1
+        ds.mu, ds.hess = f64(poly['mu']), f64(poly['hess'])
+        ds.alpha = float(poly['alpha'])
+        ds.f_mu = f64(np.asarray(poly['f_mu'], dtype=np.float64).reshape(m))
+    return ds, keep
+
+
 class DevicePolyModel:
     """A multi-output PolyModel resident on one GPU: ``PolyModel.fun / jac / fun_and_jac`` over batches of points
     (modules/poly.py:430-503) for linear, quadratic and cubic configs; masks are scattered to dense per-output
@@ -278,69 +412,8 @@ class DevicePolyModel:
 
     def __init__(self, poly, ctx=None):
         self.ctx = ctx if ctx is not None else get_context()
-        d, m = int(poly['input_size']), int(poly['output_size'])
-        c0 = np.zeros(m)
-        lin = np.zeros((m, d))
-        quad = np.zeros((m, d, d))
-        has_quad = False
-        cubic = []
-        for cf in poly['configs']:
-            im = np.asarray(cf['input_mask'], dtype=np.int64)
-            om = np.asarray(cf['output_mask'], dtype=np.int64)
-            coef = np.asarray(cf['coef'], dtype=np.float64)
-            if cf['order'] == 'linear':
-                c0[om] += coef[:, 0]
-                lin[np.ix_(om, im)] += coef[:, 1:]
-            elif cf['order'] == 'quadratic':
-                has_quad = True
-                iu = np.triu_indices(im.size)
-                for q, o in enumerate(om):
-                    quad[o, im[iu[0]], im[iu[1]]] += coef[q][iu]
-            elif cf['order'] in ('cubic-2', 'cubic-3'):
-                cubic.append((cf['order'], im, om, coef))
-            else:
-                raise ValueError('unexpected PolyConfig order "{}".'.format(cf['order']))
-        # cubic configs, compact over the union of the dimensions they touch (per order)
-        mask2 = np.unique(np.concatenate([c[1] for c in cubic if c[0] == 'cubic-2'] or [np.zeros(0, np.int64)])).astype(np.int32)
-        mask3 = np.unique(np.concatenate([c[1] for c in cubic if c[0] == 'cubic-3'] or [np.zeros(0, np.int64)])).astype(np.int32)
-        cub2 = np.zeros((m, mask2.size, mask2.size))
-        cub3 = np.zeros((m, mask3.size, mask3.size, mask3.size))
-        for order, im, om, coef in cubic:
-            if order == 'cubic-2':
-                pos = np.searchsorted(mask2, im)
-                for q, o in enumerate(om):
-                    cub2[o][np.ix_(pos, pos)] += coef[q]
-            else:
-                pos = np.searchsorted(mask3, im)
-                n_ = im.size
-                jj, kk, ll = np.meshgrid(np.arange(n_), np.arange(n_), np.arange(n_), indexing='ij')
-                sel = (jj < kk) & (kk < ll)  # only j < k < l is defined (modules/_poly.pyx:86-137)
-                for q, o in enumerate(om):
-                    cub3[o, pos[jj[sel]], pos[kk[sel]], pos[ll[sel]]] += coef[q][sel]
-        self.d, self.m = d, m
-        ds = _lib.PolymodelDesc()
-        keep = []
-
-        def f64(a):
-            a = np.ascontiguousarray(a, dtype=np.float64)
-            keep.append(a)
-            return a.ctypes.data_as(C.POINTER(C.c_double))
-
-        ds.d, ds.m = d, m
-        ds.c0, ds.lin = f64(c0), f64(lin)
-        if has_quad:
-            ds.quad = f64(quad)
-        if mask2.size:
-            keep.append(mask2)
-            ds.n2, ds.mask2, ds.cubic2 = int(mask2.size), mask2.ctypes.data_as(C.POINTER(C.c_int)), f64(cub2)
-        if mask3.size:
-            keep.append(mask3)
-            ds.n3, ds.mask3, ds.cubic3 = int(mask3.size), mask3.ctypes.data_as(C.POINTER(C.c_int)), f64(cub3)
-        if poly.get('use_bound', False) and (has_quad or cubic):  # (not for an all-linear model, modules/poly.py:467)
-            ds.use_bound = 1
-            ds.mu, ds.hess = f64(poly['mu']), f64(poly['hess'])
-            ds.alpha = float(poly['alpha'])
-            ds.f_mu = f64(np.asarray(poly['f_mu'], dtype=np.float64).reshape(m))
+        self.d, self.m = int(poly['input_size']), int(poly['output_size'])
+        ds, keep = polymodel_desc_from_poly(poly)
         self._desc, self._keep = ds, keep
         self._uploaded = None
 

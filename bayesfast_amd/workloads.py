@@ -4,8 +4,8 @@ Only NumPy: these build the density *spec* (plain dict) that both the device pat
 """
 import numpy as np
 
-__all__ = ['correlated_gaussian_spec', 'banana_logp', 'funnel_logp', 'planck_like_logp', 'sobol_normal', 'B_STEP_BYTES',
-           'flops_per_leapfrog', 'flops_per_leapfrog_spec']
+__all__ = ['correlated_gaussian_spec', 'banana_logp', 'funnel_logp', 'planck_like_logp', 'des_like_pipeline', 'sobol_normal',
+           'B_STEP_BYTES', 'flops_per_leapfrog', 'flops_per_leapfrog_spec']
 
 
 def B_STEP_BYTES(d):
@@ -113,6 +113,47 @@ def planck_like_logp(d=128, seed=18, n_cubic=16, amp=0.02):
     return logp, np.linalg.cholesky((R * lam) @ R.T)
 
 
+def des_like_pipeline(d=27, m=457, n_nonlinear=9, n_prior=13, seed=1):
+    """The shape of examples/des-y1-w-cosmosis.ipynb (cells 9-18) with a synthetic theory model (the notebook's is CosmoSIS,
+    which nothing here can run): d = 27 parameters in a box ``para_range`` with hard bounds, a theory vector of m = 457
+    whitened data points that is linear in all parameters and quadratic (plus a small non-polynomial term, so that the
+    surrogate is not exact) in ``nonlinear`` = 9 of them, like = -|theory - data|^2 / 2 + norm, and a Gaussian prior on 13
+    of the parameters.  Returns a dict: para_range (d, 2), nonlinear, model(x (n, d)) -> (n, m), data (m,), norm, prior_mu /
+    prior_prec (d,), prior_c0, x_true, and logp(x) the true log-density."""
+    rng = np.random.default_rng(seed)
+    lo = -1. - rng.uniform(size=d)
+    hi = 1. + rng.uniform(size=d)
+    para_range = np.stack([lo, hi], 1)
+    nonlinear = np.sort(rng.choice(d, n_nonlinear, replace=False))
+    A = rng.normal(size=(m, d))
+    B = rng.normal(size=(m, n_nonlinear, n_nonlinear)) * 0.5
+    t0 = rng.normal(size=m) * 3.
+    u_true = rng.uniform(0.35, 0.65, size=d)
+
+    def model(x):
+        u = (np.atleast_2d(np.asarray(x, dtype=np.float64)) - lo) / (hi - lo)
+        z = u[:, nonlinear]
+        return t0 + u @ A.T + np.einsum('ojk,nj,nk->no', B, z, z, optimize=True) + 0.1 * np.sin(3. * z[:, :1])
+
+    x_true = lo + u_true * (hi - lo)
+    data = model(x_true)[0] + rng.normal(size=m)
+    norm = -0.5 * m * np.log(2 * np.pi)
+    pidx = np.sort(rng.choice(d, n_prior, replace=False))
+    prior_mu, prior_prec = np.zeros(d), np.zeros(d)
+    sig = 0.05 * (hi - lo)[pidx]
+    prior_mu[pidx] = x_true[pidx] + 0.3 * sig * rng.normal(size=n_prior)
+    prior_prec[pidx] = 1. / sig**2
+    prior_c0 = float(-0.5 * np.sum(np.log(2 * np.pi * sig**2)))
+
+    def logp(x):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        r = model(x) - data
+        return -0.5 * np.sum(r * r, axis=1) + norm + prior_c0 - 0.5 * np.sum(prior_prec * (x - prior_mu)**2, axis=1)
+
+    return dict(d=d, m=m, para_range=para_range, nonlinear=nonlinear, model=model, data=data, norm=float(norm), prior_mu=prior_mu,
+                prior_prec=prior_prec, prior_c0=prior_c0, x_true=x_true, logp=logp)
+
+
 def flops_per_leapfrog_spec(spec):
     """Algorithmic flops of one leapfrog step on a density spec: one d x d matvec (2 d^2) each for S x, the bound's
     H (x - mu) and the decay term's H_d (x - mu_d), plus the cubic configs' contractions on their masked inputs
@@ -120,6 +161,19 @@ def flops_per_leapfrog_spec(spec):
     d = int(spec['d'])
     poly = spec['poly']
     orders = {c['order']: np.asarray(c['input_mask']).size for c in poly['configs']}
+    if spec.get('chi2') is not None:
+        # pipeline density: f = C phi and C^T r, C (m, n_monomials) with the configs' masks (bfhip_pld.h), plus the matvecs of
+        # the bound and of the decay term; a full precision matrix is folded into C at upload and costs nothing per step
+        nf = 1
+        for c in poly['configs']:
+            n = np.asarray(c['input_mask']).size
+            nf += {'linear': n, 'quadratic': n * (n + 1) // 2, 'cubic-2': n * n, 'cubic-3': n * (n - 1) * (n - 2) // 6}[c['order']]
+        f = 4 * int(poly['output_size']) * nf
+        if poly.get('use_bound'):
+            f += 2 * d * d
+        if spec.get('use_decay'):
+            f += 2 * d * d
+        return f
     f = 0
     if 'quadratic' in orders:
         f += 2 * d * d

@@ -399,8 +399,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
     t_fit = {}
     # launch lengths that keep a block within seconds: the banana's refitted surrogate and config 5 run every tree to the
     # depth limit (1023 leapfrogs per iteration)
-    iters = iters or {'gauss32': 250, 'banana_decay': 50, 'funnel': 100, 'cubic128': 20}[name]
-    n_adapt = n_adapt or {'gauss32': 500, 'banana_decay': 200, 'funnel': 300, 'cubic128': 150}[name]
+    iters = iters or {'gauss32': 250, 'banana_decay': 50, 'funnel': 100, 'cubic128': 20, 'des_pipeline': 100}[name]
+    n_adapt = n_adapt or {'gauss32': 500, 'banana_decay': 200, 'funnel': 300, 'cubic128': 150, 'des_pipeline': 300}[name]
 
     def fit(den, x, lp, key):
         torch.cuda.synchronize()
@@ -409,6 +409,40 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         torch.cuda.synchronize()
         t_fit[key] = (time.perf_counter() - t0) * 1e3
 
+    if name == 'des_pipeline':
+        # SURVEY 8f-1, the reference's real use (examples/des-y1-w-cosmosis.ipynb): a 457-output surrogate (linear in all 27
+        # parameters, quadratic in 9), a whitened chi-square and a Gaussian prior, behind the box transform with hard bounds;
+        # NUTS runs on it inside the fused kernel (bfhip_pld.h: two FP64-MFMA contractions per gradient)
+        from bayesfast_amd.workloads import des_like_pipeline
+        w = des_like_pipeline()
+        d, m, C = w['d'], w['m'], chains or 4096
+        su = bfa.PolyModel([bfa.PolyConfig('linear'), bfa.PolyConfig('quadratic', input_mask=w['nonlinear'])], input_size=d,
+                           output_size=m, input_scales=w['para_range'])
+        den = bfa.Chi2PipelineDensity(su, w['data'], prec_diag=np.ones(m), logp0=w['norm'], prior_mu=w['prior_mu'],
+                                      prior_prec=w['prior_prec'], prior_c0=w['prior_c0'], input_scales=w['para_range'], hard_bounds=True)
+        lo, hi = w['para_range'][:, 0], w['para_range'][:, 1]
+        u_true = (w['x_true'] - lo) / (hi - lo)
+        n_fit = 4 * su.n_param
+        x_fit = lo + (hi - lo) * np.clip(u_true + 0.08 * rng.normal(size=(n_fit, d)), 0.02, 0.98)
+        y_fit = w['model'](x_fit)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        den.fit(x_fit, w['logp'](x_fit), y=y_fit)
+        torch.cuda.synchronize()
+        t_fit['fit_ms'] = (time.perf_counter() - t0) * 1e3
+        x0 = den.from_original(lo + (hi - lo) * np.clip(u_true + 0.02 * rng.normal(size=(C, d)), 0.02, 0.98))
+        what = ('SURVEY 8f-1 / examples/des-y1-w-cosmosis.ipynb shape: %d chains x %d parameters (box transform, hard bounds), surrogate '
+                'of %d outputs = linear + quadratic on %d inputs (%d coefficients per output, fitted on %d points), whitened chi-square '
+                '+ Gaussian prior on 13 parameters, bound on' % (C, d, m, len(w['nonlinear']), su.n_param, n_fit))
+        r, s_, _ = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what)
+        so = den.to_original_device(s_).reshape(-1, d)
+        r['posterior_mean_offset_in_prior_sigma'] = float(np.max(np.abs((so.mean(0).cpu().numpy() - w['x_true']) / (0.05 * (hi - lo)))))
+        sp = den.spec()
+        pl = sp['poly']
+        r['pipeline'] = {'outputs': m, 'monomials': 1 + d + len(w['nonlinear']) * (len(w['nonlinear']) + 1) // 2,
+                         'coefficient_matrix_bytes': 8 * m * (1 + d + len(w['nonlinear']) * (len(w['nonlinear']) + 1) // 2),
+                         'use_bound': bool(pl.get('use_bound'))}
+        return dict(r, **t_fit)
     if name == 'gauss32':
         from bayesfast_amd.workloads import correlated_gaussian_spec, sobol_normal
         d, C = 32, chains or 1024
@@ -477,8 +511,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
     raise ValueError(name)
 
 
-CONFIG_BLOCKS = ('gauss32', 'banana_decay', 'funnel', 'cubic128')
-CONFIG_KEYS = ('config2', 'config3', 'config4', 'config5')
+CONFIG_BLOCKS = ('gauss32', 'banana_decay', 'funnel', 'cubic128', 'des_pipeline')
+CONFIG_KEYS = ('config2', 'config3', 'config4', 'config5', 'pipeline_des')
 
 
 def _spawn_ranks(n, backend):

@@ -295,6 +295,43 @@ int bfhip_chi2_stage(bfhip_ctx *ctx, int n, int m, int d, const double *f, const
                      const double *prec_diag, double logp0, double *logp, double *grad);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pipeline density: the density of a Density whose module list is
+ *   [model (replaced by a multi-output PolyModel surrogate), Gaussian likelihood of its m outputs, optional prior module]
+ * with use_surrogate=True -- core/density.py:487-566 (the surrogate replaces the modules of its scope, :527-551; every
+ * later module's Jacobian multiplies the ones before it, :552-560), modules/poly.py:430-503 (multi-output evaluation and
+ * the bound's linear extrapolation), core/density.py:724-754 (transform, decay); the shape of
+ * examples/des-y1-w-cosmosis.ipynb cells 12-18 (d = 27, m = 457: chi2_f / chi2_fj on the whitened data vector, des_post_f /
+ * des_post_fj adding a Gaussian prior of some inputs).
+ *   like  = logp0 - (f(x) - y)^T prec (f(x) - y) / 2          prec (m,m) symmetric positive definite, or diag(prec_diag)
+ *   logp  = like + prior_c0 - sum_i prior_prec[i] (x_i - prior_mu[i])^2 / 2        (prior_*: original-space inputs; optional)
+ * After the upload this IS the context's density: bfhip_logp_grad, bfhip_constraint and bfhip_sampler_run (NUTS / HMC,
+ * diagonal metric, d <= 64) run on it.  The (m, d) Jacobian is never formed: the Cholesky factor of prec is folded into
+ * the coefficient matrix at upload and grad = -(d phi / dx)^T C'^T (C' phi - y') is two FP64-MFMA contractions per
+ * evaluation with the 16 chains of a workgroup as columns (bayesfast_amd/csrc/bfhip_pld.h).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int d, m;
+    const double *ranges;         /* as bfhip_density_desc */
+    const uint8_t *hard_bounds;
+    const double *su_lo, *su_diff;
+    bfhip_polymodel_desc model;   /* the surrogate: dense per-output coefficients, masks scattered; model.d = d, model.m = m */
+    const double *y;              /* (m) */
+    const double *prec;           /* (m,m) row-major, or NULL */
+    const double *prec_diag;      /* (m) when prec is NULL */
+    double logp0;
+    const double *prior_mu;       /* (d) or NULL */
+    const double *prior_prec;     /* (d) inverse variances, 0 where an input has no prior; NULL with prior_mu */
+    double prior_c0;
+    int use_decay;                /* as bfhip_density_desc */
+    const double *decay_mu, *decay_hess;
+    double decay_alpha2, decay_gamma;
+} bfhip_pipeline_desc;
+
+/* Copies, whitens and re-lays-out the description into device memory.  Synchronous.  BFHIP_ERR_ARG when prec is not positive
+ * definite; BFHIP_ERR_UNSUPPORTED when d > 64 or the working set of one workgroup does not fit the CU's LDS. */
+int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *desc);
+
+/* ------------------------------------------------------------------------------------------------
  * Surrogate fit, PolyModel.fit (modules/poly.py:505-589).
  * ---------------------------------------------------------------------------------------------- */
 /* Design-matrix block for one PolyConfig: x (n, n_in) gathered inputs -> A[:, col0 : col0+width] of the

@@ -495,6 +495,10 @@ def test_surrogate_plus_chi2_pipeline_matches_reference_density():
     lp, g = ref.logp_and_grad(z['xt'])
     np.testing.assert_allclose(lp, z['logp'], rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(g, z['grad'], rtol=1e-9, atol=1e-9 * np.abs(z['grad']).max())
+    # the first implementation (f and the (n, m, d) Jacobians, then the chi-square stage) is a second, independent route
+    lpd, gd = ref.logp_and_grad_device(z['xt'])
+    np.testing.assert_allclose(lpd.cpu().numpy(), lp, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(gd.cpu().numpy(), g, rtol=1e-10, atol=1e-10 * np.abs(z['grad']).max())
     lp1, g1 = ref.logp_and_grad(z['xt'][30])
     np.testing.assert_allclose([lp1], [z['logp'][30]], rtol=1e-10)
     np.testing.assert_allclose(g1, z['grad'][30], rtol=1e-9, atol=1e-9 * np.abs(z['grad']).max())

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Pipeline density (bfhip_pld.h) on its own: the stand-alone evaluation's rate and the fused sampler's, on a synthetic
+DES-shaped density (random coefficients, no fit), to separate the cost of the two contractions from the sampler's.
+
+  python3 tools/pld_rate.py [m] [d] [n_quad_inputs] [chains]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def spec_of(m, d, nq, seed=0, bound=True, transform=True):
+    rng = np.random.default_rng(seed)
+    mask = np.sort(rng.choice(d, nq, replace=False))
+    lin = rng.normal(size=(m, d + 1))
+    quad = np.zeros((m, nq, nq))
+    iu = np.triu_indices(nq)
+    quad[:, iu[0], iu[1]] = rng.normal(size=(m, iu[0].size)) * 0.3
+    x = rng.normal(size=(400, d)) * 0.3 + 0.5
+    mu = x.mean(0)
+    hess = np.linalg.inv(np.cov(x, rowvar=False))
+    alpha = float(np.max(np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5)) * (1. if bound else 1e6)
+    poly = dict(input_size=d, output_size=m, use_bound=True, mu=mu, hess=hess, alpha=alpha, f_mu=np.zeros(m),
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(m), coef=lin),
+                         dict(order='quadratic', input_mask=mask, output_mask=np.arange(m), coef=quad)])
+    u0 = np.full(d, 0.5)
+    f0 = lin[:, 0] + lin[:, 1:] @ u0 + np.einsum('ojk,j,k->o', quad, u0[mask], u0[mask])
+    rg = np.stack([-np.ones(d), np.ones(d)], 1) * 2.
+    return dict(d=d, ranges=rg if transform else None, hard_bounds=np.ones((d, 2), np.uint8) if transform else None,
+                su_lo=rg[:, 0] if transform else None, su_diff=(rg[:, 1] - rg[:, 0]) if transform else None, poly=poly, use_decay=False,
+                chi2=dict(y=f0 + rng.normal(size=m), prec_diag=np.ones(m), logp0=0.),
+                prior=dict(mu=np.zeros(d), prec_diag=np.where(np.arange(d) % 2, 4., 0.), c0=0.))
+
+
+def main():
+    import torch
+    from bayesfast_amd.device import get_context, DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import flops_per_leapfrog_spec
+    m = int(sys.argv[1]) if len(sys.argv) > 1 else 457
+    d = int(sys.argv[2]) if len(sys.argv) > 2 else 27
+    nq = int(sys.argv[3]) if len(sys.argv) > 3 else 9
+    C = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    ctx = get_context(0)
+    spec = spec_of(m, d, nq)
+    dd = DeviceDensity(spec, ctx)
+    fl = flops_per_leapfrog_spec(spec)
+    rng = np.random.default_rng(1)
+    out = {'m': m, 'd': d, 'n_quad': nq, 'flops_per_eval': fl}
+    n = 65536
+    x = ctx.tensor(rng.normal(size=(n, d)) * 0.2)
+    dd.logp_and_grad(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(ctx.stream)
+    for _ in range(5):
+        dd.logp_and_grad(x)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / 5
+    out['eval'] = {'points_per_s': n / t, 'TFLOPs': n * fl / t / 1e12, 'us_per_16_points_per_cu': t * 1e6 / (n / 16 / 256)}
+    x0 = rng.normal(size=(C, d)) * 0.1
+    ch = DeviceChains(dd, x0, seed=1)
+    ch.run(150, 'NUTS', n_warmup=150, check=False)
+    lf0 = ch.total_leapfrog
+    torch.cuda.synchronize()
+    e0.record(ctx.stream)
+    _, st = ch.run(50, 'NUTS', n_warmup=150, check=False)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    ch.raise_on_error()
+    t = e0.elapsed_time(e1) * 1e-3
+    nl = ch.total_leapfrog - lf0
+    out['nuts'] = {'leapfrog_per_s': nl / t, 'TFLOPs': nl * fl / t / 1e12, 'mean_tree_size': float(st[:, :, 3].mean()),
+                   'us_per_trip': t * 1e6 / (50 * (float(st[:, :, 3].mean()) + 1))}
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
