@@ -32,7 +32,7 @@ import copy
 
 import numpy as np
 
-__all__ = ['reference_classes', 'PolyModel', 'GaussianLikelihood', 'sample', 'patch', 'as_surrogate_density']
+__all__ = ['reference_classes', 'PolyModel', 'GaussianLikelihood', 'GaussianPrior', 'GaussianBaseDensity', 'sample', 'patch', 'as_surrogate_density']
 
 _CLASSES = {}
 
@@ -83,25 +83,106 @@ def reference_classes(bayesfast=None):
                 self._set_bound(np.asarray(x), logp)  # the reference's own host code (modules/poly.py:262-292)
 
     class GaussianLikelihood(bf.core.module.Module):
-        __doc__ = ("logp = logp0 - prec (m - y)^2 / 2 of ONE scalar variable m, as a ``bayesfast.Module`` with analytic "
-                   "fun / jac: the module downstream of a single-output surrogate that the device density can chain in "
-                   "the kernel (core/density.py:552-560).")
+        __doc__ = ("like = logp0 - (m - y)^T prec (m - y) / 2 of a surrogate's output variable m, as a ``bayesfast.Module`` with "
+                   "analytic fun / jac: the module downstream of a surrogate that the device density chains in the kernel "
+                   "(core/density.py:552-560).  Scalar y and prec: the likelihood of a single-output surrogate "
+                   "(examples/2d-donut.ipynb's second module).  y (m,) with prec (m, m), prec_diag (m,) or neither (identity): "
+                   "the chi-square of a multi-output surrogate (examples/des-y1-w-cosmosis.ipynb cell 12: chi2_f / chi2_fj).")
 
-        def __init__(self, y, prec, logp0=0., input_vars='__var__', output_vars='__var__', **kwargs):
-            self._bfhip_link = dict(kind='gaussian', y=float(y), prec=float(prec), logp0=float(logp0))
-            if not self._bfhip_link['prec'] > 0:
-                raise ValueError('prec should be positive.')
-            lk = self._bfhip_link
+        def __init__(self, y, prec=None, logp0=0., input_vars='__var__', output_vars='__var__', prec_diag=None, **kwargs):
+            yv = np.atleast_1d(np.asarray(y, dtype=np.float64))
+            if yv.ndim != 1:
+                raise ValueError('y should be a scalar or a 1-d array.')
+            m = yv.size
+            if m == 1 and prec_diag is None and np.ndim(prec) == 0 and prec is not None:
+                self._bfhip_link = dict(kind='gaussian', y=float(yv[0]), prec=float(prec), logp0=float(logp0))
+                if not self._bfhip_link['prec'] > 0:
+                    raise ValueError('prec should be positive.')
+                lk = self._bfhip_link
 
-            def fun(m):
-                r = np.asarray(m, dtype=np.float64) - lk['y']
-                return lk['logp0'] - 0.5 * (r * (lk['prec'] * r))
+                def fun(mm):
+                    r = np.asarray(mm, dtype=np.float64) - lk['y']
+                    return lk['logp0'] - 0.5 * (r * (lk['prec'] * r))
 
-            def jac(m):
-                r = np.atleast_1d(np.asarray(m, dtype=np.float64) - lk['y'])
-                return np.diag(-(lk['prec'] * r))
+                def jac(mm):
+                    r = np.atleast_1d(np.asarray(mm, dtype=np.float64) - lk['y'])
+                    return np.diag(-(lk['prec'] * r))
+            else:
+                if prec is not None and prec_diag is not None:
+                    raise ValueError('give me at most one of prec and prec_diag.')
+                P = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64).reshape(m, m)
+                pd = (np.ones(m) if P is None else None) if prec_diag is None else np.ascontiguousarray(prec_diag, dtype=np.float64).reshape(m)
+                self._bfhip_chi2 = dict(y=yv.copy(), prec=P, prec_diag=pd, logp0=float(logp0))
+                c2 = self._bfhip_chi2
+
+                def _r(mm):
+                    dlt = np.asarray(mm, dtype=np.float64).reshape(m) - c2['y']
+                    return dlt, (c2['prec'] @ dlt if c2['prec'] is not None else c2['prec_diag'] * dlt)
+
+                def fun(mm):
+                    dlt, r = _r(mm)
+                    return np.atleast_1d(c2['logp0'] - 0.5 * (dlt @ r))
+
+                def jac(mm):
+                    return -_r(mm)[1][np.newaxis]
 
             super().__init__(fun=fun, jac=jac, input_vars=input_vars, output_vars=output_vars, **kwargs)
+
+    class GaussianPrior(bf.core.module.Module):
+        __doc__ = ("logp = like + c0 - sum_i prec[i] (x_i - mu[i])^2 / 2: the LAST module of a pipeline, reading the likelihood "
+                   "variable and the density's input variable (examples/des-y1-w-cosmosis.ipynb cell 12: des_post_f / "
+                   "des_post_fj), evaluated inside the kernel as the prior stage of the pipeline density.  mu, prec: (d,), "
+                   "prec[i] = 0 for inputs without a prior; or indices + mu + sigma for the inputs that have one.")
+
+        def __init__(self, input_size, mu=None, prec=None, c0=0., indices=None, sigma=None, input_vars=('like', 'x'), output_vars='logp',
+                     **kwargs):
+            d = int(input_size)
+            if indices is not None:
+                idx = np.asarray(indices, dtype=int).reshape(-1)
+                mu_full, prec_full = np.zeros(d), np.zeros(d)
+                mu_full[idx] = np.asarray(mu, dtype=np.float64).reshape(-1)
+                prec_full[idx] = 1. / np.asarray(sigma, dtype=np.float64).reshape(-1)**2
+            else:
+                mu_full = np.ascontiguousarray(mu, dtype=np.float64).reshape(d)
+                prec_full = np.ascontiguousarray(prec, dtype=np.float64).reshape(d)
+            if not np.all(prec_full >= 0):
+                raise ValueError('the prior precisions should be non-negative.')
+            self._bfhip_prior = dict(mu=mu_full, prec_diag=prec_full, c0=float(c0))
+            pr = self._bfhip_prior
+
+            def fun(like, x):
+                dx = np.asarray(x, dtype=np.float64) - pr['mu']
+                return np.atleast_1d(like) + pr['c0'] - 0.5 * np.sum(pr['prec_diag'] * dx * dx)
+
+            def jac(like, x):
+                dx = np.asarray(x, dtype=np.float64) - pr['mu']
+                return np.concatenate((np.ones((1, 1)), -(pr['prec_diag'] * dx)[np.newaxis]), axis=-1)
+
+            super().__init__(fun=fun, jac=jac, input_vars=list(input_vars), output_vars=output_vars, **kwargs)
+
+    class GaussianBaseDensity(bf.core.density.DensityLite):
+        __doc__ = ("The base density of the tempered samplers, N(mean, cov) in the sampler's space, as a ``bayesfast.DensityLite`` "
+                   "with analytic logp / grad: ``TNTrace(density_base=GaussianBaseDensity(mean, cov), logxi=...)`` passes the "
+                   "reference's type check (samplers/sample_trace.py:547-555) and the device's tempered kernel reads mean and "
+                   "cov from it (``bfhip_tnuts_run`` takes a quadratic base log-density).")
+
+        def __init__(self, mean, cov):
+            mean = np.atleast_1d(np.asarray(mean, dtype=np.float64))
+            cov = np.atleast_2d(np.asarray(cov, dtype=np.float64))
+            if cov.shape != (mean.size, mean.size):
+                raise ValueError('cov should have shape (d, d).')
+            prec = np.linalg.inv(cov)
+            c0 = -0.5 * (mean.size * np.log(2 * np.pi) + np.linalg.slogdet(cov)[1])
+            self._bfhip_gaussian = dict(mean=mean, cov=cov)
+
+            def logp(x):
+                r = np.asarray(x, dtype=np.float64) - mean
+                return c0 - 0.5 * np.einsum('...i,ij,...j->...', r, prec, r)
+
+            def grad(x):
+                return -(np.asarray(x, dtype=np.float64) - mean) @ prec
+
+            super().__init__(logp=logp, grad=grad, input_size=mean.size, vectorized=True)
 
     class _ChainStats:
         """Mixin: the per-chain statistics as arrays (``NStats`` / ``HStats`` keep Python lists, stats.py:39-52)."""
@@ -123,6 +204,9 @@ def reference_classes(bayesfast=None):
         pass
 
     class _HStats(_ChainStats, stats_mod.HStats):
+        pass
+
+    class _TNStats(_ChainStats, stats_mod.TNStats):
         pass
 
     class TraceTuple(st.TraceTuple):
@@ -214,11 +298,15 @@ def reference_classes(bayesfast=None):
             t._samples = inner._samples[i]
             t._samples_original = inner._samples_original[i]
             t._logp_original = inner._logp_original[i]
-            cls = _HStats if self._sampler == 'HMC' else _NStats
-            t._stats = cls()._fill(inner._stats[i], inner.n_warmup)
+            if self._sampler == 'TNUTS':   # TNStats: (u, weight) in front of the NUTS columns (samplers/hmc_utils/stats.py:22-24)
+                t._stats = _TNStats()._fill(np.concatenate([inner._array('stats_t')[i], inner._stats[i]], axis=1), inner.n_warmup)
+            else:
+                cls = _HStats if self._sampler == 'HMC' else _NStats
+                t._stats = cls()._fill(inner._stats[i], inner.n_warmup)
             return t
 
-    ns = SimpleNamespace(bayesfast=bf, PolyModel=PolyModel, GaussianLikelihood=GaussianLikelihood, TraceTuple=TraceTuple,
+    ns = SimpleNamespace(bayesfast=bf, PolyModel=PolyModel, GaussianLikelihood=GaussianLikelihood, GaussianPrior=GaussianPrior,
+                         GaussianBaseDensity=GaussianBaseDensity, TraceTuple=TraceTuple,
                          _our_st=_our_st)
     _CLASSES[id(bf)] = ns
     return ns
@@ -232,6 +320,16 @@ def PolyModel(*args, **kwargs):
 def GaussianLikelihood(*args, **kwargs):
     """``reference_classes().GaussianLikelihood(...)``."""
     return reference_classes().GaussianLikelihood(*args, **kwargs)
+
+
+def GaussianBaseDensity(*args, **kwargs):
+    """``reference_classes().GaussianBaseDensity(...)``."""
+    return reference_classes().GaussianBaseDensity(*args, **kwargs)
+
+
+def GaussianPrior(*args, **kwargs):
+    """``reference_classes().GaussianPrior(...)``."""
+    return reference_classes().GaussianPrior(*args, **kwargs)
 
 
 def as_surrogate_density(density):
@@ -251,10 +349,18 @@ def as_surrogate_density(density):
     sl, ml = list(density._surrogate_list), list(density._module_list)
     if getattr(density, '_use_surrogate', True) is False or len(sl) == 0:
         raise NotImplementedError('the device sampler runs the SURROGATE density; this Density is not using one.')
-    if len(sl) != 1 or int(sl[0]._output_size) != 1:
-        raise NotImplementedError('the device sampler takes exactly one PolyModel surrogate with output_size 1.')
+    if len(sl) != 1:
+        raise NotImplementedError('the device sampler takes exactly one PolyModel surrogate.')
     su = sl[0]
     i_step, n_step = int(su._scope[0]) % max(len(ml), 1), int(su._scope[1])
+    rest = ml[n_step:] if i_step == 0 else None
+    if rest is not None and len(rest) >= 1 and hasattr(rest[0], '_bfhip_chi2') and len(rest) <= 2:
+        # [surrogate of the first modules (any output_size), Gaussian likelihood of its outputs(, Gaussian prior)]: the pipeline
+        # density (bfhip_pipeline_upload; examples/des-y1-w-cosmosis.ipynb cells 12-18)
+        return _pipeline_density_from_reference(density, su, rest)
+    if int(su._output_size) != 1:
+        raise NotImplementedError('a surrogate with output_size > 1 needs a bayesfast_amd.integrate.GaussianLikelihood of its '
+                                  'outputs (and optionally a GaussianPrior) as the modules behind it.')
     link = None
     if i_step == 0 and n_step == len(ml):
         pass
@@ -268,6 +374,47 @@ def as_surrogate_density(density):
                                   'bayesfast_amd.integrate.GaussianLikelihood of its output runs inside the kernel.')
     out = surrogate_density_from_reference(density)
     out.link = link
+    out._device = None
+    return out
+
+
+def _pipeline_density_from_reference(density, su, rest):
+    """The reference ``Density`` [.., surrogate ``su``, GaussianLikelihood(, GaussianPrior)] -> ``Chi2PipelineDensity`` with the
+    reference object's surrogate coefficients, bound, transforms and decay state (attributes read by duck typing)."""
+    from .core.density import Chi2PipelineDensity
+    from .adapters import polymodel_from_reference
+    like = rest[0]
+    if list(like.input_vars) != list(su.output_vars):
+        raise NotImplementedError('the Gaussian likelihood should read the surrogate\'s output variable.')
+    c2 = like._bfhip_chi2
+    if c2['y'].size != int(su._output_size):
+        raise ValueError('the likelihood\'s data vector and the surrogate\'s output_size disagree.')
+    prior = None
+    if len(rest) == 2:
+        post = rest[1]
+        if not hasattr(post, '_bfhip_prior'):
+            raise NotImplementedError('the module behind the likelihood is arbitrary Python; only a '
+                                      'bayesfast_amd.integrate.GaussianPrior runs inside the kernel.')
+        if list(post.input_vars) != list(like.output_vars) + list(density.input_vars):
+            raise NotImplementedError('the prior module should read [the likelihood variable, the density\'s input variable].')
+        prior = post._bfhip_prior
+    d = int(density.input_size)
+    if list(su.input_vars) != list(density.input_vars) or int(su._input_size) != d:
+        raise NotImplementedError('the surrogate should read the density\'s whole input.')
+    hb = density._hard_bounds
+    hb = bool(hb) if isinstance(hb, (bool, np.bool_)) else np.array(hb)
+    out = Chi2PipelineDensity(polymodel_from_reference(su), c2['y'], prec=c2['prec'], prec_diag=c2['prec_diag'], logp0=c2['logp0'],
+                              prior_mu=None if prior is None else prior['mu'], prior_prec=None if prior is None else prior['prec_diag'],
+                              prior_c0=0. if prior is None else prior['c0'],
+                              input_scales=None if density._input_scales is None else np.array(density._input_scales, dtype=np.float64),
+                              hard_bounds=hb if density._input_scales is not None else False,
+                              decay_options=dict(use_decay=bool(density._use_decay)))
+    if density._use_decay:
+        out._mu = np.array(density._mu, dtype=np.float64)
+        out._hess = np.array(density._hess, dtype=np.float64)
+        out._alpha_2 = float(density._alpha_2)
+        out._alpha = float(density._alpha_2)**0.5
+        out._gamma = float(density._gamma)
     out._device = None
     return out
 
@@ -313,7 +460,10 @@ def _our_trace(ns, ref_trace, sampler):
     # one integer from the trace's generator seeds the per-chain xoshiro streams (the reference spawns one PCG64 per chain
     # from the same generator, samplers/sample_trace.py:192-193)
     kw['random_generator'] = int(ref_trace.random_generator.integers(0, 2**63 - 1))
-    if sampler == 'NUTS':
+    if sampler == 'TNUTS':
+        gb = ref_trace.density_base._bfhip_gaussian
+        t = st.TNTrace(st.GaussianBase(gb['mean'], gb['cov']), logxi=ref_trace.logxi, max_treedepth=ref_trace._max_treedepth, **kw)
+    elif sampler == 'NUTS':
         t = st.NTrace(max_treedepth=ref_trace._max_treedepth, **kw)
     else:
         t = st.HTrace(n_int_step=ref_trace._n_int_step, **kw)
@@ -341,12 +491,21 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
             sample_trace = st.NTrace(**kw)
         elif sampler == 'HMC':
             sample_trace = st.HTrace(**kw)
-        elif sampler in ('TNUTS', 'THMC', 'Ensemble'):
-            raise NotImplementedError('the drop-in seam covers NUTS and HMC.')
+        elif sampler == 'TNUTS':   # core/sample.py:83-84
+            sample_trace = st.TNTrace(**kw)
+        elif sampler == 'THMC':
+            raise NotImplementedError('THMC: the reference\'s own THTrace constructor raises (samplers/sample_trace.py:600).')
+        elif sampler == 'Ensemble':
+            raise NotImplementedError
         else:
             raise ValueError('unexpected value for sampler.')
-    elif isinstance(sample_trace, (st.TNTrace, st.THTrace)):
-        raise NotImplementedError('the drop-in seam covers NUTS and HMC.')
+    if isinstance(sample_trace, st.THTrace):
+        raise NotImplementedError('the drop-in seam covers NUTS, HMC and TNUTS.')
+    elif isinstance(sample_trace, st.TNTrace):
+        sampler = 'TNUTS'
+        if not hasattr(sample_trace.density_base, '_bfhip_gaussian'):
+            raise NotImplementedError('the device\'s tempered sampler takes a Gaussian base density: '
+                                      'bayesfast_amd.integrate.GaussianBaseDensity(mean, cov).')
     elif isinstance(sample_trace, st.NTrace):
         sampler = 'NUTS'
     elif isinstance(sample_trace, st.HTrace):

@@ -36,6 +36,31 @@ class OracleDensity:
         return torch.from_numpy(np.atleast_1d(lp)), torch.from_numpy(np.atleast_2d(g))
 
 
+class OracleTransform:
+    """``DeviceDensity.constraint`` for a density with input scales, answered by the oracle's transforms (row by row)."""
+    _FN = {'from_original': 'bfo_from_original_f', 'from_original_grad': 'bfo_from_original_j', 'from_original_grad2': 'bfo_from_original_jj',
+           'to_original': 'bfo_to_original_f', 'to_original_grad': 'bfo_to_original_j', 'to_original_grad2': 'bfo_to_original_jj'}
+
+    def __init__(self, ranges, hard_bounds):
+        self.ranges = np.ascontiguousarray(ranges, dtype=np.float64)
+        self.hb = np.ascontiguousarray(hard_bounds, dtype=np.uint8)
+
+    def constraint(self, which, x):
+        import ctypes as C
+        dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+        xt = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
+        shape = xt.shape
+        rows = np.ascontiguousarray(xt.reshape(-1, shape[-1]), dtype=np.float64)
+        out = np.empty_like(rows)
+        f = getattr(orc.lib(), self._FN[which])
+        for i in range(rows.shape[0]):
+            rc = f(rows[i].ctypes.data_as(dp), self.ranges.ctypes.data_as(dp), out[i].ctypes.data_as(dp), self.hb.ctypes.data_as(up),
+                   rows.shape[1])
+            if which.startswith('from') and rc:
+                raise ValueError('variable #{} out of bound.'.format(rc - 1))
+        return torch.from_numpy(out.reshape(shape))
+
+
 class OracleChains:
     """The constructor and ``run`` arguments of ``DeviceChains``; chains are ``oracle.ChainSet`` on the same xoshiro streams
     (seed, first_stream + i), so what runs here is what the device tests compare the kernels with."""
@@ -69,6 +94,32 @@ class OracleChains:
         self.total_leapfrog += n
         self.last_layout = 'oracle'
         return torch.from_numpy(s), torch.from_numpy(np.stack([st[k] for k in orc.NSTATS], -1))
+
+    def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
+                     target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True, update_window=1,
+                     doubling=True, check=True):
+        """``DeviceChains.run_tempered`` answered by the oracle's TNUTS (one chain after the other, same xoshiro streams)."""
+        i = self._init
+        if getattr(self, 'tchains', None) is None:
+            self.tchains = [orc.Chain(self.x_0[c], step_size=i['step_size'], adapt_step_size=adapt_step_size, target_accept=target_accept,
+                                      gamma=gamma, k=k, t_0=t_0, metric=None, adapt_metric=adapt_metric, initial_mean=i['initial_mean'],
+                                      initial_weight=i['initial_weight'], adapt_window=i['adapt_window'], update_window=update_window,
+                                      doubling=doubling) for c in range(self.n_chain)]
+            self.trngs = [orc.make_rng('xoshiro', seed=i['seed'], stream=i['first_stream'] + c) for c in range(self.n_chain)]
+            self.tu = np.random.default_rng(i['seed']).normal(size=self.n_chain) if u_0 is None else np.asarray(u_0, dtype=np.float64)
+        base = orc.gaussian_base_spec(np.asarray(base_mean, dtype=np.float64), np.asarray(base_cov, dtype=np.float64))
+        ss, sts, stts = [], [], []
+        for c in range(self.n_chain):
+            s, st, u = orc.tnuts_run(self.density.spec, base, float(logxi), self.tchains[c], self.trngs[c], float(self.tu[c]), int(n_run),
+                                     int(n_warmup), max_treedepth=max_treedepth, max_change=max_change)
+            self.tu[c] = u
+            ss.append(s)
+            sts.append(np.stack([st[k] for k in orc.NSTATS], -1))
+            stts.append(np.stack([st['u'], st['weight']], -1))
+            self.total_leapfrog += int(st['tree_size'].sum())
+        self.i_iter += int(n_run)
+        self.cs = type('CS', (), {'chains': self.tchains})()
+        return torch.from_numpy(np.stack(ss)), torch.from_numpy(np.stack(sts)), torch.from_numpy(np.stack(stts))
 
     def raise_on_error(self):
         pass
@@ -111,4 +162,5 @@ def install(monkeypatch):
     from bayesfast_amd.core.density import SurrogateDensity
     monkeypatch.setattr(chains, 'DeviceChains', OracleChains)
     monkeypatch.setattr(SurrogateDensity, 'device', lambda self, ctx=None: OracleDensity(self.spec()))
+    monkeypatch.setattr(SurrogateDensity, '_transform_device', lambda self: OracleTransform(self._input_scales, self._hard_bounds))
     monkeypatch.setattr(integrate, '_device_fit', oracle_fit)

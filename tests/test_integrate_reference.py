@@ -157,3 +157,94 @@ def test_sample_on_the_seam_takes_reference_traces_and_continues(bf, seam):
     den.use_surrogate = False
     with pytest.raises(NotImplementedError):
         integrate.sample(den, {'n_chain': 2, 'n_iter': 20, 'n_warmup': 10})
+
+
+def test_des_shaped_pipeline_on_the_seam(bf, seam):
+    """SURVEY 8f-1 through the seam: a reference ``Density`` with module_list = [model -> m (22 outputs), GaussianLikelihood of m,
+    GaussianPrior(like, x)] and the seam's multi-output PolyModel as the surrogate of the first module
+    (examples/des-y1-w-cosmosis.ipynb cells 12-18 in small).  The seam's analytic modules are real ``bayesfast.Module``s: the
+    reference evaluates the pipeline with them (use_surrogate=True), ``as_surrogate_density`` turns it into the pipeline
+    density the device samples, both give the same logp / grad, and ``bf.sample`` runs NUTS on it."""
+    from bayesfast_amd import integrate
+    from bayesfast_amd.core.density import Chi2PipelineDensity
+    from oracle import oracle as orc
+    rng = np.random.default_rng(91)
+    d, m = 6, 22
+    lo, hi = -1. - rng.uniform(size=d), 1.5 + rng.uniform(size=d)
+    para_range = np.stack([lo, hi], 1)
+    nonlinear = np.array([0, 2, 3])
+    W1 = rng.normal(size=(m, d)) * 0.6
+    W2 = rng.normal(size=(m, 3, 3)) * 0.25
+    dvec = rng.normal(size=m) * 0.3
+
+    def model(x):
+        z = x[nonlinear]
+        return W1 @ x + np.einsum('ojk,j,k->o', W2, z, z) + 0.05 * np.sin(2. * z[0])
+
+    mod0 = bf.Module(fun=model, input_vars='x', output_vars='m')
+    like = seam.GaussianLikelihood(dvec, logp0=-1.5, input_vars='m', output_vars='like')            # identity precision
+    post = seam.GaussianPrior(d, indices=[1, 4, 5], mu=[0.1, -0.2, 0.05], sigma=[0.3, 0.4, 0.25], c0=0.7, input_vars=['like', 'x'],
+                              output_vars='logp')
+    su = seam.PolyModel([bf.modules.PolyConfig('linear'), bf.modules.PolyConfig('quadratic', input_mask=nonlinear)], input_size=d,
+                        output_size=m, input_vars='x', output_vars='m', input_scales=para_range)
+    den = bf.Density(density_name='logp', module_list=[mod0, like, post], surrogate_list=[su], input_vars='x', input_shapes=d,
+                     input_scales=para_range, hard_bounds=True)
+    xf = lo + (hi - lo) * (0.5 + 0.2 * rng.normal(size=(4 * int(su.n_param), d))).clip(0.03, 0.97)
+    den.fit([den.fun(x, original_space=True, use_surrogate=False) for x in xf])                     # the device fit (stand-in here)
+    den.use_surrogate = True
+    ours = integrate.as_surrogate_density(den)
+    assert isinstance(ours, Chi2PipelineDensity) and ours.input_size == d
+    spec = ours.spec()
+    assert spec['chi2']['prec_diag'].shape == (m,) and spec['prior']['prec_diag'][0] == 0. and spec['prior']['prec_diag'][1] > 0.
+    xo = lo + (hi - lo) * rng.uniform(0.05, 0.95, size=(12, d))
+    xt = np.array([den.from_original(x) for x in xo])
+    for sp, pts in ((True, xo), (False, xt)):
+        ref = [den.logp_and_grad(x, original_space=sp, use_surrogate=True) for x in pts]
+        lp, g = orc.logp_and_grad(spec, pts, original_space=sp)
+        np.testing.assert_allclose(lp, [r[0] for r in ref], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(g, [r[1] for r in ref], rtol=1e-10, atol=1e-10)
+    tt = bf.sample(den, bf.samplers.NTrace(n_chain=4, n_iter=60, n_warmup=40, x_0=xo[:4], random_generator=3), verbose=False)
+    assert isinstance(tt, bf.samplers.TraceTuple) and tt.samples.shape == (4, 60, d)
+    s = tt.get()
+    assert np.all(s > lo) and np.all(s < hi) and np.all(np.isfinite(tt.get(return_type='logp')))
+    # a full precision matrix and a likelihood the kernel does not know
+    A = rng.normal(size=(m, m)) * 0.1
+    like2 = seam.GaussianLikelihood(dvec, prec=np.eye(m) + A @ A.T, input_vars='m', output_vars='logp')
+    den2 = bf.Density(density_name='logp', module_list=[mod0, like2], surrogate_list=[su], input_vars='x', input_shapes=d)
+    den2.use_surrogate = True
+    sp2 = integrate.as_surrogate_density(den2).spec()
+    assert sp2['chi2']['prec'].shape == (m, m) and sp2['prior'] is None
+    ref = [den2.logp_and_grad(x, original_space=True, use_surrogate=True) for x in xo[:5]]
+    lp, g = orc.logp_and_grad(sp2, xo[:5], original_space=True)
+    np.testing.assert_allclose(lp, [r[0] for r in ref], rtol=1e-11)
+    np.testing.assert_allclose(g, [r[1] for r in ref], rtol=1e-9, atol=1e-9)
+    den3 = bf.Density(density_name='logp', module_list=[mod0, bf.Module(fun=lambda mm: -0.5 * np.sum(mm**2, keepdims=True), input_vars='m',
+                                                                           output_vars='logp')],
+                      surrogate_list=[su], input_vars='x', input_shapes=d)
+    den3.use_surrogate = True
+    with pytest.raises(NotImplementedError):
+        integrate.as_surrogate_density(den3)
+
+
+def test_tempered_nuts_on_the_seam(bf, seam):
+    """core/sample.py:83-84: ``sample(density, TNTrace(density_base=..., logxi=...))`` -- the reference's own TNTrace, with the
+    seam's GaussianBaseDensity (a real DensityLite, so the trace's type check passes) as the base density; the result is a
+    reference TraceTuple whose chains are TNTraces carrying u and the weights (samplers/sample_trace.py:540-583)."""
+    pm = seam.PolyModel('quadratic', input_size=3, output_size=1, input_vars='x', output_vars='logp')
+    den = bf.Density(module_list=[bf.Module(fun=lambda x: -0.5 * np.sum(x**2, -1, keepdims=True), input_vars='x', output_vars='logp')],
+                     input_shapes=[3], input_vars='x', density_name='logp', surrogate_list=pm)
+    x = np.random.default_rng(1).normal(size=(60, 3)) * 2.
+    pm.fit(x, -0.5 * np.sum(x**2, -1, keepdims=True), -0.5 * np.sum(x**2, -1))
+    den.use_surrogate = True
+    base = seam.GaussianBaseDensity(np.zeros(3), 1.5 * np.eye(3))
+    np.testing.assert_allclose(base.logp(np.ones(3)), -0.5 * 3 / 1.5 - 1.5 * np.log(2 * np.pi * 1.5), rtol=1e-12)
+    tr = bf.samplers.TNTrace(density_base=base, logxi=0.3, n_chain=3, n_iter=50, n_warmup=30, random_generator=8)
+    tt = bf.sample(den, tr, verbose=False)
+    assert isinstance(tt, bf.samplers.TraceTuple) and tt.i_iter == 50 and tt.samples.shape == (3, 50, 3)
+    chains = list(tt)
+    assert all(isinstance(t, bf.samplers.TNTrace) for t in chains)
+    assert chains[0].u.shape == (50,) and chains[0].weights.shape == (50,) and np.all(chains[0].weights > 0)
+    assert len(chains[0].stats._tree_size) == 50 and np.isfinite(bf.samplers._get_step_size(tt))
+    with pytest.raises(NotImplementedError):   # an arbitrary Python base density cannot run inside the kernel
+        bf.sample(den, bf.samplers.TNTrace(density_base=bf.DensityLite(logp=lambda x: -0.5 * np.sum(x**2), input_size=3), n_chain=2,
+                                           n_iter=10, n_warmup=5), verbose=False)
