@@ -36,11 +36,13 @@ struct PldLds {
     double *RB;    // [NS2][XS]     r as the B operand of GEMM2
     double *PHI;   // [NS1][XS]     monomials as the B operand of GEMM1; slot 0 of W afterwards
     double *WX;    // [KS2 - 1][NS1][XS]  further partial-sum slots of W
+    const unsigned long long *GT;   // [n_ent][DP]  gradient table (staged from pl.gtab once per launch)
+    const unsigned *MONO;           // [PP]         monomial table (staged from pl.mono)
 };
 
-__host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2) {
+__host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent) {
     const size_t ns1 = PP / 4, ns2 = MP / 4, nt1 = MP / 16;
-    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + nt1 * 32 + ns2 * PLD_XS + (size_t)KS2 * ns1 * PLD_XS;
+    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + nt1 * 32 + ns2 * PLD_XS + (size_t)KS2 * ns1 * PLD_XS + (size_t)n_ent * DP + PP / 2;
 }
 
 #ifndef BF_HOST_EMU
@@ -53,15 +55,22 @@ __device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl) {
     L.RB = L.RED + pl.NT1 * 32;
     L.PHI = L.RB + (size_t)pl.NS2 * PLD_XS;
     L.WX = L.PHI + (size_t)pl.NS1 * PLD_XS;
+    double *gt = L.WX + (size_t)(pl.KS2 - 1) * pl.NS1 * PLD_XS;
+    L.GT = (const unsigned long long *)gt;
+    L.MONO = (const unsigned *)(gt + (size_t)pl.n_ent * DP);
     return L;
 }
 
-// once per launch, all threads: y' and f_mu' into LDS
-__device__ inline void pld_stage(const PldDev &pl, const PldLds &L, int tid, int nth) {
+// once per launch, all threads: y', f_mu' and the two index tables into LDS
+__device__ inline void pld_stage(const PldDev &pl, const PldLds &L, int DP, int tid, int nth) {
     for (int i = tid; i < pl.MP; i += nth) {
         L.YW[i] = pl.yw[i];
         L.YW[pl.MP + i] = pl.fmuw[i];
     }
+    unsigned long long *gt = (unsigned long long *)L.GT;
+    for (int i = tid; i < pl.n_ent * DP; i += nth) gt[i] = pl.gtab[i];
+    unsigned *mo = (unsigned *)L.MONO;
+    for (int i = tid; i < pl.PP; i += nth) mo[i] = pl.mono[i];
 }
 
 // chain wave c (lane = dimension): the evaluation point, beta (0 inside the bound) and the monomials of the chain
@@ -77,7 +86,7 @@ __device__ inline void pld_point(const PldDev &pl, const PldLds &L, int DP, int 
     for (int p0 = 0; p0 < pl.PP; p0 += 64) {
         const int p = p0 + lane;
         if (p < pl.PP) {
-            const unsigned mo = pl.mono[p];
+            const unsigned mo = L.MONO[p];
             const double v = (xe[mo & 255u] * xe[(mo >> 8) & 255u]) * xe[(mo >> 16) & 255u];
             L.PHI[(p >> 2) * PLD_XS + c + 16 * (p & 3)] = v;
         }
@@ -118,9 +127,281 @@ __device__ inline d4_t pld_tile(const double *__restrict__ Af, const double *Bf,
     return acc;
 }
 
+// two row tiles against the SAME B operand (GEMM1: both tiles multiply Phi): two independent accumulation chains per wave, one
+// LDS read per k-step for both
+__device__ inline void pld_tile2(const double *__restrict__ Af0, const double *__restrict__ Af1, const double *Bf, int n_steps, int lane,
+                                 d4_t &acc0, d4_t &acc1) {
+    acc0 = d4_t{0., 0., 0., 0.};
+    acc1 = d4_t{0., 0., 0., 0.};
+    const double *ap0 = Af0 + lane, *ap1 = Af1 + lane, *bp = Bf + lane;
+    double x0[4], y0[4], b0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { x0[q] = ap0[q * 64]; y0[q] = ap1[q * 64]; b0[q] = bp[q * PLD_XS]; }
+    for (int s = 4; s < n_steps; s += 4) {
+        double x1[4], y1[4], b1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x1[q] = ap0[(s + q) * 64]; y1[q] = ap1[(s + q) * 64]; b1[q] = bp[(s + q) * PLD_XS]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], b0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[q], b0[q], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x0[q] = x1[q]; y0[q] = y1[q]; b0[q] = b1[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], b0[q], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[q], b0[q], acc1, 0, 0, 0);
+    }
+}
+
+// the epilogue of one row tile of GEMM1: the bound's extrapolation per chain, r = F - y' into the B operand of GEMM2, and the
+// tile's contributions to sum r^2 and sum (f_0 - f_mu) r
+__device__ inline void pld_epilogue1(const PldDev &pl, const PldLds &L, double alpha, double beta, int t, const d4_t &acc, int lane) {
+    const int mg = lane >> 4;
+    double s_rr = 0., s_fr = 0.;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = 16 * t + 4 * r4 + mg;
+        const double f0 = acc[r4], y = L.YW[row], fmu = L.YW[pl.MP + row];
+        const double fv = beta > 0. ? (beta * f0 - (beta - alpha) * fmu) / alpha : f0;   // modules/poly.py:487
+        const double r = fv - y;
+        L.RB[(4 * t + r4) * PLD_XS + lane] = r;   // row >> 2 = 4 t + r4, 16 (row & 3) + chain = lane
+        s_rr += r * r;
+        s_fr += (f0 - fmu) * r;
+    }
+    s_rr = pld_rowsum4(s_rr);
+    s_fr = pld_rowsum4(s_fr);
+    if (lane < 16) {
+        L.RED[(t * 2 + 0) * 16 + lane] = s_rr;
+        L.RED[(t * 2 + 1) * 16 + lane] = s_fr;
+    }
+}
+
+// GEMM1 and its epilogue, all NWV waves of the workgroup: F_0 = C' Phi, row tiles dealt two at a time
+__device__ inline void pld_gemm1(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
+    const double beta = L.CH[lane & 15];
+    for (int t = w; t < pl.NT1; t += 2 * nwv) {
+        const int t2 = t + nwv;
+        if (t2 < pl.NT1) {
+            d4_t a0, a1;
+            pld_tile2(pl.CF + (size_t)t * pl.NS1 * 64, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1);
+            pld_epilogue1(pl, L, alpha, beta, t, a0, lane);
+            pld_epilogue1(pl, L, alpha, beta, t2, a1, lane);
+        } else {
+            const d4_t a0 = pld_tile(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.NS1, lane);
+            pld_epilogue1(pl, L, alpha, beta, t, a0, lane);
+        }
+    }
+}
+
+// two independent (row tile, K range) contractions side by side (GEMM2: different A and different B): two accumulation chains
+// per wave keep the matrix pipe fed when only two waves share a SIMD
+__device__ inline void pld_tile2b(const double *__restrict__ Af0, const double *Bf0, const double *__restrict__ Af1, const double *Bf1,
+                                  int n_steps, int lane, d4_t &acc0, d4_t &acc1) {
+    acc0 = d4_t{0., 0., 0., 0.};
+    acc1 = d4_t{0., 0., 0., 0.};
+    const double *ap0 = Af0 + lane, *ap1 = Af1 + lane, *bp0 = Bf0 + lane, *bp1 = Bf1 + lane;
+    double x0[4], y0[4], b0[4], c0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { x0[q] = ap0[q * 64]; y0[q] = ap1[q * 64]; b0[q] = bp0[q * PLD_XS]; c0[q] = bp1[q * PLD_XS]; }
+    for (int s = 4; s < n_steps; s += 4) {
+        double x1[4], y1[4], b1[4], c1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x1[q] = ap0[(s + q) * 64]; y1[q] = ap1[(s + q) * 64];
+            b1[q] = bp0[(s + q) * PLD_XS]; c1[q] = bp1[(s + q) * PLD_XS];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], b0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[q], c0[q], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x0[q] = x1[q]; y0[q] = y1[q]; b0[q] = b1[q]; c0[q] = c1[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[q], b0[q], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[q], c0[q], acc1, 0, 0, 0);
+    }
+}
+
+// GEMM2, all waves: W = C'^T R, (row tile, K part) jobs, two at a time while both have the same number of k-steps; part kp
+// lands in W slot kp (slot 0 = PHI, which GEMM1 has consumed)
+__device__ inline void pld_gemm2(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
+    const int n_job = pl.NT2 * pl.KS2;
+    auto steps_of = [&](int job) { const int s0 = (job % pl.KS2) * pl.KPJ2; int ns = pl.NS2 - s0; return ns > pl.KPJ2 ? pl.KPJ2 : ns; };
+    auto dest = [&](int job) { const int kp = job % pl.KS2; return (kp == 0 ? L.PHI : L.WX + (size_t)(kp - 1) * pl.NS1 * PLD_XS) + (size_t)4 * (job / pl.KS2) * PLD_XS; };
+    auto a_of = [&](int job) { return pl.CTF + ((size_t)(job / pl.KS2) * pl.NS2 + (job % pl.KS2) * pl.KPJ2) * 64; };
+    auto b_of = [&](int job) { return L.RB + (size_t)(job % pl.KS2) * pl.KPJ2 * PLD_XS; };
+    for (int job = w; job < n_job; job += 2 * nwv) {
+        const int job2 = job + nwv;
+        const int ns = steps_of(job);
+        d4_t acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
+        const bool two = job2 < n_job;
+        if (two && steps_of(job2) == ns && ns > 0) {
+            pld_tile2b(a_of(job), b_of(job), a_of(job2), b_of(job2), ns, lane, acc0, acc1);
+        } else {
+            if (ns > 0) acc0 = pld_tile(a_of(job), b_of(job), ns, lane);
+            if (two && steps_of(job2) > 0) acc1 = pld_tile(a_of(job2), b_of(job2), steps_of(job2), lane);
+        }
+        double *W0 = dest(job);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) W0[r4 * PLD_XS + lane] = acc0[r4];
+        if (two) {
+            double *W1 = dest(job2);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) W1[r4 * PLD_XS + lane] = acc1[r4];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Eight-chain form (the fused sampler runs the pipeline density with eight waves of 256 registers: bfhip_sampler.hip,
+// BF_PLD_WAVES): the 16-column tile would hold the FP64 pipe for 64 cycles per k-step with half of its columns empty, so a
+// k-step is TWO v_mfma_f64_4x4x4_4b instead -- four 4-row blocks of the tile against the SAME four columns (chains 0-3, then
+// 4-7): 35 cycles of the pipe instead of 64.  Operand maps: A lane 16 k + m as for the 16 x 16 x 4 tile; B lane 16 k + 4 b + n
+// reads column n (+ 4); D lane 16 i + 4 b + n is row 4 b + i of chain n (+ 4).  Two row tiles (GEMM1) or two jobs (GEMM2) run
+// side by side in a wave, eight k-steps are fetched while the eight before them run.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PldAcc8 { double lo, hi; };   // chains 0-3 and 4-7 of one row per lane
+
+template <bool SAME_B>
+__device__ inline void pld_tile2_q8(const double *__restrict__ Af0, const double *Bf0, const double *__restrict__ Af1, const double *Bf1,
+                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1) {
+    // chunks of four k-steps (n_steps is a multiple of 4), the A fragments of TWO chunks ahead on their way while one runs: no
+    // guard inside a chunk, so the loads are counted exactly (vmcnt) and stay in flight across the matrix instructions
+    acc0 = PldAcc8{0., 0.};
+    acc1 = PldAcc8{0., 0.};
+    const int bo = (lane & ~15) + (lane & 3);   // column n = lane & 3 of k = lane >> 4
+    const double *ap0 = Af0 + lane, *ap1 = Af1 + lane, *bp0 = Bf0 + bo, *bp1 = Bf1 + bo;
+    const int n_ch = n_steps >> 2;
+    double xa[4], ya[4], xb[4], yb[4], xc[4], yc[4];
+    auto fetch = [&](int c, double (&x)[4], double (&y)[4]) {
+#pragma unroll
+#ifdef PLD_KNOCK_A   // (tuning: the A fragments of ONE chunk over and over -- L1 hits -- to separate load latency from the rest)
+        for (int q = 0; q < 4; ++q) { x[q] = ap0[q * 64]; y[q] = ap1[q * 64]; }
+#else
+        for (int q = 0; q < 4; ++q) { x[q] = ap0[(4 * c + q) * 64]; y[q] = ap1[(4 * c + q) * 64]; }
+#endif
+    };
+    auto run = [&](int c, const double (&x)[4], const double (&y)[4]) {
+        double bl[4], bh[4], cl[4], chh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bl[q] = bp0[(4 * c + q) * PLD_XS];
+            bh[q] = bp0[(4 * c + q) * PLD_XS + 4];
+            if (!SAME_B) { cl[q] = bp1[(4 * c + q) * PLD_XS]; chh[q] = bp1[(4 * c + q) * PLD_XS + 4]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0.lo = __builtin_amdgcn_mfma_f64_4x4x4f64(x[q], bl[q], acc0.lo, 0, 0, 0);
+            acc0.hi = __builtin_amdgcn_mfma_f64_4x4x4f64(x[q], bh[q], acc0.hi, 0, 0, 0);
+            acc1.lo = __builtin_amdgcn_mfma_f64_4x4x4f64(y[q], SAME_B ? bl[q] : cl[q], acc1.lo, 0, 0, 0);
+            acc1.hi = __builtin_amdgcn_mfma_f64_4x4x4f64(y[q], SAME_B ? bh[q] : chh[q], acc1.hi, 0, 0, 0);
+        }
+    };
+    if (n_ch <= 0) return;
+    fetch(0, xa, ya);
+    if (n_ch > 1) fetch(1, xb, yb);
+    // (three buffers taken in turn by position in the loop body: rotating them by register moves would make every move wait
+    // for the loads just issued)
+    for (int c = 0; c < n_ch; c += 3) {
+        if (c + 2 < n_ch) fetch(c + 2, xc, yc);
+        run(c, xa, ya);
+        if (c + 1 < n_ch) {
+            if (c + 3 < n_ch) fetch(c + 3, xa, ya);
+            run(c + 1, xb, yb);
+        }
+        if (c + 2 < n_ch) {
+            if (c + 4 < n_ch) fetch(c + 4, xb, yb);
+            run(c + 2, xc, yc);
+        }
+    }
+}
+
+__device__ inline double pld_sum_b(double v) {   // sum over the four blocks b = (lane >> 2) & 3 of a 16-lane row, in every lane
+    auto ror = [](double u, int ctrl) {
+        const int lo = ctrl == 4 ? __builtin_amdgcn_mov_dpp(__double2loint(u), 0x124, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(__double2loint(u), 0x128, 0xf, 0xf, true);
+        const int hi = ctrl == 4 ? __builtin_amdgcn_mov_dpp(__double2hiint(u), 0x124, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(__double2hiint(u), 0x128, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    };
+    v += ror(v, 4);   // row_ror:4
+    v += ror(v, 8);   // row_ror:8
+    return v;
+}
+
+// epilogue of one row tile of GEMM1, eight-chain form: lane 16 i + 4 b + n holds row 16 t + 4 b + i of chains n and n + 4
+__device__ inline void pld_epilogue1_q8(const PldDev &pl, const PldLds &L, double alpha, int t, const PldAcc8 &acc, int lane) {
+    const int i = lane >> 4, b = (lane >> 2) & 3, n = lane & 3;
+    const int row = 16 * t + 4 * b + i;
+    const double y = L.YW[row], fmu = L.YW[pl.MP + row];
+    double s_rr[2], s_fr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double beta = L.CH[n + 4 * h], f0 = h ? acc.hi : acc.lo;
+        const double fv = beta > 0. ? (beta * f0 - (beta - alpha) * fmu) / alpha : f0;   // modules/poly.py:487
+        const double r = fv - y;
+        L.RB[(4 * t + b) * PLD_XS + n + 4 * h + 16 * i] = r;   // row >> 2 = 4 t + b, row & 3 = i
+        s_rr[h] = pld_rowsum4(pld_sum_b(r * r));
+        s_fr[h] = pld_rowsum4(pld_sum_b((f0 - fmu) * r));
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            L.RED[(t * 2 + 0) * 16 + lane + 4 * h] = s_rr[h];
+            L.RED[(t * 2 + 1) * 16 + lane + 4 * h] = s_fr[h];
+        }
+    }
+}
+
+__device__ inline void pld_gemm1_q8(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
+    for (int t = w; t < pl.NT1; t += 2 * nwv) {
+        const int t2 = t + nwv < pl.NT1 ? t + nwv : t;   // (an odd tile out is computed twice side by side: same result, same time)
+        PldAcc8 a0, a1;
+        pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1);
+        pld_epilogue1_q8(pl, L, alpha, t, a0, lane);
+        if (t2 != t) pld_epilogue1_q8(pl, L, alpha, t2, a1, lane);
+    }
+}
+
+__device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
+    const int n_job = pl.NT2 * pl.KS2;
+    const int i = lane >> 4, b = (lane >> 2) & 3, n = lane & 3;
+    auto steps_of = [&](int job) { const int s0 = (job % pl.KS2) * pl.KPJ2; int ns = pl.NS2 - s0; return ns > pl.KPJ2 ? pl.KPJ2 : ns; };
+    auto dest = [&](int job) { const int kp = job % pl.KS2; return (kp == 0 ? L.PHI : L.WX + (size_t)(kp - 1) * pl.NS1 * PLD_XS) + (size_t)4 * (job / pl.KS2) * PLD_XS; };
+    auto a_of = [&](int job) { return pl.CTF + ((size_t)(job / pl.KS2) * pl.NS2 + (job % pl.KS2) * pl.KPJ2) * 64; };
+    auto b_of = [&](int job) { return L.RB + (size_t)(job % pl.KS2) * pl.KPJ2 * PLD_XS; };
+    for (int job = w; job < n_job; job += 2 * nwv) {
+        const int job2 = (job + nwv < n_job && steps_of(job + nwv) == steps_of(job)) ? job + nwv : job;
+        PldAcc8 a0, a1;
+        pld_tile2_q8<false>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1);
+        double *W0 = dest(job) + b * PLD_XS + n + 16 * i;   // monomial p = 16 u + 4 b + i: p >> 2 = 4 u + b, p & 3 = i
+        W0[0] = a0.lo;
+        W0[4] = a0.hi;
+        if (job2 != job) {
+            double *W1 = dest(job2) + b * PLD_XS + n + 16 * i;
+            W1[0] = a1.lo;
+            W1[4] = a1.hi;
+        } else if (job + nwv < n_job) {   // a partner with another number of k-steps (the last K part): on its own
+            const int j3 = job + nwv;
+            PldAcc8 c0, c1;
+            pld_tile2_q8<false>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1);
+            double *W3 = dest(j3) + b * PLD_XS + n + 16 * i;
+            W3[0] = c0.lo;
+            W3[4] = c0.hi;
+        }
+    }
+}
+
+// Sixteen waves of 128 registers (the fused sampler above ~8 chains per CU): one row tile / one job at a time per wave -- four
+// waves share a SIMD, so their accumulation chains interleave on the matrix pipe, and the registers of a second chain or of a
+// deeper prefetch would be spilled.
 // GEMM1 and its epilogue, all NWV waves of the workgroup: F_0 = C' Phi per row tile, the bound's extrapolation per chain,
 // r = F - y' into the B operand of GEMM2, and the tile's contributions to sum r^2 and sum (f_0 - f_mu) r
-__device__ inline void pld_gemm1(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
+__device__ inline void pld_gemm1_w16(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
     const int mc = lane & 15, mg = lane >> 4;
     const double beta = L.CH[mc];
     for (int t = w; t < pl.NT1; t += nwv) {
@@ -146,7 +427,7 @@ __device__ inline void pld_gemm1(const PldDev &pl, const PldLds &L, double alpha
 }
 
 // GEMM2, all waves: W = C'^T R, (row tile, K part) jobs; part kp lands in W slot kp (slot 0 = PHI, which GEMM1 has consumed)
-__device__ inline void pld_gemm2(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
+__device__ inline void pld_gemm2_w16(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
     const int n_job = pl.NT2 * pl.KS2;
     for (int job = w; job < n_job; job += nwv) {
         const int u = job / pl.KS2, kp = job % pl.KS2;
@@ -175,7 +456,7 @@ __device__ inline double pld_grad(const PldDev &pl, const PldLds &L, int DP, int
     const double *xe = L.XE + c * (DP + 2);
     double g = 0.;
     for (int i = 0; i < pl.n_ent; ++i) {
-        const unsigned long long en = pl.gtab[(size_t)i * DP + dim];
+        const unsigned long long en = L.GT[(size_t)i * DP + dim];
         const unsigned eh = (unsigned)(en >> 32);
         const int p = (int)(unsigned)en, off = (p >> 2) * PLD_XS + c + 16 * (p & 3);
         double wv = L.PHI[off];

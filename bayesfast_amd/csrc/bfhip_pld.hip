@@ -183,14 +183,14 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     for (int ks = 1; ks <= PLD_MAX_KS2; ++ks) {
         const int kpj = roundup((NS2 + ks - 1) / ks, 4);
         if (ks > 1 && (ks - 1) * kpj >= NS2) continue;   // an empty part
-        if (base_bytes + pld_lds_doubles(DP, MP, PP, ks) * sizeof(double) > (size_t)160 * 1024) continue;
+        if (base_bytes + pld_lds_doubles(DP, MP, PP, ks, (int)n_ent) * sizeof(double) > (size_t)160 * 1024) continue;
         const long cost = (long)((NT2 * ks + 15) / 16) * kpj;
         if (!best_ks || cost < best_cost) { best_ks = ks; best_cost = cost; }
     }
     if (!best_ks) {
         dm.pld.on = 0;
         return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_pipeline_upload: %d outputs x %d monomials need %zu KB of LDS per workgroup (160 KB)",
-                            m, nf, (base_bytes + pld_lds_doubles(DP, MP, PP, 1) * sizeof(double)) / 1024);
+                            m, nf, (base_bytes + pld_lds_doubles(DP, MP, PP, 1, (int)n_ent) * sizeof(double)) / 1024);
     }
 
     // ---- one device buffer: doubles, then 8-byte entries, then the monomial words ----
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int 
     const int DP = m.DP, d = m.d;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const PldLds L = pld_lds(lds, DP, pl);
-    double *XM = lds + pld_lds_doubles(DP, pl.MP, pl.PP, pl.KS2);   // [16][2][DP]  x - mu and x_o - mu_decay of every point
-    pld_stage(pl, L, tid, 1024);
+    double *XM = lds + pld_lds_doubles(DP, pl.MP, pl.PP, pl.KS2, pl.n_ent);   // [16][2][DP]  x - mu and x_o - mu_decay of every point
+    pld_stage(pl, L, DP, tid, 1024);
     const bool tr = m.has_transform && !original_space;
     for (int base = blockIdx.x * 16; base < n; base += gridDim.x * 16) {
         const int i = base + w;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int 
 
 int bf_pld_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad) {
     const DevModel &m = ctx->model;
-    const size_t lds = (pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2) + (size_t)16 * 2 * m.DP) * sizeof(double);
+    const size_t lds = (pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent) + (size_t)16 * 2 * m.DP) * sizeof(double);
     if (lds > (size_t)160 * 1024) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "pipeline density: %zu KB of LDS", lds / 1024);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_pld_logp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

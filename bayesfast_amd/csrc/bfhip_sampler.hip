@@ -151,7 +151,12 @@ struct SamplerGeo {
 // 256 VGPRs each (half-empty tiles, twice as many workgroups).  The same for the full-rank metric at any d: its
 // matrix-vector products stream the chain's own d x d matrix in batches of 16 columns, and at 128 VGPRs the batches were
 // spilled -- 163 VGPRs of scratch -- so that every column's load was waited for on its own.
-#define BF_SAMPLER_WAVES(W, FULLM) (((W) == 8 || (FULLM)) ? 8 : 16)
+// The pipeline density has both forms: FS = 8, sixteen waves of 128 registers (~230 spilled VGPRs: its scratch traffic evicts
+// part of the coefficient fragments from the XCD's L2, 17 KB of HBM reads per leapfrog step, but sixteen chains fill the
+// 16-column tiles), and FS = 9, eight waves of 256 registers (no spills, 4 x 4 x 4 tiles for its eight chains).  Measured on the
+// DES shape (tools/pld_rate.py): 4096 chains 5.7 against 5.2 x 10^7 leapfrog steps/s, 1024 chains 1.8 against 2.6 x 10^7 -- the
+// launch takes FS = 9 when its chains fit eight to a CU.
+#define BF_SAMPLER_WAVES(W, FULLM, FS) (((W) == 8 || (FULLM) || (FS) == 9) ? 8 : 16)
 
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
 // extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
@@ -165,11 +170,11 @@ __device__ inline bool g_sliced_proof_on(const SamplerArgs &a) { return a.no_bou
 __device__ inline bool g_no_quad_tiles(const SamplerArgs &a) { return a.no_quad != 0; }
 
 template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
-__global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
-    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
+__global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
+    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
     // FS == 8: the pipeline density (bfhip_pld.h: multi-output surrogate + Gaussian likelihood + prior); transforms, input
     // scaling, bound and decay are run-time features as in FS == 0, the polynomial itself is the two contractions of phase P
-    constexpr bool PLD = FS == 8;
+    constexpr bool PLD = FS == 8 || FS == 9;   // (9: eight waves of 256 registers, for launches of at most 8 chains per CU)
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0 && !PLD;
     const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
     PldLds PL;
     if constexpr (PLD) {
         PL = pld_lds(CUB, DP, m.pld);
-        pld_stage(m.pld, PL, tid, NTH);
+        pld_stage(m.pld, PL, DP, tid, NTH);
     }
     int mk2 = 0, mk3 = 0, pj2[E], pj3[E];
 #pragma unroll
@@ -1066,7 +1071,23 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
                 xo[e] = q[e];
                 jac[e] = 1.;
                 gj[e] = 0.;
-                if (f_tr) {
+                if (PLD && f_tr) {
+                    // (the pipeline instantiation: one INLINED exponential and logarithm for every kind of bound -- the
+                    // out-of-line libm calls of this file cost a round of register spills each at this kernel's pressure;
+                    // the same expressions as bf_to_original_g of the lane-per-chain kernels)
+                    const int kind = (int)pdl(PD_KIND, e);
+                    const double rg = pdl(PD_RG, e);
+                    const double ex = __ocml_exp_f64(kind == 1 ? -q[e] : q[e]);
+                    const double t = 1. / (1. + ex);
+                    double tmp = q[e], jt = 1., gq_ = 0.;
+                    if (kind == 1) { tmp = t; jt = t * (1. - t); gq_ = (ex - 1.) * t; }
+                    if (kind == 2) { tmp = ex; jt = ex; gq_ = 1.; }
+                    if (kind == 3) { tmp = 1. - ex; jt = -ex; gq_ = 1.; }
+                    xo[e] = pdl(PD_LO, e) + tmp * rg;
+                    jac[e] = jt * rg;
+                    gj[e] = gq_;
+                    logdet += __ocml_log_f64(fabs(jac[e]));
+                } else if (f_tr) {
                     double J, J2;
                     bf_to_original(q[e], (int)pdl(PD_KIND, e), pdl(PD_LO, e), pdl(PD_RG, e), xo[e], J, J2);
                     logdet += log(fabs(J));
@@ -1318,11 +1339,13 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM) * 64) void bf_sampler_ke
             TRACEP(7);
             __syncthreads();  // P1: monomials of every evaluating chain
             TRACEP(8);
-            pld_gemm1(pl, PL, m.alpha, w, NWV, lane);
+            if constexpr (NWV == 8) pld_gemm1_q8(pl, PL, m.alpha, w, NWV, lane);   // (at most eight chains: 4 x 4 x 4 tiles)
+            else pld_gemm1_w16(pl, PL, m.alpha, w, NWV, lane);
             TRACEP(11);
             __syncthreads();  // P2: residuals
             TRACEP(12);
-            pld_gemm2(pl, PL, w, NWV, lane);
+            if constexpr (NWV == 8) pld_gemm2_q8(pl, PL, w, NWV, lane);
+            else pld_gemm2_w16(pl, PL, w, NWV, lane);
             TRACEP(13);
             __syncthreads();  // P3: W = C'^T r
             TRACEP(14);
@@ -1712,7 +1735,7 @@ static bool sampler_cubic_lds(const DevModel &m, bool plain) {
 }
 static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
     if (m.pld.on)   // (the pipeline block sits where the cubic tables would: behind the matvec results, 16-byte aligned)
-        return (((sampler_lds_base(m, false) + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2)) * sizeof(double);
+        return (((sampler_lds_base(m, false) + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent)) * sizeof(double);
     return (sampler_lds_base(m, plain) + (sampler_cubic_lds(m, plain) ? sampler_cubic_doubles(m) : 0)) * sizeof(double);
 }
 // what the sampler's own regions take for a pipeline density (bfhip_pipeline_upload sizes the K-split of GEMM2 with it)
@@ -1743,7 +1766,7 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM);
+    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS);
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
     args.cub_lds = sampler_cubic_lds(ctx->model, FS == 1) ? 1 : 0;
@@ -1788,6 +1811,10 @@ static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
 extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 
+// test / tuning hook (not part of include/bfhip.h; also BFHIP_PLD_WAVES): 8 or 16 waves per workgroup for the pipeline density, 0 = by chain count
+static int g_pld_waves = [] { const char *e = getenv("BFHIP_PLD_WAVES"); return e ? atoi(e) : 0; }();
+extern "C" void bfhip_debug_pld_waves(int v) { g_pld_waves = v; }
+
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
@@ -1796,7 +1823,9 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         if (args.mat) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density runs with the diagonal metric only");
         constexpr int WP = W <= 4 ? W : 1;   // (keeps W = 8 from instantiating it)
         if (W > 4) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density is implemented for d <= 64");
-        return launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
+        // eight chains per workgroup (and 256 registers a wave) while that fills the chip, sixteen beyond
+        const bool w8 = g_pld_waves ? g_pld_waves == 8 : args.n_chain <= 8 * ctx->n_cu;
+        return w8 ? launch_sampler_t<WP, NUTS, false, 9>(ctx, args) : launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
     }
     if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);
 #ifndef BF_TRACE
@@ -1903,7 +1932,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
         const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
         const bool tr_only = common && m.has_transform && !m.use_decay, dec_only = common && m.use_decay && !m.has_transform && !args.no_fuse;
         const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only || dec_only);
-        if (m.pld.on) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_sampler_kernel<%d, %s, false, 8>", W, nuts ? "true" : "false");
+        if (m.pld.on) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_sampler_kernel<%d, %s, false, 8 | 9>", W, nuts ? "true" : "false");
         else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
     }
     switch (W) {

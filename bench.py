@@ -359,12 +359,24 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
            'nuts_iterations_timed': steps * iters, 'nuts_adaptation_iterations': n_adapt, 'ms_per_launch': ms / steps,
            'target_accept': target_accept, 'mean_tree_size': float(ts.mean()), 'max_tree_depth': int(stn[:, :, _lib.NSTATS.index('tree_depth')].max()),
            'divergence_rate': float(stn[:, :, _lib.NSTATS.index('diverging')].mean()),
+           # a launch lasts as long as its busiest chain: leapfrogs of the busiest chain / of the average chain in the last launch
+           'launch_tail': float(ts.sum(1).max() / max(ts.sum(1).mean(), 1.)),
            'mean_accept': float(stn[:, :, _lib.NSTATS.index('mean_tree_accept')].mean()),
            'chain_layout': _layout_of(kname().decode(), ch.last_layout),
            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': ach / 78.6, 'traffic': None,
                         'kernel': kname().decode(), 'kernel_ms_per_launch': ms / steps, 'flops_per_leapfrog': fl},
            'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9, 'peak': 8000.,
                                         'unit': 'GB/s', 'frac': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9 / 8000.}}
+    try:   # HBM-side bytes per launch: a STORED profile value (tools/profile_configs.sh), used when kernel and shape match
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'config_traffic.json')))
+        for e in tj.values():
+            for blk in e.values():
+                if (blk.get('kernel_named_by_library') == out['roofline']['kernel'] and blk.get('chains') == int(C) and blk.get('dim') == int(d)
+                        and abs(blk.get('mean_tree_size', -1.) / out['mean_tree_size'] - 1.) < 0.25 and 'hbm_bytes_per_leapfrog' in blk):
+                    out['roofline']['traffic'] = blk['hbm_bytes_per_leapfrog'] * n_lf / steps
+                    out['roofline']['traffic_source'] = 'stored profile (profiles/config_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), not this run'
+    except Exception:
+        pass
     if cpu_seconds > 0:
         try:
             step = float((ch.field('log_bar').exp() * d**0.25).mean())   # what _get_step_size hands to the next round
@@ -399,7 +411,7 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
     t_fit = {}
     # launch lengths that keep a block within seconds: the banana's refitted surrogate and config 5 run every tree to the
     # depth limit (1023 leapfrogs per iteration)
-    iters = iters or {'gauss32': 250, 'banana_decay': 50, 'funnel': 100, 'cubic128': 20, 'des_pipeline': 100}[name]
+    iters = iters or {'gauss32': 250, 'banana_decay': 100, 'funnel': 100, 'cubic128': 20, 'des_pipeline': 100}[name]
     n_adapt = n_adapt or {'gauss32': 500, 'banana_decay': 200, 'funnel': 300, 'cubic128': 150, 'des_pipeline': 300}[name]
 
     def fit(den, x, lp, key):
