@@ -105,20 +105,62 @@ __global__ __launch_bounds__(256) void bf_gram_kernel(int n, int P, const double
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0., 0., 0., 0.};
-    for (int r0 = r_begin; r0 < r_end; r0 += 4) {
+    // Software pipeline over steps of four rows: the operands of the step after next are on their way while a step's 16 matrix
+    // instructions run (three register sets taken in turn by position in the loop body: no moves that would wait for the
+    // loads).  A diagonal block (bi == bj) has one operand set.  Column guards are hoisted: only the last block column of G
+    // is ragged.
+    const bool diag = bi == bj;
+    const double *pa[4], *pb[4];
+    bool oka[4], okb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ca = I0 + 16 * t + ci, cb = J0 + 16 * t + ci;
+        oka[t] = ca < P;
+        okb[t] = cb < P;
+        pa[t] = A + (oka[t] ? ca : 0);
+        pb[t] = A + (okb[t] ? cb : 0);
+    }
+    auto fetch = [&](int r0, double (&fa)[4], double (&fb)[4]) {
         const int row = r0 + kr;
         const bool rok = row < r_end;
-        double fa[4], fb[4];
+        const size_t ro = (size_t)(rok ? row : r_begin) * lda;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int ca = I0 + 16 * t + ci, cb = J0 + 16 * t + ci;
-            fa[t] = (rok && ca < P) ? A[(size_t)row * lda + ca] : 0.;
-            fb[t] = (rok && cb < P) ? A[(size_t)row * lda + cb] : 0.;
+            const double va = pa[t][ro];
+            fa[t] = (rok && oka[t]) ? va : 0.;
         }
+        if (!diag) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double vb = pb[t][ro];
+                fb[t] = (rok && okb[t]) ? vb : 0.;
+            }
+        }
+    };
+    auto run = [&](const double (&fa)[4], const double (&fb)[4]) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], diag ? fa[b] : fb[b], acc[a][b], 0, 0, 0);
+    };
+    double fa0[4], fb0[4], fa1[4], fb1[4], fa2[4], fb2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fb0[t] = fb1[t] = fb2[t] = 0.;
+    if (r_begin < r_end) {
+        fetch(r_begin, fa0, fb0);
+        fetch(r_begin + 4, fa1, fb1);   // (rows past r_end read as zeros)
+        for (int r0 = r_begin; r0 < r_end; r0 += 12) {
+            fetch(r0 + 8, fa2, fb2);
+            run(fa0, fb0);
+            if (r0 + 4 < r_end) {
+                fetch(r0 + 12, fa0, fb0);
+                run(fa1, fb1);
+            }
+            if (r0 + 8 < r_end) {
+                fetch(r0 + 16, fa1, fb1);
+                run(fa2, fb2);
+            }
+        }
     }
     // D[row = kr + 4 r][col = ci] of tile (a, b)
     double *out = part + ((size_t)sk * n_blk + blk) * (GB_ * GB_);
@@ -188,10 +230,20 @@ extern "C" int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, 
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_gram: invalid argument");
     const int nb = (P + GB_ - 1) / GB_;
     const int n_blk = nb * (nb + 1) / 2;
-    int split = (4 * ctx->n_cu * 2 + n_blk - 1) / n_blk;  // aim at ~2 waves per SIMD
-    if (split < 1) split = 1;
-    if (split > 16) split = 16;
-    if (split > (n + 63) / 64) split = (n + 63) / 64;
+    // split-K: a wave holds a 64 x 64 block's 128 accumulator registers, so two waves fit a SIMD and the chip has
+    // 8 n_cu slots; the waves run in rounds of that many, a round lasting as long as one wave's rows.  The split that
+    // minimises rounds x rows per wave (2380 waves of 1073 rows on 2048 slots would be two rounds for 1.16 rounds of work)
+    int split = 1;
+    {
+        const long slots = 8L * ctx->n_cu;
+        long best = -1;
+        const int smax = (n + 63) / 64 < 16 ? (n + 63) / 64 : 16;
+        for (int sp = 1; sp <= (smax > 1 ? smax : 1); ++sp) {
+            const long rows = ((n + sp - 1) / sp + 3) / 4 * 4, rounds = ((long)n_blk * sp + slots - 1) / slots;
+            const long cost = rounds * (rows + 64);   // (+ a wave's start-up and write-out)
+            if (best < 0 || cost < best) { best = cost; split = sp; }
+        }
+    }
     size_t need = (size_t)split * n_blk * GB_ * GB_ * sizeof(double);
     const size_t need_atb = (size_t)ATB_SEG_ * (m > 0 ? m : 1) * P * sizeof(double);
     if (need < need_atb) need = need_atb;

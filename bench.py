@@ -361,6 +361,8 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
            'divergence_rate': float(stn[:, :, _lib.NSTATS.index('diverging')].mean()),
            # a launch lasts as long as its busiest chain: leapfrogs of the busiest chain / of the average chain in the last launch
            'launch_tail': float(ts.sum(1).max() / max(ts.sum(1).mean(), 1.)),
+           # ... and how the work is spread over the chains: the share of all leapfrogs taken by the busiest 2 % of the chains
+           'work_share_top_2pct_chains': float(np.sort(ts.sum(1))[-max(1, int(0.02 * C)):].sum() / max(ts.sum(), 1.)),
            'mean_accept': float(stn[:, :, _lib.NSTATS.index('mean_tree_accept')].mean()),
            'chain_layout': _layout_of(kname().decode(), ch.last_layout),
            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': ach / 78.6, 'traffic': None,
