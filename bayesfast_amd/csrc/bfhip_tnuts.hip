@@ -64,28 +64,55 @@ __global__ __launch_bounds__(64 * WPB) void bf_tnuts_kernel(DevModel m, TnutsArg
     }
     __syncthreads();
     if (!real) return;  // (no barrier below: every wave is on its own)
-    double *xs = XS + w * 64;
     double *lsw = LSC + w * (TN_MAXL * TS_N);
     const bool in = lane < d;
     const double c_lin = in ? m.pd[PD_LIN * m.DP + lane] : 0., c_mu = in ? m.pd[PD_MU * m.DP + lane] : 0.;
     const double b_lin = in ? a.base_lin[lane] : 0.;
+    // x_k of the wave's vector as a scalar broadcast (no LDS round trip)
+    auto bcast = [&](double x, int k) -> double {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
+    };
+    // M x with the matrix in LDS by columns: four accumulation chains (k mod 4), added at the end.  (The rows' sums associate
+    // differently from a single chain over k: rounding-level, inside the tolerance of the oracle comparison.)
     auto matvec = [&](const double *Mt, double x) -> double {
-        xs[lane] = x;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        double acc = 0.;
-        for (int k = 0; k < d; ++k) acc = __builtin_fma(Mt[k * 64 + lane], xs[k], acc);
-        __builtin_amdgcn_wave_barrier();
-        return acc;
+        double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+        int k = 0;
+        for (; k + 4 <= d; k += 4) {
+            const double m0 = Mt[k * 64 + lane], m1 = Mt[(k + 1) * 64 + lane], m2 = Mt[(k + 2) * 64 + lane], m3 = Mt[(k + 3) * 64 + lane];
+            a0 = __builtin_fma(m0, bcast(x, k), a0);
+            a1 = __builtin_fma(m1, bcast(x, k + 1), a1);
+            a2 = __builtin_fma(m2, bcast(x, k + 2), a2);
+            a3 = __builtin_fma(m3, bcast(x, k + 3), a3);
+        }
+        for (; k < d; ++k) a0 = __builtin_fma(Mt[k * 64 + lane], bcast(x, k), a0);
+        return (a0 + a1) + (a2 + a3);
+    };
+    // the three products every evaluation needs -- S q, H (q - mu), S_b q -- in ONE pass over k: six independent chains, the
+    // broadcasts of q shared by S and S_b
+    auto matvec3 = [&](double q, double xm, double &sx, double &hv, double &bx) {
+        double s0 = 0., s1 = 0., h0 = 0., h1 = 0., b0 = 0., b1 = 0.;
+        int k = 0;
+        for (; k + 2 <= d; k += 2) {
+            const double ms0 = St[k * 64 + lane], mh0 = Ht[k * 64 + lane], mb0 = Bt[k * 64 + lane];
+            const double ms1 = St[(k + 1) * 64 + lane], mh1 = Ht[(k + 1) * 64 + lane], mb1 = Bt[(k + 1) * 64 + lane];
+            const double q0 = bcast(q, k), q1 = bcast(q, k + 1), x0 = bcast(xm, k), x1 = bcast(xm, k + 1);
+            s0 = __builtin_fma(ms0, q0, s0); h0 = __builtin_fma(mh0, x0, h0); b0 = __builtin_fma(mb0, q0, b0);
+            s1 = __builtin_fma(ms1, q1, s1); h1 = __builtin_fma(mh1, x1, h1); b1 = __builtin_fma(mb1, q1, b1);
+        }
+        if (k < d) {
+            const double q0 = bcast(q, k), x0 = bcast(xm, k);
+            s0 = __builtin_fma(St[k * 64 + lane], q0, s0); h0 = __builtin_fma(Ht[k * 64 + lane], x0, h0); b0 = __builtin_fma(Bt[k * 64 + lane], q0, b0);
+        }
+        sx = s0 + s1; hv = h0 + h1; bx = b0 + b1;
     };
     // phi, dphi, psi, dpsi at q (this lane's coordinate): integration.py:180-181 / base_hmc.py:227-231
     auto potentials = [&](double q, double &phi, double &dphi, double &psi, double &dpsi) {
         // target surrogate with its bound (modules/poly.py:466-503)
-        double sx = matvec(St, q);
+        const double xm = in ? q - c_mu : 0.;
+        double sx, hv, bx;
+        matvec3(q, xm, sx, hv, bx);
         double gn = sx + c_lin;
         double f = m.c0 + tn_wsum(in ? __builtin_fma(0.5 * q, sx, c_lin * q) : 0.);
-        const double xm = in ? q - c_mu : 0.;
-        const double hv = matvec(Ht, xm);
         const double beta = sqrt(tn_wsum(xm * hv));
         if (beta > m.alpha) {
             const double x0 = in ? (m.alpha * q + (beta - m.alpha) * c_mu) / beta : 0.;
@@ -99,7 +126,6 @@ __global__ __launch_bounds__(64 * WPB) void bf_tnuts_kernel(DevModel m, TnutsArg
         phi = -f;
         dphi = in ? -gn : 0.;
         // base: c0 + lin.x + x.S_b x / 2, plus log xi
-        const double bx = matvec(Bt, q);
         const double fb = a.base_c0 + tn_wsum(in ? __builtin_fma(0.5 * q, bx, b_lin * q) : 0.);
         psi = -(fb + a.logxi);
         dpsi = in ? -(bx + b_lin) : 0.;
