@@ -484,6 +484,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         what = ('config 3: %d chains x 64-d rotated banana (Q = 0.01), quadratic surrogate P = %d fitted on 2 P N(0, I) points, '
                 'bound and decay on; round %%d' % (C, su.n_param))
         r0, s, st = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what % 0)
+        if os.environ.get('BENCH_ROUND0_ONLY'):   # (tools/profile_configs.sh: counters of the first round's kernel on its own)
+            return r0
         # one refit cycle (core/recipe.py:1074-1155 without the cut-off): 2 P of round 0's samples by their logq
         xs, lq = s.reshape(-1, d).cpu().numpy(), st[:, :, 0].reshape(-1).cpu().numpy()
         ok = np.isfinite(lq) & np.all(np.isfinite(xs), axis=1)

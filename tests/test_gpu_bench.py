@@ -72,7 +72,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert r.returncode != 0
 
 
-@pytest.mark.parametrize('name', ['gauss32', 'banana_decay', 'funnel', 'cubic128'])
+@pytest.mark.parametrize('name', ['gauss32', 'banana_decay', 'funnel', 'cubic128', 'des_pipeline'])
 def test_bench_config_blocks(name):
     """The blocks on the BASELINE configs' own targets (bench.py: config_block), at a reduced chain count: each prints its
     rate, tree statistics, divergence rate and its own roofline."""
@@ -81,7 +81,7 @@ def test_bench_config_blocks(name):
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     assert j['config_block'] == name and j['value'] > 0 and j['chains'] == 128
-    for k in ('mean_tree_size', 'divergence_rate', 'roofline', 'workload', 'ms_per_launch'):
+    for k in ('mean_tree_size', 'divergence_rate', 'roofline', 'workload', 'ms_per_launch', 'launch_tail', 'work_share_top_2pct_chains'):
         assert k in j, k
     assert 0. <= j['divergence_rate'] <= 1. and j['roofline']['frac'] > 0
     if name == 'banana_decay':

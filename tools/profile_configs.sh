@@ -5,12 +5,16 @@
 # into gpurun_out/cfgprof_<tag>/<name>/, then tools/summarise_config_profiles.py -> <tag>_config_counters.json.
 # usage (through gpurun):  tools/profile_configs.sh r04a [workloads...]
 tag=${1:-r04}; shift
-wl=${@:-gauss32 banana_decay funnel cubic128 des_pipeline}
+wl=${@:-gauss32 banana_decay banana_round0 funnel cubic128 des_pipeline}
 out=$PWD/gpurun_out/cfgprof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-for w in $wl; do
-  o=$out/$w; mkdir -p "$o"
+for wn in $wl; do
+  o=$out/$wn; mkdir -p "$o"
+  w=$wn
+  unset BENCH_ROUND0_ONLY
+  # (the first round of config 3 on its own: its kernel also runs in the second round's adaptation launches)
+  if [ "$wn" = banana_round0 ]; then w=banana_decay; export BENCH_ROUND0_ONLY=1; fi
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$o/trace" -- python3 "$OLDPWD/bench.py" --workload $w --no-cpu-baseline > "$o/line_trace.json" 2> "$o/err_trace.log" )
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$o/pmc_fetch" -- python3 "$OLDPWD/bench.py" --workload $w --no-cpu-baseline > "$o/line_fetch.json" 2> "$o/err_fetch.log" )
   ( cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$o/pmc_write" -- python3 "$OLDPWD/bench.py" --workload $w --no-cpu-baseline > "$o/line_write.json" 2> "$o/err_write.log" )
