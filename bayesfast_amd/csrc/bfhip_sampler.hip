@@ -175,6 +175,10 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     // FS == 8: the pipeline density (bfhip_pld.h: multi-output surrogate + Gaussian likelihood + prior); transforms, input
     // scaling, bound and decay are run-time features as in FS == 0, the polynomial itself is the two contractions of phase P
     constexpr bool PLD = FS == 8 || FS == 9;   // (9: eight waves of 256 registers, for launches of at most 8 chains per CU)
+#ifndef BF_CHAIN_UNITS_MORE
+#define BF_CHAIN_UNITS_MORE 0
+#endif
+    constexpr bool CHAIN_UNITS = PLD || (W == 8 && !FULLM) || (BF_CHAIN_UNITS_MORE && !STAMPS);   // (see the end of the trip loop)
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0 && !PLD;
     const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
@@ -1132,6 +1136,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         if (lane == 0) {
             if (unit != U_DONE) alive[trip & 1] = 1;
             if (TAIL && evaluating) atomicOr((unsigned *)&alive[2 + (trip & 1)], 1u << w);
+            if (PLD && evaluating) alive[2 + (trip & 1)] = 1;   // (some chain of the workgroup needs the contractions in this trip)
         }
         stamp(0);
         __syncthreads();  // B1
@@ -1139,6 +1144,10 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         stamp(1);
         if (rfl(alive[trip & 1]) == 0) break;  // every chain of the group is done (uniform)
         const unsigned ev_mask = TAIL ? (unsigned)rfl(alive[2 + (trip & 1)]) : 0u;
+        // pipeline density: a trip in which NO chain of the workgroup evaluates (chains in step spend every second trip in a merge,
+        // a doubling's end or the iteration's end) skips the matvec jobs and phase P with its three barriers -- uniform over the
+        // workgroup, the flag is complete at B1
+        const bool pld_eval = !PLD || rfl(alive[2 + (trip & 1)]) != 0;
         const bool skip_h = PROOF && f_bound && f_quad && !f_decay && rfl(alive[4 + (trip & 1)]) == 0;  // (uniform over the workgroup)
         if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; alive[6 + ((trip + 1) & 1)] = 0; }
         TRACE(3);
@@ -1294,6 +1303,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 for (int r4 = 0; r4 < 4; ++r4) GB[((slot_m * KS_P + kp) * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc[r4];
             }
             TRACE(5);
+        } else if (!pld_eval) {
         } else if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>());
         else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>());
         else run_jobs(std::integral_constant<int, 1>());
@@ -1336,6 +1346,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 const double x_ev = beta_o > 0. ? (m.alpha * xs[0] + (beta_o - m.alpha) * c_mu[0]) / beta_o : xs[0];   // :482
                 pld_point(pl, PL, DP, w, lane, lane < d ? x_ev : 0., beta_o);
             }
+            if (pld_eval) {   // (uniform over the workgroup)
             TRACEP(7);
             __syncthreads();  // P1: monomials of every evaluating chain
             TRACEP(8);
@@ -1349,6 +1360,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             TRACEP(13);
             __syncthreads();  // P3: W = C'^T r
             TRACEP(14);
+            }
             if (evaluating) {
                 double s2[2];
                 pld_sums(pl, PL, w, lane, s2[0], s2[1]);
@@ -1654,6 +1666,19 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         const int mode_in = mode;
         // every chain runs ONE unit here, in parallel: chains that evaluated finish their leaf / init, the
         // others do their pending merge level / doubling end / iteration-end piece
+        if constexpr (CHAIN_UNITS) {
+            // Expensive trips (the pipeline density: two contractions and three more barriers, tens of microseconds; d = 128: 12 us):
+            // a bookkeeping unit is a few hundred cycles next to that, so the chain runs its units until it needs the next
+            // gradient (or is done) instead of spending a trip on each -- 8 trips per 7-leaf iteration instead of 15, two thirds of
+            // the trips of a 1023-leaf tree.  The same units in the same order: samples, statistics and random streams do not
+            // change (the prefetches a unit issues for its successor are simply consumed at once).  (At d <= 64 on the common
+            // surrogate a trip is 3 us and one unit per trip was measured faster, see run_unit.)
+            bool first = true;
+            do {
+                run_unit(first && unit_in == U_EVAL && have_eval, E_new, logp_new);
+                first = false;
+            } while (unit != U_EVAL && unit != U_DONE);
+        } else
         if (unit_in == U_EVAL) run_unit(have_eval, E_new, logp_new);
         else run_unit(false, 0., 0.);
         TRACE(10);
