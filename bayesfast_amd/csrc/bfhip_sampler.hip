@@ -178,7 +178,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #ifndef BF_CHAIN_UNITS_MORE
 #define BF_CHAIN_UNITS_MORE 0
 #endif
-    constexpr bool CHAIN_UNITS = PLD || (W == 8 && !FULLM) || (BF_CHAIN_UNITS_MORE && !STAMPS);   // (see the end of the trip loop)
+    constexpr bool CHAIN_UNITS = PLD || W == 8 || FULLM || (BF_CHAIN_UNITS_MORE && !STAMPS);   // (see the end of the trip loop)
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0 && !PLD;
     const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
@@ -1671,8 +1671,10 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             // a bookkeeping unit is a few hundred cycles next to that, so the chain runs its units until it needs the next
             // gradient (or is done) instead of spending a trip on each -- 8 trips per 7-leaf iteration instead of 15, two thirds of
             // the trips of a 1023-leaf tree.  The same units in the same order: samples, statistics and random streams do not
-            // change (the prefetches a unit issues for its successor are simply consumed at once).  (At d <= 64 on the common
-            // surrogate a trip is 3 us and one unit per trip was measured faster, see run_unit.)
+            // change (the prefetches a unit issues for its successor are simply consumed at once).  Measured: DES-shaped pipeline
+            // 7.5 -> 9.8 x 10^7 leapfrog steps/s, config 5 (d = 128, 1023-leaf trees) 7.4 -> 8.2, full-rank metric 7.0 -> 7.4 fixed
+            // and 2.1 -> 2.5 adapting.  (At d <= 64 on the common surrogate a trip is 3 us and one unit per trip was measured
+            // faster, see run_unit.)
             bool first = true;
             do {
                 run_unit(first && unit_in == U_EVAL && have_eval, E_new, logp_new);
