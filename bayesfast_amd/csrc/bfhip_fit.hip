@@ -172,20 +172,40 @@ __global__ __launch_bounds__(256) void bf_gram_kernel(int n, int P, const double
             for (int r = 0; r < 4; ++r) out[(16 * a + kr + 4 * r) * GB_ + 16 * b + ci] = acc[a][b][r];
 }
 
-__global__ void bf_gram_reduce_kernel(int P, int nb, int split, const double *__restrict__ part, double *__restrict__ G) {
+// One workgroup per 64 x 64 block: the split-K partials are added in part order (fixed: bitwise reproducible), the block is
+// written row by row and, for an off-diagonal block, its transpose row by row too -- through an LDS tile, so that both writes
+// are coalesced (the mirror block written element by element down a column was 3/4 of this kernel's time).
+__global__ __launch_bounds__(256) void bf_gram_reduce_kernel(int P, int nb, int split, const double *__restrict__ part, double *__restrict__ G) {
+    __shared__ double T[GB_][GB_ + 1];
     const int n_blk = nb * (nb + 1) / 2;
     const int blk = blockIdx.x;
     int bi = 0, rem = blk;
     while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
     const int bj = bi + rem;
-    for (int e = threadIdx.x; e < GB_ * GB_; e += blockDim.x) {
-        double s = 0.;
-        for (int k = 0; k < split; ++k) s += part[((size_t)k * n_blk + blk) * (GB_ * GB_) + e];
-        const int i = bi * GB_ + e / GB_, j = bj * GB_ + e % GB_;
-        if (i < P && j < P) {
-            G[(size_t)i * P + j] = s;
-            if (bi != bj) G[(size_t)j * P + i] = s;
-        }
+    const double *pp = part + (size_t)blk * (GB_ * GB_);
+    const size_t stride = (size_t)n_blk * (GB_ * GB_);
+    // thread t owns elements e = t + 256 k (k < 16): the sums of its 16 elements advance together over the parts
+    double sacc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sacc[k] = 0.;
+    for (int q = 0; q < split; ++q) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sacc[k] += pp[(size_t)q * stride + threadIdx.x + 256 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = threadIdx.x + 256 * k, r = e / GB_, c = e % GB_;
+        const int i = bi * GB_ + r, j = bj * GB_ + c;
+        if (i < P && j < P) G[(size_t)i * P + j] = sacc[k];
+        T[r][c] = sacc[k];
+    }
+    if (bi == bj) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = threadIdx.x + 256 * k, r = e / GB_, c = e % GB_;   // element (r, c) of the mirror block = T[c][r]
+        const int i = bj * GB_ + r, j = bi * GB_ + c;
+        if (i < P && j < P) G[(size_t)i * P + j] = T[c][r];
     }
 }
 

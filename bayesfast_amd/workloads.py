@@ -4,7 +4,7 @@ Only NumPy: these build the density *spec* (plain dict) that both the device pat
 """
 import numpy as np
 
-__all__ = ['correlated_gaussian_spec', 'banana_logp', 'funnel_logp', 'planck_like_logp', 'des_like_pipeline', 'sobol_normal',
+__all__ = ['correlated_gaussian_spec', 'banana_logp', 'funnel_logp', 'planck_like_logp', 'des_like_pipeline', 'random_pipeline_spec', 'sobol_normal',
            'B_STEP_BYTES', 'flops_per_leapfrog', 'flops_per_leapfrog_spec']
 
 
@@ -152,6 +152,32 @@ def des_like_pipeline(d=27, m=457, n_nonlinear=9, n_prior=13, seed=1):
 
     return dict(d=d, m=m, para_range=para_range, nonlinear=nonlinear, model=model, data=data, norm=float(norm), prior_mu=prior_mu,
                 prior_prec=prior_prec, prior_c0=prior_c0, x_true=x_true, logp=logp)
+
+
+def random_pipeline_spec(m, d, nq, seed=0, bound=True, transform=True):
+    """A pipeline-density spec (DeviceDensity / the oracle take it) with random coefficients, no fit: m outputs, linear in all d
+    inputs and quadratic in nq of them, unit precision, a prior on every second input, optionally behind the box transform
+    with hard bounds and surrogate input scales; the bound's ellipsoid from a random cloud (bound=False: far away)."""
+    rng = np.random.default_rng(seed)
+    mask = np.sort(rng.choice(d, nq, replace=False))
+    lin = rng.normal(size=(m, d + 1))
+    quad = np.zeros((m, nq, nq))
+    iu = np.triu_indices(nq)
+    quad[:, iu[0], iu[1]] = rng.normal(size=(m, iu[0].size)) * 0.3
+    x = rng.normal(size=(400, d)) * 0.3 + 0.5
+    mu = x.mean(0)
+    hess = np.linalg.inv(np.cov(x, rowvar=False))
+    alpha = float(np.max(np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5)) * (1. if bound else 1e6)
+    poly = dict(input_size=d, output_size=m, use_bound=True, mu=mu, hess=hess, alpha=alpha, f_mu=np.zeros(m),
+                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(m), coef=lin),
+                         dict(order='quadratic', input_mask=mask, output_mask=np.arange(m), coef=quad)])
+    u0 = np.full(d, 0.5)
+    f0 = lin[:, 0] + lin[:, 1:] @ u0 + np.einsum('ojk,j,k->o', quad, u0[mask], u0[mask])
+    rg = np.stack([-np.ones(d), np.ones(d)], 1) * 2.
+    return dict(d=d, ranges=rg if transform else None, hard_bounds=np.ones((d, 2), np.uint8) if transform else None,
+                su_lo=rg[:, 0] if transform else None, su_diff=(rg[:, 1] - rg[:, 0]) if transform else None, poly=poly, use_decay=False,
+                chi2=dict(y=f0 + rng.normal(size=m), prec_diag=np.ones(m), logp0=0.),
+                prior=dict(mu=np.zeros(d), prec_diag=np.where(np.arange(d) % 2, 4., 0.), c0=0.))
 
 
 def flops_per_leapfrog_spec(spec):

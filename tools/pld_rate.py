@@ -12,27 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def spec_of(m, d, nq, seed=0, bound=True, transform=True):
-    rng = np.random.default_rng(seed)
-    mask = np.sort(rng.choice(d, nq, replace=False))
-    lin = rng.normal(size=(m, d + 1))
-    quad = np.zeros((m, nq, nq))
-    iu = np.triu_indices(nq)
-    quad[:, iu[0], iu[1]] = rng.normal(size=(m, iu[0].size)) * 0.3
-    x = rng.normal(size=(400, d)) * 0.3 + 0.5
-    mu = x.mean(0)
-    hess = np.linalg.inv(np.cov(x, rowvar=False))
-    alpha = float(np.max(np.einsum('ij,jk,ik->i', x - mu, hess, x - mu)**0.5)) * (1. if bound else 1e6)
-    poly = dict(input_size=d, output_size=m, use_bound=True, mu=mu, hess=hess, alpha=alpha, f_mu=np.zeros(m),
-                configs=[dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(m), coef=lin),
-                         dict(order='quadratic', input_mask=mask, output_mask=np.arange(m), coef=quad)])
-    u0 = np.full(d, 0.5)
-    f0 = lin[:, 0] + lin[:, 1:] @ u0 + np.einsum('ojk,j,k->o', quad, u0[mask], u0[mask])
-    rg = np.stack([-np.ones(d), np.ones(d)], 1) * 2.
-    return dict(d=d, ranges=rg if transform else None, hard_bounds=np.ones((d, 2), np.uint8) if transform else None,
-                su_lo=rg[:, 0] if transform else None, su_diff=(rg[:, 1] - rg[:, 0]) if transform else None, poly=poly, use_decay=False,
-                chi2=dict(y=f0 + rng.normal(size=m), prec_diag=np.ones(m), logp0=0.),
-                prior=dict(mu=np.zeros(d), prec_diag=np.where(np.arange(d) % 2, 4., 0.), c0=0.))
+from bayesfast_amd.workloads import random_pipeline_spec as spec_of  # noqa: E402
 
 
 def main():
