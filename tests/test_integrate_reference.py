@@ -248,3 +248,52 @@ def test_tempered_nuts_on_the_seam(bf, seam):
     with pytest.raises(NotImplementedError):   # an arbitrary Python base density cannot run inside the kernel
         bf.sample(den, bf.samplers.TNTrace(density_base=bf.DensityLite(logp=lambda x: -0.5 * np.sum(x**2), input_size=3), n_chain=2,
                                            n_iter=10, n_warmup=5), verbose=False)
+
+
+def test_reference_recipe_runs_the_des_shaped_pipeline_on_the_seam(bf, seam):
+    """The reference's own ``Recipe.run()`` in the shape of examples/des-y1-w-cosmosis.ipynb cells 14-21 -- OptimizeStep with a
+    LINEAR multi-output surrogate, two SampleSteps with the block-quadratic one (``reuse_samples=1``), PostStep with truncated
+    importance sampling -- on a Density = [model (22 outputs), seam GaussianLikelihood, seam GaussianPrior] with input scales
+    and hard bounds: every fit goes through the device fit, every ``sample`` through the pipeline density of the seam.  It must
+    reach ``finished``, count its true-model calls as the notebook's does (a few hundred), and put the posterior on the truth."""
+    rng = np.random.default_rng(91)
+    d, m = 6, 22
+    lo, hi = -1. - rng.uniform(size=d), 1.5 + rng.uniform(size=d)
+    para_range = np.stack([lo, hi], 1)
+    nonlinear = np.array([0, 2, 3])
+    W1 = rng.normal(size=(m, d)) * 1.5
+    W2 = rng.normal(size=(m, 3, 3)) * 0.5
+    x_true = lo + (hi - lo) * rng.uniform(0.4, 0.6, size=d)
+
+    def model(x):
+        z = x[nonlinear]
+        return W1 @ x + np.einsum('ojk,j,k->o', W2, z, z) + 0.05 * np.sin(2. * z[0])
+
+    dvec = model(x_true) + rng.normal(size=m)
+    bf.utils.random.set_generator(27)
+    bf.utils.parallel.set_backend(4)
+    mod0 = bf.Module(fun=model, input_vars='x', output_vars='m')
+    like = seam.GaussianLikelihood(dvec, logp0=-1.5, input_vars='m', output_vars='like')
+    post = seam.GaussianPrior(d, indices=[1, 4, 5], mu=x_true[[1, 4, 5]], sigma=[0.3, 0.4, 0.25], c0=0.7, input_vars=['like', 'x'],
+                              output_vars='logp')
+    den = bf.Density(density_name='logp', module_list=[mod0, like, post], input_vars='x', input_shapes=d, input_scales=para_range,
+                     hard_bounds=True)
+    su0 = seam.PolyModel('linear', input_size=d, output_size=m, input_vars='x', output_vars='m', input_scales=para_range)
+    su1 = seam.PolyModel([bf.modules.PolyConfig('linear'), bf.modules.PolyConfig('quadratic', input_mask=nonlinear)], input_size=d,
+                         output_size=m, input_vars='x', output_vars='m', input_scales=para_range)
+    tr = {'n_chain': 4, 'n_iter': 600, 'n_warmup': 300}
+    x_0 = bf.utils.sobol.multivariate_normal(x_true, np.diag(((hi - lo) / 50)**2), 40)
+    rec = bf.recipe.Recipe(density=den, optimize=bf.recipe.OptimizeStep(surrogate_list=su0, alpha_n=2, x_0=x_0, sample_trace=dict(tr)),
+                           sample=[bf.recipe.SampleStep(surrogate_list=su1, alpha_n=2, reuse_samples=1, sample_trace=dict(tr)),
+                                   bf.recipe.SampleStep(surrogate_list=su1, alpha_n=2, reuse_samples=1, sample_trace=dict(tr))],
+                           post=bf.recipe.PostStep(n_is=400, k_trunc=0.25))
+    rec.run()
+    assert tuple(rec.recipe_trace.finished) == (True, True, True)
+    res = rec.get()
+    assert res.samples.shape == (400, d) and np.isfinite(res.weights_trunc).all()
+    assert 300 < res.n_call < 900                      # 40 + the fit points of three steps + 400 importance-sampling calls
+    tt = rec.recipe_trace.results.sample[-1].sample_trace
+    assert isinstance(tt, bf.samplers.TraceTuple) and tt.samples.shape == (4, 600, d)
+    s = res.samples
+    assert np.all(np.abs(s.mean(0) - x_true) < 4. * s.std(0)), (s.mean(0) - x_true) / s.std(0)
+    assert np.all(s > lo) and np.all(s < hi)
