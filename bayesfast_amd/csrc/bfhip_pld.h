@@ -32,7 +32,7 @@ struct PldLds {
     double *XE;    // [16][DP + 2]  evaluation point of every chain, then 1 and 0
     double *CH;    // [16]          beta of the chains outside the bound's ellipsoid, 0 inside
     double *YW;    // [2][MP]       y' and f_mu'
-    double *RED;   // [NT1][2][16]  per row tile and chain: sum r^2, sum (f_0 - f_mu) r
+    double *RED;   // [16][2][16]   per wave and chain: sum r^2, sum (f_0 - f_mu) r over the wave's row tiles
     double *RB;    // [NS2][XS]     r as the B operand of GEMM2
     double *PHI;   // [NS1][XS]     monomials as the B operand of GEMM1; slot 0 of W afterwards
     double *WX;    // [KS2 - 1][NS1][XS]  further partial-sum slots of W
@@ -41,8 +41,8 @@ struct PldLds {
 };
 
 __host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent) {
-    const size_t ns1 = PP / 4, ns2 = MP / 4, nt1 = MP / 16;
-    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + nt1 * 32 + ns2 * PLD_XS + (size_t)KS2 * ns1 * PLD_XS + (size_t)n_ent * DP + PP / 2;
+    const size_t ns1 = PP / 4, ns2 = MP / 4;
+    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + 512 + ns2 * PLD_XS + (size_t)KS2 * ns1 * PLD_XS + (size_t)n_ent * DP + PP / 2;
 }
 
 #ifndef BF_HOST_EMU
@@ -52,7 +52,7 @@ __device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl) {
     L.CH = L.XE + 16 * (DP + 2);
     L.YW = L.CH + 16;
     L.RED = L.YW + 2 * pl.MP;
-    L.RB = L.RED + pl.NT1 * 32;
+    L.RB = L.RED + 512;
     L.PHI = L.RB + (size_t)pl.NS2 * PLD_XS;
     L.WX = L.PHI + (size_t)pl.NS1 * PLD_XS;
     double *gt = L.WX + (size_t)(pl.KS2 - 1) * pl.NS1 * PLD_XS;
@@ -157,43 +157,48 @@ __device__ inline void pld_tile2(const double *__restrict__ Af0, const double *_
 }
 
 // the epilogue of one row tile of GEMM1: the bound's extrapolation per chain, r = F - y' into the B operand of GEMM2, and the
-// tile's contributions to sum r^2 and sum (f_0 - f_mu) r
-__device__ inline void pld_epilogue1(const PldDev &pl, const PldLds &L, double alpha, double beta, int t, const d4_t &acc, int lane) {
+// lane's contributions to sum r^2 and sum (f_0 - f_mu) r (reduced once per wave, after its last tile: pld_red_put)
+__device__ inline void pld_epilogue1(const PldDev &pl, const PldLds &L, double alpha, double inv_alpha, double beta, int t, const d4_t &acc,
+                                     int lane, double &s_rr, double &s_fr) {
     const int mg = lane >> 4;
-    double s_rr = 0., s_fr = 0.;
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int row = 16 * t + 4 * r4 + mg;
         const double f0 = acc[r4], y = L.YW[row], fmu = L.YW[pl.MP + row];
-        const double fv = beta > 0. ? (beta * f0 - (beta - alpha) * fmu) / alpha : f0;   // modules/poly.py:487
+        const double fv = beta > 0. ? (beta * f0 - (beta - alpha) * fmu) * inv_alpha : f0;   // modules/poly.py:487
         const double r = fv - y;
         L.RB[(4 * t + r4) * PLD_XS + lane] = r;   // row >> 2 = 4 t + r4, 16 (row & 3) + chain = lane
         s_rr += r * r;
         s_fr += (f0 - fmu) * r;
     }
+}
+// the wave's two sums per chain (lane & 15 = chain; the four 16-lane rows hold different output rows) into its RED slot
+__device__ inline void pld_red_put(const PldLds &L, int w, int lane, double s_rr, double s_fr) {
     s_rr = pld_rowsum4(s_rr);
     s_fr = pld_rowsum4(s_fr);
     if (lane < 16) {
-        L.RED[(t * 2 + 0) * 16 + lane] = s_rr;
-        L.RED[(t * 2 + 1) * 16 + lane] = s_fr;
+        L.RED[(w * 2 + 0) * 16 + lane] = s_rr;
+        L.RED[(w * 2 + 1) * 16 + lane] = s_fr;
     }
 }
 
 // GEMM1 and its epilogue, all NWV waves of the workgroup: F_0 = C' Phi, row tiles dealt two at a time
 __device__ inline void pld_gemm1(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
-    const double beta = L.CH[lane & 15];
+    const double beta = L.CH[lane & 15], inv_alpha = 1. / alpha;
+    double s_rr = 0., s_fr = 0.;
     for (int t = w; t < pl.NT1; t += 2 * nwv) {
         const int t2 = t + nwv;
         if (t2 < pl.NT1) {
             d4_t a0, a1;
             pld_tile2(pl.CF + (size_t)t * pl.NS1 * 64, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1);
-            pld_epilogue1(pl, L, alpha, beta, t, a0, lane);
-            pld_epilogue1(pl, L, alpha, beta, t2, a1, lane);
+            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
+            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
         } else {
             const d4_t a0 = pld_tile(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.NS1, lane);
-            pld_epilogue1(pl, L, alpha, beta, t, a0, lane);
+            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
         }
     }
+    pld_red_put(L, w, lane, s_rr, s_fr);
 }
 
 // two independent (row tile, K range) contractions side by side (GEMM2: different A and different B): two accumulation chains
@@ -333,38 +338,46 @@ __device__ inline double pld_sum_b(double v) {   // sum over the four blocks b =
     return v;
 }
 
-// epilogue of one row tile of GEMM1, eight-chain form: lane 16 i + 4 b + n holds row 16 t + 4 b + i of chains n and n + 4
-__device__ inline void pld_epilogue1_q8(const PldDev &pl, const PldLds &L, double alpha, int t, const PldAcc8 &acc, int lane) {
+// epilogue of one row tile of GEMM1, eight-chain form: lane 16 i + 4 b + n holds row 16 t + 4 b + i of chains n and n + 4; the
+// lane's contributions to the two sums are accumulated over the wave's tiles and reduced once (pld_red_put_q8)
+__device__ inline void pld_epilogue1_q8(const PldDev &pl, const PldLds &L, double alpha, double inv_alpha, const double (&beta)[2], int t,
+                                        const PldAcc8 &acc, int lane, double (&s_rr)[2], double (&s_fr)[2]) {
     const int i = lane >> 4, b = (lane >> 2) & 3, n = lane & 3;
     const int row = 16 * t + 4 * b + i;
     const double y = L.YW[row], fmu = L.YW[pl.MP + row];
-    double s_rr[2], s_fr[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const double beta = L.CH[n + 4 * h], f0 = h ? acc.hi : acc.lo;
-        const double fv = beta > 0. ? (beta * f0 - (beta - alpha) * fmu) / alpha : f0;   // modules/poly.py:487
+        const double f0 = h ? acc.hi : acc.lo;
+        const double fv = beta[h] > 0. ? (beta[h] * f0 - (beta[h] - alpha) * fmu) * inv_alpha : f0;   // modules/poly.py:487
         const double r = fv - y;
         L.RB[(4 * t + b) * PLD_XS + n + 4 * h + 16 * i] = r;   // row >> 2 = 4 t + b, row & 3 = i
-        s_rr[h] = pld_rowsum4(pld_sum_b(r * r));
-        s_fr[h] = pld_rowsum4(pld_sum_b((f0 - fmu) * r));
+        s_rr[h] += r * r;
+        s_fr[h] += (f0 - fmu) * r;
     }
-    if (lane < 4) {
+}
+__device__ inline void pld_red_put_q8(const PldLds &L, int w, int lane, const double (&s_rr)[2], const double (&s_fr)[2]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            L.RED[(t * 2 + 0) * 16 + lane + 4 * h] = s_rr[h];
-            L.RED[(t * 2 + 1) * 16 + lane + 4 * h] = s_fr[h];
+    for (int h = 0; h < 2; ++h) {
+        const double a = pld_rowsum4(pld_sum_b(s_rr[h])), c = pld_rowsum4(pld_sum_b(s_fr[h]));
+        if (lane < 4) {
+            L.RED[(w * 2 + 0) * 16 + lane + 4 * h] = a;
+            L.RED[(w * 2 + 1) * 16 + lane + 4 * h] = c;
         }
     }
 }
 
 __device__ inline void pld_gemm1_q8(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
+    const double inv_alpha = 1. / alpha;
+    const double beta[2] = {L.CH[lane & 3], L.CH[(lane & 3) + 4]};
+    double s_rr[2] = {0., 0.}, s_fr[2] = {0., 0.};
     for (int t = w; t < pl.NT1; t += 2 * nwv) {
         const int t2 = t + nwv < pl.NT1 ? t + nwv : t;   // (an odd tile out is computed twice side by side: same result, same time)
         PldAcc8 a0, a1;
         pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1);
-        pld_epilogue1_q8(pl, L, alpha, t, a0, lane);
-        if (t2 != t) pld_epilogue1_q8(pl, L, alpha, t2, a1, lane);
+        pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
+        if (t2 != t) pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
     }
+    pld_red_put_q8(L, w, lane, s_rr, s_fr);
 }
 
 __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
@@ -402,28 +415,13 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
 // GEMM1 and its epilogue, all NWV waves of the workgroup: F_0 = C' Phi per row tile, the bound's extrapolation per chain,
 // r = F - y' into the B operand of GEMM2, and the tile's contributions to sum r^2 and sum (f_0 - f_mu) r
 __device__ inline void pld_gemm1_w16(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
-    const int mc = lane & 15, mg = lane >> 4;
-    const double beta = L.CH[mc];
+    const double beta = L.CH[lane & 15], inv_alpha = 1. / alpha;
+    double s_rr = 0., s_fr = 0.;
     for (int t = w; t < pl.NT1; t += nwv) {
         const d4_t acc = pld_tile(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.NS1, lane);
-        double s_rr = 0., s_fr = 0.;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int row = 16 * t + 4 * r4 + mg;
-            const double f0 = acc[r4], y = L.YW[row], fmu = L.YW[pl.MP + row];
-            const double fv = beta > 0. ? (beta * f0 - (beta - alpha) * fmu) / alpha : f0;   // modules/poly.py:487
-            const double r = fv - y;
-            L.RB[(4 * t + r4) * PLD_XS + lane] = r;   // row >> 2 = 4 t + r4, 16 (row & 3) + chain = lane
-            s_rr += r * r;
-            s_fr += (f0 - fmu) * r;
-        }
-        s_rr = pld_rowsum4(s_rr);
-        s_fr = pld_rowsum4(s_fr);
-        if (lane < 16) {
-            L.RED[(t * 2 + 0) * 16 + lane] = s_rr;
-            L.RED[(t * 2 + 1) * 16 + lane] = s_fr;
-        }
+        pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, acc, lane, s_rr, s_fr);
     }
+    pld_red_put(L, w, lane, s_rr, s_fr);
 }
 
 // GEMM2, all waves: W = C'^T R, (row tile, K part) jobs; part kp lands in W slot kp (slot 0 = PHI, which GEMM1 has consumed)
@@ -442,13 +440,11 @@ __device__ inline void pld_gemm2_w16(const PldDev &pl, const PldLds &L, int w, i
     }
 }
 
-// chain wave c after GEMM2: the chain's sums (lane t holds row tile t's parts; the caller reduces over the wave) ...
-__device__ inline void pld_sums(const PldDev &pl, const PldLds &L, int c, int lane, double &s_rr, double &s_fr) {
-    s_rr = s_fr = 0.;
-    for (int t = lane; t < pl.NT1; t += 64) {
-        s_rr += L.RED[(t * 2 + 0) * 16 + c];
-        s_fr += L.RED[(t * 2 + 1) * 16 + c];
-    }
+// chain wave c after GEMM2: the chain's sums (lane v holds wave v's part; the caller reduces over the wave) ...
+__device__ inline void pld_sums(const PldDev &pl, const PldLds &L, int c, int lane, int nwv, double &s_rr, double &s_fr) {
+    (void)pl;
+    s_rr = lane < nwv ? L.RED[(lane * 2 + 0) * 16 + c] : 0.;
+    s_fr = lane < nwv ? L.RED[(lane * 2 + 1) * 16 + c] : 0.;
 }
 
 // ... and component `dim` of J_0^T r: the monomials that contain x_dim, each times its cofactor

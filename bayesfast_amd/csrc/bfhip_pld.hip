@@ -307,7 +307,7 @@ __global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int 
         pld_gemm2(pl, L, w, 16, lane);
         __syncthreads();
         double s_rr, s_fr;
-        pld_sums(pl, L, w, lane, s_rr, s_fr);
+        pld_sums(pl, L, w, lane, 16, s_rr, s_fr);
         s_rr = pld_wave_sum(s_rr);
         s_fr = pld_wave_sum(s_fr);
         double gn = lane < DP ? pld_grad(pl, L, DP, w, lane) : 0.;   // (J_0^T r)_lane

@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             }
             if (evaluating) {
                 double s2[2];
-                pld_sums(pl, PL, w, lane, s2[0], s2[1]);
+                pld_sums(pl, PL, w, lane, NWV, s2[0], s2[1]);
                 wave_sum_n<2>(s2);
                 double gj0 = lane < DP ? pld_grad(pl, PL, DP, w, lane) : 0.;   // (J_0^T r)_lane
                 TRACEP(15);
