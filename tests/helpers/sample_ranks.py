@@ -20,9 +20,21 @@ def main(out):
     rng = np.random.default_rng(3)
     Pm = np.eye(d) + 0.3 * rng.normal(size=(d, d)) / np.sqrt(d)
     Pm = Pm @ Pm.T
-    den = bfa.SurrogateDensity(bfa.PolyModel('quadratic', input_size=d, output_size=1))
-    xf = rng.normal(size=(120, d)) * 1.5
-    den.fit(xf, -0.5 * np.einsum('ij,jk,ik->i', xf, Pm, xf))
+    if os.environ.get('BF_TEST_PIPELINE'):   # the pipeline density (multi-output surrogate + chi-square + prior behind the box transform)
+        from bayesfast_amd.workloads import des_like_pipeline
+        w = des_like_pipeline(d=d, m=24, n_nonlinear=3, n_prior=3, seed=5)
+        su = bfa.PolyModel([bfa.PolyConfig('linear'), bfa.PolyConfig('quadratic', input_mask=w['nonlinear'])], input_size=d, output_size=24,
+                           input_scales=w['para_range'])
+        den = bfa.Chi2PipelineDensity(su, w['data'], prec_diag=np.ones(24), logp0=w['norm'], prior_mu=w['prior_mu'], prior_prec=w['prior_prec'],
+                                      prior_c0=w['prior_c0'], input_scales=w['para_range'], hard_bounds=True)
+        lo, hi = w['para_range'][:, 0], w['para_range'][:, 1]
+        u0 = (w['x_true'] - lo) / (hi - lo)
+        xf = lo + (hi - lo) * np.clip(u0 + 0.1 * rng.normal(size=(5 * su.n_param, d)), 0.02, 0.98)
+        den.fit(xf, w['logp'](xf), y=w['model'](xf))
+    else:
+        den = bfa.SurrogateDensity(bfa.PolyModel('quadratic', input_size=d, output_size=1))
+        xf = rng.normal(size=(120, d)) * 1.5
+        den.fit(xf, -0.5 * np.einsum('ij,jk,ik->i', xf, Pm, xf))
     # default trace: no seed given by the caller (rank 0's entropy is what every rank must use), then a second round
     # warm-started from the first (_get_step_size / _get_metric reduce over all ranks)
     seed = int(os.environ['BF_TEST_SEED'])

@@ -252,8 +252,8 @@ def test_config4_funnel_target_accept_095():
     assert acc > 0.85, acc
 
 
-@pytest.mark.parametrize('ipl', [0, 7])
-def test_sample_two_ranks_equals_one_rank(tmp_path, ipl):
+@pytest.mark.parametrize('ipl,pipeline', [(0, False), (7, False), (0, True)])
+def test_sample_two_ranks_equals_one_rank(tmp_path, ipl, pipeline):
     """(ipl = 7: nine launches per round under layout 'auto' -- the layout of a launch is a pure function of the launches
     before it, decided from the trees of ALL ranks' chains, so it is the same for one rank and for two.)
     sample() under torch.distributed (two ranks sharing the box's GPU over gloo, ragged shards 11 + 11 of 22 chains) returns
@@ -264,6 +264,8 @@ def test_sample_two_ranks_equals_one_rank(tmp_path, ipl):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     helper = os.path.join(root, 'tests', 'helpers', 'sample_ranks.py')
     env = dict(os.environ, BF_TEST_SEED='17', BFHIP_SHARE_DEVICE='1', BF_TEST_IPL=str(ipl))
+    if pipeline:   # (the same on the pipeline density: Chi2PipelineDensity shards like any SurrogateDensity)
+        env['BF_TEST_PIPELINE'] = '1'
     one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
     r = subprocess.run([sys.executable, helper, one], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
