@@ -33,7 +33,10 @@ enum {
 // ---- pipeline density (bfhip_pld.h): multi-output surrogate + Gaussian likelihood (+ prior), device-side description ----
 struct PldDev {
     int on;                 // the uploaded density is a pipeline density
-    int m, MP, NT1, NS2;    // outputs; padded to 16; row tiles of GEMM1; k-steps of GEMM2
+    int m, MP, NT1, NS2;    // rows of C' (the outputs, or the monomial count when the outputs were compressed); padded to 16; row
+                            // tiles of GEMM1; k-steps of GEMM2
+    int m_full;             // the surrogate's output_size
+    double k_ff, k_fy;      // compressed outputs: |tail of Q^T f_mu'|^2 and (tail of Q^T f_mu') . (tail of Q^T y'), 0 otherwise
     int nf, PP, NS1, NT2;   // monomials; padded to 16; k-steps of GEMM1; row tiles of GEMM2
     int KS2, KPJ2;          // K-split of GEMM2 (partial sums in separate W slots) and k-steps per part
     int n_ent;              // entries per dimension of the gradient table

@@ -9,8 +9,9 @@
 //     grad = -(d phi / d x)^T C^T prec (f - y).
 // The precision's Cholesky factor is folded into the coefficients when the density is uploaded (C' = L^T C, y' = L^T y,
 // f_mu' = L^T f_mu: the bound's extrapolation, modules/poly.py:480-503, is linear in f_0 and f_mu, so it commutes with the
-// whitening), which removes the m x m product from the kernel: what is left are two dense contractions on the FP64 matrix
-// cores with the 16 chains as the 16 columns,
+// whitening), which removes the m x m product from the kernel; when there are more outputs than monomials the output space is
+// compressed to nf rows by a Householder factorisation C' = Q [R; 0], exactly (bfhip_pld.hip): what is left are two dense
+// contractions on the FP64 matrix cores with the 16 chains as the 16 columns,
 //     GEMM1   F (MP x 16)  = C' (MP x PP)   Phi (PP x 16)         r = F - y'  (bound: F extrapolated first)
 //     GEMM2   W (PP x 16)  = C'^T (PP x MP) R   (MP x 16)
 // and a sparse per-chain contraction  (J_0^T r)_j = sum_e mult_e W[p_e] x[a_e] x[b_e]  over the monomials that contain x_j.

@@ -1,6 +1,7 @@
 // bfhip_pld.hip -- pipeline density (bfhip_pld.h): upload (monomial table, whitening, MFMA fragments, gradient table) and
 // the stand-alone batched logp / grad; the fused sampler's instantiation for it lives in bfhip_sampler.hip.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "bfhip_common.h"
@@ -99,9 +100,9 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
                 if (j < 0 || j >= d || k < 0 || k >= d || l < 0 || l >= d) return bf_set_error(BFHIP_ERR_ARG, "mask3 out of range");
                 add(j, k, l, [&](int o) { return pm.cubic3[(((size_t)o * pm.n3 + a) * pm.n3 + b) * pm.n3 + c]; });
             }
-    const int nf = (int)mono.size(), PP = roundup(nf, 16), MP = roundup(m, 16);
+    const int nf = (int)mono.size(), PP = roundup(nf, 16);
+    int MP = roundup(m, 16);
     if (PP >= 65536) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_pipeline_upload: %d monomials", nf);
-    const int NT1 = MP / 16, NS1 = PP / 4, NT2 = PP / 16, NS2 = MP / 4;
 
     // ---- whitening: prec = L L^T; C' = L^T C, y' = L^T y, f_mu' = L^T f_mu ----
     std::vector<double> Cw((size_t)MP * PP, 0.), yw(MP, 0.), fmuw(MP, 0.);
@@ -137,6 +138,60 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
             for (int p = 0; p < nf; ++p) Cw[(size_t)i * PP + p] = s * col[p][i];
         }
     }
+
+    // ---- output-space compression: more outputs than monomials -> m_eff = nf, exactly ----
+    // f_0 = C' phi lives in the column space of C' (at most nf dimensions of the m): with the Householder factorisation
+    // C' = Q [R; 0] (Q m x m orthogonal), |a f_0 - b f_mu' - y'|^2 = |a R phi - b (Q^T f_mu')_head - (Q^T y')_head|^2 + |b (Q^T f_mu')_tail
+    // + (Q^T y')_tail|^2, and J_0^T r = (d phi)^T R^T r_head: the device works with R (nf x nf), the heads of Q^T y' and Q^T f_mu',
+    // and three scalars of the tails (|y_tail|^2 goes into logp0; |f_mu_tail|^2 and f_mu_tail . y_tail enter only outside the
+    // bound, where b = (beta - alpha) / alpha is not zero).  At the DES shape (m = 457, nf = 73) both contractions shrink 6.3x.
+    double k_ff = 0., k_fy = 0., k_yy = 0.;
+    int m_eff = m;
+    const bool compress = !(getenv("BFHIP_PLD_NO_COMPRESS") && atoi(getenv("BFHIP_PLD_NO_COMPRESS"))) && m > nf;
+    if (compress) {
+        // Householder QR of the m x nf block of Cw, in place; the reflectors are applied to yw and fmuw as they are formed
+        std::vector<double> v(m);
+        for (int j = 0; j < nf; ++j) {
+            double nrm = 0.;
+            for (int i = j; i < m; ++i) nrm += Cw[(size_t)i * PP + j] * Cw[(size_t)i * PP + j];
+            nrm = std::sqrt(nrm);
+            if (!(nrm > 0.)) continue;   // (a zero column below the diagonal: nothing to reflect)
+            const double x0 = Cw[(size_t)j * PP + j];
+            const double alpha_h = x0 > 0. ? -nrm : nrm;
+            double vnorm2 = 0.;
+            for (int i = j; i < m; ++i) { v[i] = Cw[(size_t)i * PP + j]; }
+            v[j] -= alpha_h;
+            for (int i = j; i < m; ++i) vnorm2 += v[i] * v[i];
+            if (!(vnorm2 > 0.)) continue;
+            const double tau = 2. / vnorm2;
+            auto reflect_col = [&](auto get, auto put) {
+                double dotv = 0.;
+                for (int i = j; i < m; ++i) dotv += v[i] * get(i);
+                const double sc = tau * dotv;
+                for (int i = j; i < m; ++i) put(i, get(i) - sc * v[i]);
+            };
+            for (int c = j; c < nf; ++c)
+                reflect_col([&](int i) { return Cw[(size_t)i * PP + c]; }, [&](int i, double val) { Cw[(size_t)i * PP + c] = val; });
+            reflect_col([&](int i) { return yw[i]; }, [&](int i, double val) { yw[i] = val; });
+            reflect_col([&](int i) { return fmuw[i]; }, [&](int i, double val) { fmuw[i] = val; });
+            for (int i = j + 1; i < m; ++i) Cw[(size_t)i * PP + j] = 0.;   // (exactly: below the diagonal of R)
+        }
+        for (int i = nf; i < m; ++i) {
+            k_ff += fmuw[i] * fmuw[i];
+            k_fy += fmuw[i] * yw[i];
+            k_yy += yw[i] * yw[i];
+        }
+        m_eff = nf;
+        MP = roundup(m_eff, 16);
+        std::vector<double> C2((size_t)MP * PP, 0.), y2(MP, 0.), f2(MP, 0.);
+        for (int i = 0; i < m_eff; ++i) {
+            for (int c = 0; c < nf; ++c) C2[(size_t)i * PP + c] = Cw[(size_t)i * PP + c];
+            y2[i] = yw[i];
+            f2[i] = fmuw[i];
+        }
+        Cw.swap(C2); yw.swap(y2); fmuw.swap(f2);
+    }
+    const int NT1 = MP / 16, NS1 = PP / 4, NT2 = PP / 16, NS2 = MP / 4;
 
     // ---- A fragments of C' and C'^T ----
     std::vector<double> CF((size_t)NT1 * NS1 * 64), CTF((size_t)NT2 * NS2 * 64);
@@ -225,7 +280,8 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     const double *dbase = (const double *)ctx->pld_buf;
     PldDev &pl = dm.pld;
     pl.on = 1;
-    pl.m = m; pl.MP = MP; pl.NT1 = NT1; pl.NS2 = NS2;
+    pl.m = m_eff; pl.m_full = m; pl.MP = MP; pl.NT1 = NT1; pl.NS2 = NS2;
+    pl.k_ff = k_ff; pl.k_fy = k_fy;
     pl.nf = nf; pl.PP = PP; pl.NS1 = NS1; pl.NT2 = NT2;
     pl.KS2 = best_ks; pl.KPJ2 = roundup((NS2 + best_ks - 1) / best_ks, 4);
     pl.n_ent = (int)n_ent;
@@ -234,7 +290,7 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     pl.prior_mu = dbase + o_pr; pl.prior_prec = dbase + o_pr + DP;
     pl.gtab = (const unsigned long long *)(dbase + o_g);
     pl.mono = (const unsigned *)(dbase + o_m);
-    pl.logp0 = ds->logp0;
+    pl.logp0 = ds->logp0 - 0.5 * k_yy;   // (the part of the data vector outside the surrogate's column space: a constant)
     pl.prior_c0 = ds->prior_c0;
     ctx->has_model = 1;
     return 0;
@@ -311,6 +367,11 @@ __global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int 
         s_rr = pld_wave_sum(s_rr);
         s_fr = pld_wave_sum(s_fr);
         double gn = lane < DP ? pld_grad(pl, L, DP, w, lane) : 0.;   // (J_0^T r)_lane
+        if (beta > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
+            const double b = (beta - m.alpha) / m.alpha;
+            s_rr += b * (b * pl.k_ff + 2. * pl.k_fy);
+            s_fr += b * pl.k_ff + pl.k_fy;
+        }
         if (beta > 0.) {   // modules/poly.py:494-496 contracted with r
             const double r_dotj = pld_wave_sum(gn * xm);
             gn += (s_fr / m.alpha - r_dotj / beta) * (hv / beta);

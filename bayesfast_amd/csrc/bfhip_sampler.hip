@@ -154,8 +154,8 @@ struct SamplerGeo {
 // The pipeline density has both forms: FS = 8, sixteen waves of 128 registers (~230 spilled VGPRs: its scratch traffic evicts
 // part of the coefficient fragments from the XCD's L2, 17 KB of HBM reads per leapfrog step, but sixteen chains fill the
 // 16-column tiles), and FS = 9, eight waves of 256 registers (no spills, 4 x 4 x 4 tiles for its eight chains).  Measured on the
-// DES shape (tools/pld_rate.py): 4096 chains 5.7 against 5.2 x 10^7 leapfrog steps/s, 1024 chains 1.8 against 2.6 x 10^7 -- the
-// launch takes FS = 9 when its chains fit eight to a CU.
+// DES shape before the outputs were compressed (tools/pld_rate.py): 4096 chains 5.7 against 5.2 x 10^7 leapfrog steps/s, 1024
+// chains 1.8 against 2.6 x 10^7; launch_sampler has the rule that followed once they were.
 #define BF_SAMPLER_WAVES(W, FULLM, FS) (((W) == 8 || (FULLM) || (FS) == 9) ? 8 : 16)
 
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
@@ -1366,6 +1366,11 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 pld_sums(pl, PL, w, lane, NWV, s2[0], s2[1]);
                 wave_sum_n<2>(s2);
                 double gj0 = lane < DP ? pld_grad(pl, PL, DP, w, lane) : 0.;   // (J_0^T r)_lane
+                if (beta_o > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
+                    const double b = (beta_o - m.alpha) / m.alpha;
+                    s2[0] += b * (b * pl.k_ff + 2. * pl.k_fy);
+                    s2[1] += b * pl.k_ff + pl.k_fy;
+                }
                 TRACEP(15);
                 if (beta_o > 0.) {   // modules/poly.py:494-496, contracted with r
                     const double r_dotj = wave_sum(gj0 * xm0);
@@ -1851,7 +1856,11 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         constexpr int WP = W <= 4 ? W : 1;   // (keeps W = 8 from instantiating it)
         if (W > 4) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density is implemented for d <= 64");
         // eight chains per workgroup (and 256 registers a wave) while that fills the chip, sixteen beyond
-        const bool w8 = g_pld_waves ? g_pld_waves == 8 : args.n_chain <= 8 * ctx->n_cu;
+        // (measured, tools/pld_rate.py: with the outputs compressed to the monomial count the DES shape's contractions are 200
+        // tile k-steps and the eight-wave form wins at every chain count -- 1.41 against 1.30 x 10^8 at 4096 chains; at 1800 tile
+        // k-steps, a quadratic config on 20 inputs, the sixteen-wave form's full tiles win, 8.2 against 7.3 x 10^7)
+        const long gemm_steps = (long)m.pld.NT1 * m.pld.NS1 + (long)m.pld.NT2 * m.pld.NS2;
+        const bool w8 = g_pld_waves ? g_pld_waves == 8 : (args.n_chain <= 8 * ctx->n_cu || gemm_steps <= 800);
         return w8 ? launch_sampler_t<WP, NUTS, false, 9>(ctx, args) : launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
     }
     if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);
