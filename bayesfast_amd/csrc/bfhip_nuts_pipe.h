@@ -68,7 +68,6 @@ __device__ inline double bf_pipe_mfma(double a_, double b_, double c_) { return 
 
 template <int W, bool TR, bool DEC = false, int QUAD = 0>
 __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
-    static_assert(!(QUAD && DEC), "the fused second pass keeps the 16-column tiles");
     using G = SamplerGeo<W>;
     using PG = PipeGeo<W, DEC>;
     constexpr int DP = G::DP, NS = G::NS, XS = G::XS, GS = G::GS;
@@ -104,6 +103,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     const double c_lin = lane_ok ? m.pd[PD_LIN * DP + lane] : 0.;
     const double c_mu = lane_ok ? m.pd[PD_MU * DP + lane] : 0.;
     const double c_dmu = (DEC && lane_ok) ? m.pd[PD_DMU * DP + lane] : 0.;
+    const double c_smu = lane_ok ? m.pd[PD_SMU * DP + lane] : 0.;
     // constraint transform of this lane's dimension (TR) and what phase A leaves for phase C: x(q), dx/dq,
     // (d2x/dq2) / (dx/dq), log |dx/dq|
     const int c_kind = (TR && lane_ok) ? (int)m.pd[PD_KIND * DP + lane] : 0;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     double L0p = 0., L0q = 0.;            // stack level 0 (a single waiting leaf)
     double TPg = 0., L0g = 0.;            // the gradient at the proposals TPq / L0q (the next iteration may start there)
     uint64_t rs[4] = {0, 0, 0, 0};
-    int i_iter = 0, mode = M_DONE, prev_mode = M_INIT, err = 0;
+    int i_iter = 0, mode = M_DONE, err = 0;
     double eps = 0., eps_t = 0.;
     int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0;
     double start_energy = 0., acc_sum = 0.;
@@ -322,9 +322,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         TRACE(0);
         // ================= phase A: first half of the (speculative) leapfrog step, B operands =================
         bool evaluating = false;
-        if (mode == M_OOB) {
-            evaluating = true;  // second pass at the projected point (eps_t stays: the step's second half comes after it)
-        } else if (mode == M_INIT) {
+        if (mode == M_INIT) {
             evaluating = true;  // compute_state at the start of a launch (base_hmc.py:70): a step of length 0
             eps_t = 0.;
         } else if (mode == M_LEAF) {
@@ -351,7 +349,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             if (evaluating) eps_t = eps * (double)dir_use;
         }
         if (evaluating) {
-            if (mode != M_OOB) {
+            {
                 const double dt = 0.5 * eps_t;
                 p = p + dt * g;                    // integration.py:80
                 q = q + eps_t * (var * p);         // :82-85
@@ -364,12 +362,9 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 jac = J;
                 gj = J2 / J;
             }
-            double x_eval = xs;
-            if (mode == M_OOB)  // modules/poly.py:482
-                x_eval = (m.alpha * xs + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
             if (lane_ok) {
                 const int xi = (lane >> 2) * XS + w + 16 * (lane & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
-                XB[xi] = x_eval;
+                XB[xi] = xs;
                 XB[NS * XS + xi] = xs - c_mu;
                 if constexpr (DEC) XB[2 * NS * XS + xi] = xs - c_dmu;   // (the decay term lives in the original space)
             }
@@ -676,24 +671,20 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 TPg = g;
             }
         };
-        // DEC: a leaf outside the bound takes its second pass (the surrogate at the projected point, poly.py:480-503) in THIS
-        // trip -- one more pair of barriers and the S tiles again -- as bf_sampler_kernel's decay instantiation does (FUSE): the
-        // densities that carry the decay term run outside the bound nearly all the time, and a second pass that was a trip of
-        // its own had nothing to overlap with in this kernel
-        bool oob_fused = false;
-        double beta_k = 0., hv_k = 0., dgr_k = 0., bd2_k = 0., logdet_k = 0.;
+        // Outside the bound (modules/poly.py:480-503) the surrogate is wanted at the projected point x_0 = mu + t (x - mu),
+        // t = alpha / beta.  It is linear + quadratic, so S x_0 = S mu + t (S x - S mu) follows from the S x of THIS trip and
+        // the per-dimension table's S mu -- no second pass over the tiles, no trip of its own (M_OOB is not used by this
+        // kernel) -- and the two sums of the reference's formulas are polynomials in t of two t-free sums:
+        //   a1 = (x - mu) . (S mu + lin),  a2 = (x - mu) . S (x - mu)   (bfhip_oob.h).
         if (evaluating && !ended) {
             const double sx = lane_ok ? gb_read(0) : 0.;
             const double hv = lane_ok ? gb_read(1) : 0.;
             const double dgr = (DEC && lane_ok) ? gb_read(2) : 0.;   // H_decay (x - mu_decay)
-            double xev = xs;
-            if (mode == M_OOB) xev = (m.alpha * xs + (cs_get(CS_BETA) - m.alpha) * c_mu) / cs_get(CS_BETA);
             double gn = sx + c_lin;
             const double xm = xs - c_mu;
-            const bool fast_kin = !DEC && mode != M_OOB;   // (with the decay term the gradient is final only after its sum)
+            constexpr bool fast_kin = !DEC;   // (with the decay term the gradient is final only after its sum)
             // (the surrogate's value, linear + quadratic term, summed per lane: one reduction for both)
-            double r3[3] = {0., __builtin_fma(0.5 * xev, sx, c_lin * xev), xm * hv};
-            double r_dotj = gn * xm;  // dot(jj_0, x - mu), poly.py:496 (used in the OOB pass only)
+            double r3[3] = {0., __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv};
             if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
                 double ge = gn * jac;
                 if constexpr (TR) ge += gj;
@@ -704,74 +695,25 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             wave_sum_n<3>(r3);
             TRACE(8);
             const double r_kin = r3[0], r_val = r3[1], r_b2 = r3[2];
-            if (mode == M_OOB) r_dotj = wave_sum(r_dotj);
             double r_bd2 = 0.;
             if constexpr (DEC) r_bd2 = wave_sum((xs - c_dmu) * dgr);
             double logdet = 0.;
             if constexpr (TR) logdet = wave_sum(logdet_l);
             double f = (m.c0 + r_val) + 0.;
             double beta = 0.;
-            bool oob_now = false;
-            {
-                const double a2 = m.alpha * m.alpha;
-                if (mode != M_OOB && !(r_b2 < a2 * (1. - 1e-12))) beta = usqrt(r_b2);
-                if (mode == M_OOB) {  // second pass: f, gn currently hold f_0 and jj_0 (poly.py:484-496)
-                    const double f0 = f, beta_saved = cs_get(CS_BETA);
-                    f = (beta_saved * f0 - (beta_saved - m.alpha) * m.f_mu) / m.alpha;
-                    const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta_saved;
-                    gn = gn + coef * (hv / beta_saved);
-                } else if (beta > m.alpha) {
-                    oob_now = true;
-                }
+            const double a2 = m.alpha * m.alpha;
+            if (!(r_b2 < a2 * (1. - 1e-12))) beta = usqrt(r_b2);
+            bool kin_ready = fast_kin;
+            if (beta > m.alpha) {
+                const double sv = sx - c_smu, gmu = c_smu + c_lin;
+                double r2[2] = {xm * gmu, xm * sv};
+                wave_sum_n<2>(r2);
+                const BfOob o = bf_oob_scalars(m.alpha, m.f_mu, m.f_poly_mu, beta, r2[0], r2[1]);
+                f = o.f;
+                gn = bf_oob_grad(o, gmu, sv, hv, beta);
+                kin_ready = false;
             }
-            if (oob_now && DEC) {
-                oob_fused = true;
-                beta_k = beta; hv_k = hv; dgr_k = dgr; bd2_k = r_bd2; logdet_k = logdet;
-                if (lane_ok) XB[(lane >> 2) * XS + w + 16 * (lane & 3)] = (m.alpha * xs + (beta - m.alpha) * c_mu) / beta;
-                if (lane == 0) alive[4 + (trip & 1)] = 1;
-            } else if (oob_now) {
-                // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
-                cs_set(CS_BETA, beta);
-                prev_mode = mode;
-                mode = M_OOB;
-            } else {
-                if (mode == M_OOB) mode = prev_mode;
-                finish(f, gn, fast_kin, r_kin, logdet, r_bd2, dgr);
-            }
-        }
-        if constexpr (DEC) {
-            __syncthreads();  // X: the projected points are in the S operand, the flag of the second round is set
-            if (rfl(alive[4 + (trip & 1)]) != 0) {
-                if (w < W * KS_P) {  // the waves with an S job: the same chain of MFMAs on the new operand
-                    d4_t acc2 = {0., 0., 0., 0.};
-                    const double *Xf0 = XB + ((w % KS_P) * KPJ_P) * XS + lane;
-                    double xv[KPJ_P];
-#pragma unroll
-                    for (int k2 = 0; k2 < KPJ_P; ++k2) xv[k2] = Xf0[k2 * XS];
-#pragma unroll
-                    for (int k2 = 0; k2 < KPJ_P; ++k2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[k2], xv[k2], acc2, 0, 0, 0);
-                    const int mc = lane & 15, mg = lane >> 4;
-                    const int t = w / KS_P, kp = w % KS_P;
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) GB[(kp * 16 + mc) * GS + 16 * t + 4 * r4 + mg] = acc2[r4];
-                }
-                __syncthreads();  // Y
-                if (oob_fused) {  // poly.py:484-496 at x_0
-                    const double beta = beta_k;
-                    const double sx = lane_ok ? gb_read(0) : 0.;
-                    const double xev = (m.alpha * xs + (beta - m.alpha) * c_mu) / beta;
-                    double gn = sx + c_lin;
-                    double r3[3] = {0., __builtin_fma(0.5 * xev, sx, c_lin * xev), 0.};
-                    double r_dotj = gn * (xs - c_mu);
-                    wave_sum_n<3>(r3);
-                    r_dotj = wave_sum(r_dotj);
-                    const double f0 = (m.c0 + r3[1]) + 0.;
-                    const double f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
-                    const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
-                    gn = gn + coef * (hv_k / beta);
-                    finish(f, gn, false, 0., logdet_k, bd2_k, dgr_k);
-                }
-            }
+            finish(f, gn, kin_ready, r_kin, logdet, r_bd2, dgr);
         }
     }
 

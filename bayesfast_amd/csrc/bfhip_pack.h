@@ -58,12 +58,35 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
                 else { S[(size_t)j * d + k] = a; S[(size_t)k * d + j] = a; }
             }
         to_fragments(S.data(), d, DP, false, Sf);
+        // S mu: outside the bound the sampler kernels get S x_0 of the projected point x_0 = mu + (alpha / beta) (x - mu)
+        // from S x by linearity instead of a second pass over the tiles (bfhip_nuts_pipe.h, bfhip_group.h)
+        if (ds->use_bound)
+            for (int j = 0; j < d; ++j) {
+                double s = 0.;
+                for (int k = 0; k < d; ++k) s += S[(size_t)j * d + k] * ds->mu[k];
+                pd[PD_SMU * DP + j] = s;
+            }
     }
     if (ds->use_bound) to_fragments(ds->hess, d, DP, false, Hf);
     // decay gradient is (x - mu) H, i.e. H^T (x - mu): core/density.py:745
     if (ds->use_decay) to_fragments(ds->decay_hess, d, DP, true, Hdf);
 
     return DP;
+}
+
+// The linear + quadratic surrogate at the bound's centre, c0 + lin . mu + mu^T A mu (upper triangle of A, modules/_poly.pyx:13-43):
+// the start of the expansion of f(x_0) along the ray.  NOT the descriptor's f_mu, which is whatever the caller's
+// PolyModel._f_mu holds and enters the reference's formulas as such (modules/poly.py:487,496).
+static inline double bf_poly_at_mu(const bfhip_density_desc *ds) {
+    if (!ds->use_bound) return 0.;
+    const int d = ds->d;
+    double f = ds->c0;
+    for (int j = 0; j < d; ++j) {
+        if (ds->lin) f += ds->lin[j] * ds->mu[j];
+        if (ds->quad)
+            for (int k = j; k < d; ++k) f += ds->quad[(size_t)j * d + k] * ds->mu[j] * ds->mu[k];
+    }
+    return f;
 }
 
 // An upper bound c of the largest eigenvalue of the symmetric part of H, PROVEN by a successful Cholesky factorisation of

@@ -38,6 +38,7 @@
 #include "bfhip_eval.h"
 #include "bfhip_metric.h"
 #include "bfhip_pld.h"
+#include "bfhip_oob.h"
 
 // The f64 libm expansions (exp, log, sincospi, sqrt) are long inline sequences whose constants get hoisted
 // out of the trip loop; inlined at every call site they push the kernel far over its 128-VGPR budget
@@ -190,13 +191,8 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     // the coefficient matrices are not staged in LDS at all.
     constexpr bool AREG = PLAIN && W <= 4;
     constexpr bool TAIL = AREG;
-    // FUSE (the decay instantiations, FS = 3 and 7): a leaf outside the bound's ellipsoid takes its second pass -- the surrogate at
-    // the projected point, modules/poly.py:480-503 -- INSIDE the trip of the first (one more pair of barriers and a round of
-    // S tiles) instead of a trip of its own in mode M_OOB.  The workloads that use the decay term run outside the bound all
-    // the time (100 % of config 3's and config 4's leaves), so for them every leaf was two trips.  Same
-    // expressions in the same order as the M_OOB pass (bfhip_debug_no_fuse selects that one: tests compare the two).
-    constexpr bool FUSE = (FS == 3 || FS == 7) && !FULLM && !STAMPS;   // (decay; decay + constraint transform)
-    const bool fuse = FUSE && a.no_fuse == 0;
+    // Outside the bound's ellipsoid a linear + quadratic surrogate needs no second pass: S x_0 of the projected point follows from
+    // S x by linearity (bfhip_oob.h).  Only cubic configs evaluate again, in a trip of their own (mode M_OOB).
     constexpr int KS_P = (W == 2 || W == 4) ? 2 : 1, KPJ_P = (4 * W) / KS_P, NJOB_P = 2 * W * KS_P;
     using G = SamplerGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, E = G::E, XS = G::XS, GS = G::GS, MAT = G::MAT;
@@ -1149,7 +1145,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         // workgroup, the flag is complete at B1
         const bool pld_eval = !PLD || rfl(alive[2 + (trip & 1)]) != 0;
         const bool skip_h = PROOF && f_bound && f_quad && !f_decay && rfl(alive[4 + (trip & 1)]) == 0;  // (uniform over the workgroup)
-        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; alive[6 + ((trip + 1) & 1)] = 0; }
+        if (tid == 0) { alive[(trip + 1) & 1] = 0; alive[2 + ((trip + 1) & 1)] = 0; alive[4 + ((trip + 1) & 1)] = 0; }
         TRACE(3);
 
         // ================= phase B: gradient tiles on MFMA =================
@@ -1319,9 +1315,6 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         double logp_new = 0., E_new = 0.;
         bool have_eval = false, kin_ready = false;
         double kin_fast = 0.;
-        // (hoisted for the fused second pass: what its first half leaves for the second)
-        double f_keep = 0., beta_keep = 0., bd2_keep = 0., logdet_keep = 0.;
-        bool oob_fused = false;
         if constexpr (PLD) {
             // ================= phase P: the pipeline density (bfhip_pld.h) =================
             // Every wave of the workgroup takes part in the two contractions; a chain that evaluates owns column w of them.
@@ -1400,11 +1393,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         if (evaluating) {
             double r_quad = 0., r_lin = 0., r_b2 = 0., r_dotj = 0., r_bd2 = 0., r_kin = 0.;
             const bool fast_kin = !FULLM && !f_decay && !f_link && mode != M_OOB;
-            double xev[E], r_cub = 0.;
+            double xev[E], sxv[E], r_cub = 0.;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int dim = lane * E + e;
                 const double sx = (f_quad && lane_ok) ? gb_read(slot_S, dim) : 0.;
+                sxv[e] = sx;
                 hv[e] = (f_bound && lane_ok && !skip_h) ? gb_read(slot_H, dim) : 0.;
                 dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
                 xev[e] = xs[e];
@@ -1542,21 +1536,31 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                     oob_now = true;
                 }
             }
-            kin_ready = fast_kin && !oob_now;
-            kin_fast = r_kin;
-            if (oob_now && fuse) {
-                // the projected point x_0 (poly.py:482) into this chain's column of the S operand, the second round is on
-                oob_fused = true;
-                beta_keep = beta;
-                bd2_keep = r_bd2;
-                logdet_keep = logdet;
+            bool oob_lin = false;
+            if (oob_now && !f_cubic) {
+                // linear + quadratic surrogate: S x_0 follows from S x, no second pass (bfhip_oob.h; the same expressions in
+                // bf_nuts_pipe_kernel)
+                double r2[2] = {0., 0.};
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const int dim = lane * E + e;
-                    if (dim < DP) XB[(dim >> 2) * XS + w + 16 * (dim & 3)] = (m.alpha * xs[e] + (beta - m.alpha) * c_mu[e]) / beta;
+                    const double xm = xs[e] - c_mu[e], smu = pdl(PD_SMU, e);
+                    r2[0] += xm * (smu + c_lin[e]);
+                    r2[1] += xm * (sxv[e] - smu);
                 }
-                if (lane == 0) alive[6 + (trip & 1)] = 1;
-            } else if (oob_now) {
+                wave_sum_n<2>(r2);
+                const BfOob o = bf_oob_scalars(m.alpha, m.f_mu, m.f_poly_mu, beta, r2[0], r2[1]);
+                f = o.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double smu = pdl(PD_SMU, e);
+                    gn[e] = bf_oob_grad(o, smu + c_lin[e], sxv[e] - smu, hv[e], beta);
+                }
+                oob_now = false;
+                oob_lin = true;
+            }
+            kin_ready = fast_kin && !oob_now && !oob_lin;
+            kin_fast = r_kin;
+            if (oob_now) {
                 // outside the alpha-ellipsoid: spend one more trip on the projected point x_0
                 cs_set(CS_BETA, beta);
                 prev_mode = mode;
@@ -1591,60 +1595,6 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 have_eval = true;
             }
         }
-        if constexpr (FUSE) {
-            if (fuse) {  // (uniform over the workgroup)
-                __syncthreads();  // X: the projected points are in the S operand, the flag of the second round is set
-                if (rfl(alive[6 + (trip & 1)]) != 0) {
-                    // the S tiles again (the other matrices' results do not change: the chain keeps them), same K-split.
-                    // (Splitting the K range of this round over all 16 waves -- 4 k-steps per job instead of 16 -- changed
-                    // nothing: 3.80 against 3.83 x 10^8 on the funnel.)
-                    if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>(), true);
-                    else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>(), true);
-                    else run_jobs(std::integral_constant<int, 1>(), true);
-                    __syncthreads();  // Y
-                    if (oob_fused) {
-                        // modules/poly.py:484-496 at x_0, then what follows an in-bound evaluation
-                        const double beta = beta_keep;
-                        double r_lin = 0., r_dotj = 0.;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            const int dim = lane * E + e;
-                            const double sx = lane_ok ? gb_read(slot_S, dim) : 0.;
-                            const double xev = (m.alpha * xs[e] + (beta - m.alpha) * c_mu[e]) / beta;
-                            r_lin += __builtin_fma(0.5 * xev, sx, c_lin[e] * xev);
-                            gn[e] = sx + c_lin[e];
-                            r_dotj += gn[e] * (xs[e] - c_mu[e]);
-                        }
-                        double r3[3] = {0., r_lin, 0.};
-                        wave_sum_n<3>(r3);
-                        r_lin = r3[1];
-                        r_dotj = wave_sum(r_dotj);
-                        const double f0 = (m.c0 + r_lin) + 0.;
-                        double f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
-                        const double coef = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            gn[e] = gn[e] + coef * (hv[e] / beta);
-                            gn[e] = gn[e] * jac[e];
-                        }
-                        f -= m.decay_gamma * bf_clip0(bd2_keep - m.decay_alpha2);
-                        if (bd2_keep > m.decay_alpha2) {
-#pragma unroll
-                            for (int e = 0; e < E; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
-                        }
-                        if (f_tr) {  // density.py:747-750
-                            f += logdet_keep;
-#pragma unroll
-                            for (int e = 0; e < E; ++e) gn[e] += gj[e];
-                        }
-                        logp_new = f;
-                        have_eval = true;
-                        kin_ready = false;
-                    }
-                }
-            }
-        }
-        (void)f_keep;
         if (have_eval) {
             // second half of the leapfrog and the kinetic energy
             double kin = 0.;
@@ -1778,8 +1728,6 @@ size_t bf_sampler_lds_bytes_base(const DevModel &m) { return ((sampler_lds_base(
 // waves, which share four SIMDs.  When the chains do not fill the chip at 16 per workgroup, fewer chains per workgroup
 // on more CUs shorten the trip: the waves without a chain still take their share of the jobs.  (Results do not depend on
 // it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG / bfhip_debug_wave_cpg override (tests, tuning).
-static int g_no_fuse = [] { const char *e = getenv("BFHIP_NO_FUSE"); return e ? atoi(e) : 0; }();
-extern "C" void bfhip_debug_no_fuse(int v) { g_no_fuse = v; }  // test / tuning hook: the decay kernel's second passes in trips of their own
 static int g_no_quad = [] { const char *e = getenv("BFHIP_NO_QUAD"); return e ? atoi(e) : 0; }();
 extern "C" void bfhip_debug_no_quad_tiles(int v) { g_no_quad = v; }  // test / tuning hook: 16-column tiles whatever the number of chains
 static int g_wave_cpg = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
@@ -1817,8 +1765,8 @@ template <int W, bool TR = false, bool DEC = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
-    // (at most four / eight chains in a workgroup: 4 x 4 x 4 MFMA tiles; not with the decay term's fused second pass)
-    constexpr bool CANQ = !DEC;
+    // (at most four / eight chains in a workgroup: 4 x 4 x 4 MFMA tiles)
+    constexpr bool CANQ = true;
     auto k = (CANQ && args.cpg <= 4 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
              : ((CANQ && args.cpg <= 8 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
     const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);
@@ -1880,8 +1828,8 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
         !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
-    // ... and with the decay penalty (the GBS recipes' densities: configs 3 and 4); BFHIP_NO_FUSE keeps those on the sliced kernel
-    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && !args.no_fuse && m.has_quad && m.use_bound && m.use_decay &&
+    // ... and with the decay penalty (the GBS recipes' densities: configs 3 and 4)
+    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.use_decay &&
         !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
@@ -1917,7 +1865,6 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     SamplerArgs args;
     args.cpg = 0;
     args.cub_lds = 0;
-    args.no_fuse = g_no_fuse;
     args.no_quad = g_no_quad;
     args.cfg = *cfg;
     args.n_chain = n_chain;
@@ -1966,7 +1913,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     {
         // (the conditions of launch_sampler: the common surrogate, plain or behind the constraint transform)
         const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
-        const bool tr_only = common && m.has_transform && !m.use_decay, dec_only = common && m.use_decay && !m.has_transform && !args.no_fuse;
+        const bool tr_only = common && m.has_transform && !m.use_decay, dec_only = common && m.use_decay && !m.has_transform;
         const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only || dec_only);
         if (m.pld.on) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_sampler_kernel<%d, %s, false, 8 | 9>", W, nuts ? "true" : "false");
         else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);

@@ -6,7 +6,6 @@ struct SamplerArgs {
     bfhip_sampler_config cfg;
     int n_chain, iter_end, iter_out0, n_out, nslot;
     int cpg;       // wave-per-chain kernels: chains per workgroup (0: one per wave), bfhip_sampler.hip: wave_layout_cpg
-    int no_fuse;   // bf_sampler_kernel, decay instantiation: second passes in trips of their own (bfhip_debug_no_fuse: tests)
     int no_quad;   // bf_sampler_kernel: 16-column tiles even with at most four chains in the workgroup (bfhip_debug_no_quad_tiles: tests)
     int cub_lds;   // bf_sampler_kernel: the cubic coefficient tables are staged in LDS (sampler_cubic_lds)
     int tail_max;  // plain kernel: at most this many evaluating chains of a group take the VALU matvec (0: never)
