@@ -106,6 +106,7 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     m.lam_max_d = ds->use_decay ? bf_bound_lam_max(ds->decay_hess, ds->d) : 0.;
     m.f_mu = ds->f_mu;
     m.f_poly_mu = bf_poly_at_mu(ds);
+    m.inv_alpha = ds->use_bound ? 1. / ds->alpha : 0.;
     m.decay_alpha2 = ds->decay_alpha2;
     m.decay_gamma = ds->decay_gamma;
     if (ds->link_kind != 0 && ds->link_kind != 1) return bf_set_error(BFHIP_ERR_ARG, "bfhip_density_upload: unknown link_kind %d", ds->link_kind);

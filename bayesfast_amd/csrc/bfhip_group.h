@@ -40,6 +40,7 @@
 #pragma once
 #include "bfhip_lane.h"
 #include "bfhip_sampler_defs.h"
+#include "bfhip_oob.h"
 
 #define BF_DBL_MAX 1.7976931348623157e308
 
@@ -70,7 +71,8 @@
 #define BF_TREE_DRAW(rs) bf_xoshiro_next(rs)
 #endif
 
-template <int W>
+// TIGHT: W = 4 with the decay matrix (159 of 160 KB of LDS): one merge level fewer in LDS
+template <int W, bool TIGHT = false>
 struct GroupGeo {
     static constexpr int DP = 16 * W, NS = 4 * W;
     static constexpr int KS = (W == 2 || W == 4) ? 2 : 1;  // K halves of a matvec (same association as the sliced kernel)
@@ -82,8 +84,8 @@ struct GroupGeo {
     static constexpr int T_STK1 = 0, T_LEFT = 5, T_RIGHT = 8, T_PROP = 11, T_PSUM = 13, NTV = 14;
     // exchanged sums: evaluation, level-0 merge, merge levels 1..LSH, the doubling's checks in LDS; the merge levels
     // above LSH (one leaf in 2^LSH reaches them) go through global scratch
-    static constexpr int LSH = 3;
-    static constexpr int V_KIN = 0, V_VAL = 1, V_B2 = 2, V_DOTJ = 3, V_BD2 = 4, V_LOGDET = 5, V_KIN0 = 6, V_M0 = 7;
+    static constexpr int LSH = TIGHT ? 2 : 3;
+    static constexpr int V_KIN = 0, V_VAL = 1, V_B2 = 2, V_A1 = 3, V_A2 = 4, V_BD2 = 5, V_LOGDET = 6, V_KIN0 = 7, V_M0 = 8;
     static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * LSH, NVAL = V_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);       // sums of the merge levels LSH+1 .. MAXL-1
     static constexpr size_t lds_doubles(int nmat) {
@@ -113,8 +115,8 @@ BF_DEV void bf_to_original_g(double x, int kind, double lo, double rg, double &x
 
 template <int W, bool NUTS, int FS>
 BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) {
-    using G = GroupGeo<W>;
     constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0;
+    using G = GroupGeo<W, DEC && W == 4>;
     constexpr int DP = G::DP, NS = G::NS, KS = G::KS, NMAT = DEC ? 3 : 2, LSS = G::LSS;
     double *XB = lds;                          // [NMAT][NS][64]  B operands: x | x - mu | x_orig - mu_decay
     double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
@@ -139,13 +141,14 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         afH[s] = m.Hf[(j * NS + s) * 64 + lane];
         if constexpr (DEC) afD[s] = m.Hdf[(j * NS + s) * 64 + lane];
     }
-    double c_lin[4], c_mu[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1];
+    double c_lin[4], c_mu[4], c_smu[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1];
     int c_kind[TR ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int dim = dbase + 4 * r;
         c_lin[r] = m.pd[PD_LIN * DP + dim];
         c_mu[r] = m.pd[PD_MU * DP + dim];
+        c_smu[r] = m.pd[PD_SMU * DP + dim];
         if constexpr (TR) {
             c_kind[r] = (int)m.pd[PD_KIND * DP + dim];
             c_lo[r] = m.pd[PD_LO * DP + dim];
@@ -164,17 +167,17 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     }
     // ---- per-chain state: scalars (one copy per lane) ----
     uint64_t rs[4] = {0, 0, 0, 0};
-    int mode = M_DONE, prev_mode = M_INIT, i_iter = 0, err = 0;
+    int mode = M_DONE, i_iter = 0, err = 0;
     int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0, h_accepted = 0;
     double eps = 0., eps_t = 0., start_energy = 0., acc_sum = 0.;
     double T_W = 0., T_acc = 0., T_E = 0., T_logp = 0.;
-    double max_de = 0., w_off = 0., tree_W = 1., beta = 1.;
-    // an evaluation whose gradient depends on its own sums takes a further pass over the same point, M_FIN, with the
-    // scalars of the pass before: outside the bound (fin_oob: poly.py:496-503, after the pass at the projected point,
-    // M_OOB) and / or with the decay term active (fin_dec: density.py:744-746)
-    constexpr int M_FIN = 4;
-    bool fin_oob = false, fin_dec = false;
-    double coef2 = 0., logp_keep = 0.;
+    double max_de = 0., w_off = 0., tree_W = 1.;
+    // An evaluation whose gradient depends on its own sums -- outside the bound (poly.py:496-503; S x_0 of the projected point by
+    // linearity, bfhip_oob.h: no pass at x_0) and / or with the decay term active (density.py:744-746) -- is LATE: its second
+    // half step, kinetic energy and U-turn sums follow the scalars in a further exchange of the same trip (barrier B3).  A
+    // group whose evaluating chains were all late leaves the early exchange of those sums out of its next trip (skip_early:
+    // every lane holds every chain's scalars, so the flag is the same in all waves; the numbers do not depend on it).
+    bool skip_early = false;
     double L0_W = 0., L0_acc = 0., L0_E = 0., L0_logp = 0.;
     double prop_E = 0., prop_logp = 0.;
     double h_acc = 0., h_de = 0., h_end_E = 0., h_end_logp = 0.;
@@ -392,7 +395,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         const bool ev = mode != M_DONE;
         double xs[4], xev[4], jac[4], gj[4], xo[4];
         double ldet[4] = {0., 0., 0., 0.};
-        if (ev && mode != M_OOB && mode != M_FIN) {
+        if (ev) {
             eps_t = (mode == M_LEAF) ? eps * (double)dir : 0.;  // compute_state (base_hmc.py:70) is a step of length 0
             const double dt = 0.5 * eps_t;
 #pragma unroll
@@ -417,8 +420,6 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             xo[r] = xs[r];
             xev[r] = xs[r];
-            if (mode == M_OOB || (mode == M_FIN && fin_oob))  // passes at the projected point, modules/poly.py:482
-                xev[r] = (m.alpha * xs[r] + (beta - m.alpha) * c_mu[r]) / beta;
             XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
             XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
             if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
@@ -435,7 +436,6 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 t_r2[r] = ev ? xm * xm : 0.;
             }
             double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
-            if (mode == M_OOB || mode == M_FIN) r2p = __builtin_inf();  // passes that need H (x - mu) itself
             if (gq == 0) PB[j * 16 + c] = r2p;
             if constexpr (DEC) {
                 // the same for the decay term (density.py:740-746): inactive while (x - mu_d)^T H_d (x - mu_d) <= alpha_d^2
@@ -445,7 +445,6 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     t_r2[r] = ev ? xm * xm : 0.;
                 }
                 double r2d = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
-                if (mode == M_FIN) r2d = __builtin_inf();  // the pass that needs the decay gradient itself
                 if (gq == 0) PB[(W + j) * 16 + c] = r2d;
             }
         }
@@ -502,10 +501,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 
         GTRACE(3);
         // ================= phase C: the evaluation's sums, and the U-turn sums of the leaf it completes =================
-        double gn[4], ge[4], pn[4];
+        double gn[4], ge[4], pn[4], t_kin[4];
         const double dt_c = 0.5 * eps_t;
+        const bool early = !skip_early;   // the kinetic energy and the U-turn sums ride in this exchange (same in all waves)
         {
-            double t_val[4], t_b2[4], t_bd2[4], t_kin[4];
+            double t_val[4], t_b2[4], t_bd2[4], t_a1[4], t_a2[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 gn[r] = sx[r] + c_lin[r];
@@ -513,32 +513,34 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 t_val[r] = bf_fma(0.5 * xev[r], sx[r], c_lin[r] * xev[r]);
                 const double xm = xs[r] - c_mu[r];
                 t_b2[r] = xm * hv[r];
+                // outside the bound (bfhip_oob.h): a1 = (x - mu) . (S mu + lin), a2 = (x - mu) . S (x - mu)
+                t_a1[r] = xm * (c_smu[r] + c_lin[r]);
+                t_a2[r] = xm * (sx[r] - c_smu[r]);
                 t_bd2[r] = DEC ? (xo[r] - c_dmu[r]) * dgr[r] : 0.;
-                // inside the bound (and the decay ellipsoid), and in a final pass, the gradient is complete: chain rule,
-                // transform term (module.py:226, density.py:558,747-750), second half of the step (integration.py:90)
-                // and the kinetic energy (metrics.py:88-91) ride along
+                // inside the bound (and the decay ellipsoid) the gradient is complete: chain rule, transform term
+                // (module.py:226, density.py:558,747-750), second half of the step (integration.py:90) and the kinetic
+                // energy (metrics.py:88-91) ride along
                 double t = gn[r];
-                if (mode == M_FIN && fin_oob) t = t + coef2 * (hv[r] / beta);  // poly.py:496-503
                 if constexpr (TR) t = t * jac[r];
-                if constexpr (DEC) { if (mode == M_FIN && fin_dec) t -= 2. * m.decay_gamma * dgr[r]; }
                 if constexpr (TR) t += gj[r];
                 ge[r] = t;
                 pn[r] = bf_fma(dt_c, ge[r], p[r]);
                 t_kin[r] = pn[r] * (var[r] * pn[r]);
             }
-            static_assert(G::V_KIN == 0 && G::V_VAL == 1 && G::V_B2 == 2, "posted as one batch");
+            static_assert(G::V_KIN == 0 && G::V_VAL == 1 && G::V_B2 == 2 && G::V_A1 == 3 && G::V_A2 == 4, "posted as one batch");
             if (skipH) {
-                double e2[2] = {sum4(t_kin), sum4(t_val)};
-                post_n(G::V_KIN, e2);
+                if (early) {
+                    double e2[2] = {sum4(t_kin), sum4(t_val)};
+                    post_n(G::V_KIN, e2);
+                } else {
+                    post(G::V_VAL, sum4(t_val));
+                }
+            } else if (early) {
+                double e5[5] = {sum4(t_kin), sum4(t_val), sum4(t_b2), sum4(t_a1), sum4(t_a2)};
+                post_n(G::V_KIN, e5);
             } else {
-                double e3[3] = {sum4(t_kin), sum4(t_val), sum4(t_b2)};
-                post_n(G::V_KIN, e3);
-            }
-            if (bf_any(mode == M_OOB)) {
-                double t_dotj[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t_dotj[r] = gn[r] * (xs[r] - c_mu[r]);  // dot(jj_0, x - mu), poly.py:496
-                post(G::V_DOTJ, sum4(t_dotj));
+                double e4[4] = {sum4(t_val), sum4(t_b2), sum4(t_a1), sum4(t_a2)};
+                post_n(G::V_VAL, e4);
             }
             if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
             if constexpr (TR) {
@@ -641,112 +643,103 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 post_n(G::V_EXT, s6);
             }
         };
-        // every chain whose leaf this pass may complete
-        const bool spec1 = NUTS && ev && (mode == M_LEAF || (mode == M_FIN && prev_mode == M_LEAF));
+        // every chain whose leaf this evaluation completes
+        const bool spec1 = NUTS && ev && mode == M_LEAF;
         GTRACE(4);
-        if (NUTS) uturn_sums(spec1);
+        if (NUTS && early) uturn_sums(spec1);
         GTRACE(5);
         bf_sync();  // B2
         GTRACE(6);
 
         // ================= the evaluation's scalars =================
         // this trip's sums, fetched together (one LDS round trip instead of one per value)
-        double sv_e[3], sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
-        if (skipH) {
-            double sv_2[2];
-            rd_n(G::V_KIN, sv_2);
-            sv_e[0] = sv_2[0]; sv_e[1] = sv_2[1]; sv_e[2] = 0.;  // inside the bound, proven
+        double s_kin = 0., s_val = 0., s_b2 = 0., s_a1 = 0., s_a2 = 0.;
+        double sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
+        if (skipH) {   // inside the bound, proven
+            if (early) {
+                double sv_2[2];
+                rd_n(G::V_KIN, sv_2);
+                s_kin = sv_2[0]; s_val = sv_2[1];
+            } else {
+                s_val = rd(G::V_VAL);
+            }
+        } else if (early) {
+            double sv_5[5];
+            rd_n(G::V_KIN, sv_5);
+            s_kin = sv_5[0]; s_val = sv_5[1]; s_b2 = sv_5[2]; s_a1 = sv_5[3]; s_a2 = sv_5[4];
         } else {
-            rd_n(G::V_KIN, sv_e);
+            double sv_4[4];
+            rd_n(G::V_VAL, sv_4);
+            s_val = sv_4[0]; s_b2 = sv_4[1]; s_a1 = sv_4[2]; s_a2 = sv_4[3];
         }
         const bool any_e0 = bf_any(need_E0);
         if (any_e0) rd_n(G::V_KIN0, sv_k0);
-        if (any_m0) rd_n(G::V_M0, sv_m0);
-        if (any_lv1) rd_n(G::V_LV, sv_l1);
-        if (any_ext) rd_n(G::V_EXT, sv_x);
-        bool fin = false;
+        // the U-turn sums of this exchange (the flags are uturn_sums' own: wave-uniform)
+        auto read_uturn = [&]() {
+            if (any_m0) rd_n(G::V_M0, sv_m0);
+            if (any_lv1) rd_n(G::V_LV, sv_l1);
+            if (any_ext) rd_n(G::V_EXT, sv_x);
+        };
+        if (NUTS && early) read_uturn();
+        bool fin = false, late = false, dec_on = false;
         double logp_new = 0., kin = 0.;
-        // The common trip: every evaluating chain is in its first pass over the point and proven inside the bound, so the
-        // value is complete (the branches below are skipped as one; per-lane branches cost a round trip through the scalar
-        // unit each, with one wave per SIMD nothing hides it).  Same arithmetic as the general path.
-        const bool first_pass = mode != M_FIN && mode != M_OOB;
-        const bool all_plain = skipH && !bf_any(ev && !first_pass);
-        if (all_plain) {
-            if (ev) {
-                double f = (m.c0 + sv_e[1]) + 0.;
-                fin_oob = false;
-                fin_dec = false;
-                if constexpr (DEC) {  // density.py:740-746
-                    const double r_bd2 = rd(G::V_BD2);
-                    const double ex = r_bd2 - m.decay_alpha2;
-                    f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
-                    fin_dec = r_bd2 > m.decay_alpha2;
-                }
-                if constexpr (TR) f += rd(G::V_LOGDET);
-                if (DEC && fin_dec) {
-                    prev_mode = mode;
-                    logp_keep = f;
-                    mode = M_FIN;
-                } else {
-                    fin = true;
-                    logp_new = f;
-                    kin = sv_e[0];
+        double f = (m.c0 + s_val) + 0.;
+        // (the common trip -- every chain proven inside the bound, no decay term -- skips the rare branches as one: per-lane
+        // branches cost a round trip through the scalar unit each, with one wave per SIMD nothing hides it)
+        const bool rare = DEC || !skipH;   // wave-uniform
+        if (rare && ev) {
+            if (!skipH) {
+                // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
+                // decided on the squares whenever b2 is not within rounding distance of alpha^2
+                const double a2 = m.alpha * m.alpha;
+                double bt = 0.;
+                if (!(s_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(s_b2);
+                if (bt > m.alpha) {   // outside the alpha-ellipsoid (poly.py:480-503)
+                    const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, bt, s_a1, s_a2);
+                    f = o.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gn[r] = bf_oob_grad(o, c_smu[r] + c_lin[r], sx[r] - c_smu[r], hv[r]);
+                    late = true;
                 }
             }
-        } else
-        if (ev) {
-            if (mode == M_FIN) {
-                fin = true;
-                logp_new = logp_keep;
-                kin = sv_e[0];
-                mode = prev_mode;
-            } else {
-                const double r_val = sv_e[1], r_b2 = sv_e[2];
-                double f = (m.c0 + r_val) + 0.;
-                bool have_f = false;
-                if (mode == M_OOB) {
-                    // f holds f_0 at the projected point (poly.py:484-496)
-                    const double r_dotj = rd(G::V_DOTJ);
-                    const double f0 = f;
-                    f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
-                    coef2 = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
-                    have_f = true;
-                } else {
-                    // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
-                    // decided on the squares whenever b2 is not within rounding distance of alpha^2
-                    const double a2 = m.alpha * m.alpha;
-                    double bt = 0.;
-                    if (!(r_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(r_b2);
-                    if (bt > m.alpha) {
-                        beta = bt;  // outside the alpha-ellipsoid: next pass at the projected point x_0
-                        prev_mode = mode;
-                        mode = M_OOB;
-                    } else {
-                        have_f = true;
-                    }
-                }
-                if (have_f) {
-                    fin_oob = mode == M_OOB;
-                    fin_dec = false;
-                    if constexpr (DEC) {  // density.py:740-746
-                        const double r_bd2 = rd(G::V_BD2);
-                        const double ex = r_bd2 - m.decay_alpha2;
-                        f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
-                        fin_dec = r_bd2 > m.decay_alpha2;
-                    }
-                    if constexpr (TR) f += rd(G::V_LOGDET);
-                    if (fin_oob || fin_dec) {
-                        if (!fin_oob) prev_mode = mode;
-                        logp_keep = f;
-                        mode = M_FIN;
-                    } else {
-                        fin = true;
-                        logp_new = f;
-                        kin = sv_e[0];
-                    }
-                }
+            if constexpr (DEC) {  // density.py:740-746
+                const double r_bd2 = rd(G::V_BD2);
+                const double ex = r_bd2 - m.decay_alpha2;
+                f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                dec_on = r_bd2 > m.decay_alpha2;
+                late = late || dec_on;
             }
         }
+        if constexpr (TR) f += rd(G::V_LOGDET);
+        if (rare && ev && late) {   // the complete gradient: poly.py:496-503, chain rule, decay, transform term; second half step
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double t = gn[r];
+                if constexpr (TR) t = t * jac[r];
+                if constexpr (DEC) { if (dec_on) t -= 2. * m.decay_gamma * dgr[r]; }
+                if constexpr (TR) t += gj[r];
+                ge[r] = t;
+                pn[r] = bf_fma(dt_c, ge[r], p[r]);
+                t_kin[r] = pn[r] * (var[r] * pn[r]);
+            }
+        }
+        if (ev) {
+            fin = true;
+            logp_new = f;
+            kin = s_kin;
+        }
+        // the late exchange: the kinetic energy and the U-turn sums with the complete momenta (all chains of the group again --
+        // the ones that were not late post the numbers they posted before)
+        const bool late_x = bf_any(ev && (late || !early));
+        if (late_x) {
+            if (early) bf_sync();  // B2': the early exchange's sums have been read by every wave
+            post(G::V_KIN, sum4(t_kin));
+            if (NUTS) uturn_sums(spec1);
+            bf_sync();  // B3
+            kin = rd(G::V_KIN);
+            if (NUTS) read_uturn();
+        }
+        skip_early = late_x && !bf_any(ev && !late);
         double E_new = 0.;
         if (fin) {
 #pragma unroll

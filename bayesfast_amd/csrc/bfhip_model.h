@@ -63,6 +63,7 @@ struct DevModel {
     const double *Hdf;  // decay Hessian
     double c0, alpha, f_mu, decay_alpha2, decay_gamma;
     double f_poly_mu;   // the linear + quadratic surrogate at mu (bf_poly_at_mu)
+    double inv_alpha;   // 1 / alpha (0 without a bound)
     int has_link;       // the surrogate's output m feeds a Gaussian likelihood: logp = link_logp0 - link_prec (m - link_y)^2 / 2
     double link_y, link_prec, link_logp0;
     double lam_max_d;   // the same for the decay Hessian

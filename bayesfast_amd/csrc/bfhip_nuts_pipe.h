@@ -684,19 +684,27 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             const double xm = xs - c_mu;
             constexpr bool fast_kin = !DEC;   // (with the decay term the gradient is final only after its sum)
             // (the surrogate's value, linear + quadratic term, summed per lane: one reduction for both)
-            double r3[3] = {0., __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv};
-            if (fast_kin) {  // in-bound gradient is already final: the kinetic energy rides along
-                double ge = gn * jac;
-                if constexpr (TR) ge += gj;
-                const double pe = p + (0.5 * eps_t) * ge;
-                r3[0] = pe * (var * pe);
-            }
+            const double sv = sx - c_smu, gmu = c_smu + c_lin;   // S (x - mu), the gradient at mu (bfhip_oob.h)
+            double r_kin = 0., r_val, r_b2, r_bd2 = 0., r_a[2] = {0., 0.};
             TRACE(7);
-            wave_sum_n<3>(r3);
+            if constexpr (DEC) {
+                // (the densities that carry the decay term live outside the bound: its sum and the two sums of the extrapolation
+                // ride in the first reduction -- the same numbers as reductions of their own)
+                double r5[5] = {(xs - c_dmu) * dgr, __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv, xm * gmu, xm * sv};
+                wave_sum_n<5>(r5);
+                r_bd2 = r5[0]; r_val = r5[1]; r_b2 = r5[2]; r_a[0] = r5[3]; r_a[1] = r5[4];
+            } else {
+                double r3[3] = {0., __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv};
+                {  // in-bound gradient is already final: the kinetic energy rides along
+                    double ge = gn * jac;
+                    if constexpr (TR) ge += gj;
+                    const double pe = p + (0.5 * eps_t) * ge;
+                    r3[0] = pe * (var * pe);
+                }
+                wave_sum_n<3>(r3);
+                r_kin = r3[0]; r_val = r3[1]; r_b2 = r3[2];
+            }
             TRACE(8);
-            const double r_kin = r3[0], r_val = r3[1], r_b2 = r3[2];
-            double r_bd2 = 0.;
-            if constexpr (DEC) r_bd2 = wave_sum((xs - c_dmu) * dgr);
             double logdet = 0.;
             if constexpr (TR) logdet = wave_sum(logdet_l);
             double f = (m.c0 + r_val) + 0.;
@@ -705,12 +713,13 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             if (!(r_b2 < a2 * (1. - 1e-12))) beta = usqrt(r_b2);
             bool kin_ready = fast_kin;
             if (beta > m.alpha) {
-                const double sv = sx - c_smu, gmu = c_smu + c_lin;
-                double r2[2] = {xm * gmu, xm * sv};
-                wave_sum_n<2>(r2);
-                const BfOob o = bf_oob_scalars(m.alpha, m.f_mu, m.f_poly_mu, beta, r2[0], r2[1]);
+                if constexpr (!DEC) {
+                    r_a[0] = xm * gmu; r_a[1] = xm * sv;
+                    wave_sum_n<2>(r_a);
+                }
+                const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, beta, r_a[0], r_a[1]);
                 f = o.f;
-                gn = bf_oob_grad(o, gmu, sv, hv, beta);
+                gn = bf_oob_grad(o, gmu, sv, hv);
                 kin_ready = false;
             }
             finish(f, gn, kin_ready, r_kin, logdet, r_bd2, dgr);

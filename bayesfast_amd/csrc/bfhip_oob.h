@@ -16,17 +16,20 @@
 #pragma once
 #include "bfhip_model.h"
 
-struct BfOob { double t, f, coef; };
+// One division per evaluation (1 / beta; 1 / alpha comes with the model): the quotients of the reference's formulas are
+// products with the reciprocals.
+struct BfOob { double t, f, coef, rbeta; };
 
-__host__ __device__ inline BfOob bf_oob_scalars(double alpha, double f_mu, double f_poly_mu, double beta, double a1, double a2) {
+__host__ __device__ inline BfOob bf_oob_scalars(double alpha, double inv_alpha, double f_mu, double f_poly_mu, double beta, double a1, double a2) {
     BfOob o;
-    o.t = alpha / beta;
+    o.rbeta = 1. / beta;
+    o.t = alpha * o.rbeta;
     const double f0 = f_poly_mu + o.t * (a1 + 0.5 * o.t * a2);
-    o.f = (beta * f0 - (beta - alpha) * f_mu) / alpha;
-    o.coef = (f0 - f_mu) / alpha - (a1 + o.t * a2) / beta;
+    o.f = (beta * f0 - (beta - alpha) * f_mu) * inv_alpha;
+    o.coef = (f0 - f_mu) * inv_alpha - (a1 + o.t * a2) * o.rbeta;
     return o;
 }
 
-__host__ __device__ inline double bf_oob_grad(const BfOob &o, double g_mu, double sv, double hv, double beta) {
-    return (g_mu + o.t * sv) + o.coef * (hv / beta);
+__host__ __device__ inline double bf_oob_grad(const BfOob &o, double g_mu, double sv, double hv) {
+    return (g_mu + o.t * sv) + o.coef * (hv * o.rbeta);
 }

@@ -1548,12 +1548,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                     r2[1] += xm * (sxv[e] - smu);
                 }
                 wave_sum_n<2>(r2);
-                const BfOob o = bf_oob_scalars(m.alpha, m.f_mu, m.f_poly_mu, beta, r2[0], r2[1]);
+                const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, beta, r2[0], r2[1]);
                 f = o.f;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const double smu = pdl(PD_SMU, e);
-                    gn[e] = bf_oob_grad(o, smu + c_lin[e], sxv[e] - smu, hv[e], beta);
+                    gn[e] = bf_oob_grad(o, smu + c_lin[e], sxv[e] - smu, hv[e]);
                 }
                 oob_now = false;
                 oob_lin = true;
@@ -1817,19 +1817,20 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS) ? 1 : 0>(ctx, args)
                      : launch_sampler_t<W, NUTS, (W == 4 && NUTS), 0>(ctx, args);
 #endif
-#ifdef BF_TRACE
-    if (plain && NUTS && W <= 4 && !g_no_pipe)
+#ifdef BF_TRACE   // (tuning builds: the pipelined kernel writes its own stamps)
+    const bool stamped = false;
 #else
-    if (plain && NUTS && W <= 4 && !g_no_pipe && !args.stamps)
+    const bool stamped = args.stamps != NULL;
 #endif
+    if (plain && NUTS && W <= 4 && !g_no_pipe && !stamped)
         return launch_nuts_pipe<(W <= 4 ? W : 1)>(ctx, args);
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
     // ... and the same surrogate behind the constraint transform (bounded parameters)
-    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
+    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !stamped && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
         !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
     // ... and with the decay penalty (the GBS recipes' densities: configs 3 and 4)
-    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !args.stamps && m.has_quad && m.use_bound && m.use_decay &&
+    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !stamped && m.has_quad && m.use_bound && m.use_decay &&
         !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE

@@ -47,7 +47,7 @@ struct SplitGeoT {
     //   integrators -> bookkeepers: the finished leaf (q, grad)
     static constexpr int T_STKM = 0, T_OEND = 3, T_STKP = 6, T_START = 8, T_LEAF = 11, NTV = 13;
     // sums posted by the integrators: the evaluation's and the U-turn checks of the subtrees the leaf completes
-    static constexpr int E_KIN = 0, E_VAL = 1, E_B2 = 2, E_DOTJ = 3, U_M0 = 4, U_LV = 6, U_EXT = U_LV + 6 * LSH, NE = U_EXT + 6;
+    static constexpr int E_KIN = 0, E_VAL = 1, E_B2 = 2, E_A1 = 3, E_A2 = 4, U_M0 = 5, U_LV = 7, U_EXT = U_LV + 6 * LSH, NE = U_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);
     // per-chain words exchanged between the roles (doubles): command, epoch, signed step, depth | leaf tag, provided logp
     static constexpr int X_CMD = 0, X_EPOCH = 1, X_EPS = 2, X_DEPTH = 3, X_ANN = 4, X_TAG = 5, X_LOGP = 6, X_HASLP = 7, NX = 8;
@@ -92,7 +92,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     double *LS = TV + G::NTV * DP * 16;        // [16][LSS]     subtree stack scalars (bookkeepers)
     double *VARX = LS + 16 * LSS;              // [DP][16]      the metric's variances, bookkeepers -> integrators
     double *XC = VARX + DP * 16;               // [NX][16]      commands / tags
-    double *FLG = XC + G::NX * 16;             // [0] some chain is alive  [1] some integrator chain is in a second pass
+    double *FLG = XC + G::NX * 16;             // [0] some chain is alive
     double *COLD = FLG + 16;                   // [2][NCOLD][16] adaptation scalars (bookkeepers)
 
     const int tid = bf_tid(), lane = tid & 63, wv = tid >> 6, c = lane & 15, gq = lane >> 4;
@@ -175,19 +175,20 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             afS[s] = m.Sf[(j * NS + s) * 64 + lane];
             afH[s] = m.Hf[(j * NS + s) * 64 + lane];
         }
-        double c_lin[4], c_mu[4], q[4], p[4], g[4], var[4];
+        double c_lin[4], c_mu[4], c_smu[4], q[4], p[4], g[4], var[4];
         double L0p[4], PSUM[4], pdbl[4];   // the waiting leaf's momentum, the tree's p_sum, the momentum this doubling started from
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             c_lin[r] = m.pd[PD_LIN * DP + dbase + 4 * r];
             c_mu[r] = m.pd[PD_MU * DP + dbase + 4 * r];
+            c_smu[r] = m.pd[PD_SMU * DP + dbase + 4 * r];
             q[r] = p[r] = g[r] = L0p[r] = PSUM[r] = pdbl[r] = 0.;
             var[r] = 1.;
         }
-        enum { I_IDLE = 0, I_EVAL = 1, I_OOB = 2, I_FIN = 4 };
+        enum { I_IDLE = 0, I_EVAL = 1 };
         int imode = I_IDLE, epoch_i = 0, i_leaf = 0, depth = 0, dir = 1;
         bool init_eval = false, paused_end = false;   // paused_end: this state is the end of a finished doubling, direction unknown
-        double eps_t = 0., ann_eps = 0., beta = 1., coef2 = 0., logp_keep = 0.;   // ann_eps: the announced next doubling's step (0: none)
+        double eps_t = 0., ann_eps = 0.;   // ann_eps: the announced next doubling's step (0: none)
         unsigned int n_trip = 0, n_trip_h = 0;
         auto post = [&](int vi, double part) {
             const double t = bf_xor32_add(bf_xor16_add(part));
@@ -287,7 +288,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             // ---- phase A: first half of the leapfrog step (integration.py:80-85), B operands, the proof's partial ----
             const bool ev = imode != I_IDLE;
             const bool any_ev = bf_any(ev);   // (a trip in which every chain waits for its bookkeeper: barriers only)
-            double xs[4], xev[4];
+            double xs[4];
             if (imode == I_EVAL) {
                 const double dt = 0.5 * eps_t;
 #pragma unroll
@@ -301,25 +302,17 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     xs[r] = ev ? q[r] : 0.;
-                    xev[r] = xs[r];
-                    if (imode == I_OOB || imode == (I_FIN | I_OOB))  // passes at the projected point, modules/poly.py:482
-                        xev[r] = (m.alpha * xs[r] + (beta - m.alpha) * c_mu[r]) / beta;
-                    XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
+                    XB[(0 * NS + 4 * j + r) * 64 + lane] = xs[r];
                     const double xm = xs[r] - c_mu[r];
                     XB[(1 * NS + 4 * j + r) * 64 + lane] = xm;
                     t_r2[r] = ev ? xm * xm : 0.;
                 }
                 double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
-                if (imode & (I_OOB | I_FIN)) r2p = __builtin_inf();  // passes that need H (x - mu) itself
                 if (gq == 0) PB[j * 16 + c] = r2p;
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { xs[r] = 0.; xev[r] = 0.; }
+                for (int r = 0; r < 4; ++r) xs[r] = 0.;
                 if (gq == 0) PB[j * 16 + c] = 0.;
-            }
-            {
-                const bool second = bf_any(imode & (I_OOB | I_FIN));
-                if (tid == 0) FLG[1] = second ? 1. : 0.;   // (every integrator wave holds all 16 chains' modes: wave 0 posts)
             }
             STRACE(0, 1);
             bf_sync();  // B1
@@ -327,7 +320,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             // ---- phase B: row tile j of S x and H (x - mu) ----
             double sx[4] = {0., 0., 0., 0.}, hv[4] = {0., 0., 0., 0.};
             const bool skipH = proof_holds();
-            const bool extra = !skipH || FLG[1] != 0.;
+            const bool extra = !skipH;
             if (any_ev) {
                 bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
                 constexpr int KS = W == 1 ? 1 : 2, KH = NS / KS;   // K halves of a matvec: the group kernel's association
@@ -357,28 +350,29 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             const double dt_c = (imode == I_IDLE) ? 0. : 0.5 * eps_t;
             bool fin = false, have_lp = false;
             double logp_new = 0.;
+            double t_kin[4] = {0., 0., 0., 0.};
             if (any_ev) {
-                double t_val[4], t_b2[4], t_kin[4], t_dotj[4];
+                double t_val[4], t_b2[4], t_a1[4], t_a2[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double gn = sx[r] + c_lin[r];
-                    t_val[r] = bf_fma(0.5 * xev[r], sx[r], c_lin[r] * xev[r]);
+                    t_val[r] = bf_fma(0.5 * xs[r], sx[r], c_lin[r] * xs[r]);
                     const double xm = xs[r] - c_mu[r];
                     t_b2[r] = xm * hv[r];
-                    t_dotj[r] = gn * xm;  // dot(jj_0, x - mu), poly.py:496
-                    double t = gn;
-                    if (imode == (I_FIN | I_OOB)) t = t + coef2 * (hv[r] / beta);  // poly.py:496-503
-                    ge[r] = t;
+                    // outside the bound (bfhip_oob.h): a1 = (x - mu) . (S mu + lin), a2 = (x - mu) . S (x - mu)
+                    t_a1[r] = xm * (c_smu[r] + c_lin[r]);
+                    t_a2[r] = xm * (sx[r] - c_smu[r]);
+                    ge[r] = gn;
                     pn[r] = bf_fma(dt_c, ge[r], p[r]);
                     t_kin[r] = pn[r] * (var[r] * pn[r]);
                 }
                 if (!extra) {
                     double e2[2] = {sum4(t_kin), sum4(t_val)};
                     post_n(G::E_KIN, e2);
-                    fin = ev;  // first pass, inside the bound (proven): the value is complete (the bookkeepers add it up)
+                    fin = ev;  // inside the bound (proven): the value is complete (the bookkeepers add it up)
                 } else {
-                    double e4[4] = {sum4(t_kin), sum4(t_val), sum4(t_b2), sum4(t_dotj)};
-                    post_n(G::E_KIN, e4);
+                    double e5[5] = {sum4(t_kin), sum4(t_val), sum4(t_b2), sum4(t_a1), sum4(t_a2)};
+                    post_n(G::E_KIN, e5);
                 }
             } else {
 #pragma unroll
@@ -386,36 +380,34 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             if (extra) {
                 bf_sync();  // B2a: this trip's sums
+                bool oob = false;
                 if (ev) {
-                    if (imode & I_FIN) {
-                        fin = true;
-                        have_lp = true;
-                        logp_new = logp_keep;
-                    } else {
-                        const double r_val = sumw(RBE + (G::E_VAL * W) * 16 + c, 16), r_b2 = sumw(RBE + (G::E_B2 * W) * 16 + c, 16);
-                        double f = (m.c0 + r_val) + 0.;
-                        if (imode == I_OOB) {  // f holds f_0 at the projected point (poly.py:484-496)
-                            const double r_dotj = sumw(RBE + (G::E_DOTJ * W) * 16 + c, 16);
-                            const double f0 = f;
-                            f = (beta * f0 - (beta - m.alpha) * m.f_mu) / m.alpha;
-                            coef2 = (f0 - m.f_mu) / m.alpha - r_dotj / beta;
-                            logp_keep = f;
-                            imode = I_FIN | I_OOB;
-                        } else {
-                            const double a2 = m.alpha * m.alpha;
-                            double bt = 0.;
-                            if (!(r_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(r_b2);
-                            if (bt > m.alpha) {
-                                beta = bt;  // outside the alpha-ellipsoid: next pass at the projected point x_0
-                                imode = I_OOB;
-                            } else {
-                                fin = true;
-                                have_lp = true;
-                                logp_new = f;
-                            }
+                    const double r_val = sumw(RBE + (G::E_VAL * W) * 16 + c, 16), r_b2 = sumw(RBE + (G::E_B2 * W) * 16 + c, 16);
+                    double f = (m.c0 + r_val) + 0.;
+                    const double a2 = m.alpha * m.alpha;
+                    double bt = 0.;
+                    if (!(r_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(r_b2);
+                    if (bt > m.alpha) {
+                        // outside the alpha-ellipsoid (poly.py:480-503): S x_0 of the projected point by linearity, no pass at x_0
+                        // (bfhip_oob.h; the group kernel's expressions)
+                        const double r_a1 = sumw(RBE + (G::E_A1 * W) * 16 + c, 16), r_a2 = sumw(RBE + (G::E_A2 * W) * 16 + c, 16);
+                        const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, bt, r_a1, r_a2);
+                        f = o.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ge[r] = bf_oob_grad(o, c_smu[r] + c_lin[r], sx[r] - c_smu[r], hv[r]);
+                            pn[r] = bf_fma(dt_c, ge[r], p[r]);
+                            t_kin[r] = pn[r] * (var[r] * pn[r]);
                         }
+                        oob = true;
                     }
+                    fin = true;
+                    have_lp = true;
+                    logp_new = f;
                 }
+                // the kinetic energy with the complete momentum (nobody reads E_KIN between B2a and B2; the chains inside the
+                // bound post the number they posted before)
+                if (bf_any(oob)) post(G::E_KIN, sum4(t_kin));
             }
             // ---- the finished leaf: its state, the U-turn sums of the subtrees it completes (nuts.py:146-161 per merge,
             // :88-101 per doubling), the momentum part of the subtree stack.  None of it depends on a random draw. ----
@@ -720,7 +712,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
         if (writer) XC[G::X_TAG * 16 + c] = -1.;
         const bool alive = bf_any(mode != M_DONE);
-        if (tid == W * 64) { FLG[0] = alive ? 1. : 0.; FLG[1] = 0.; }
+        if (tid == W * 64) FLG[0] = alive ? 1. : 0.;
     }
     bf_sync();  // P0
 
@@ -763,7 +755,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         STRACE(1, 1);
         bf_sync();  // B1
         STRACE(1, 2);
-        const bool extra = !proof_holds() || FLG[1] != 0.;
+        const bool extra = !proof_holds();
         if (writer) XC[G::X_CMD * 16 + c] = (double)SC_CONT;   // (the integrators took the previous trip's command before B1)
 
         const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93

@@ -277,6 +277,7 @@ extern "C" int bfemu_sampler_run(const bfhip_density_desc *ds, const bfhip_sampl
     m.lam_max_d = ds->use_decay ? bf_bound_lam_max(ds->decay_hess, ds->d) : 0.;
     m.f_mu = ds->f_mu;
     m.f_poly_mu = bf_poly_at_mu(ds);
+    m.inv_alpha = ds->use_bound ? 1. / ds->alpha : 0.;
     m.decay_alpha2 = ds->decay_alpha2;
     m.decay_gamma = ds->decay_gamma;
     const int W = DP / 16;

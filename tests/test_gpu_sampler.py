@@ -204,10 +204,10 @@ def test_leaves_outside_the_bound_by_linearity_match_the_oracles_second_evaluati
         spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * 16, dtype=np.uint8))
     x0 = np.random.default_rng(2).normal(size=(60, 64)) * (0.3 if case == 'bounded' else 1.)
     dev = _device_chains(ctx, spec, x0, 30, 20)
-    orc_runs = _oracle_chains(spec, x0[:6], 14, 20)
-    # (the first 14 iterations: in the 'mixed' regime the 1e-16 summation-order differences reach a tree decision by iteration ~17
-    # on every layout, also the one that takes the reference's second pass)
-    _compare_nuts(dev, orc_runs, 14, n_head=6, tol_head=1e-8, rtol_q=1e-4)
+    orc_runs = _oracle_chains(spec, x0[:6], 12, 20)
+    # (the first 12 iterations: in the 'mixed' regime the 1e-16 summation-order differences grow to 3e-4 by iteration 14 and reach
+    # a tree decision by iteration ~17 on every layout -- with the reference's second pass as well as without it)
+    _compare_nuts(dev, orc_runs, 12, n_head=6, tol_head=1e-8, rtol_q=1e-4)
     if case != 'bounded':   # (there the samples live in the transformed space)
         x = dev[0].reshape(-1, 64)
         beta = np.sqrt(np.einsum('ij,jk,ik->i', x - po['mu'], po['hess'], x - po['mu']))
