@@ -13,7 +13,7 @@ from bayesfast_amd.chains import DeviceChains
 from bayesfast_amd.workloads import planck_like_logp
 from bayesfast_amd import _lib
 cubic = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-NT = 64
+NT = 24
 ctx = get_context(0)
 d, Cn = 128, 1024
 rng = np.random.default_rng(2024)
