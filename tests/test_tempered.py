@@ -88,8 +88,9 @@ def test_device_tnuts_matches_oracle_on_shared_streams(fx):
 
 @pytest.mark.gpu
 def test_device_tnuts_workgroup_size_never_changes_results(fx):
-    """bf_tnuts_kernel with 8 and with 16 chains per workgroup (the library takes 16 above 2048 chains, where 8 would take two
-    rounds of workgroups): samples, statistics, tempering coordinate and weights are EQUAL -- 37 chains, ragged for both."""
+    """bf_tnuts_kernel with 4 and 8 chains per workgroup (always eight waves: the ones without a chain run the shared matvec jobs
+    only; the library takes four chains per workgroup when that spreads them over more CUs): samples, statistics, tempering
+    coordinate and weights are EQUAL -- 37 chains, ragged for both."""
     from bayesfast_amd.device import get_context, DeviceDensity
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd import _lib
@@ -99,13 +100,13 @@ def test_device_tnuts_workgroup_size_never_changes_results(fx):
     x0, u0 = rng.normal(size=(37, spec['d'])) * 0.5, rng.normal(size=37)
     out = {}
     try:
-        for wpb in (8, 16):
+        for wpb in (4, 8):
             _lib.lib().bfhip_debug_tnuts_wpb(wpb)
             dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=98)
             out[wpb] = [t.cpu().numpy() for t in dc.run_tempered(24, fx['t6.base_mean'], fx['t6.base_cov'], logxi=logxi, u_0=u0, n_warmup=16)]
     finally:
         _lib.lib().bfhip_debug_tnuts_wpb(0)
-    for a, b in zip(out[8], out[16]):
+    for a, b in zip(out[4], out[8]):
         assert np.array_equal(a, b, equal_nan=True)
 
 

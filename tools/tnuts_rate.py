@@ -24,3 +24,9 @@ torch.cuda.synchronize()
 st = out[1]
 print('tempered NUTS, %d chains: %.4g tempered leapfrog steps/s, %.1f ms per 60 iterations, mean tree size %.1f' % (
     C, (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), e0.elapsed_time(e1), st[:, :, _lib.NSTATS.index('tree_size')].mean().item()))
+ts = st[:, :, _lib.NSTATS.index('tree_size')].cpu().numpy()
+per_chain = ts.sum(1)
+print('leapfrogs per chain in the launch: mean %.0f, max %.0f (launch tail %.2f); per workgroup of 8 chains, max over mean: %.2f; tree size '
+      'quantiles 50 / 90 / 99 / max: %s' % (per_chain.mean(), per_chain.max(), per_chain.max() / per_chain.mean(),
+                                           per_chain[:C // 8 * 8].reshape(-1, 8).max(1).mean() / per_chain.mean(),
+                                           np.quantile(ts, [0.5, 0.9, 0.99, 1.0])))
