@@ -71,8 +71,7 @@
 #define BF_TREE_DRAW(rs) bf_xoshiro_next(rs)
 #endif
 
-// TIGHT: W = 4 with the decay matrix (159 of 160 KB of LDS): one merge level fewer in LDS
-template <int W, bool TIGHT = false>
+template <int W>
 struct GroupGeo {
     static constexpr int DP = 16 * W, NS = 4 * W;
     static constexpr int KS = (W == 2 || W == 4) ? 2 : 1;  // K halves of a matvec (same association as the sliced kernel)
@@ -84,8 +83,8 @@ struct GroupGeo {
     static constexpr int T_STK1 = 0, T_LEFT = 5, T_RIGHT = 8, T_PROP = 11, T_PSUM = 13, NTV = 14;
     // exchanged sums: evaluation, level-0 merge, merge levels 1..LSH, the doubling's checks in LDS; the merge levels
     // above LSH (one leaf in 2^LSH reaches them) go through global scratch
-    static constexpr int LSH = TIGHT ? 2 : 3;
-    static constexpr int V_KIN = 0, V_VAL = 1, V_B2 = 2, V_A1 = 3, V_A2 = 4, V_BD2 = 5, V_LOGDET = 6, V_KIN0 = 7, V_M0 = 8;
+    static constexpr int LSH = 3;
+    static constexpr int V_KIN = 0, V_VAL = 1, V_B2 = 2, V_BD2 = 3, V_LOGDET = 4, V_KIN0 = 5, V_M0 = 6;
     static constexpr int V_LV = V_M0 + 2, V_EXT = V_LV + 6 * LSH, NVAL = V_EXT + 6;
     static constexpr int NDEEP = 6 * (MAXL - 1 - LSH);       // sums of the merge levels LSH+1 .. MAXL-1
     static constexpr size_t lds_doubles(int nmat) {
@@ -116,7 +115,7 @@ BF_DEV void bf_to_original_g(double x, int kind, double lo, double rg, double &x
 template <int W, bool NUTS, int FS>
 BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) {
     constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0;
-    using G = GroupGeo<W, DEC && W == 4>;
+    using G = GroupGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, KS = G::KS, NMAT = DEC ? 3 : 2, LSS = G::LSS;
     double *XB = lds;                          // [NMAT][NS][64]  B operands: x | x - mu | x_orig - mu_decay
     double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
@@ -187,7 +186,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     bool need_E0 = false;     // the running iteration's start energy waits for its kinetic part (this trip's exchange)
     double kin0_part = 0.;
     unsigned long long nlf = 0;
-    unsigned int n_trip = 0, n_trip_h = 0;  // measurement: trips of this group, trips that ran the bound's tiles
+    unsigned int n_trip = 0, n_trip_h = 0, n_trip_late = 0, n_trip_skip = 0;  // measurement: trips of this group, trips that ran the
+                                                                              // bound's tiles, had a late exchange, left the early one out
 
     double *scp = a.sc + (size_t)(real ? chain : 0) * BFHIP_SC_N;
     double *vecp = a.vec + (size_t)(real ? chain : 0) * BFHIP_VEC_N * d;
@@ -455,6 +455,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // ================= phase B: row tile j of S x, H (x - mu) (, H_decay^T (x - mu_decay)) on MFMA =================
         double sx[4], hv[4], dgr[4];
         bool skipH = false;  // wave-uniform (and the same in every wave): the bound's tiles were left out, b2 is not posted
+        bool ranD = false;   // the same for the decay term's tiles
         {
             bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
             bf_acc4 aD0 = bf_acc4_zero(), aD1 = bf_acc4_zero();
@@ -483,7 +484,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
             if constexpr (DEC) {
                 const bool calm = !a.no_bound_proof && m.lam_max_d * r2d < decay_thr;
-                if (bf_any(!calm)) {
+                ranD = bf_any(!calm);
+                if (ranD) {
 #pragma unroll
                     for (int s = 0; s < KH; ++s) {
                         aD0 = bf_mfma(afD[s], XB[(2 * NS + s) * 64 + lane], aD0);
@@ -501,11 +503,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 
         GTRACE(3);
         // ================= phase C: the evaluation's sums, and the U-turn sums of the leaf it completes =================
-        double gn[4], ge[4], pn[4], t_kin[4];
+        double ge[4], pn[4];
         const double dt_c = 0.5 * eps_t;
         const bool early = !skip_early;   // the kinetic energy and the U-turn sums ride in this exchange (same in all waves)
         {
-            double t_val[4], t_b2[4], t_bd2[4], t_a1[4], t_a2[4];
+            double gn[4], t_val[4], t_b2[4], t_bd2[4], t_kin[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 gn[r] = sx[r] + c_lin[r];
@@ -513,9 +515,6 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 t_val[r] = bf_fma(0.5 * xev[r], sx[r], c_lin[r] * xev[r]);
                 const double xm = xs[r] - c_mu[r];
                 t_b2[r] = xm * hv[r];
-                // outside the bound (bfhip_oob.h): a1 = (x - mu) . (S mu + lin), a2 = (x - mu) . S (x - mu)
-                t_a1[r] = xm * (c_smu[r] + c_lin[r]);
-                t_a2[r] = xm * (sx[r] - c_smu[r]);
                 t_bd2[r] = DEC ? (xo[r] - c_dmu[r]) * dgr[r] : 0.;
                 // inside the bound (and the decay ellipsoid) the gradient is complete: chain rule, transform term
                 // (module.py:226, density.py:558,747-750), second half of the step (integration.py:90) and the kinetic
@@ -527,7 +526,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 pn[r] = bf_fma(dt_c, ge[r], p[r]);
                 t_kin[r] = pn[r] * (var[r] * pn[r]);
             }
-            static_assert(G::V_KIN == 0 && G::V_VAL == 1 && G::V_B2 == 2 && G::V_A1 == 3 && G::V_A2 == 4, "posted as one batch");
+            static_assert(G::V_KIN == 0 && G::V_VAL == 1 && G::V_B2 == 2, "posted as one batch");
             if (skipH) {
                 if (early) {
                     double e2[2] = {sum4(t_kin), sum4(t_val)};
@@ -536,11 +535,11 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     post(G::V_VAL, sum4(t_val));
                 }
             } else if (early) {
-                double e5[5] = {sum4(t_kin), sum4(t_val), sum4(t_b2), sum4(t_a1), sum4(t_a2)};
-                post_n(G::V_KIN, e5);
+                double e3[3] = {sum4(t_kin), sum4(t_val), sum4(t_b2)};
+                post_n(G::V_KIN, e3);
             } else {
-                double e4[4] = {sum4(t_val), sum4(t_b2), sum4(t_a1), sum4(t_a2)};
-                post_n(G::V_VAL, e4);
+                double e2[2] = {sum4(t_val), sum4(t_b2)};
+                post_n(G::V_VAL, e2);
             }
             if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
             if constexpr (TR) {
@@ -653,7 +652,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 
         // ================= the evaluation's scalars =================
         // this trip's sums, fetched together (one LDS round trip instead of one per value)
-        double s_kin = 0., s_val = 0., s_b2 = 0., s_a1 = 0., s_a2 = 0.;
+        double s_kin = 0., s_val = 0., s_b2 = 0.;
+        bool late_sync_done = false;
         double sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
         if (skipH) {   // inside the bound, proven
             if (early) {
@@ -664,13 +664,13 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 s_val = rd(G::V_VAL);
             }
         } else if (early) {
-            double sv_5[5];
-            rd_n(G::V_KIN, sv_5);
-            s_kin = sv_5[0]; s_val = sv_5[1]; s_b2 = sv_5[2]; s_a1 = sv_5[3]; s_a2 = sv_5[4];
+            double sv_3[3];
+            rd_n(G::V_KIN, sv_3);
+            s_kin = sv_3[0]; s_val = sv_3[1]; s_b2 = sv_3[2];
         } else {
-            double sv_4[4];
-            rd_n(G::V_VAL, sv_4);
-            s_val = sv_4[0]; s_b2 = sv_4[1]; s_a1 = sv_4[2]; s_a2 = sv_4[3];
+            double sv_2[2];
+            rd_n(G::V_VAL, sv_2);
+            s_val = sv_2[0]; s_b2 = sv_2[1];
         }
         const bool any_e0 = bf_any(need_E0);
         if (any_e0) rd_n(G::V_KIN0, sv_k0);
@@ -687,42 +687,113 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // (the common trip -- every chain proven inside the bound, no decay term -- skips the rare branches as one: per-lane
         // branches cost a round trip through the scalar unit each, with one wave per SIMD nothing hides it)
         const bool rare = DEC || !skipH;   // wave-uniform
-        if (rare && ev) {
+        if (rare) {
+            // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is decided on the
+            // squares whenever b2 is not within rounding distance of alpha^2
+            double bt = 0.;
+            bool any_oob = false, any_dec = false;
             if (!skipH) {
-                // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is
-                // decided on the squares whenever b2 is not within rounding distance of alpha^2
                 const double a2 = m.alpha * m.alpha;
-                double bt = 0.;
-                if (!(s_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(s_b2);
-                if (bt > m.alpha) {   // outside the alpha-ellipsoid (poly.py:480-503)
-                    const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, bt, s_a1, s_a2);
-                    f = o.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gn[r] = bf_oob_grad(o, c_smu[r] + c_lin[r], sx[r] - c_smu[r], hv[r]);
-                    late = true;
-                }
+                if (ev && !(s_b2 < a2 * (1. - 1e-12))) bt = bf_sqrt(s_b2);
+                any_oob = bf_any(ev && bt > m.alpha);
             }
             if constexpr (DEC) {  // density.py:740-746
-                const double r_bd2 = rd(G::V_BD2);
-                const double ex = r_bd2 - m.decay_alpha2;
-                f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
-                dec_on = r_bd2 > m.decay_alpha2;
-                late = late || dec_on;
+                if (ev) {
+                    const double r_bd2 = rd(G::V_BD2);
+                    const double ex = r_bd2 - m.decay_alpha2;
+                    f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                    dec_on = r_bd2 > m.decay_alpha2;
+                }
+                any_dec = bf_any(dec_on);
+            }
+            if (__builtin_expect(any_oob || any_dec, 0)) {   // (cold: the register allocator spills here, not in the common trip)
+                // Some chain's gradient depends on the evaluation's own sums.  Rare in this layout, so nothing of phase B is kept
+                // for it: the trip's tiles run again on the operands that are still in XB (the same numbers), and outside the
+                // bound the two sums of the extrapolation (bfhip_oob.h: a1 = (x - mu) . (S mu + lin), a2 = (x - mu) . S (x - mu)) take
+                // an exchange of their own, through the slots of the value and the bound.
+                double sx2[4], hv2[4], dgr2[4];
+                {
+                    bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
+                    bf_acc4 aD0 = bf_acc4_zero(), aD1 = bf_acc4_zero();
+                    constexpr int KH = NS / KS;
+#pragma unroll
+                    for (int s2 = 0; s2 < KH; ++s2) {
+                        aS0 = bf_mfma(afS[s2], XB[(0 * NS + s2) * 64 + lane], aS0);
+                        if constexpr (KS == 2) aS1 = bf_mfma(afS[KH + s2], XB[(0 * NS + KH + s2) * 64 + lane], aS1);
+                    }
+                    if (!skipH) {
+#pragma unroll
+                        for (int s2 = 0; s2 < KH; ++s2) {
+                            aH0 = bf_mfma(afH[s2], XB[(1 * NS + s2) * 64 + lane], aH0);
+                            if constexpr (KS == 2) aH1 = bf_mfma(afH[KH + s2], XB[(1 * NS + KH + s2) * 64 + lane], aH1);
+                        }
+                    }
+                    if constexpr (DEC) {
+                        if (ranD) {
+#pragma unroll
+                            for (int s2 = 0; s2 < KH; ++s2) {
+                                aD0 = bf_mfma(afD[s2], XB[(2 * NS + s2) * 64 + lane], aD0);
+                                if constexpr (KS == 2) aD1 = bf_mfma(afD[KH + s2], XB[(2 * NS + KH + s2) * 64 + lane], aD1);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sx2[r] = (KS == 2) ? aS0[r] + aS1[r] : aS0[r];
+                        hv2[r] = (KS == 2) ? aH0[r] + aH1[r] : aH0[r];
+                        dgr2[r] = DEC ? ((KS == 2) ? aD0[r] + aD1[r] : aD0[r]) : 0.;
+                    }
+                }
+                double s_a1 = 0., s_a2 = 0.;
+                if (any_oob) {
+                    bf_sync();  // the early exchange's sums have been read by every wave
+                    double t_a1[4], t_a2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double xm = XB[(1 * NS + 4 * j + r) * 64 + lane];   // x - mu, this lane's own operand
+                        t_a1[r] = xm * (c_smu[r] + c_lin[r]);
+                        t_a2[r] = xm * (sx2[r] - c_smu[r]);
+                    }
+                    double e2[2] = {sum4(t_a1), sum4(t_a2)};
+                    post_n(G::V_VAL, e2);
+                    bf_sync();
+                    double sv_2[2];
+                    rd_n(G::V_VAL, sv_2);
+                    s_a1 = sv_2[0]; s_a2 = sv_2[1];
+                }
+                if (ev) {
+                    double gl[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gl[r] = sx2[r] + c_lin[r];
+                    if (bt > m.alpha) {   // outside the alpha-ellipsoid (poly.py:480-503)
+                        const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, bt, s_a1, s_a2);
+                        f = o.f;
+                        if constexpr (DEC) {   // (the decay term was taken off the value at x above: off this one again)
+                            const double r_bd2 = rd(G::V_BD2);
+                            const double ex = r_bd2 - m.decay_alpha2;
+                            f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gl[r] = bf_oob_grad(o, c_smu[r] + c_lin[r], sx2[r] - c_smu[r], hv2[r]);
+                        late = true;
+                    }
+                    late = late || dec_on;
+                    if (late) {   // the complete gradient: poly.py:496-503, chain rule, decay, transform term; second half step
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double t = gl[r];
+                            if constexpr (TR) t = t * jac[r];
+                            if constexpr (DEC) { if (dec_on) t -= 2. * m.decay_gamma * dgr2[r]; }
+                            if constexpr (TR) t += gj[r];
+                            ge[r] = t;
+                            pn[r] = bf_fma(dt_c, ge[r], p[r]);
+                        }
+                    }
+                }
+                late_sync_done = any_oob;
             }
         }
         if constexpr (TR) f += rd(G::V_LOGDET);
-        if (rare && ev && late) {   // the complete gradient: poly.py:496-503, chain rule, decay, transform term; second half step
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double t = gn[r];
-                if constexpr (TR) t = t * jac[r];
-                if constexpr (DEC) { if (dec_on) t -= 2. * m.decay_gamma * dgr[r]; }
-                if constexpr (TR) t += gj[r];
-                ge[r] = t;
-                pn[r] = bf_fma(dt_c, ge[r], p[r]);
-                t_kin[r] = pn[r] * (var[r] * pn[r]);
-            }
-        }
         if (ev) {
             fin = true;
             logp_new = f;
@@ -731,8 +802,13 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // the late exchange: the kinetic energy and the U-turn sums with the complete momenta (all chains of the group again --
         // the ones that were not late post the numbers they posted before)
         const bool late_x = bf_any(ev && (late || !early));
-        if (late_x) {
-            if (early) bf_sync();  // B2': the early exchange's sums have been read by every wave
+        n_trip_late += late_x ? 1 : 0;
+        n_trip_skip += early ? 0 : 1;
+        if (__builtin_expect(late_x, 0)) {
+            if (early && !late_sync_done) bf_sync();  // B2': the early exchange's sums have been read by every wave
+            double t_kin[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t_kin[r] = pn[r] * (var[r] * pn[r]);
             post(G::V_KIN, sum4(t_kin));
             if (NUTS) uturn_sums(spec1);
             bf_sync();  // B3
@@ -1094,6 +1170,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     if (a.gcount && tid == 0) {
         bf_atomic_add_u64(a.gcount, n_trip);
         bf_atomic_add_u64(a.gcount + 1, n_trip_h);
+        bf_atomic_add_u64(a.gcount + 2, n_trip_late);
+        bf_atomic_add_u64(a.gcount + 3, n_trip_skip);
     }
     // ---- write the chain state back ----
     if (real) {

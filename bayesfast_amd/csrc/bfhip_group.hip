@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64 * W) void bf_group_kernel(DevModel m, SamplerArg
 template <int W, bool NUTS, int FS>
 static int launch_t(bfhip_ctx *ctx, const SamplerArgs &args) {
     auto k = bf_group_kernel<W, NUTS, FS>;
-    const size_t lds = GroupGeo<W, (FS & 2) && W == 4>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
+    const size_t lds = GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + 15) / 16;

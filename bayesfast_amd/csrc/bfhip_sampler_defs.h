@@ -15,7 +15,7 @@ struct SamplerArgs {
     unsigned long long *n_leapfrog;
     double *scratch;
     double *mat;  // full-rank metric: [n_chain][BF_MAT_N][d][d] (transposed storage, bfhip_metric.h), or NULL
-    unsigned long long *gcount;  // group kernel, measurement only: [0] += trips, [1] += trips that ran the bound's tiles (or NULL)
+    unsigned long long *gcount;  // group kernel, measurement only: [0] += trips, [1] += trips that ran the bound's tiles, [2] += trips with a late exchange, [3] += trips without the early one (4 words, or NULL)
     int no_bound_proof;          // group kernel, tests only: always compute the H (x - mu) tiles (bfhip_debug_no_bound_proof)
     unsigned long long *stamps;  // diagnostics only: [groups][16 waves][20]: 10 cycle counters + 10 event counts, or NULL
 };

@@ -378,7 +378,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ge[r] = 0.; pn[r] = 0.; }
             }
-            if (extra) {
+            if (__builtin_expect(extra, 0)) {   // (cold: spill code goes here, not into the proven trip)
                 bf_sync();  // B2a: this trip's sums
                 bool oob = false;
                 if (ev) {

@@ -339,12 +339,16 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
     ch.raise_on_error()
     lf0 = ch.total_leapfrog
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # measurement hook of the lane-per-chain kernels: trips, trips with the bound's tiles, with a late exchange, without the early one
+    gcount = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    _lib.lib().bfhip_debug_group_counters(__import__('ctypes').c_void_p(gcount.data_ptr()))
     torch.cuda.synchronize()
     e0.record(ctx.stream)
     for _ in range(steps):
         ch.run(iters, 'NUTS', samples=s, stats=st, **kw)
     e1.record(ctx.stream)
     torch.cuda.synchronize()
+    _lib.lib().bfhip_debug_group_counters(None)
     ch.raise_on_error()
     ms = e0.elapsed_time(e1)
     n_lf = ch.total_leapfrog - lf0
@@ -378,6 +382,9 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
                         'kernel': kname().decode(), 'kernel_ms_per_launch': ms / steps, 'flops_per_leapfrog': fl},
            'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9, 'peak': 8000.,
                                         'unit': 'GB/s', 'frac': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9 / 8000.}}
+    gc = [int(v) for v in gcount.cpu().numpy()]
+    if gc[0]:   # (the group / split kernels only)
+        out['group_trips'] = {'trips': gc[0], 'with_bound_tiles': gc[1], 'with_late_exchange': gc[2], 'without_early_exchange': gc[3]}
     try:   # HBM-side bytes per launch: a STORED profile value (tools/profile_configs.sh), used when kernel and shape match
         tj = json.load(open(os.path.join(ROOT, 'profiles', 'config_traffic.json')))
         for e in tj.values():
@@ -505,7 +512,7 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         x0b = x_new[rng.integers(0, x_new.shape[0], C)]
         r1, _, _ = _sampler_block(ctx, den, x0b, seed + 1, 0.8, n_adapt, iters, steps, 0., what % 1)
         return dict(r0, round_1={k: r1[k] for k in ('value', 'ms_per_launch', 'mean_tree_size', 'max_tree_depth', 'divergence_rate',
-                                                    'mean_accept', 'chain_layout', 'roofline')},
+                                                    'mean_accept', 'chain_layout', 'roofline', 'group_trips') if k in r1},
                     refit={'select_and_true_logp_ms': t_sel, **t_fit, 'n_fit_points': int(x_new.shape[0])})
     if name == 'funnel':
         d, C = 64, chains or 4096
@@ -646,7 +653,7 @@ def main():
 
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
         # measurement hook of the group kernel: trips, and trips that executed the bound's H (x - mu) tiles
-        gcount = torch.zeros(2, dtype=torch.int64, device=ctx.device)
+        gcount = torch.zeros(4, dtype=torch.int64, device=ctx.device)
         import ctypes
         _lib.lib().bfhip_debug_group_counters(ctypes.c_void_p(gcount.data_ptr()))
         sync()
@@ -659,7 +666,7 @@ def main():
         elapsed = time.perf_counter() - t0
         chains.raise_on_error()
         _lib.lib().bfhip_debug_group_counters(None)
-        g_trips, g_trips_h = [int(v) for v in gcount.cpu().numpy()]
+        g_trips, g_trips_h = [int(v) for v in gcount.cpu().numpy()[:2]]
         n_lf = chains.total_leapfrog - lf0
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if a.steps else 0.
         st_last = stats.cpu().numpy()
