@@ -550,7 +550,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             }
         }
         BF_MF(5);
-        if (unit == U_ABORT) {
+        if (__builtin_expect(unit == U_ABORT, 0)) {
             // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
             for (int al = (diverged ? 0 : lev); al < depth; ++al)
                 if ((i_leaf >> al) & 1) T_acc = rfl(lsw[al * LS_N + LS_ACC]) + T_acc;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         }
         BF_MF(6);
         TRACE(11);
-        if (unit == U_END1) {
+        if (__builtin_expect(unit == U_END1, 0)) {   // (cold: once per tree; the register allocator keeps its spill code here)
             ended = true;  // the tree the evaluation in flight belongs to has ended: the evaluation is dropped
             if (err == 0) {
                 // the proposal becomes the sample and the start of the next iteration.  base_hmc.py:70 evaluates it again
