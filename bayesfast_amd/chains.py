@@ -157,9 +157,12 @@ class DeviceChains:
             # the chains' behaviour, one launch late
             lay = layout
             if lay == 'auto':
-                lay = IN_STEP_LAYOUT if (sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)) else 'wave'
+                in_step = sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)   # (asked for at every launch: the
+                lay = IN_STEP_LAYOUT if in_step else 'wave'                                         # answers are consumed in order)
                 if sampler == 'NUTS' and self._small_problem():
                     lay = 'wave'
+                elif sampler == 'NUTS' and self._lanes_whatever_the_trees():
+                    lay = IN_STEP_LAYOUT
             cfg.chain_layout = {'group': 1, 'wave': 2, 'split': 3}[lay]
             self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
@@ -181,26 +184,48 @@ class DeviceChains:
             self.raise_on_error()
         return samples, stats
 
-    def _small_problem(self):
-        """NUTS on the plain surrogate where the wave-per-chain kernel beats the lane-per-chain layouts although the trees are in
-        step: the latter have d / 16 (group) or 2 d / 16 (split) waves per workgroup of 16 chains, so few chains leave most of a
-        CU idle, while the wave-per-chain kernel spreads fewer chains per workgroup over more CUs (bfhip_sampler.hip:
-        wave_layout_cpg).  Measured, in-step 7-leaf trees (tools/layout_ab.py, profiles/r03s_layout_ab.log), wave against the
-        best lane-per-chain layout: d = 32 (split, two + two waves): 1024 chains 3.2 against 3.0 x 10^8, 2048 5.5 against 6.0, 4096
-        8.2 against 12.1; d = 16 (split, one + one wave): 1024 2.75 against 2.80, 4096 7.5 against 11.0; d = 64: the split layout
-        ahead from 2048 chains.  A function of the shapes only (never of timing)."""
+    def _shape_facts(self):
+        """(plain, featured, n): the common surrogate (linear + quadratic configs with the bound) with nothing else / with the decay
+        term OR the constraint transform (the feature sets the pipelined wave-per-chain kernel has instantiations for) / chains per
+        rank (sharded: the ranks' average, equal on all of them).  A function of the shapes only."""
         if self._n_cu is None:
             self._n_cu = int(_torch().cuda.get_device_properties(self.ctx.device).multi_processor_count)
         sp = self.density.spec
-        plain = (not sp.get('use_decay') and sp.get('ranges') is None and sp.get('su_lo') is None and sp.get('link') is None and
-                 bool(sp['poly'].get('use_bound')) and sorted(c['order'] for c in sp['poly']['configs']) == ['linear', 'quadratic'])
-        if not plain or self.full_metric:   # (measured on the plain surrogate only: the pipelined wave-per-chain kernel)
+        common = (sp.get('su_lo') is None and sp.get('link') is None and sp.get('chi2') is None and bool(sp['poly'].get('use_bound')) and
+                  sorted(c['order'] for c in sp['poly']['configs']) == ['linear', 'quadratic'] and not self.full_metric)
+        dec, tr = bool(sp.get('use_decay')), sp.get('ranges') is not None
+        n = self.n_chain if self.n_chain_rule is None else self.n_chain_rule
+        return common and not dec and not tr, common and (dec != tr), n
+
+    def _small_problem(self):
+        """NUTS where the wave-per-chain kernel beats the lane-per-chain layouts although the trees are in step: the latter have
+        d / 16 (group) or 2 d / 16 (split) waves per workgroup of 16 chains, so few chains leave most of a CU idle, while the
+        wave-per-chain kernel spreads fewer chains per workgroup over more CUs (bfhip_sampler.hip: wave_layout_cpg).  Measured,
+        in-step 7-leaf trees (tools/layout_ab.py, profiles/r03s_layout_ab.log), wave against the best lane-per-chain layout: d = 32
+        (split, two + two waves): 1024 chains 3.2 against 3.0 x 10^8, 2048 5.5 against 6.0, 4096 8.2 against 12.1; d = 16 (split,
+        one + one wave): 1024 2.75 against 2.80, 4096 7.5 against 11.0; d = 64: the split layout ahead from 2048 chains.  With the
+        decay term or behind the constraint transform the lane-per-chain layout is the group kernel (no split instantiation) and the
+        pipelined kernel stays ahead up to eight chains per CU (tools/dispatch_sweep.py, profiles/r04e_dispatch_sweep.log: d = 32
+        x 1024 chains 3.3 against 2.2 x 10^8 with the decay term, 2.4 against 1.5 bounded; d = 64 x 1024 3.0 against 2.5 and 2.3
+        against 1.4; at sixteen chains per CU the group kernel wins everywhere).  A function of the shapes only (never of timing)."""
+        plain, featured, n = self._shape_facts()
+        if featured:
+            return self.d <= 64 and n <= 8 * self._n_cu
+        if not plain:   # (everything else runs the sliced kernel in the wave layout and the group kernel in step)
             return False
-        n = self.n_chain if self.n_chain_rule is None else self.n_chain_rule   # (sharded: the ranks' average, equal on all of them)
         # (32 < d <= 64: with at most four chains per workgroup -- n <= 4 x CUs, wave_layout_cpg -- the pipelined kernel's jobs run
         # on 4 x 4 x 4 MFMA tiles: 1024 chains 3.7 against the split layout's 2.9 x 10^8, 512 chains 1.9 against 1.5)
         return ((self.d <= 16 and n < 4 * self._n_cu) or (16 < self.d <= 32 and n < 6 * self._n_cu) or
                 (32 < self.d <= 64 and n <= 4 * self._n_cu))
+
+    def _lanes_whatever_the_trees(self):
+        """NUTS on the plain surrogate at d <= 32 with at least sixteen chains per CU: the split layout's trip is short there (one or
+        two integrator waves per 16 chains), and it stays ahead of the wave layout when the trees of a group differ -- 7- and 15-leaf
+        trees side by side: d = 16 x 4096 chains 12.2 against 8.9 x 10^8, d = 32 14.3 against 9.8; trees of 7 to 63 leaves: 10.6 / 10.5
+        against 9.8 (tools/dispatch_sweep.py, profiles/r04e_dispatch_sweep.log).  At eight chains per CU it depends on how different
+        the trees are, and the judgement of the last launch decides as everywhere else."""
+        plain, _, n = self._shape_facts()
+        return plain and self.d <= 32 and n >= 16 * self._n_cu
 
     def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
                      target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,

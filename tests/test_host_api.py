@@ -373,3 +373,32 @@ def test_blas_single_thread_context_limits_and_restores():
         assert np.allclose(a.T @ a, np.einsum('ij,ik->jk', a, a))
     after = [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']
     assert inside and all(n == 1 for n in inside) and after == before
+
+
+def test_layout_rules_are_functions_of_the_shapes_only():
+    """DeviceChains' shape rules for the automatic layout (tools/dispatch_sweep.py measured them): the wave layout for few chains,
+    up to eight per CU with the decay term or the constraint transform (the pipelined kernel's feature sets), never for both
+    together or for other densities; the lane layouts whatever the trees at d <= 32 from sixteen chains per CU."""
+    import types
+    from bayesfast_amd.chains import DeviceChains
+
+    def stub(d, n, spec_extra=None, configs=('linear', 'quadratic'), n_rule=None, full=False):
+        sp = dict(poly=dict(use_bound=True, configs=[dict(order=o) for o in configs]), **(spec_extra or {}))
+        o = types.SimpleNamespace(density=types.SimpleNamespace(spec=sp), d=d, n_chain=n, n_chain_rule=n_rule, full_metric=full, _n_cu=256, ctx=None)
+        for name in ('_shape_facts', '_small_problem', '_lanes_whatever_the_trees'):
+            setattr(o, name, types.MethodType(getattr(DeviceChains, name), o))
+        return o
+
+    dec = dict(use_decay=True)
+    tr = dict(ranges=np.zeros((64, 2)))
+    assert stub(64, 1024)._small_problem() and not stub(64, 2048)._small_problem()
+    assert stub(32, 1024)._small_problem() and not stub(32, 2048)._small_problem()
+    assert stub(64, 2048, dec)._small_problem() and not stub(64, 4096, dec)._small_problem()
+    assert stub(32, 2048, tr)._small_problem() and not stub(32, 4096, tr)._small_problem()
+    assert not stub(64, 512, dict(dec, **tr))._small_problem()                      # no pipelined instantiation with both
+    assert not stub(64, 512, configs=('linear', 'quadratic', 'cubic-2'))._small_problem()
+    assert not stub(64, 512, dec, full=True)._small_problem()
+    assert stub(64, 16384, dec, n_rule=2048)._small_problem()                       # sharded: chains per rank
+    assert stub(16, 4096)._lanes_whatever_the_trees() and stub(32, 8192)._lanes_whatever_the_trees()
+    assert not stub(32, 2048)._lanes_whatever_the_trees() and not stub(64, 4096)._lanes_whatever_the_trees()
+    assert not stub(16, 4096, dec)._lanes_whatever_the_trees()
