@@ -363,7 +363,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         // twice: with the subtree stack in global memory a fused merge consumes its loads at once, and the larger live
         // ranges triple the register spills; with one unit per trip the operands are prefetched a trip ahead.)
         if (unit == U_EVAL) {
-            if (have_ev && mode == M_INIT) {
+            if (__builtin_expect(have_ev && mode == M_INIT, 0)) {
                 // BaseHMC.astep start: base_hmc.py:70-76, Tree.__init__: nuts.py:24-43
                 if (!(fabs(E_new) <= 1.7976931348623157e308)) {
                     err = 1;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             }
         }
         // ---- cheap follow-ups that need no trip of their own ----
-        if (unit == U_ABORT) {
+        if (__builtin_expect(unit == U_ABORT, 0)) {
             // unwind: every pending ancestor adds its left half's accept_sum (nuts.py:173)
             for (int al = (diverged ? 0 : lev); al < depth; ++al)
                 if ((i_leaf >> al) & 1) T_acc = rfl(lsw[al * LS_N + LS_ACC]) + T_acc;
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                     (void)add_value; (void)fval;
                 };
                 double fsum = 0.;
-                if (cub_l) {
+                if (__builtin_expect(cub_l, 1)) {
                     // the same sums in the same order with the tables in LDS, the masked inputs gathered once (lane k
                     // holds x[mask[k]]) and the masks and positions of this lane in registers: nothing of the loops below
                     // goes to global memory (the 64 dependent global loads of the cubic-3 contraction were 2/3 of config 5's trip)
