@@ -77,8 +77,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XB = lds;                             // [NMAT][NS][XS] B operands: x | x - mu | x - mu_decay
     double *LS = XB + NMAT * NS * XS;             // [16][MAXL][LS_N] per-chain stack scalars
-    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating | [2] (DEC) some
-                                                  // chain takes its second pass in this trip (all by trip parity)
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity)
     double *CS = LS + 16 * MAXL * LS_N + 4;       // [16][CS_N]    cold per-chain scalars
     double *TB = CS + 16 * CS_N;                  // [16][NTL][DP] tree vectors: slots 0-7, stack level 1
     double *GB = TB + 16 * NTL * DP;              // [NMAT KS][16][GS] matvec results
