@@ -46,6 +46,7 @@ extern "C" void bfhip_ctx_destroy(bfhip_ctx *ctx) {
     if (ctx->cubic_buf) (void)hipFree(ctx->cubic_buf);
     if (ctx->pm_buf) (void)hipFree(ctx->pm_buf);
     if (ctx->pld_buf) (void)hipFree(ctx->pld_buf);
+    if (ctx->tail_buf) (void)hipFree(ctx->tail_buf);
     if (ctx->flow) (void)hipFree(ctx->flow);
     free(ctx);
 }

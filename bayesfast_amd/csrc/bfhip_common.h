@@ -53,6 +53,8 @@ struct bfhip_ctx {
         const int *mask2, *pos2, *mask3, *pos3;
         const double *A2, *A2t, *T3t;
     } pm;
+    int *tail_buf;        // the chains of a launch's tail: count, then their indices (bfhip_sampler.hip: launch_nuts_pipe)
+    int tail_cap;
     void *scratch;        // sampler tree scratch (grow-only)
     size_t scratch_bytes;
     int n_cu;

@@ -77,16 +77,26 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XB = lds;                             // [NMAT][NS][XS] B operands: x | x - mu | x - mu_decay
     double *LS = XB + NMAT * NS * XS;             // [16][MAXL][LS_N] per-chain stack scalars
-    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity)
+    int *alive = (int *)(LS + 16 * MAXL * LS_N);  // [2] any chain not done | [2] mask of the chains evaluating (by trip parity) | [6] number of
+                                                  // waves whose chain has left (tail_stop)
     double *CS = LS + 16 * MAXL * LS_N + 4;       // [16][CS_N]    cold per-chain scalars
     double *TB = CS + 16 * CS_N;                  // [16][NTL][DP] tree vectors: slots 0-7, stack level 1
     double *GB = TB + 16 * NTL * DP;              // [NMAT KS][16][GS] matvec results
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index == chain index in the group
-    const int cpg = a.cpg > 0 ? a.cpg : 16;  // chains of this workgroup (wave_layout_cpg; the other waves only run matvec jobs)
-    const int chain = blockIdx.x * cpg + w;
-    const bool real = w < cpg && chain < a.n_chain;
+    int cpg = a.cpg > 0 ? a.cpg : 16;  // chains of this workgroup (wave_layout_cpg; the other waves only run matvec jobs)
+    int chain = blockIdx.x * cpg + w;
+    bool real = w < cpg && chain < a.n_chain;
+    if (a.tail_list) {
+        // the tail of a launch: the chains that stopped early, listed; as few per workgroup as the CUs allow (the numbers do
+        // not depend on the grouping)
+        const int cnt = rfl(a.tail_count[0]);
+        cpg = cnt <= a.n_cu ? 1 : (cnt <= 2 * a.n_cu ? 2 : 4);
+        const int idx = blockIdx.x * cpg + w;
+        real = w < cpg && idx < cnt;
+        chain = real ? rfl(a.tail_list[idx]) : 0;
+    }
     const int d = m.d;
     const bool lane_ok = lane < DP;
 
@@ -181,9 +191,12 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         if (i_iter < a.iter_end && err == 0) {
             mode = M_INIT;
             draw_momentum();
+        } else if (a.tail_done && lane == 0) {
+            atomicAdd(a.tail_done, 1);   // (nothing left to do in this launch)
         }
     }
     __syncthreads();
+    if (lane == 0 && mode == M_DONE) atomicAdd(&alive[6], 1);   // (waves without a chain, chains without work)
 
 #ifdef BF_TRACE
     __shared__ unsigned long long TRC[BF_TRACE * 16];
@@ -298,11 +311,27 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             }
             i_iter += 1;
             TRACE(12);
-            if (i_iter < a.iter_end && err == 0) {
+            bool go_on = i_iter < a.iter_end && err == 0;
+            if (go_on && a.tail_stop > 0 && a.iter_end - i_iter >= 8) {
+                // The launch's tail (bfhip_sampler.hip: launch_nuts_pipe): one of the last chains of its workgroup, with at least a
+                // quarter of the launch's iterations left while three quarters of the launch's chains are through, stops here
+                // and goes on in the launch of the tail (as after any cut between launches).  (The state array still holds the
+                // iteration the chain entered the launch with.)
+                const int i_iter0 = rfl((int)scp[BFHIP_SC_I_ITER]);
+                if (4 * (a.iter_end - i_iter) >= a.iter_end - i_iter0 && 16 - rfl(alive[6]) <= a.tail_stop) {
+                    const int dg = rfl(__hip_atomic_load(a.tail_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (4 * dg >= 3 * a.n_chain) go_on = false;
+                }
+            }
+            if (go_on) {
                 mode = M_INIT;
                 draw_momentum();
             } else {
                 mode = M_DONE;
+                if (lane == 0) {
+                    atomicAdd(&alive[6], 1);   // (chains of this workgroup that have left)
+                    if (a.tail_done && (i_iter >= a.iter_end || err != 0)) atomicAdd(a.tail_done, 1);
+                }
             }
         }
     };

@@ -1685,10 +1685,42 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
 static bool g_no_pipe = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && !strcmp(e, "sliced"); }();
 extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 
+// The tail of a launch.  A launch of the wave-per-chain kernel lasts as long as its busiest chain, and at its end most workgroups
+// hold one or two unfinished chains on 16-column tiles.  Sixteen-chain launches therefore run in two parts: in the first a
+// workgroup with at most four unfinished chains lets each of them stop at the end of its iteration (tail_stop) -- once three
+// quarters of the launch's chains are through and the chain has at least a quarter of the launch's iterations left (a stopped
+// chain waits for the first part to end: worth it for a straggler in the tail, not for a chain that is merely last); a small kernel
+// lists the chains that have iterations left; the second part runs those, one to four per workgroup on 4 x 4 x 4 tiles (a lone
+// chain's leapfrog step: 2.97 against 3.90 us, tools/lone_funnel.py).  A chain's numbers depend neither on where it is cut (as
+// between any two launches) nor on its workgroup.  bfhip_debug_tail_relaunch(0) / BFHIP_TAIL_RELAUNCH=0: one part (tests compare).
+static int g_tail_relaunch = [] { const char *e = getenv("BFHIP_TAIL_RELAUNCH"); return e ? atoi(e) : 1; }();
+extern "C" void bfhip_debug_tail_relaunch(int v) { g_tail_relaunch = v; }
+// test hook: how many chains the last two-part launch listed for its second part (synchronises), -1 without one
+extern "C" int bfhip_debug_tail_count(bfhip_ctx *ctx) {
+    if (!ctx || !ctx->tail_buf) return -1;
+    int n = -1;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+    if (hipMemcpy(&n, ctx->tail_buf, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+static int g_tail_stop = [] { const char *e = getenv("BFHIP_TAIL_STOP"); return e ? atoi(e) : 4; }();   // (tuning: 1 .. 4)
+
+__global__ void bf_tail_list_kernel(int n_chain, int iter_end, const double *sc, int *buf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chain) return;
+    const double *scp = sc + (size_t)i * BFHIP_SC_N;
+    if ((int)scp[BFHIP_SC_I_ITER] < iter_end && (int)scp[BFHIP_SC_ERROR] == 0) buf[2 + atomicAdd(buf, 1)] = i;   // buf: count | done | list
+}
+
 template <int W, bool TR = false, bool DEC = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
+    args.tail_stop = 0;
+    args.tail_list = NULL;
+    args.tail_count = NULL;
+    args.tail_done = NULL;
+    args.n_cu = ctx->n_cu;
     // (at most four / eight chains in a workgroup: 4 x 4 x 4 MFMA tiles)
     constexpr bool CANQ = true;
     auto k = (CANQ && args.cpg <= 4 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
@@ -1697,8 +1729,40 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
+    const bool two_parts = g_tail_relaunch && args.cpg == 16 && !g_no_quad && !args.stamps;
+    if (two_parts) {
+        if (ctx->tail_cap < args.n_chain + 2) {
+            BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (ctx->tail_buf) BF_HIP_CHECK(hipFree(ctx->tail_buf));
+            ctx->tail_buf = NULL;
+            ctx->tail_cap = 0;
+            BF_HIP_CHECK(hipMalloc((void **)&ctx->tail_buf, (size_t)(args.n_chain + 2) * sizeof(int)));
+            ctx->tail_cap = args.n_chain + 2;
+        }
+        args.tail_stop = g_tail_stop;
+        args.tail_done = ctx->tail_buf + 1;
+        BF_HIP_CHECK(hipMemsetAsync(ctx->tail_buf, 0, 2 * sizeof(int), ctx->stream));
+    }
     hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
+    if (two_parts) {
+        hipLaunchKernelGGL(bf_tail_list_kernel, dim3((args.n_chain + 255) / 256), dim3(256), 0, ctx->stream, args.n_chain, args.iter_end, args.sc,
+                           ctx->tail_buf);
+        BF_HIP_CHECK(hipGetLastError());
+        auto k2 = bf_nuts_pipe_kernel<W, TR, DEC, 1>;
+        if (lds > 64 * 1024)
+            BF_HIP_CHECK(hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SamplerArgs a2 = args;
+        a2.tail_stop = 0;
+        a2.tail_count = ctx->tail_buf;
+        a2.tail_list = ctx->tail_buf + 2;
+        a2.tail_done = NULL;
+        a2.cpg = 4;
+        // (at most four chains of every first-part workgroup are listed: groups workgroups of four chains, or one chain per CU)
+        const int groups2 = groups > ctx->n_cu ? groups : ctx->n_cu;
+        hipLaunchKernelGGL(k2, dim3(groups2), dim3(1024), lds, ctx->stream, ctx->model, a2);
+        BF_HIP_CHECK(hipGetLastError());
+    }
     return 0;
 }
 

@@ -17,6 +17,13 @@ struct SamplerArgs {
     double *mat;  // full-rank metric: [n_chain][BF_MAT_N][d][d] (transposed storage, bfhip_metric.h), or NULL
     unsigned long long *gcount;  // group kernel, measurement only: [0] += trips, [1] += trips that ran the bound's tiles, [2] += trips with a late exchange, [3] += trips without the early one (4 words, or NULL)
     int no_bound_proof;          // group kernel, tests only: always compute the H (x - mu) tiles (bfhip_debug_no_bound_proof)
+    // bf_nuts_pipe_kernel, the launch's tail (bfhip_sampler.hip: launch_nuts_pipe): tail_stop > 0 -- a workgroup with at most that
+    // many unfinished chains lets each of them stop at the end of its iteration; tail_list / tail_count -- the chains of THIS launch
+    // (the ones that stopped), tail_count[0] of them, one to four per workgroup (n_cu decides)
+    int tail_stop, n_cu;
+    const int *tail_list, *tail_count;
+    int *tail_done;   // first part: += 1 per chain that has finished the launch's iterations (a workgroup stops its last chains only
+                      // when three quarters of the launch's chains are through: the tail, not a slow workgroup among busy ones)
     unsigned long long *stamps;  // diagnostics only: [groups][16 waves][20]: 10 cycle counters + 10 event counts, or NULL
 };
 

@@ -824,3 +824,51 @@ def test_launches_may_alternate_between_the_layouts(ctx):
         assert np.array_equal(st[i, :, _lib.NSTATS.index('diverging')], sto['diverging']), i
         np.testing.assert_allclose(s[i, :10], so[:10], rtol=1e-8, atol=1e-8)
         np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('case', ['plain', 'decay_out'])
+def test_the_tail_of_a_launch_in_few_chain_workgroups_never_changes_results(ctx, case):
+    """Sixteen-chain launches of the wave-per-chain kernel run in two parts (bfhip_sampler.hip: launch_nuts_pipe): one of the last
+    chains of a workgroup, with at least a quarter of the launch's iterations left while three quarters of the launch's chains are
+    through, stops at the end of its iteration, and the stopped chains go on in a second launch, one to four per workgroup on
+    4 x 4 x 4 tiles.  Samples, statistics, adapted state, random streams and the leapfrog count are EQUAL to the one-part launch's.
+    Stragglers made on purpose: every 19th chain gets a step size of 0.03 (63-leaf trees at a depth limit of 6 where the others
+    build 7), step-size adaptation off; the plain and the decay instantiation (every leaf outside the bound); two launches each (the
+    second resumes)."""
+    import ctypes
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = 64
+    spec, _ = correlated_gaussian_spec(d, fit_scale=0.3 if case == 'decay_out' else 1.5)
+    if case == 'decay_out':
+        po = spec['poly']
+        spec = dict(spec, use_decay=True, decay_mu=po['mu'] + 0.05, decay_hess=po['hess'], decay_alpha2=(1.5 * po['alpha'])**2, decay_gamma=0.1)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(7).normal(size=(150, d))
+    L = _lib.lib()
+    L.bfhip_debug_tail_count.argtypes = [ctypes.c_void_p]
+    L.bfhip_debug_tail_count.restype = ctypes.c_int
+    out, listed = {}, {}
+    try:
+        L.bfhip_debug_wave_cpg(16)
+        for two in (1, 0):
+            L.bfhip_debug_tail_relaunch(two)
+            dc = DeviceChains(dens, x0, seed=13, step_size=0.6)
+            for f in ('log_step', 'log_bar'):
+                dc.sc[::19, _lib.SC_FIELDS.index(f)] = np.log(0.03)
+            kw = dict(n_warmup=0, layout='wave', adapt_step_size=False, adapt_metric=False, max_treedepth=6)
+            s1, st1 = dc.run(40, 'NUTS', **kw)
+            listed[two] = L.bfhip_debug_tail_count(ctx.handle) if two else 0
+            s2, st2 = dc.run(12, 'NUTS', **kw)
+            out[two] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
+    finally:
+        L.bfhip_debug_wave_cpg(0)
+        L.bfhip_debug_tail_relaunch(1)
+    for a, b in zip(out[1][:-1], out[0][:-1]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert out[1][-1] == out[0][-1]
+    ts = out[1][1][:, :, _lib.NSTATS.index('tree_size')].sum(1)
+    assert ts[::19].min() > 3 * np.delete(ts, np.arange(0, 150, 19)).max()   # (the stragglers are stragglers)
+    assert 1 <= listed[1] <= 8, listed   # (... and the second part ran them: 8 of the 150 chains)
