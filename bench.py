@@ -165,8 +165,10 @@ def other_samplers(ctx, d, cov, C, seed):
     lf0 = ch.total_leapfrog
     (_, st, _), t = timed(lambda: ch.run_tempered(60, np.zeros(d), 1.3 * cov, n_warmup=100, check=False))
     ch.raise_on_error()
+    ts_t = st[:, :, _lib.NSTATS.index('tree_size')].sum(1)
     out['tempered'] = {'value': (ch.total_leapfrog - lf0) / t, 'unit': 'tempered leapfrog steps/sec', 'chains': C, 'dim': d,
                        'mean_tree_size': float(st[:, :, _lib.NSTATS.index('tree_size')].mean().item()),
+                       'launch_tail': float((ts_t.max() / ts_t.mean()).item()),
                        'note': 'TNUTS, Gaussian base density 1.3 x the target covariance; each step evaluates both densities twice'}
     return out
 

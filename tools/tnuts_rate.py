@@ -8,6 +8,7 @@ from bayesfast_amd.chains import DeviceChains
 from bayesfast_amd.workloads import correlated_gaussian_spec
 from bayesfast_amd import _lib
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+NI = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 ctx = get_context(0)
 spec, cov = correlated_gaussian_spec(64)
 dens = DeviceDensity(spec, ctx)
@@ -18,12 +19,12 @@ ch.run_tempered(120, np.zeros(64), base_cov, n_warmup=100, check=False)
 lf0 = ch.total_leapfrog
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(ctx.stream)
-out = ch.run_tempered(60, np.zeros(64), base_cov, n_warmup=100, check=False)
+out = ch.run_tempered(NI, np.zeros(64), base_cov, n_warmup=100, check=False)
 e1.record(ctx.stream)
 torch.cuda.synchronize()
 st = out[1]
-print('tempered NUTS, %d chains: %.4g tempered leapfrog steps/s, %.1f ms per 60 iterations, mean tree size %.1f' % (
-    C, (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), e0.elapsed_time(e1), st[:, :, _lib.NSTATS.index('tree_size')].mean().item()))
+print('tempered NUTS, %d chains: %.4g tempered leapfrog steps/s, %.1f ms per %d iterations, mean tree size %.1f' % (
+    C, (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), e0.elapsed_time(e1), NI, st[:, :, _lib.NSTATS.index('tree_size')].mean().item()))
 ts = st[:, :, _lib.NSTATS.index('tree_size')].cpu().numpy()
 per_chain = ts.sum(1)
 print('leapfrogs per chain in the launch: mean %.0f, max %.0f (launch tail %.2f); per workgroup of 8 chains, max over mean: %.2f; tree size '
