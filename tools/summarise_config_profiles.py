@@ -58,20 +58,27 @@ for wd in sorted(glob.glob(os.path.join(out, '*/'))):
         if not cand:
             continue
         k = max(cand, key=lambda c: sum(dur[c][-N_TIMED:]))
+        # a launch of the wave-per-chain kernel is two dispatches (the launch and its tail, in two instantiations that differ in
+        # the last template argument): everything below is summed over them
+        stem_of = lambda c: c.split('>(')[0].rsplit(',', 1)[0]
+        parts = [c for c in cand if stem_of(c) == stem_of(k)] if k.startswith('bf_nuts_pipe_kernel') else [k]
+        tot = lambda d_: float(sum(np.mean(d_[c][-N_TIMED:]) for c in parts if c in d_))
         lf = blk['value'] * blk['ms_per_launch'] * 1e-3
-        e = {'kernel': k, 'kernel_named_by_library': kern, 'timed_dispatches': N_TIMED, 'avg_ms_kernel_trace': float(np.mean(dur[k][-N_TIMED:])),
+        e = {'kernel': k, 'kernel_named_by_library': kern, 'timed_dispatches': N_TIMED, 'avg_ms_kernel_trace': tot(dur),
              'ms_per_launch_hip_events': blk['ms_per_launch'], 'leapfrogs_per_launch': lf}
+        if len(parts) > 1:
+            e['dispatches_per_launch'] = {c: float(np.mean(dur[c][-N_TIMED:])) for c in parts}
         if k in fetch and k in write:
-            f, wv = float(np.mean(fetch[k][-N_TIMED:])) * 1024., float(np.mean(write[k][-N_TIMED:])) * 1024.
+            f, wv = tot(fetch) * 1024., tot(write) * 1024.
             e.update(fetch_bytes_per_launch_raw=f, write_bytes_per_launch=wv, hbm_bytes_per_launch=f + wv, hbm_bytes_per_leapfrog=(f + wv) / lf,
                      note='FETCH_SIZE raw (KB -> bytes): these kernels read 8 B per lane, outside the 16-B/lane calibration of the x2 '
                           'correction of MI355X_MICROARCH.md, so the raw value is a lower bound and twice it an upper bound')
         sq = {}
         for nm in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS',
                    'SQ_VALU_MFMA_BUSY_CYCLES'):
-            v = by_kernel([r for r in sqr if r.get('Counter_Name') == nm], lambda r: float(r['Counter_Value'])).get(k)
-            if v:
-                sq[nm] = float(np.mean(v[-N_TIMED:]))
+            v = by_kernel([r for r in sqr if r.get('Counter_Name') == nm], lambda r: float(r['Counter_Value']))
+            if v.get(k):
+                sq[nm] = tot(v)
         if sq.get('SQ_WAVE_CYCLES'):
             wc = sq['SQ_WAVE_CYCLES']
             sq['share_executing'] = sq.get('SQ_ACTIVE_INST_ANY', 0.) / wc
