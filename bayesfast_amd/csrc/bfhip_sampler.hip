@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #pragma unroll
     for (int e = 0; e < E; ++e) pj2[e] = pj3[e] = -1;
     if (cub_l) {
-        const int n22 = m.n2 * m.n2, n33 = m.n3 * m.n3 * m.n3;
+        const int n22 = m.n2 * m.n2;
         for (int i = tid; i < n22; i += NTH) { CUB[i] = m.A2t[i]; CUB[n22 + i] = m.A2[i]; }
         // T3t is [k][l][j]; in LDS it is [c][k][j][lq][i] with l = 16 c + lq + 4 i (zero where l >= n3): lane (j, lq) of the
         // contraction reads its four l of a chunk as two 16-byte pairs, and a wave's 64 lanes read 2 KB in a row
