@@ -107,7 +107,9 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0 && !PLD;
     const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = SPEC ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
-    const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = (SPEC || PLD) ? false : (bool)m.has_cubic;
+    // FS == 16: linear + quadratic + cubic configs with the bound and nothing else (BASELINE config 5's surrogate), fixed at compile time
+    constexpr bool CUBIC = FS == 16;
+    const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = CUBIC ? true : ((SPEC || PLD) ? false : (bool)m.has_cubic);
     const bool f_link = (SPEC || PLD) ? false : (bool)m.has_link;  // Gaussian likelihood of the surrogate's output (density.py:552-560)
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
     // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
@@ -1830,6 +1832,10 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         if (m.use_decay) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 3 : 0)>(ctx, args);
         if (m.has_transform) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 5 : 0)>(ctx, args);
     }
+    // d = 128 with cubic configs and nothing else (config 5): the feature set fixed at compile time too
+    if (W == 8 && NUTS && !g_no_plain && m.has_quad && m.use_bound && m.has_cubic && !m.use_decay && !m.has_transform && !m.has_su &&
+        !m.has_link)
+        return launch_sampler_t<(W == 8 ? 8 : W), NUTS, false, (W == 8 && NUTS ? 16 : 0)>(ctx, args);
 #endif
     return launch_sampler_t<W, NUTS, false, 0>(ctx, args);
 }
