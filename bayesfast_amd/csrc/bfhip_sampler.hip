@@ -81,7 +81,7 @@ struct SamplerGeo {
 // 16-column tiles), and FS = 9, eight waves of 256 registers (no spills, 4 x 4 x 4 tiles for its eight chains).  Measured on the
 // DES shape before the outputs were compressed (tools/pld_rate.py): 4096 chains 5.7 against 5.2 x 10^7 leapfrog steps/s, 1024
 // chains 1.8 against 2.6 x 10^7; launch_sampler has the rule that followed once they were.
-#define BF_SAMPLER_WAVES(W, FULLM, FS) (((W) == 8 || (FULLM) || (FS) == 9) ? 8 : 16)
+#define BF_SAMPLER_WAVES(W, FULLM, FS) (((W) == 8 || (FULLM) || (FS) == 9 || (FS) == 10) ? 8 : 16)
 
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
 // extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
@@ -99,17 +99,19 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
     // FS == 8: the pipeline density (bfhip_pld.h: multi-output surrogate + Gaussian likelihood + prior); transforms, input
     // scaling, bound and decay are run-time features as in FS == 0, the polynomial itself is the two contractions of phase P
-    constexpr bool PLD = FS == 8 || FS == 9;   // (9: eight waves of 256 registers, for launches of at most 8 chains per CU)
+    constexpr bool PLD = FS == 8 || FS == 9 || FS == 10;   // (9: eight waves of 256 registers, for launches of at most 8 chains per CU;
+    constexpr bool PLDC = FS == 10;                         //  10: the same with the DES-shaped feature set fixed at compile time -- box
+                                                            //  transform, input scaling, bound, no decay term)
 #ifndef BF_CHAIN_UNITS_MORE
 #define BF_CHAIN_UNITS_MORE 0
 #endif
     constexpr bool CHAIN_UNITS = PLD || W == 8 || FULLM || (BF_CHAIN_UNITS_MORE && !STAMPS);   // (see the end of the trip loop)
     constexpr bool PLAIN = FS == 1, SPEC = FS != 0 && !PLD;
-    const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = SPEC ? true : (bool)m.use_bound;
-    const bool f_decay = SPEC ? (FS & 2) != 0 : (bool)m.use_decay, f_tr = SPEC ? (FS & 4) != 0 : (bool)m.has_transform;
+    const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = (SPEC || PLDC) ? true : (bool)m.use_bound;
+    const bool f_decay = SPEC ? (FS & 2) != 0 : (PLDC ? false : (bool)m.use_decay), f_tr = SPEC ? (FS & 4) != 0 : (PLDC ? true : (bool)m.has_transform);
     // FS == 16: linear + quadratic + cubic configs with the bound and nothing else (BASELINE config 5's surrogate), fixed at compile time
     constexpr bool CUBIC = FS == 16;
-    const bool f_su = SPEC ? false : (bool)m.has_su, f_cubic = CUBIC ? true : ((SPEC || PLD) ? false : (bool)m.has_cubic);
+    const bool f_su = SPEC ? false : (PLDC ? true : (bool)m.has_su), f_cubic = CUBIC ? true : ((SPEC || PLD) ? false : (bool)m.has_cubic);
     const bool f_link = (SPEC || PLD) ? false : (bool)m.has_link;  // Gaussian likelihood of the surrogate's output (density.py:552-560)
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
     // PLAIN at d <= 64: there are at most 16 matvec jobs of at most 8 k-steps, so wave w runs the SAME job
@@ -1799,9 +1801,10 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         // k-steps, a quadratic config on 20 inputs, the sixteen-wave form's full tiles win, 8.2 against 7.3 x 10^7)
         const long gemm_steps = (long)m.pld.NT1 * m.pld.NS1 + (long)m.pld.NT2 * m.pld.NS2;
         const bool w8 = g_pld_waves ? g_pld_waves == 8 : (args.n_chain <= 8 * ctx->n_cu || gemm_steps <= 800);
+        if (w8 && m.has_transform && m.has_su && m.use_bound && !m.use_decay && !g_no_plain) return launch_sampler_t<WP, NUTS, false, 10>(ctx, args);
         return w8 ? launch_sampler_t<WP, NUTS, false, 9>(ctx, args) : launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
     }
-    if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);
+    if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);   // (a compile-time feature set changes nothing here: 7.4 x 10^7 either way)
 #ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
         return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS) ? 1 : 0>(ctx, args)
