@@ -81,6 +81,9 @@ struct SamplerGeo {
 // 16-column tiles), and FS = 9, eight waves of 256 registers (no spills, 4 x 4 x 4 tiles for its eight chains).  Measured on the
 // DES shape before the outputs were compressed (tools/pld_rate.py): 4096 chains 5.7 against 5.2 x 10^7 leapfrog steps/s, 1024
 // chains 1.8 against 2.6 x 10^7; launch_sampler has the rule that followed once they were.
+#ifndef BF_JOB_CHUNK
+#define BF_JOB_CHUNK 4
+#endif
 #define BF_SAMPLER_WAVES(W, FULLM, FS) (((W) == 8 || (FULLM) || (FS) == 9 || (FS) == 10) ? 8 : 16)
 
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 // the chains' waves are busy with the cubic configs; the chain-less waves share the jobs, TWO at a time: two
                 // independent chains of MFMAs whose operand loads (A from L2 at d = 128) are in flight together
                 const int st = NWV - cpg;
-                constexpr int C2 = KPJ < 4 ? KPJ : 4;
+                constexpr int C2 = KPJ < BF_JOB_CHUNK ? KPJ : BF_JOB_CHUNK;   // (k-steps whose operands are fetched together)
                 for (int job = w - cpg; job >= 0 && job < n_job; job += 2 * st) {
                     const bool two = job + st < n_job;
                     const int jb2 = two ? job + st : job;
@@ -1231,7 +1234,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         } else if (ks_rt == 2) run_jobs(std::integral_constant<int, (W >= 2 ? 2 : 1)>());
         else if (ks_rt == 4) run_jobs(std::integral_constant<int, (W >= 4 ? 4 : 1)>());
         else run_jobs(std::integral_constant<int, 1>());
-        if (cub_early && evaluating) fs_c = cubic_lds(xea, gc2_c, gc3_c);   // (this wave had no job: see run_jobs)
+        if (cub_early && evaluating) { TRACE(4); fs_c = cubic_lds(xea, gc2_c, gc3_c); TRACE(5); }   // (this wave had no job: see run_jobs)
         const int unit_in = unit;
         stamp(2);
         __syncthreads();  // B2
