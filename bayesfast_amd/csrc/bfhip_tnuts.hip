@@ -47,6 +47,7 @@ __device__ inline double tn_logaddexp(double a, double b) {
 #define TN_XS 65   // row stride of the B operands and of the results (doubles)
 
 #define TN_WAVES 8
+template <int W>   // row tiles of the matrices: the padded dimension is 16 W (W = 1, 2, 4), known at compile time
 __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, TnutsArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int d = a.d;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chain = blockIdx.x * a.cpg + w;
     const bool real = w < a.cpg && chain < a.n_chain;
-    const int NS = m.DP / 4, W = m.DP / 16;
+    constexpr int NS = 4 * W, DPW = 16 * W;
     // A operands of this wave's jobs, in registers for the whole launch: waves 0..3 row tile w of S (afr) and of S_b (afb), waves
     // 4..7 row tile w - 4 of H (afr)
     const int jt = w & 3;                 // row tile
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
     __syncthreads();
     double *lsw = LSC + w * (TN_MAXL * TS_N);
     const bool in = lane < d;
-    const double c_lin = in ? m.pd[PD_LIN * m.DP + lane] : 0., c_mu = in ? m.pd[PD_MU * m.DP + lane] : 0.;
-    const double c_smu = in ? m.pd[PD_SMU * m.DP + lane] : 0.;
+    const double c_lin = in ? m.pd[PD_LIN * DPW + lane] : 0., c_mu = in ? m.pd[PD_MU * DPW + lane] : 0.;
+    const double c_smu = in ? m.pd[PD_SMU * DPW + lane] : 0.;
     const double b_lin = in ? a.base_lin[lane] : 0.;
     // One rendezvous of the workgroup: this wave's point (active: it has one) -> S q, H (q - mu), S_b q of its chain.  Returns
     // false when no chain of the workgroup is active any more (the same answer in every wave).
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
     auto exchange = [&](bool active, double q, double xm, double &sx, double &hv, double &bx) -> bool {
         const int par = n_x & 1;
         n_x += 1;
-        if (lane < m.DP) {
+        if (lane < DPW) {
             const int xi = (lane >> 2) * TN_XS + w + 16 * (lane & 3);
             XB[xi] = q;
             XB[16 * TN_XS + xi] = xm;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
             }
         }
         __syncthreads();  // R2
-        const bool rd = lane < m.DP;
+        const bool rd = lane < DPW;
         sx = rd ? GB[(0 * 16 + w) * TN_XS + lane] : 0.;
         hv = rd ? GB[(1 * 16 + w) * TN_XS + lane] : 0.;
         bx = rd ? GB[(2 * 16 + w) * TN_XS + lane] : 0.;
@@ -498,7 +499,8 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     a.base_S = tp->base_S; a.base_lin = tp->base_lin; a.base_c0 = tp->base_c0; a.logxi = tp->logxi;
     a.cpg = cpg;
     const size_t lds = ((size_t)5 * 16 * TN_XS + TN_WAVES * TN_MAXL * TS_N + 2) * sizeof(double);
-    hipLaunchKernelGGL(bf_tnuts_kernel, dim3((n_chain + cpg - 1) / cpg), dim3(64 * TN_WAVES), lds, ctx->stream, m, a);
+    auto k = m.DP == 64 ? bf_tnuts_kernel<4> : (m.DP == 32 ? bf_tnuts_kernel<2> : bf_tnuts_kernel<1>);
+    hipLaunchKernelGGL(k, dim3((n_chain + cpg - 1) / cpg), dim3(64 * TN_WAVES), lds, ctx->stream, m, a);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
