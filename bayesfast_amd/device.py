@@ -102,6 +102,10 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# tuning / test switch: fold Surrogate.input_scales into linear + quadratic surrogates at upload (density_desc_from_spec)
+FOLD_INPUT_SCALES = __import__('os').environ.get('BFHIP_NO_SU_FOLD', '') in ('', '0')
+
+
 def density_desc_from_spec(spec):
     """Flatten a density spec (dict, see below) into a bfhip_density_desc + the arrays it points to.
 
@@ -137,9 +141,10 @@ def density_desc_from_spec(spec):
                 raise ValueError('hard_bounds should have shape (d, 2).')
             keep.append(hb)
             ds.hard_bounds = hb.ctypes.data_as(C.POINTER(C.c_uint8))
+    su_lo = su_diff = None
     if spec.get('su_lo') is not None:
-        ds.su_lo = f64(spec['su_lo'], (d,))
-        ds.su_diff = f64(spec['su_diff'], (d,))
+        su_lo = np.asarray(spec['su_lo'], dtype=np.float64).reshape(d)
+        su_diff = np.asarray(spec['su_diff'], dtype=np.float64).reshape(d)
     c0 = 0.
     lin = np.zeros(d)
     quad = np.zeros((d, d))
@@ -170,6 +175,30 @@ def density_desc_from_spec(spec):
             j, k, l = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing='ij')
             sel = (j < k) & (k < l)
             cubic3[im[j[sel]], im[k[sel]], im[l[sel]]] += coef[0][sel]
+    mu_b = hess_b = None
+    if poly.get('use_bound', False):
+        mu_b, hess_b = np.asarray(poly['mu'], dtype=np.float64).reshape(d), np.asarray(poly['hess'], dtype=np.float64).reshape(d, d)
+    if su_lo is not None and not (has['cubic-2'] or has['cubic-3']) and FOLD_INPUT_SCALES:
+        # Surrogate.input_scales (module.py:190-226: x_s = (x - lo) / diff before the polynomial, the gradient divided by diff
+        # after it) folded into a linear + quadratic polynomial's coefficients and its bound: with D = diag(1 / diff),
+        #   c0 + l . x_s + x_s^T A x_s = c0' + l' . x + x^T A' x,   A' = D A D,  l' = D l - (A' + A'^T) lo,
+        #   c0' = c0 - (D l) . lo + lo^T A' lo;   (x_s - mu)^T H (x_s - mu) = (x - mu')^T H' (x - mu'),  mu' = lo + diff mu,  H' = D H D
+        # -- the same function of x (the bound's radius, the extrapolation outside it and the gradient with it: every term of
+        # modules/poly.py:480-503 is D times its scaled-space form), equal to rounding.  The device then sees a surrogate
+        # WITHOUT input scaling, which every fused sampler kernel takes (with it, only the generic instantiation of the sliced
+        # kernel does).  Cubic configs keep the scaling as a device-side step.
+        dinv = 1. / su_diff
+        quad = quad * np.outer(dinv, dinv)
+        dl = lin * dinv
+        c0 = c0 - float(dl @ su_lo) + float(su_lo @ quad @ su_lo)
+        lin = dl - (quad + quad.T) @ su_lo
+        if mu_b is not None:
+            mu_b = su_lo + su_diff * mu_b
+            hess_b = hess_b * np.outer(dinv, dinv)
+        su_lo = su_diff = None
+    if su_lo is not None:
+        ds.su_lo = f64(su_lo, (d,))
+        ds.su_diff = f64(su_diff, (d,))
     ds.c0 = c0
     ds.lin = f64(lin)
     if has['quadratic']:
@@ -181,8 +210,8 @@ def density_desc_from_spec(spec):
     all_linear = not (has['quadratic'] or has['cubic-2'] or has['cubic-3'])
     if poly.get('use_bound', False) and not all_linear:
         ds.use_bound = 1
-        ds.mu = f64(poly['mu'], (d,))
-        ds.hess = f64(poly['hess'], (d, d))
+        ds.mu = f64(mu_b, (d,))
+        ds.hess = f64(hess_b, (d, d))
         ds.alpha = float(poly['alpha'])
         ds.f_mu = float(np.asarray(poly['f_mu']).reshape(-1)[0])
     if spec.get('use_decay', False):

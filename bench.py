@@ -127,6 +127,41 @@ def hetero_rate(ctx, d, C, seed, iters, steps=3, layout='auto'):
                         '(adapt_metric off), target_accept 0.9, %d x %d post-adaptation iterations' % (C, d, steps, iters)}
 
 
+def scaled_inputs_rate(ctx, d, C, seed, iters, steps=3):
+    """Secondary figure: the headline surrogate WITH Surrogate.input_scales (module.py:190-226), as every surrogate of the reference's
+    recipes has them: x = lo + diff x_s, the polynomial in x_s.  The scaling is folded into the coefficients and the bound at upload
+    (device.density_desc_from_spec), so the launch runs on the same kernels as the headline; the bound's ellipsoid is no longer
+    aligned with the proof's sphere, so more trips run its tiles.  Post-adaptation launches, HIP events."""
+    import torch
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    rng = np.random.default_rng(seed + 5)
+    lo, diff = rng.normal(size=d), rng.uniform(0.5, 3., size=d)
+    spec, _ = correlated_gaussian_spec(d)
+    spec = dict(spec, su_lo=lo, su_diff=diff)
+    ch = DeviceChains(DeviceDensity(spec, ctx), lo + diff * rng.normal(size=(C, d)), seed=seed + 5)
+    kw = dict(n_warmup=N_ADAPT, check=False)
+    ch.run(N_ADAPT, 'NUTS', **kw)
+    ch.run(iters, 'NUTS', **kw)
+    ch.raise_on_error()
+    lf0 = ch.total_leapfrog
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(ctx.stream)
+    for _ in range(steps):
+        s, st = ch.run(iters, 'NUTS', **kw)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    ch.raise_on_error()
+    kname = _lib.lib().bfhip_debug_last_kernel
+    kname.restype = __import__('ctypes').c_char_p
+    return {'value': (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), 'unit': 'leapfrog steps/sec', 'chains': C, 'dim': d,
+            'mean_tree_size': float(st[:, :, _lib.NSTATS.index('tree_size')].mean().item()), 'kernel': kname().decode(),
+            'note': 'the headline surrogate behind input scales (lo + diff x_s), folded into its coefficients at upload'}
+
+
 def other_samplers(ctx, d, cov, C, seed):
     """Secondary figures: the two samplers of the path that are not the default -- NUTS with the full-rank metric
     (QuadMetricFull, metrics.py:94-132; every chain streams its own d x d covariance twice per leapfrog step) after adaptation,
@@ -790,6 +825,7 @@ def main():
             try:
                 with torch.cuda.device(ctx.device):
                     out['hetero'] = hetero_rate(ctx, d, C, a.seed, a.iters)
+                    out['scaled_inputs'] = scaled_inputs_rate(ctx, d, C, a.seed, a.iters)
                     out['refit_cycle'] = refit_cycle(d, cov, C, a.seed)
                     out.update(other_samplers(ctx, d, cov, C, a.seed))
             except Exception as ex:  # side measurements; the headline line must still print

@@ -32,7 +32,7 @@ def test_bench_single_gpu_line():
     assert 'workload' in j['config'] and 'model' not in j['config']
     assert 'extras_error' not in j, j.get('extras_error')
     assert rf['frac'] <= rf['frac_algorithmic'] and 'trees have' in j['config']['workload']
-    for k in ('hetero', 'refit_cycle', 'full_metric', 'tempered'):   # the side blocks
+    for k in ('hetero', 'scaled_inputs', 'refit_cycle', 'full_metric', 'tempered'):   # the side blocks
         assert k in j, k
     assert j['full_metric']['value'] > 0 and j['tempered']['value'] > 0 and j['refit_cycle']['total_ms'] > 0
 

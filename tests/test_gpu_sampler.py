@@ -872,3 +872,33 @@ def test_the_tail_of_a_launch_in_few_chain_workgroups_never_changes_results(ctx,
     ts = out[1][1][:, :, _lib.NSTATS.index('tree_size')].sum(1)
     assert ts[::19].min() > 3 * np.delete(ts, np.arange(0, 150, 19)).max()   # (the stragglers are stragglers)
     assert 1 <= listed[1] <= 8, listed   # (... and the second part ran them: 8 of the 150 chains)
+
+
+def test_surrogate_with_input_scales_runs_on_the_fused_fast_kernels_and_matches_the_oracle(ctx):
+    """A linear + quadratic surrogate WITH Surrogate.input_scales (module.py:190-226; every surrogate of the reference's recipes
+    has them): the scaling is folded into the coefficients and the bound at upload (device.density_desc_from_spec), so NUTS runs
+    on the pipelined / split / group kernels instead of the sliced kernel's generic instantiation -- and equals the oracle, which
+    scales the input as the reference does: logp and gradient inside and outside the bound to 1e-10, trajectories, on every layout."""
+    from oracle import oracle as orc
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = 64
+    rng = np.random.default_rng(31)
+    lo, diff = rng.normal(size=d), rng.uniform(0.5, 3., size=d)
+    spec, _ = correlated_gaussian_spec(d)     # a surrogate in ITS input space; the density's input is x = lo + diff x_s
+    spec = dict(spec, su_lo=lo, su_diff=diff)
+    dens = DeviceDensity(spec, ctx)
+    x = lo + diff * rng.normal(size=(40, d)) * np.where(np.arange(40)[:, None] < 20, 1., 6.)   # (half of them outside the bound)
+    lp, g = [np.asarray(t.cpu()) if hasattr(t, 'cpu') else np.asarray(t) for t in dens.logp_and_grad(x)]
+    lp0, g0 = orc.logp_and_grad(spec, x)
+    np.testing.assert_allclose(lp, lp0, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(g, g0, rtol=1e-10, atol=1e-9)
+    assert (lp0[20:] < lp0[:20].min()).all()   # (the second half is far out)
+    x0 = lo + diff * rng.normal(size=(6, d))
+    dev = _device_chains(ctx, spec, x0, 14, 9)
+    orc_runs = _oracle_chains(spec, x0, 14, 9)
+    _compare_nuts(dev, orc_runs, 14, n_head=6, tol_head=1e-8)
+    kname = _lib.lib().bfhip_debug_last_kernel
+    kname.restype = __import__('ctypes').c_char_p
+    assert not kname().decode().startswith('bf_sampler_kernel'), kname().decode()

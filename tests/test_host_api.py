@@ -402,3 +402,46 @@ def test_layout_rules_are_functions_of_the_shapes_only():
     assert stub(16, 4096)._lanes_whatever_the_trees() and stub(32, 8192)._lanes_whatever_the_trees()
     assert not stub(32, 2048)._lanes_whatever_the_trees() and not stub(64, 4096)._lanes_whatever_the_trees()
     assert not stub(16, 4096, dec)._lanes_whatever_the_trees()
+
+
+def test_input_scales_fold_into_a_quadratic_surrogate_and_its_bound():
+    """device.density_desc_from_spec folds Surrogate.input_scales (module.py:190-226) into a linear + quadratic surrogate's
+    coefficients and its bound's centre and Hessian: the folded polynomial at x equals the scaled one at (x - lo) / diff, the
+    bound's radius is the same number, gradients differ by the factor 1 / diff -- and cubic configs keep the scaling."""
+    from bayesfast_amd.device import density_desc_from_spec
+    rng = np.random.default_rng(4)
+    d = 7
+    lo, diff = rng.normal(size=d), rng.uniform(0.3, 4., size=d)
+    im = np.arange(d)
+    cl, cq = rng.normal(size=(1, d + 1)), rng.normal(size=(1, d, d))
+    mu, hh = rng.normal(size=d) * 0.2, rng.normal(size=(d, d))
+    hess = hh @ hh.T + d * np.eye(d)
+    poly = dict(input_size=d, output_size=1, use_bound=True, mu=mu, hess=hess, alpha=3., f_mu=np.array([0.7]),
+                configs=[dict(order='linear', input_mask=im, output_mask=np.arange(1), coef=cl),
+                         dict(order='quadratic', input_mask=im, output_mask=np.arange(1), coef=cq)])
+    spec = dict(d=d, ranges=None, hard_bounds=None, su_lo=lo, su_diff=diff, poly=poly, use_decay=False)
+    ds, keep = density_desc_from_spec(spec)
+    assert not ds.su_lo and not ds.su_diff
+    arr = lambda p, n: np.ctypeslib.as_array(p, shape=(n,)).copy()
+    lin, quad = arr(ds.lin, d), arr(ds.quad, d * d).reshape(d, d)
+    mu2, h2 = arr(ds.mu, d), arr(ds.hess, d * d).reshape(d, d)
+    iu = np.triu_indices(d)
+    A = np.zeros((d, d))
+    A[iu] = cq[0][iu]
+    for x in rng.normal(size=(5, d)) * 3.:
+        xs = (x - lo) / diff
+        f_ref = cl[0, 0] + cl[0, 1:] @ xs + xs @ A @ xs
+        f_fold = ds.c0 + lin @ x + x @ np.triu(quad) @ x
+        assert abs(f_fold - f_ref) < 1e-11 * (1. + abs(f_ref))
+        g_ref = (cl[0, 1:] + (A + A.T) @ xs) / diff
+        g_fold = lin + (np.triu(quad) + np.triu(quad).T) @ x
+        np.testing.assert_allclose(g_fold, g_ref, rtol=1e-11, atol=1e-11)
+        b_ref = (xs - mu) @ hess @ (xs - mu)
+        b_fold = (x - mu2) @ h2 @ (x - mu2)
+        assert abs(b_fold - b_ref) < 1e-11 * (1. + abs(b_ref))
+    assert ds.alpha == 3. and ds.f_mu == 0.7
+    # cubic configs: the scaling stays a device-side step
+    poly3 = dict(poly, configs=poly['configs'] + [dict(order='cubic-2', input_mask=im, output_mask=np.arange(1), coef=rng.normal(size=(1, d, d)))])
+    ds3, keep3 = density_desc_from_spec(dict(spec, poly=poly3))
+    assert bool(ds3.su_lo) and bool(ds3.su_diff)
+    np.testing.assert_array_equal(arr(ds3.mu, d), mu)
