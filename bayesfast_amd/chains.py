@@ -192,7 +192,9 @@ class DeviceChains:
             self._n_cu = int(_torch().cuda.get_device_properties(self.ctx.device).multi_processor_count)
         sp = self.density.spec
         # (input scaling of a linear + quadratic surrogate is folded into its coefficients at upload: device.density_desc_from_spec)
-        common = (sp.get('link') is None and sp.get('chi2') is None and bool(sp['poly'].get('use_bound')) and
+        from .device import folds_input_scales
+        common = ((sp.get('su_lo') is None or folds_input_scales(sp)) and sp.get('link') is None and sp.get('chi2') is None and
+                  bool(sp['poly'].get('use_bound')) and
                   sorted(c['order'] for c in sp['poly']['configs']) == ['linear', 'quadratic'] and not self.full_metric)
         dec, tr = bool(sp.get('use_decay')), sp.get('ranges') is not None
         n = self.n_chain if self.n_chain_rule is None else self.n_chain_rule

@@ -104,6 +104,18 @@ def _ptr(t):
 
 # tuning / test switch: fold Surrogate.input_scales into linear + quadratic surrogates at upload (density_desc_from_spec)
 FOLD_INPUT_SCALES = __import__('os').environ.get('BFHIP_NO_SU_FOLD', '') in ('', '0')
+FOLD_MAX_OFFSET = 30.
+
+
+def folds_input_scales(spec):
+    """Whether density_desc_from_spec folds the spec's Surrogate.input_scales into the polynomial (see there): a linear +
+    quadratic surrogate whose range lies within FOLD_MAX_OFFSET widths of the origin."""
+    if spec.get('su_lo') is None or not FOLD_INPUT_SCALES:
+        return False
+    if any(cf['order'] in ('cubic-2', 'cubic-3') for cf in spec['poly']['configs']):
+        return False
+    lo, diff = np.asarray(spec['su_lo'], dtype=np.float64), np.asarray(spec['su_diff'], dtype=np.float64)
+    return bool(float(np.max(np.abs(lo) / np.abs(diff))) <= FOLD_MAX_OFFSET)
 
 
 def density_desc_from_spec(spec):
@@ -178,7 +190,7 @@ def density_desc_from_spec(spec):
     mu_b = hess_b = None
     if poly.get('use_bound', False):
         mu_b, hess_b = np.asarray(poly['mu'], dtype=np.float64).reshape(d), np.asarray(poly['hess'], dtype=np.float64).reshape(d, d)
-    if su_lo is not None and not (has['cubic-2'] or has['cubic-3']) and FOLD_INPUT_SCALES:
+    if su_lo is not None and folds_input_scales(spec):
         # Surrogate.input_scales (module.py:190-226: x_s = (x - lo) / diff before the polynomial, the gradient divided by diff
         # after it) folded into a linear + quadratic polynomial's coefficients and its bound: with D = diag(1 / diff),
         #   c0 + l . x_s + x_s^T A x_s = c0' + l' . x + x^T A' x,   A' = D A D,  l' = D l - (A' + A'^T) lo,
@@ -186,7 +198,9 @@ def density_desc_from_spec(spec):
         # -- the same function of x (the bound's radius, the extrapolation outside it and the gradient with it: every term of
         # modules/poly.py:480-503 is D times its scaled-space form), equal to rounding.  The device then sees a surrogate
         # WITHOUT input scaling, which every fused sampler kernel takes (with it, only the generic instantiation of the sliced
-        # kernel does).  Cubic configs keep the scaling as a device-side step.
+        # kernel does).  Cubic configs keep the scaling as a device-side step, and so does a range that lies far from the origin
+        # in units of its own width (|lo| / diff > FOLD_MAX_OFFSET): the folded polynomial is the scaled one expanded around
+        # x = 0, and its terms are (1 + |lo| / diff)^2 times the size of their sum -- 1e3 at the limit, i.e. 1e-13 relative.
         dinv = 1. / su_diff
         quad = quad * np.outer(dinv, dinv)
         dl = lin * dinv

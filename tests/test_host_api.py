@@ -445,3 +445,6 @@ def test_input_scales_fold_into_a_quadratic_surrogate_and_its_bound():
     ds3, keep3 = density_desc_from_spec(dict(spec, poly=poly3))
     assert bool(ds3.su_lo) and bool(ds3.su_diff)
     np.testing.assert_array_equal(arr(ds3.mu, d), mu)
+    # ... and so does a range far from the origin in units of its width (cancellation in the folded form)
+    ds4, keep4 = density_desc_from_spec(dict(spec, su_lo=lo + 1000.))
+    assert bool(ds4.su_lo) and bool(ds4.su_diff)
