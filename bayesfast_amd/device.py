@@ -105,6 +105,7 @@ def _ptr(t):
 # tuning / test switch: fold Surrogate.input_scales into linear + quadratic surrogates at upload (density_desc_from_spec)
 FOLD_INPUT_SCALES = __import__('os').environ.get('BFHIP_NO_SU_FOLD', '') in ('', '0')
 FOLD_MAX_OFFSET = 30.
+FOLD_MAX_OFFSET_CUBIC = 10.   # (cubic terms: (1 + |lo| / diff)^3)
 
 
 def folds_input_scales(spec):
@@ -112,10 +113,9 @@ def folds_input_scales(spec):
     quadratic surrogate whose range lies within FOLD_MAX_OFFSET widths of the origin."""
     if spec.get('su_lo') is None or not FOLD_INPUT_SCALES:
         return False
-    if any(cf['order'] in ('cubic-2', 'cubic-3') for cf in spec['poly']['configs']):
-        return False
+    cubic = any(cf['order'] in ('cubic-2', 'cubic-3') for cf in spec['poly']['configs'])
     lo, diff = np.asarray(spec['su_lo'], dtype=np.float64), np.asarray(spec['su_diff'], dtype=np.float64)
-    return bool(float(np.max(np.abs(lo) / np.abs(diff))) <= FOLD_MAX_OFFSET)
+    return bool(float(np.max(np.abs(lo) / np.abs(diff))) <= (FOLD_MAX_OFFSET_CUBIC if cubic else FOLD_MAX_OFFSET))
 
 
 def density_desc_from_spec(spec):
@@ -198,14 +198,35 @@ def density_desc_from_spec(spec):
         # -- the same function of x (the bound's radius, the extrapolation outside it and the gradient with it: every term of
         # modules/poly.py:480-503 is D times its scaled-space form), equal to rounding.  The device then sees a surrogate
         # WITHOUT input scaling, which every fused sampler kernel takes (with it, only the generic instantiation of the sliced
-        # kernel does).  Cubic configs keep the scaling as a device-side step, and so does a range that lies far from the origin
-        # in units of its own width (|lo| / diff > FOLD_MAX_OFFSET): the folded polynomial is the scaled one expanded around
-        # x = 0, and its terms are (1 + |lo| / diff)^2 times the size of their sum -- 1e3 at the limit, i.e. 1e-13 relative.
+        # kernel does).  A range that lies far from the origin in units of its own width (|lo| / diff > FOLD_MAX_OFFSET) keeps the
+        # scaling as a device-side step: the folded polynomial is the scaled one expanded around x = 0, and its terms are
+        # (1 + |lo| / diff)^2 (cubic configs: ^3, with a tighter limit) times the size of their sum -- 1e3 at the limit, i.e. 1e-13 relative.
         dinv = 1. / su_diff
-        quad = quad * np.outer(dinv, dinv)
-        dl = lin * dinv
-        c0 = c0 - float(dl @ su_lo) + float(su_lo @ quad @ su_lo)
-        lin = dl - (quad + quad.T) @ su_lo
+        if has['cubic-2'] or has['cubic-3']:
+            # with cubic configs: the third-order Taylor expansion of p(D (x - lo)) around x = 0 (exact: p is a cubic).  Value,
+            # gradient and Hessian of p at a = -D lo in the scaled space; the third derivatives do not depend on the shift.
+            a = -su_lo * dinv
+            c3 = cubic3 if cubic3 is not None else np.zeros((d, d, d))
+            s3 = sum(np.transpose(c3, pm) for pm in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)))
+            qs = quad + quad.T
+            c2a = cubic2 @ a
+            p_a = c0 + float(lin @ a) + float(a @ quad @ a) + float((a * a) @ c2a) + float(np.einsum('jkl,j,k,l->', c3, a, a, a))
+            g_a = lin + qs @ a + 2. * a * c2a + cubic2.T @ (a * a) + 0.5 * np.einsum('ikl,k,l->i', s3, a, a)
+            m1 = 2. * a[:, None] * cubic2
+            h_a = qs + 2. * np.diag(c2a) + m1 + m1.T + np.einsum('iml,l->im', s3, a)
+            c0 = p_a
+            lin = g_a * dinv
+            hs = h_a * np.outer(dinv, dinv)
+            quad = np.triu(hs, 1) + 0.5 * np.diag(np.diag(hs))
+            cubic2 = cubic2 * np.outer(dinv * dinv, dinv)
+            if cubic3 is not None:
+                cubic3 = cubic3 * dinv[:, None, None] * dinv[None, :, None] * dinv[None, None, :]
+            has['quadratic'] = True   # (the shift makes quadratic terms of cubic ones)
+        else:
+            quad = quad * np.outer(dinv, dinv)
+            dl = lin * dinv
+            c0 = c0 - float(dl @ su_lo) + float(su_lo @ quad @ su_lo)
+            lin = dl - (quad + quad.T) @ su_lo
         if mu_b is not None:
             mu_b = su_lo + su_diff * mu_b
             hess_b = hess_b * np.outer(dinv, dinv)

@@ -902,3 +902,26 @@ def test_surrogate_with_input_scales_runs_on_the_fused_fast_kernels_and_matches_
     kname = _lib.lib().bfhip_debug_last_kernel
     kname.restype = __import__('ctypes').c_char_p
     assert not kname().decode().startswith('bf_sampler_kernel'), kname().decode()
+
+
+def test_cubic_surrogate_with_input_scales_is_folded_too(ctx):
+    """Cubic configs behind Surrogate.input_scales: the third-order expansion around x = 0 (device.density_desc_from_spec) against the
+    oracle's scaled evaluation -- logp and gradient to 1e-9, NUTS trajectories -- at d = 24 (sliced kernel) with ragged masks."""
+    from oracle import oracle as orc
+    from bayesfast_amd.device import DeviceDensity, folds_input_scales
+    d = 24
+    rng = np.random.default_rng(33)
+    spec = _cubic_spec(d=d, seed=5, m2=np.sort(rng.choice(d, 9, replace=False)), m3=np.sort(rng.choice(d, 7, replace=False)), amp=0.15)
+    lo, diff = rng.normal(size=d) * 0.5, rng.uniform(0.7, 2., size=d)
+    spec = dict(spec, su_lo=lo, su_diff=diff)
+    assert folds_input_scales(spec)
+    dens = DeviceDensity(spec, ctx)
+    x = lo + diff * rng.normal(size=(30, d)) * 0.7
+    lp, g = [np.asarray(t.cpu()) if hasattr(t, 'cpu') else np.asarray(t) for t in dens.logp_and_grad(x)]
+    lp0, g0 = orc.logp_and_grad(spec, x)
+    np.testing.assert_allclose(lp, lp0, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(g, g0, rtol=1e-9, atol=1e-9)
+    x0 = lo + diff * rng.normal(size=(5, d)) * 0.5
+    dev = _device_chains(ctx, spec, x0, 12, 8)
+    orc_runs = _oracle_chains(spec, x0, 12, 8)
+    _compare_nuts(dev, orc_runs, 12, n_head=6, tol_head=1e-7, rtol_q=1e-4)

@@ -440,11 +440,33 @@ def test_input_scales_fold_into_a_quadratic_surrogate_and_its_bound():
         b_fold = (x - mu2) @ h2 @ (x - mu2)
         assert abs(b_fold - b_ref) < 1e-11 * (1. + abs(b_ref))
     assert ds.alpha == 3. and ds.f_mu == 0.7
-    # cubic configs: the scaling stays a device-side step
-    poly3 = dict(poly, configs=poly['configs'] + [dict(order='cubic-2', input_mask=im, output_mask=np.arange(1), coef=rng.normal(size=(1, d, d)))])
+    # cubic configs: the third-order expansion around x = 0
+    c2, c3 = rng.normal(size=(1, d, d)), rng.normal(size=(1, d, d, d))
+    poly3 = dict(poly, configs=poly['configs'] + [dict(order='cubic-2', input_mask=im, output_mask=np.arange(1), coef=c2),
+                                                  dict(order='cubic-3', input_mask=im, output_mask=np.arange(1), coef=c3)])
     ds3, keep3 = density_desc_from_spec(dict(spec, poly=poly3))
-    assert bool(ds3.su_lo) and bool(ds3.su_diff)
-    np.testing.assert_array_equal(arr(ds3.mu, d), mu)
+    assert not ds3.su_lo and not ds3.su_diff
+    lin3, quad3 = arr(ds3.lin, d), arr(ds3.quad, d * d).reshape(d, d)
+    q2, q3 = arr(ds3.cubic2, d * d).reshape(d, d), arr(ds3.cubic3, d**3).reshape(d, d, d)
+    j, k, l = np.meshgrid(np.arange(d), np.arange(d), np.arange(d), indexing='ij')
+    t3 = np.where((j < k) & (k < l), c3[0], 0.)
+
+    def cubic_poly(c0_, l_, q_, c2_, c3_, z):   # the reference's conventions (modules/_poly.pyx:13-137)
+        return c0_ + l_ @ z + z @ np.triu(q_) @ z + (z * z) @ (c2_ @ z) + np.einsum('jkl,j,k,l->', c3_, z, z, z)
+
+    for x in rng.normal(size=(5, d)) * 2.:
+        xs = (x - lo) / diff
+        f_ref = cubic_poly(cl[0, 0], cl[0, 1:], A, c2[0], t3, xs)
+        f_fold = cubic_poly(ds3.c0, lin3, quad3, q2, q3, x)
+        assert abs(f_fold - f_ref) < 1e-10 * (1. + abs(f_ref)), (f_fold, f_ref)
+        h = 1e-6   # (the gradient by differences of the folded form against differences of the scaled one)
+        for i in (0, d - 1):
+            e = np.zeros(d)
+            e[i] = h
+            gf = (cubic_poly(ds3.c0, lin3, quad3, q2, q3, x + e) - cubic_poly(ds3.c0, lin3, quad3, q2, q3, x - e)) / (2 * h)
+            gr = (cubic_poly(cl[0, 0], cl[0, 1:], A, c2[0], t3, (x + e - lo) / diff) - cubic_poly(cl[0, 0], cl[0, 1:], A, c2[0], t3, (x - e - lo) / diff)) / (2 * h)
+            assert abs(gf - gr) < 1e-5 * (1. + abs(gr))
+    np.testing.assert_allclose(arr(ds3.mu, d), lo + diff * mu)
     # ... and so does a range far from the origin in units of its width (cancellation in the folded form)
     ds4, keep4 = density_desc_from_spec(dict(spec, su_lo=lo + 1000.))
     assert bool(ds4.su_lo) and bool(ds4.su_diff)
