@@ -140,7 +140,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         afH[s] = m.Hf[(j * NS + s) * 64 + lane];
         if constexpr (DEC) afD[s] = m.Hdf[(j * NS + s) * 64 + lane];
     }
-    double c_lin[4], c_mu[4], c_smu[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1];
+    double c_lin[4], c_mu[4], c_smu[4], c_hd[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1];
     int c_kind[TR ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -148,6 +148,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         c_lin[r] = m.pd[PD_LIN * DP + dim];
         c_mu[r] = m.pd[PD_MU * DP + dim];
         c_smu[r] = m.pd[PD_SMU * DP + dim];
+        c_hd[r] = m.pd[PD_HD * DP + dim];
         if constexpr (TR) {
             c_kind[r] = (int)m.pd[PD_KIND * DP + dim];
             c_lo[r] = m.pd[PD_LO * DP + dim];
@@ -424,7 +425,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
             if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
         }
-        // Bound proof.  (x - mu)^T H (x - mu) <= lam_max(H) |x - mu|^2: when that is below alpha^2 for every chain of the
+        // Bound proof.  (x - mu)^T H (x - mu) <= lam_max sum_j hd_j (x_j - mu_j)^2: when that is below alpha^2 for every chain of the
         // group the test of modules/poly.py:467-469 is decided (inside) without the H (x - mu) tiles -- half of the trip's
         // MFMAs.  The partial |x - mu|^2 rides through the barrier the operands need anyway; the outcome is the one the
         // full computation has (margin 1e-9 against its rounding), so results do not depend on whether a group skips.
@@ -433,7 +434,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double xm = xs[r] - c_mu[r];
-                t_r2[r] = ev ? xm * xm : 0.;
+                t_r2[r] = ev ? c_hd[r] * (xm * xm) : 0.;   // (the proof's weighted norm: bf_bound_lam_max_weighted)
             }
             double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
             if (gq == 0) PB[j * 16 + c] = r2p;

@@ -28,6 +28,7 @@ enum {
     PD_MU,        // bound centre
     PD_DMU,       // decay centre
     PD_SMU,       // S mu (S = A + A^T, mu the bound centre)
+    PD_HD,        // the weights of the bound proof's norm: the diagonal of the bound's Hessian (bf_bound_lam_max_weighted), or ones
     PD_N
 };
 
@@ -67,7 +68,8 @@ struct DevModel {
     int has_link;       // the surrogate's output m feeds a Gaussian likelihood: logp = link_logp0 - link_prec (m - link_y)^2 / 2
     double link_y, link_prec, link_logp0;
     double lam_max_d;   // the same for the decay Hessian
-    double lam_max;     // a proven upper bound of the largest eigenvalue of (H + H^T) / 2 (bf_bound_lam_max), 0 without a bound
+    double lam_max;     // the bound proof's constant: (x - mu)^T H (x - mu) <= lam_max sum_j hd_j (x_j - mu_j)^2 for every x, hd = the
+                        // table row PD_HD (bf_bound_lam_max_weighted); 0 without a bound
     // cubic terms in compact (masked) form; pos2/pos3 map a dimension to its index in the mask or -1
     int n2, n3;
     const int *mask2, *pos2, *mask3, *pos3;  // mask: [n], pos: [DP]

@@ -32,6 +32,13 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
     for (int i = 0; i < DP; ++i) {
         pd[PD_RG * DP + i] = 1.;
         pd[PD_SU_DIFF * DP + i] = 1.;
+        pd[PD_HD * DP + i] = 1.;
+    }
+    if (ds->use_bound) {   // the weights of the bound proof's norm (bf_bound_lam_max_weighted)
+        bool ok = true;
+        for (int i = 0; i < d; ++i) ok = ok && ds->hess[(size_t)i * d + i] > 0. && std::isfinite(ds->hess[(size_t)i * d + i]);
+        if (ok)
+            for (int i = 0; i < d; ++i) pd[PD_HD * DP + i] = ds->hess[(size_t)i * d + i];
     }
     for (int i = 0; i < d; ++i) {
         if (ds->ranges) {
@@ -144,6 +151,18 @@ static inline double bf_bound_lam_max(const double *hess, int d) {
         if (ok) return c * (1. + 1e-9);
     }
     return gersh * (1. + 1e-9);
+}
+
+// The bound proof with a weighted norm: (x - mu)^T H (x - mu) = y^T N y <= lam_max(N) |y|^2 with y_j = sqrt(hd_j) (x_j - mu_j) and
+// N = diag(hd)^-1/2 sym(H) diag(hd)^-1/2, hd > 0 (bf_pack_density takes the diagonal of H, or ones).  For a Hessian that is a
+// well-conditioned matrix seen through per-dimension scales -- the bound of a surrogate whose input scales were folded in, any bound
+// fitted in parameters of different units -- lam_max(N) |y|^2 is as tight as the plain norm is for the unscaled matrix, where
+// lam_max(H) |x - mu|^2 overshoots by the square of the scales' spread.  Returns the proven constant for the weights hd (d of them).
+static inline double bf_bound_lam_max_weighted(const double *hess, int d, const double *hd) {
+    std::vector<double> N((size_t)d * d);
+    for (int i = 0; i < d; ++i)
+        for (int k = 0; k < d; ++k) N[(size_t)i * d + k] = hess[(size_t)i * d + k] / std::sqrt(hd[i] * hd[k]);
+    return bf_bound_lam_max(N.data(), d);
 }
 
 // stream = global chain index, so results do not depend on how chains are sharded over GPUs

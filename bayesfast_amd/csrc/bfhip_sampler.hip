@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const double xm = xs[e] - c_mu[e];
-                    r2 += (lane * E + e < d) ? xm * xm : 0.;
+                    r2 += (lane * E + e < d) ? pdl(PD_HD, e) * (xm * xm) : 0.;   // (the proof's weighted norm: bf_bound_lam_max_weighted)
                 }
                 r2 = wave_sum(r2);
                 const bool inside = mode != M_OOB && g_sliced_proof_on(a) && m.lam_max * r2 < m.alpha * m.alpha * (1. - 1e-9);

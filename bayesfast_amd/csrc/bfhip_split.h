@@ -175,13 +175,14 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             afS[s] = m.Sf[(j * NS + s) * 64 + lane];
             afH[s] = m.Hf[(j * NS + s) * 64 + lane];
         }
-        double c_lin[4], c_mu[4], c_smu[4], q[4], p[4], g[4], var[4];
+        double c_lin[4], c_mu[4], c_smu[4], c_hd[4], q[4], p[4], g[4], var[4];
         double L0p[4], PSUM[4], pdbl[4];   // the waiting leaf's momentum, the tree's p_sum, the momentum this doubling started from
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             c_lin[r] = m.pd[PD_LIN * DP + dbase + 4 * r];
             c_mu[r] = m.pd[PD_MU * DP + dbase + 4 * r];
             c_smu[r] = m.pd[PD_SMU * DP + dbase + 4 * r];
+            c_hd[r] = m.pd[PD_HD * DP + dbase + 4 * r];
             q[r] = p[r] = g[r] = L0p[r] = PSUM[r] = pdbl[r] = 0.;
             var[r] = 1.;
         }
@@ -305,7 +306,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     XB[(0 * NS + 4 * j + r) * 64 + lane] = xs[r];
                     const double xm = xs[r] - c_mu[r];
                     XB[(1 * NS + 4 * j + r) * 64 + lane] = xm;
-                    t_r2[r] = ev ? xm * xm : 0.;
+                    t_r2[r] = ev ? c_hd[r] * (xm * xm) : 0.;   // (the proof's weighted norm: bf_bound_lam_max_weighted)
                 }
                 double r2p = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
                 if (gq == 0) PB[j * 16 + c] = r2p;
