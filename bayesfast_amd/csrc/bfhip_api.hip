@@ -104,7 +104,7 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     m.c0 = ds->c0;
     m.alpha = ds->alpha;
     m.lam_max = ds->use_bound ? bf_bound_lam_max_weighted(ds->hess, ds->d, h.data() + (size_t)PD_HD * DP) : 0.;
-    m.lam_max_d = ds->use_decay ? bf_bound_lam_max(ds->decay_hess, ds->d) : 0.;
+    m.lam_max_d = ds->use_decay ? bf_bound_lam_max_weighted(ds->decay_hess, ds->d, h.data() + (size_t)PD_HDD * DP) : 0.;
     m.f_mu = ds->f_mu;
     m.f_poly_mu = bf_poly_at_mu(ds);
     m.inv_alpha = ds->use_bound ? 1. / ds->alpha : 0.;

@@ -140,7 +140,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         afH[s] = m.Hf[(j * NS + s) * 64 + lane];
         if constexpr (DEC) afD[s] = m.Hdf[(j * NS + s) * 64 + lane];
     }
-    double c_lin[4], c_mu[4], c_smu[4], c_hd[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1];
+    double c_lin[4], c_mu[4], c_smu[4], c_hd[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1], c_hdd[DEC ? 4 : 1];
     int c_kind[TR ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -154,7 +154,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             c_lo[r] = m.pd[PD_LO * DP + dim];
             c_rg[r] = m.pd[PD_RG * DP + dim];
         }
-        if constexpr (DEC) c_dmu[r] = m.pd[PD_DMU * DP + dim];
+        if constexpr (DEC) { c_dmu[r] = m.pd[PD_DMU * DP + dim]; c_hdd[r] = m.pd[PD_HDD * DP + dim]; }
     }
 
     // ---- per-chain state: vectors (4 elements per lane) ----
@@ -443,7 +443,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double xm = xo[r] - c_dmu[r];
-                    t_r2[r] = ev ? xm * xm : 0.;
+                    t_r2[r] = ev ? c_hdd[r] * (xm * xm) : 0.;
                 }
                 double r2d = bf_xor32_add(bf_xor16_add(sum4(t_r2)));
                 if (gq == 0) PB[(W + j) * 16 + c] = r2d;

@@ -29,6 +29,7 @@ enum {
     PD_DMU,       // decay centre
     PD_SMU,       // S mu (S = A + A^T, mu the bound centre)
     PD_HD,        // the weights of the bound proof's norm: the diagonal of the bound's Hessian (bf_bound_lam_max_weighted), or ones
+    PD_HDD,       // the same for the decay term's Hessian
     PD_N
 };
 

@@ -2,6 +2,7 @@
 // shared by bfhip_density_upload and the host emulation of the group kernel under tests/emu).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "bfhip_model.h"
 
@@ -33,12 +34,21 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
         pd[PD_RG * DP + i] = 1.;
         pd[PD_SU_DIFF * DP + i] = 1.;
         pd[PD_HD * DP + i] = 1.;
+        pd[PD_HDD * DP + i] = 1.;
     }
+    // (tuning switch: BFHIP_NO_PROOF_WEIGHTS=1 keeps the plain norm in both proofs)
+    static const bool no_weights = [] { const char *e = getenv("BFHIP_NO_PROOF_WEIGHTS"); return e && atoi(e) != 0; }();
     if (ds->use_bound) {   // the weights of the bound proof's norm (bf_bound_lam_max_weighted)
-        bool ok = true;
+        bool ok = !no_weights;
         for (int i = 0; i < d; ++i) ok = ok && ds->hess[(size_t)i * d + i] > 0. && std::isfinite(ds->hess[(size_t)i * d + i]);
         if (ok)
             for (int i = 0; i < d; ++i) pd[PD_HD * DP + i] = ds->hess[(size_t)i * d + i];
+    }
+    if (ds->use_decay) {
+        bool ok = !no_weights;
+        for (int i = 0; i < d; ++i) ok = ok && ds->decay_hess[(size_t)i * d + i] > 0. && std::isfinite(ds->decay_hess[(size_t)i * d + i]);
+        if (ok)
+            for (int i = 0; i < d; ++i) pd[PD_HDD * DP + i] = ds->decay_hess[(size_t)i * d + i];
     }
     for (int i = 0; i < d; ++i) {
         if (ds->ranges) {

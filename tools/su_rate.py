@@ -1,5 +1,6 @@
 """Tuning: NUTS on a 64-d quadratic surrogate WITH input scales (4096 chains), folded at upload (default) or kept as a device-side
-step (BFHIP_NO_SU_FOLD=1: the sliced kernel's generic instantiation).  usage: [BFHIP_NO_SU_FOLD=1] python tools/su_rate.py"""
+step (BFHIP_NO_SU_FOLD=1: the sliced kernel's generic instantiation); DECAY=1 adds a decay term in the original space;
+BFHIP_NO_PROOF_WEIGHTS=1 keeps the plain norm in the bound / decay proofs.  usage: [BFHIP_NO_SU_FOLD=1] [DECAY=1] python tools/su_rate.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,6 +14,11 @@ rng = np.random.default_rng(31)
 lo, diff = rng.normal(size=d), rng.uniform(0.5, 3., size=d)
 spec, _ = correlated_gaussian_spec(d)
 spec = dict(spec, su_lo=lo, su_diff=diff)
+if os.environ.get('DECAY'):   # a decay term (original space, as Density._set_decay makes it) around the same ellipsoid, never active
+    po = spec['poly']
+    dinv = 1. / diff
+    spec = dict(spec, use_decay=True, decay_mu=lo + diff * po['mu'], decay_hess=po['hess'] * np.outer(dinv, dinv),
+                decay_alpha2=(1.5 * po['alpha'])**2, decay_gamma=0.1)
 ch = DeviceChains(DeviceDensity(spec, ctx), lo + diff * rng.normal(size=(C, d)), seed=3)
 kw = dict(n_warmup=750, check=False)
 ch.run(750, 'NUTS', **kw)
