@@ -1605,6 +1605,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #define TRACE(k) do { if (w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
 #endif
 #include "bfhip_nuts_pipe.h"
+#include "bfhip_lone.h"
 
 static int g_tail_max = 4;  // tuning / test hook: 0 disables the VALU matvec of the plain kernel
 extern "C" void bfhip_debug_tail_max(int v) { g_tail_max = v; }
@@ -1719,6 +1720,60 @@ __global__ void bf_tail_list_kernel(int n_chain, int iter_end, const double *sc,
     if ((int)scp[BFHIP_SC_I_ITER] < iter_end && (int)scp[BFHIP_SC_ERROR] == 0) buf[2 + atomicAdd(buf, 1)] = i;   // buf: count | done | list
 }
 
+// measurement hook (not part of include/bfhip.h): the kernel the last bfhip_sampler_run dispatched to
+static char g_last_kernel[96] = "";
+extern "C" const char *bfhip_debug_last_kernel(void) { return g_last_kernel; }
+
+// The latency kernel (bfhip_lone.h): one chain per workgroup of 2 + W waves.  It serves the second part of a two-part launch
+// (the chains listed in tail_buf) and whole launches whose chains all fit the chip at once -- every workgroup must be resident,
+// a chain that waited for a slot would double the launch.  g_lone: 1 automatic, 0 never, 2 wherever it is implemented
+// (tests: any chain count, in as many rounds as it takes).
+static int g_lone = [] { const char *e = getenv("BFHIP_LONE"); return e ? atoi(e) : 1; }();
+extern "C" void bfhip_debug_lone(int v) { g_lone = v; }
+
+static unsigned long long *g_stamps_lone = NULL;   // tuning builds (-DBF_LTRACE): cycle stamps of workgroup 0's integrator and bookkeeper
+extern "C" void bfhip_debug_stamps_lone(unsigned long long *buf) { g_stamps_lone = buf; }
+
+// the second instantiation's waves per SIMD: 4 (W + 1) waves a CU at d <= 32, 2 x 5 at d <= 64
+template <int W> struct LoneOcc { static constexpr int MINW = W == 1 ? 2 : 3; };   // (W = 4: two workgroups of five waves a CU)
+
+template <int W, bool TR, bool DEC>
+static int lone_blocks_per_cu(bfhip_ctx *ctx, bool roomy) {
+    const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
+    int nb = 0;
+    auto k1 = bf_lone_kernel<W, TR, DEC, 1>;
+    auto k4 = bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>;
+    const void *k = roomy ? (const void *)k1 : (const void *)k4;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, LoneWaves<W>::NW * 64, lds) != hipSuccess) return 0;
+    return nb;
+}
+
+// returns 1 when the launch was taken, 0 when the caller should use the pipelined kernel, < 0 on error
+template <int W, bool TR, bool DEC>
+static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks, bool tail) {
+    if (!g_lone || args_in.stamps) return 0;
+    SamplerArgs args = args_in;
+    args.n_cu = ctx->n_cu;
+    args.tail_stop = 0;
+    args.tail_done = NULL;
+    if (!tail) { args.tail_list = NULL; args.tail_count = NULL; }
+    args.stamps = g_stamps_lone;
+    const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
+    // the roomy instantiation when every workgroup still fits, the tighter one otherwise
+    const int need = (n_blocks + ctx->n_cu - 1) / ctx->n_cu;
+    bool roomy = true;
+    if (lone_blocks_per_cu<W, TR, DEC>(ctx, true) < need) {
+        roomy = false;
+        if (lone_blocks_per_cu<W, TR, DEC>(ctx, false) < need && g_lone != 2 && !tail) return 0;
+    }
+    if (roomy) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1>), dim3(n_blocks), dim3(LoneWaves<W>::NW * 64), lds, ctx->stream, ctx->model, args);
+    else hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>), dim3(n_blocks), dim3(LoneWaves<W>::NW * 64), lds, ctx->stream, ctx->model, args);
+    BF_HIP_CHECK(hipGetLastError());
+    if (!tail) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", roomy ? 1 : LoneOcc<W>::MINW);
+    return 1;
+}
+
 template <int W, bool TR = false, bool DEC = false>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
@@ -1732,6 +1787,10 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     constexpr bool CANQ = true;
     auto k = (CANQ && args.cpg <= 4 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
              : ((CANQ && args.cpg <= 8 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
+    if ((args.cpg <= 4 && !g_no_quad && g_wave_cpg == 0) || g_lone == 2) {
+        const int r = launch_lone<W, TR, DEC>(ctx, args, args.n_chain, false);
+        if (r != 0) return r < 0 ? r : 0;
+    }
     const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1765,6 +1824,11 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
         a2.tail_list = ctx->tail_buf + 2;
         a2.tail_done = NULL;
         a2.cpg = 4;
+        {   // the stragglers one per workgroup in the latency kernel (at most tail_stop chains of every first-part workgroup are listed)
+            const int most = args.n_chain < g_tail_stop * groups ? args.n_chain : g_tail_stop * groups;
+            const int r = launch_lone<W, TR, DEC>(ctx, a2, most, true);
+            if (r != 0) return r < 0 ? r : 0;
+        }
         // (at most four chains of every first-part workgroup are listed: groups workgroups of four chains, or one chain per CU)
         const int groups2 = groups > ctx->n_cu ? groups : ctx->n_cu;
         hipLaunchKernelGGL(k2, dim3(groups2), dim3(1024), lds, ctx->stream, ctx->model, a2);
@@ -1778,9 +1842,6 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
 static bool g_no_group = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && (!strcmp(e, "sliced") || !strcmp(e, "pipe")); }();
 extern "C" void bfhip_debug_no_group(int v) { g_no_group = v != 0; }
 
-// measurement hook (not part of include/bfhip.h): the kernel the last bfhip_sampler_run dispatched to
-static char g_last_kernel[96] = "";
-extern "C" const char *bfhip_debug_last_kernel(void) { return g_last_kernel; }
 
 static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases

@@ -312,6 +312,58 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
         assert ts.max() >= 15 and ts.min() <= 3   # warm-up went through long and short trees
 
 
+@pytest.mark.parametrize('case', ['balanced', 'leaky_bound', 'depth_limit', 'divergent', 'd40', 'd32', 'd10', 'bounded', 'bounded20', 'decay', 'decay_out', 'decay32', 'decay10'])
+def test_lone_kernel_is_bit_identical_to_pipelined_kernel(ctx, case):
+    """bf_lone_kernel (bfhip_lone.h: one chain per workgroup -- an integrator wave, a bookkeeper wave one leaf behind, W matvec
+    waves on 4 x 4 x 4 tiles, three barriers per trip) performs the pipelined kernel's arithmetic per chain in the same order:
+    samples, statistics, adapted state, random streams and the leapfrog count must agree bit for bit with bf_nuts_pipe_kernel
+    at sixteen chains per workgroup -- through warm-up (long and short trees, direction changes), outside the bound, at the
+    depth limit, with divergent first steps, ragged dimensions, behind the constraint transform and with the decay term; a
+    second launch resumes from the stored state."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    import ctypes
+    dec = case[:5] == 'decay'
+    d = int(case[1:]) if case[0] == 'd' and case[1:].isdigit() else (int(case[5:]) if dec and case[5:].isdigit() else (20 if case == 'bounded20' else 64))
+    spec, _ = correlated_gaussian_spec(d, fit_scale=0.3 if case == 'decay_out' else (1.0 if case == 'leaky_bound' else 1.5))
+    if dec:
+        po = spec['poly']
+        spec = dict(spec, use_decay=True, decay_mu=po['mu'] + 0.05, decay_hess=po['hess'],
+                    decay_alpha2=((1.5 if case == 'decay_out' else 0.8) * po['alpha'])**2, decay_gamma=0.1)
+    if case[:7] == 'bounded':
+        lo = np.full(d, -9.) + np.arange(d) * 0.01
+        spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * (d // 4), dtype=np.uint8))
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(2).normal(size=(70, d)) * (3. if case == 'divergent' else (0.3 if case[:7] == 'bounded' else 1.))
+    kw = {'depth_limit': dict(max_treedepth=2), 'divergent': dict(max_change=5.)}.get(case, {})
+    out = {}
+    L = _lib.lib()
+    try:
+        L.bfhip_debug_no_group(1)
+        for lone in (0, 2):
+            L.bfhip_debug_lone(lone)
+            L.bfhip_debug_wave_cpg(16 if lone == 0 else 0)
+            dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
+            s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw, layout='wave')
+            s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw, layout='wave')
+            out[lone] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
+            L.bfhip_debug_last_kernel.restype = ctypes.c_char_p
+            assert (b'bf_lone_kernel' in L.bfhip_debug_last_kernel()) == (lone == 2)
+    finally:
+        L.bfhip_debug_lone(1)
+        L.bfhip_debug_wave_cpg(0)
+        L.bfhip_debug_no_group(0)
+    names = ['samples', 'stats', 'samples2', 'stats2', 'sc', 'vec', 'rng']
+    for nm, a, b in zip(names, out[0][:-1], out[2][:-1]):
+        assert np.array_equal(a, b, equal_nan=True), (nm, np.argwhere(~((a == b) | ((a != a) & (b != b))))[:5])
+    assert out[0][-1] == out[2][-1]
+    ts = out[0][1][:, :, _lib.NSTATS.index('tree_size')]
+    if case == 'balanced':
+        assert ts.max() >= 15 and ts.min() <= 3
+
+
 def test_launch_cuts_do_not_change_results(ctx):
     """DeviceChains.run queues launches of launch_iters iterations; the cut must not show in any output."""
     from bayesfast_amd.device import DeviceDensity
