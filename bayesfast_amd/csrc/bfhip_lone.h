@@ -135,17 +135,18 @@ struct LoneJobs {
 // instructions.  Measured at d = 64, profiles/r05_lone_layouts.log: four job waves on four SIMDs with the bookkeeper next to the
 // integrator, 1.76 us per leapfrog step; three job waves on SIMDs 1-3 and a SIMD without jobs for integrator and bookkeeper, 1.87:
 // the bookkeeper's exponential runs 500 cycles shorter and the jobs 400 longer.)
-template <int W> struct LoneWaves {
+// (The same with the decay term, whose jobs are twelve chains of sixteen k-steps: three job waves of four chains, 1.72 against 1.67 us.)
+template <int W, bool DEC> struct LoneWaves {
     static constexpr bool ITILE = true;                   // the integrator runs jobs
-    static constexpr int NT = W;                          // waves that run jobs
+    static constexpr int NT = ITILE ? W : 3;              // waves that run jobs
     static constexpr int KW = ITILE ? NT : NT + 1;        // the bookkeeper's wave
     static constexpr int NW = KW + 1;
 };
 
 template <int W, bool TR, bool DEC, int MINW>
-__global__ __launch_bounds__(LoneWaves<W>::NW * 64, MINW) void bf_lone_kernel(DevModel m, SamplerArgs a) {
+__global__ __launch_bounds__((LoneWaves<W, DEC>::NW * 64), MINW) void bf_lone_kernel(DevModel m, SamplerArgs a) {
     using LG = LoneGeo<W, DEC>;
-    using LWV = LoneWaves<W>;
+    using LWV = LoneWaves<W, DEC>;
     constexpr int DP = LG::DP, NS = LG::NS, KS = LG::KS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XT = lds + LG::o_XT, *GB = lds + LG::o_GB, *LF = lds + LG::o_LF, *NI = lds + LG::o_NI, *VD = lds + LG::o_VD;

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 const int i_iter0 = rfl((int)scp[BFHIP_SC_I_ITER]);
                 if (4 * (a.iter_end - i_iter) >= a.iter_end - i_iter0 && 16 - rfl(alive[6]) <= a.tail_stop) {
                     const int dg = rfl(__hip_atomic_load(a.tail_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (4 * dg >= 3 * a.n_chain) go_on = false;
+                    if (4 * dg >= a.tail_q * a.n_chain) go_on = false;
                 }
             }
             if (go_on) {

@@ -1711,7 +1711,14 @@ extern "C" int bfhip_debug_tail_count(bfhip_ctx *ctx) {
     if (hipMemcpy(&n, ctx->tail_buf, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return n;
 }
-static int g_tail_stop = [] { const char *e = getenv("BFHIP_TAIL_STOP"); return e ? atoi(e) : 4; }();   // (tuning: 1 .. 4)
+static int g_lone = [] { const char *e = getenv("BFHIP_LONE"); return e ? atoi(e) : 1; }();
+extern "C" void bfhip_debug_lone(int v) { g_lone = v; }
+static int g_tail_stop = [] { const char *e = getenv("BFHIP_TAIL_STOP"); return e ? atoi(e) : 4; }();   // (tuning: 1 .. 16; 1 .. 4 without the latency kernel)
+static int g_tail_q = [] { const char *e = getenv("BFHIP_TAIL_Q"); return e ? atoi(e) : 3; }();         // (tuning: quarters of the chains that must be through, 1 .. 4)
+static int tail_stop_now() {
+    const int hi = g_lone ? 16 : 4;   // (the few-chain instantiation of the second part takes four chains of every first-part workgroup at most)
+    return g_tail_stop < 1 ? 1 : (g_tail_stop > hi ? hi : g_tail_stop);
+}
 
 __global__ void bf_tail_list_kernel(int n_chain, int iter_end, const double *sc, int *buf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1728,8 +1735,6 @@ extern "C" const char *bfhip_debug_last_kernel(void) { return g_last_kernel; }
 // (the chains listed in tail_buf) and whole launches whose chains all fit the chip at once -- every workgroup must be resident,
 // a chain that waited for a slot would double the launch.  g_lone: 1 automatic, 0 never, 2 wherever it is implemented
 // (tests: any chain count, in as many rounds as it takes).
-static int g_lone = [] { const char *e = getenv("BFHIP_LONE"); return e ? atoi(e) : 1; }();
-extern "C" void bfhip_debug_lone(int v) { g_lone = v; }
 
 static unsigned long long *g_stamps_lone = NULL;   // tuning builds (-DBF_LTRACE): cycle stamps of workgroup 0's integrator and bookkeeper
 extern "C" void bfhip_debug_stamps_lone(unsigned long long *buf) { g_stamps_lone = buf; }
@@ -1745,7 +1750,7 @@ static int lone_blocks_per_cu(bfhip_ctx *ctx, bool roomy) {
     auto k4 = bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>;
     const void *k = roomy ? (const void *)k1 : (const void *)k4;
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, LoneWaves<W>::NW * 64, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, LoneWaves<W, DEC>::NW * 64, lds) != hipSuccess) return 0;
     return nb;
 }
 
@@ -1767,8 +1772,8 @@ static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks,
         roomy = false;
         if (lone_blocks_per_cu<W, TR, DEC>(ctx, false) < need && g_lone != 2 && !tail) return 0;
     }
-    if (roomy) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1>), dim3(n_blocks), dim3(LoneWaves<W>::NW * 64), lds, ctx->stream, ctx->model, args);
-    else hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>), dim3(n_blocks), dim3(LoneWaves<W>::NW * 64), lds, ctx->stream, ctx->model, args);
+    if (roomy) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1>), dim3(n_blocks), dim3(LoneWaves<W, DEC>::NW * 64), lds, ctx->stream, ctx->model, args);
+    else hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>), dim3(n_blocks), dim3(LoneWaves<W, DEC>::NW * 64), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     if (!tail) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", roomy ? 1 : LoneOcc<W>::MINW);
     return 1;
@@ -1805,7 +1810,8 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
             BF_HIP_CHECK(hipMalloc((void **)&ctx->tail_buf, (size_t)(args.n_chain + 2) * sizeof(int)));
             ctx->tail_cap = args.n_chain + 2;
         }
-        args.tail_stop = g_tail_stop;
+        args.tail_stop = tail_stop_now();
+        args.tail_q = g_tail_q < 1 ? 1 : (g_tail_q > 4 ? 4 : g_tail_q);
         args.tail_done = ctx->tail_buf + 1;
         BF_HIP_CHECK(hipMemsetAsync(ctx->tail_buf, 0, 2 * sizeof(int), ctx->stream));
     }
@@ -1825,7 +1831,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
         a2.tail_done = NULL;
         a2.cpg = 4;
         {   // the stragglers one per workgroup in the latency kernel (at most tail_stop chains of every first-part workgroup are listed)
-            const int most = args.n_chain < g_tail_stop * groups ? args.n_chain : g_tail_stop * groups;
+            const int most = args.n_chain < args.tail_stop * groups ? args.n_chain : args.tail_stop * groups;
             const int r = launch_lone<W, TR, DEC>(ctx, a2, most, true);
             if (r != 0) return r < 0 ? r : 0;
         }
