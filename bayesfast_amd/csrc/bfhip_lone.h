@@ -138,7 +138,10 @@ struct LoneJobs {
 // (The same with the decay term, whose jobs are twelve chains of sixteen k-steps: three job waves of four chains, 1.72 against 1.67 us.)
 template <int W, bool DEC> struct LoneWaves {
     static constexpr bool ITILE = true;                   // the integrator runs jobs
-    static constexpr int NT = ITILE ? W : 3;              // waves that run jobs
+    // waves that run jobs.  d <= 32: the integrator alone -- its 8 chains of 4 k-steps cost 250 cycles more than shared with a second
+    // wave, but a workgroup is then two waves and four of them fit a CU at 256 registers a wave, without the bookkeeper's spills:
+    // 32-d x 1024 chains 4.18 -> 4.47 x 10^8 (profiles/r05_lone_layouts.log)
+    static constexpr int NT = W <= 2 ? 1 : W;
     static constexpr int KW = ITILE ? NT : NT + 1;        // the bookkeeper's wave
     static constexpr int NW = KW + 1;
 };
