@@ -750,6 +750,27 @@ def main():
                             'identical_on_all_ranks': bool(all(float(c.item()) == float(chk.item()) for c in chk_all)),
                             'includes': 'local device sort of %d keys + 4 collectives (%s), max over ranks, best of 3' % (n_rows, a.backend)}
 
+        # What sample() adds per launch when the chains are sharded (core/sample.py:104-105, DeviceChains._note_trees): the histogram
+        # of the launch's tree sizes summed over the ranks, so that every rank chooses the same layout for the next launch -- a
+        # stream synchronisation and one 32 KB all-reduce.  Not part of `value` (the timed loop above runs one layout); reported so
+        # that the weak-scaling loss of a sharded sample() has a prior.
+        vote = None
+        if dist is not None:
+            from bayesfast_amd import parallel
+            chains.hist_reduce = parallel.all_reduce_sum
+            tv = []
+            for _ in range(5):
+                sync()
+                t1 = time.perf_counter()
+                chains._note_trees(stats, 0, a.iters, 'NUTS')
+                tv.append((time.perf_counter() - t1) * 1e3)
+            chains.hist_reduce = None
+            tvx = torch.tensor([min(tv[1:])], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tvx, op=dist.ReduceOp.MAX)
+            vote = {'ms_per_launch': float(tvx.item()), 'share_of_a_launch': float(tvx.item()) / (elapsed_max / max(a.steps, 1) * 1e3),
+                    'includes': 'histogram of the last 32 iterations\' tree sizes (device), stream synchronisation, all-reduce of 4096 int64 '
+                                '(%s), max over ranks, best of 4' % a.backend}
+
     if rank == 0:
         value = total_lf / elapsed_max
         lf_per_launch = n_lf / max(a.steps, 1)
@@ -808,6 +829,8 @@ def main():
         }
         if exchange is not None:
             out['refit_exchange'] = exchange
+        if vote is not None:
+            out['layout_vote'] = vote
         try:   # the AS-SHIPPED reference's rate: a stored measurement of the build container (tools/time_reference.py), never timed here
             rt = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_timing.json')))
             out['reference_as_shipped'] = {'leapfrog_steps_per_sec_per_core': rt['leapfrog_steps_per_sec_per_core'],

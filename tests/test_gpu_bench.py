@@ -50,6 +50,25 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     ex = j['refit_exchange']   # the path's one exchange step, timed on its own: four collectives, the same rows on every rank
     assert ex['collectives'] == 4 and ex['identical_on_all_ranks'] and ex['ms'] > 0 and ex['rows_selected'] == 4290
     assert ex['wire_bytes_per_rank'] < 256 * 250 * 65 * 8 / 4   # far below the shard's samples
+    assert j['layout_vote']['ms_per_launch'] > 0   # (what a sharded sample() pays per launch to agree on the next layout)
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu_gloo():
+    """The launch the driver makes on an 8-GPU node, rehearsed on one GPU: eight ranks over gloo, each with its shard of the
+    chains (stream = global chain index), the barrier-bracketed timing with the maximum over the ranks, the summed leapfrog
+    count, the refit's exchange (the same 2 P rows on all eight ranks) and the cost of the per-launch layout vote."""
+    port = 29300 + os.getpid() % 150
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), 'bench.py', '--gpus', '8', '--steps', '1', '--warmup', '1', '--chains', '128',
+           '--backend', 'gloo', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert j['n_gpus'] == 8 and j['scaling'] == 'weak' and j['value'] > 0 and j['config']['chains_per_gpu'] == 128
+    ex = j['refit_exchange']
+    assert ex['collectives'] == 4 and ex['identical_on_all_ranks'] and ex['rows_selected'] == 4290 and ex['rows_per_rank'] == 128 * 250
+    assert j['layout_vote']['ms_per_launch'] > 0
+    assert 'cpu_baseline' not in j or j['cpu_baseline'] is None
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():

@@ -252,10 +252,11 @@ def test_config4_funnel_target_accept_095():
     assert acc > 0.85, acc
 
 
-@pytest.mark.parametrize('ipl,pipeline', [(0, False), (7, False), (0, True)])
-def test_sample_two_ranks_equals_one_rank(tmp_path, ipl, pipeline):
+@pytest.mark.parametrize('ipl,pipeline,n_rank', [(0, False, 2), (7, False, 2), (0, True, 2), (7, False, 8)])
+def test_sample_two_ranks_equals_one_rank(tmp_path, ipl, pipeline, n_rank):
     """(ipl = 7: nine launches per round under layout 'auto' -- the layout of a launch is a pure function of the launches
-    before it, decided from the trees of ALL ranks' chains, so it is the same for one rank and for two.)
+    before it, decided from the trees of ALL ranks' chains, so it is the same for one rank and for two.  n_rank = 8: the node's
+    launch rehearsed on one GPU -- ragged shards 3, 3, 3, 3, 3, 3, 2, 2 of the 22 chains, a layout vote per launch.)
     sample() under torch.distributed (two ranks sharing the box's GPU over gloo, ragged shards 11 + 11 of 22 chains) returns
     exactly what one rank returns: x_0 and the xoshiro streams follow the global chain index, the trace's seed is resolved
     once and broadcast, and the warm start of the next round (_get_step_size, _get_metric) reduces over all ranks."""
@@ -270,9 +271,9 @@ def test_sample_two_ranks_equals_one_rank(tmp_path, ipl, pipeline):
     r = subprocess.run([sys.executable, helper, one], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     port = 29500 + os.getpid() % 150
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_rank), '--master-addr',
                         '127.0.0.1', '--master-port', str(port), helper, two], cwd=root, env=env, capture_output=True, text=True,
-                       timeout=900)
+                       timeout=1500)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     a, b = np.load(one), np.load(two)
     assert a['s'].shape == (22, 60, 6)
