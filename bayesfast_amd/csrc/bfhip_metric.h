@@ -165,6 +165,52 @@ __device__ inline void bf_velocity_full(const double *covT, const double (&pv)[E
     }
 }
 
+// Two velocities in ONE pass over the matrix: a leapfrog step takes cov p' at its end (integration.py:92) and cov (p' + eps/2 g') at
+// the start of the next one (:82) -- both vectors are known when the first product is taken, and the 32 KB of a chain's
+// covariance are what the full-rank metric's kernel is bound by.  Each sum is bf_velocity_full's, term by term.
+template <int E>
+__device__ inline void bf_velocity_full2(const double *covT, const double (&p0)[E], const double (&p1)[E], double (&o0)[E], double (&o1)[E],
+                                         int d, int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) o0[e] = o1[e] = 0.;
+    constexpr int B = 16;
+    int k = 0;
+    for (; k + B <= d; k += B) {
+        double c[B][E];
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                c[u][e] = (i < d) ? covT[(size_t)(k + u) * d + i] : 0.;
+            }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const double a0 = bf_pick<E>(p0, k + u), a1 = bf_pick<E>(p1, k + u);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = lane * E + e;
+                if (i < d) {
+                    o0[e] = __dadd_rn(o0[e], __dmul_rn(c[u][e], a0));
+                    o1[e] = __dadd_rn(o1[e], __dmul_rn(c[u][e], a1));
+                }
+            }
+        }
+    }
+    for (; k < d; ++k) {
+        const double a0 = bf_pick<E>(p0, k), a1 = bf_pick<E>(p1, k);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            if (i < d) {
+                const double cv = covT[(size_t)k * d + i];
+                o0[e] = __dadd_rn(o0[e], __dmul_rn(cv, a0));
+                o1[e] = __dadd_rn(o1[e], __dmul_rn(cv, a1));
+            }
+        }
+    }
+}
+
 // Three velocities in ONE pass over the matrix (the U-turn checks of a merge level and of a doubling's end need cov p of three
 // stored momenta: nuts.py:150-160, 88-100): each vector's sum is the one bf_velocity_full makes, term by term; the 32 KB of a
 // chain's covariance are read once instead of three times.

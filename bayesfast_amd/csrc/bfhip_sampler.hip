@@ -97,7 +97,7 @@ struct SamplerGeo {
 __device__ inline bool g_sliced_proof_on(const SamplerArgs &a) { return a.no_bound_proof == 0; }
 __device__ inline bool g_no_quad_tiles(const SamplerArgs &a) { return a.no_quad != 0; }
 
-template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM>
+template <int W, bool NUTS, bool STAMPS, int FS, int FULLM>   // (FULLM: 0 diagonal metric, 1 full-rank, 2 full-rank with the next step's velocity taken ahead)
 __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sampler_kernel(DevModel m, SamplerArgs a) {
     constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS), NTH = NWV * 64;  // waves (= chains) of a workgroup, threads
     // FS == 8: the pipeline density (bfhip_pld.h: multi-output surrogate + Gaussian likelihood + prior); transforms, input
@@ -269,6 +269,14 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             for (int e = 0; e < E; ++e) out[e] = var[e] * pv[e];
         }
     };
+
+    // Full-rank metric: the velocity of the NEXT step's half-step momentum, taken in the pass that takes this step's final velocity
+    // (bf_velocity_full2).  p_ahead is the momentum it belongs to: the next phase A uses the cached product only if its own
+    // half-step momentum has exactly these bits (the tree goes on from this leaf with the same step; at a turn of the direction,
+    // a new tree or a step-size change it does not, and the pass is taken as before) -- the same numbers either way.
+    double p_ahead[FULLM ? E : 1], v_ahead[FULLM ? E : 1];
+    bool ahead_ok = false;
+    constexpr bool VEL_AHEAD = FULLM == 2;
 
     auto velocity3 = [&](const double (&a0)[E], const double (&a1)[E], const double (&a2)[E], double (&o0)[E], double (&o1)[E], double (&o2)[E]) {
         if constexpr (FULLM) {
@@ -992,7 +1000,22 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #pragma unroll
                 for (int e = 0; e < E; ++e) p[e] = p[e] + dt * g[e];  // integration.py:80
                 double vh[E];
-                velocity(p, vh);                                       // :82
+                bool hit = false;
+                if constexpr (VEL_AHEAD) {
+                    if (ahead_ok) {
+                        bool same = true;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) same = same && (__double_as_longlong(p[e]) == __double_as_longlong(p_ahead[e]));
+                        hit = __builtin_amdgcn_ballot_w64(!same) == 0ull;
+                    }
+                    ahead_ok = false;
+                }
+                if (hit) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) vh[e] = v_ahead[e];
+                } else {
+                    velocity(p, vh);                                   // :82
+                }
 #pragma unroll
                 for (int e = 0; e < E; ++e) q[e] = q[e] + eps_t * vh[e];  // :85
             }
@@ -1535,7 +1558,17 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 p[e] = p[e] + dt * gn[e];        // integration.py:90
                 g[e] = gn[e];
             }
-            if constexpr (FULLM) {
+            // (not while the metric adapts: an iteration then ends with passes over three more matrices and the second column costs
+            // more than the pass it saves -- 3.0 against 3.3 x 10^7, tools/full_metric_rate.py)
+            if constexpr (VEL_AHEAD) {
+                // (integration.py:92, and :82 of the step that follows if the tree goes on from here: p + eps/2 g with this step's eps)
+#pragma unroll
+                for (int e = 0; e < E; ++e) p_ahead[e] = p[e] + dt * g[e];
+                bf_velocity_full2<E>(matp + BF_MAT_COV * msz, p, p_ahead, vcur, v_ahead, d, lane);
+                ahead_ok = mode != M_INIT;   // (the evaluation that opens a launch is a step of length 0)
+#pragma unroll
+                for (int e = 0; e < E; ++e) kin += p[e] * vcur[e];
+            } else if constexpr (FULLM) {
                 velocity(p, vcur);               // integration.py:92
 #pragma unroll
                 for (int e = 0; e < E; ++e) kin += p[e] * vcur[e];
@@ -1672,7 +1705,7 @@ static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
     return cpg;
 }
 
-template <int W, bool NUTS, bool STAMPS, int FS, bool FULLM = false>
+template <int W, bool NUTS, bool STAMPS, int FS, int FULLM = 0>
 static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = bf_sampler_kernel<W, NUTS, STAMPS, FS, FULLM>;
     const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
@@ -1857,6 +1890,8 @@ extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 static int g_pld_waves = [] { const char *e = getenv("BFHIP_PLD_WAVES"); return e ? atoi(e) : 0; }();
 extern "C" void bfhip_debug_pld_waves(int v) { g_pld_waves = v; }
 
+static bool g_no_vel_ahead = [] { const char *e = getenv("BFHIP_NO_VEL_AHEAD"); return e && atoi(e); }();   // tuning / test switch
+
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
@@ -1874,7 +1909,13 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         if (w8 && m.has_transform && m.has_su && m.use_bound && !m.use_decay && !g_no_plain) return launch_sampler_t<WP, NUTS, false, 10>(ctx, args);
         return w8 ? launch_sampler_t<WP, NUTS, false, 9>(ctx, args) : launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
     }
-    if (args.mat) return launch_sampler_t<W, NUTS, false, 0, true>(ctx, args);   // (a compile-time feature set changes nothing here: 7.4 x 10^7 either way)
+    if (args.mat) {   // (a compile-time feature set changes nothing here: 7.4 x 10^7 either way)
+        // While the metric adapts an iteration ends with passes over three more matrices, and the second column of the
+        // velocity-ahead pass costs more than the pass it saves (3.0 against 3.3 x 10^7, tools/full_metric_rate.py); afterwards it
+        // is worth a fifth (7.4 -> 8.9 x 10^7).  Both forms in one kernel were slower than either.  The same numbers from both.
+        const bool adapting = args.cfg.adapt_metric && args.iter_out0 < args.cfg.n_warmup;
+        return (adapting || g_no_vel_ahead) ? launch_sampler_t<W, NUTS, false, 0, 1>(ctx, args) : launch_sampler_t<W, NUTS, false, 0, 2>(ctx, args);
+    }
 #ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
         return plain ? launch_sampler_t<W, NUTS, (W == 4 && NUTS), (W == 4 && NUTS) ? 1 : 0>(ctx, args)
