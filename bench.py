@@ -580,6 +580,54 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
     raise ValueError(name)
 
 
+def evidence_block(ctx, seed, chains=1024, n_iter=340, n_warmup=120, sit_iter=6):
+    """BASELINE config 5's last clause, "evidence via GBS", at config 5's size on the device path: the config-5 surrogate (d = 128,
+    linear + quadratic + cubic-2 + cubic-3 on 16 inputs, P = 9201) fitted on the GAUSSIAN part of the Planck-like target (the
+    cubic perturbation switched off, so that the evidence has a closed form: log Z = d/2 log 2 pi + 1/2 log det Sigma), sampled by
+    `sample()` with 1024 chains, and the samples handed to GBS (evidence/gaussianized.py:179-216: SIT, transforms/sit.py:223-459,
+    fitted on the first half, bridge sampling on the second half and as many draws from the SIT).  Wall clock per stage."""
+    import warnings
+    import torch
+    import bayesfast_amd as bfa
+    from bayesfast_amd.workloads import planck_like_logp
+    rng = np.random.default_rng(seed)
+    d = 128
+    logp, chol = planck_like_logp(d, amp=0.)
+    m16 = np.arange(16)
+    su = bfa.PolyModel([bfa.PolyConfig('linear'), bfa.PolyConfig('quadratic'), bfa.PolyConfig('cubic-2', input_mask=m16),
+                        bfa.PolyConfig('cubic-3', input_mask=m16)], input_size=d, output_size=1, bound_options=dict(alpha_p=150.))
+    den = bfa.SurrogateDensity(su)
+    x_fit = rng.normal(size=(2 * su.n_param, d)) @ chol.T * 1.3
+    out = {'workload': 'config 5, evidence via GBS: %d chains x 128-d, the cubic-cross surrogate (P = %d) fitted on the Gaussian part of the '
+                       'Planck-like target (cond 1e4; closed-form log Z), sample() with %d iterations (%d warm-up) per chain, then GBS with %d '
+                       'SIT iterations on half of the kept samples and bridge sampling on the other half' % (
+                           chains, su.n_param, n_iter, n_warmup, sit_iter)}
+
+    def timed(key, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        out[key] = (time.perf_counter() - t0) * 1e3
+        return r
+
+    timed('fit_ms', lambda: den.fit(x_fit, logp(x_fit)))
+    tt = timed('sample_ms', lambda: bfa.sample(den, {'n_chain': chains, 'n_iter': n_iter, 'n_warmup': n_warmup, 'random_generator': seed},
+                                               verbose=False))
+    n_kept = chains * (n_iter - n_warmup)
+    gbs = bfa.GBS(sit=dict(n_iter=sit_iter, random_generator=5), n_q=n_kept // 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        logz, err = timed('gbs_ms', lambda: gbs(tt, den.logp))
+    exact = 0.5 * d * np.log(2. * np.pi) + float(np.sum(np.log(np.diag(chol))))
+    out.update({'log_z': float(logz), 'log_z_err': float(err), 'log_z_exact': exact, 'abs_error_in_sigma': float(abs(logz - exact) / max(err, 1e-300)),
+                'samples_kept': int(n_kept), 'n_call': int(tt.n_call), 'chains': int(chains), 'dim': d,
+                'sample_leapfrog_steps_per_sec': float(tt.n_call) / (out['sample_ms'] * 1e-3),
+                'sit_ms_per_iteration': out['gbs_ms'] / sit_iter,
+                'note': 'gbs_ms is SIT fit + draws + four logq / logp passes + the bridge iteration; sit_ms_per_iteration is gbs_ms / SIT iterations (an upper bound of one)'})
+    return out
+
+
 CONFIG_BLOCKS = ('gauss32', 'banana_decay', 'funnel', 'cubic128', 'des_pipeline')
 CONFIG_KEYS = ('config2', 'config3', 'config4', 'config5', 'pipeline_des')
 
@@ -618,7 +666,7 @@ def main():
     ap.add_argument('--no-fit', action='store_true', help='skip the (untimed, separately reported) surrogate fit')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary figures (hetero workload, refit cycle)')
     ap.add_argument('--no-configs', action='store_true', help="skip the blocks on the BASELINE configs' own targets (config2/3/4/5)")
-    ap.add_argument('--workload', default=None, choices=CONFIG_BLOCKS,
+    ap.add_argument('--workload', default=None, choices=CONFIG_BLOCKS + ('evidence128',),
                     help='run ONE config block only and print it (profiling: rocprofv3 -- python3 bench.py --workload funnel)')
     a = ap.parse_args()
     if a.no_extras:
@@ -660,8 +708,11 @@ def main():
     ctx = DeviceContext(dev_index)
     if a.workload:  # one config block on its own (the profiles of profiles/r03_config{3,4,5}.json come from these commands)
         with torch.cuda.device(ctx.device):
-            blk = config_block(a.workload, ctx, a.seed, cpu_seconds=0. if a.no_cpu_baseline else 4.,
-                               chains=None if a.chains == 4096 else a.chains)
+            if a.workload == 'evidence128':
+                blk = evidence_block(ctx, a.seed, chains=1024 if a.chains == 4096 else a.chains)
+            else:
+                blk = config_block(a.workload, ctx, a.seed, cpu_seconds=0. if a.no_cpu_baseline else 4.,
+                                   chains=None if a.chains == 4096 else a.chains)
         print(json.dumps({'config_block': a.workload, **blk}))
         return
     with torch.cuda.device(ctx.device):
@@ -860,6 +911,11 @@ def main():
                         out[key] = config_block(name, ctx, a.seed, cpu_seconds=0. if a.no_cpu_baseline else 4.)
                 except Exception as ex:  # side measurements; the headline line must still print
                     out[key] = {'error': repr(ex)}
+            try:   # config 5's "evidence via GBS" at config 5's size
+                with torch.cuda.device(ctx.device):
+                    out['config5_evidence'] = evidence_block(ctx, a.seed)
+            except Exception as ex:
+                out['config5_evidence'] = {'error': repr(ex)}
             c3 = out.get('config3', {})   # SURVEY 8d's headline config, beside the benign-target `value`
             out['config3_round0_value'] = c3.get('value')
             out['config3_round1_value'] = (c3.get('round_1') or {}).get('value')

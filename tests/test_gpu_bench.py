@@ -105,3 +105,18 @@ def test_bench_config_blocks(name):
     assert 0. <= j['divergence_rate'] <= 1. and j['roofline']['frac'] > 0
     if name == 'banana_decay':
         assert 'round_1' in j and j['refit']['n_fit_points'] == 4290
+
+
+def test_bench_config5_evidence_block():
+    """BASELINE config 5's "evidence via GBS" at config 5's dimension (bench.py: evidence_block; a reduced chain count here):
+    sample() on the 128-d cubic-cross surrogate of the Planck-like target's Gaussian part, GBS on the device path, and the
+    closed-form log Z within the estimate's own error."""
+    r = subprocess.run([sys.executable, 'bench.py', '--workload', 'evidence128', '--chains', '256', '--no-cpu-baseline'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j['config_block'] == 'evidence128' and j['dim'] == 128 and j['chains'] == 256
+    for k in ('fit_ms', 'sample_ms', 'gbs_ms', 'log_z', 'log_z_err', 'log_z_exact', 'sit_ms_per_iteration'):
+        assert k in j and j[k] == j[k], k
+    assert 0. < j['log_z_err'] < 0.05
+    assert abs(j['log_z'] - j['log_z_exact']) < 4. * j['log_z_err'] + 0.02, j
