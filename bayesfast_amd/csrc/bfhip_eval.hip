@@ -407,6 +407,43 @@ extern "C" int bfhip_logp_grad(bfhip_ctx *ctx, int n, const double *x, int origi
     return bf_set_error(BFHIP_ERR_UNSUPPORTED, "unsupported padded dimension %d", ctx->model.DP);
 }
 
+// CpuLeapfrogIntegrator._step around an evaluation that is a launch of its own (the pipeline density: bf_pld_logp_grad):
+// one wave per chain, lane = dimension.  first: p += eps/2 g; q += eps var p  (integration.py:80-85).
+// second (after logp, grad at the new q): p += eps/2 g'; v = var p; E = p.v / 2 - logp  (:90-93).
+template <int E>
+__global__ __launch_bounds__(256) void bf_leapfrog_half_kernel(int n, int d, int second, const double *__restrict__ eps,
+                                                              const double *__restrict__ var, double *__restrict__ q, double *__restrict__ p,
+                                                              const double *__restrict__ grad, const double *__restrict__ logp,
+                                                              double *__restrict__ energy, double *__restrict__ velocity_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double e = eps[i], dt = 0.5 * e;
+    double kin = 0.;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int j = lane + 64 * k;
+        if (j < d) {
+            const size_t o = (size_t)i * d + j;
+            const double pn = p[o] + dt * grad[o];
+            p[o] = pn;
+            const double v = var[o] * pn;
+            if (!second) {
+                q[o] = q[o] + e * v;
+            } else {
+                if (velocity_out) velocity_out[o] = v;
+                kin += pn * v;
+            }
+        }
+    }
+    if (second) {
+        for (int o = 32; o >= 1; o >>= 1) kin += __shfl_xor(kin, o, 64);
+        if (lane == 0) energy[i] = 0.5 * kin - logp[i];
+    }
+}
+
+int bf_pld_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad);
+
 extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const double *var, double *q, double *p,
                               double *grad, double *logp, double *energy, double *velocity_out) {
     BfDeviceGuard dev_guard(ctx);
@@ -414,7 +451,19 @@ extern "C" int bfhip_leapfrog(bfhip_ctx *ctx, int n, const double *eps, const do
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_leapfrog: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_leapfrog: no density uploaded");
     if (n == 0) return 0;
-    if (ctx->model.pld.on) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_leapfrog: not implemented for the pipeline density (bfhip_sampler_run is)");
+    if (ctx->model.pld.on) {
+        // the pipeline density's evaluation is a launch of its own (two contractions shared by a workgroup's points): the step is
+        // half step, evaluation, half step -- the same arithmetic as the fused form, three launches
+        const int d = ctx->model.d, blocks = (n + 3) / 4;
+        if (d <= 64) hipLaunchKernelGGL(bf_leapfrog_half_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, n, d, 0, eps, var, q, p, grad, logp, energy, velocity_out);
+        else hipLaunchKernelGGL(bf_leapfrog_half_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, n, d, 0, eps, var, q, p, grad, logp, energy, velocity_out);
+        BF_HIP_CHECK(hipGetLastError());
+        if (int rc = bf_pld_logp_grad(ctx, n, q, 0, logp, grad)) return rc;
+        if (d <= 64) hipLaunchKernelGGL(bf_leapfrog_half_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, n, d, 1, eps, var, q, p, grad, logp, energy, velocity_out);
+        else hipLaunchKernelGGL(bf_leapfrog_half_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, n, d, 1, eps, var, q, p, grad, logp, energy, velocity_out);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int grid = eval_grid(ctx, n);
     const size_t lds = bf_eval_lds_bytes(ctx->model);
     switch (ctx->model.DP / 16) {

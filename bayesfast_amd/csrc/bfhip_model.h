@@ -43,6 +43,7 @@ struct PldDev {
     int nf, PP, NS1, NT2;   // monomials; padded to 16; k-steps of GEMM1; row tiles of GEMM2
     int KS2, KPJ2;          // K-split of GEMM2 (partial sums in separate W slots) and k-steps per part
     int n_ent;              // entries per dimension of the gradient table
+    int only8;              // the LDS block fits in the eight-chain forms' layout only (33 doubles per B-operand row): the launchers take them
     int has_prior;
     const double *CF, *CTF; // A fragments (see above)
     const double *yw, *fmuw;    // (MP) whitened data vector and f_mu, zero padded

@@ -28,8 +28,14 @@
 #define PLD_XS 65
 #define PLD_MAX_KS2 8
 
+// B-operand rows of the eight-chain form: [k = 0 .. 3][chain 0 .. 7] + 1 (the sixteen-chain forms: [k][chain 0 .. 15] + 1 = PLD_XS).
+// Half the LDS per monomial and per output row: what lets a surrogate of more than ~350 monomials (the 27-d full quadratic of the
+// DES example: 406) run at all (bfhip_pipeline_upload: only8).
+#define PLD_XS8 33
+
 // LDS regions of the pipeline block (doubles), in this order behind `base`
 struct PldLds {
+    int XS, CW;    // row stride of the B operands and chains per k of a row: 65 / 16, or 33 / 8 (eight-chain form)
     double *XE;    // [16][DP + 2]  evaluation point of every chain, then 1 and 0
     double *CH;    // [16]          beta of the chains outside the bound's ellipsoid, 0 inside
     double *YW;    // [2][MP]       y' and f_mu'
@@ -41,22 +47,24 @@ struct PldLds {
     const unsigned *MONO;           // [PP]         monomial table (staged from pl.mono)
 };
 
-__host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent) {
+__host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent, int xs = PLD_XS) {
     const size_t ns1 = PP / 4, ns2 = MP / 4;
-    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + 512 + ns2 * PLD_XS + (size_t)KS2 * ns1 * PLD_XS + (size_t)n_ent * DP + PP / 2;
+    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + 512 + ns2 * xs + (size_t)KS2 * ns1 * xs + (size_t)n_ent * DP + PP / 2;
 }
 
 #ifndef BF_HOST_EMU
-__device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl) {
+__device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw = 16) {
     PldLds L;
+    L.CW = cw;
+    L.XS = cw == 8 ? PLD_XS8 : PLD_XS;
     L.XE = base;
     L.CH = L.XE + 16 * (DP + 2);
     L.YW = L.CH + 16;
     L.RED = L.YW + 2 * pl.MP;
     L.RB = L.RED + 512;
-    L.PHI = L.RB + (size_t)pl.NS2 * PLD_XS;
-    L.WX = L.PHI + (size_t)pl.NS1 * PLD_XS;
-    double *gt = L.WX + (size_t)(pl.KS2 - 1) * pl.NS1 * PLD_XS;
+    L.PHI = L.RB + (size_t)pl.NS2 * L.XS;
+    L.WX = L.PHI + (size_t)pl.NS1 * L.XS;
+    double *gt = L.WX + (size_t)(pl.KS2 - 1) * pl.NS1 * L.XS;
     L.GT = (const unsigned long long *)gt;
     L.MONO = (const unsigned *)(gt + (size_t)pl.n_ent * DP);
     return L;
@@ -89,7 +97,7 @@ __device__ inline void pld_point(const PldDev &pl, const PldLds &L, int DP, int 
         if (p < pl.PP) {
             const unsigned mo = L.MONO[p];
             const double v = (xe[mo & 255u] * xe[(mo >> 8) & 255u]) * xe[(mo >> 16) & 255u];
-            L.PHI[(p >> 2) * PLD_XS + c + 16 * (p & 3)] = v;
+            L.PHI[(p >> 2) * L.XS + c + L.CW * (p & 3)] = v;
         }
     }
 }
@@ -276,12 +284,12 @@ struct PldAcc8 { double lo, hi; };   // chains 0-3 and 4-7 of one row per lane
 
 template <bool SAME_B>
 __device__ inline void pld_tile2_q8(const double *__restrict__ Af0, const double *Bf0, const double *__restrict__ Af1, const double *Bf1,
-                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1) {
+                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1, int XS, int CW) {
     // chunks of four k-steps (n_steps is a multiple of 4), the A fragments of TWO chunks ahead on their way while one runs: no
     // guard inside a chunk, so the loads are counted exactly (vmcnt) and stay in flight across the matrix instructions
     acc0 = PldAcc8{0., 0.};
     acc1 = PldAcc8{0., 0.};
-    const int bo = (lane & ~15) + (lane & 3);   // column n = lane & 3 of k = lane >> 4
+    const int bo = CW * (lane >> 4) + (lane & 3);   // column n = lane & 3 of k = lane >> 4
     const double *ap0 = Af0 + lane, *ap1 = Af1 + lane, *bp0 = Bf0 + bo, *bp1 = Bf1 + bo;
     const int n_ch = n_steps >> 2;
     double xa[4], ya[4], xb[4], yb[4], xc[4], yc[4];
@@ -297,9 +305,9 @@ __device__ inline void pld_tile2_q8(const double *__restrict__ Af0, const double
         double bl[4], bh[4], cl[4], chh[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            bl[q] = bp0[(4 * c + q) * PLD_XS];
-            bh[q] = bp0[(4 * c + q) * PLD_XS + 4];
-            if (!SAME_B) { cl[q] = bp1[(4 * c + q) * PLD_XS]; chh[q] = bp1[(4 * c + q) * PLD_XS + 4]; }
+            bl[q] = bp0[(4 * c + q) * XS];
+            bh[q] = bp0[(4 * c + q) * XS + 4];
+            if (!SAME_B) { cl[q] = bp1[(4 * c + q) * XS]; chh[q] = bp1[(4 * c + q) * XS + 4]; }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -351,7 +359,7 @@ __device__ inline void pld_epilogue1_q8(const PldDev &pl, const PldLds &L, doubl
         const double f0 = h ? acc.hi : acc.lo;
         const double fv = beta[h] > 0. ? (beta[h] * f0 - (beta[h] - alpha) * fmu) * inv_alpha : f0;   // modules/poly.py:487
         const double r = fv - y;
-        L.RB[(4 * t + b) * PLD_XS + n + 4 * h + 16 * i] = r;   // row >> 2 = 4 t + b, row & 3 = i
+        L.RB[(4 * t + b) * L.XS + n + 4 * h + L.CW * i] = r;   // row >> 2 = 4 t + b, row & 3 = i
         s_rr[h] += r * r;
         s_fr[h] += (f0 - fmu) * r;
     }
@@ -374,7 +382,7 @@ __device__ inline void pld_gemm1_q8(const PldDev &pl, const PldLds &L, double al
     for (int t = w; t < pl.NT1; t += 2 * nwv) {
         const int t2 = t + nwv < pl.NT1 ? t + nwv : t;   // (an odd tile out is computed twice side by side: same result, same time)
         PldAcc8 a0, a1;
-        pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1);
+        pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1, L.XS, L.CW);
         pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
         if (t2 != t) pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
     }
@@ -385,25 +393,25 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
     const int n_job = pl.NT2 * pl.KS2;
     const int i = lane >> 4, b = (lane >> 2) & 3, n = lane & 3;
     auto steps_of = [&](int job) { const int s0 = (job % pl.KS2) * pl.KPJ2; int ns = pl.NS2 - s0; return ns > pl.KPJ2 ? pl.KPJ2 : ns; };
-    auto dest = [&](int job) { const int kp = job % pl.KS2; return (kp == 0 ? L.PHI : L.WX + (size_t)(kp - 1) * pl.NS1 * PLD_XS) + (size_t)4 * (job / pl.KS2) * PLD_XS; };
+    auto dest = [&](int job) { const int kp = job % pl.KS2; return (kp == 0 ? L.PHI : L.WX + (size_t)(kp - 1) * pl.NS1 * L.XS) + (size_t)4 * (job / pl.KS2) * L.XS; };
     auto a_of = [&](int job) { return pl.CTF + ((size_t)(job / pl.KS2) * pl.NS2 + (job % pl.KS2) * pl.KPJ2) * 64; };
-    auto b_of = [&](int job) { return L.RB + (size_t)(job % pl.KS2) * pl.KPJ2 * PLD_XS; };
+    auto b_of = [&](int job) { return L.RB + (size_t)(job % pl.KS2) * pl.KPJ2 * L.XS; };
     for (int job = w; job < n_job; job += 2 * nwv) {
         const int job2 = (job + nwv < n_job && steps_of(job + nwv) == steps_of(job)) ? job + nwv : job;
         PldAcc8 a0, a1;
-        pld_tile2_q8<false>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1);
-        double *W0 = dest(job) + b * PLD_XS + n + 16 * i;   // monomial p = 16 u + 4 b + i: p >> 2 = 4 u + b, p & 3 = i
+        pld_tile2_q8<false>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1, L.XS, L.CW);
+        double *W0 = dest(job) + b * L.XS + n + L.CW * i;   // monomial p = 16 u + 4 b + i: p >> 2 = 4 u + b, p & 3 = i
         W0[0] = a0.lo;
         W0[4] = a0.hi;
         if (job2 != job) {
-            double *W1 = dest(job2) + b * PLD_XS + n + 16 * i;
+            double *W1 = dest(job2) + b * L.XS + n + L.CW * i;
             W1[0] = a1.lo;
             W1[4] = a1.hi;
         } else if (job + nwv < n_job) {   // a partner with another number of k-steps (the last K part): on its own
             const int j3 = job + nwv;
             PldAcc8 c0, c1;
-            pld_tile2_q8<false>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1);
-            double *W3 = dest(j3) + b * PLD_XS + n + 16 * i;
+            pld_tile2_q8<false>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1, L.XS, L.CW);
+            double *W3 = dest(j3) + b * L.XS + n + L.CW * i;
             W3[0] = c0.lo;
             W3[4] = c0.hi;
         }
@@ -455,9 +463,9 @@ __device__ inline double pld_grad(const PldDev &pl, const PldLds &L, int DP, int
     for (int i = 0; i < pl.n_ent; ++i) {
         const unsigned long long en = L.GT[(size_t)i * DP + dim];
         const unsigned eh = (unsigned)(en >> 32);
-        const int p = (int)(unsigned)en, off = (p >> 2) * PLD_XS + c + 16 * (p & 3);
+        const int p = (int)(unsigned)en, off = (p >> 2) * L.XS + c + L.CW * (p & 3);
         double wv = L.PHI[off];
-        for (int kp = 1; kp < pl.KS2; ++kp) wv += L.WX[(size_t)(kp - 1) * pl.NS1 * PLD_XS + off];
+        for (int kp = 1; kp < pl.KS2; ++kp) wv += L.WX[(size_t)(kp - 1) * pl.NS1 * L.XS + off];
         const double mult = (double)((eh >> 16) & 255u);
         g += (mult * wv) * (xe[eh & 255u] * xe[(eh >> 8) & 255u]);
     }

@@ -233,19 +233,23 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     // ---- K-split of GEMM2: the fewest rounds x steps per job that fits the CU's LDS with the sampler's own regions ----
     dm.pld.on = 1;   // (the LDS size below depends on it)
     const size_t base_bytes = bf_sampler_lds_bytes_base(dm);
-    int best_ks = 0;
+    int best_ks = 0, only8 = 0;
     long best_cost = 0;
-    for (int ks = 1; ks <= PLD_MAX_KS2; ++ks) {
-        const int kpj = roundup((NS2 + ks - 1) / ks, 4);
-        if (ks > 1 && (ks - 1) * kpj >= NS2) continue;   // an empty part
-        if (base_bytes + pld_lds_doubles(DP, MP, PP, ks, (int)n_ent) * sizeof(double) > (size_t)160 * 1024) continue;
-        const long cost = (long)((NT2 * ks + 15) / 16) * kpj;
-        if (!best_ks || cost < best_cost) { best_ks = ks; best_cost = cost; }
+    // (the sixteen-chain forms' layout first -- every form can run then --, else the eight-chain forms' compact rows)
+    for (int xs : {PLD_XS, PLD_XS8}) {
+        for (int ks = 1; ks <= PLD_MAX_KS2; ++ks) {
+            const int kpj = roundup((NS2 + ks - 1) / ks, 4);
+            if (ks > 1 && (ks - 1) * kpj >= NS2) continue;   // an empty part
+            if (base_bytes + pld_lds_doubles(DP, MP, PP, ks, (int)n_ent, xs) * sizeof(double) > (size_t)160 * 1024) continue;
+            const long cost = (long)((NT2 * ks + 15) / 16) * kpj;
+            if (!best_ks || cost < best_cost) { best_ks = ks; best_cost = cost; }
+        }
+        if (best_ks) { only8 = xs == PLD_XS8; break; }
     }
     if (!best_ks) {
         dm.pld.on = 0;
         return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_pipeline_upload: %d outputs x %d monomials need %zu KB of LDS per workgroup (160 KB)",
-                            m, nf, (base_bytes + pld_lds_doubles(DP, MP, PP, 1, (int)n_ent) * sizeof(double)) / 1024);
+                            m, nf, (base_bytes + pld_lds_doubles(DP, MP, PP, 1, (int)n_ent, PLD_XS8) * sizeof(double)) / 1024);
     }
 
     // ---- one device buffer: doubles, then 8-byte entries, then the monomial words ----
@@ -285,6 +289,7 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     pl.nf = nf; pl.PP = PP; pl.NS1 = NS1; pl.NT2 = NT2;
     pl.KS2 = best_ks; pl.KPJ2 = roundup((NS2 + best_ks - 1) / best_ks, 4);
     pl.n_ent = (int)n_ent;
+    pl.only8 = only8;
     pl.has_prior = ds->prior_mu != NULL;
     pl.CF = dbase + o_cf; pl.CTF = dbase + o_ctf; pl.yw = dbase + o_y; pl.fmuw = dbase + o_f;
     pl.prior_mu = dbase + o_pr; pl.prior_prec = dbase + o_pr + DP;
@@ -311,17 +316,20 @@ __device__ inline double pld_frag_at(const double *Mf, int DP, int i, int k) {
     return Mf[(((i >> 4) * (DP / 4)) + (k >> 2)) * 64 + (i & 15) + 16 * (k & 3)];
 }
 
-__global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int n, const double *__restrict__ x, int original_space,
-                                                              double *__restrict__ logp, double *__restrict__ grad) {
+// NPT points per workgroup: 16 (sixteen waves, 16-column tiles) or 8 (eight waves, the eight-chain forms' compact LDS rows: what
+// a surrogate with more monomials than the sixteen-point layout holds runs on)
+template <int NPT>
+__global__ __launch_bounds__(NPT * 64) void bf_pld_logp_grad_kernel(DevModel m, int n, const double *__restrict__ x, int original_space,
+                                                                  double *__restrict__ logp, double *__restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const PldDev &pl = m.pld;
     const int DP = m.DP, d = m.d;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const PldLds L = pld_lds(lds, DP, pl);
-    double *XM = lds + pld_lds_doubles(DP, pl.MP, pl.PP, pl.KS2, pl.n_ent);   // [16][2][DP]  x - mu and x_o - mu_decay of every point
-    pld_stage(pl, L, DP, tid, 1024);
+    const PldLds L = pld_lds(lds, DP, pl, NPT);
+    double *XM = lds + pld_lds_doubles(DP, pl.MP, pl.PP, pl.KS2, pl.n_ent, L.XS);   // [NPT][2][DP]  x - mu and x_o - mu_decay of every point
+    pld_stage(pl, L, DP, tid, NPT * 64);
     const bool tr = m.has_transform && !original_space;
-    for (int base = blockIdx.x * 16; base < n; base += gridDim.x * 16) {
+    for (int base = blockIdx.x * NPT; base < n; base += gridDim.x * NPT) {
         const int i = base + w;
         const bool valid = i < n, on = lane < d;
         double xo = 0., jac = 1., gj = 0., logdet = 0.;
@@ -358,12 +366,14 @@ __global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int 
         const double x_eval = beta > 0. ? (m.alpha * xs + (beta - m.alpha) * mu) / beta : xs;   // :482
         pld_point(pl, L, DP, w, lane, (valid && on) ? x_eval : 0., valid ? beta : 0.);
         __syncthreads();
-        pld_gemm1(pl, L, m.alpha, w, 16, lane);
+        if constexpr (NPT == 8) pld_gemm1_q8(pl, L, m.alpha, w, 8, lane);
+        else pld_gemm1(pl, L, m.alpha, w, 16, lane);
         __syncthreads();
-        pld_gemm2(pl, L, w, 16, lane);
+        if constexpr (NPT == 8) pld_gemm2_q8(pl, L, w, 8, lane);
+        else pld_gemm2(pl, L, w, 16, lane);
         __syncthreads();
         double s_rr, s_fr;
-        pld_sums(pl, L, w, lane, 16, s_rr, s_fr);
+        pld_sums(pl, L, w, lane, NPT, s_rr, s_fr);
         s_rr = pld_wave_sum(s_rr);
         s_fr = pld_wave_sum(s_fr);
         double gn = lane < DP ? pld_grad(pl, L, DP, w, lane) : 0.;   // (J_0^T r)_lane
@@ -403,13 +413,17 @@ __global__ __launch_bounds__(1024) void bf_pld_logp_grad_kernel(DevModel m, int 
 
 int bf_pld_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space, double *logp, double *grad) {
     const DevModel &m = ctx->model;
-    const size_t lds = (pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent) + (size_t)16 * 2 * m.DP) * sizeof(double);
+    const int npt = m.pld.only8 ? 8 : 16;
+    const size_t lds = (pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent, npt == 8 ? PLD_XS8 : PLD_XS) + (size_t)npt * 2 * m.DP) * sizeof(double);
     if (lds > (size_t)160 * 1024) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "pipeline density: %zu KB of LDS", lds / 1024);
+    auto k16 = bf_pld_logp_grad_kernel<16>;
+    auto k8 = bf_pld_logp_grad_kernel<8>;
     if (lds > 64 * 1024)
-        BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_pld_logp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int grid = (n + 15) / 16;
+        BF_HIP_CHECK(hipFuncSetAttribute(npt == 8 ? (const void *)k8 : (const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int grid = (n + npt - 1) / npt;
     if (grid > 4 * ctx->n_cu) grid = 4 * ctx->n_cu;
-    hipLaunchKernelGGL(bf_pld_logp_grad_kernel, dim3(grid), dim3(1024), lds, ctx->stream, m, n, x, original_space, logp, grad);
+    if (npt == 8) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, ctx->stream, m, n, x, original_space, logp, grad);
+    else hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, ctx->stream, m, n, x, original_space, logp, grad);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     // pipeline density: its regions behind the matvec results (there are no cubic tables then)
     PldLds PL;
     if constexpr (PLD) {
-        PL = pld_lds(CUB, DP, m.pld);
+        PL = pld_lds(CUB, DP, m.pld, NWV == 8 ? 8 : 16);   // (the eight-chain forms: compact B-operand rows)
         pld_stage(m.pld, PL, DP, tid, NTH);
     }
     int mk2 = 0, mk3 = 0, pj2[E], pj3[E];
@@ -1680,9 +1680,10 @@ static bool sampler_cubic_lds(const DevModel &m, bool plain) {
     return m.has_cubic && m.n2 <= 64 && m.n3 <= 64 &&
            (sampler_lds_base(m, plain) + sampler_cubic_doubles(m)) * sizeof(double) <= (size_t)160 * 1024;
 }
-static size_t sampler_lds_bytes(const DevModel &m, bool plain) {
+static size_t sampler_lds_bytes(const DevModel &m, bool plain, int nwv = 16) {
     if (m.pld.on)   // (the pipeline block sits where the cubic tables would: behind the matvec results, 16-byte aligned)
-        return (((sampler_lds_base(m, false) + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent)) * sizeof(double);
+        return (((sampler_lds_base(m, false) + 1) & ~(size_t)1) +
+                pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent, nwv == 8 ? PLD_XS8 : PLD_XS)) * sizeof(double);
     return (sampler_lds_base(m, plain) + (sampler_cubic_lds(m, plain) ? sampler_cubic_doubles(m) : 0)) * sizeof(double);
 }
 // what the sampler's own regions take for a pipeline density (bfhip_pipeline_upload sizes the K-split of GEMM2 with it)
@@ -1708,7 +1709,7 @@ static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
 template <int W, bool NUTS, bool STAMPS, int FS, int FULLM = 0>
 static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = bf_sampler_kernel<W, NUTS, STAMPS, FS, FULLM>;
-    const size_t lds = sampler_lds_bytes(ctx->model, FS == 1);
+    const size_t lds = sampler_lds_bytes(ctx->model, FS == 1, BF_SAMPLER_WAVES(W, FULLM, FS));
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS);
@@ -1905,7 +1906,7 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         // tile k-steps and the eight-wave form wins at every chain count -- 1.41 against 1.30 x 10^8 at 4096 chains; at 1800 tile
         // k-steps, a quadratic config on 20 inputs, the sixteen-wave form's full tiles win, 8.2 against 7.3 x 10^7)
         const long gemm_steps = (long)m.pld.NT1 * m.pld.NS1 + (long)m.pld.NT2 * m.pld.NS2;
-        const bool w8 = g_pld_waves ? g_pld_waves == 8 : (args.n_chain <= 8 * ctx->n_cu || gemm_steps <= 800);
+        const bool w8 = m.pld.only8 || (g_pld_waves ? g_pld_waves == 8 : (args.n_chain <= 8 * ctx->n_cu || gemm_steps <= 800));
         if (w8 && m.has_transform && m.has_su && m.use_bound && !m.use_decay && !g_no_plain) return launch_sampler_t<WP, NUTS, false, 10>(ctx, args);
         return w8 ? launch_sampler_t<WP, NUTS, false, 9>(ctx, args) : launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
     }
