@@ -37,7 +37,9 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
         pd[PD_HDD * DP + i] = 1.;
     }
     // (tuning switch: BFHIP_NO_PROOF_WEIGHTS=1 keeps the plain norm in both proofs)
-    static const bool no_weights = [] { const char *e = getenv("BFHIP_NO_PROOF_WEIGHTS"); return e && atoi(e) != 0; }();
+    // (read at every upload: the switch may change inside a process, and this header is compiled into several objects)
+    const char *nw_env = getenv("BFHIP_NO_PROOF_WEIGHTS");
+    const bool no_weights = nw_env && atoi(nw_env) != 0;
     if (ds->use_bound) {   // the weights of the bound proof's norm (bf_bound_lam_max_weighted)
         bool ok = !no_weights;
         for (int i = 0; i < d; ++i) ok = ok && ds->hess[(size_t)i * d + i] > 0. && std::isfinite(ds->hess[(size_t)i * d + i]);

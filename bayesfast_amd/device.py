@@ -338,7 +338,10 @@ class DeviceDensity:
         self.upload()
 
     def upload(self):
-        """Make this density the context's current one (a context holds one density at a time)."""
+        """Make this density the context's current one (a context holds one density at a time).  An upload that is refused may
+        have replaced the context's density already (the pipeline upload runs the density upload first): the context then has NO
+        current density, and whichever density is used next uploads itself again."""
+        self.ctx._current_density = None
         if self.spec.get('chi2') is not None:   # [multi-output surrogate, Gaussian likelihood, optional prior]: bfhip_pipeline_upload
             ds, keep = pipeline_desc_from_spec(self.spec)
             _lib.check(self.ctx._lib.bfhip_pipeline_upload(self.ctx.handle, C.byref(ds)))

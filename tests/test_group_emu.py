@@ -217,6 +217,45 @@ def test_group_kernel_feature_sets_match_oracle(samp, decay, bounds, d):
         np.testing.assert_allclose(s[i][:5], so[:5], rtol=1e-8, atol=1e-8)
 
 
+@pytest.mark.parametrize('case', ['scales_1e3', 'scales_small_alpha', 'scales_decay', 'scales_1e5_split'])
+def test_group_kernel_folded_input_scales_weighted_proof_and_linearity_match_oracle(case):
+    """The upload paths of round 4 on the CPU (device.py: density_desc_from_spec), through the group and split kernels' host
+    emulation: Surrogate.input_scales folded into the coefficients, the bound's centre and Hessian (a Hessian seen through
+    per-dimension scales spread over three to five decades: the weighted bound proof), the bound shrunk so that leaves sit outside
+    it (S x_0 by linearity, bfhip_oob.h), and the decay term on top.  The oracle evaluates the unfolded density."""
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    d = 24
+    spec = dict(correlated_gaussian_spec(d, fit_scale=1.5)[0])
+    rng = np.random.default_rng(31)
+    spread = 5. if case == 'scales_1e5_split' else 3.
+    diff = 10.**rng.uniform(-spread / 2., spread / 2., size=d)
+    lo = rng.normal(size=d) * diff * 0.5
+    spec.update(su_lo=lo, su_diff=diff)
+    po = dict(spec['poly'])
+    if case == 'scales_small_alpha':
+        po['alpha'] = 0.35 * float(po['alpha'])   # most leaves outside the bound
+    spec['poly'] = po
+    if case == 'scales_decay':
+        # (the decay term lives in the original space: its ellipsoid is the bound's seen through the scales)
+        mu_o = lo + diff * np.asarray(po['mu'])
+        hess_o = np.asarray(po['hess']) / np.outer(diff, diff)
+        spec.update(use_decay=True, decay_mu=mu_o + 0.05 * diff, decay_hess=hess_o, decay_alpha2=(0.8 * float(po['alpha']))**2, decay_gamma=0.1)
+    x0 = lo + diff * (rng.normal(size=(4, d)) * 0.6)
+    kw = dict(layout='split') if case == 'scales_1e5_split' else {}
+    step = 0.5 * float(diff.min())   # (identity metric at the start: the step the narrowest direction takes)
+    dev = _emu(spec, x0, 9, 6, step_size=step, **kw)
+    orc_runs = _oracle(spec, x0, 9, 6, step_size=step)
+    s, st, ec = dev
+    for i, (so, sto, ch) in enumerate(orc_runs):
+        for f in ('tree_depth', 'tree_size', 'diverging'):
+            assert np.array_equal(st[f][i], sto[f]), (case, i, f, st[f][i], sto[f])
+        np.testing.assert_allclose((s[i][:6] - lo) / diff, (so[:6] - lo) / diff, rtol=1e-7, atol=1e-7, err_msg='chain %d' % i)
+        np.testing.assert_allclose(st['logp'][i][:6], sto['logp'][:6], rtol=1e-8, atol=1e-7)
+    if case == 'scales_small_alpha':
+        from oracle import oracle as orc
+        assert dev[1]['tree_size'].sum() > 0
+
+
 def test_group_kernel_bad_initial_energy_sets_error_flag(samp):
     """Non-finite initial energy is an error, not a divergence (base_hmc.py:72-76): error code 1, nothing sampled."""
     spec = _spec(samp, 'plain16.')
