@@ -135,6 +135,34 @@ class BfhipError(RuntimeError):
     pass
 
 
+# ---- test / tuning switches (include/bfhip_debug.h): used by tests/, tools/ and bench.py's measurement legs only ----
+def debug_set(key, value):
+    """One of the library's integer switches by name (process-wide)."""
+    f = lib().bfhip_debug_set
+    f.restype, f.argtypes = C.c_int, [C.c_char_p, C.c_longlong]
+    check(f(key.encode(), int(value)))
+
+
+def debug_get(key):
+    f = lib().bfhip_debug_get
+    f.restype, f.argtypes = C.c_longlong, [C.c_char_p]
+    return int(f(key.encode()))
+
+
+def debug_buffer(key, tensor_or_none):
+    """Attach (a device tensor) or detach (None) one of the measurement buffers."""
+    f = lib().bfhip_debug_buffer
+    f.restype, f.argtypes = C.c_int, [C.c_char_p, C.c_void_p]
+    check(f(key.encode(), None if tensor_or_none is None else C.c_void_p(tensor_or_none.data_ptr())))
+
+
+def last_kernel():
+    """The kernel the last bfhip_sampler_run dispatched to."""
+    f = lib().bfhip_debug_last_kernel
+    f.restype = C.c_char_p
+    return f().decode()
+
+
 def check(rc):
     if rc != 0:
         msg = lib().bfhip_last_error().decode()

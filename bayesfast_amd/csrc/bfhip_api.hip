@@ -18,6 +18,66 @@ int bf_set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+// ---- test / tuning switches (include/bfhip_debug.h, bfhip_tune.h) ----
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+BfTune &bf_tune() {
+    static BfTune t = [] {
+        BfTune u;
+        memset(&u, 0, sizeof(u));
+        const char *nk = getenv("BFHIP_NUTS_KERNEL");
+        u.no_group = env_int("BFHIP_NO_GROUP", (nk && (!strcmp(nk, "sliced") || !strcmp(nk, "pipe"))) ? 1 : 0);
+        u.no_pipe = env_int("BFHIP_NO_PIPE", (nk && !strcmp(nk, "sliced")) ? 1 : 0);
+        u.no_plain = env_int("BFHIP_NO_PLAIN", 0);
+        u.no_quad = env_int("BFHIP_NO_QUAD", 0);
+        u.wave_cpg = env_int("BFHIP_WAVE_CPG", 0);
+        u.tail_relaunch = env_int("BFHIP_TAIL_RELAUNCH", 1);
+        u.tail_stop = env_int("BFHIP_TAIL_STOP", 4);
+        u.tail_q = env_int("BFHIP_TAIL_Q", 3);
+        u.tail_max = env_int("BFHIP_TAIL_MAX", 4);
+        u.lone = env_int("BFHIP_LONE", 1);
+        u.pld_waves = env_int("BFHIP_PLD_WAVES", 0);
+        u.no_vel_ahead = env_int("BFHIP_NO_VEL_AHEAD", 0);
+        u.tnuts_wpb = env_int("BFHIP_TNUTS_WPB", 0);
+        u.no_bound_proof = env_int("BFHIP_NO_BOUND_PROOF", 0);
+        u.no_proof_weights = env_int("BFHIP_NO_PROOF_WEIGHTS", 0);
+        u.pld_no_compress = env_int("BFHIP_PLD_NO_COMPRESS", 0);
+        return u;
+    }();
+    return t;
+}
+static int *tune_field(const char *key) {
+    BfTune &t = bf_tune();
+    struct { const char *k; int *p; } tab[] = {
+        {"no_group", &t.no_group}, {"no_pipe", &t.no_pipe}, {"no_plain", &t.no_plain}, {"no_quad", &t.no_quad}, {"wave_cpg", &t.wave_cpg},
+        {"tail_relaunch", &t.tail_relaunch}, {"tail_stop", &t.tail_stop}, {"tail_q", &t.tail_q}, {"tail_max", &t.tail_max}, {"lone", &t.lone},
+        {"pld_waves", &t.pld_waves}, {"no_vel_ahead", &t.no_vel_ahead}, {"tnuts_wpb", &t.tnuts_wpb}, {"no_bound_proof", &t.no_bound_proof},
+        {"no_proof_weights", &t.no_proof_weights}, {"pld_no_compress", &t.pld_no_compress}};
+    for (auto &e : tab)
+        if (key && !strcmp(key, e.k)) return e.p;
+    return NULL;
+}
+extern "C" int bfhip_debug_set(const char *key, long long value) {
+    int *f = tune_field(key);
+    if (!f) return bf_set_error(BFHIP_ERR_ARG, "bfhip_debug_set: unknown switch '%s'", key ? key : "(null)");
+    *f = (int)value;
+    return 0;
+}
+extern "C" long long bfhip_debug_get(const char *key) {
+    const int *f = tune_field(key);
+    return f ? *f : 0;
+}
+extern "C" int bfhip_debug_buffer(const char *key, void *device_ptr) {
+    BfTune &t = bf_tune();
+    unsigned long long *p = (unsigned long long *)device_ptr;
+    if (key && !strcmp(key, "stamps")) t.stamps = p;
+    else if (key && !strcmp(key, "stamps_lone")) t.stamps_lone = p;
+    else if (key && !strcmp(key, "gstamps")) t.gstamps = p;
+    else if (key && !strcmp(key, "group_counters")) t.group_counters = p;
+    else return bf_set_error(BFHIP_ERR_ARG, "bfhip_debug_buffer: unknown buffer '%s'", key ? key : "(null)");
+    return 0;
+}
+extern "C" const char *bfhip_debug_last_kernel(void) { return bf_tune().last_kernel; }
+
 extern "C" int bfhip_version(void) { return 100; }
 extern "C" const char *bfhip_last_error(void) { return g_err; }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../include/bfhip.h"
 #include "bfhip_model.h"
+#include "bfhip_tune.h"
 
 // ---- wave helpers ---------------------------------------------------------------------------------
 __device__ inline double bf_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }

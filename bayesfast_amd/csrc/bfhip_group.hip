@@ -6,11 +6,9 @@
 #include "bfhip_split.h"
 
 // measurement hook (not part of include/bfhip.h): device buffer of two counters, trips and trips with the bound's tiles
-static unsigned long long *g_gcount = NULL;
-extern "C" void bfhip_debug_group_counters(unsigned long long *buf) { g_gcount = buf; }
-static unsigned long long *g_gcount_ptr() { return g_gcount; }
-static unsigned long long *g_gstamps_ptr();
-int bf_no_bound_proof();
+static unsigned long long *g_gcount_ptr() { return bf_tune().group_counters; }
+static unsigned long long *g_gstamps_ptr() { return bf_tune().gstamps; }
+int bf_no_bound_proof() { return bf_tune().no_bound_proof; }
 
 template <int W, bool NUTS, int FS>
 __global__ __launch_bounds__(64 * W) void bf_group_kernel(DevModel m, SamplerArgs a) {
@@ -108,21 +106,15 @@ bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {
 int bf_group_scratch_slots(int DP) { return 5 * (BFHIP_MAX_TREEDEPTH - 2); }
 
 // tuning hook (not part of include/bfhip.h): cycle stamps of workgroup 0's first trips, see GTRACE in bfhip_group.h
-static unsigned long long *g_gstamps = NULL;
-extern "C" void bfhip_debug_gstamps(unsigned long long *buf) { g_gstamps = buf; }
-static unsigned long long *g_gstamps_ptr() { return g_gstamps; }
 
 // test hook (not part of include/bfhip.h): 1 = never skip the bound's tiles (the results must not change)
-static int g_no_bound_proof = 0;
-extern "C" void bfhip_debug_no_bound_proof(int on) { g_no_bound_proof = on; }
-int bf_no_bound_proof() { return g_no_bound_proof; }
 
 
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
-    args.gcount = g_gcount;
-    args.stamps = g_gstamps;
-    args.no_bound_proof = g_no_bound_proof;
+    args.gcount = bf_tune().group_counters;
+    args.stamps = bf_tune().gstamps;
+    args.no_bound_proof = bf_tune().no_bound_proof;
     const DevModel &m = ctx->model;
     const bool nuts = args.cfg.sampler == 0;
     const int fs = 1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0);

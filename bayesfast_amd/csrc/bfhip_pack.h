@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "bfhip_model.h"
+#include "bfhip_tune.h"
 
 static inline int padded_tiles(int d) { return d <= 16 ? 1 : d <= 32 ? 2 : d <= 64 ? 4 : 8; }
 
@@ -37,9 +38,7 @@ static inline int bf_pack_density(const bfhip_density_desc *ds, std::vector<doub
         pd[PD_HDD * DP + i] = 1.;
     }
     // (tuning switch: BFHIP_NO_PROOF_WEIGHTS=1 keeps the plain norm in both proofs)
-    // (read at every upload: the switch may change inside a process, and this header is compiled into several objects)
-    const char *nw_env = getenv("BFHIP_NO_PROOF_WEIGHTS");
-    const bool no_weights = nw_env && atoi(nw_env) != 0;
+    const bool no_weights = bf_tune().no_proof_weights != 0;   // (tuning switch: the plain norm in both proofs)
     if (ds->use_bound) {   // the weights of the bound proof's norm (bf_bound_lam_max_weighted)
         bool ok = !no_weights;
         for (int i = 0; i < d; ++i) ok = ok && ds->hess[(size_t)i * d + i] > 0. && std::isfinite(ds->hess[(size_t)i * d + i]);

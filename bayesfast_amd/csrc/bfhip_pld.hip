@@ -147,7 +147,7 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     // bound, where b = (beta - alpha) / alpha is not zero).  At the DES shape (m = 457, nf = 73) both contractions shrink 6.3x.
     double k_ff = 0., k_fy = 0., k_yy = 0.;
     int m_eff = m;
-    const bool compress = !(getenv("BFHIP_PLD_NO_COMPRESS") && atoi(getenv("BFHIP_PLD_NO_COMPRESS"))) && m > nf;
+    const bool compress = !bf_tune().pld_no_compress && m > nf;
     if (compress) {
         // Householder QR of the m x nf block of Cw, in place; the reflectors are applied to yw and fmuw as they are formed
         std::vector<double> v(m);

@@ -1640,13 +1640,9 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #include "bfhip_nuts_pipe.h"
 #include "bfhip_lone.h"
 
-static int g_tail_max = 4;  // tuning / test hook: 0 disables the VALU matvec of the plain kernel
-extern "C" void bfhip_debug_tail_max(int v) { g_tail_max = v; }
-static bool g_no_plain = false;  // tuning hook: force the generic instantiation
-extern "C" void bfhip_debug_no_plain(int v) { g_no_plain = v != 0; }
 // the common surrogate: linear + quadratic configs with the extrapolation bound and nothing else
 static bool sampler_plain(const DevModel &m) {
-    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
+    return m.has_quad && m.use_bound && !m.use_decay && !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link && !(bf_tune().no_plain != 0);
 }
 
 // K-split of the matvec jobs: the largest power of two KS <= W with n_mat * W * KS <= 16
@@ -1693,13 +1689,9 @@ size_t bf_sampler_lds_bytes_base(const DevModel &m) { return ((sampler_lds_base(
 // trip is its matvec jobs -- the same MFMAs whatever the number of columns in use -- plus the bookkeeping of the chains'
 // waves, which share four SIMDs.  When the chains do not fill the chip at 16 per workgroup, fewer chains per workgroup
 // on more CUs shorten the trip: the waves without a chain still take their share of the jobs.  (Results do not depend on
-// it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG / bfhip_debug_wave_cpg override (tests, tuning).
-static int g_no_quad = [] { const char *e = getenv("BFHIP_NO_QUAD"); return e ? atoi(e) : 0; }();
-extern "C" void bfhip_debug_no_quad_tiles(int v) { g_no_quad = v; }  // test / tuning hook: 16-column tiles whatever the number of chains
-static int g_wave_cpg = [] { const char *e = getenv("BFHIP_WAVE_CPG"); return e ? atoi(e) : 0; }();
-extern "C" void bfhip_debug_wave_cpg(int v) { g_wave_cpg = v; }  // test / tuning hook (0: automatic)
+// it: a chain's arithmetic never involves its neighbours'.)  BFHIP_WAVE_CPG / bfhip_debug_set("wave_cpg") override (tests, tuning).
 static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
-    const int forced = g_wave_cpg;
+    const int forced = bf_tune().wave_cpg;
     if (forced > 0) return forced < nwv ? forced : nwv;
     int cpg = nwv;
     while (cpg > 1 && (n_chain + cpg / 2 - 1) / (cpg / 2) <= ctx->n_cu) cpg /= 2;
@@ -1724,8 +1716,6 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
 
 // test / tuning hook: NUTS on the common surrogate through bf_sampler_kernel instead of the pipelined kernel
 // (also selected by the environment variable BFHIP_NUTS_KERNEL=sliced)
-static bool g_no_pipe = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && !strcmp(e, "sliced"); }();
-extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 
 // The tail of a launch.  A launch of the wave-per-chain kernel lasts as long as its busiest chain, and at its end most workgroups
 // hold one or two unfinished chains on 16-column tiles.  Sixteen-chain launches therefore run in two parts: in the first a
@@ -1734,9 +1724,7 @@ extern "C" void bfhip_debug_no_pipe(int v) { g_no_pipe = v != 0; }
 // chain waits for the first part to end: worth it for a straggler in the tail, not for a chain that is merely last); a small kernel
 // lists the chains that have iterations left; the second part runs those, one to four per workgroup on 4 x 4 x 4 tiles (a lone
 // chain's leapfrog step: 2.97 against 3.90 us, tools/lone_funnel.py).  A chain's numbers depend neither on where it is cut (as
-// between any two launches) nor on its workgroup.  bfhip_debug_tail_relaunch(0) / BFHIP_TAIL_RELAUNCH=0: one part (tests compare).
-static int g_tail_relaunch = [] { const char *e = getenv("BFHIP_TAIL_RELAUNCH"); return e ? atoi(e) : 1; }();
-extern "C" void bfhip_debug_tail_relaunch(int v) { g_tail_relaunch = v; }
+// between any two launches) nor on its workgroup.  bfhip_debug_set("tail_relaunch", 0) / BFHIP_TAIL_RELAUNCH=0: one part (tests compare).
 // test hook: how many chains the last two-part launch listed for its second part (synchronises), -1 without one
 extern "C" int bfhip_debug_tail_count(bfhip_ctx *ctx) {
     if (!ctx || !ctx->tail_buf) return -1;
@@ -1745,13 +1733,9 @@ extern "C" int bfhip_debug_tail_count(bfhip_ctx *ctx) {
     if (hipMemcpy(&n, ctx->tail_buf, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return n;
 }
-static int g_lone = [] { const char *e = getenv("BFHIP_LONE"); return e ? atoi(e) : 1; }();
-extern "C" void bfhip_debug_lone(int v) { g_lone = v; }
-static int g_tail_stop = [] { const char *e = getenv("BFHIP_TAIL_STOP"); return e ? atoi(e) : 4; }();   // (tuning: 1 .. 16; 1 .. 4 without the latency kernel)
-static int g_tail_q = [] { const char *e = getenv("BFHIP_TAIL_Q"); return e ? atoi(e) : 3; }();         // (tuning: quarters of the chains that must be through, 1 .. 4)
 static int tail_stop_now() {
-    const int hi = g_lone ? 16 : 4;   // (the few-chain instantiation of the second part takes four chains of every first-part workgroup at most)
-    return g_tail_stop < 1 ? 1 : (g_tail_stop > hi ? hi : g_tail_stop);
+    const int hi = bf_tune().lone ? 16 : 4;   // (the few-chain instantiation of the second part takes four chains of every first-part workgroup at most)
+    return bf_tune().tail_stop < 1 ? 1 : (bf_tune().tail_stop > hi ? hi : bf_tune().tail_stop);
 }
 
 __global__ void bf_tail_list_kernel(int n_chain, int iter_end, const double *sc, int *buf) {
@@ -1761,17 +1745,12 @@ __global__ void bf_tail_list_kernel(int n_chain, int iter_end, const double *sc,
     if ((int)scp[BFHIP_SC_I_ITER] < iter_end && (int)scp[BFHIP_SC_ERROR] == 0) buf[2 + atomicAdd(buf, 1)] = i;   // buf: count | done | list
 }
 
-// measurement hook (not part of include/bfhip.h): the kernel the last bfhip_sampler_run dispatched to
-static char g_last_kernel[96] = "";
-extern "C" const char *bfhip_debug_last_kernel(void) { return g_last_kernel; }
 
 // The latency kernel (bfhip_lone.h): one chain per workgroup of 2 + W waves.  It serves the second part of a two-part launch
 // (the chains listed in tail_buf) and whole launches whose chains all fit the chip at once -- every workgroup must be resident,
-// a chain that waited for a slot would double the launch.  g_lone: 1 automatic, 0 never, 2 wherever it is implemented
+// a chain that waited for a slot would double the launch.  bf_tune().lone: 1 automatic, 0 never, 2 wherever it is implemented
 // (tests: any chain count, in as many rounds as it takes).
 
-static unsigned long long *g_stamps_lone = NULL;   // tuning builds (-DBF_LTRACE): cycle stamps of workgroup 0's integrator and bookkeeper
-extern "C" void bfhip_debug_stamps_lone(unsigned long long *buf) { g_stamps_lone = buf; }
 
 // the second instantiation's waves per SIMD: 4 (W + 1) waves a CU at d <= 32, 2 x 5 at d <= 64
 template <int W> struct LoneOcc { static constexpr int MINW = W == 1 ? 2 : 3; };   // (W = 4: two workgroups of five waves a CU)
@@ -1791,25 +1770,25 @@ static int lone_blocks_per_cu(bfhip_ctx *ctx, bool roomy) {
 // returns 1 when the launch was taken, 0 when the caller should use the pipelined kernel, < 0 on error
 template <int W, bool TR, bool DEC>
 static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks, bool tail) {
-    if (!g_lone || args_in.stamps) return 0;
+    if (!bf_tune().lone || args_in.stamps) return 0;
     SamplerArgs args = args_in;
     args.n_cu = ctx->n_cu;
     args.tail_stop = 0;
     args.tail_done = NULL;
     if (!tail) { args.tail_list = NULL; args.tail_count = NULL; }
-    args.stamps = g_stamps_lone;
+    args.stamps = bf_tune().stamps_lone;
     const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
     // the roomy instantiation when every workgroup still fits, the tighter one otherwise
     const int need = (n_blocks + ctx->n_cu - 1) / ctx->n_cu;
     bool roomy = true;
     if (lone_blocks_per_cu<W, TR, DEC>(ctx, true) < need) {
         roomy = false;
-        if (lone_blocks_per_cu<W, TR, DEC>(ctx, false) < need && g_lone != 2 && !tail) return 0;
+        if (lone_blocks_per_cu<W, TR, DEC>(ctx, false) < need && bf_tune().lone != 2 && !tail) return 0;
     }
     if (roomy) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1>), dim3(n_blocks), dim3(LoneWaves<W, DEC>::NW * 64), lds, ctx->stream, ctx->model, args);
     else hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>), dim3(n_blocks), dim3(LoneWaves<W, DEC>::NW * 64), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
-    if (!tail) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", roomy ? 1 : LoneOcc<W>::MINW);
+    if (!tail) snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", roomy ? 1 : LoneOcc<W>::MINW);
     return 1;
 }
 
@@ -1824,9 +1803,9 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     args.n_cu = ctx->n_cu;
     // (at most four / eight chains in a workgroup: 4 x 4 x 4 MFMA tiles)
     constexpr bool CANQ = true;
-    auto k = (CANQ && args.cpg <= 4 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
-             : ((CANQ && args.cpg <= 8 && !g_no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
-    if ((args.cpg <= 4 && !g_no_quad && g_wave_cpg == 0) || g_lone == 2) {
+    auto k = (CANQ && args.cpg <= 4 && !bf_tune().no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
+             : ((CANQ && args.cpg <= 8 && !bf_tune().no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
+    if ((args.cpg <= 4 && !bf_tune().no_quad && bf_tune().wave_cpg == 0) || bf_tune().lone == 2) {
         const int r = launch_lone<W, TR, DEC>(ctx, args, args.n_chain, false);
         if (r != 0) return r < 0 ? r : 0;
     }
@@ -1834,7 +1813,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
-    const bool two_parts = g_tail_relaunch && args.cpg == 16 && !g_no_quad && !args.stamps;
+    const bool two_parts = bf_tune().tail_relaunch && args.cpg == 16 && !bf_tune().no_quad && !args.stamps;
     if (two_parts) {
         if (ctx->tail_cap < args.n_chain + 2) {
             BF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1845,7 +1824,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
             ctx->tail_cap = args.n_chain + 2;
         }
         args.tail_stop = tail_stop_now();
-        args.tail_q = g_tail_q < 1 ? 1 : (g_tail_q > 4 ? 4 : g_tail_q);
+        args.tail_q = bf_tune().tail_q < 1 ? 1 : (bf_tune().tail_q > 4 ? 4 : bf_tune().tail_q);
         args.tail_done = ctx->tail_buf + 1;
         BF_HIP_CHECK(hipMemsetAsync(ctx->tail_buf, 0, 2 * sizeof(int), ctx->stream));
     }
@@ -1879,19 +1858,12 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
 
 // test / tuning hook: keep NUTS / HMC on the common surrogate off the group kernel (bfhip_group.hip), i.e. on the
 // kernels of this file (also selected by BFHIP_NUTS_KERNEL=sliced or =pipe)
-static bool g_no_group = [] { const char *e = getenv("BFHIP_NUTS_KERNEL"); return e && (!strcmp(e, "sliced") || !strcmp(e, "pipe")); }();
-extern "C" void bfhip_debug_no_group(int v) { g_no_group = v != 0; }
 
 
-static unsigned long long *g_stamps = NULL;
 // diagnostics hook (not part of include/bfhip.h): per-wave cycle counters of the sampler kernel's phases
-extern "C" void bfhip_debug_stamps(unsigned long long *buf) { g_stamps = buf; }
 
 // test / tuning hook (not part of include/bfhip.h; also BFHIP_PLD_WAVES): 8 or 16 waves per workgroup for the pipeline density, 0 = by chain count
-static int g_pld_waves = [] { const char *e = getenv("BFHIP_PLD_WAVES"); return e ? atoi(e) : 0; }();
-extern "C" void bfhip_debug_pld_waves(int v) { g_pld_waves = v; }
 
-static bool g_no_vel_ahead = [] { const char *e = getenv("BFHIP_NO_VEL_AHEAD"); return e && atoi(e); }();   // tuning / test switch
 
 template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
@@ -1906,8 +1878,8 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         // tile k-steps and the eight-wave form wins at every chain count -- 1.41 against 1.30 x 10^8 at 4096 chains; at 1800 tile
         // k-steps, a quadratic config on 20 inputs, the sixteen-wave form's full tiles win, 8.2 against 7.3 x 10^7)
         const long gemm_steps = (long)m.pld.NT1 * m.pld.NS1 + (long)m.pld.NT2 * m.pld.NS2;
-        const bool w8 = m.pld.only8 || (g_pld_waves ? g_pld_waves == 8 : (args.n_chain <= 8 * ctx->n_cu || gemm_steps <= 800));
-        if (w8 && m.has_transform && m.has_su && m.use_bound && !m.use_decay && !g_no_plain) return launch_sampler_t<WP, NUTS, false, 10>(ctx, args);
+        const bool w8 = m.pld.only8 || (bf_tune().pld_waves ? bf_tune().pld_waves == 8 : (args.n_chain <= 8 * ctx->n_cu || gemm_steps <= 800));
+        if (w8 && m.has_transform && m.has_su && m.use_bound && !m.use_decay && !(bf_tune().no_plain != 0)) return launch_sampler_t<WP, NUTS, false, 10>(ctx, args);
         return w8 ? launch_sampler_t<WP, NUTS, false, 9>(ctx, args) : launch_sampler_t<WP, NUTS, false, 8>(ctx, args);
     }
     if (args.mat) {   // (a compile-time feature set changes nothing here: 7.4 x 10^7 either way)
@@ -1915,7 +1887,7 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         // velocity-ahead pass costs more than the pass it saves (3.0 against 3.3 x 10^7, tools/full_metric_rate.py); afterwards it
         // is worth a fifth (7.4 -> 8.9 x 10^7).  Both forms in one kernel were slower than either.  The same numbers from both.
         const bool adapting = args.cfg.adapt_metric && args.iter_out0 < args.cfg.n_warmup;
-        return (adapting || g_no_vel_ahead) ? launch_sampler_t<W, NUTS, false, 0, 1>(ctx, args) : launch_sampler_t<W, NUTS, false, 0, 2>(ctx, args);
+        return (adapting || (bf_tune().no_vel_ahead != 0)) ? launch_sampler_t<W, NUTS, false, 0, 1>(ctx, args) : launch_sampler_t<W, NUTS, false, 0, 2>(ctx, args);
     }
 #ifndef BF_TRACE
     if (W == 4 && NUTS && args.stamps)  // diagnostic build, d <= 64 NUTS only
@@ -1927,28 +1899,28 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
 #else
     const bool stamped = args.stamps != NULL;
 #endif
-    if (plain && NUTS && W <= 4 && !g_no_pipe && !stamped)
+    if (plain && NUTS && W <= 4 && !(bf_tune().no_pipe != 0) && !stamped)
         return launch_nuts_pipe<(W <= 4 ? W : 1)>(ctx, args);
     if (plain) return launch_sampler_t<W, NUTS, false, 1>(ctx, args);
     // ... and the same surrogate behind the constraint transform (bounded parameters)
-    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !stamped && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
+    if (W <= 4 && NUTS && !(bf_tune().no_pipe != 0) && !(bf_tune().no_plain != 0) && !stamped && m.has_quad && m.use_bound && m.has_transform && !m.use_decay &&
         !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
     // ... and with the decay penalty (the GBS recipes' densities: configs 3 and 4)
-    if (W <= 4 && NUTS && !g_no_pipe && !g_no_plain && !stamped && m.has_quad && m.use_bound && m.use_decay &&
+    if (W <= 4 && NUTS && !(bf_tune().no_pipe != 0) && !(bf_tune().no_plain != 0) && !stamped && m.has_quad && m.use_bound && m.use_decay &&
         !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link)
         return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4)>(ctx, args);
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
     // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)
-    if (W == 4 && !g_no_plain && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link) {
+    if (W == 4 && !(bf_tune().no_plain != 0) && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link) {
         constexpr int W4 = W == 4 ? 4 : W;  // (keeps the other W from instantiating these)
         if (m.use_decay && m.has_transform) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 7 : 0)>(ctx, args);
         if (m.use_decay) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 3 : 0)>(ctx, args);
         if (m.has_transform) return launch_sampler_t<W4, NUTS, false, (W == 4 ? 5 : 0)>(ctx, args);
     }
     // d = 128 with cubic configs and nothing else (config 5): the feature set fixed at compile time too
-    if (W == 8 && NUTS && !g_no_plain && m.has_quad && m.use_bound && m.has_cubic && !m.use_decay && !m.has_transform && !m.has_su &&
+    if (W == 8 && NUTS && !(bf_tune().no_plain != 0) && m.has_quad && m.use_bound && m.has_cubic && !m.use_decay && !m.has_transform && !m.has_su &&
         !m.has_link)
         return launch_sampler_t<(W == 8 ? 8 : W), NUTS, false, (W == 8 && NUTS ? 16 : 0)>(ctx, args);
 #endif
@@ -1975,14 +1947,14 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     SamplerArgs args;
     args.cpg = 0;
     args.cub_lds = 0;
-    args.no_quad = g_no_quad;
+    args.no_quad = bf_tune().no_quad;
     args.cfg = *cfg;
     args.n_chain = n_chain;
     args.iter_end = iter_end;
     args.iter_out0 = iter_out0;
     args.n_out = n_out;
     args.nslot = SL_PIPE_N;  // both ends, proposal, p_sum, 4 vectors per stack level (+ the proposals' gradients: pipelined kernel)
-    args.tail_max = g_tail_max;
+    args.tail_max = bf_tune().tail_max;
     args.ks = sampler_ksplit(m);
     args.gbn = sampler_gb_slots(m);
     args.rng = rng;
@@ -1991,7 +1963,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     args.samples = samples;
     args.stats = stats;
     args.n_leapfrog = n_leapfrog;
-    args.stamps = g_stamps;
+    args.stamps = bf_tune().stamps;
     args.no_bound_proof = bf_no_bound_proof();
     args.gcount = NULL;
     args.mat = (cfg->full_metric && cfg->metric_mat) ? cfg->metric_mat : NULL;
@@ -2010,23 +1982,23 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     // the common surrogate (linear + quadratic configs with the bound; decay and constraint transform optional) at
     // d <= 64 with the diagonal metric: the group kernel
     if (cfg->chain_layout < 0 || cfg->chain_layout > 3) return bf_set_error(BFHIP_ERR_ARG, "chain_layout should be 0, 1, 2 or 3");
-    if (cfg->chain_layout == 3 && !g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_split_supports(m, args)) {
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_split_kernel<%d>", W);
+    if (cfg->chain_layout == 3 && !(bf_tune().no_group != 0) && !(bf_tune().no_pipe != 0) && !(bf_tune().no_plain != 0) && !args.stamps && bf_split_supports(m, args)) {
+        snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_split_kernel<%d>", W);
         return bf_launch_split(ctx, args);
     }
     const bool want_group = cfg->chain_layout == 1 || cfg->chain_layout == 3 || (cfg->chain_layout == 0 && !nuts);
-    if (want_group && !g_no_group && !g_no_pipe && !g_no_plain && !args.stamps && bf_group_supports(m, args)) {
-        snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_group_kernel<%d, %s, %d>", W, nuts ? "true" : "false",
+    if (want_group && !(bf_tune().no_group != 0) && !(bf_tune().no_pipe != 0) && !(bf_tune().no_plain != 0) && !args.stamps && bf_group_supports(m, args)) {
+        snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_group_kernel<%d, %s, %d>", W, nuts ? "true" : "false",
                  1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0));
         return bf_launch_group(ctx, args);
     }
     {
         // (the conditions of launch_sampler: the common surrogate, plain or behind the constraint transform)
-        const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !g_no_plain;
+        const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !(bf_tune().no_plain != 0);
         const bool tr_only = common && m.has_transform && !m.use_decay, dec_only = common && m.use_decay && !m.has_transform;
-        const bool pipe = nuts && W <= 4 && !g_no_pipe && !args.mat && !args.stamps && (sampler_plain(m) || tr_only || dec_only);
-        if (m.pld.on) snprintf(g_last_kernel, sizeof(g_last_kernel), "bf_sampler_kernel<%d, %s, false, 8 | 9>", W, nuts ? "true" : "false");
-        else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
+        const bool pipe = nuts && W <= 4 && !(bf_tune().no_pipe != 0) && !args.mat && !args.stamps && (sampler_plain(m) || tr_only || dec_only);
+        if (m.pld.on) snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_sampler_kernel<%d, %s, false, 8 | 9>", W, nuts ? "true" : "false");
+        else snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "%s<%d, ...>", pipe ? "bf_nuts_pipe_kernel" : "bf_sampler_kernel", W);
     }
     switch (W) {
 #ifndef BF_ONLY_HEADLINE  // tuning builds (-DBF_ONLY_HEADLINE) compile the 64-d instantiations only

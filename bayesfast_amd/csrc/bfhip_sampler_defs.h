@@ -6,7 +6,7 @@ struct SamplerArgs {
     bfhip_sampler_config cfg;
     int n_chain, iter_end, iter_out0, n_out, nslot;
     int cpg;       // wave-per-chain kernels: chains per workgroup (0: one per wave), bfhip_sampler.hip: wave_layout_cpg
-    int no_quad;   // bf_sampler_kernel: 16-column tiles even with at most four chains in the workgroup (bfhip_debug_no_quad_tiles: tests)
+    int no_quad;   // bf_sampler_kernel: 16-column tiles even with at most four chains in the workgroup (bfhip_debug_set("no_quad"): tests)
     int cub_lds;   // bf_sampler_kernel: the cubic coefficient tables are staged in LDS (sampler_cubic_lds)
     int tail_max;  // plain kernel: at most this many evaluating chains of a group take the VALU matvec (0: never)
     int ks, gbn;  // K-split of the matvec jobs (so that all 16 waves get one) and the number of result slots
@@ -16,7 +16,7 @@ struct SamplerArgs {
     double *scratch;
     double *mat;  // full-rank metric: [n_chain][BF_MAT_N][d][d] (transposed storage, bfhip_metric.h), or NULL
     unsigned long long *gcount;  // group kernel, measurement only: [0] += trips, [1] += trips that ran the bound's tiles, [2] += trips with a late exchange, [3] += trips without the early one (4 words, or NULL)
-    int no_bound_proof;          // group kernel, tests only: always compute the H (x - mu) tiles (bfhip_debug_no_bound_proof)
+    int no_bound_proof;          // group kernel, tests only: always compute the H (x - mu) tiles (bfhip_debug_set("no_bound_proof"))
     // bf_nuts_pipe_kernel, the launch's tail (bfhip_sampler.hip: launch_nuts_pipe): tail_stop > 0 -- a workgroup with at most that
     // many unfinished chains lets each of them stop at the end of its iteration; tail_list / tail_count -- the chains of THIS launch
     // (the ones that stopped), tail_count[0] of them, one to four per workgroup (n_cu decides)
@@ -46,7 +46,7 @@ int bf_pld_logp_grad(struct bfhip_ctx *ctx, int n, const double *x, int original
 struct bfhip_ctx;
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args);
 int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args);
-int bf_no_bound_proof();  // test hook state (bfhip_debug_no_bound_proof, bfhip_group.hip)
+int bf_no_bound_proof();  // test hook state (bfhip_debug_set("no_bound_proof"))
 // bfhip_split.h: NUTS on the plain common surrogate at 33 <= d <= 64, integrator and bookkeeper waves (chain_layout 3)
 bool bf_split_supports(const DevModel &m, const SamplerArgs &args);
 int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args);

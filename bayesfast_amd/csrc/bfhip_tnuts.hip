@@ -458,8 +458,6 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
     }
 }
 
-static int g_tnuts_wpb = [] { const char *e = getenv("BFHIP_TNUTS_WPB"); return e ? atoi(e) : 0; }();
-extern "C" void bfhip_debug_tnuts_wpb(int v) { g_tnuts_wpb = v; }  // test / tuning hook: chains per workgroup (4, 8; 0: automatic)
 
 extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, const bfhip_tempering *tp, int n_chain, int iter_end,
                                uint64_t *rng, double *sc, double *vec, double *u, int iter_out0, int n_out, double *samples,
@@ -478,8 +476,8 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
         return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_tnuts_run: the tempered sampler covers the common surrogate (linear + quadratic "
                                                    "configs with the bound, no transform / scaling / decay / cubic) at d <= 64 with the diagonal metric");
     // Chains per workgroup (a workgroup is always eight waves, two workgroups per CU: the waves without a chain run matvec jobs
-    // only): eight, or four when that spreads few chains over more CUs.  BFHIP_TNUTS_WPB / bfhip_debug_tnuts_wpb override.
-    const int forced = g_tnuts_wpb;
+    // only): eight, or four when that spreads few chains over more CUs.  BFHIP_TNUTS_WPB / bfhip_debug_set("tnuts_wpb") override.
+    const int forced = bf_tune().tnuts_wpb;
     const int cpg = (forced == 4 || forced == 8) ? forced : (n_chain > 8 * ctx->n_cu ? 8 : 4);
     const size_t need = (size_t)((n_chain + 15) / 16 * 16) * (4 * TN_MAXL) * 64 * sizeof(double);
     if (ctx->scratch_bytes < need) {

@@ -1,0 +1,28 @@
+// bfhip_tune.h -- the library's test / tuning switches in one place (include/bfhip_debug.h is their interface).
+// One process-wide instance (bfhip_api.hip), filled from the environment when first used.
+#pragma once
+
+struct BfTune {
+    // --- kernel selection (all choices give the same results; tests compare them) ---
+    int no_group;        // BFHIP_NO_GROUP / BFHIP_NUTS_KERNEL=sliced|pipe: keep NUTS / HMC off the lane-per-chain kernels
+    int no_pipe;         // BFHIP_NO_PIPE / BFHIP_NUTS_KERNEL=sliced: NUTS on bf_sampler_kernel instead of the pipelined kernel
+    int no_plain;        // BFHIP_NO_PLAIN: the run-time feature set instead of the compile-time instantiations
+    int no_quad;         // BFHIP_NO_QUAD: 16-column tiles whatever the number of chains in a workgroup
+    int wave_cpg;        // BFHIP_WAVE_CPG: chains per workgroup of the wave-per-chain kernels (0: automatic)
+    int tail_relaunch;   // BFHIP_TAIL_RELAUNCH (default 1): the stragglers of a sixteen-chain launch in a second launch
+    int tail_stop;       // BFHIP_TAIL_STOP (default 4): a workgroup with at most this many unfinished chains may stop them
+    int tail_q;          // BFHIP_TAIL_Q (default 3): ... once this many quarters of the launch's chains are through
+    int tail_max;        // BFHIP_TAIL_MAX (default 4): plain sliced kernel, chains of a group that may take the VALU matvec
+    int lone;            // BFHIP_LONE (default 1): the latency kernel -- 1 automatic, 0 never, 2 wherever it is implemented
+    int pld_waves;       // BFHIP_PLD_WAVES: 8 or 16 waves per workgroup for the pipeline density (0: by chain count)
+    int no_vel_ahead;    // BFHIP_NO_VEL_AHEAD: full-rank metric without the next step's velocity taken ahead
+    int tnuts_wpb;       // BFHIP_TNUTS_WPB: tempered NUTS, chains per workgroup (4, 8; 0: automatic)
+    int no_bound_proof;  // BFHIP_NO_BOUND_PROOF: always compute the H (x - mu) tiles
+    int no_proof_weights;// BFHIP_NO_PROOF_WEIGHTS: the bound proof with the plain norm (read at upload)
+    int pld_no_compress; // BFHIP_PLD_NO_COMPRESS: the pipeline density without the output-space compression (read at upload)
+    // --- measurement buffers (device pointers or NULL) ---
+    unsigned long long *stamps, *stamps_lone, *gstamps, *group_counters;
+    char last_kernel[96];
+};
+
+BfTune &bf_tune();

@@ -155,10 +155,9 @@ def scaled_inputs_rate(ctx, d, C, seed, iters, steps=3):
     e1.record(ctx.stream)
     torch.cuda.synchronize()
     ch.raise_on_error()
-    kname = _lib.lib().bfhip_debug_last_kernel
-    kname.restype = __import__('ctypes').c_char_p
+    kname = _lib.last_kernel
     return {'value': (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), 'unit': 'leapfrog steps/sec', 'chains': C, 'dim': d,
-            'mean_tree_size': float(st[:, :, _lib.NSTATS.index('tree_size')].mean().item()), 'kernel': kname().decode(),
+            'mean_tree_size': float(st[:, :, _lib.NSTATS.index('tree_size')].mean().item()), 'kernel': kname(),
             'note': 'the headline surrogate behind input scales (lo + diff x_s), folded into its coefficients at upload'}
 
 
@@ -378,19 +377,18 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     # measurement hook of the lane-per-chain kernels: trips, trips with the bound's tiles, with a late exchange, without the early one
     gcount = torch.zeros(4, dtype=torch.int64, device=ctx.device)
-    _lib.lib().bfhip_debug_group_counters(__import__('ctypes').c_void_p(gcount.data_ptr()))
+    _lib.debug_buffer('group_counters', gcount)
     torch.cuda.synchronize()
     e0.record(ctx.stream)
     for _ in range(steps):
         ch.run(iters, 'NUTS', samples=s, stats=st, **kw)
     e1.record(ctx.stream)
     torch.cuda.synchronize()
-    _lib.lib().bfhip_debug_group_counters(None)
+    _lib.debug_buffer('group_counters', None)
     ch.raise_on_error()
     ms = e0.elapsed_time(e1)
     n_lf = ch.total_leapfrog - lf0
-    kname = _lib.lib().bfhip_debug_last_kernel
-    kname.restype = __import__('ctypes').c_char_p
+    kname = _lib.last_kernel
     stn = st.cpu().numpy()
     ts = stn[:, :, _lib.NSTATS.index('tree_size')]
     spec = den.spec()
@@ -412,11 +410,11 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
            # ... and how the work is spread over the chains: the share of all leapfrogs taken by the busiest 2 % of the chains
            'work_share_top_2pct_chains': float(np.sort(ts.sum(1))[-max(1, int(0.02 * C)):].sum() / max(ts.sum(), 1.)),
            'mean_accept': float(stn[:, :, _lib.NSTATS.index('mean_tree_accept')].mean()),
-           'chain_layout': _layout_of(kname().decode(), ch.last_layout),
+           'chain_layout': _layout_of(kname(), ch.last_layout),
            'roofline': {'bound': 'mfma', 'achieved': ach * exec_share, 'peak': 78.6, 'unit': 'TFLOP/s', 'frac': ach * exec_share / 78.6,
                         'traffic': None, 'achieved_algorithmic': ach, 'frac_algorithmic': ach / 78.6,
                         'executed_share_of_algorithmic_flops': exec_share,
-                        'kernel': kname().decode(), 'kernel_ms_per_launch': ms / steps, 'flops_per_leapfrog': fl},
+                        'kernel': kname(), 'kernel_ms_per_launch': ms / steps, 'flops_per_leapfrog': fl},
            'roofline_hbm_algorithmic': {'bound': 'hbm', 'achieved': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9, 'peak': 8000.,
                                         'unit': 'GB/s', 'frac': n_lf * B_STEP_BYTES(d) / (ms * 1e-3) / 1e9 / 8000.}}
     gc = [int(v) for v in gcount.cpu().numpy()]
@@ -743,7 +741,7 @@ def main():
         # measurement hook of the group kernel: trips, and trips that executed the bound's H (x - mu) tiles
         gcount = torch.zeros(4, dtype=torch.int64, device=ctx.device)
         import ctypes
-        _lib.lib().bfhip_debug_group_counters(ctypes.c_void_p(gcount.data_ptr()))
+        _lib.debug_buffer('group_counters', gcount)
         sync()
         t0 = time.perf_counter()
         for k in range(a.steps):
@@ -753,14 +751,13 @@ def main():
         sync()
         elapsed = time.perf_counter() - t0
         chains.raise_on_error()
-        _lib.lib().bfhip_debug_group_counters(None)
+        _lib.debug_buffer('group_counters', None)
         g_trips, g_trips_h = [int(v) for v in gcount.cpu().numpy()[:2]]
         n_lf = chains.total_leapfrog - lf0
         kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if a.steps else 0.
         st_last = stats.cpu().numpy()
-        kname = _lib.lib().bfhip_debug_last_kernel
-        kname.restype = __import__('ctypes').c_char_p
-        kernel_name = kname().decode()
+        kname = _lib.last_kernel
+        kernel_name = kname()
 
         red_dev = ctx.device if (dist is None or a.backend == 'nccl') else torch.device('cpu')
         tot = torch.tensor([float(n_lf)], dtype=torch.float64, device=red_dev)

@@ -407,9 +407,9 @@ int bfhip_bridge_sums(bfhip_ctx *ctx, long n_a, const double *a, long n_b, const
 int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const double *logq_p, long n_q, const double *logp_q,
                        const double *logq_q, double logr, double *f1, double *f2);
 
-/* NOT part of this interface: the shared library also exports bfhip_debug_* symbols -- test and tuning hooks (force a chain layout,
- * a kernel form or a chains-per-workgroup count; read measurement counters; run a launch in one part) that tests/ and bench.py reach
- * by name.  They change results never and timing often; a binding has no use for them and they may change without notice. */
+/* NOT part of this interface: the library's test and tuning switches (force a chain layout, a kernel form or a chains-per-workgroup
+ * count; attach measurement buffers; run a launch in one part).  They have ONE entry point each for integers and for buffers,
+ * declared with their keys in include/bfhip_debug.h; they never change what a call computes, and a binding has no use for them. */
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,18 @@
 #include "bfhip_split.h"
 #include "bfhip_pack.h"
 
+// the library's tuning switches as the host emulation sees them: the one the upload path reads, from the environment
+BfTune &bf_tune() {
+    static BfTune t = [] {
+        BfTune u;
+        memset(&u, 0, sizeof(u));
+        const char *e = getenv("BFHIP_NO_PROOF_WEIGHTS");
+        u.no_proof_weights = e ? atoi(e) : 0;
+        return u;
+    }();
+    return t;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // cooperative fibres: one per lane of the workgroup
 // ---------------------------------------------------------------------------------------------------------------

@@ -28,6 +28,25 @@ def test_header_symbols_exported(library):
     assert declared == set(_lib.SYMBOLS), 'python binding table and header disagree'
 
 
+def test_debug_header_is_the_whole_tuning_surface(library):
+    """include/bfhip_debug.h: every bfhip_debug_* export is declared there and nowhere else, the integer switches go through
+    ONE setter by key (unknown keys are refused), and nothing of it is in the drop-in header."""
+    import subprocess
+    dbg = open(os.path.join(ROOT, 'include', 'bfhip_debug.h')).read()
+    declared = set(re.findall(r'\b(bfhip_debug_[a-z_0-9]+)\s*\(', dbg))
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r'\b(bfhip_debug_[a-z_0-9]+)\b', out))
+    assert exported == declared == {'bfhip_debug_set', 'bfhip_debug_get', 'bfhip_debug_buffer', 'bfhip_debug_last_kernel', 'bfhip_debug_tail_count'}
+    assert 'bfhip_debug_set' not in re.findall(r'\b(bfhip_[a-z_0-9]+)\s*\(', open(os.path.join(ROOT, 'include', 'bfhip.h')).read())
+    for key in re.findall(r'"([a-z_0-9]+)"', dbg.split('Integer switches by name')[1].split('*/')[0]):
+        before = _lib.debug_get(key)
+        _lib.debug_set(key, before + 1)
+        assert _lib.debug_get(key) == before + 1
+        _lib.debug_set(key, before)
+    with pytest.raises(ValueError):
+        _lib.debug_set('no_such_switch', 1)
+
+
 def test_enums_match_header():
     hdr = open(os.path.join(ROOT, 'include', 'bfhip.h')).read()
     sc = re.search(r'BFHIP_SC_LOG_STEP = 0,(.*?)BFHIP_SC_N\n', hdr, re.S).group(1)

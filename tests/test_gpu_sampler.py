@@ -126,7 +126,7 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     """The plain kernel switches its matvec from MFMA tiles to per-row FMA chains while at most 4 chains of a
     16-chain group are evaluating.  v_mfma_f64_16x16x4_f64 accumulates every entry as one sequential fma chain
     over k, which the FMA path repeats, so samples and statistics must agree bit for bit with the MFMA-only
-    run (the hook bfhip_debug_tail_max(0) disables the switch)."""
+    run (bfhip_debug_set('tail_max', 0) disables the switch)."""
     from bayesfast_amd.device import DeviceDensity
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
@@ -136,15 +136,15 @@ def test_tail_matvec_is_bit_identical_to_mfma_path(ctx, d):
     x0 = np.random.default_rng(1).normal(size=(150, d))  # 9 full groups and a ragged one
     out = {}
     try:
-        _lib.lib().bfhip_debug_no_pipe(1)  # (at d <= 64 NUTS runs on the pipelined kernel by default, which has no tail path)
+        _lib.debug_set('no_pipe', 1)  # (at d <= 64 NUTS runs on the pipelined kernel by default, which has no tail path)
         for tm in (0, 4):
-            _lib.lib().bfhip_debug_tail_max(tm)
+            _lib.debug_set('tail_max', tm)
             dc = DeviceChains(dens, x0, seed=5)
             s, st = dc.run(40, 'NUTS', n_warmup=20, layout='wave')
             out[tm] = (s.cpu().numpy(), st.cpu().numpy())
     finally:
-        _lib.lib().bfhip_debug_tail_max(4)
-        _lib.lib().bfhip_debug_no_pipe(0)
+        _lib.debug_set('tail_max', 4)
+        _lib.debug_set('no_pipe', 0)
     assert np.array_equal(out[0][0], out[4][0])
     assert np.array_equal(out[0][1], out[4][1], equal_nan=True)
 
@@ -173,7 +173,7 @@ def test_group_kernel_bound_proof_never_changes_results(ctx, case):
     kw = {'divergent': dict(max_change=5.)}.get(case, {})
     sampler = 'HMC' if case == 'hmc' else 'NUTS'
     out = {}
-    hook = _lib.lib().bfhip_debug_no_bound_proof
+    hook = lambda v: _lib.debug_set('no_bound_proof', v)
     try:
         for off in (0, 1):
             hook(off)
@@ -246,18 +246,18 @@ def test_chains_per_workgroup_never_change_results(ctx, kernel):
     out = {}
     L = _lib.lib()
     try:
-        L.bfhip_debug_no_group(1)
-        L.bfhip_debug_no_pipe(0 if kernel.startswith('pipe') else 1)
+        _lib.debug_set('no_group', 1)
+        _lib.debug_set('no_pipe', 0 if kernel.startswith('pipe') else 1)
         for cpg in (16, 8, 4, 1):   # (8: the pipelined kernel takes two 4 x 4 x 4 instructions per k-step)
-            L.bfhip_debug_wave_cpg(cpg)
+            _lib.debug_set('wave_cpg', cpg)
             dc = DeviceChains(dens, x0, seed=4)
             s1, st1 = dc.run(24, 'NUTS', n_warmup=16, layout='wave')
             s2, st2 = dc.run(8, 'NUTS', n_warmup=16, layout='wave')
             out[cpg] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
     finally:
-        L.bfhip_debug_wave_cpg(0)
-        L.bfhip_debug_no_pipe(0)
-        L.bfhip_debug_no_group(0)
+        _lib.debug_set('wave_cpg', 0)
+        _lib.debug_set('no_pipe', 0)
+        _lib.debug_set('no_group', 0)
     for cpg in (8, 4, 1):
         for a, b in zip(out[16][:-1], out[cpg][:-1]):
             assert np.array_equal(a, b, equal_nan=True), cpg
@@ -290,16 +290,16 @@ def test_pipelined_nuts_kernel_is_bit_identical_to_sliced_kernel(ctx, case):
     kw = {'depth_limit': dict(max_treedepth=2), 'divergent': dict(max_change=5.)}.get(case, {})
     out = {}
     try:
-        _lib.lib().bfhip_debug_no_group(1)  # (the default dispatch is the group kernel, bfhip_group.hip)
+        _lib.debug_set('no_group', 1)  # (the default dispatch is the group kernel, bfhip_group.hip)
         for sliced in (0, 1):
-            _lib.lib().bfhip_debug_no_pipe(sliced)
+            _lib.debug_set('no_pipe', sliced)
             dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
             s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw, layout='wave')
             s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw, layout='wave')   # resume: the second launch starts from the stored state
             out[sliced] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
     finally:
-        _lib.lib().bfhip_debug_no_pipe(0)
-        _lib.lib().bfhip_debug_no_group(0)
+        _lib.debug_set('no_pipe', 0)
+        _lib.debug_set('no_group', 0)
     for a, b in zip(out[0][:-1], out[1][:-1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert out[0][-1] == out[1][-1] == int(out[0][1][:, :, _lib.NSTATS.index('tree_size')].sum() + out[0][3][:, :, _lib.NSTATS.index('tree_size')].sum())
@@ -341,20 +341,19 @@ def test_lone_kernel_is_bit_identical_to_pipelined_kernel(ctx, case):
     out = {}
     L = _lib.lib()
     try:
-        L.bfhip_debug_no_group(1)
+        _lib.debug_set('no_group', 1)
         for lone in (0, 2):
-            L.bfhip_debug_lone(lone)
-            L.bfhip_debug_wave_cpg(16 if lone == 0 else 0)
+            _lib.debug_set('lone', lone)
+            _lib.debug_set('wave_cpg', 16 if lone == 0 else 0)
             dc = DeviceChains(dens, x0, seed=11, step_size=2. if case == 'divergent' else 1.)
             s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw, layout='wave')
             s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw, layout='wave')
             out[lone] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
-            L.bfhip_debug_last_kernel.restype = ctypes.c_char_p
-            assert (b'bf_lone_kernel' in L.bfhip_debug_last_kernel()) == (lone == 2)
+            assert ('bf_lone_kernel' in _lib.last_kernel()) == (lone == 2)
     finally:
-        L.bfhip_debug_lone(1)
-        L.bfhip_debug_wave_cpg(0)
-        L.bfhip_debug_no_group(0)
+        _lib.debug_set('lone', 1)
+        _lib.debug_set('wave_cpg', 0)
+        _lib.debug_set('no_group', 0)
     names = ['samples', 'stats', 'samples2', 'stats2', 'sc', 'vec', 'rng']
     for nm, a, b in zip(names, out[0][:-1], out[2][:-1]):
         assert np.array_equal(a, b, equal_nan=True), (nm, np.argwhere(~((a == b) | ((a != a) & (b != b))))[:5])
@@ -490,8 +489,7 @@ def test_split_layout_is_bit_identical_to_group_layout_on_the_device(ctx, d):
     spec, _ = correlated_gaussian_spec(d)
     dens = DeviceDensity(spec, ctx)
     rng = np.random.default_rng(3)
-    kname = _lib.lib().bfhip_debug_last_kernel
-    kname.restype = C.c_char_p
+    kname = _lib.last_kernel
     for x0, n, nw, kw in ((rng.normal(size=(37, d)), 60, 40, {}), (rng.normal(size=(20, d)) * 6., 30, 20, {}),
                           (rng.normal(size=(300, d)), 90, 50, dict(launch_iters=17))):
         out = []
@@ -499,7 +497,7 @@ def test_split_layout_is_bit_identical_to_group_layout_on_the_device(ctx, d):
             ch = DeviceChains(dens, x0, seed=5)
             s, st = ch.run(n, 'NUTS', n_warmup=nw, layout=layout, **kw)
             out.append([t.cpu().numpy() for t in (s, st, ch.sc, ch.vec, ch.rng)] + [ch.total_leapfrog])
-            assert kname().decode().startswith('bf_split_kernel' if layout == 'split' else 'bf_group_kernel')
+            assert kname().startswith('bf_split_kernel' if layout == 'split' else 'bf_group_kernel')
         for u, v in zip(*out):
             assert np.array_equal(u, v, equal_nan=True) if isinstance(u, np.ndarray) else u == v
 
@@ -834,7 +832,7 @@ def test_sliced_kernel_bound_proof_at_d128_never_changes_results(ctx, case):
     spec, _ = correlated_gaussian_spec(d, fit_scale=1.0 if case == 'leaky' else 1.5)
     dens = DeviceDensity(spec, ctx)
     x0 = np.random.default_rng(2).normal(size=(44, d))
-    hook = _lib.lib().bfhip_debug_no_bound_proof
+    hook = lambda v: _lib.debug_set('no_bound_proof', v)
     out = {}
     try:
         for off in (0, 1):
@@ -904,9 +902,9 @@ def test_the_tail_of_a_launch_in_few_chain_workgroups_never_changes_results(ctx,
     L.bfhip_debug_tail_count.restype = ctypes.c_int
     out, listed = {}, {}
     try:
-        L.bfhip_debug_wave_cpg(16)
+        _lib.debug_set('wave_cpg', 16)
         for two in (1, 0):
-            L.bfhip_debug_tail_relaunch(two)
+            _lib.debug_set('tail_relaunch', two)
             dc = DeviceChains(dens, x0, seed=13, step_size=0.6)
             for f in ('log_step', 'log_bar'):
                 dc.sc[::19, _lib.SC_FIELDS.index(f)] = np.log(0.03)
@@ -916,8 +914,8 @@ def test_the_tail_of_a_launch_in_few_chain_workgroups_never_changes_results(ctx,
             s2, st2 = dc.run(12, 'NUTS', **kw)
             out[two] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog]
     finally:
-        L.bfhip_debug_wave_cpg(0)
-        L.bfhip_debug_tail_relaunch(1)
+        _lib.debug_set('wave_cpg', 0)
+        _lib.debug_set('tail_relaunch', 1)
     for a, b in zip(out[1][:-1], out[0][:-1]):
         assert np.array_equal(a, b, equal_nan=True)
     assert out[1][-1] == out[0][-1]
@@ -951,9 +949,8 @@ def test_surrogate_with_input_scales_runs_on_the_fused_fast_kernels_and_matches_
     dev = _device_chains(ctx, spec, x0, 14, 9)
     orc_runs = _oracle_chains(spec, x0, 14, 9)
     _compare_nuts(dev, orc_runs, 14, n_head=6, tol_head=1e-8)
-    kname = _lib.lib().bfhip_debug_last_kernel
-    kname.restype = __import__('ctypes').c_char_p
-    assert not kname().decode().startswith('bf_sampler_kernel'), kname().decode()
+    kname = _lib.last_kernel
+    assert not kname().startswith('bf_sampler_kernel'), kname()
 
 
 def test_cubic_surrogate_with_input_scales_is_folded_too(ctx):

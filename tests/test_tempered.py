@@ -101,11 +101,11 @@ def test_device_tnuts_workgroup_size_never_changes_results(fx):
     out = {}
     try:
         for wpb in (4, 8):
-            _lib.lib().bfhip_debug_tnuts_wpb(wpb)
+            _lib.debug_set('tnuts_wpb', wpb)
             dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=98)
             out[wpb] = [t.cpu().numpy() for t in dc.run_tempered(24, fx['t6.base_mean'], fx['t6.base_cov'], logxi=logxi, u_0=u0, n_warmup=16)]
     finally:
-        _lib.lib().bfhip_debug_tnuts_wpb(0)
+        _lib.debug_set('tnuts_wpb', 0)
     for a, b in zip(out[4], out[8]):
         assert np.array_equal(a, b, equal_nan=True)
 

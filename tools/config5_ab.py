@@ -15,8 +15,7 @@ d = 128
 rng = np.random.default_rng(2024)
 logp, chol = planck_like_logp(d, amp=float(os.environ.get("AMP", "0.02")))
 m16 = np.arange(16)
-kname = _lib.lib().bfhip_debug_last_kernel
-kname.restype = __import__('ctypes').c_char_p
+kname = _lib.last_kernel
 for cubic in (True, False):
     cfgs = [bfa.PolyConfig('linear'), bfa.PolyConfig('quadratic')]
     if cubic:
@@ -41,4 +40,4 @@ for cubic in (True, False):
         torch.cuda.synchronize()
         n = ch.total_leapfrog - lf0
         print('chains %d cubic %d max_treedepth %d: %.3g leapfrog steps/s, mean tree %.1f, %s' % (
-            C, cubic, depth, n / (e0.elapsed_time(e1) * 1e-3), n / (C * iters), kname().decode()), flush=True)
+            C, cubic, depth, n / (e0.elapsed_time(e1) * 1e-3), n / (C * iters), kname()), flush=True)

@@ -12,8 +12,7 @@ from bayesfast_amd.workloads import correlated_gaussian_spec
 from bayesfast_amd import _lib
 quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 ctx = get_context(0)
-KN = _lib.lib().bfhip_debug_last_kernel
-KN.restype = __import__('ctypes').c_char_p
+KN = _lib.last_kernel
 
 
 def spec_of(d, family):
@@ -42,7 +41,7 @@ def rate(dens, x0, ta, layout, family):
         s, st = ch.run(200, 'NUTS', **kw)
     e1.record(ctx.stream)
     torch.cuda.synchronize()
-    return (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), st[:, :, _lib.NSTATS.index('tree_size')].mean().item(), KN().decode()
+    return (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), st[:, :, _lib.NSTATS.index('tree_size')].mean().item(), KN()
 
 
 cells = []

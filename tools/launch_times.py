@@ -14,8 +14,7 @@ ctx = get_context(0)
 spec, _ = correlated_gaussian_spec(d)
 dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(1).normal(size=(C, d))
-kname = _lib.lib().bfhip_debug_last_kernel
-kname.restype = __import__('ctypes').c_char_p
+kname = _lib.last_kernel
 for rep in range(2):
     ch = DeviceChains(dens, x0, seed=3)
     rows = []
@@ -29,7 +28,7 @@ for rep in range(2):
         ts = st[:, :, _lib.NSTATS.index('tree_size')]
         tot = ts.sum(1)                                   # leapfrog steps per chain in this launch
         wg = tot.view(-1, 16).max(1).values               # ... of the slowest chain of every 16-chain workgroup
-        rows.append((n, e0.elapsed_time(e1), ch.total_leapfrog - lf0, ch.last_layout, kname().decode(), float(ts.mean()), float(ts.max()),
+        rows.append((n, e0.elapsed_time(e1), ch.total_leapfrog - lf0, ch.last_layout, kname(), float(ts.mean()), float(ts.max()),
                      float(tot.mean() / wg.mean()), float(tot.mean() / tot.max())))
 tot = 0.
 for n, ms, lf, lay, kn, tm, tx, e16, eall in rows:

@@ -20,8 +20,7 @@ if os.environ.get('BOUNDED'):  # behind the constraint transform: all four kinds
     spec = dict(spec, ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array([[1, 1], [1, 0], [0, 1], [0, 0]] * (D // 4), dtype=np.uint8))
 dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(1).normal(size=(C, D)) * (0.3 if os.environ.get('BOUNDED') else 1.)
-KN = _lib.lib().bfhip_debug_last_kernel
-KN.restype = __import__('ctypes').c_char_p
+KN = _lib.last_kernel
 for layout in ('group', 'split', 'wave'):
     ch = DeviceChains(dens, x0, seed=3)
     kw = dict(n_warmup=750, target_accept=ta, check=False, layout=layout)
@@ -37,4 +36,4 @@ for layout in ('group', 'split', 'wave'):
     ts = st[:, :, _lib.NSTATS.index('tree_size')].mean().item()
     gc = torch.zeros(2, dtype=torch.int64, device='cuda')
     print('d %d target_accept %.2f chains %d layout %-5s (%s): %.4g leapfrog steps/s, mean tree size %.1f' % (
-        D, ta, C, layout, KN().decode(), (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), ts))
+        D, ta, C, layout, KN(), (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), ts))

@@ -14,10 +14,10 @@ dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(2).normal(size=(70, d))
 L = _lib.lib()
 out = {}
-L.bfhip_debug_no_group(1)
+_lib.debug_set('no_group', 1)
 for lone in (0, 2):
-    L.bfhip_debug_lone(lone)
-    L.bfhip_debug_wave_cpg(16 if lone == 0 else 0)
+    _lib.debug_set('lone', lone)
+    _lib.debug_set('wave_cpg', 16 if lone == 0 else 0)
     dc = DeviceChains(dens, x0, seed=11)
     s1, st1 = dc.run(45, 'NUTS', n_warmup=nw, layout='wave')
     out[lone] = (s1.cpu().numpy(), st1.cpu().numpy(), dc.sc.cpu().numpy(), dc.vec.cpu().numpy(), dc.rng.cpu().numpy())

@@ -12,13 +12,13 @@ spec, _ = correlated_gaussian_spec(d, fit_scale=1.5)
 dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(2).normal(size=(70, d))
 L = _lib.lib()
-L.bfhip_debug_no_group(1)
+_lib.debug_set('no_group', 1)
 F = _lib.SC_FIELDS
 for k in range(1, 6):
     out = {}
     for lone in (0, 2):
-        L.bfhip_debug_lone(lone)
-        L.bfhip_debug_wave_cpg(16 if lone == 0 else 0)
+        _lib.debug_set('lone', lone)
+        _lib.debug_set('wave_cpg', 16 if lone == 0 else 0)
         dc = DeviceChains(dens, x0, seed=11)
         s1, st1 = dc.run(k, 'NUTS', n_warmup=30, layout='wave')
         out[lone] = (dc.sc.cpu().numpy(), st1.cpu().numpy())

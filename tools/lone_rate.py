@@ -32,7 +32,6 @@ else:
 ch = DeviceChains(dd, x0, seed=5)
 ch.run(300, 'NUTS', **kw)
 L = _lib.lib()
-L.bfhip_debug_last_kernel.restype = ctypes.c_char_p
 res = []
 for rep in range(3):
     lf0 = ch.total_leapfrog
@@ -43,4 +42,4 @@ for rep in range(3):
     res.append(((ch.total_leapfrog - lf0) / dt, dt * 1e6 / ts.max(), ts.mean() / n_it))
 r = np.array(res)
 print('%s d=%d chains=%d BFHIP_LONE=%s kernel %s: %.4g lf/s, %.2f us per leapfrog of the busiest chain, mean tree %.1f'
-      % (what, d, Cn, os.environ.get('BFHIP_LONE'), L.bfhip_debug_last_kernel().decode(), r[:, 0].max(), r[:, 1].min(), r[:, 2].mean()))
+      % (what, d, Cn, os.environ.get('BFHIP_LONE'), _lib.last_kernel(), r[:, 0].max(), r[:, 1].min(), r[:, 2].mean()))

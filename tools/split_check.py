@@ -18,5 +18,5 @@ for name, x0, n, nw, kw in (('small', rng.normal(size=(37, 64)), 60, 40, {}), ('
                             ('big', rng.normal(size=(4096, 64)), 300, 200, {}), ('cut', rng.normal(size=(100, 64)), 90, 50, dict(launch_iters=17))):
     a = run('group', x0, n, nw, **kw)
     b = run('split', x0, n, nw, **kw)
-    kname = _lib.lib().bfhip_debug_last_kernel; kname.restype = __import__('ctypes').c_char_p
-    print(name, kname().decode(), [bool(np.array_equal(u, v, equal_nan=True)) if isinstance(u, np.ndarray) else u == v for u, v in zip(a, b)], a[1][:, :, 3].mean())
+    kname = _lib.last_kernel
+    print(name, kname(), [bool(np.array_equal(u, v, equal_nan=True)) if isinstance(u, np.ndarray) else u == v for u, v in zip(a, b)], a[1][:, :, 3].mean())

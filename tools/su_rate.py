@@ -30,7 +30,6 @@ for _ in range(3):
     s, st = ch.run(250, 'NUTS', **kw)
 e1.record(ctx.stream)
 torch.cuda.synchronize()
-KN = _lib.lib().bfhip_debug_last_kernel
-KN.restype = __import__('ctypes').c_char_p
+KN = _lib.last_kernel
 print('input scales %s: %.4g leapfrog steps/s, mean tree size %.1f, %s' % ('kept on the device' if os.environ.get('BFHIP_NO_SU_FOLD') else 'folded at upload',
-      (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), st[:, :, _lib.NSTATS.index('tree_size')].mean().item(), KN().decode()))
+      (ch.total_leapfrog - lf0) / (e0.elapsed_time(e1) * 1e-3), st[:, :, _lib.NSTATS.index('tree_size')].mean().item(), KN()))

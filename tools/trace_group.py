@@ -17,10 +17,9 @@ dc = DeviceChains(DeviceDensity(spec, ctx), np.random.default_rng(1).normal(size
 dc.run(800, 'NUTS', n_warmup=750, **RKW)
 buf = torch.zeros((N * 8,), dtype=torch.int64, device='cuda')
 L = _lib.lib()
-L.bfhip_debug_gstamps.argtypes = [C.c_void_p]
-L.bfhip_debug_gstamps(C.c_void_p(buf.data_ptr()))
+_lib.debug_buffer('gstamps', buf)
 dc.run(20, 'NUTS', n_warmup=750, **RKW)
-L.bfhip_debug_gstamps(None)
+_lib.debug_buffer('gstamps', None)
 t = buf.cpu().numpy().reshape(N, 8).astype(np.int64)
 LBL = os.environ.get("GLABELS", "1 phase A done | 2 after B1 | 3 MFMAs + tile sums | 4 eval sums posted | 5 U-turn sums posted | 6 after B2 | 7 eval scalars | (next 0) state machine"); print("points:", LBL)
 for i in range(2, N - 1):

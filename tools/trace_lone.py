@@ -34,12 +34,11 @@ ch = DeviceChains(dd, x0, seed=5)
 ch.run(300, 'NUTS', **kw)
 buf = torch.zeros(NT * 32, dtype=torch.int64, device=ctx.device)
 L = _lib.lib()
-L.bfhip_debug_stamps_lone.argtypes = [C.c_void_p]
-L.bfhip_debug_stamps_lone(C.c_void_p(buf.data_ptr()))
+_lib.debug_buffer('stamps_lone', buf)
 ch.run(8, 'NUTS', **kw)
 torch.cuda.synchronize()
-L.bfhip_debug_stamps_lone(None)
-L.bfhip_debug_last_kernel.restype = C.c_char_p; print(L.bfhip_debug_last_kernel().decode())
+_lib.debug_buffer('stamps_lone', None)
+print(_lib.last_kernel())
 t = buf.cpu().numpy().reshape(NT, 2, 16).astype(np.float64)
 print('trip |  I: total  waitB0      A  waitB1    tile  waitB2       C |  K: total  waitB0    load      dE   wait1 exp+mg0   wait2    rest verdict')
 rows = []

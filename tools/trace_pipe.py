@@ -36,12 +36,11 @@ ch = DeviceChains(dd, x0, seed=5)
 ch.run(300, 'NUTS', **kw)
 buf = torch.zeros(NT * 16, dtype=torch.int64, device=ctx.device)
 L = _lib.lib()
-L.bfhip_debug_stamps.argtypes = [C.c_void_p]
-L.bfhip_debug_stamps(C.c_void_p(buf.data_ptr()))
+_lib.debug_buffer('stamps', buf)
 ch.run(4, 'NUTS', **kw)
 torch.cuda.synchronize()
-L.bfhip_debug_stamps(None)
-L.bfhip_debug_last_kernel.restype = C.c_char_p; print(L.bfhip_debug_last_kernel().decode())
+_lib.debug_buffer('stamps', None)
+print(_lib.last_kernel())
 t = buf.cpu().numpy().reshape(NT, 16).astype(np.float64)
 names = ['A', 'wait B1', 'B: MF0', 'B: ->9', 'B: ->10', 'B: ->11', 'B: ->4', 'B: ->5', 'wait B2', 'C: gather', 'C: sums', 'C: rest']
 pairs = [(0, 1), (1, 2), (2, 3), (3, 9), (9, 10), (10, 11), (11, 4), (4, 5), (5, 6), (6, 7), (7, 8)]

@@ -22,11 +22,10 @@ kw = dict(n_warmup=100, check=False)
 ch.run(100, 'NUTS', **kw)
 buf = torch.zeros(NT * 16, dtype=torch.int64, device=ctx.device)
 L = _lib.lib()
-L.bfhip_debug_stamps.argtypes = [C.c_void_p]
-L.bfhip_debug_stamps(C.c_void_p(buf.data_ptr()))
+_lib.debug_buffer('stamps', buf)
 ch.run(8, 'NUTS', **kw)
 torch.cuda.synchronize()
-L.bfhip_debug_stamps(None)
+_lib.debug_buffer('stamps', None)
 t = buf.cpu().numpy().reshape(NT, 16).astype(np.float64)
 names = ['A', 'wait B1', 'flags', 'H jobs', 'wait B2', 'P0', 'wait P1', 'gemm1', 'wait P2', 'gemm2', 'wait P3', 'sums+grad', 'rest C', 'unit']
 pairs = [(0, 1), (1, 2), (2, 3), (3, 5), (5, 6), (6, 7), (7, 8), (8, 11), (11, 12), (12, 13), (13, 14), (14, 15), (15, 9), (9, 10)]

@@ -32,11 +32,10 @@ kw = dict(n_warmup=100, check=False, max_treedepth=6)
 ch.run(100, 'NUTS', **kw)
 buf = torch.zeros(NT * 16, dtype=torch.int64, device=ctx.device)
 L = _lib.lib()
-L.bfhip_debug_stamps.argtypes = [C.c_void_p]
-L.bfhip_debug_stamps(C.c_void_p(buf.data_ptr()))
+_lib.debug_buffer('stamps', buf)
 ch.run(4, 'NUTS', **kw)
 torch.cuda.synchronize()
-L.bfhip_debug_stamps(None)
+_lib.debug_buffer('stamps', None)
 t = buf.cpu().numpy().reshape(NT, 16).astype(np.float64)
 names = ['A', 'wait B1', 'flags', 'jobs', 'jobs->5', 'wait B2', 'C: gather', 'C: sums', 'C: rest', 'unit']
 pairs = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)]

@@ -14,10 +14,9 @@ dc = DeviceChains(DeviceDensity(spec, ctx), np.random.default_rng(1).normal(size
 dc.run(800, 'NUTS', n_warmup=750, layout='split')
 buf = torch.zeros((N * 16,), dtype=torch.int64, device='cuda')
 L = _lib.lib()
-L.bfhip_debug_gstamps.argtypes = [C.c_void_p]
-L.bfhip_debug_gstamps(C.c_void_p(buf.data_ptr()))
+_lib.debug_buffer('gstamps', buf)
 dc.run(20, 'NUTS', n_warmup=750, layout='split')
-L.bfhip_debug_gstamps(None)
+_lib.debug_buffer('gstamps', None)
 t = buf.cpu().numpy().reshape(N, 2, 8).astype(np.int64)
 print('integrator: top | ->B1 | B1 | tiles | posted | B2      bookkeeper: top | ->B1 | B1 | sums read | machine done | B2 || leaf and merges done | iteration end done (rows, adaptation)   (cycles from the integrator\'s top)')
 for i in range(2, N - 1):
