@@ -520,7 +520,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         fit(den, x_fit, logp(x_fit), 'fit_ms')
         x0 = sobol_normal(C, d, seed=seed + 1)
         what = ('config 2: %d chains x 32-d correlated Gaussian (P = L L^T, SURVEY 8d), quadratic PolyModel P = %d fitted on 2 P '
-                'Sobol-normal points, bound on; NUTS defaults' % (C, su.n_param))
+                'Sobol-normal points, bound on; NUTS defaults.  Departure from SURVEY 8d: the fit points are drawn 1.5 x wider than N(0, I) '
+                '(with a training set as tight as the posterior the chains leak through the bound in 32 dimensions: DESIGN.md section 5)' % (C, su.n_param))
         r, s_, _ = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what)
         var_ratio = float(np.mean(s_.reshape(-1, d).var(0).cpu().numpy() / np.diag(cov)))
         return dict(r, posterior_variance_ratio=var_ratio, **t_fit)
@@ -533,7 +534,9 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         fit(den, x_fit, logp(x_fit), 'fit_0_ms')
         x0 = x_fit[rng.integers(0, x_fit.shape[0], C)] * 0.5
         what = ('config 3: %d chains x 64-d rotated banana (Q = 0.01), quadratic surrogate P = %d fitted on 2 P N(0, I) points, '
-                'bound and decay on; round %%d' % (C, su.n_param))
+                'bound and decay on; round %%d.  Departures from SURVEY 8d: the fit points are pseudo-random N(0, I) draws, not Sobol-normal, '
+                'and the density carries the decay term the reference\'s GBS recipes use (core/density.py:740-746) -- without it the '
+                'chains run away along the first fit\'s indefinite quadratic form (DESIGN.md section 5)' % (C, su.n_param))
         r0, s, st = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what % 0)
         if os.environ.get('BENCH_ROUND0_ONLY'):   # (tools/profile_configs.sh: counters of the first round's kernel on its own)
             return r0
@@ -558,7 +561,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         fit(den, x_fit, logp(x_fit), 'fit_ms')
         x0 = x_fit[rng.integers(0, x_fit.shape[0], C)] * 0.5
         what = ('config 4 (one GPU of 8): %d chains x 64-d funnel (a = 1, b = 0.5), quadratic surrogate P = %d fitted on 2 P N(0, I) '
-                'points, bound and decay on, target_accept 0.95' % (C, su.n_param))
+                'points, bound and decay on, target_accept 0.95.  Departures from SURVEY 8d: pseudo-random N(0, I) fit points (not '
+                'Sobol-normal) and the decay term (core/density.py:740-746), as in the reference\'s funnel-gbs notebook' % (C, su.n_param))
         r, _, _ = _sampler_block(ctx, den, x0, seed, 0.95, n_adapt, iters, steps, cpu_seconds, what)
         return dict(r, **t_fit)
     if name == 'cubic128':
@@ -572,7 +576,8 @@ def config_block(name, ctx, seed, cpu_seconds=4., chains=None, iters=None, steps
         fit(den, x_fit, logp(x_fit), 'fit_ms')
         x0 = x_fit[rng.integers(0, x_fit.shape[0], C)] * 0.5
         what = ('config 5 (one GPU of 8): %d chains x 128-d Planck-18-like synthetic logp (cond 1e4 Gaussian + cubic terms on 16 '
-                'inputs), cubic-cross PolyModel P = %d fitted on 2 P points, bound on' % (C, su.n_param))
+                'inputs), cubic-cross PolyModel P = %d fitted on 2 P points, bound on.  Departure from SURVEY 8d: the fit points are '
+                'pseudo-random draws from the target\'s Gaussian part (not Sobol-normal)' % (C, su.n_param))
         r, _, _ = _sampler_block(ctx, den, x0, seed, 0.8, n_adapt, iters, steps, cpu_seconds, what)
         return dict(r, **t_fit)
     raise ValueError(name)
