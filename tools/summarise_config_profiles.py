@@ -5,7 +5,7 @@ import sys, os, glob, json, csv
 import numpy as np
 out, tag = sys.argv[1], sys.argv[2]
 N_TIMED = 2   # bench.py config_block: steps = 2 timed launches per block
-SAMPLERS = ('bf_sampler_kernel', 'bf_nuts_pipe_kernel', 'bf_group_kernel', 'bf_split_kernel')
+SAMPLERS = ('bf_sampler_kernel', 'bf_nuts_pipe_kernel', 'bf_group_kernel', 'bf_split_kernel', 'bf_lone_kernel')
 
 
 def rows(d, pattern):
