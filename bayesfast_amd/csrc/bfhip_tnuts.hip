@@ -19,6 +19,7 @@
 // other sampler kernels, so a chain reproduces the CPU oracle for the same xoshiro stream.
 #include <cmath>
 #include "bfhip_common.h"
+#include "bfhip_eval.h"
 #include "bfhip_sampler_defs.h"
 #include "bfhip_wave.h"
 #include "bfhip_oob.h"
@@ -47,13 +48,18 @@ __device__ inline double tn_logaddexp(double a, double b) {
 #define TN_XS 65   // row stride of the B operands and of the results (doubles)
 
 #define TN_WAVES 8
-template <int W>   // row tiles of the matrices: the padded dimension is 16 W (W = 1, 2, 4), known at compile time
+// TR: the target lives behind the constraint transform (Density.input_scales / hard_bounds: density.py:92-140, 747-750) -- the
+// surrogate is evaluated at x(q), its gradient gets the chain-rule factor and the log-Jacobian term; the base density stays in
+// the sampler's space (base_hmc.py:227-231 evaluates both at q).  DEC: the decay penalty of the target (density.py:740-746), a
+// fourth product H_d (x - mu_d) on the waves that run H.  (Round 5: every GBS example of the reference has bounds or decay.)
+template <int W, bool TR = false, bool DEC = false>   // row tiles of the matrices: the padded dimension is 16 W (W = 1, 2, 4), known at compile time
 __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, TnutsArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int d = a.d;
-    double *XB = lds;                        // [2][16][TN_XS] B operands: q | q - mu  (k-step s, lane l: dimension 4 s + (l >> 4) of chain l & 15)
-    double *GB = XB + 2 * 16 * TN_XS;        // [3][16][TN_XS] results: S q | H (q - mu) | S_b q, [matrix][chain][dimension]
-    double *LSC = GB + 3 * 16 * TN_XS;       // [TN_WAVES][TN_MAXL][TS_N]
+    constexpr int NXB = 4, NGB = 4;          // (regions 2 and 3 are used with TR / DEC only)
+    double *XB = lds;                        // [4][16][TN_XS] B operands: x | x - mu | q (base; = x without TR) | x - mu_decay  (k-step s, lane l: dimension 4 s + (l >> 4) of chain l & 15)
+    double *GB = XB + NXB * 16 * TN_XS;      // [4][16][TN_XS] results: S x | H (x - mu) | S_b q | H_d (x - mu_d), [matrix][chain][dimension]
+    double *LSC = GB + NGB * 16 * TN_XS;     // [TN_WAVES][TN_MAXL][TS_N]
     int *flags = (int *)(LSC + TN_WAVES * TN_MAXL * TS_N);   // [2] some chain of the workgroup is active (by rendezvous parity)
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chain = blockIdx.x * a.cpg + w;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
     // 4..7 row tile w - 4 of H (afr)
     const int jt = w & 3;                 // row tile
     const bool has_job = jt < W, job_h = w >= 4;
-    double afr[16], afb[16];
+    double afr[16], afb[16];   // (afb: S_b on waves 0-3, H_decay on waves 4-7)
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
         double v = 0., vb = 0.;
@@ -71,28 +77,34 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
             v = (job_h ? m.Hf : m.Sf)[((size_t)jt * NS + s2) * 64 + lane];
             const int row = 16 * jt + (lane & 15), col = 4 * s2 + (lane >> 4);
             if (!job_h && row < d && col < d) vb = a.base_S[(size_t)row * d + col];
+            if (DEC && job_h) vb = m.Hdf[((size_t)jt * NS + s2) * 64 + lane];
         }
         afr[s2] = v;
         afb[s2] = vb;
     }
     if (threadIdx.x < 2) flags[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < 5 * 16 * TN_XS; i += 64 * TN_WAVES) XB[i] = 0.;   // (XB and GB: the columns without a chain stay zero)
+    for (int i = threadIdx.x; i < (NXB + NGB) * 16 * TN_XS; i += 64 * TN_WAVES) XB[i] = 0.;   // (XB and GB: the columns without a chain stay zero)
     __syncthreads();
     double *lsw = LSC + w * (TN_MAXL * TS_N);
     const bool in = lane < d;
     const double c_lin = in ? m.pd[PD_LIN * DPW + lane] : 0., c_mu = in ? m.pd[PD_MU * DPW + lane] : 0.;
     const double c_smu = in ? m.pd[PD_SMU * DPW + lane] : 0.;
     const double b_lin = in ? a.base_lin[lane] : 0.;
+    const double c_dmu = (DEC && in) ? m.pd[PD_DMU * DPW + lane] : 0.;
+    const int c_kind = (TR && in) ? (int)m.pd[PD_KIND * DPW + lane] : 0;
+    const double c_lo = (TR && in) ? m.pd[PD_LO * DPW + lane] : 0., c_rg = (TR && in) ? m.pd[PD_RG * DPW + lane] : 1.;
     // One rendezvous of the workgroup: this wave's point (active: it has one) -> S q, H (q - mu), S_b q of its chain.  Returns
     // false when no chain of the workgroup is active any more (the same answer in every wave).
     int n_x = 0;
-    auto exchange = [&](bool active, double q, double xm, double &sx, double &hv, double &bx) -> bool {
+    auto exchange = [&](bool active, double x, double xm, double qb, double xd, double &sx, double &hv, double &bx, double &dgr) -> bool {
         const int par = n_x & 1;
         n_x += 1;
         if (lane < DPW) {
             const int xi = (lane >> 2) * TN_XS + w + 16 * (lane & 3);
-            XB[xi] = q;
+            XB[xi] = x;
             XB[16 * TN_XS + xi] = xm;
+            if constexpr (TR) XB[2 * 16 * TN_XS + xi] = qb;
+            if constexpr (DEC) XB[3 * 16 * TN_XS + xi] = xd;
         }
         if (active && lane == 0) flags[par] = 1;
         __syncthreads();  // R1
@@ -103,20 +115,31 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
             // same four columns: A lane 16 k + m as for the 16 x 16 x 4 tile, B lane 16 k + 4 b + n reads column n, D lane
             // 16 i + 4 b + n is row 4 b + i of column n) -- 36 against 64 cycles of the FP64 pipe, the same sequential sum per entry
             const double *Xq = XB + (job_h ? 16 * TN_XS : 0) + (lane & ~15) + (lane & 3);
+            // the second chain of the wave: S_b against q (region 2 with the transform, region 0 = x = q without) on waves 0-3,
+            // H_decay against x - mu_decay (region 3) on waves 4-7
+            const bool second = !job_h || DEC;
+            const double *Xs = XB + (job_h ? 3 : (TR ? 2 : 0)) * 16 * TN_XS + (lane & ~15) + (lane & 3);
             double a0 = 0., a1 = 0., b0 = 0., b1 = 0.;
 #pragma unroll
             for (int c0 = 0; c0 < 16; c0 += 4) {
                 if (c0 < NS) {
-                    double x0[4], x1[4];
+                    double x0[4], x1[4], y0[4], y1[4];
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) { x0[s2] = Xq[(c0 + s2) * TN_XS]; x1[s2] = Xq[(c0 + s2) * TN_XS + 4]; }
+                    if constexpr (TR || DEC) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) { y0[s2] = Xs[(c0 + s2) * TN_XS]; y1[s2] = Xs[(c0 + s2) * TN_XS + 4]; }
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) { y0[s2] = x0[s2]; y1[s2] = x1[s2]; }
+                    }
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) {
                         a0 = __builtin_amdgcn_mfma_f64_4x4x4f64(afr[c0 + s2], x0[s2], a0, 0, 0, 0);
                         a1 = __builtin_amdgcn_mfma_f64_4x4x4f64(afr[c0 + s2], x1[s2], a1, 0, 0, 0);
-                        if (!job_h) {
-                            b0 = __builtin_amdgcn_mfma_f64_4x4x4f64(afb[c0 + s2], x0[s2], b0, 0, 0, 0);
-                            b1 = __builtin_amdgcn_mfma_f64_4x4x4f64(afb[c0 + s2], x1[s2], b1, 0, 0, 0);
+                        if (second) {
+                            b0 = __builtin_amdgcn_mfma_f64_4x4x4f64(afb[c0 + s2], y0[s2], b0, 0, 0, 0);
+                            b1 = __builtin_amdgcn_mfma_f64_4x4x4f64(afb[c0 + s2], y1[s2], b1, 0, 0, 0);
                         }
                     }
                 }
@@ -124,9 +147,9 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
             const int col = lane & 3, row = 16 * jt + 4 * ((lane >> 2) & 3) + (lane >> 4);
             GB[((job_h ? 1 : 0) * 16 + col) * TN_XS + row] = a0;
             GB[((job_h ? 1 : 0) * 16 + 4 + col) * TN_XS + row] = a1;
-            if (!job_h) {
-                GB[(2 * 16 + col) * TN_XS + row] = b0;
-                GB[(2 * 16 + 4 + col) * TN_XS + row] = b1;
+            if (second) {
+                GB[((job_h ? 3 : 2) * 16 + col) * TN_XS + row] = b0;
+                GB[((job_h ? 3 : 2) * 16 + 4 + col) * TN_XS + row] = b1;
             }
         }
         __syncthreads();  // R2
@@ -134,32 +157,55 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
         sx = rd ? GB[(0 * 16 + w) * TN_XS + lane] : 0.;
         hv = rd ? GB[(1 * 16 + w) * TN_XS + lane] : 0.;
         bx = rd ? GB[(2 * 16 + w) * TN_XS + lane] : 0.;
+        dgr = (DEC && rd) ? GB[(3 * 16 + w) * TN_XS + lane] : 0.;
         return any;
     };
     // phi, dphi, psi, dpsi at q (this lane's coordinate): integration.py:180-181 / base_hmc.py:227-231
     auto potentials = [&](double q, double &phi, double &dphi, double &psi, double &dpsi) {
-        // target surrogate with its bound (modules/poly.py:466-503)
-        const double xm = in ? q - c_mu : 0.;
-        double sx, hv, bx;
-        (void)exchange(true, in ? q : 0., xm, sx, hv, bx);
+        // target surrogate with its bound (modules/poly.py:466-503), behind the constraint transform when there is one
+        double x = q, jac = 1., gj = 0., logdet_l = 0.;
+        if constexpr (TR) {
+            double J, J2;
+            bf_to_original(q, c_kind, c_lo, c_rg, x, J, J2);
+            if (in) {
+                logdet_l = log(fabs(J));
+                jac = J;
+                gj = J2 / J;
+            } else {
+                x = 0.;
+            }
+        }
+        const double xm = in ? x - c_mu : 0.;
+        const double xd = (DEC && in) ? x - c_dmu : 0.;
+        double sx, hv, bx, dgr;
+        (void)exchange(true, in ? x : 0., xm, in ? q : 0., xd, sx, hv, bx, dgr);
         double gn = sx + c_lin;
-        // the evaluation's sums in one reduction: target value, bound, base value, and the two sums of the extrapolation
-        // outside the bound (bfhip_oob.h)
+        // the evaluation's sums in one reduction: target value, bound, base value, the two sums of the extrapolation outside the
+        // bound (bfhip_oob.h), the log-Jacobian and the decay term's radius
         const double sv = sx - c_smu, gmu = c_smu + c_lin;
-        double r5[5] = {in ? __builtin_fma(0.5 * q, sx, c_lin * q) : 0., xm * hv, in ? __builtin_fma(0.5 * q, bx, b_lin * q) : 0.,
-                        xm * gmu, xm * sv};
-        wave_sum_n<5>(r5);
-        double f = m.c0 + r5[0];
-        const double beta = sqrt(r5[1]);
+        double r7[7] = {in ? __builtin_fma(0.5 * x, sx, c_lin * x) : 0., xm * hv, in ? __builtin_fma(0.5 * q, bx, b_lin * q) : 0.,
+                        xm * gmu, xm * sv, logdet_l, xd * dgr};
+        wave_sum_n<(TR || DEC) ? 7 : 5>(reinterpret_cast<double (&)[(TR || DEC) ? 7 : 5]>(r7));
+        double f = m.c0 + r7[0];
+        const double beta = sqrt(r7[1]);
         if (beta > m.alpha) {
-            const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, beta, r5[3], r5[4]);
+            const BfOob o = bf_oob_scalars(m.alpha, m.inv_alpha, m.f_mu, m.f_poly_mu, beta, r7[3], r7[4]);
             f = o.f;
             gn = bf_oob_grad(o, gmu, sv, hv);
+        }
+        gn = gn * jac;   // chain rule (module.py:226, density.py:558); 1 without the transform
+        if constexpr (DEC) {  // density.py:740-746 (the decay gradient is added in the original space, as in the reference)
+            f -= m.decay_gamma * bf_clip0(r7[6] - m.decay_alpha2);
+            if (r7[6] > m.decay_alpha2) gn -= 2. * m.decay_gamma * dgr;
+        }
+        if constexpr (TR) {   // density.py:747-750
+            f += r7[5];
+            gn += gj;
         }
         phi = rfl(-f);   // (wave-uniform values go back to scalar registers: FP64 arithmetic leaves them in vector ones)
         dphi = in ? -gn : 0.;
         // base: c0 + lin.x + x.S_b x / 2, plus log xi
-        const double fb = a.base_c0 + r5[2];
+        const double fb = a.base_c0 + r7[2];
         psi = rfl(-(fb + a.logxi));
         dpsi = in ? -(bx + b_lin) : 0.;
     };
@@ -453,8 +499,8 @@ __global__ __launch_bounds__(64 * TN_WAVES) void bf_tnuts_kernel(DevModel m, Tnu
     }
     // the chains of this wave's workgroup that are still running need its matvec job (and the barriers)
     {
-        double t0, t1, t2;
-        while (exchange(false, 0., 0., t0, t1, t2)) { }
+        double t0, t1, t2, t3;
+        while (exchange(false, 0., 0., 0., 0., t0, t1, t2, t3)) { }
     }
 }
 
@@ -472,9 +518,11 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     if (cfg->max_treedepth < 1 || cfg->max_treedepth > BFHIP_MAX_TREEDEPTH || !(cfg->max_change > 0.) || cfg->update_window < 1)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: invalid sampler configuration");
     const DevModel &m = ctx->model;
-    if (!bf_model_plain(m) || m.DP > 64 || cfg->full_metric)
+    const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link;
+    if (!common || m.DP > 64 || cfg->full_metric)
         return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_tnuts_run: the tempered sampler covers the common surrogate (linear + quadratic "
-                                                   "configs with the bound, no transform / scaling / decay / cubic) at d <= 64 with the diagonal metric");
+                                                   "configs with the bound; constraint transform and decay optional; no device-side input "
+                                                   "scaling, no cubic configs) at d <= 64 with the diagonal metric");
     // Chains per workgroup (a workgroup is always eight waves, two workgroups per CU: the waves without a chain run matvec jobs
     // only): eight, or four when that spreads few chains over more CUs.  BFHIP_TNUTS_WPB / bfhip_debug_set("tnuts_wpb") override.
     const int forced = bf_tune().tnuts_wpb;
@@ -496,8 +544,13 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     a.scratch = (double *)ctx->scratch;
     a.base_S = tp->base_S; a.base_lin = tp->base_lin; a.base_c0 = tp->base_c0; a.logxi = tp->logxi;
     a.cpg = cpg;
-    const size_t lds = ((size_t)5 * 16 * TN_XS + TN_WAVES * TN_MAXL * TS_N + 2) * sizeof(double);
-    auto k = m.DP == 64 ? bf_tnuts_kernel<4> : (m.DP == 32 ? bf_tnuts_kernel<2> : bf_tnuts_kernel<1>);
+    const size_t lds = ((size_t)8 * 16 * TN_XS + TN_WAVES * TN_MAXL * TS_N + 2) * sizeof(double);
+    const bool tr = m.has_transform != 0, dec = m.use_decay != 0;
+    void (*k)(DevModel, TnutsArgs) = NULL;
+#define TN_PICK(Wv) (tr ? (dec ? bf_tnuts_kernel<Wv, true, true> : bf_tnuts_kernel<Wv, true, false>) : (dec ? bf_tnuts_kernel<Wv, false, true> : bf_tnuts_kernel<Wv, false, false>))
+    k = m.DP == 64 ? TN_PICK(4) : (m.DP == 32 ? TN_PICK(2) : TN_PICK(1));
+#undef TN_PICK
+    if (lds > 64 * 1024) BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((n_chain + cpg - 1) / cpg), dim3(64 * TN_WAVES), lds, ctx->stream, m, a);
     BF_HIP_CHECK(hipGetLastError());
     return 0;

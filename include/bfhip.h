@@ -217,8 +217,9 @@ int bfhip_tree_size_mode_share(bfhip_ctx *ctx, int n_chain, int n_out, const dou
 /* ------------------------------------------------------------------------------------------------
  * Tempered NUTS: TNUTS (samplers/tnuts.py:15-41) = BaseTHMC.astep
  * (samplers/hmc_utils/base_hmc.py:220-262) + the NUTS tree + TCpuLeapfrogIntegrator (samplers/hmc_utils/integration.py:98-222).
- * The target is the uploaded surrogate density (common surrogate: linear + quadratic configs with the bound, d <= 64,
- * diagonal metric); the base density of TNTrace(density_base=..., logxi=...) (samplers/sample_trace.py:540-567,607-629) is a
+ * The target is the uploaded surrogate density (common surrogate: linear + quadratic configs with the bound, optionally behind the
+ * constraint transform -- input_scales / hard bounds -- and with the decay term; surrogate input scales fold away at upload;
+ * d <= 64, diagonal metric); the base density of TNTrace(density_base=..., logxi=...) (samplers/sample_trace.py:540-567,607-629) is a
  * quadratic log-density  c0 + lin.x + x.S x / 2  given by DEVICE arrays (e.g. a Gaussian).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -87,6 +87,46 @@ def test_device_tnuts_matches_oracle_on_shared_streams(fx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('feature', ['bounds', 'decay', 'bounds_decay', 'decay32'])
+def test_device_tnuts_behind_the_transform_and_with_decay_matches_oracle(fx, feature):
+    """Round 5: the tempered sampler on targets with hard bounds / input scales (the constraint transform: density.py:92-140,
+    747-750) and with the decay penalty (:740-746) -- what every GBS example of the reference has -- against the oracle's TNUTS
+    (whose potentials are the general Density.logp_and_grad) on shared streams.  The base density stays in the sampler's space."""
+    from oracle import oracle as orc
+    from bayesfast_amd.device import get_context, DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    d = 32 if feature == 'decay32' else 12
+    spec = dict(correlated_gaussian_spec(d, fit_scale=1.5)[0])
+    po = spec['poly']
+    if 'decay' in feature:
+        spec.update(use_decay=True, decay_mu=np.asarray(po['mu']) + 0.05, decay_hess=po['hess'], decay_alpha2=(0.8 * float(po['alpha']))**2, decay_gamma=0.1)
+    if 'bounds' in feature:
+        lo = np.full(d, -9.) + np.arange(d) * 0.01
+        spec.update(ranges=np.stack([lo, lo + 18.], 1), hard_bounds=np.array(([[1, 1], [1, 0], [0, 1], [0, 0]] * d)[:d], dtype=np.uint8))
+    rng = np.random.default_rng(5)
+    base_mean, base_cov = np.zeros(d), np.eye(d) * (0.3 if 'bounds' in feature else 1.5)
+    base = orc.gaussian_base_spec(base_mean, base_cov)
+    ctx = get_context(0)
+    n_chain, n_iter, n_warmup = 11, 16, 10
+    x0 = rng.normal(size=(n_chain, d)) * 0.3
+    u0 = rng.normal(size=n_chain)
+    dc = DeviceChains(DeviceDensity(spec, ctx), x0, seed=77)
+    s, st, stt = dc.run_tempered(n_iter, base_mean, base_cov, logxi=0.3, u_0=u0, n_warmup=n_warmup)
+    s, st, stt = s.cpu().numpy(), st.cpu().numpy(), stt.cpu().numpy()
+    for i in (0, 4, 10):
+        so, sto, _ = orc.tnuts_run(spec, base, 0.3, orc.Chain(x0[i]), orc.make_rng('xoshiro', seed=77, stream=i), u0[i], n_iter, n_warmup)
+        for f in ('tree_depth', 'tree_size', 'diverging'):
+            assert np.array_equal(st[i, :, _lib.NSTATS.index(f)], sto[f]), (feature, i, f, st[i, :, _lib.NSTATS.index(f)], sto[f])
+        np.testing.assert_allclose(s[i, :6], so[:6], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(stt[i, :6, 0], sto['u'][:6], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(stt[i, :6, 1], sto['weight'][:6], rtol=1e-7, atol=1e-8)
+        for f in ('logp', 'energy', 'step_size'):
+            np.testing.assert_allclose(st[i, :6, _lib.NSTATS.index(f)], sto[f][:6], rtol=1e-8, atol=1e-8, err_msg=f)
+
+
+@pytest.mark.gpu
 def test_device_tnuts_workgroup_size_never_changes_results(fx):
     """bf_tnuts_kernel with 4 and 8 chains per workgroup (always eight waves: the ones without a chain run the shared matvec jobs
     only; the library takes four chains per workgroup when that spreads them over more CUs): samples, statistics, tempering
@@ -137,3 +177,30 @@ def test_sample_entry_point_runs_tnuts_and_tempering_brings_base_mass(fx):
     assert 0.9 < ratio < 1.7
     with pytest.raises(NotImplementedError):
         bfa.sample(dens, dict(n_chain=4), sampler='THMC')
+
+
+@pytest.mark.gpu
+def test_sample_tnuts_on_a_bounded_density_with_decay():
+    """bayesfast_amd.sample(..., sampler='TNUTS') on a density with input_scales, hard bounds and the decay term -- the shape of
+    the reference's GBS notebooks -- runs on the device (round 5; it was refused before) and stays inside the bounds."""
+    import bayesfast_amd as bfa
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    d = 8
+    _, cov = correlated_gaussian_spec(d)
+    prec = np.linalg.inv(cov)
+    rng = np.random.default_rng(2)
+    rg = np.stack([np.full(d, -6.), np.full(d, 6.)], 1)
+    su = bfa.PolyModel('quadratic', input_size=d, output_size=1, bound_options=dict(alpha_p=150.))
+    dens = bfa.SurrogateDensity(su, input_scales=rg, hard_bounds=True, decay_options=dict(use_decay=True))
+    xf = np.clip(rng.multivariate_normal(np.zeros(d), cov * 2.25, size=4 * su.n_param), -5.9, 5.9)
+    dens.fit(xf, -0.5 * np.einsum('ij,jk,ik->i', xf, prec, xf))
+    np.random.seed(0)
+    kw = dict(density_base=bfa.GaussianBase(np.zeros(d), np.eye(d) * 0.05), logxi=0., n_chain=24, n_iter=160, n_warmup=80, random_generator=4)
+    tt = bfa.sample(dens, kw, sampler='TNUTS', verbose=False)
+    xs = tt.get(flatten=True, original_space=True)
+    assert tt.sampler == 'TNUTS' and xs.shape == (24 * 80, d)
+    assert np.isfinite(xs).all() and (xs > -6.).all() and (xs < 6.).all()
+    w = tt.stat('weight')
+    assert np.isfinite(w).all() and (w > 0).all()
+    ratio = np.mean(xs.var(0) / np.diag(cov))
+    assert 0.5 < ratio < 2.0, ratio
