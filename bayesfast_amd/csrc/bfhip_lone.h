@@ -136,20 +136,22 @@ struct LoneJobs {
 // integrator, 1.76 us per leapfrog step; three job waves on SIMDs 1-3 and a SIMD without jobs for integrator and bookkeeper, 1.87:
 // the bookkeeper's exponential runs 500 cycles shorter and the jobs 400 longer.)
 // (The same with the decay term, whose jobs are twelve chains of sixteen k-steps: three job waves of four chains, 1.72 against 1.67 us.)
-template <int W, bool DEC> struct LoneWaves {
+// FORM 1 (d > 32 only): three job waves instead of four -- a workgroup of four waves, two of them a CU at 256 registers a wave, for
+// launches of up to two chains per CU (the jobs take 48 matrix instructions per wave instead of 32).
+template <int W, bool DEC, int FORM = 0> struct LoneWaves {
     static constexpr bool ITILE = true;                   // the integrator runs jobs
     // waves that run jobs.  d <= 32: the integrator alone -- its 8 chains of 4 k-steps cost 250 cycles more than shared with a second
     // wave, but a workgroup is then two waves and four of them fit a CU at 256 registers a wave, without the bookkeeper's spills:
     // 32-d x 1024 chains 4.18 -> 4.47 x 10^8 (profiles/r05_lone_layouts.log)
-    static constexpr int NT = W <= 2 ? 1 : W;
+    static constexpr int NT = W <= 2 ? 1 : (FORM == 1 ? 3 : W);
     static constexpr int KW = ITILE ? NT : NT + 1;        // the bookkeeper's wave
     static constexpr int NW = KW + 1;
 };
 
-template <int W, bool TR, bool DEC, int MINW>
-__global__ __launch_bounds__((LoneWaves<W, DEC>::NW * 64), MINW) void bf_lone_kernel(DevModel m, SamplerArgs a) {
+template <int W, bool TR, bool DEC, int MINW, int FORM = 0>
+__global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_lone_kernel(DevModel m, SamplerArgs a) {
     using LG = LoneGeo<W, DEC>;
-    using LWV = LoneWaves<W, DEC>;
+    using LWV = LoneWaves<W, DEC, FORM>;
     constexpr int DP = LG::DP, NS = LG::NS, KS = LG::KS;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *XT = lds + LG::o_XT, *GB = lds + LG::o_GB, *LF = lds + LG::o_LF, *NI = lds + LG::o_NI, *VD = lds + LG::o_VD;

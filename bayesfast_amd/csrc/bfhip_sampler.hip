@@ -1755,16 +1755,32 @@ __global__ void bf_tail_list_kernel(int n_chain, int iter_end, const double *sc,
 // the second instantiation's waves per SIMD: 4 (W + 1) waves a CU at d <= 32, 2 x 5 at d <= 64
 template <int W> struct LoneOcc { static constexpr int MINW = W == 1 ? 2 : 3; };   // (W = 4: two workgroups of five waves a CU)
 
-template <int W, bool TR, bool DEC>
-static int lone_blocks_per_cu(bfhip_ctx *ctx, bool roomy) {
+// form 0: the roomy instantiation (W job waves at d > 32); form 1: three job waves (d > 32: two four-wave workgroups a CU at 256
+// registers); form 2: the tight instantiation (168 / 128 registers: the tail's stragglers when they outnumber the CUs' room)
+template <int W, bool TR, bool DEC, int FORM>
+static const void *lone_kernel_ptr() {
+    if constexpr (FORM == 0) { auto k = bf_lone_kernel<W, TR, DEC, 1, 0>; return (const void *)k; }
+    else if constexpr (FORM == 1) { auto k = bf_lone_kernel<W, TR, DEC, 1, (W == 4 ? 1 : 0)>; return (const void *)k; }
+    else { auto k = bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW, 0>; return (const void *)k; }
+}
+template <int W, bool DEC, int FORM> constexpr int lone_threads() { return LoneWaves<W, DEC, (FORM == 1 && W == 4) ? 1 : 0>::NW * 64; }
+
+template <int W, bool TR, bool DEC, int FORM>
+static int lone_blocks_per_cu(bfhip_ctx *ctx) {
     const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
     int nb = 0;
-    auto k1 = bf_lone_kernel<W, TR, DEC, 1>;
-    auto k4 = bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>;
-    const void *k = roomy ? (const void *)k1 : (const void *)k4;
+    const void *k = lone_kernel_ptr<W, TR, DEC, FORM>();
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, LoneWaves<W, DEC>::NW * 64, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, lone_threads<W, DEC, FORM>(), lds) != hipSuccess) return 0;
     return nb;
+}
+
+template <int W, bool TR, bool DEC, int FORM>
+static void lone_launch_form(bfhip_ctx *ctx, const SamplerArgs &args, int n_blocks) {
+    const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
+    if constexpr (FORM == 0) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1, 0>), dim3(n_blocks), dim3(lone_threads<W, DEC, 0>()), lds, ctx->stream, ctx->model, args);
+    else if constexpr (FORM == 1) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1, (W == 4 ? 1 : 0)>), dim3(n_blocks), dim3(lone_threads<W, DEC, 1>()), lds, ctx->stream, ctx->model, args);
+    else hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW, 0>), dim3(n_blocks), dim3(lone_threads<W, DEC, 2>()), lds, ctx->stream, ctx->model, args);
 }
 
 // returns 1 when the launch was taken, 0 when the caller should use the pipelined kernel, < 0 on error
@@ -1777,18 +1793,24 @@ static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks,
     args.tail_done = NULL;
     if (!tail) { args.tail_list = NULL; args.tail_count = NULL; }
     args.stamps = bf_tune().stamps_lone;
-    const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
-    // the roomy instantiation when every workgroup still fits, the tighter one otherwise
+    // every workgroup must be resident (a chain that waited for a slot would double the launch): the roomiest form that holds them
     const int need = (n_blocks + ctx->n_cu - 1) / ctx->n_cu;
-    bool roomy = true;
-    if (lone_blocks_per_cu<W, TR, DEC>(ctx, true) < need) {
-        roomy = false;
-        if (lone_blocks_per_cu<W, TR, DEC>(ctx, false) < need && bf_tune().lone != 2 && !tail) return 0;
+    int form = 0;
+    if (lone_blocks_per_cu<W, TR, DEC, 0>(ctx) < need) {
+        form = 1;
+        if (W != 4 || lone_blocks_per_cu<W, TR, DEC, 1>(ctx) < need) {
+            form = 2;
+            // (a whole launch takes the kernel only in a roomy form: two workgroups per CU at 168 registers ran a 64-d chain at half
+            // the speed of one; the tight form is for the tail, whose chains are there anyway, and for tests)
+            if (bf_tune().lone != 2 && !tail) return 0;
+        }
     }
-    if (roomy) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1>), dim3(n_blocks), dim3(LoneWaves<W, DEC>::NW * 64), lds, ctx->stream, ctx->model, args);
-    else hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW>), dim3(n_blocks), dim3(LoneWaves<W, DEC>::NW * 64), lds, ctx->stream, ctx->model, args);
+    if (bf_tune().lone_form >= 0 && bf_tune().lone_form <= 2) form = bf_tune().lone_form;   // (tests: the forms give the same numbers)
+    if (form == 0) lone_launch_form<W, TR, DEC, 0>(ctx, args, n_blocks);
+    else if (form == 1) lone_launch_form<W, TR, DEC, 1>(ctx, args, n_blocks);
+    else lone_launch_form<W, TR, DEC, 2>(ctx, args, n_blocks);
     BF_HIP_CHECK(hipGetLastError());
-    if (!tail) snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", roomy ? 1 : LoneOcc<W>::MINW);
+    if (!tail) snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", form);
     return 1;
 }
 

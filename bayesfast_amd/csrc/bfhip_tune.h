@@ -14,6 +14,7 @@ struct BfTune {
     int tail_q;          // BFHIP_TAIL_Q (default 3): ... once this many quarters of the launch's chains are through
     int tail_max;        // BFHIP_TAIL_MAX (default 4): plain sliced kernel, chains of a group that may take the VALU matvec
     int lone;            // BFHIP_LONE (default 1): the latency kernel -- 1 automatic, 0 never, 2 wherever it is implemented
+    int lone_form;       // BFHIP_LONE_FORM (default -1: by occupancy): 0 roomy, 1 three job waves (d > 32), 2 tight registers
     int pld_waves;       // BFHIP_PLD_WAVES: 8 or 16 waves per workgroup for the pipeline density (0: by chain count)
     int no_vel_ahead;    // BFHIP_NO_VEL_AHEAD: full-rank metric without the next step's velocity taken ahead
     int tnuts_wpb;       // BFHIP_TNUTS_WPB: tempered NUTS, chains per workgroup (4, 8; 0: automatic)

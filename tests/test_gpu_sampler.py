@@ -361,6 +361,23 @@ def test_lone_kernel_is_bit_identical_to_pipelined_kernel(ctx, case):
     ts = out[0][1][:, :, _lib.NSTATS.index('tree_size')]
     if case == 'balanced':
         assert ts.max() >= 15 and ts.min() <= 3
+    if case in ('balanced', 'decay', 'd32', 'bounded'):
+        # the kernel's other forms (three job waves at d > 32; the tight-register instantiation of a crowded tail): the same numbers
+        try:
+            _lib.debug_set('no_group', 1)
+            _lib.debug_set('lone', 2)
+            for form in (1, 2):
+                _lib.debug_set('lone_form', form)
+                dc = DeviceChains(dens, x0, seed=11, step_size=1.)
+                s1, st1 = dc.run(45, 'NUTS', n_warmup=30, **kw, layout='wave')
+                s2, st2 = dc.run(15, 'NUTS', n_warmup=30, **kw, layout='wave')
+                got = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)]
+                for nm, a, b in zip(names, out[2][:-1], got):
+                    assert np.array_equal(a, b, equal_nan=True), (form, nm)
+        finally:
+            _lib.debug_set('lone_form', -1)
+            _lib.debug_set('lone', 1)
+            _lib.debug_set('no_group', 0)
 
 
 def test_launch_cuts_do_not_change_results(ctx):
