@@ -218,7 +218,9 @@ class DeviceChains:
             return False
         # (32 < d <= 64: with at most four chains per workgroup -- n <= 4 x CUs, wave_layout_cpg -- the pipelined kernel's jobs run
         # on 4 x 4 x 4 MFMA tiles: 1024 chains 3.7 against the split layout's 2.9 x 10^8, 512 chains 1.9 against 1.5)
-        return ((self.d <= 16 and n < 4 * self._n_cu) or (16 < self.d <= 32 and n < 6 * self._n_cu) or
+        # (round 5: up to four chains per CU at d <= 32 the wave layout is the latency kernel, csrc/bfhip_lone.h -- d = 16 x 1024 chains
+        # 4.8 against the split layout's 2.8 x 10^8, profiles/r05_lone_sweep.log -- so four chains per CU are "small" at d <= 16 too)
+        return ((self.d <= 16 and n <= 4 * self._n_cu) or (16 < self.d <= 32 and n < 6 * self._n_cu) or
                 (32 < self.d <= 64 and n <= 4 * self._n_cu))
 
     def _lanes_whatever_the_trees(self):
