@@ -84,7 +84,18 @@ struct SamplerGeo {
 #ifndef BF_JOB_CHUNK
 #define BF_JOB_CHUNK 4
 #endif
-#define BF_SAMPLER_WAVES(W, FULLM, FS) (((W) == 8 || (FULLM) || (FS) == 9 || (FS) == 10) ? 8 : 16)
+// FS = 17 (config 5's shard, at most four chains per CU): FOUR waves of 512 registers, each with a chain and with two row tiles of S
+// in registers for the whole launch.  In the eight-wave form every workgroup streams the 128 KB of S fragments from L2 in every
+// trip -- 33 GB/s per CU in 8-byte loads, which is what the XCD's L2 gives at that width (MI355X_MICROARCH.md, indexed rows): the
+// jobs were 9.3 k of the trip's 18.7 k cycles (tools/trace_sliced.py, profiles/r05b_trace_config5.log).
+// (the A operand from an accumulation register: the 256 of them hold the four row tiles for the whole launch, and the compiler's own
+// allocation copied every operand to a vector register first -- two v_accvgpr_read per MFMA)
+// (inline assembly hides the instruction from the compiler's hazard recogniser: the s_nop 1 in front keeps dependent MFMAs of two
+// interleaved chains five issue slots apart -- the compiler's own code keeps three to four -- and BF_MFMA_Q_DONE separates the last
+// one from the first read of its result)
+#define BF_MFMA_Q_ACC(acc, af, xv) asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(acc) : "a"(af), "v"(xv))
+#define BF_MFMA_Q_DONE(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
+#define BF_SAMPLER_WAVES(W, FULLM, FS) ((FS) == 17 ? 4 : (((W) == 8 || (FULLM) || (FS) == 9 || (FS) == 10) ? 8 : 16))
 
 // PLAIN fixes the feature set of the common surrogate at compile time (linear + quadratic configs with the
 // extrapolation bound; no constraint transform, no input scaling, no decay, no cubic configs): the branches
@@ -113,7 +124,8 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     const bool f_quad = SPEC ? true : (PLD ? false : (bool)m.has_quad), f_bound = (SPEC || PLDC) ? true : (bool)m.use_bound;
     const bool f_decay = SPEC ? (FS & 2) != 0 : (PLDC ? false : (bool)m.use_decay), f_tr = SPEC ? (FS & 4) != 0 : (PLDC ? true : (bool)m.has_transform);
     // FS == 16: linear + quadratic + cubic configs with the bound and nothing else (BASELINE config 5's surrogate), fixed at compile time
-    constexpr bool CUBIC = FS == 16;
+    constexpr bool CUBIC = FS == 16 || FS == 17;
+    constexpr bool AREG8 = FS == 17;   // (S fragments in registers: see BF_SAMPLER_WAVES)
     const bool f_su = SPEC ? false : (PLDC ? true : (bool)m.has_su), f_cubic = CUBIC ? true : ((SPEC || PLD) ? false : (bool)m.has_cubic);
     const bool f_link = (SPEC || PLD) ? false : (bool)m.has_link;  // Gaussian likelihood of the surrogate's output (density.py:552-560)
     const int ks_rt = PLAIN ? ((W == 2 || W == 4) ? 2 : 1) : a.ks;  // K-split of the matvec jobs (sampler_ksplit)
@@ -172,6 +184,16 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #pragma unroll
         for (int s = 0; s < KPJ_P; ++s) afr[s] = (w < NJOB_P) ? Af[s * 64] : 0.;
     }
+    double afr8[AREG8 ? 4 : 1][AREG8 ? NS : 1];   // row tiles w and w + 4 of S, then of H, all k-steps
+    if constexpr (AREG8) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                afr8[jt][s] = m.Sf[((w + 4 * jt) * NS + s) * 64 + lane];
+                afr8[2 + jt][s] = m.Hf[((w + 4 * jt) * NS + s) * 64 + lane];
+            }
+    }
     if constexpr (TAIL) {
         // frag[(t * NS + s) * 64 + l] = M[16 t + (l & 15)][4 s + (l >> 4)]  ->  RM[b][row][col]
         for (int i = tid; i < MAT; i += NTH) {
@@ -199,13 +221,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     if (cub_l) {
         const int n22 = m.n2 * m.n2;
         for (int i = tid; i < n22; i += NTH) { CUB[i] = m.A2t[i]; CUB[n22 + i] = m.A2[i]; }
-        // T3t is [k][l][j]; in LDS it is [c][k][j][lq][i] with l = 16 c + lq + 4 i (zero where l >= n3): lane (j, lq) of the
-        // contraction reads its four l of a chunk as two 16-byte pairs, and a wave's 64 lanes read 2 KB in a row
+        // T3t is [k][l][j]; in LDS it is [k][l / 2][j][l & 1] with l padded to a multiple of 16 (zero where l >= n3): lane (j, kq)
+        // of the contraction reads T[j, k, l], T[j, k, l + 1] as one 16-byte pair, sixteen lanes 256 bytes in a row
         const int n3 = m.n3, nc3 = (n3 + 15) >> 4;
         double *T3x = lds + (((size_t)(CUB + 2 * n22 - lds) + 1) & ~(size_t)1);
         for (int i = tid; i < nc3 * n3 * n3 * 16; i += NTH) {
-            const int q = i & 15, jj = (i >> 4) % n3, k = ((i >> 4) / n3) % n3, c = (i >> 4) / (n3 * n3);
-            const int l = 16 * c + (q >> 2) + 4 * (q & 3);
+            const int jj = (i >> 1) % n3, l = 2 * (((i >> 1) / n3) % (8 * nc3)) + (i & 1), k = (i >> 1) / (n3 * 8 * nc3);
             T3x[i] = l < n3 ? m.T3t[((size_t)k * n3 + l) * n3 + jj] : 0.;
         }
         mk2 = lane < m.n2 ? m.mask2[lane] : 0;
@@ -364,11 +385,20 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
 #ifdef BF_TRACE
     __shared__ unsigned long long TRC[BF_TRACE * 16];
 #define TRACE(k) do { if ((!PLD || (k) <= 10) && w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
+#ifdef BF_TRACE_CUBIC   // (stamps 11-13 inside cubic_lds instead of the leaf unit's)
+#define TRACEU(k) do { } while (0)
+#define TRACEC(k) TRACE(k)
+#else
+#define TRACEU(k) TRACE(k)
+#define TRACEC(k) do { } while (0)
+#endif
 #define TRACEP(k) do { if (PLD && w == 0 && blockIdx.x == 0 && trip_no < BF_TRACE && lane == 0) TRC[trip_no * 16 + (k)] = clock64(); } while (0)
     for (int i = threadIdx.x; i < BF_TRACE * 16; i += NTH) TRC[i] = 0;
 #else
 #define TRACE(k) do { } while (0)
 #define TRACEP(k) do { } while (0)
+#define TRACEU(k) do { } while (0)
+#define TRACEC(k) do { } while (0)
 #endif
 
     auto run_unit = [&](bool have_ev, double E_new, double logp_new) {
@@ -406,7 +436,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                     double dE = E_new - start_energy;
                     if (dE != dE) dE = INFINITY;
                     if (fabs(dE) > fabs(max_de)) max_de = dE;
-                    TRACE(11);
+                    TRACEU(11);
                     cs_set(CS_T_E, E_new);
                     cs_set(CS_T_LOGP, logp_new);
                     T_acc = 0.; lev = 0;
@@ -429,7 +459,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                         T_W = uexp(aw);
                         const double pacc = (w_off == 0.) ? T_W : uexp(-dE);
                         T_acc = pacc > 1. ? 1. : pacc;
-                        TRACE(12);
+                        TRACEU(12);
 #pragma unroll
                         for (int e = 0; e < E; ++e) { TLp[e] = p[e]; TPs[e] = p[e]; TPq[e] = q[e]; }
                         unit = U_MERGE;  // resolved below (push / complete need no further trip)
@@ -443,14 +473,14 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                                 d0 += ps0 * (FULLM ? L0v[FULLM ? e : 0] : var[e] * L0p[e]);  // nuts.py:150-151
                                 d1 += ps0 * (FULLM ? vcur[FULLM ? e : 0] : var[e] * p[e]);
                             }
-                            TRACE(13);
+                            TRACEU(13);
                             { double r2[2] = {d0, d1}; wave_sum_n<2>(r2); d0 = r2[0]; d1 = r2[1]; }
-                            TRACE(14);
+                            TRACEU(14);
                             T_acc = L0_acc + T_acc;  // :173
                             const double Wsum = L0_W + T_W;
                             if (Wsum != Wsum) err = 2;
                             const double u = bf_u01(bf_xoshiro_next(rs));  // :163-167, drawn even when turning
-                            TRACE(15);
+                            TRACEU(15);
                             if ((d0 <= 0.) || (d1 <= 0.)) {
                                 unit = U_ABORT;
                                 lev = 1;
@@ -889,6 +919,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 if (mine) dst[e] += gv;
             }
         };
+        TRACEC(11);
         const int n2 = m.n2, n3 = m.n3;
         const double *A2t_l = CUB, *A2_l = CUB + n2 * n2;
         const double *T3_l = lds + (((size_t)(CUB + 2 * n2 * n2 - lds) + 1) & ~(size_t)1);
@@ -900,6 +931,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             const int j = jb + jl;
             const bool on = j < n2;
             const int jc = on ? j : 0;
+            const double xj = __shfl(xm2, jc, 64);   // (on its way before the sums, used after them)
             double v1 = 0., v2 = 0.;
             for (int kk = 0; kk < n2; kk += 16) {
                 double a1[4], a2[4], xk[4];
@@ -931,58 +963,65 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             }
             v1 = swap32_add_f64(swap16_add_f64(v1));
             v2 = swap32_add_f64(swap16_add_f64(v2));
-            const double xj = __shfl(xm2, jc, 64);
             const double gj2 = 2. * xj * v1 + v2;
             if (on && kq == 0) fsum += xj * xj * v1;
             fetch_l(pj2, jb, gj2, gc2);
         }
-        // cubic-3, lane (j, lq): sum_k x_k sum_{l = lq mod 4} T[j, k, l] x_l -- the lane's own four x_l of a chunk of 16
-        // stay in registers, x_k is the only broadcast (a third of the instructions of the (j, kq) form,
-        // which read every x_l through a readlane; the trip is its instruction count)
+        TRACEC(12);
+        // cubic-3, lane (j, kq): sum_k x_k M[j, k] with M[j, k] = sum_l T[j, k, l] x_l taken as ONE fma chain over l from zero -- what a
+        // matrix instruction computes for a tile of M (and sixteen independent chains per lane at 16 inputs, where the (j, lq) form
+        // before it had one chain over k: it was the longest piece of config 5's trip, tools/trace_sliced.py).  The lane's k are
+        // 16 g + 4 u + kq; x_l is a scalar operand, x_k the only broadcast per lane.
         for (int jb = 0; jb < n3; jb += 16) {
             const int j = jb + jl;
             const bool on = j < n3;
             const int jc = on ? j : 0;
+            const int nl2 = 8 * nc3;
+            const double xj = __shfl(xm3, jc, 64);
             double sacc = 0.;
-            for (int c = 0; c < nc3; ++c) {
-                double xq[4];
+            for (int g = 0; g < nc3; ++g) {
+                double mk[4] = {0., 0., 0., 0.};
+                int Tk[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int l = 16 * c + kq + 4 * i;
-                    xq[i] = __shfl(xm3, l < n3 ? l : 0, 64);   // (the table is zero there)
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 16 * g + 4 * u + kq;
+                    Tk[u] = ((k < n3 ? k : 0) * nl2 * n3 + jc) * 2;
                 }
-                const double *Tc = T3_l + ((size_t)c * n3 * n3 + jc) * 16 + kq * 4;
-                for (int k = 0; k < n3; k += 4) {
-                    d2_t ta[4][2];
-                    const bool full = k + 4 <= n3;   // (wave-uniform)
+                for (int l2 = 0; l2 < nl2; l2 += 2) {
+                    d2_t ta[2][4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double *pk = Tc + (size_t)((full || k + u < n3) ? k + u : 0) * n3 * 16;
-                        ta[u][0] = *(const d2_t *)pk;
-                        ta[u][1] = *(const d2_t *)(pk + 2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // all eight loads on their way before the first product
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        double t = ta[u][0][0] * xq[0];
-                        t += ta[u][0][1] * xq[1];
-                        t += ta[u][1][0] * xq[2];
-                        t += ta[u][1][1] * xq[3];
-                        if (full || k + u < n3) sacc += t * readlane_f64(xm3, (k + u) & 63);
+                        for (int u = 0; u < 4; ++u) ta[i][u] = *(const d2_t *)(T3_l + Tk[u] + (l2 + i) * n3 * 2);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int l = 2 * (l2 + i);   // (uniform; past n3 the table is zero and any finite x will do)
+                        const double x0 = readlane_f64(xm3, l < n3 ? l : 0), x1 = readlane_f64(xm3, l + 1 < n3 ? l + 1 : 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            mk[u] = __builtin_fma(ta[i][u][0], x0, mk[u]);
+                            mk[u] = __builtin_fma(ta[i][u][1], x1, mk[u]);
+                        }
                     }
                 }
+                double xk[4];   // (the four broadcasts on their way together, then the chain)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xk[u] = __shfl(xm3, 16 * g + 4 * u + kq < n3 ? 16 * g + 4 * u + kq : 0, 64);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sacc = __builtin_fma(mk[u], 16 * g + 4 * u + kq < n3 ? xk[u] : 0., sacc);
             }
             sacc = swap32_add_f64(swap16_add_f64(sacc));
-            const double xj = __shfl(xm3, jc, 64);
             if (on && kq == 0) fsum += xj * (0.5 * sacc) * (1. / 3.);
             fetch_l(pj3, jb, 0.5 * sacc, gc3);
         }
+        TRACEC(13);
         return fsum;
     };
     // (d = 128 only, where they were measured: the 128-register instantiations of d <= 64 and the full-rank one have no
     // register to spare -- with these paths compiled in they spilled 25 % more VGPRs, the full-rank one 135 instead of 90)
     constexpr bool XT = W == 8 && !FULLM;
-    const bool cub_early = XT && cub_l && 2 * cpg <= NWV;   // (fixed for the launch, the same in every wave)
+    const bool cub_early = XT && !AREG8 && cub_l && 2 * cpg <= NWV;   // (fixed for the launch, the same in every wave)
     for (int trip = 0;; ++trip) {
         trip_no = trip;
         TRACE(0);
@@ -1179,6 +1218,58 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 }
             } else
             for (int job = w; job < n_job; job += NWV) {
+                if constexpr (AREG8 && KS == 1) {
+                    // this wave's jobs, row tiles w and w + 4 of S and of H, as ONE pass over the k-steps with the A operands from
+                    // registers: four independent accumulation chains (each the same instructions in the same order as the
+                    // eight-wave form's job, so the same numbers); the next chunk's B operands are fetched under this chunk's MFMAs
+                    if (mat0 == 0 && mat1 == 1) {
+                        if (job != w) continue;   // (the wave's other jobs went with its first)
+                        const bool with_h = n_job > W;
+                        const double *Xs = XB + (lane & ~15) + (lane & 3), *Xh = Xs + NS * XS;
+                        double q1 = 0., q2 = 0., q3 = 0., q4 = 0.;
+                        double xs_[8], xh_[8];
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) { xs_[s] = Xs[s * XS]; xh_[s] = with_h ? Xh[s * XS] : 0.; }
+#pragma unroll
+                        for (int c0 = 0; c0 < NS; c0 += 8) {
+                            double ns_[8], nh_[8];
+                            if (c0 + 8 < NS) {
+#pragma unroll
+                                for (int s = 0; s < 8; ++s) { ns_[s] = Xs[(c0 + 8 + s) * XS]; nh_[s] = with_h ? Xh[(c0 + 8 + s) * XS] : 0.; }
+                            }
+                            if (with_h) {
+#pragma unroll
+                                for (int s = 0; s < 8; ++s) {
+                                    BF_MFMA_Q_ACC(q1, afr8[0][c0 + s], xs_[s]);
+                                    BF_MFMA_Q_ACC(q2, afr8[1][c0 + s], xs_[s]);
+                                    BF_MFMA_Q_ACC(q3, afr8[2][c0 + s], xh_[s]);
+                                    BF_MFMA_Q_ACC(q4, afr8[3][c0 + s], xh_[s]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int s = 0; s < 8; ++s) {
+                                    BF_MFMA_Q_ACC(q1, afr8[0][c0 + s], xs_[s]);
+                                    BF_MFMA_Q_ACC(q2, afr8[1][c0 + s], xs_[s]);
+                                }
+                            }
+                            if (c0 + 8 < NS) {
+#pragma unroll
+                                for (int s = 0; s < 8; ++s) { xs_[s] = ns_[s]; xh_[s] = nh_[s]; }
+                            }
+                        }
+                        BF_MFMA_Q_DONE(q1, q2, q3, q4);
+                        double *gq = GB + (lane & 3) * GS + 4 * ((lane >> 2) & 3) + (lane >> 4);
+                        gq[16 * w] = q1;
+                        gq[16 * (w + 4)] = q2;
+                        if (with_h) {
+                            gq[16 * GS + 16 * w] = q3;
+                            gq[16 * GS + 16 * (w + 4)] = q4;
+                        }
+                        TRACE(4);
+                        TRACE(5);
+                        continue;
+                    }
+                }
                 const int slot_m = job / (W * KS), rem = job % (W * KS);
                 const int t = rem / KS, kp = rem % KS;
                 const int b = slot_m == 0 ? mat0 : (slot_m == 1 ? mat1 : 2);  // 0 S, 1 H, 2 H_decay
@@ -1709,6 +1800,8 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
     args.cub_lds = sampler_cubic_lds(ctx->model, FS == 1) ? 1 : 0;
     const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
+    snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_sampler_kernel<%d, %s, %s, %d, %d>", W, NUTS ? "true" : "false",
+             STAMPS ? "true" : "false", FS, FULLM);
     hipLaunchKernelGGL(k, dim3(groups), dim3(NWV * 64), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1943,8 +2036,14 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     }
     // d = 128 with cubic configs and nothing else (config 5): the feature set fixed at compile time too
     if (W == 8 && NUTS && !(bf_tune().no_plain != 0) && m.has_quad && m.use_bound && m.has_cubic && !m.use_decay && !m.has_transform && !m.has_su &&
-        !m.has_link)
+        !m.has_link) {
+        // at most four chains per CU (config 5's shard): four waves, each with a chain and two row tiles of S in registers
+        const int form = bf_tune().cubic_form;
+        if (form != 8 && bf_tune().wave_cpg == 0 && sampler_ksplit(m) == 1 && sampler_cubic_lds(m, false) &&
+            (form == 4 || args.n_chain <= 4 * ctx->n_cu))
+            return launch_sampler_t<(W == 8 ? 8 : W), NUTS, false, (W == 8 && NUTS ? 17 : 0)>(ctx, args);
         return launch_sampler_t<(W == 8 ? 8 : W), NUTS, false, (W == 8 && NUTS ? 16 : 0)>(ctx, args);
+    }
 #endif
     return launch_sampler_t<W, NUTS, false, 0>(ctx, args);
 }

@@ -893,6 +893,43 @@ def test_launches_may_alternate_between_the_layouts(ctx):
         np.testing.assert_allclose(s[i], so, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('n_chain', [37, 600])
+def test_config5_four_wave_form_is_bit_identical_to_the_eight_wave_form(ctx, n_chain):
+    """bf_sampler_kernel<8, ..., 17> (config 5's shard: four waves of 512 registers, each with a chain and two row tiles of S in
+    registers for the whole launch) against <8, ..., 16> (eight waves, S streamed from L2 in every trip): samples, statistics,
+    adapted state, random streams and leapfrog counts EQUAL -- with one chain per workgroup (37 chains) and with four (600)."""
+    import bayesfast_amd as bfa
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import planck_like_logp
+    from bayesfast_amd import _lib
+    d = 128
+    rng = np.random.default_rng(2024)
+    logp, chol = planck_like_logp(d)
+    m16 = np.arange(16)
+    su = bfa.PolyModel([bfa.PolyConfig('linear'), bfa.PolyConfig('quadratic'), bfa.PolyConfig('cubic-2', input_mask=m16),
+                        bfa.PolyConfig('cubic-3', input_mask=m16)], input_size=d, output_size=1)
+    den = bfa.SurrogateDensity(su)
+    x_fit = rng.normal(size=(su.n_param + 800, d)) @ chol.T
+    den.fit(x_fit, logp(x_fit))
+    x0 = x_fit[:n_chain] * 0.5
+    dd = den.device(ctx)
+    out = {}
+    try:
+        for form in (8, 4):
+            _lib.debug_set('cubic_form', form)
+            dc = DeviceChains(dd, x0, seed=5)
+            kw = dict(n_warmup=24, max_treedepth=5)
+            s1, st1 = dc.run(24, 'NUTS', **kw)
+            s2, st2 = dc.run(8, 'NUTS', **kw)
+            out[form] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog, _lib.last_kernel()]
+    finally:
+        _lib.debug_set('cubic_form', 0)
+    assert ', 16, 0>' in out[8][-1] and ', 17, 0>' in out[4][-1], (out[8][-1], out[4][-1])
+    for a, b in zip(out[8][:-2], out[4][:-2]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert out[8][-2] == out[4][-2] > 0
+
+
 def test_auto_layout_runs_two_groups_per_cu_in_the_group_kernel_at_d32(ctx):
     """chains._two_groups_fit_a_cu: 32 chains per CU at 17 <= d <= 32 with the trees in step -- 'auto' runs the group kernel (two
     workgroups per CU, a wave per SIMD) where it ran the split kernel (one), with the same results bit for bit."""

@@ -51,3 +51,7 @@ for i in range(NT - 1):
 tot = np.array(tot)
 print('mean %6.0f  ' % np.nanmean(tot[:, 0]) + '  '.join('%9.0f' % v for v in np.nanmean(tot[:, 1:], 0)))
 print('(s_memtime ticks of 10 ns = 24 shader cycles at 2.4 GHz)')
+
+if os.environ.get('CUBIC_STAMPS'):   # a -DBF_TRACE_CUBIC build: stamps 11 (masked inputs gathered), 12 (cubic-2 done), 13 (cubic-3 done)
+    ok = (t[:, 11] > 0) & (t[:, 13] > 0)
+    print('cubic_lds, mean cycles over %d trips: cubic-2 %.0f, cubic-3 %.0f' % (ok.sum(), np.mean((t[:, 12] - t[:, 11])[ok]), np.mean((t[:, 13] - t[:, 12])[ok])))
