@@ -172,6 +172,102 @@ __global__ __launch_bounds__(256) void bf_gram_kernel(int n, int P, const double
             for (int r = 0; r < 4; ++r) out[(16 * a + kr + 4 * r) * GB_ + 16 * b + ci] = acc[a][b][r];
 }
 
+// The same partial sums from a workgroup of four waves on a 128 x 128 block (BI <= BJ in units of 128 columns): wave (wi, wj) owns
+// the 64 x 64 sub-block (2 BI + wi, 2 BJ + wj) with the accumulation order of bf_gram_kernel (steps of four rows, ascending), so its
+// partials are bf_gram_kernel's bit for bit -- but the two 128-column panels of a stage of 16 rows go through LDS once for the four
+// waves: half the bytes per multiply-add from L2 / HBM.  (The design matrix of config 5's fit is 1.35 GB; with one wave per 64 x 64
+// block the kernel ran at 47 % of the FP64 matrix rate, waiting for its operands: profiles/r05b_fit_profile.txt.)
+#define G2_R 16        // rows per stage
+#define G2_LD 272      // LDS row stride in doubles: rows kr and kr + 1 of a k-step start 32 banks apart
+__global__ __launch_bounds__(256, 2) void bf_gram128_kernel(int n, int P, const double *__restrict__ A, int lda, int nb,
+                                                            int split, double *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) double g2_lds[];   // [2][G2_R][G2_LD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w >> 1, wj = w & 1;
+    const int nb2 = (nb + 1) / 2, n_blk = nb * (nb + 1) / 2;
+    const int blk2 = blockIdx.x / split, sk = blockIdx.x % split;
+    int BI = 0, rem = blk2;
+    while (rem >= nb2 - BI) { rem -= nb2 - BI; ++BI; }
+    const int BJ = BI + rem;
+    const bool diag2 = BI == BJ;
+    const int I0 = BI * 128, J0 = BJ * 128;
+    const int rows_per = ((n + split - 1) / split + 3) / 4 * 4;
+    const int r_begin = sk * rows_per, r_end = min(n, r_begin + rows_per);
+    const int bi = 2 * BI + wi, bj = 2 * BJ + wj;
+    const bool mine = bi < nb && bj < nb && bi <= bj;   // (the mirror sub-block of a diagonal block and the ragged last column: idle)
+    const bool diag = bi == bj;
+    const int ci = lane & 15, kr = lane >> 4;
+    d4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (d4_t){0., 0., 0., 0.};
+    // staging: thread t moves elements e = t + 256 j (j < 16) of a stage, row e / 256, column e % 256 (0-127: panel I, 128-255: J)
+    const int scol = tid, ncol = diag2 ? 128 : 256;
+    const int gcol = scol < 128 ? I0 + scol : J0 + scol - 128;
+    const bool cok = scol < ncol && gcol < P;
+    const double *gp = A + (cok ? gcol : 0);
+    double st[G2_R];
+    auto gload = [&](int r0) {
+        if (r0 + G2_R <= r_end) {   // (a full stage: sixteen loads on their way together -- with the row guard below the compiler
+            const double *rp = gp + (size_t)r0 * lda;   //  branches on the uniform condition and waits for every load on its own)
+#pragma unroll
+            for (int j = 0; j < G2_R; ++j) st[j] = rp[(size_t)j * lda];   // (columns past P: masked when the stage is stored)
+        } else {
+#pragma unroll
+            for (int j = 0; j < G2_R; ++j) {
+                const int row = r0 + j;
+                const bool rok = row < r_end;
+                const double v = gp[(size_t)(rok ? row : r_begin) * lda];
+                st[j] = (rok && cok) ? v : 0.;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        double *dst = g2_lds + (size_t)buf * G2_R * G2_LD + scol;
+        if (scol < ncol) {
+#pragma unroll
+            for (int j = 0; j < G2_R; ++j) dst[j * G2_LD] = cok ? st[j] : 0.;
+        }
+    };
+    const int ao = wi * 64 + ci, bo = (diag2 ? 0 : 128) + wj * 64 + ci;
+    auto compute = [&](int buf) {
+        const double *src = g2_lds + (size_t)buf * G2_R * G2_LD;
+#pragma unroll
+        for (int k = 0; k < G2_R / 4; ++k) {
+            double fa[4], fb[4];
+            const double *rowp = src + (4 * k + kr) * G2_LD;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { fa[t] = rowp[ao + 16 * t]; fb[t] = rowp[bo + 16 * t]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[a], diag ? fa[b] : fb[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    if (r_begin < r_end) {
+        gload(r_begin);
+        lstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int r0 = r_begin; r0 < r_end; r0 += G2_R, buf ^= 1) {
+            const bool more = r0 + G2_R < r_end;
+            if (more) gload(r0 + G2_R);
+            if (mine) compute(buf);
+            if (more) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (!mine) return;
+    const int blk = bi * nb - bi * (bi - 1) / 2 + (bj - bi);
+    double *out = part + ((size_t)sk * n_blk + blk) * (GB_ * GB_);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(16 * a + kr + 4 * r) * GB_ + 16 * b + ci] = acc[a][b][r];
+}
+
 // One workgroup per 64 x 64 block: the split-K partials are added in part order (fixed: bitwise reproducible), the block is
 // written row by row and, for an off-diagonal block, its transpose row by row too -- through an LDS tile, so that both writes
 // are coalesced (the mirror block written element by element down a column was 3/4 of this kernel's time).
@@ -270,6 +366,12 @@ extern "C" int bfhip_gram(bfhip_ctx *ctx, int n, int P, int m, const double *A, 
     if (int rc = ensure_scratch(ctx, need)) return rc;
     double *part = (double *)ctx->scratch;
     const int waves = n_blk * split;
+    if (nb >= 8 && !bf_tune().gram_one_wave) {   // (below, the 64 x 64 blocks of a small Gram matrix fill the chip better one wave each)
+        const int nb2 = (nb + 1) / 2;
+        const size_t lds = (size_t)2 * G2_R * G2_LD * sizeof(double);
+        BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_gram128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bf_gram128_kernel, dim3(nb2 * (nb2 + 1) / 2 * split), dim3(256), lds, ctx->stream, n, P, A, lda, nb, split, part);
+    } else
     hipLaunchKernelGGL(bf_gram_kernel, dim3((waves + 3) / 4), dim3(256), 0, ctx->stream, n, P, A, lda, nb, split, part);
     hipLaunchKernelGGL(bf_gram_reduce_kernel, dim3(n_blk), dim3(256), 0, ctx->stream, P, nb, split, part, G);
     if (m > 0) {  // (the Gram partials have been consumed by the reduce kernel: the scratch is free again)

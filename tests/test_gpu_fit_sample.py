@@ -79,6 +79,32 @@ def test_gram_and_solve_vs_numpy():
     assert int(info.item()) > 0
 
 
+@pytest.mark.parametrize('n,P', [(700, 520), (1500, 1024), (333, 777), (2600, 1300)])
+def test_gram_in_128_column_blocks_equals_the_one_wave_kernel_bit_for_bit(n, P):
+    """bf_gram128_kernel (four waves on a 128 x 128 block, the panels of a 16-row stage through LDS once) against bf_gram_kernel (one
+    wave per 64 x 64 block): the same split-K partials in the same order, so the same Gram matrix bit for bit -- an odd and an even
+    number of 64-column blocks, a ragged last block, fewer rows than columns -- and A^T A to rounding."""
+    import torch
+    from bayesfast_amd.device import get_context, _ptr
+    from bayesfast_amd import _lib
+    ctx = get_context(0)
+    A = np.random.default_rng(n + P).normal(size=(n, P))
+    B = A[:, :1].copy()
+    At, Bt = ctx.tensor(A, torch.float64), ctx.tensor(B, torch.float64)
+    out = {}
+    try:
+        for one_wave in (1, 0):
+            _lib.debug_set('gram_one_wave', one_wave)
+            Gt, rt = ctx.empty((P, P)), ctx.empty((P, 1))
+            Gt.fill_(float('nan'))
+            _lib.check(ctx._lib.bfhip_gram(ctx.handle, n, P, 1, _ptr(At), P, _ptr(Bt), _ptr(Gt), _ptr(rt)))
+            out[one_wave] = Gt.cpu().numpy()
+    finally:
+        _lib.debug_set('gram_one_wave', 0)
+    assert np.array_equal(out[0], out[1])
+    np.testing.assert_allclose(out[0], A.T @ A, rtol=1e-12, atol=1e-10)
+
+
 def test_polymodel_fit_matches_reference_fixture():
     """Masked multi-output model of the reference fixture: device fit vs the reference's own coefficients."""
     from bayesfast_amd import PolyModel, PolyConfig
