@@ -40,8 +40,9 @@ for nref in (0, 2):
     c = r.cpu().numpy()[:, 0]
     res = (A @ r - B).abs().max().item()
     print('bfhip_lstsq n_refine = {}: {} ms   info {}  max |A c - b| {:.3e}'.format(nref, ' '.join('%.2f' % t for t in ms), int(info.item()), res))
-ref = np.linalg.lstsq(A.cpu().numpy(), y, rcond=None)[0]
-print('max |c - lstsq| / max |c|: {:.3e}'.format(np.abs(c - ref).max() / np.abs(ref).max()))
+if P <= 3000 or os.environ.get('HOST_CHECK'):   # (the host's gelsd of a 16770 x 8385 matrix takes minutes on a loaded box)
+    ref = np.linalg.lstsq(A.cpu().numpy(), y, rcond=None)[0]
+    print('max |c - lstsq| / max |c|: {:.3e}'.format(np.abs(c - ref).max() / np.abs(ref).max()))
 # where the host time of PolyModel.fit goes
 import cProfile, pstats
 pr = cProfile.Profile()
