@@ -518,63 +518,79 @@ __global__ __launch_bounds__(256) void bf_chol_first_kernel(int P, double *__res
     bf_chol64_two_waves(R1, R0, &ready, P, 0, nbk, G, Linv, info);
 }
 
-// panel k0 (a full 64 columns: there are rows below it): see above
-__global__ __launch_bounds__(256) void bf_chol_panel_kernel(int P, int k0, double *__restrict__ G, double *__restrict__ LinvAll,
-                                                          int *__restrict__ info) {
+// panel k0 (a full 64 columns: there are rows below it): see above.
+// np = 2: TWO panels in one pass over the trailing matrix (k0 and k0 + 64; the trailing blocks start at k0 + 128): every panel reads and
+// writes the whole trailing matrix, 60 GB over the factorisation at P = 8385, and with the update of panel k0 delayed until panel
+// k0 + 64 is there too the pass is taken half as often (measured: the 128-d fit 53.4 -> 52.0 ms -- the launches are bound by each
+// workgroup's chain of dependent phases more than by the traffic).  The block column of the second panel is brought up to
+// date first, by a launch of this kernel with col_only = 1 (one workgroup per block of that column: update with panel k0, L_ik into the
+// upper triangle, and the column's diagonal block factored and inverted), which is what the second panel's L_i,k+1 is formed from here.
+__global__ __launch_bounds__(256) void bf_chol_panel_kernel(int P, int k0, int np, int col_only, double *__restrict__ G,
+                                                          double *__restrict__ LinvAll, int *__restrict__ info) {
     __shared__ __attribute__((aligned(16))) double R0[NB_][LDP_];
     __shared__ __attribute__((aligned(16))) double R1[NB_][LDP_];
     __shared__ int ready;
-    const int t0 = k0 + NB_;  // first trailing row
+    const int t0 = k0 + np * NB_;  // first trailing row
     const int nb = (P - t0 + NB_ - 1) / NB_;
-    int bj = 0, rem = blockIdx.x;  // lower triangle of the trailing blocks, by columns: bi >= bj
-    while (rem >= nb - bj) { rem -= nb - bj; ++bj; }
+    int bj = 0, rem = blockIdx.x;  // lower triangle of the trailing blocks, by columns: bi >= bj (col_only: the first column)
+    if (!col_only)
+        while (rem >= nb - bj) { rem -= nb - bj; ++bj; }
     const int bi = bj + rem;
     const int I0 = t0 + bi * NB_, J0 = t0 + bj * NB_;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ci = lane & 15, kr = lane >> 4;
     const bool diag = bi == bj;
-    const double *Linv = LinvAll + (size_t)(k0 / NB_) * NB_ * NB_;
-    for (int i = wv; i < NB_; i += 4) R0[i][lane] = Linv[i * NB_ + lane];
     if (threadIdx.x == 0) ready = 0;
-    __syncthreads();
-    // rows 16 wv .. 16 wv + 15 of L_ik = A_ik Linv^T and of L_jk: D[r][c] = sum_m A[r][m] Linv[c][m] (m <= c)
-    d4_t li[4], lj[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) li[b] = lj[b] = (d4_t){0., 0., 0., 0.};
-    {
-        const int ra = I0 + 16 * wv + ci, rb = J0 + 16 * wv + ci;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int col = k0 + 4 * s + kr;
-            const double fa = ra < P ? G[(size_t)ra * P + col] : 0.;
-            const double fb = (!diag && rb < P) ? G[(size_t)rb * P + col] : 0.;
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (s <= 4 * b + 3) {  // (Linv is lower triangular: columns 16 b .. 16 b + 15 end at m = 16 b + 15)
-                    const double fl = R0[16 * b + ci][4 * s + kr];
-                    li[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fl, li[b], 0, 0, 0);
-                    if (!diag) lj[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fl, lj[b], 0, 0, 0);
-                }
-        }
-    }
-    __syncthreads();  // every wave is through with Linv: R0 <- L_ik, R1 <- L_jk
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            R0[16 * wv + kr + 4 * r][16 * b + ci] = li[b][r];
-            if (!diag) R1[16 * wv + kr + 4 * r][16 * b + ci] = lj[b][r];
-        }
-    __syncthreads();
-    double (*RJ)[LDP_] = diag ? R0 : R1;
     d4_t acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = (d4_t){0., 0., 0., 0.};
+    for (int pp = 0; pp < np; ++pp) {
+        const int kk = k0 + pp * NB_;
+        const double *Linv = LinvAll + (size_t)(kk / NB_) * NB_ * NB_;
+        if (pp > 0) __syncthreads();  // (every wave is through with the first panel's L_ik, L_jk)
+        for (int i = wv; i < NB_; i += 4) R0[i][lane] = Linv[i * NB_ + lane];
+        __syncthreads();
+        // rows 16 wv .. 16 wv + 15 of L_ik = A_ik Linv^T and of L_jk: D[r][c] = sum_m A[r][m] Linv[c][m] (m <= c)
+        d4_t li[4], lj[4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const double fa = R0[16 * wv + ci][4 * s + kr];
+        for (int b = 0; b < 4; ++b) li[b] = lj[b] = (d4_t){0., 0., 0., 0.};
+        {
+            const int ra = I0 + 16 * wv + ci, rb = J0 + 16 * wv + ci;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, RJ[16 * b + ci][4 * s + kr], acc[b], 0, 0, 0);
+            for (int s = 0; s < 16; ++s) {
+                const int col = kk + 4 * s + kr;
+                const double fa = ra < P ? G[(size_t)ra * P + col] : 0.;
+                const double fb = (!diag && rb < P) ? G[(size_t)rb * P + col] : 0.;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (s <= 4 * b + 3) {  // (Linv is lower triangular: columns 16 b .. 16 b + 15 end at m = 16 b + 15)
+                        const double fl = R0[16 * b + ci][4 * s + kr];
+                        li[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fl, li[b], 0, 0, 0);
+                        if (!diag) lj[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb, fl, lj[b], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();  // every wave is through with Linv: R0 <- L_ik, R1 <- L_jk
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                R0[16 * wv + kr + 4 * r][16 * b + ci] = li[b][r];
+                if (!diag) R1[16 * wv + kr + 4 * r][16 * b + ci] = lj[b][r];
+            }
+        __syncthreads();
+        double (*RJ)[LDP_] = diag ? R0 : R1;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const double fa = R0[16 * wv + ci][4 * s + kr];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, RJ[16 * b + ci][4 * s + kr], acc[b], 0, 0, 0);
+        }
+        if (bj == 0) {  // L_ik, transposed, into block (k, i) of the upper triangle (the first of two panels: stored by the column launch)
+            if (pp == np - 1)
+                for (int m = wv; m < NB_; m += 4)
+                    if (I0 + lane < P) G[(size_t)(kk + m) * P + I0 + lane] = R0[lane][m];
+        }
     }
     const bool next_diag = diag && bi == 0;  // tile (k+1, k+1): factored here
     double nv[4][4];
@@ -589,10 +605,6 @@ __global__ __launch_bounds__(256) void bf_chol_panel_kernel(int P, int k0, doubl
                 G[(size_t)i * P + j] = nv[b][r];
             }
         }
-    if (bj == 0) {  // L_ik, transposed, into block (k, i) of the upper triangle
-        for (int m = wv; m < NB_; m += 4)
-            if (I0 + lane < P) G[(size_t)(k0 + m) * P + I0 + lane] = R0[lane][m];
-    }
     if (!next_diag) return;
     __syncthreads();  // (uniform: the whole workgroup is here) R0 and R1 are free
     const int nbk = min(NB_, P - t0);
@@ -635,9 +647,17 @@ static int solve_spd_impl(bfhip_ctx *ctx, int P, int m, double *G, double *r, in
     hipLaunchKernelGGL(bf_diag_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, G, dsc);
     hipLaunchKernelGGL(bf_scale_kernel, dim3(P), dim3(256), 0, st, P, m, G, r, dsc);
     hipLaunchKernelGGL(bf_chol_first_kernel, dim3(1), dim3(256), 0, st, P, G, LinvAll, info);
-    for (int k0 = 0; k0 + NB_ < P; k0 += NB_) {
-        const int nb = (P - k0 - NB_ + NB_ - 1) / NB_;
-        hipLaunchKernelGGL(bf_chol_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, P, k0, G, LinvAll, info);
+    for (int k0 = 0; k0 + NB_ < P;) {
+        const int nb = (P - k0 - NB_ + NB_ - 1) / NB_;   // blocks of rows below panel k0
+        if (nb >= 8 && !bf_tune().chol_one_panel) {       // two panels per pass over the trailing matrix (small ones fit the caches)
+            hipLaunchKernelGGL(bf_chol_panel_kernel, dim3(nb), dim3(256), 0, st, P, k0, 1, 1, G, LinvAll, info);
+            const int nb2 = nb - 1;
+            hipLaunchKernelGGL(bf_chol_panel_kernel, dim3(nb2 * (nb2 + 1) / 2), dim3(256), 0, st, P, k0, 2, 0, G, LinvAll, info);
+            k0 += 2 * NB_;
+        } else {
+            hipLaunchKernelGGL(bf_chol_panel_kernel, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, P, k0, 1, 0, G, LinvAll, info);
+            k0 += NB_;
+        }
     }
     return 0;
 }

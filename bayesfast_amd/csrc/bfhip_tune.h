@@ -18,6 +18,7 @@ struct BfTune {
     int pld_waves;       // BFHIP_PLD_WAVES: 8 or 16 waves per workgroup for the pipeline density (0: by chain count)
     int cubic_form;      // BFHIP_CUBIC_FORM (default 0: by chain count): d = 128 cubic surrogate -- 8 the eight-wave form, 4 four waves with S in registers
     int gram_one_wave;   // BFHIP_GRAM_ONE_WAVE: the Gram matrix with one wave per 64 x 64 block at every size (the same partial sums)
+    int chol_one_panel;  // BFHIP_CHOL_ONE_PANEL: the Cholesky factorisation with one panel per pass over the trailing matrix at every size
     int no_vel_ahead;    // BFHIP_NO_VEL_AHEAD: full-rank metric without the next step's velocity taken ahead
     int tnuts_wpb;       // BFHIP_TNUTS_WPB: tempered NUTS, chains per workgroup (4, 8; 0: automatic)
     int no_bound_proof;  // BFHIP_NO_BOUND_PROOF: always compute the H (x - mu) tiles

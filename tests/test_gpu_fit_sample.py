@@ -105,6 +105,49 @@ def test_gram_in_128_column_blocks_equals_the_one_wave_kernel_bit_for_bit(n, P):
     np.testing.assert_allclose(out[0], A.T @ A, rtol=1e-12, atol=1e-10)
 
 
+@pytest.mark.parametrize('n,P,m', [(1500, 700, 2), (2400, 1100, 1), (1300, 1283, 3)])
+def test_cholesky_with_two_panels_per_pass_solves_like_the_one_panel_form(n, P, m):
+    """bfhip_solve_spd with two panels per pass over the trailing matrix (delayed rank-128 update; the second panel's block column
+    brought up to date by a column launch first) against one panel per pass and against NumPy: an odd and an even number of panels,
+    a ragged last block, a nearly square system; the rank-deficiency report still names the first bad pivot."""
+    import torch
+    from bayesfast_amd.device import get_context, _ptr
+    from bayesfast_amd import _lib
+    ctx = get_context(0)
+    rng = np.random.default_rng(n + P)
+    A = rng.normal(size=(n, P)) * np.exp(rng.normal(size=P))[None]   # (columns on different scales: the equilibration matters)
+    B = rng.normal(size=(n, m))
+    At, Bt = ctx.tensor(A, torch.float64), ctx.tensor(B, torch.float64)
+    out = {}
+    try:
+        for one in (1, 0):
+            _lib.debug_set('chol_one_panel', one)
+            Gt, rt = ctx.empty((P, P)), ctx.empty((P, m))
+            info = torch.ones((1,), dtype=torch.int32, device=ctx.device)
+            _lib.check(ctx._lib.bfhip_gram(ctx.handle, n, P, m, _ptr(At), P, _ptr(Bt), _ptr(Gt), _ptr(rt)))
+            _lib.check(ctx._lib.bfhip_solve_spd(ctx.handle, P, m, _ptr(Gt), _ptr(rt), _ptr(info)))
+            assert int(info.item()) == 0
+            out[one] = rt.cpu().numpy()
+        ref = np.linalg.lstsq(A, B, rcond=None)[0]
+        np.testing.assert_allclose(out[0], out[1], rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+        np.testing.assert_allclose(out[0], ref, rtol=1e-6, atol=1e-8 * np.abs(ref).max())
+        # a duplicated column in the second panel of a pair: reported with its index, as by the one-panel form
+        A2 = A.copy()
+        A2[:, 100] = A2[:, 99]
+        At2 = ctx.tensor(A2, torch.float64)
+        bad = {}
+        for one in (1, 0):
+            _lib.debug_set('chol_one_panel', one)
+            Gt, rt = ctx.empty((P, P)), ctx.empty((P, m))
+            info = torch.zeros((1,), dtype=torch.int32, device=ctx.device)
+            _lib.check(ctx._lib.bfhip_gram(ctx.handle, n, P, m, _ptr(At2), P, _ptr(Bt), _ptr(Gt), _ptr(rt)))
+            _lib.check(ctx._lib.bfhip_solve_spd(ctx.handle, P, m, _ptr(Gt), _ptr(rt), _ptr(info)))
+            bad[one] = int(info.item())
+        assert bad[0] == bad[1] == 101
+    finally:
+        _lib.debug_set('chol_one_panel', 0)
+
+
 def test_polymodel_fit_matches_reference_fixture():
     """Masked multi-output model of the reference fixture: device fit vs the reference's own coefficients."""
     from bayesfast_amd import PolyModel, PolyConfig
