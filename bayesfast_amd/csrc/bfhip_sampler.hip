@@ -1985,9 +1985,11 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
     const bool plain = sampler_plain(m) && !args.mat;
     if (m.pld.on) {   // pipeline density: the FS = 8 instantiation (d <= 64, diagonal metric)
-        if (args.mat) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density runs with the diagonal metric only");
         constexpr int WP = W <= 4 ? W : 1;   // (keeps W = 8 from instantiating it)
         if (W > 4) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density is implemented for d <= 64");
+        if (args.mat) {   // full-rank metric: the eight-wave form with the run-time feature set (bfhip_metric.h streams the chain's own matrices)
+            return launch_sampler_t<WP, NUTS, false, 9, 1>(ctx, args);
+        }
         // eight chains per workgroup (and 256 registers a wave) while that fills the chip, sixteen beyond
         // (measured, tools/pld_rate.py: with the outputs compressed to the monomial count the DES shape's contractions are 200
         // tile k-steps and the eight-wave form wins at every chain count -- 1.41 against 1.30 x 10^8 at 4096 chains; at 1800 tile
