@@ -900,6 +900,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     // many chain-less waves as chains (wave_layout_cpg: config 5's shard, 4 chains on 8 waves), right after barrier B1 by the
     // chain's wave while the chain-less waves take ALL the matvec jobs: the contraction (a third of the trip) then runs beside
     // the jobs, which wait for their A operands from L2 most of the time, instead of behind them.
+    constexpr bool XT = W == 8 && !FULLM;
     auto cubic_lds = [&](const double (&xe)[E], double (&gc2)[E], double (&gc3)[E]) -> double {
         const int jl = lane & 15, kq = lane >> 4;
         auto xl_ = [&](int dim) {
@@ -924,6 +925,58 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
         const double *A2t_l = CUB, *A2_l = CUB + n2 * n2;
         const double *T3_l = lds + (((size_t)(CUB + 2 * n2 * n2 - lds) + 1) & ~(size_t)1);
         const int nc3 = (n3 + 15) >> 4;
+        if (AREG8 && n2 == 16 && n3 == 16 && !a.cub_loops) {   // (the four-wave form: where the contraction is on the trip's critical path)
+            // Sixteen masked inputs in both configs (config 5): the loops below written out as ONE basic block -- the same sums in the
+            // same order, but the cubic-2 part's broadcasts, table reads and lane exchanges (1.4 k cycles of round trips on their own)
+            // travel under the cubic-3 part's fma chains instead of in front of them.
+            double a1[4], a2[4], xk2[4], xk3[4], mk[4] = {0., 0., 0., 0.};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * u + kq;
+                xk2[u] = __shfl(xm2, k, 64);
+                xk3[u] = __shfl(xm3, k, 64);
+                a1[u] = A2t_l[k * 16 + jl];
+                a2[u] = A2_l[k * 16 + jl];
+            }
+            const double xj2 = __shfl(xm2, jl, 64), xj3 = __shfl(xm3, jl, 64);
+            const double *Tb = T3_l + ((size_t)kq * 8 * 16 + jl) * 2;   // k = 4 u + kq: stride 4 * 8 * 16 * 2 doubles per u
+#pragma unroll
+            for (int l2 = 0; l2 < 8; l2 += 2) {
+                d2_t ta[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ta[i][u] = *(const d2_t *)(Tb + (size_t)u * (4 * 8 * 16 * 2) + (l2 + i) * 16 * 2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const double x0 = readlane_f64(xm3, 2 * (l2 + i)), x1 = readlane_f64(xm3, 2 * (l2 + i) + 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        mk[u] = __builtin_fma(ta[i][u][0], x0, mk[u]);
+                        mk[u] = __builtin_fma(ta[i][u][1], x1, mk[u]);
+                    }
+                }
+            }
+            double v1 = 0., v2 = 0., sacc = 0.;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v1 += a1[u] * xk2[u];
+                v2 += a2[u] * (xk2[u] * xk2[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sacc = __builtin_fma(mk[u], xk3[u], sacc);
+            v1 = swap32_add_f64(swap16_add_f64(v1));
+            v2 = swap32_add_f64(swap16_add_f64(v2));
+            sacc = swap32_add_f64(swap16_add_f64(sacc));
+            const double gj2 = 2. * xj2 * v1 + v2;
+            if (kq == 0) fsum += xj2 * xj2 * v1;
+            if (kq == 0) fsum += xj3 * (0.5 * sacc) * (1. / 3.);
+            fetch_l(pj2, 0, gj2, gc2);
+            fetch_l(pj3, 0, 0.5 * sacc, gc3);
+            TRACEC(12);
+            TRACEC(13);
+            return fsum;
+        }
         // (The loads of a batch are issued together, then the sums run in the original order: with one LDS
         // round trip per term the contraction was 13 k of config 5's 29 k cycles per trip,
         // tools/trace_sliced.py.  Terms past the tables' ends are +0 and leave the sums as they were.)
@@ -1020,7 +1073,6 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     };
     // (d = 128 only, where they were measured: the 128-register instantiations of d <= 64 and the full-rank one have no
     // register to spare -- with these paths compiled in they spilled 25 % more VGPRs, the full-rank one 135 instead of 90)
-    constexpr bool XT = W == 8 && !FULLM;
     const bool cub_early = XT && !AREG8 && cub_l && 2 * cpg <= NWV;   // (fixed for the launch, the same in every wave)
     for (int trip = 0;; ++trip) {
         trip_no = trip;
@@ -1799,6 +1851,7 @@ static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
     args.cub_lds = sampler_cubic_lds(ctx->model, FS == 1) ? 1 : 0;
+    args.cub_loops = bf_tune().cubic_loops;
     const int groups = (args.n_chain + args.cpg - 1) / args.cpg;
     snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_sampler_kernel<%d, %s, %s, %d, %d>", W, NUTS ? "true" : "false",
              STAMPS ? "true" : "false", FS, FULLM);

@@ -21,7 +21,8 @@ struct SamplerArgs {
     // many unfinished chains lets each of them stop at the end of its iteration; tail_list / tail_count -- the chains of THIS launch
     // (the ones that stopped), tail_count[0] of them, one to four per workgroup (n_cu decides)
     int tail_stop, n_cu;
-    int tail_q;       // ... once tail_q quarters of the launch's chains are through
+    int tail_q;
+    int cub_loops;      // cubic configs: the general loops also at sixteen masked inputs (tests compare; BFHIP_CUBIC_LOOPS)       // ... once tail_q quarters of the launch's chains are through
     const int *tail_list, *tail_count;
     int *tail_done;   // first part: += 1 per chain that has finished the launch's iterations (a workgroup stops its last chains only
                       // when three quarters of the launch's chains are through: the tail, not a slow workgroup among busy ones)

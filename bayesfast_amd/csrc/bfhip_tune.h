@@ -19,6 +19,7 @@ struct BfTune {
     int cubic_form;      // BFHIP_CUBIC_FORM (default 0: by chain count): d = 128 cubic surrogate -- 8 the eight-wave form, 4 four waves with S in registers
     int gram_one_wave;   // BFHIP_GRAM_ONE_WAVE: the Gram matrix with one wave per 64 x 64 block at every size (the same partial sums)
     int chol_one_panel;  // BFHIP_CHOL_ONE_PANEL: the Cholesky factorisation with one panel per pass over the trailing matrix at every size
+    int cubic_loops;     // BFHIP_CUBIC_LOOPS: cubic configs by the general loops also at sixteen masked inputs (the same sums in the same order)
     int no_vel_ahead;    // BFHIP_NO_VEL_AHEAD: full-rank metric without the next step's velocity taken ahead
     int tnuts_wpb;       // BFHIP_TNUTS_WPB: tempered NUTS, chains per workgroup (4, 8; 0: automatic)
     int no_bound_proof;  // BFHIP_NO_BOUND_PROOF: always compute the H (x - mu) tiles

@@ -915,8 +915,9 @@ def test_config5_four_wave_form_is_bit_identical_to_the_eight_wave_form(ctx, n_c
     dd = den.device(ctx)
     out = {}
     try:
-        for form in (8, 4):
-            _lib.debug_set('cubic_form', form)
+        for form in (8, 4, 40):   # (40: the four-wave form with the cubic contraction by its general loops instead of the written-out block)
+            _lib.debug_set('cubic_form', form % 10 if form > 8 else form)
+            _lib.debug_set('cubic_loops', int(form > 8))
             dc = DeviceChains(dd, x0, seed=5)
             kw = dict(n_warmup=24, max_treedepth=5)
             s1, st1 = dc.run(24, 'NUTS', **kw)
@@ -924,10 +925,12 @@ def test_config5_four_wave_form_is_bit_identical_to_the_eight_wave_form(ctx, n_c
             out[form] = [t.cpu().numpy() for t in (s1, st1, s2, st2, dc.sc, dc.vec, dc.rng)] + [dc.total_leapfrog, _lib.last_kernel()]
     finally:
         _lib.debug_set('cubic_form', 0)
+        _lib.debug_set('cubic_loops', 0)
     assert ', 16, 0>' in out[8][-1] and ', 17, 0>' in out[4][-1], (out[8][-1], out[4][-1])
-    for a, b in zip(out[8][:-2], out[4][:-2]):
-        assert np.array_equal(a, b, equal_nan=True)
-    assert out[8][-2] == out[4][-2] > 0
+    for other in (4, 40):
+        for a, b in zip(out[8][:-2], out[other][:-2]):
+            assert np.array_equal(a, b, equal_nan=True), other
+        assert out[8][-2] == out[other][-2] > 0
 
 
 def test_auto_layout_runs_two_groups_per_cu_in_the_group_kernel_at_d32(ctx):
