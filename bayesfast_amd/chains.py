@@ -157,8 +157,11 @@ class DeviceChains:
             # the chains' behaviour, one launch late
             lay = layout
             if lay == 'auto':
-                in_step = sampler == 'HMC' or self._trees_in_step(lag=1 if i_launch > 0 else 2)   # (asked for at every launch: the
-                lay = IN_STEP_LAYOUT if in_step else 'wave'                                         # answers are consumed in order)
+                tree = self._trees_in_step(lag=1 if i_launch > 0 else 2)   # (asked for at every launch: the answers are consumed in order)
+                in_step = sampler == 'HMC' or tree > 0
+                lay = IN_STEP_LAYOUT if in_step else 'wave'
+                if sampler == 'NUTS' and tree >= 24 and self._deep_trees_prefer_waves():
+                    lay = 'wave'
                 if sampler == 'NUTS' and self._small_problem():
                     lay = 'wave'
                 elif sampler == 'NUTS' and self._lanes_whatever_the_trees():
@@ -233,6 +236,18 @@ class DeviceChains:
         the trees are, and the judgement of the last launch decides as everywhere else."""
         plain, _, n = self._shape_facts()
         return plain and self.d <= 32 and n >= 16 * self._n_cu
+
+    def _deep_trees_prefer_waves(self):
+        """The common surrogate WITH the decay term at 33 <= d <= 64: the group kernel's rate falls with the tree size (every trip runs
+        the bound's and the decay's tiles, and a chain outside the decay ellipsoid makes its whole group's trips 60 % longer, which the
+        launch then waits for), the pipelined wave-per-chain kernel's does not -- 4096 chains x 64-d, trees in step: 7 leaves 9.7 against
+        6.2 x 10^8, 15: 7.7 against 6.6, 31: 6.3 against 7.0, 1022 (config 3's second round): 5.8 -- 3.7 with ONE such chain -- against
+        7.4 (tools/layout_ab.py, bench.py --workload banana_decay; docs/EXPERIMENTS.md).  From 24 leaves up 'auto' takes the wave
+        layout there.  Behind the constraint transform the group kernel stays ahead (31 leaves: 6.6 against 5.0), and the plain
+        surrogate's split kernel too (10.6 against 9.2).  A function of the shapes only."""
+        plain, featured, n = self._shape_facts()
+        sp = self.density.spec
+        return featured and bool(sp.get('use_decay')) and 32 < self.d <= 64
 
     def _two_groups_fit_a_cu(self):
         """Trees in step at 17 <= d <= 32 with at least two 16-chain groups per CU: the group kernel's two waves and 75 KB of LDS
@@ -316,7 +331,7 @@ class DeviceChains:
                 hist.scatter_add_(0, ts, torch.ones_like(ts))
             self.ctx.stream.synchronize()
             self.hist_reduce(hist)
-            self._answers.append(bool(float(hist.max()) >= share * float(hist.sum())))
+            self._answers.append(max(1, int(hist.argmax())) if float(hist.max()) >= share * float(hist.sum()) else 0)
             del self._answers[:-4]
             return
         if getattr(self, '_step_host', None) is None:
@@ -335,18 +350,18 @@ class DeviceChains:
         del self._answers[:-4]  # (at most the last two are ever read: the ring's 8 slots stay unambiguous)
 
     def _trees_in_step(self, lag=1):
-        """The answer of ``_note_trees`` for the launch ``lag`` launches back (1 = the last one), waited for if it is still
-        on its way; False when there is none (the first launches of a chain set, launches that were not NUTS).  A pure
+        """The answer of ``_note_trees`` for the launch ``lag`` launches back (1 = the last one) -- the common tree size when the
+        chains ran in step, else 0 --, waited for if it is still on its way; 0 when there is none (the first launches of a chain set, launches that were not NUTS).  A pure
         function of the launches so far: an answer that happens to have arrived early is not used before its turn."""
         ans = getattr(self, '_answers', [])
         if len(ans) < lag:
-            return False
+            return 0
         a = ans[-lag]
         if isinstance(a, tuple):
             ev, slot = a
             ev.synchronize()
-            a = ans[-lag] = bool(int(self._step_host[slot]))
-        return bool(a)
+            a = ans[-lag] = int(self._step_host[slot])
+        return int(a or 0)
 
     def raise_on_error(self):
         """Synchronises; raises like the reference does for a chain that hit a fatal condition."""

@@ -2241,8 +2241,9 @@ __global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_ou
     __shared__ unsigned int hist[4096];
     __shared__ unsigned int best;
     __shared__ int last;
+    __shared__ unsigned int mode_at;
     for (int i = threadIdx.x; i < 4096; i += 256) hist[i] = 0;
-    if (threadIdx.x == 0) best = 0;
+    if (threadIdx.x == 0) { best = 0; mode_at = 0xFFFFFFFFu; }
     __syncthreads();
     const long total = (long)n_chain * n_rows;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -2261,15 +2262,18 @@ __global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_ou
     __syncthreads();
     if (!last) return;
     __threadfence();
-    unsigned int mx = 0;
+    unsigned int mx = 0, at = 0;
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const unsigned int v = atomicExch(&gh[i], 0u);  // (read through the atomic path, and cleared for the next call)
-        mx = v > mx ? v : mx;
+        if (v > mx) { mx = v; at = (unsigned)i; }
     }
     atomicMax(&best, mx);
     __syncthreads();
+    if (mx == best && mx > 0) atomicMin(&mode_at, at);   // (the smallest size among equally common ones)
+    __syncthreads();
     if (threadIdx.x == 0) {
-        work[0] = ((double)best >= share * (double)total) ? 1 : 0;
+        const int mode = mode_at < 4096u ? (int)mode_at : 0;
+        work[0] = ((double)best >= share * (double)total) ? (mode > 1 ? mode : 1) : 0;
         work[4097] = 0;
     }
 }

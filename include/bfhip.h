@@ -206,8 +206,9 @@ int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_cha
                       uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
                       double *stats, unsigned long long *n_leapfrog);
 
-/* Helper of the layout choice (chain_layout above): work[0] := 1 when at least `share` of the NUTS trees in rows
- * [row0, row0 + n_rows) of stats (C,n_out,BFHIP_STAT_STRIDE), all chains, have the most common tree_size, else 0.
+/* Helper of the layout choice (chain_layout above): work[0] := the most common tree_size (at least 1; sizes from 4095 up count as
+ * 4095) when at least `share` of the NUTS trees in rows [row0, row0 + n_rows) of stats (C,n_out,BFHIP_STAT_STRIDE), all chains,
+ * have it, else 0.
  * work: BFHIP_TREE_MODE_WORK int32 on the device, zeroed once by the caller and left clean by every call.  Queued on the
  * context's stream behind the launch that wrote the rows; nothing synchronises. */
 #define BFHIP_TREE_MODE_WORK 4098

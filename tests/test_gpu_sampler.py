@@ -814,8 +814,8 @@ def test_config1_donut_shapes_2d_decay_no_bound(ctx, order):
 
 
 def test_tree_size_mode_share_flag_matches_numpy(ctx):
-    """bfhip_tree_size_mode_share (the layout choice's helper): flag = [share of the most common tree_size in the given rows
-    >= threshold], for uniform, mixed and out-of-range sizes; the work buffer is left clean between calls."""
+    """bfhip_tree_size_mode_share (the layout choice's helper): the most common tree_size of the given rows when its share
+    >= threshold, else 0, for uniform, mixed and out-of-range sizes; the work buffer is left clean between calls."""
     import torch
     from bayesfast_amd import _lib
     from bayesfast_amd.device import _ptr
@@ -828,7 +828,8 @@ def test_tree_size_mode_share_flag_matches_numpy(ctx):
         sizes = np.where(rng.uniform(size=(n_chain, n_out)) < p_mode, 7, rng.choice([1, 3, 15, 31, 5000], size=(n_chain, n_out)))
         st[:, :, ts_col] = sizes
         blk = np.minimum(sizes[:, row0:row0 + n_rows], 4095).reshape(-1)
-        want = int(np.bincount(blk).max() >= share * blk.size)
+        cnt = np.bincount(blk)
+        want = max(1, int(cnt.argmax())) if cnt.max() >= share * blk.size else 0   # (the most common size, or 0: not in step)
         t = ctx.tensor(st)
         _lib.check(ctx._lib.bfhip_tree_size_mode_share(ctx.handle, n_chain, n_out, _ptr(t), row0, n_rows, float(share), _ptr(work)))
         torch.cuda.synchronize()
@@ -898,6 +899,8 @@ def test_config5_four_wave_form_is_bit_identical_to_the_eight_wave_form(ctx, n_c
     """bf_sampler_kernel<8, ..., 17> (config 5's shard: four waves of 512 registers, each with a chain and two row tiles of S in
     registers for the whole launch) against <8, ..., 16> (eight waves, S streamed from L2 in every trip): samples, statistics,
     adapted state, random streams and leapfrog counts EQUAL -- with one chain per workgroup (37 chains) and with four (600)."""
+    if _LAYOUT['v'] != 'group':
+        pytest.skip('does not depend on the module-wide layout parameter')
     import bayesfast_amd as bfa
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import planck_like_logp
@@ -933,9 +936,46 @@ def test_config5_four_wave_form_is_bit_identical_to_the_eight_wave_form(ctx, n_c
         assert out[8][-2] == out[other][-2] > 0
 
 
+def test_auto_layout_takes_the_wave_kernel_for_deep_trees_with_the_decay_term(ctx):
+    """chains._deep_trees_prefer_waves: the common surrogate with the decay term at d = 64, trees in step -- 'auto' runs the group
+    kernel while the trees have 7 leaves and the pipelined wave-per-chain kernel once they have 31 (the helper of the layout vote
+    reports the common tree size); the forced group layout gives the same trees and moments."""
+    if _LAYOUT['v'] != 'group':
+        pytest.skip('does not depend on the module-wide layout parameter')
+    from bayesfast_amd.device import DeviceDensity
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import correlated_gaussian_spec
+    from bayesfast_amd import _lib
+    import torch
+    d = 64
+    n = 9 * torch.cuda.get_device_properties(0).multi_processor_count   # (more than eight chains per CU: not a "small problem")
+    spec, _ = correlated_gaussian_spec(d)
+    po = spec['poly']
+    spec = dict(spec, use_decay=True, decay_mu=po['mu'], decay_hess=po['hess'], decay_alpha2=(1.5 * po['alpha'])**2, decay_gamma=0.1)
+    dens = DeviceDensity(spec, ctx)
+    x0 = np.random.default_rng(4).normal(size=(n, d))
+    ts = _lib.NSTATS.index('tree_size')
+    for ta, leaves, want in ((0.8, 7, 'in step'), (0.99, 31, 'wave')):
+        out = {}
+        for lay in ('auto', 'group'):
+            dc = DeviceChains(dens, x0, seed=5)
+            kw = dict(n_warmup=500, layout=lay, launch_iters=100, target_accept=ta)
+            dc.run(500, 'NUTS', **kw)
+            s, st = dc.run(200, 'NUTS', **kw)
+            out[lay] = (s.cpu().numpy(), st.cpu().numpy(), dc.sc.cpu().numpy(), dc.rng.cpu().numpy(), dc.last_layout, _lib.last_kernel())
+        assert np.median(out['auto'][1][:, -50:, ts]) == leaves
+        assert (out['auto'][4] == 'wave') == (want == 'wave'), (ta, out['auto'][4:])   # ('split' falls back to the group kernel here)
+        assert ('bf_nuts_pipe_kernel<4' if want == 'wave' else 'bf_group_kernel<4, true, 3>') in out['auto'][5], out['auto'][5]
+        # (the lane-per-chain and the wave-per-chain kernels agree to rounding, not bit for bit: the same trees, the same moments)
+        assert np.median(out['group'][1][:, -50:, ts]) == leaves
+        np.testing.assert_allclose(out['auto'][0][:, -100:].var((0, 1)), out['group'][0][:, -100:].var((0, 1)), rtol=0.05)
+
+
 def test_auto_layout_runs_two_groups_per_cu_in_the_group_kernel_at_d32(ctx):
     """chains._two_groups_fit_a_cu: 32 chains per CU at 17 <= d <= 32 with the trees in step -- 'auto' runs the group kernel (two
     workgroups per CU, a wave per SIMD) where it ran the split kernel (one), with the same results bit for bit."""
+    if _LAYOUT['v'] != 'group':
+        pytest.skip('does not depend on the module-wide layout parameter')
     from bayesfast_amd.device import DeviceDensity
     from bayesfast_amd.chains import DeviceChains
     from bayesfast_amd.workloads import correlated_gaussian_spec
