@@ -22,6 +22,9 @@ HSTATS = ('logp', 'energy', 'n_int_step', 'accept_stat', 'accepted', 'step_size'
           'energy_change', 'diverging')
 MAX_DIM = 128
 MAX_TREEDEPTH = 12
+TREE_MODE_WORK = 4162   # BFHIP_TREE_MODE_WORK
+# lower edges of the size classes of bfhip_tree_size_mode_share (bf_lag_edge): 1, 2, 3, 4, 6, 8, 12, 16, ...
+LAG_EDGES = tuple((j + 1) if j < 2 else ((1 << ((j + 1) // 2)) if (j & 1) else (3 << (j // 2 - 1))) for j in range(64))
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)

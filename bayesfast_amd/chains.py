@@ -157,10 +157,17 @@ class DeviceChains:
             # the chains' behaviour, one launch late
             lay = layout
             if lay == 'auto':
-                tree = self._trees_in_step(lag=1 if i_launch > 0 else 2)   # (asked for at every launch: the answers are consumed in order)
+                ans = self._trees_in_step(lag=1 if i_launch > 0 else 2)   # (asked for at every launch: the answers are consumed in order)
+                tree, laggard = ans & 4095, ans >= 4096
                 in_step = sampler == 'HMC' or tree > 0
                 lay = IN_STEP_LAYOUT if in_step else 'wave'
                 if sampler == 'NUTS' and tree >= 24 and self._deep_trees_prefer_waves():
+                    lay = 'wave'
+                # Some chain builds trees sixteen times the common size (outside the bound, say, where the surrogate is its linear
+                # extrapolation): a launch lasts as long as its busiest chain, and only the wave layout's launches have a second part
+                # for such chains (bfhip_sampler.hip: launch_nuts_pipe).  64-d x 4096 chains, ONE chain of them outside the bound:
+                # split 2.6 x 10^8 (from 11.8), group 1.7, wave 4.9 (tools/leak_probe.py).
+                if sampler == 'NUTS' and laggard:
                     lay = 'wave'
                 if sampler == 'NUTS' and self._small_problem():
                     lay = 'wave'
@@ -327,16 +334,26 @@ class DeviceChains:
                 ts = stats[:, r0:row1, _lib.NSTATS.index('tree_size')].reshape(-1)
                 # (binned as bf_tree_mode_kernel bins them: negative and NaN sizes go to bucket 4095)
                 ts = torch.where((ts >= 0.) & (ts < 4095.), ts, torch.full_like(ts, 4095.)).to(torch.int64)
-                hist = torch.zeros(4096, dtype=torch.int64, device=self.ctx.device)
+                hist = torch.zeros(4096 + 64, dtype=torch.int64, device=self.ctx.device)
                 hist.scatter_add_(0, ts, torch.ones_like(ts))
+                # (the chains by the size class of their leapfrogs in the window, as bf_tree_mode_kernel counts them)
+                edges = torch.tensor(_lib.LAG_EDGES, dtype=torch.int64, device=self.ctx.device)
+                cls = (torch.searchsorted(edges, ts.view(self.n_chain, -1).sum(1), right=True) - 1).clamp_(0, 63)
+                hist.scatter_add_(0, 4096 + cls, torch.ones_like(cls))
             self.ctx.stream.synchronize()
             self.hist_reduce(hist)
-            self._answers.append(max(1, int(hist.argmax())) if float(hist.max()) >= share * float(hist.sum()) else 0)
+            h = [int(v) for v in hist.cpu()]
+            sizes, classes = h[:4096], h[4096:]
+            mode = max(1, sizes.index(max(sizes)))
+            n_all, tot = sum(classes), sum(i * v for i, v in enumerate(sizes))
+            top = max(j for j in range(64) if classes[j]) if n_all else 0
+            lag = 4096 if (tot > 0 and _lib.LAG_EDGES[top] * n_all >= 2 * tot) else 0   # (some chain lags far behind the rest)
+            self._answers.append(mode + lag if max(sizes) >= share * sum(sizes) else 0)
             del self._answers[:-4]
             return
         if getattr(self, '_step_host', None) is None:
             self._step_host = torch.zeros(8, dtype=torch.int32, pin_memory=True)
-            self._step_dev = torch.zeros(4098, dtype=torch.int32, device=self.ctx.device)  # BFHIP_TREE_MODE_WORK
+            self._step_dev = torch.zeros(_lib.TREE_MODE_WORK, dtype=torch.int32, device=self.ctx.device)
             self._n_flag = 0
         _lib.check(self.ctx._lib.bfhip_tree_size_mode_share(self.ctx.handle, self.n_chain, stats.shape[1], _ptr(stats), r0,
                                                             row1 - r0, float(share), _ptr(self._step_dev)))
@@ -351,7 +368,7 @@ class DeviceChains:
 
     def _trees_in_step(self, lag=1):
         """The answer of ``_note_trees`` for the launch ``lag`` launches back (1 = the last one) -- the common tree size when the
-        chains ran in step, else 0 --, waited for if it is still on its way; 0 when there is none (the first launches of a chain set, launches that were not NUTS).  A pure
+        chains ran in step (+ 4096 when some chain builds far larger trees than the rest), else 0 --, waited for if it is still on its way; 0 when there is none (the first launches of a chain set, launches that were not NUTS).  A pure
         function of the launches so far: an answer that happens to have arrived early is not used before its turn."""
         ans = getattr(self, '_answers', [])
         if len(ans) < lag:

@@ -2232,18 +2232,32 @@ extern "C" int bfhip_metric_init_full(bfhip_ctx *ctx, int n_chain, int d, const 
 
 // ---------------------------------------------------------------------------------------------------
 // "Did the chains run in step?" -- the share of the most common NUTS tree size among rows [row0, row0 + n_rows) of the
-// statistics of all chains, compared with a threshold.  work (BFHIP_TREE_MODE_WORK int32, zeroed once by the caller):
-// [0] the answer, [1 .. 4096] histogram of the sizes 0 .. 4095, [4097] arrival counter; every workgroup adds its LDS
-// histogram, the last one to arrive decides and clears the buffer for the next call.
+// statistics of all chains, compared with a threshold -- and "does some chain lag far behind?": a launch lasts as long as its
+// busiest chain, so the largest per-chain sum of tree sizes over the window is compared with the mean.  work
+// (BFHIP_TREE_MODE_WORK int32, zeroed once by the caller): [0] the answer, [1 .. 4096] histogram of the sizes 0 .. 4095,
+// [4097] arrival counter, [4098 .. 4098 + 63] chains by the size class of their window sum (bf_lag_class); every workgroup adds
+// its part, the last one to arrive decides and clears the buffer for the next call.  Integers only, and sums that do not depend
+// on how the chains are split over launches or ranks: the sharded path (chains.py: hist_reduce) takes the same decision from the
+// ranks' summed histograms.
 // ---------------------------------------------------------------------------------------------------
+// size classes 1, 2, 3, 4, 6, 8, 12, 16, ... (lower edges; class j holds the sums in [edge j, edge j + 1))
+__host__ __device__ inline long bf_lag_edge(int j) { return j < 2 ? j + 1 : ((j & 1) ? 1L << ((j + 1) / 2) : 3L << (j / 2 - 1)); }
+__host__ __device__ inline int bf_lag_class(long v) {
+    int j = 0;
+    while (j < 63 && bf_lag_edge(j + 1) <= v) ++j;
+    return j;
+}
 __global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_out, const double *__restrict__ stats, int row0,
                                                            int n_rows, double share, int *__restrict__ work) {
     __shared__ unsigned int hist[4096];
+    __shared__ unsigned int lagc[64];
     __shared__ unsigned int best;
     __shared__ int last;
     __shared__ unsigned int mode_at;
+    __shared__ unsigned long long tot_sum;
     for (int i = threadIdx.x; i < 4096; i += 256) hist[i] = 0;
-    if (threadIdx.x == 0) { best = 0; mode_at = 0xFFFFFFFFu; }
+    if (threadIdx.x < 64) lagc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { best = 0; mode_at = 0xFFFFFFFFu; tot_sum = 0; }
     __syncthreads();
     const long total = (long)n_chain * n_rows;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -2252,10 +2266,19 @@ __global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_ou
         const int b = t >= 0. && t < 4095. ? (int)t : 4095;
         atomicAdd(&hist[b], 1u);
     }
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < n_chain; c += (long)gridDim.x * 256) {   // this chain's leapfrogs in the window
+        long sum = 0;
+        for (int r = 0; r < n_rows; ++r) {
+            const double t = stats[(c * n_out + row0 + r) * BFHIP_STAT_STRIDE + BFHIP_NS_TREE_SIZE];
+            sum += t >= 0. && t < 4095. ? (int)t : 4095;
+        }
+        atomicAdd(&lagc[bf_lag_class(sum)], 1u);
+    }
     __syncthreads();
-    unsigned int *gh = (unsigned int *)work + 1;
+    unsigned int *gh = (unsigned int *)work + 1, *gl = (unsigned int *)work + 4098;
     for (int i = threadIdx.x; i < 4096; i += 256)
         if (hist[i]) atomicAdd(&gh[i], hist[i]);
+    if (threadIdx.x < 64 && lagc[threadIdx.x]) atomicAdd(&gl[threadIdx.x], lagc[threadIdx.x]);
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) last = atomicAdd(&work[4097], 1) == (int)gridDim.x - 1;
@@ -2263,17 +2286,27 @@ __global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_ou
     if (!last) return;
     __threadfence();
     unsigned int mx = 0, at = 0;
+    unsigned long long part = 0;
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const unsigned int v = atomicExch(&gh[i], 0u);  // (read through the atomic path, and cleared for the next call)
+        part += (unsigned long long)v * (unsigned)i;
         if (v > mx) { mx = v; at = (unsigned)i; }
     }
+    if (threadIdx.x < 64) lagc[threadIdx.x] = atomicExch(&gl[threadIdx.x], 0u);
     atomicMax(&best, mx);
+    atomicAdd(&tot_sum, part);
     __syncthreads();
     if (mx == best && mx > 0) atomicMin(&mode_at, at);   // (the smallest size among equally common ones)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int mode = mode_at < 4096u ? (int)mode_at : 0;
-        work[0] = ((double)best >= share * (double)total) ? (mode > 1 ? mode : 1) : 0;
+        const int mode = mode_at < 4096u ? (mode_at > 1u ? (int)mode_at : 1) : 1;
+        int top = 0;
+        for (int j = 0; j < 64; ++j)
+            if (lagc[j]) top = j;
+        // (the busiest chain's window sum is at least its class's lower edge: at least twice the mean, in integers)
+        const bool lag = (unsigned long long)bf_lag_edge(top) * (unsigned long long)n_chain >= 2ull * tot_sum && tot_sum > 0;
+        // [0] the common size when the trees are in step, else 0; + 4096: some chain lags far behind the rest
+        work[0] = ((double)best >= share * (double)total) ? (mode | (lag ? 1 << 12 : 0)) : 0;
         work[4097] = 0;
     }
 }

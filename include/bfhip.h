@@ -206,12 +206,13 @@ int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_cha
                       uint64_t *rng, double *sc, double *vec, int iter_out0, int n_out, double *samples,
                       double *stats, unsigned long long *n_leapfrog);
 
-/* Helper of the layout choice (chain_layout above): work[0] := the most common tree_size (at least 1; sizes from 4095 up count as
- * 4095) when at least `share` of the NUTS trees in rows [row0, row0 + n_rows) of stats (C,n_out,BFHIP_STAT_STRIDE), all chains,
- * have it, else 0.
+/* Helper of the layout choice (chain_layout above): work[0] := the most common tree_size (1 .. 4095; larger sizes count as 4095)
+ * when at least `share` of the NUTS trees in rows [row0, row0 + n_rows) of stats (C,n_out,BFHIP_STAT_STRIDE), all chains, have it,
+ * else 0; plus 4096 when some chain's trees of these rows add up to at least twice the mean over the chains (to the resolution of
+ * the size classes 1, 2, 3, 4, 6, 8, 12, ...: a launch lasts as long as its busiest chain).
  * work: BFHIP_TREE_MODE_WORK int32 on the device, zeroed once by the caller and left clean by every call.  Queued on the
  * context's stream behind the launch that wrote the rows; nothing synchronises. */
-#define BFHIP_TREE_MODE_WORK 4098
+#define BFHIP_TREE_MODE_WORK 4162
 int bfhip_tree_size_mode_share(bfhip_ctx *ctx, int n_chain, int n_out, const double *stats, int row0, int n_rows, double share,
                                int *work);
 

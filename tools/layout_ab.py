@@ -11,7 +11,7 @@ ta = float(sys.argv[1]) if len(sys.argv) > 1 else 0.8
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 ctx = get_context(0)
-spec, _ = correlated_gaussian_spec(D)
+spec, _ = correlated_gaussian_spec(D, fit_scale=float(os.environ.get('FIT_SCALE', 1.5)))   # (FIT_SCALE < 1.3: chains leak through the bound)
 if os.environ.get('DECAY'):   # the decay term of core/density.py:740-746 around the bound's ellipsoid, never active here
     po = spec['poly']
     spec = dict(spec, use_decay=True, decay_mu=po['mu'], decay_hess=po['hess'], decay_alpha2=(float(os.environ['DECAY']) * po['alpha'])**2, decay_gamma=0.1)
@@ -21,7 +21,7 @@ if os.environ.get('BOUNDED'):  # behind the constraint transform: all four kinds
 dens = DeviceDensity(spec, ctx)
 x0 = np.random.default_rng(1).normal(size=(C, D)) * (0.3 if os.environ.get('BOUNDED') else 1.)
 KN = _lib.last_kernel
-for layout in ('group', 'split', 'wave'):
+for layout in ('group', 'split', 'wave', 'auto'):
     ch = DeviceChains(dens, x0, seed=3)
     kw = dict(n_warmup=750, target_accept=ta, check=False, layout=layout)
     ch.run(750, 'NUTS', **kw)
