@@ -167,12 +167,12 @@ class DeviceChains:
                 # extrapolation): a launch lasts as long as its busiest chain, and only the wave layout's launches have a second part
                 # for such chains (bfhip_sampler.hip: launch_nuts_pipe).  64-d x 4096 chains, ONE chain of them outside the bound:
                 # split 2.6 x 10^8 (from 11.8), group 1.7, wave 4.9 (tools/leak_probe.py).
-                if sampler == 'NUTS' and laggard:
-                    lay = 'wave'
                 if sampler == 'NUTS' and self._small_problem():
                     lay = 'wave'
                 elif sampler == 'NUTS' and self._lanes_whatever_the_trees():
                     lay = IN_STEP_LAYOUT
+                if sampler == 'NUTS' and laggard:
+                    lay = 'wave'
                 if lay == 'split' and in_step and self._two_groups_fit_a_cu():
                     lay = 'group'
             cfg.chain_layout = {'group': 1, 'wave': 2, 'split': 3}[lay]

@@ -1,6 +1,6 @@
 """Tuning: the in-step layouts against the wave layout when chains leak through the surrogate's bound (the headline family with a
 training set FIT_SCALE times the posterior's width: below ~1.25 some chains sit outside the alpha-ellipsoid): rates, the share of
-samples outside, and the group kernels' trip counters.  usage: FIT_SCALE=1.2 python tools/leak_probe.py [chains]"""
+samples outside, and the group kernels' trip counters.  usage: FIT_SCALE=1.2 python tools/leak_probe.py [chains] [dim]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,7 @@ from bayesfast_amd.chains import DeviceChains
 from bayesfast_amd.workloads import correlated_gaussian_spec
 from bayesfast_amd import _lib
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-D = 64
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ctx = get_context(0)
 spec, _ = correlated_gaussian_spec(D, fit_scale=float(os.environ.get('FIT_SCALE', 1.2)))
 po = spec['poly']
