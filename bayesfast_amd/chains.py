@@ -163,14 +163,15 @@ class DeviceChains:
                 lay = IN_STEP_LAYOUT if in_step else 'wave'
                 if sampler == 'NUTS' and tree >= 24 and self._deep_trees_prefer_waves():
                     lay = 'wave'
-                # Some chain builds trees sixteen times the common size (outside the bound, say, where the surrogate is its linear
-                # extrapolation): a launch lasts as long as its busiest chain, and only the wave layout's launches have a second part
-                # for such chains (bfhip_sampler.hip: launch_nuts_pipe).  64-d x 4096 chains, ONE chain of them outside the bound:
-                # split 2.6 x 10^8 (from 11.8), group 1.7, wave 4.9 (tools/leak_probe.py).
                 if sampler == 'NUTS' and self._small_problem():
                     lay = 'wave'
                 elif sampler == 'NUTS' and self._lanes_whatever_the_trees():
                     lay = IN_STEP_LAYOUT
+                # Some chain builds trees many times the common size (outside the bound, say, where the surrogate is its linear
+                # extrapolation; reported from four times the mean over the window, in step or not): a launch lasts as long as its
+                # busiest chain, and only the wave layout's launches have a second part for such chains (bfhip_sampler.hip:
+                # launch_nuts_pipe).  64-d x 4096 chains, ONE chain of them outside the bound (16 x the others' leapfrogs): split
+                # 2.6 x 10^8 (from 11.8), group 1.7, wave 4.9 (tools/leak_probe.py).
                 if sampler == 'NUTS' and laggard:
                     lay = 'wave'
                 if lay == 'split' and in_step and self._two_groups_fit_a_cu():
@@ -347,8 +348,8 @@ class DeviceChains:
             mode = max(1, sizes.index(max(sizes)))
             n_all, tot = sum(classes), sum(i * v for i, v in enumerate(sizes))
             top = max(j for j in range(64) if classes[j]) if n_all else 0
-            lag = 4096 if (tot > 0 and _lib.LAG_EDGES[top] * n_all >= 2 * tot) else 0   # (some chain lags far behind the rest)
-            self._answers.append(mode + lag if max(sizes) >= share * sum(sizes) else 0)
+            lag = 4096 if (tot > 0 and _lib.LAG_EDGES[top] * n_all >= 4 * tot) else 0   # (some chain lags far behind the rest: bf_tree_mode_kernel)
+            self._answers.append((mode if max(sizes) >= share * sum(sizes) else 0) + lag)
             del self._answers[:-4]
             return
         if getattr(self, '_step_host', None) is None:

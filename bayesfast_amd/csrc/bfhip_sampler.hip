@@ -2303,10 +2303,13 @@ __global__ __launch_bounds__(256) void bf_tree_mode_kernel(int n_chain, int n_ou
         int top = 0;
         for (int j = 0; j < 64; ++j)
             if (lagc[j]) top = j;
-        // (the busiest chain's window sum is at least its class's lower edge: at least twice the mean, in integers)
-        const bool lag = (unsigned long long)bf_lag_edge(top) * (unsigned long long)n_chain >= 2ull * tot_sum && tot_sum > 0;
-        // [0] the common size when the trees are in step, else 0; + 4096: some chain lags far behind the rest
-        work[0] = ((double)best >= share * (double)total) ? (mode | (lag ? 1 << 12 : 0)) : 0;
+        // (the busiest chain's window sum is at least its class's lower edge: at least FOUR times the mean, in integers -- at twice the
+        // mean the wave layout's second part only breaks even at 64-d, and one chain in thousands at 2x is likely while the step sizes
+        // still adapt; the measurement behind the rule is a 16x chain)
+        const bool lag = (unsigned long long)bf_lag_edge(top) * (unsigned long long)n_chain >= 4ull * tot_sum && tot_sum > 0;
+        // [0] the common size when the trees are in step, else 0; + 4096: some chain lags far behind the rest (reported whether or not
+        // the trees are in step: a launch lasts as long as its busiest chain either way)
+        work[0] = (((double)best >= share * (double)total) ? mode : 0) | (lag ? 1 << 12 : 0);
         work[4097] = 0;
     }
 }

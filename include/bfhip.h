@@ -37,6 +37,7 @@ typedef struct bfhip_ctx bfhip_ctx;
 #define BFHIP_MAX_DIM 128         /* input_size limit of the device path */
 #define BFHIP_MAX_TREEDEPTH 12
 
+/* 101 (round 6): BFHIP_TREE_MODE_WORK grew to 4162 and work[0] of bfhip_tree_size_mode_share carries the laggard bit; 100 before. */
 int bfhip_version(void);
 const char *bfhip_last_error(void);
 
@@ -208,10 +209,12 @@ int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, int n_cha
 
 /* Helper of the layout choice (chain_layout above): work[0] := the most common tree_size (1 .. 4095; larger sizes count as 4095)
  * when at least `share` of the NUTS trees in rows [row0, row0 + n_rows) of stats (C,n_out,BFHIP_STAT_STRIDE), all chains, have it,
- * else 0; plus 4096 when some chain's trees of these rows add up to at least twice the mean over the chains (to the resolution of
- * the size classes 1, 2, 3, 4, 6, 8, 12, ...: a launch lasts as long as its busiest chain).
- * work: BFHIP_TREE_MODE_WORK int32 on the device, zeroed once by the caller and left clean by every call.  Queued on the
- * context's stream behind the launch that wrote the rows; nothing synchronises. */
+ * else 0; plus 4096 -- whether or not the trees are in step -- when some chain's trees of these rows add up to at least four times
+ * the mean over the chains (to the resolution of the size classes 1, 2, 3, 4, 6, 8, 12, ...: a launch lasts as long as its busiest
+ * chain).  Read it as (work[0] & 4095, work[0] >> 12).
+ * work: BFHIP_TREE_MODE_WORK int32 on the device, zeroed once by the caller and left clean by every call (the kernel writes all
+ * BFHIP_TREE_MODE_WORK entries: a binding built against bfhip_version() 100, where the buffer was 4098 ints, must be rebuilt).
+ * Queued on the context's stream behind the launch that wrote the rows; nothing synchronises. */
 #define BFHIP_TREE_MODE_WORK 4162
 int bfhip_tree_size_mode_share(bfhip_ctx *ctx, int n_chain, int n_out, const double *stats, int row0, int n_rows, double share,
                                int *work);

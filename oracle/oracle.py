@@ -268,7 +268,7 @@ def logp_and_grad(spec, x, original_space=False, tuned=False):
         f = lib().bfo_tuned_prepare
         f.restype = C.c_int
         if f(C.byref(dn)) != 0:
-            raise ValueError('the tuned evaluation covers the plain linear + quadratic surrogate only')
+            raise ValueError('the tuned evaluation does not cover this density')
     x = _f64(x)
     single = x.ndim == 1
     x2 = np.atleast_2d(x)

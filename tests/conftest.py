@@ -16,3 +16,33 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+# every integer switch of include/bfhip_debug.h
+DEBUG_SWITCHES = ('no_group', 'no_pipe', 'no_plain', 'no_quad', 'wave_cpg', 'tail_relaunch', 'tail_stop', 'tail_q', 'tail_max', 'lone',
+                  'lone_form', 'pld_waves', 'cubic_form', 'cubic_loops', 'gram_one_wave', 'chol_one_panel', 'no_vel_ahead', 'tnuts_wpb',
+                  'no_bound_proof', 'no_proof_weights', 'pld_no_compress')
+
+
+@pytest.fixture(autouse=True)
+def _restore_debug_switches(request):
+    """GPU tests flip the library's tuning switches (bfhip_debug_set) and reset them to the built-in defaults in their finally
+    blocks; this fixture puts back what was there BEFORE the test, so that a BFHIP_* environment override (read once, when the
+    library is first used) survives for the tests that follow."""
+    if request.node.get_closest_marker('gpu') is None:
+        yield
+        return
+    from bayesfast_amd import _lib
+    before = {}
+    for k in DEBUG_SWITCHES:
+        try:
+            before[k] = _lib.debug_get(k)
+        except Exception:
+            pass
+    yield
+    for k, v in before.items():
+        try:
+            if _lib.debug_get(k) != v:
+                _lib.debug_set(k, v)
+        except Exception:
+            pass

@@ -290,7 +290,7 @@ def test_full_metric_rejects_indefinite_covariance():
 
 def test_tuned_baseline_evaluation_agrees_with_the_faithful_one():
     """bench.py's CPU baseline times bf_cpu_tuned.c (symmetrised dense matvec, AVX2); it must be the same density: equal
-    to rounding inside the bound, and the faithful extrapolation outside (it declines those points)."""
+    to rounding inside the bound and outside (where it extrapolates by linearity instead of a second evaluation)."""
     from bayesfast_amd.workloads import correlated_gaussian_spec
     spec, cov = correlated_gaussian_spec(64)
     rng = np.random.default_rng(3)
@@ -300,9 +300,84 @@ def test_tuned_baseline_evaluation_agrees_with_the_faithful_one():
     f1, g1 = orc.logp_and_grad(spec, x, tuned=True)
     np.testing.assert_allclose(f1, f0, rtol=1e-12, atol=1e-11)
     np.testing.assert_allclose(g1, g0, rtol=1e-11, atol=1e-11)
-    assert np.array_equal(f1[200:], f0[200:])  # outside the bound: the faithful path itself
     f2, _ = orc.logp_and_grad(spec, x)  # and the registration does not outlive the call
     assert np.array_equal(f2, f0)
+
+
+def _random_single_output_spec(d, rng, cubic, decay, transform, su, link):
+    """A single-output surrogate density with the chosen features (test input for the tuned evaluation)."""
+    cfgs = [dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(1), coef=rng.normal(size=(1, d + 1))),
+            dict(order='quadratic', input_mask=np.arange(d), output_mask=np.arange(1), coef=np.triu(rng.normal(size=(d, d)))[None] * -0.3)]
+    if cubic:
+        m2, m3 = np.sort(rng.choice(d, 5, replace=False)), np.sort(rng.choice(d, 6, replace=False))
+        a3 = np.zeros((1, 6, 6, 6))
+        for j in range(6):
+            for k in range(j + 1, 6):
+                for l in range(k + 1, 6):
+                    a3[0, j, k, l] = 0.05 * rng.normal()
+        cfgs += [dict(order='cubic-2', input_mask=m2, output_mask=np.arange(1), coef=0.05 * rng.normal(size=(1, 5, 5))),
+                 dict(order='cubic-3', input_mask=m3, output_mask=np.arange(1), coef=a3)]
+    xs = rng.normal(size=(40 * d, d))
+    poly = dict(input_size=d, output_size=1, configs=cfgs, use_bound=False)
+    poly.update(orc.set_bound(poly, xs, rng.normal(size=xs.shape[0]), dict(alpha_p=80.)))
+    spec = dict(d=d, poly=poly)
+    if decay:
+        spec.update(orc.set_decay(xs * 0.7, alpha_p=90.))
+    if transform:
+        spec['ranges'] = np.stack((-4. - rng.uniform(size=d), 4. + rng.uniform(size=d)), axis=1)
+        hb = np.zeros((d, 2), np.uint8)
+        hb[: d // 3] = 1
+        hb[d // 3: d // 2, 0] = 1
+        spec['hard_bounds'] = hb
+    if su:
+        spec['su_lo'], spec['su_diff'] = rng.normal(size=d) * 0.1, rng.uniform(0.7, 1.5, size=d)
+    if link:
+        spec['link'] = dict(kind='gaussian', y=0.3, prec=0.7, logp0=-1.2)
+    return spec
+
+
+@pytest.mark.parametrize('cubic,decay,transform,su,link', [(0, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 1, 1, 0), (0, 0, 1, 0, 1), (0, 1, 0, 1, 0), (1, 0, 0, 0, 1)])
+def test_tuned_evaluation_of_every_single_output_feature_set(cubic, decay, transform, su, link):
+    """Round 6: the tuned evaluation covers decay, points outside the bound (by linearity, or a second evaluation with cubic
+    configs), cubic configs, transforms, input scaling and the Gaussian link -- the config blocks' CPU baselines all run it."""
+    d = 12
+    rng = np.random.default_rng(100 + 16 * cubic + 8 * decay + 4 * transform + 2 * su + link)
+    spec = _random_single_output_spec(d, rng, cubic, decay, transform, su, link)
+    for original_space in (False, True):
+        x = rng.normal(size=(300, d)) * np.repeat([0.6, 2.5], 150)[:, None]
+        if transform and original_space:
+            x = np.clip(x, -3.9, 3.9)
+        f0, g0 = orc.logp_and_grad(spec, x, original_space=original_space)
+        f1, g1 = orc.logp_and_grad(spec, x, original_space=original_space, tuned=True)
+        assert np.all(np.isfinite(f0))
+        np.testing.assert_allclose(f1, f0, rtol=1e-11, atol=1e-10)
+        np.testing.assert_allclose(g1, g0, rtol=1e-10, atol=1e-10)
+    # points on both sides of the bound were there
+    xm = (x - spec.get('su_lo', 0.)) / spec.get('su_diff', 1.) - spec['poly']['mu'] if not transform else None
+    if xm is not None:
+        b = np.sqrt(np.einsum('ij,jk,ik->i', xm, spec['poly']['hess'], xm))
+        assert 20 < np.sum(b > spec['poly']['alpha']) < 280
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_tuned_evaluation_of_the_des_shaped_pipeline_matches_the_reference(tag):
+    """The tuned pipeline evaluation (monomial vector, two dense products) against the REFERENCE's values (pipeline_des.npz)."""
+    from specio import rebuild_pipeline_des
+    z = np.load(os.path.join(G, 'pipeline_des.npz'))
+    spec = rebuild_pipeline_des(z, tag)
+    for sp, key, pts in ((True, 'orig', z[tag + '.xo']), (False, 'trans', z[tag + '.xt'])):
+        lp, g = orc.logp_and_grad(spec, pts, original_space=sp, tuned=True)
+        np.testing.assert_allclose(lp, z['%s.logp_%s' % (tag, key)], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(g, z['%s.grad_%s' % (tag, key)], rtol=1e-10, atol=1e-10)
+
+
+def test_tuned_evaluation_of_a_pipeline_with_full_precision_and_cubic_configs():
+    from specio import rebuild_pipeline
+    z = np.load(os.path.join(G, 'pipeline.npz'))
+    spec = rebuild_pipeline(z)
+    lp, g = orc.logp_and_grad(spec, z['xt'], original_space=True, tuned=True)
+    np.testing.assert_allclose(lp, z['logp'], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(g, z['grad'], rtol=1e-10, atol=1e-10)
 
 
 # ---- multi-output surrogate + chi-square (+ prior) pipelines, SURVEY 8f-1: fixtures pipeline.npz, pipeline_des.npz ----

@@ -1,4 +1,4 @@
-// compile the lone kernel alone to look at its registers: includes what bfhip_sampler.hip includes before it
+// compile the lone kernel alone to look at its registers (hipcc -I bayesfast_amd/csrc ...): includes what bfhip_sampler.hip includes before it
 #include <type_traits>
 #include <cstring>
 #include <cstdio>

@@ -3,6 +3,8 @@ the average duration of the timed dispatches (kernel trace), HBM-side bytes per 
 passes, raw KB counters -> bytes) and the SQ counters, each over the last `n_timed` dispatches of that kernel in the run."""
 import sys, os, glob, json, csv
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from benchlib.blocks import source_hash   # (the HIP sources the profiled library was built from: bench.py reads a stored traffic value only for the same sources)
 out, tag = sys.argv[1], sys.argv[2]
 N_TIMED = 2   # bench.py config_block: steps = 2 timed launches per block
 SAMPLERS = ('bf_sampler_kernel', 'bf_nuts_pipe_kernel', 'bf_group_kernel', 'bf_split_kernel', 'bf_lone_kernel')
@@ -85,6 +87,7 @@ for wd in sorted(glob.glob(os.path.join(out, '*/'))):
             sq['share_waiting'] = sq.get('SQ_WAIT_ANY', 0.) / wc
             sq['mfma_busy_share_of_wave_cycles'] = sq.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.) / wc
         e['sq'] = sq
+        e['source_hash'] = source_hash()
         for key in ('value', 'mean_tree_size', 'max_tree_depth', 'launch_tail', 'chains', 'dim'):
             if key in blk:
                 e[key] = blk[key]
@@ -93,4 +96,5 @@ for wd in sorted(glob.glob(os.path.join(out, '*/'))):
 if 'banana_round0' in res and 'banana_decay' in res:   # (round 0's kernel also runs in round 1's adaptation: its own run is the clean one)
     res['banana_decay'].pop('round_0', None)
 json.dump(res, open(os.path.join(out, '%s_config_counters.json' % tag), 'w'), indent=1)
+json.dump(res, open(os.path.join(out, 'config_traffic.json'), 'w'), indent=1)   # (copied to profiles/config_traffic.json: what bench.py's roofline.traffic reads)
 print(json.dumps(res, indent=1)[:5000])
