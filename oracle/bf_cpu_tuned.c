@@ -59,6 +59,7 @@ typedef struct {
     tuned_mono *mono;
     double *C;          /* (m, nf) */
     double *Ct;         /* (nf, m) */
+    double *Hs, *Hds;   /* symmetrised bound / decay Hessians */
 } tuned_t;
 
 static tuned_t g_tab[TUNED_MAX];
@@ -230,7 +231,7 @@ static int tuned_eval(const bfo_density *dn, const double *x, int original_space
     int oob = 0;
     if (pm->use_bound) {
         for (int i = 0; i < d; ++i) xm[i] = xs[i] - pm->mu[i];
-        matvec(pm->hess, xm, hv, d);   /* the Hessian is symmetric (the inverse of a covariance): H xm = xm H */
+        matvec(t->Hs, xm, hv, d);   /* the symmetrised Hessian: H xm = xm H */
         beta = sqrt(dotn(xm, hv, d));
         oob = beta > pm->alpha;
         if (beta != beta) return 0;    /* NaN: the faithful path decides */
@@ -283,7 +284,7 @@ static int tuned_eval(const bfo_density *dn, const double *x, int original_space
     if (dn->use_decay) {
         double xd[TUNED_MAXD], hd[TUNED_MAXD];
         for (int i = 0; i < d; ++i) xd[i] = xo[i] - dn->decay_mu[i];
-        matvec(dn->decay_hess, xd, hd, d);
+        matvec(t->Hds, xd, hd, d);
         const double b2 = dotn(xd, hd, d), ex = b2 - dn->decay_alpha2;
         f -= dn->decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
         if (b2 > dn->decay_alpha2) for (int i = 0; i < d; ++i) g[i] -= 2. * dn->decay_gamma * hd[i];
@@ -302,17 +303,23 @@ static int tuned_eval(const bfo_density *dn, const double *x, int original_space
     return 1;
 }
 
-static int is_symmetric(const double *M, int d) {
+/* The bound's and the decay term's Hessians are inverses of covariance matrices (modules/poly.py:269, core/density.py:803):
+ * symmetric up to the rounding of np.linalg.inv.  The tuned evaluation uses the symmetrised copy (H + H^T) / 2, so that x H and
+ * H x are one product; a matrix that is not symmetric to 1e-9 of its largest entry is declined (the faithful path runs). */
+static double *symmetrised(const double *M, int d) {
+    double mx = 0.;
+    for (int i = 0; i < d * d; ++i) mx = fabs(M[i]) > mx ? fabs(M[i]) : mx;
     for (int i = 0; i < d; ++i)
-        for (int k = i + 1; k < d; ++k) {
-            const double a = M[(size_t)i * d + k], b = M[(size_t)k * d + i];
-            if (fabs(a - b) > 1e-12 * (fabs(a) + fabs(b)) + 1e-300) return 0;
-        }
-    return 1;
+        for (int k = i + 1; k < d; ++k)
+            if (!(fabs(M[(size_t)i * d + k] - M[(size_t)k * d + i]) <= 1e-9 * mx)) return NULL;
+    double *S = (double *)malloc(sizeof(double) * (size_t)d * d);
+    for (int i = 0; i < d; ++i)
+        for (int k = 0; k < d; ++k) S[(size_t)i * d + k] = 0.5 * (M[(size_t)i * d + k] + M[(size_t)k * d + i]);
+    return S;
 }
 
 static void tuned_free(tuned_t *t) {
-    free(t->S); free(t->lin); free(t->Smu); free(t->mono); free(t->C); free(t->Ct);
+    free(t->S); free(t->lin); free(t->Smu); free(t->mono); free(t->C); free(t->Ct); free(t->Hs); free(t->Hds);
     memset(t, 0, sizeof(*t));
 }
 
@@ -321,18 +328,18 @@ int bfo_tuned_prepare(const bfo_density *dn) {
     const bfo_poly_model *pm = &dn->poly;
     const int d = dn->d, m = pm->output_size;
     if (d > TUNED_MAXD || g_n >= TUNED_MAX) return -1;
-    if (pm->use_bound && !is_symmetric(pm->hess, d)) return -1;
-    if (dn->use_decay && !is_symmetric(dn->decay_hess, d)) return -1;
     if (m != 1 && dn->link_kind != 2) return -1;
     tuned_t *t = &g_tab[g_n];
     memset(t, 0, sizeof(*t));
+    if (pm->use_bound && !(t->Hs = symmetrised(pm->hess, d))) return -1;
+    if (dn->use_decay && !(t->Hds = symmetrised(dn->decay_hess, d))) { tuned_free(t); return -1; }
     t->dn = dn;
     t->d = d;
     t->m = m;
     if (dn->link_kind == 2) {
         /* monomials: the constant, then every config's terms in its own packing order; identical monomials of different
          * configs stay separate columns (their coefficients add up in the product) */
-        if (m > TUNED_MAXM) return -1;
+        if (m > TUNED_MAXM) { tuned_free(t); return -1; }
         size_t nf = 1;
         for (int c = 0; c < pm->n_config; ++c) {
             const size_t n = (size_t)pm->configs[c].n_in;
@@ -343,7 +350,7 @@ int bfo_tuned_prepare(const bfo_density *dn) {
             case BFO_CUBIC_3: nf += n * (n - 1) * (n - 2) / 6; break;
             }
         }
-        if (nf > TUNED_MAXNF) return -1;
+        if (nf > TUNED_MAXNF) { tuned_free(t); return -1; }
         t->nf = (int)nf;
         t->mono = (tuned_mono *)malloc(sizeof(tuned_mono) * nf);
         t->C = (double *)calloc((size_t)m * nf, sizeof(double));

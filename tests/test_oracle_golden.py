@@ -359,6 +359,28 @@ def test_tuned_evaluation_of_every_single_output_feature_set(cubic, decay, trans
         assert 20 < np.sum(b > spec['poly']['alpha']) < 280
 
 
+def test_tuned_evaluation_takes_hessians_that_are_symmetric_only_to_rounding():
+    """np.linalg.inv of an ill-conditioned covariance is symmetric to ~1e-16 x cond, not bit for bit (the refitted banana of
+    bench.py's headline, config 5's cond-1e4 target): the tuned evaluation symmetrises and must not decline such a density."""
+    d = 16
+    rng = np.random.default_rng(77)
+    spec = _random_single_output_spec(d, rng, 0, 1, 0, 0, 0)
+    sc = np.logspace(-3, 2, d)
+    xs = rng.normal(size=(40 * d, d)) * sc
+    spec['poly'].update(orc.set_bound(dict(spec['poly'], use_bound=False), xs, rng.normal(size=xs.shape[0]), dict(alpha_p=80.)))
+    spec.update(orc.set_decay(xs, alpha_p=90.))
+    h = spec['poly']['hess']
+    assert np.max(np.abs(h - h.T)) > 0.   # (not exactly symmetric, or the test tests nothing)
+    cs = orc.ChainSet(spec, xs[:2], 1, tuned=True)
+    assert cs.tuned
+    cs.close()
+    x = rng.normal(size=(100, d)) * sc * np.repeat([0.5, 3.], 50)[:, None]
+    f0, g0 = orc.logp_and_grad(spec, x)
+    f1, g1 = orc.logp_and_grad(spec, x, tuned=True)
+    np.testing.assert_allclose(f1, f0, rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(g1, g0, rtol=1e-8, atol=1e-8 * np.max(np.abs(g0)))
+
+
 @pytest.mark.parametrize('tag', ['a', 'b'])
 def test_tuned_evaluation_of_the_des_shaped_pipeline_matches_the_reference(tag):
     """The tuned pipeline evaluation (monomial vector, two dense products) against the REFERENCE's values (pipeline_des.npz)."""
