@@ -274,9 +274,6 @@ class DeviceChains:
         from NumPy's global generator, base_hmc.py:241); later calls continue from the chains' own u.
 
         Returns (samples (n_chain, n_run, d), stats (n_chain, n_run, 11), stats_t (n_chain, n_run, 2) = u and weight)."""
-        torch = _torch()
-        if self.full_metric:  # bf_tnuts_kernel has the diagonal metric only; running on would silently ignore the covariance
-            raise NotImplementedError('TNUTS with a full-rank metric is not implemented; use a diagonal metric.')
         self.density.upload_if_needed()
         d = self.d
         mean = np.asarray(base_mean, dtype=np.float64).reshape(d)
@@ -298,6 +295,8 @@ class DeviceChains:
         cfg.target_accept, cfg.gamma, cfg.k, cfg.t_0 = float(target_accept), float(gamma), float(k), float(t_0)
         cfg.adapt_step_size, cfg.adapt_metric = int(bool(adapt_step_size)), int(bool(adapt_metric))
         cfg.update_window, cfg.doubling = int(update_window), int(bool(doubling))
+        cfg.full_metric = int(self.full_metric)   # (the full-rank metric, cubic configs, d = 128, the pipeline density: bfhip_tnuts_gen.hip)
+        cfg.metric_mat = self.mat.data_ptr() if self.full_metric else None
         n_run = int(n_run)
         samples = self.ctx.empty((self.n_chain, n_run, d))
         stats = self.ctx.empty((self.n_chain, n_run, _lib.STAT_STRIDE))

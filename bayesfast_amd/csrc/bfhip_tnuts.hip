@@ -24,26 +24,7 @@
 #include "bfhip_wave.h"
 #include "bfhip_oob.h"
 
-#define TN_MAXL BFHIP_MAX_TREEDEPTH
-enum { TS_LS = 0, TS_ACC, TS_E, TS_LOGP, TS_U, TS_W, TS_N };  // per-level stack scalars
-
-struct TnutsArgs {
-    bfhip_sampler_config cfg;
-    int n_chain, iter_end, iter_out0, n_out, d;
-    int cpg;          // chains per workgroup (8 or 4: the other waves only run matvec jobs)
-    uint64_t *rng;
-    double *sc, *vec, *tu, *samples, *stats, *stats_t;
-    unsigned long long *n_leapfrog;
-    double *scratch;  // [n_chain][4 * TN_MAXL][64] subtree stack vectors
-    const double *base_S, *base_lin;  // (d,d) symmetric S_b = A_b + A_b^T, (d,)
-    double base_c0, logxi;
-};
-
-__device__ inline double tn_wsum(double v) { return wave_sum(v); }   // (bfhip_wave.h: two 4 x 4 x 4 MFMAs and two row rotations)
-__device__ inline double tn_logaddexp(double a, double b) {
-    const double mx = a > b ? a : b, mn = a > b ? b : a;
-    return (mx == -INFINITY) ? -INFINITY : mx + log1p(exp(mn - mx));
-}
+#include "bfhip_tnuts.h"
 
 #define TN_XS 65   // row stride of the B operands and of the results (doubles)
 
@@ -511,18 +492,18 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || !cfg || !tp || n_chain < 0) return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: invalid argument");
     if (!ctx->has_model) return bf_set_error(BFHIP_ERR_STATE, "bfhip_tnuts_run: no density uploaded");
-    if (ctx->model.pld.on) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_tnuts_run: not implemented for the pipeline density");
     if (n_chain == 0) return 0;
     if (!rng || !sc || !vec || !u || !tp->base_S || !tp->base_lin || n_out < 0 || (n_out > 0 && (!samples || !stats || !stats_t)))
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: NULL array");
     if (cfg->max_treedepth < 1 || cfg->max_treedepth > BFHIP_MAX_TREEDEPTH || !(cfg->max_change > 0.) || cfg->update_window < 1)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: invalid sampler configuration");
+    if (cfg->full_metric && !cfg->metric_mat) return bf_set_error(BFHIP_ERR_ARG, "bfhip_tnuts_run: full_metric needs metric_mat");
     const DevModel &m = ctx->model;
-    const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link;
-    if (!common || m.DP > 64 || cfg->full_metric)
-        return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_tnuts_run: the tempered sampler covers the common surrogate (linear + quadratic "
-                                                   "configs with the bound; constraint transform and decay optional; no device-side input "
-                                                   "scaling, no cubic configs) at d <= 64 with the diagonal metric");
+    // the tuned instantiations: the common surrogate (linear + quadratic configs with the bound; constraint transform and decay
+    // optional) at d <= 64 with the diagonal metric.  Everything else -- cubic configs, d = 128, device-side input scaling, the
+    // Gaussian link, the pipeline density, the full-rank metric -- runs on the generic kernel (bfhip_tnuts_gen.hip)
+    const bool common = m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !m.pld.on;
+    const bool generic = !common || m.DP > 64 || cfg->full_metric || bf_tune().tnuts_generic;
     // Chains per workgroup (a workgroup is always eight waves, two workgroups per CU: the waves without a chain run matvec jobs
     // only): eight, or four when that spreads few chains over more CUs.  BFHIP_TNUTS_WPB / bfhip_debug_set("tnuts_wpb") override.
     const int forced = bf_tune().tnuts_wpb;
@@ -535,6 +516,17 @@ extern "C" int bfhip_tnuts_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg, 
         ctx->scratch_bytes = 0;
         BF_HIP_CHECK(hipMalloc(&ctx->scratch, need));
         ctx->scratch_bytes = need;
+    }
+    if (generic) {
+        TnutsArgs g;
+        g.cfg = *cfg;
+        g.n_chain = n_chain; g.iter_end = iter_end; g.iter_out0 = iter_out0; g.n_out = n_out; g.d = m.d;
+        g.rng = rng; g.sc = sc; g.vec = vec; g.tu = u; g.samples = samples; g.stats = stats; g.stats_t = stats_t;
+        g.n_leapfrog = n_leapfrog;
+        g.scratch = NULL;
+        g.base_S = tp->base_S; g.base_lin = tp->base_lin; g.base_c0 = tp->base_c0; g.logxi = tp->logxi;
+        g.cpg = cpg;
+        return bf_tnuts_gen_launch(ctx, g, cfg->full_metric ? (const double *)cfg->metric_mat : NULL);
     }
     TnutsArgs a;
     a.cfg = *cfg;

@@ -22,6 +22,7 @@ struct BfTune {
     int cubic_loops;     // BFHIP_CUBIC_LOOPS: cubic configs by the general loops also at sixteen masked inputs (the same sums in the same order)
     int no_vel_ahead;    // BFHIP_NO_VEL_AHEAD: full-rank metric without the next step's velocity taken ahead
     int tnuts_wpb;       // BFHIP_TNUTS_WPB: tempered NUTS, chains per workgroup (4, 8; 0: automatic)
+    int tnuts_generic;   // BFHIP_TNUTS_GENERIC: tempered NUTS on the generic kernel (bfhip_tnuts_gen.hip) also where the tuned one applies (tests compare them)
     int no_bound_proof;  // BFHIP_NO_BOUND_PROOF: always compute the H (x - mu) tiles
     int no_proof_weights;// BFHIP_NO_PROOF_WEIGHTS: the bound proof with the plain norm (read at upload)
     int pld_no_compress; // BFHIP_PLD_NO_COMPRESS: the pipeline density without the output-space compression (read at upload)
