@@ -102,6 +102,28 @@ __device__ inline void pld_point(const PldDev &pl, const PldLds &L, int DP, int 
     }
 }
 
+// the same for a wave that holds E dimensions per lane (dimension lane E + e: d = 128, E = 2)
+template <int E>
+__device__ inline void pld_point_e(const PldDev &pl, const PldLds &L, int DP, int c, int lane, const double (&x_eval)[E], double beta_oob) {
+    double *xe = L.XE + c * (DP + 2);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (lane * E + e < DP) xe[lane * E + e] = x_eval[e];
+    if (lane == 0) {
+        xe[DP] = 1.;
+        xe[DP + 1] = 0.;
+        L.CH[c] = beta_oob;
+    }
+    for (int p0 = 0; p0 < pl.PP; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < pl.PP) {
+            const unsigned mo = L.MONO[p];
+            const double v = (xe[mo & 255u] * xe[(mo >> 8) & 255u]) * xe[(mo >> 16) & 255u];
+            L.PHI[(p >> 2) * L.XS + c + L.CW * (p & 3)] = v;
+        }
+    }
+}
+
 __device__ inline double pld_rowsum4(double v) {   // sum over the four 16-lane rows of the wave, in every lane
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);

@@ -41,7 +41,7 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     const int d = ds->d, m = ds->m;
     const bfhip_polymodel_desc &pm = ds->model;
     if (d < 1 || m < 1 || pm.d != d || pm.m != m) return bf_set_error(BFHIP_ERR_ARG, "bfhip_pipeline_upload: d, m and the model's disagree");
-    if (d > 64) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_pipeline_upload: input_size %d > 64 is not implemented", d);
+    if (d > BFHIP_MAX_DIM) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_pipeline_upload: input_size %d > %d is not implemented", d, BFHIP_MAX_DIM);
     if (!pm.c0 || !pm.lin || !ds->y) return bf_set_error(BFHIP_ERR_ARG, "bfhip_pipeline_upload: c0, lin and y are required");
     if ((ds->prec == NULL) == (ds->prec_diag == NULL)) return bf_set_error(BFHIP_ERR_ARG, "give exactly one of prec and prec_diag");
     if ((ds->prior_mu == NULL) != (ds->prior_prec == NULL)) return bf_set_error(BFHIP_ERR_ARG, "prior_mu and prior_prec go together");
@@ -317,8 +317,8 @@ __device__ inline double pld_frag_at(const double *Mf, int DP, int i, int k) {
 }
 
 // NPT points per workgroup: 16 (sixteen waves, 16-column tiles) or 8 (eight waves, the eight-chain forms' compact LDS rows: what
-// a surrogate with more monomials than the sixteen-point layout holds runs on)
-template <int NPT>
+// a surrogate with more monomials than the sixteen-point layout holds runs on); E dimensions per lane (2 at d > 64)
+template <int NPT, int E>
 __global__ __launch_bounds__(NPT * 64) void bf_pld_logp_grad_kernel(DevModel m, int n, const double *__restrict__ x, int original_space,
                                                                   double *__restrict__ logp, double *__restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -331,40 +331,62 @@ __global__ __launch_bounds__(NPT * 64) void bf_pld_logp_grad_kernel(DevModel m, 
     const bool tr = m.has_transform && !original_space;
     for (int base = blockIdx.x * NPT; base < n; base += gridDim.x * NPT) {
         const int i = base + w;
-        const bool valid = i < n, on = lane < d;
-        double xo = 0., jac = 1., gj = 0., logdet = 0.;
-        const double xin = (valid && on) ? x[(size_t)i * d + lane] : 0.;
-        xo = xin;
-        if (tr && on) {
-            double J, J2;
-            bf_to_original(xin, (int)m.pd[PD_KIND * DP + lane], m.pd[PD_LO * DP + lane], m.pd[PD_RG * DP + lane], xo, J, J2);
-            logdet = log(fabs(J));
-            jac = J;
-            gj = J2 / J;
-        }
-        const double su_diff = (m.has_su && on) ? m.pd[PD_SU_DIFF * DP + lane] : 1.;
-        const double xs = (m.has_su && on) ? (xo - m.pd[PD_SU_LO * DP + lane]) / su_diff : xo;
-        const double xm = on ? xs - m.pd[PD_MU * DP + lane] : 0.;
-        const double xd = (m.use_decay && on) ? xo - m.pd[PD_DMU * DP + lane] : 0.;
+        const bool valid = i < n;
+        double xo[E], jac[E], gj[E], su_diff[E], xs[E], xm[E], xd[E], hv[E], dgr[E], mu[E];
+        double logdet = 0.;
+        bool on[E];
         double *xmw = XM + (size_t)w * 2 * DP;
-        if (lane < DP) { xmw[lane] = xm; xmw[DP + lane] = xd; }
-        double hv = 0., dgr = 0.;
-        if (lane < DP) {
-            if (m.use_bound)
-                for (int k = 0; k < d; ++k) hv += pld_frag_at(m.Hf, DP, lane, k) * xmw[k];
-            if (m.use_decay)
-                for (int k = 0; k < d; ++k) dgr += pld_frag_at(m.Hdf, DP, lane, k) * xmw[DP + k];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
+            on[e] = dim < d;
+            const double xin = (valid && on[e]) ? x[(size_t)i * d + dim] : 0.;
+            xo[e] = xin;
+            jac[e] = 1.;
+            gj[e] = 0.;
+            if (tr && on[e]) {
+                double J, J2;
+                bf_to_original(xin, (int)m.pd[PD_KIND * DP + dim], m.pd[PD_LO * DP + dim], m.pd[PD_RG * DP + dim], xo[e], J, J2);
+                logdet += log(fabs(J));
+                jac[e] = J;
+                gj[e] = J2 / J;
+            }
+            su_diff[e] = (m.has_su && on[e]) ? m.pd[PD_SU_DIFF * DP + dim] : 1.;
+            xs[e] = (m.has_su && on[e]) ? (xo[e] - m.pd[PD_SU_LO * DP + dim]) / su_diff[e] : xo[e];
+            mu[e] = on[e] ? m.pd[PD_MU * DP + dim] : 0.;
+            xm[e] = on[e] ? xs[e] - mu[e] : 0.;
+            xd[e] = (m.use_decay && on[e]) ? xo[e] - m.pd[PD_DMU * DP + dim] : 0.;
+            if (dim < DP) { xmw[dim] = xm[e]; xmw[DP + dim] = xd[e]; }
         }
-        const double r_b2 = pld_wave_sum(xm * hv), r_bd2 = pld_wave_sum(xd * dgr);
+        double b2 = 0., bd2 = 0.;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
+            hv[e] = 0.;
+            dgr[e] = 0.;
+            if (dim < DP) {
+                if (m.use_bound)
+                    for (int k = 0; k < d; ++k) hv[e] += pld_frag_at(m.Hf, DP, dim, k) * xmw[k];
+                if (m.use_decay)
+                    for (int k = 0; k < d; ++k) dgr[e] += pld_frag_at(m.Hdf, DP, dim, k) * xmw[DP + k];
+            }
+            b2 += xm[e] * hv[e];
+            bd2 += xd[e] * dgr[e];
+        }
+        const double r_b2 = pld_wave_sum(b2), r_bd2 = pld_wave_sum(bd2);
         logdet = pld_wave_sum(logdet);
         double beta = 0.;
         if (m.use_bound) {   // modules/poly.py:467-469
             const double b = sqrt(r_b2);
             if (b > m.alpha) beta = b;
         }
-        const double mu = on ? m.pd[PD_MU * DP + lane] : 0.;
-        const double x_eval = beta > 0. ? (m.alpha * xs + (beta - m.alpha) * mu) / beta : xs;   // :482
-        pld_point(pl, L, DP, w, lane, (valid && on) ? x_eval : 0., valid ? beta : 0.);
+        double x_eval[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double xv = beta > 0. ? (m.alpha * xs[e] + (beta - m.alpha) * mu[e]) / beta : xs[e];   // :482
+            x_eval[e] = (valid && on[e]) ? xv : 0.;
+        }
+        pld_point_e<E>(pl, L, DP, w, lane, x_eval, valid ? beta : 0.);
         __syncthreads();
         if constexpr (NPT == 8) pld_gemm1_q8(pl, L, m.alpha, w, 8, lane);
         else pld_gemm1(pl, L, m.alpha, w, 16, lane);
@@ -376,36 +398,52 @@ __global__ __launch_bounds__(NPT * 64) void bf_pld_logp_grad_kernel(DevModel m, 
         pld_sums(pl, L, w, lane, NPT, s_rr, s_fr);
         s_rr = pld_wave_sum(s_rr);
         s_fr = pld_wave_sum(s_fr);
-        double gn = lane < DP ? pld_grad(pl, L, DP, w, lane) : 0.;   // (J_0^T r)_lane
+        double gn[E], dj = 0.;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gn[e] = lane * E + e < DP ? pld_grad(pl, L, DP, w, lane * E + e) : 0.;   // (J_0^T r)_dim
+            dj += gn[e] * xm[e];
+        }
         if (beta > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
             const double b = (beta - m.alpha) / m.alpha;
             s_rr += b * (b * pl.k_ff + 2. * pl.k_fy);
             s_fr += b * pl.k_ff + pl.k_fy;
-        }
-        if (beta > 0.) {   // modules/poly.py:494-496 contracted with r
-            const double r_dotj = pld_wave_sum(gn * xm);
-            gn += (s_fr / m.alpha - r_dotj / beta) * (hv / beta);
+            const double r_dotj = pld_wave_sum(dj);   // modules/poly.py:494-496 contracted with r
+#pragma unroll
+            for (int e = 0; e < E; ++e) gn[e] += (s_fr / m.alpha - r_dotj / beta) * (hv[e] / beta);
         }
         double f = pl.logp0 - 0.5 * s_rr;
-        double g = -gn;
-        if (m.has_su) g = g / su_diff;   // core/module.py:226
-        g = g * jac;                      // density.py:558
-        if (pl.has_prior) {
-            const double dx = on ? xo - pl.prior_mu[lane] : 0., pp = on ? pl.prior_prec[lane] : 0.;
-            f += pl.prior_c0 - 0.5 * pld_wave_sum(pp * dx * dx);
-            g += -(pp * dx) * jac;
+        double g[E], pr = 0.;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int dim = lane * E + e;
+            g[e] = -gn[e];
+            if (m.has_su) g[e] = g[e] / su_diff[e];   // core/module.py:226
+            g[e] = g[e] * jac[e];                      // density.py:558
+            if (pl.has_prior) {
+                const double dx = on[e] ? xo[e] - pl.prior_mu[dim] : 0., pp = on[e] ? pl.prior_prec[dim] : 0.;
+                pr += pp * dx * dx;
+                g[e] += -(pp * dx) * jac[e];
+            }
         }
+        if (pl.has_prior) f += pl.prior_c0 - 0.5 * pld_wave_sum(pr);
         if (m.use_decay) {   // density.py:740-746
             f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
-            if (r_bd2 > m.decay_alpha2) g -= 2. * m.decay_gamma * dgr;
+            if (r_bd2 > m.decay_alpha2) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) g[e] -= 2. * m.decay_gamma * dgr[e];
+            }
         }
         if (tr) {            // :747-750
             f += logdet;
-            g += gj;
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] += gj[e];
         }
         if (valid) {
             if (lane == 0) logp[i] = f;
-            if (grad && on) grad[(size_t)i * d + lane] = g;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (grad && on[e]) grad[(size_t)i * d + lane * E + e] = g[e];
         }
         __syncthreads();   // the LDS regions are rewritten by the next batch
     }
@@ -416,14 +454,13 @@ int bf_pld_logp_grad(bfhip_ctx *ctx, int n, const double *x, int original_space,
     const int npt = m.pld.only8 ? 8 : 16;
     const size_t lds = (pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent, npt == 8 ? PLD_XS8 : PLD_XS) + (size_t)npt * 2 * m.DP) * sizeof(double);
     if (lds > (size_t)160 * 1024) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "pipeline density: %zu KB of LDS", lds / 1024);
-    auto k16 = bf_pld_logp_grad_kernel<16>;
-    auto k8 = bf_pld_logp_grad_kernel<8>;
-    if (lds > 64 * 1024)
-        BF_HIP_CHECK(hipFuncSetAttribute(npt == 8 ? (const void *)k8 : (const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool e2 = m.DP > 64;   // two dimensions per lane
+    void (*k)(DevModel, int, const double *, int, double *, double *) =
+        npt == 8 ? (e2 ? bf_pld_logp_grad_kernel<8, 2> : bf_pld_logp_grad_kernel<8, 1>) : (e2 ? bf_pld_logp_grad_kernel<16, 2> : bf_pld_logp_grad_kernel<16, 1>);
+    if (lds > 64 * 1024) BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int grid = (n + npt - 1) / npt;
     if (grid > 4 * ctx->n_cu) grid = 4 * ctx->n_cu;
-    if (npt == 8) hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, ctx->stream, m, n, x, original_space, logp, grad);
-    else hipLaunchKernelGGL(k16, dim3(grid), dim3(1024), lds, ctx->stream, m, n, x, original_space, logp, grad);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(npt * 64), lds, ctx->stream, m, n, x, original_space, logp, grad);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1417,24 +1417,34 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
             // Every wave of the workgroup takes part in the two contractions; a chain that evaluates owns column w of them.
             // The bound is decided FIRST (its H (x - mu) tiles are this trip's phase B), so a point outside the ellipsoid is
             // evaluated once, at its projection (modules/poly.py:480-503), never in a second trip.
-            static_assert(!PLD || E == 1, "the pipeline density is instantiated for d <= 64");
             const PldDev &pl = m.pld;
-            double xm0 = 0., beta_o = 0., r_bd2 = 0.;
+            double xmv[E], beta_o = 0., r_bd2 = 0.;
+#pragma unroll
+            for (int e = 0; e < E; ++e) xmv[e] = 0.;
             if (evaluating) {
                 double r_b2 = 0.;
-                hv[0] = (f_bound && lane_ok) ? gb_read(slot_H, lane) : 0.;
-                dgr[0] = (f_decay && lane_ok) ? gb_read(slot_D, lane) : 0.;
-                xm0 = xs[0] - c_mu[0];
-                r_b2 = xm0 * hv[0];
-                if (f_decay) r_bd2 = (xo[0] - pdl(PD_DMU, 0)) * dgr[0];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int dim = lane * E + e;
+                    hv[e] = (f_bound && lane_ok) ? gb_read(slot_H, dim) : 0.;
+                    dgr[e] = (f_decay && lane_ok) ? gb_read(slot_D, dim) : 0.;
+                    xmv[e] = xs[e] - c_mu[e];
+                    r_b2 += xmv[e] * hv[e];
+                    if (f_decay) r_bd2 += (xo[e] - pdl(PD_DMU, e)) * dgr[e];
+                }
                 { double r2[2] = {r_b2, r_bd2}; wave_sum_n<2>(r2); r_b2 = r2[0]; r_bd2 = r2[1]; }
                 if (f_tr) logdet = wave_sum(logdet);
                 if (f_bound && !(r_b2 < m.alpha * m.alpha * (1. - 1e-12))) {   // modules/poly.py:467-469
                     const double b = usqrt(r_b2);
                     if (b > m.alpha) beta_o = b;
                 }
-                const double x_ev = beta_o > 0. ? (m.alpha * xs[0] + (beta_o - m.alpha) * c_mu[0]) / beta_o : xs[0];   // :482
-                pld_point(pl, PL, DP, w, lane, lane < d ? x_ev : 0., beta_o);
+                double x_ev[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double xv = beta_o > 0. ? (m.alpha * xs[e] + (beta_o - m.alpha) * c_mu[e]) / beta_o : xs[e];   // :482
+                    x_ev[e] = lane * E + e < d ? xv : 0.;
+                }
+                pld_point_e<E>(pl, PL, DP, w, lane, x_ev, beta_o);
             }
             if (pld_eval) {   // (uniform over the workgroup)
             TRACEP(7);
@@ -1455,7 +1465,12 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 double s2[2];
                 pld_sums(pl, PL, w, lane, NWV, s2[0], s2[1]);
                 wave_sum_n<2>(s2);
-                double gj0 = lane < DP ? pld_grad(pl, PL, DP, w, lane) : 0.;   // (J_0^T r)_lane
+                double gj0[E], dj = 0.;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    gj0[e] = lane * E + e < DP ? pld_grad(pl, PL, DP, w, lane * E + e) : 0.;   // (J_0^T r)_dim
+                    dj += gj0[e] * xmv[e];
+                }
                 if (beta_o > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
                     const double b = (beta_o - m.alpha) / m.alpha;
                     s2[0] += b * (b * pl.k_ff + 2. * pl.k_fy);
@@ -1463,25 +1478,36 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
                 }
                 TRACEP(15);
                 if (beta_o > 0.) {   // modules/poly.py:494-496, contracted with r
-                    const double r_dotj = wave_sum(gj0 * xm0);
-                    gj0 += (s2[1] / m.alpha - r_dotj / beta_o) * (hv[0] / beta_o);
+                    const double r_dotj = wave_sum(dj);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gj0[e] += (s2[1] / m.alpha - r_dotj / beta_o) * (hv[e] / beta_o);
                 }
                 double f = pl.logp0 - 0.5 * s2[0];
-                gn[0] = -gj0;                                   // density.py:552-560: dot(J_like, J_surrogate)
-                if (f_su) gn[0] = gn[0] / pdl(PD_SU_DIFF, 0);   // module.py:226
-                gn[0] = gn[0] * jac[0];                         // density.py:558
-                if (pl.has_prior) {   // the last module: like + log prior of the original-space inputs
-                    const double dx = lane < d ? xo[0] - pl.prior_mu[lane] : 0., pp = lane < d ? pl.prior_prec[lane] : 0.;
-                    f += pl.prior_c0 - 0.5 * wave_sum(pp * dx * dx);
-                    gn[0] += -(pp * dx) * jac[0];
+                double pr = 0.;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int dim = lane * E + e;
+                    gn[e] = -gj0[e];                                   // density.py:552-560: dot(J_like, J_surrogate)
+                    if (f_su) gn[e] = gn[e] / pdl(PD_SU_DIFF, e);      // module.py:226
+                    gn[e] = gn[e] * jac[e];                            // density.py:558
+                    if (pl.has_prior) {   // the last module: like + log prior of the original-space inputs
+                        const double dx = dim < d ? xo[e] - pl.prior_mu[dim] : 0., pp = dim < d ? pl.prior_prec[dim] : 0.;
+                        pr += pp * dx * dx;
+                        gn[e] += -(pp * dx) * jac[e];
+                    }
                 }
+                if (pl.has_prior) f += pl.prior_c0 - 0.5 * wave_sum(pr);
                 if (f_decay) {
                     f -= m.decay_gamma * bf_clip0(r_bd2 - m.decay_alpha2);
-                    if (r_bd2 > m.decay_alpha2) gn[0] -= 2. * m.decay_gamma * dgr[0];
+                    if (r_bd2 > m.decay_alpha2) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) gn[e] -= 2. * m.decay_gamma * dgr[e];
+                    }
                 }
                 if (f_tr) {
                     f += logdet;
-                    gn[0] += gj[0];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) gn[e] += gj[e];
                 }
                 logp_new = f;
                 have_eval = true;
@@ -2037,9 +2063,15 @@ template <int W, bool NUTS>
 static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
     const DevModel &m = ctx->model;
     const bool plain = sampler_plain(m) && !args.mat;
-    if (m.pld.on) {   // pipeline density: the FS = 8 instantiation (d <= 64, diagonal metric)
-        constexpr int WP = W <= 4 ? W : 1;   // (keeps W = 8 from instantiating it)
-        if (W > 4) return bf_set_error(BFHIP_ERR_UNSUPPORTED, "the pipeline density is implemented for d <= 64");
+    if (m.pld.on) {   // pipeline density: the FS = 8 / 9 / 10 instantiations
+        if constexpr (W == 8) {
+            // d = 128 (round 6): the eight-wave form with the run-time feature set, two dimensions per lane in phase P
+            if (sampler_lds_bytes(m, false, 8) > (size_t)160 * 1024)
+                return bf_set_error(BFHIP_ERR_UNSUPPORTED, "bfhip_sampler_run: this pipeline density needs %zu KB of LDS at d = %d (160 KB)",
+                                    sampler_lds_bytes(m, false, 8) / 1024, m.d);
+            return args.mat ? launch_sampler_t<8, NUTS, false, 9, 1>(ctx, args) : launch_sampler_t<8, NUTS, false, 9>(ctx, args);
+        }
+        constexpr int WP = W <= 4 ? W : 1;   // (keeps W = 8 from instantiating the other forms)
         if (args.mat) {   // full-rank metric: the eight-wave form with the run-time feature set (bfhip_metric.h streams the chain's own matrices)
             return launch_sampler_t<WP, NUTS, false, 9, 1>(ctx, args);
         }
