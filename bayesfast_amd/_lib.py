@@ -125,6 +125,10 @@ def lib():
                 'bayesfast_amd: the HIP extension %s is missing; build it with '
                 '`python -c "import __graft_entry__ as g; g.build()"` or `make -C bayesfast_amd/csrc`. '
                 'There is no CPU fallback.' % LIB_PATH)
+        # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so): it must be in the process BEFORE this library is, so that
+        # the library's libamdhip64 dependency binds to the one PyTorch uses -- two HIP runtimes in one process and the second finds
+        # "no ROCm-capable device" (seen when a test fixture loaded the library ahead of the first `import torch`)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)

@@ -389,13 +389,34 @@ def test_fit_ill_conditioned_designs_match_reference_lstsq():
         pm0._N_REFINE = 0
         pm0.fit(z[tag + '.x'], z[tag + '.y'])
         assert coef_err(pm0) > max(plain_floor, 20. * coef_err(pm)), (tag, coef_err(pm0), coef_err(pm))
-    # exactly rank deficient (duplicated input): gelsd returns the minimum-norm coefficients, the ridge solve another
-    # member of the solution set; on the data both give the same fitted values
+    # exactly rank deficient (input 3 duplicates input 0): gelsd returns the MINIMUM-NORM coefficients (modules/poly.py:570), and
+    # so does the device fit (round 6: truncated eigen-solve of the Gram matrix + refinement) -- the reference's own coefficients
+    # to 1e-8, not only its fitted values
     pr = PolyModel('quadratic', input_size=4, output_size=1, bound_options=dict(use_bound=False))
     with pytest.warns(RuntimeWarning, match='rank deficient'):
         pr.fit(z['rankdef.x'], z['rankdef.y'])
     f = np.array([pr.fun(x)[0] for x in z['rankdef.x'][:40]])
-    np.testing.assert_allclose(f, z['rankdef.f_fit'][:40], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f, z['rankdef.f_fit'][:40], rtol=0, atol=1e-9)
+    ref = rebuild_poly(z, 'rankdef.poly.')
+    scale = max(np.abs(np.asarray(r['coef'])).max() for r in ref['configs'])
+    for c, r in zip(pr.configs, ref['configs']):
+        np.testing.assert_allclose(_indep(c.order, c._coef), _indep(r['order'], r['coef']), rtol=0, atol=1e-8 * scale, err_msg=c.order)
+    # and against SciPy's gelsd on a fresh rank-deficient design with a weighted fit: a constant input AND a duplicated one
+    import scipy.linalg
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(60, 5))
+    x[:, 4] = x[:, 1]
+    x[:, 2] = 0.7
+    y = rng.normal(size=(60, 2))
+    w = rng.uniform(0.5, 2., size=60)
+    p2 = PolyModel('quadratic', input_size=5, output_size=2, bound_options=dict(use_bound=False))
+    with pytest.warns(RuntimeWarning, match='rank deficient'):
+        p2.fit(x, y, w=w)
+    from oracle import oracle as orc
+    Ad = np.concatenate([np.ones((60, 1)), x, orc.design_block('quadratic', x)], axis=1) * w[:, None]
+    sol = scipy.linalg.lstsq(Ad, y * w[:, None])[0]
+    got = np.stack([np.concatenate([p2.configs[0]._coef[o], _indep('quadratic', p2.configs[1]._coef)[o].ravel()]) for o in range(2)], 1)
+    np.testing.assert_allclose(got, sol, rtol=0, atol=1e-8 * np.abs(sol).max())
 
 
 def test_fit_rank_deficient_design_warns_and_regularises():
