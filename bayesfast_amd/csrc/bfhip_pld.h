@@ -45,7 +45,12 @@ struct PldLds {
     double *WX;    // [KS2 - 1][NS1][XS]  further partial-sum slots of W
     const unsigned long long *GT;   // [n_ent][DP]  gradient table (staged from pl.gtab once per launch)
     const unsigned *MONO;           // [PP]         monomial table (staged from pl.mono)
+    double *CL;    // [MP][PP + 1] row-major copy of C' (eight-chain forms, when it fits: both contractions read their A operands from it
+                   //              instead of streaming the fragments from L2 in every trip), or NULL
+    int CLS;       // its row stride (odd: the 16 rows a tile's lanes read fall into 16 different bank pairs)
 };
+
+__host__ __device__ inline size_t pld_cl_doubles(int MP, int PP) { return (size_t)MP * (PP + 1) + 1; }
 
 __host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent, int xs = PLD_XS) {
     const size_t ns1 = PP / 4, ns2 = MP / 4;
@@ -53,7 +58,7 @@ __host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS
 }
 
 #ifndef BF_HOST_EMU
-__device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw = 16) {
+__device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw = 16, bool with_cl = false) {
     PldLds L;
     L.CW = cw;
     L.XS = cw == 8 ? PLD_XS8 : PLD_XS;
@@ -67,6 +72,8 @@ __device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw 
     double *gt = L.WX + (size_t)(pl.KS2 - 1) * pl.NS1 * L.XS;
     L.GT = (const unsigned long long *)gt;
     L.MONO = (const unsigned *)(gt + (size_t)pl.n_ent * DP);
+    L.CLS = pl.PP + 1;
+    L.CL = with_cl ? gt + (size_t)pl.n_ent * DP + ((pl.PP / 2 + 1) & ~1) : nullptr;   // (behind the monomial words, 16-byte aligned)
     return L;
 }
 
@@ -80,6 +87,13 @@ __device__ inline void pld_stage(const PldDev &pl, const PldLds &L, int DP, int 
     for (int i = tid; i < pl.n_ent * DP; i += nth) gt[i] = pl.gtab[i];
     unsigned *mo = (unsigned *)L.MONO;
     for (int i = tid; i < pl.PP; i += nth) mo[i] = pl.mono[i];
+    if (L.CL) {   // CF[(t NS1 + s) 64 + l] = C'[16 t + (l & 15)][4 s + (l >> 4)]  ->  CL[row][col]
+        const int n = pl.NT1 * pl.NS1 * 64;
+        for (int i = tid; i < n; i += nth) {
+            const int l = i & 63, s2 = (i >> 6) % pl.NS1, t = (i >> 6) / pl.NS1;
+            L.CL[(size_t)(16 * t + (l & 15)) * L.CLS + 4 * s2 + (l >> 4)] = pl.CF[i];
+        }
+    }
 }
 
 // chain wave c (lane = dimension): the evaluation point, beta (0 inside the bound) and the monomials of the chain
@@ -304,23 +318,25 @@ __device__ inline void pld_gemm2(const PldDev &pl, const PldLds &L, int w, int n
 // ---------------------------------------------------------------------------------------------------------------------
 struct PldAcc8 { double lo, hi; };   // chains 0-3 and 4-7 of one row per lane
 
+// (ap0 / ap1: this lane's A operand of k-step 0; a_step: doubles from one k-step to the next -- 64 for fragments in global memory,
+// 4 or 4 CLS for the row-major copy in LDS, PldLds::CL)
 template <bool SAME_B>
-__device__ inline void pld_tile2_q8(const double *__restrict__ Af0, const double *Bf0, const double *__restrict__ Af1, const double *Bf1,
-                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1, int XS, int CW) {
+__device__ inline void pld_tile2_q8(const double *__restrict__ ap0, const double *Bf0, const double *__restrict__ ap1, const double *Bf1,
+                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1, int XS, int CW, int a_step) {
     // chunks of four k-steps (n_steps is a multiple of 4), the A fragments of TWO chunks ahead on their way while one runs: no
     // guard inside a chunk, so the loads are counted exactly (vmcnt) and stay in flight across the matrix instructions
     acc0 = PldAcc8{0., 0.};
     acc1 = PldAcc8{0., 0.};
     const int bo = CW * (lane >> 4) + (lane & 3);   // column n = lane & 3 of k = lane >> 4
-    const double *ap0 = Af0 + lane, *ap1 = Af1 + lane, *bp0 = Bf0 + bo, *bp1 = Bf1 + bo;
+    const double *bp0 = Bf0 + bo, *bp1 = Bf1 + bo;
     const int n_ch = n_steps >> 2;
     double xa[4], ya[4], xb[4], yb[4], xc[4], yc[4];
     auto fetch = [&](int c, double (&x)[4], double (&y)[4]) {
 #pragma unroll
 #ifdef PLD_KNOCK_A   // (tuning: the A fragments of ONE chunk over and over -- L1 hits -- to separate load latency from the rest)
-        for (int q = 0; q < 4; ++q) { x[q] = ap0[q * 64]; y[q] = ap1[q * 64]; }
+        for (int q = 0; q < 4; ++q) { x[q] = ap0[q * a_step]; y[q] = ap1[q * a_step]; }
 #else
-        for (int q = 0; q < 4; ++q) { x[q] = ap0[(4 * c + q) * 64]; y[q] = ap1[(4 * c + q) * 64]; }
+        for (int q = 0; q < 4; ++q) { x[q] = ap0[(size_t)(4 * c + q) * a_step]; y[q] = ap1[(size_t)(4 * c + q) * a_step]; }
 #endif
     };
     auto run = [&](int c, const double (&x)[4], const double (&y)[4]) {
@@ -404,7 +420,12 @@ __device__ inline void pld_gemm1_q8(const PldDev &pl, const PldLds &L, double al
     for (int t = w; t < pl.NT1; t += 2 * nwv) {
         const int t2 = t + nwv < pl.NT1 ? t + nwv : t;   // (an odd tile out is computed twice side by side: same result, same time)
         PldAcc8 a0, a1;
-        pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64, L.PHI, pl.NS1, lane, a0, a1, L.XS, L.CW);
+        if (L.CL)
+            pld_tile2_q8<true>(L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4), L.PHI,
+                               L.CL + (size_t)(16 * t2 + (lane & 15)) * L.CLS + (lane >> 4), L.PHI, pl.NS1, lane, a0, a1, L.XS, L.CW, 4);
+        else
+            pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64 + lane, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64 + lane, L.PHI, pl.NS1, lane, a0, a1,
+                               L.XS, L.CW, 64);
         pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
         if (t2 != t) pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
     }
@@ -416,12 +437,18 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
     const int i = lane >> 4, b = (lane >> 2) & 3, n = lane & 3;
     auto steps_of = [&](int job) { const int s0 = (job % pl.KS2) * pl.KPJ2; int ns = pl.NS2 - s0; return ns > pl.KPJ2 ? pl.KPJ2 : ns; };
     auto dest = [&](int job) { const int kp = job % pl.KS2; return (kp == 0 ? L.PHI : L.WX + (size_t)(kp - 1) * pl.NS1 * L.XS) + (size_t)4 * (job / pl.KS2) * L.XS; };
-    auto a_of = [&](int job) { return pl.CTF + ((size_t)(job / pl.KS2) * pl.NS2 + (job % pl.KS2) * pl.KPJ2) * 64; };
+    // (A operand of (row tile u, k-step s): C'^T[16 u + (l & 15)][4 s + (l >> 4)] = C'[4 s + (l >> 4)][16 u + (l & 15)])
+    const int a_step = L.CL ? 4 * L.CLS : 64;
+    auto a_of = [&](int job) -> const double * {
+        const int u = job / pl.KS2, s0 = (job % pl.KS2) * pl.KPJ2;
+        if (L.CL) return L.CL + (size_t)(4 * s0 + (lane >> 4)) * L.CLS + 16 * u + (lane & 15);
+        return pl.CTF + ((size_t)u * pl.NS2 + s0) * 64 + lane;
+    };
     auto b_of = [&](int job) { return L.RB + (size_t)(job % pl.KS2) * pl.KPJ2 * L.XS; };
     for (int job = w; job < n_job; job += 2 * nwv) {
         const int job2 = (job + nwv < n_job && steps_of(job + nwv) == steps_of(job)) ? job + nwv : job;
         PldAcc8 a0, a1;
-        pld_tile2_q8<false>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1, L.XS, L.CW);
+        pld_tile2_q8<false>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1, L.XS, L.CW, a_step);
         double *W0 = dest(job) + b * L.XS + n + L.CW * i;   // monomial p = 16 u + 4 b + i: p >> 2 = 4 u + b, p & 3 = i
         W0[0] = a0.lo;
         W0[4] = a0.hi;
@@ -432,7 +459,7 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
         } else if (job + nwv < n_job) {   // a partner with another number of k-steps (the last K part): on its own
             const int j3 = job + nwv;
             PldAcc8 c0, c1;
-            pld_tile2_q8<false>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1, L.XS, L.CW);
+            pld_tile2_q8<false>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1, L.XS, L.CW, a_step);
             double *W3 = dest(j3) + b * L.XS + n + L.CW * i;
             W3[0] = c0.lo;
             W3[4] = c0.hi;
@@ -478,18 +505,29 @@ __device__ inline void pld_sums(const PldDev &pl, const PldLds &L, int c, int la
     s_fr = lane < nwv ? L.RED[(lane * 2 + 1) * 16 + c] : 0.;
 }
 
-// ... and component `dim` of J_0^T r: the monomials that contain x_dim, each times its cofactor
+// ... and component `dim` of J_0^T r: the monomials that contain x_dim, each times its cofactor.  Four entries at a time (n_ent is a
+// multiple of 4: bfhip_pipeline_upload pads the table with entries that contribute +0): an entry is a chain of three dependent
+// LDS reads (table word -> W value and cofactors), and one at a time they were 4.2 k cycles of the DES trip
+// (profiles/r06b_trace_pld_des.log); the sum keeps its order.
 __device__ inline double pld_grad(const PldDev &pl, const PldLds &L, int DP, int c, int dim) {
     const double *xe = L.XE + c * (DP + 2);
     double g = 0.;
-    for (int i = 0; i < pl.n_ent; ++i) {
-        const unsigned long long en = L.GT[(size_t)i * DP + dim];
-        const unsigned eh = (unsigned)(en >> 32);
-        const int p = (int)(unsigned)en, off = (p >> 2) * L.XS + c + L.CW * (p & 3);
-        double wv = L.PHI[off];
-        for (int kp = 1; kp < pl.KS2; ++kp) wv += L.WX[(size_t)(kp - 1) * pl.NS1 * L.XS + off];
-        const double mult = (double)((eh >> 16) & 255u);
-        g += (mult * wv) * (xe[eh & 255u] * xe[(eh >> 8) & 255u]);
+    for (int i = 0; i < pl.n_ent; i += 4) {
+        unsigned long long en[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) en[q] = L.GT[(size_t)(i + q) * DP + dim];
+        double wv[4], cf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned eh = (unsigned)(en[q] >> 32);
+            const int p = (int)(unsigned)en[q], off = (p >> 2) * L.XS + c + L.CW * (p & 3);
+            wv[q] = L.PHI[off];
+            for (int kp = 1; kp < pl.KS2; ++kp) wv[q] += L.WX[(size_t)(kp - 1) * pl.NS1 * L.XS + off];
+            cf[q] = xe[eh & 255u] * xe[(eh >> 8) & 255u];
+            wv[q] = (double)((eh >> 16) & 255u) * wv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g += wv[q] * cf[q];
     }
     return g;
 }

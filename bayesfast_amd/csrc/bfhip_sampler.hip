@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BF_SAMPLER_WAVES(W, FULLM, FS) * 64) void bf_sample
     // pipeline density: its regions behind the matvec results (there are no cubic tables then)
     PldLds PL;
     if constexpr (PLD) {
-        PL = pld_lds(CUB, DP, m.pld, NWV == 8 ? 8 : 16);   // (the eight-chain forms: compact B-operand rows)
+        PL = pld_lds(CUB, DP, m.pld, NWV == 8 ? 8 : 16, NWV == 8 && a.pld_cl != 0);   // (the eight-chain forms: compact B-operand rows)
         pld_stage(m.pld, PL, DP, tid, NTH);
     }
     int mk2 = 0, mk3 = 0, pj2[E], pj3[E];
@@ -1870,11 +1870,18 @@ static int wave_layout_cpg(const bfhip_ctx *ctx, int n_chain, int nwv) {
 template <int W, bool NUTS, bool STAMPS, int FS, int FULLM = 0>
 static int launch_sampler_t(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = bf_sampler_kernel<W, NUTS, STAMPS, FS, FULLM>;
-    const size_t lds = sampler_lds_bytes(ctx->model, FS == 1, BF_SAMPLER_WAVES(W, FULLM, FS));
+    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS);
+    size_t lds = sampler_lds_bytes(ctx->model, FS == 1, NWV);
+    SamplerArgs args = args_in;
+    args.pld_cl = 0;
+    if (ctx->model.pld.on && NWV == 8 && !(bf_tune().pld_no_cl != 0)) {
+        // the eight-wave forms read the A operands of both contractions from a row-major copy of C' in LDS when it fits behind the
+        // rest (the DES shape: 52 KB), instead of streaming 2 x 51 KB of fragments from L2 in every trip -- the same numbers
+        const size_t with_cl = lds + pld_cl_doubles(ctx->model.pld.MP, ctx->model.pld.PP) * sizeof(double) + 16;
+        if (with_cl <= (size_t)160 * 1024) { lds = with_cl; args.pld_cl = 1; }
+    }
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    constexpr int NWV = BF_SAMPLER_WAVES(W, FULLM, FS);
-    SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, NWV);
     args.cub_lds = sampler_cubic_lds(ctx->model, FS == 1) ? 1 : 0;
     args.cub_loops = bf_tune().cubic_loops;

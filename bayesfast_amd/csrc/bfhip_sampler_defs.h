@@ -8,6 +8,7 @@ struct SamplerArgs {
     int cpg;       // wave-per-chain kernels: chains per workgroup (0: one per wave), bfhip_sampler.hip: wave_layout_cpg
     int no_quad;   // bf_sampler_kernel: 16-column tiles even with at most four chains in the workgroup (bfhip_debug_set("no_quad"): tests)
     int cub_lds;   // bf_sampler_kernel: the cubic coefficient tables are staged in LDS (sampler_cubic_lds)
+    int pld_cl;    // bf_sampler_kernel, pipeline density, eight-wave forms: a row-major copy of C' is staged in LDS (PldLds::CL)
     int tail_max;  // plain kernel: at most this many evaluating chains of a group take the VALU matvec (0: never)
     int ks, gbn;  // K-split of the matvec jobs (so that all 16 waves get one) and the number of result slots
     uint64_t *rng;
