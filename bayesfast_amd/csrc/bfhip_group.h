@@ -36,11 +36,17 @@
 // in LDS next to the tree's ends, proposal and p_sum, and deeper levels in the context's global scratch.
 //
 // FS (feature set): 1 = linear + quadratic configs with the bound; bit 1 (2) = decay penalty (density.py:740-746);
-// bit 2 (4) = constraint transform (density.py:92-140,747-750).
+// bit 2 (4) = constraint transform (density.py:92-140,747-750); bit 3 (8, round 6) = the PIPELINE DENSITY (bfhip_pld.h: multi-output
+// surrogate + Gaussian likelihood + prior) instead of the single-output polynomial: the wave-per-chain kernel spends a
+// wave per chain on the tree logic between two evaluations and 28 k cycles on a trip of EIGHT chains at the DES shape
+// (profiles/r06b_trace_pld_des.log); here the 16 chains of a group share every instruction of it.  The evaluation is always "late"
+// (the gradient needs the contractions' result): phase A | B1 | the bound's tiles, sums | B2 | evaluation points | P0 | monomials |
+// P1 | F = C' Phi | P2 | W = C'^T r | P3 | gradient gather, second half step, U-turn sums | B3 | the state machine as before.
 #pragma once
 #include "bfhip_lane.h"
 #include "bfhip_sampler_defs.h"
 #include "bfhip_oob.h"
+#include "bfhip_pld.h"
 
 #define BF_DBL_MAX 1.7976931348623157e308
 
@@ -114,7 +120,7 @@ BF_DEV void bf_to_original_g(double x, int kind, double lo, double rg, double &x
 
 template <int W, bool NUTS, int FS>
 BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) {
-    constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0;
+    constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0, PLDG = (FS & 8) != 0;
     using G = GroupGeo<W>;
     constexpr int DP = G::DP, NS = G::NS, KS = G::KS, NMAT = DEC ? 3 : 2, LSS = G::LSS;
     double *XB = lds;                          // [NMAT][NS][64]  B operands: x | x - mu | x_orig - mu_decay
@@ -131,20 +137,36 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     const int nw = a.cfg.n_warmup;
     const double bound_thr = m.use_bound ? m.alpha * m.alpha * (1. - 1e-9) : __builtin_inf();
     const double decay_thr = m.decay_alpha2 * (1. - 1e-9);
+#ifndef BF_HOST_EMU
+    // pipeline density: its LDS block behind the group's own regions (sixteen-chain layout: the chains are the 16 columns)
+    PldLds PL;
+    if constexpr (PLDG) {
+        PL = pld_lds(lds + ((G::lds_doubles(NMAT) + 1) & ~(size_t)1), DP, m.pld, 16);
+        pld_stage(m.pld, PL, DP, tid, 64 * W);
+    }
+#endif
 
     // ---- constants: A operands of this wave's row tile, per-dimension table rows ----
     double afS[NS], afH[NS], afD[DEC ? NS : 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        afS[s] = m.Sf[(j * NS + s) * 64 + lane];
-        afH[s] = m.Hf[(j * NS + s) * 64 + lane];
+        afS[s] = PLDG ? 0. : m.Sf[(j * NS + s) * 64 + lane];
+        afH[s] = (PLDG && !m.use_bound) ? 0. : m.Hf[(j * NS + s) * 64 + lane];
         if constexpr (DEC) afD[s] = m.Hdf[(j * NS + s) * 64 + lane];
     }
     double c_lin[4], c_mu[4], c_smu[4], c_hd[4], c_lo[TR ? 4 : 1], c_rg[TR ? 4 : 1], c_dmu[DEC ? 4 : 1], c_hdd[DEC ? 4 : 1];
     int c_kind[TR ? 4 : 1];
+    double c_sulo[PLDG ? 4 : 1], c_sudf[PLDG ? 4 : 1], c_pmu[PLDG ? 4 : 1], c_ppr[PLDG ? 4 : 1];   // surrogate input scaling, prior
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int dim = dbase + 4 * r;
+        if constexpr (PLDG) {
+            const bool su = m.has_su && dim < d;
+            c_sulo[r] = su ? m.pd[PD_SU_LO * DP + dim] : 0.;
+            c_sudf[r] = su ? m.pd[PD_SU_DIFF * DP + dim] : 1.;
+            c_pmu[r] = (m.pld.has_prior && dim < d) ? m.pld.prior_mu[dim] : 0.;
+            c_ppr[r] = (m.pld.has_prior && dim < d) ? m.pld.prior_prec[dim] : 0.;
+        }
         c_lin[r] = m.pd[PD_LIN * DP + dim];
         c_mu[r] = m.pd[PD_MU * DP + dim];
         c_smu[r] = m.pd[PD_SMU * DP + dim];
@@ -420,8 +442,9 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
             xo[r] = xs[r];
+            if constexpr (PLDG) { if (m.has_su) xs[r] = (xs[r] - c_sulo[r]) / c_sudf[r]; }   // the surrogate's input (module.py:76-83)
             xev[r] = xs[r];
-            XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
+            if constexpr (!PLDG) XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
             XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
             if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
         }
@@ -429,7 +452,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // group the test of modules/poly.py:467-469 is decided (inside) without the H (x - mu) tiles -- half of the trip's
         // MFMAs.  The partial |x - mu|^2 rides through the barrier the operands need anyway; the outcome is the one the
         // full computation has (margin 1e-9 against its rounding), so results do not depend on whether a group skips.
-        {
+        if constexpr (!PLDG) {
             double t_r2[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -461,19 +484,23 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             bf_acc4 aS0 = bf_acc4_zero(), aS1 = bf_acc4_zero(), aH0 = bf_acc4_zero(), aH1 = bf_acc4_zero();
             bf_acc4 aD0 = bf_acc4_zero(), aD1 = bf_acc4_zero();
             constexpr int KH = NS / KS;
+            if constexpr (!PLDG) {
 #pragma unroll
-            for (int s = 0; s < KH; ++s) {
-                aS0 = bf_mfma(afS[s], XB[(0 * NS + s) * 64 + lane], aS0);
-                if constexpr (KS == 2) aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
+                for (int s = 0; s < KH; ++s) {
+                    aS0 = bf_mfma(afS[s], XB[(0 * NS + s) * 64 + lane], aS0);
+                    if constexpr (KS == 2) aS1 = bf_mfma(afS[KH + s], XB[(0 * NS + KH + s) * 64 + lane], aS1);
+                }
             }
-            double r2 = PB[c], r2d = DEC ? PB[W * 16 + c] : 0.;  // (read behind the S tiles: the matrix pipe is busy with them)
+            double r2 = PLDG ? 0. : PB[c], r2d = (DEC && !PLDG) ? PB[W * 16 + c] : 0.;  // (read behind the S tiles: the matrix pipe is busy with them)
+            if constexpr (!PLDG) {
 #pragma unroll
-            for (int w2 = 1; w2 < W; ++w2) {
-                r2 += PB[w2 * 16 + c];
-                if constexpr (DEC) r2d += PB[(W + w2) * 16 + c];
+                for (int w2 = 1; w2 < W; ++w2) {
+                    r2 += PB[w2 * 16 + c];
+                    if constexpr (DEC) r2d += PB[(W + w2) * 16 + c];
+                }
             }
-            const bool inside = !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven)
-            skipH = !bf_any(!inside);
+            const bool inside = !PLDG && !a.no_bound_proof && m.lam_max * r2 < bound_thr;  // (NaN: not proven; the pipeline form has no proof)
+            skipH = PLDG ? !m.use_bound : !bf_any(!inside);
             n_trip += 1;
             n_trip_h += skipH ? 0 : 1;
             if (!skipH) {
@@ -484,7 +511,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
             if constexpr (DEC) {
-                const bool calm = !a.no_bound_proof && m.lam_max_d * r2d < decay_thr;
+                const bool calm = !PLDG && !a.no_bound_proof && m.lam_max_d * r2d < decay_thr;
                 ranD = bf_any(!calm);
                 if (ranD) {
 #pragma unroll
@@ -506,8 +533,30 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         // ================= phase C: the evaluation's sums, and the U-turn sums of the leaf it completes =================
         double ge[4], pn[4];
         const double dt_c = 0.5 * eps_t;
-        const bool early = !skip_early;   // the kinetic energy and the U-turn sums ride in this exchange (same in all waves)
-        {
+        const bool early = PLDG ? false : !skip_early;   // the kinetic energy and the U-turn sums ride in this exchange (same in all waves)
+        if constexpr (PLDG) {
+            // the sums that do not need the contractions: the bound's and the decay term's radii, the log-Jacobian, the prior
+            double t_b2[4], t_bd2[4], t_pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                t_b2[r] = (xs[r] - c_mu[r]) * hv[r];
+                t_bd2[r] = DEC ? (xo[r] - c_dmu[r]) * dgr[r] : 0.;
+                const double dx = ev ? xo[r] - c_pmu[r] : 0.;
+                t_pr[r] = c_ppr[r] * dx * dx;
+            }
+            if (!skipH) post(G::V_B2, sum4(t_b2));
+            if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
+            if (m.pld.has_prior) post(G::V_VAL, sum4(t_pr));
+            if constexpr (TR) {
+                double l4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) l4[r] = ev ? bf_log(ldet[r]) : 0.;
+                post(G::V_LOGDET, sum4(l4));
+            }
+            if (bf_any(need_E0)) post(G::V_KIN0, kin0_part);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ge[r] = 0.; pn[r] = p[r]; }
+        } else {
             double gn[4], t_val[4], t_b2[4], t_bd2[4], t_kin[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -656,7 +705,9 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         double s_kin = 0., s_val = 0., s_b2 = 0.;
         bool late_sync_done = false;
         double sv_k0[1] = {0.}, sv_m0[2] = {1., 1.}, sv_l1[6] = {1., 1., 1., 1., 1., 1.}, sv_x[6] = {1., 1., 1., 1., 1., 1.};
-        if (skipH) {   // inside the bound, proven
+        if constexpr (PLDG) {
+            // (the pipeline form reads its sums below)
+        } else if (skipH) {   // inside the bound, proven
             if (early) {
                 double sv_2[2];
                 rd_n(G::V_KIN, sv_2);
@@ -685,9 +736,97 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         bool fin = false, late = false, dec_on = false;
         double logp_new = 0., kin = 0.;
         double f = (m.c0 + s_val) + 0.;
+#ifndef BF_HOST_EMU
+        if constexpr (PLDG) {
+            // ================= the pipeline density (bfhip_pld.h; core/density.py:527-560, modules/poly.py:430-503) =================
+            const PldDev &pl = m.pld;
+            const double r_b2 = skipH ? 0. : rd(G::V_B2);
+            const double r_pr = pl.has_prior ? rd(G::V_VAL) : 0.;
+            double r_bd2 = 0.;
+            if constexpr (DEC) r_bd2 = rd(G::V_BD2);
+            // the bound is decided FIRST, so a point outside the ellipsoid is evaluated once, at its projection (poly.py:480-503)
+            double beta_o = 0.;
+            if (!skipH && !(r_b2 < m.alpha * m.alpha * (1. - 1e-12))) {   // :467-469
+                const double b = bf_sqrt(r_b2);
+                if (b > m.alpha) beta_o = b;
+            }
+            {
+                double *xe = PL.XE + c * (DP + 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dim = dbase + 4 * r;
+                    const double x_ev = beta_o > 0. ? (m.alpha * xs[r] + (beta_o - m.alpha) * c_mu[r]) / beta_o : xs[r];   // :482
+                    xe[dim] = (ev && dim < d) ? x_ev : 0.;
+                }
+                if (writer) {
+                    xe[DP] = 1.;
+                    xe[DP + 1] = 0.;
+                    PL.CH[c] = ev ? beta_o : 0.;
+                }
+            }
+            bf_sync();  // P0: the evaluation points of the 16 chains
+            for (int idx = tid; idx < pl.PP * 16; idx += 64 * W) {   // the monomials of every chain: B operand of GEMM1
+                const int pm = idx >> 4, cc = idx & 15;
+                const unsigned mo = PL.MONO[pm];
+                const double *xe2 = PL.XE + cc * (DP + 2);
+                PL.PHI[(pm >> 2) * PLD_XS + cc + 16 * (pm & 3)] = (xe2[mo & 255u] * xe2[(mo >> 8) & 255u]) * xe2[(mo >> 16) & 255u];
+            }
+            bf_sync();  // P1
+            pld_gemm1(pl, PL, m.alpha, j, W, lane);
+            bf_sync();  // P2: residuals
+            pld_gemm2(pl, PL, j, W, lane);
+            bf_sync();  // P3: W = C'^T r
+            double s_rr = 0., s_fr = 0.;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) {
+                s_rr += PL.RED[(w2 * 2 + 0) * 16 + c];
+                s_fr += PL.RED[(w2 * 2 + 1) * 16 + c];
+            }
+            double gj0[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gj0[r] = pld_grad(pl, PL, DP, c, dbase + 4 * r);   // (J_0^T r) of this lane's dimensions
+            if (beta_o > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
+                const double b = (beta_o - m.alpha) / m.alpha;
+                s_rr += b * (b * pl.k_ff + 2. * pl.k_fy);
+                s_fr += b * pl.k_ff + pl.k_fy;
+            }
+            if (bf_any(ev && beta_o > 0.)) {   // modules/poly.py:494-496, contracted with r: one more sum over the dimensions
+                double t_dj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t_dj[r] = gj0[r] * (xs[r] - c_mu[r]);
+                post(G::V_VAL, sum4(t_dj));
+                bf_sync();
+                const double r_dotj = rd(G::V_VAL);
+                if (beta_o > 0.) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gj0[r] += (s_fr / m.alpha - r_dotj / beta_o) * (hv[r] / beta_o);
+                }
+            }
+            f = pl.logp0 - 0.5 * s_rr;
+            if (pl.has_prior) f += pl.prior_c0 - 0.5 * r_pr;   // the last module: like + log prior of the original-space inputs
+            if constexpr (DEC) {   // density.py:740-746
+                const double ex = r_bd2 - m.decay_alpha2;
+                f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+                dec_on = r_bd2 > m.decay_alpha2;
+            }
+            if constexpr (TR) f += rd(G::V_LOGDET);   // :748
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double t = -gj0[r];                         // density.py:552-560: dot(J_like, J_surrogate)
+                if (m.has_su) t = t / c_sudf[r];            // module.py:226
+                t = t * jac[r];                             // density.py:558
+                if (pl.has_prior) t += -(c_ppr[r] * (xo[r] - c_pmu[r])) * jac[r];
+                if constexpr (DEC) { if (dec_on) t -= 2. * m.decay_gamma * dgr[r]; }
+                if constexpr (TR) t += gj[r];               // :749-750
+                ge[r] = t;
+                pn[r] = bf_fma(dt_c, ge[r], p[r]);          // integration.py:90
+            }
+            late = ev;
+        }
+#endif
         // (the common trip -- every chain proven inside the bound, no decay term -- skips the rare branches as one: per-lane
         // branches cost a round trip through the scalar unit each, with one wave per SIMD nothing hides it)
-        const bool rare = DEC || !skipH;   // wave-uniform
+        const bool rare = !PLDG && (DEC || !skipH);   // wave-uniform
         if (rare) {
             // beta = sqrt(b2) is only needed outside the ellipsoid; the test beta > alpha (poly.py:467-469) is decided on the
             // squares whenever b2 is not within rounding distance of alpha^2
@@ -794,7 +933,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 late_sync_done = any_oob;
             }
         }
-        if constexpr (TR) f += rd(G::V_LOGDET);
+        if constexpr (TR && !PLDG) f += rd(G::V_LOGDET);
         if (ev) {
             fin = true;
             logp_new = f;

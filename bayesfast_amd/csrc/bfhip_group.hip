@@ -19,7 +19,11 @@ __global__ __launch_bounds__(64 * W) void bf_group_kernel(DevModel m, SamplerArg
 template <int W, bool NUTS, int FS>
 static int launch_t(bfhip_ctx *ctx, const SamplerArgs &args) {
     auto k = bf_group_kernel<W, NUTS, FS>;
-    const size_t lds = GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
+    size_t lds = GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
+    if (FS & 8) {   // the pipeline density's block behind the group's own regions (sixteen-chain layout)
+        const PldDev &pl = ctx->model.pld;
+        lds = (((GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) + 1) & ~(size_t)1) + pld_lds_doubles(16 * W, pl.MP, pl.PP, pl.KS2, pl.n_ent, PLD_XS)) * sizeof(double);
+    }
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int groups = (args.n_chain + 15) / 16;
@@ -40,6 +44,8 @@ static int launch_w(bfhip_ctx *ctx, const SamplerArgs &args, bool nuts, int fs) 
         case 3: return launch_t<W, true, 3>(ctx, args);
         case 5: return launch_t<W, true, 5>(ctx, args);
         case 7: return launch_t<W, true, 7>(ctx, args);
+        case 8: return launch_t<W, true, 8>(ctx, args);     // the pipeline density (bfhip_group.h: PLDG)
+        case 12: return launch_t<W, true, 12>(ctx, args);   // ... behind the constraint transform
         }
     } else {
         switch (fs) {
@@ -99,7 +105,18 @@ int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     return 0;
 }
 
+// LDS bytes of the group kernel on the pipeline density (0: not a pipeline density)
+static size_t group_pld_lds_bytes(const DevModel &m) {
+    if (!m.pld.on) return 0;
+    const int W = m.DP / 16;
+    const size_t own = W == 4 ? GroupGeo<4>::lds_doubles(2) : (W == 2 ? GroupGeo<2>::lds_doubles(2) : GroupGeo<1>::lds_doubles(2));
+    return (((own + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent, PLD_XS)) * sizeof(double);
+}
+
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {
+    if (m.pld.on)   // the pipeline density (round 6): NUTS, no decay term, the sixteen-chain LDS layout has to fit beside the tree vectors
+        return m.DP <= 64 && args.cfg.sampler == 0 && !m.use_decay && !args.mat && !m.pld.only8 && !(bf_tune().no_group_pld != 0) &&
+               group_pld_lds_bytes(m) <= (size_t)160 * 1024;
     return m.DP <= 64 && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !args.mat;
 }
 
@@ -117,7 +134,7 @@ int bf_launch_group(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     args.no_bound_proof = bf_tune().no_bound_proof;
     const DevModel &m = ctx->model;
     const bool nuts = args.cfg.sampler == 0;
-    const int fs = 1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0);
+    const int fs = m.pld.on ? (8 | (m.has_transform ? 4 : 0)) : (1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0));
     switch (m.DP / 16) {
 #ifndef BF_ONLY_HEADLINE
     case 1: return launch_w<1>(ctx, args, nuts, fs);

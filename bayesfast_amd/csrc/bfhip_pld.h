@@ -318,11 +318,13 @@ __device__ inline void pld_gemm2(const PldDev &pl, const PldLds &L, int w, int n
 // ---------------------------------------------------------------------------------------------------------------------
 struct PldAcc8 { double lo, hi; };   // chains 0-3 and 4-7 of one row per lane
 
-// (ap0 / ap1: this lane's A operand of k-step 0; a_step: doubles from one k-step to the next -- 64 for fragments in global memory,
-// 4 or 4 CLS for the row-major copy in LDS, PldLds::CL)
-template <bool SAME_B>
+// (ap0 / ap1: this lane's A operand of k-step 0.  ASTEP: doubles from one k-step to the next, a compile-time constant where there
+// is one -- 64 for fragments in global memory, 4 for GEMM1 on the row-major LDS copy (PldLds::CL) -- so that the loads of a chunk
+// keep immediate offsets; 0: run time (a_step: GEMM2 on the copy walks rows, 4 CLS doubles apart).  The chunks are fetched in
+// order, so the running pointers advance by one chunk per fetch.)
+template <bool SAME_B, int ASTEP>
 __device__ inline void pld_tile2_q8(const double *__restrict__ ap0, const double *Bf0, const double *__restrict__ ap1, const double *Bf1,
-                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1, int XS, int CW, int a_step) {
+                                    int n_steps, int lane, PldAcc8 &acc0, PldAcc8 &acc1, int XS, int CW, int a_step = 0) {
     // chunks of four k-steps (n_steps is a multiple of 4), the A fragments of TWO chunks ahead on their way while one runs: no
     // guard inside a chunk, so the loads are counted exactly (vmcnt) and stay in flight across the matrix instructions
     acc0 = PldAcc8{0., 0.};
@@ -330,13 +332,15 @@ __device__ inline void pld_tile2_q8(const double *__restrict__ ap0, const double
     const int bo = CW * (lane >> 4) + (lane & 3);   // column n = lane & 3 of k = lane >> 4
     const double *bp0 = Bf0 + bo, *bp1 = Bf1 + bo;
     const int n_ch = n_steps >> 2;
+    const int st = ASTEP ? ASTEP : a_step;
     double xa[4], ya[4], xb[4], yb[4], xc[4], yc[4];
-    auto fetch = [&](int c, double (&x)[4], double (&y)[4]) {
+    const double *fa0 = ap0, *fa1 = ap1;
+    auto fetch = [&](double (&x)[4], double (&y)[4]) {
 #pragma unroll
-#ifdef PLD_KNOCK_A   // (tuning: the A fragments of ONE chunk over and over -- L1 hits -- to separate load latency from the rest)
-        for (int q = 0; q < 4; ++q) { x[q] = ap0[q * a_step]; y[q] = ap1[q * a_step]; }
-#else
-        for (int q = 0; q < 4; ++q) { x[q] = ap0[(size_t)(4 * c + q) * a_step]; y[q] = ap1[(size_t)(4 * c + q) * a_step]; }
+        for (int q = 0; q < 4; ++q) { x[q] = fa0[q * st]; y[q] = fa1[q * st]; }
+#ifndef PLD_KNOCK_A   // (tuning: the A fragments of ONE chunk over and over -- L1 hits -- to separate load latency from the rest)
+        fa0 += 4 * st;
+        fa1 += 4 * st;
 #endif
     };
     auto run = [&](int c, const double (&x)[4], const double (&y)[4]) {
@@ -356,19 +360,19 @@ __device__ inline void pld_tile2_q8(const double *__restrict__ ap0, const double
         }
     };
     if (n_ch <= 0) return;
-    fetch(0, xa, ya);
-    if (n_ch > 1) fetch(1, xb, yb);
+    fetch(xa, ya);
+    if (n_ch > 1) fetch(xb, yb);
     // (three buffers taken in turn by position in the loop body: rotating them by register moves would make every move wait
     // for the loads just issued)
     for (int c = 0; c < n_ch; c += 3) {
-        if (c + 2 < n_ch) fetch(c + 2, xc, yc);
+        if (c + 2 < n_ch) fetch(xc, yc);
         run(c, xa, ya);
         if (c + 1 < n_ch) {
-            if (c + 3 < n_ch) fetch(c + 3, xa, ya);
+            if (c + 3 < n_ch) fetch(xa, ya);
             run(c + 1, xb, yb);
         }
         if (c + 2 < n_ch) {
-            if (c + 4 < n_ch) fetch(c + 4, xb, yb);
+            if (c + 4 < n_ch) fetch(xb, yb);
             run(c + 2, xc, yc);
         }
     }
@@ -421,11 +425,11 @@ __device__ inline void pld_gemm1_q8(const PldDev &pl, const PldLds &L, double al
         const int t2 = t + nwv < pl.NT1 ? t + nwv : t;   // (an odd tile out is computed twice side by side: same result, same time)
         PldAcc8 a0, a1;
         if (L.CL)
-            pld_tile2_q8<true>(L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4), L.PHI,
-                               L.CL + (size_t)(16 * t2 + (lane & 15)) * L.CLS + (lane >> 4), L.PHI, pl.NS1, lane, a0, a1, L.XS, L.CW, 4);
+            pld_tile2_q8<true, 4>(L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4), L.PHI,
+                                  L.CL + (size_t)(16 * t2 + (lane & 15)) * L.CLS + (lane >> 4), L.PHI, pl.NS1, lane, a0, a1, L.XS, L.CW);
         else
-            pld_tile2_q8<true>(pl.CF + (size_t)t * pl.NS1 * 64 + lane, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64 + lane, L.PHI, pl.NS1, lane, a0, a1,
-                               L.XS, L.CW, 64);
+            pld_tile2_q8<true, 64>(pl.CF + (size_t)t * pl.NS1 * 64 + lane, L.PHI, pl.CF + (size_t)t2 * pl.NS1 * 64 + lane, L.PHI, pl.NS1, lane, a0, a1,
+                                   L.XS, L.CW);
         pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
         if (t2 != t) pld_epilogue1_q8(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
     }
@@ -448,7 +452,8 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
     for (int job = w; job < n_job; job += 2 * nwv) {
         const int job2 = (job + nwv < n_job && steps_of(job + nwv) == steps_of(job)) ? job + nwv : job;
         PldAcc8 a0, a1;
-        pld_tile2_q8<false>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1, L.XS, L.CW, a_step);
+        if (L.CL) pld_tile2_q8<false, 0>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1, L.XS, L.CW, a_step);
+        else pld_tile2_q8<false, 64>(a_of(job), b_of(job), a_of(job2), b_of(job2), steps_of(job), lane, a0, a1, L.XS, L.CW);
         double *W0 = dest(job) + b * L.XS + n + L.CW * i;   // monomial p = 16 u + 4 b + i: p >> 2 = 4 u + b, p & 3 = i
         W0[0] = a0.lo;
         W0[4] = a0.hi;
@@ -459,7 +464,8 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
         } else if (job + nwv < n_job) {   // a partner with another number of k-steps (the last K part): on its own
             const int j3 = job + nwv;
             PldAcc8 c0, c1;
-            pld_tile2_q8<false>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1, L.XS, L.CW, a_step);
+            if (L.CL) pld_tile2_q8<false, 0>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1, L.XS, L.CW, a_step);
+            else pld_tile2_q8<false, 64>(a_of(j3), b_of(j3), a_of(j3), b_of(j3), steps_of(j3), lane, c0, c1, L.XS, L.CW);
             double *W3 = dest(j3) + b * L.XS + n + L.CW * i;
             W3[0] = c0.lo;
             W3[4] = c0.hi;
@@ -505,29 +511,20 @@ __device__ inline void pld_sums(const PldDev &pl, const PldLds &L, int c, int la
     s_fr = lane < nwv ? L.RED[(lane * 2 + 1) * 16 + c] : 0.;
 }
 
-// ... and component `dim` of J_0^T r: the monomials that contain x_dim, each times its cofactor.  Four entries at a time (n_ent is a
-// multiple of 4: bfhip_pipeline_upload pads the table with entries that contribute +0): an entry is a chain of three dependent
-// LDS reads (table word -> W value and cofactors), and one at a time they were 4.2 k cycles of the DES trip
-// (profiles/r06b_trace_pld_des.log); the sum keeps its order.
+// ... and component `dim` of J_0^T r: the monomials that contain x_dim, each times its cofactor
+// (round 6, measured and dropped: four entries at a time -- the table padded to a multiple of four -- to overlap the three
+// dependent LDS reads of an entry: DES shape 1.46 -> 1.02 x 10^8, the register arrays cost more than the latency they hide)
 __device__ inline double pld_grad(const PldDev &pl, const PldLds &L, int DP, int c, int dim) {
     const double *xe = L.XE + c * (DP + 2);
     double g = 0.;
-    for (int i = 0; i < pl.n_ent; i += 4) {
-        unsigned long long en[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) en[q] = L.GT[(size_t)(i + q) * DP + dim];
-        double wv[4], cf[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned eh = (unsigned)(en[q] >> 32);
-            const int p = (int)(unsigned)en[q], off = (p >> 2) * L.XS + c + L.CW * (p & 3);
-            wv[q] = L.PHI[off];
-            for (int kp = 1; kp < pl.KS2; ++kp) wv[q] += L.WX[(size_t)(kp - 1) * pl.NS1 * L.XS + off];
-            cf[q] = xe[eh & 255u] * xe[(eh >> 8) & 255u];
-            wv[q] = (double)((eh >> 16) & 255u) * wv[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g += wv[q] * cf[q];
+    for (int i = 0; i < pl.n_ent; ++i) {
+        const unsigned long long en = L.GT[(size_t)i * DP + dim];
+        const unsigned eh = (unsigned)(en >> 32);
+        const int p = (int)(unsigned)en, off = (p >> 2) * L.XS + c + L.CW * (p & 3);
+        double wv = L.PHI[off];
+        for (int kp = 1; kp < pl.KS2; ++kp) wv += L.WX[(size_t)(kp - 1) * pl.NS1 * L.XS + off];
+        const double mult = (double)((eh >> 16) & 255u);
+        g += (mult * wv) * (xe[eh & 255u] * xe[(eh >> 8) & 255u]);
     }
     return g;
 }

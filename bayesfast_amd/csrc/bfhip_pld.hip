@@ -225,7 +225,6 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     }
     size_t n_ent = 0;
     for (int j = 0; j < DP; ++j) n_ent = per_dim[j].size() > n_ent ? per_dim[j].size() : n_ent;
-    n_ent = (n_ent + 3) / 4 * 4;   // (pld_grad takes four entries at a time; the padding entries contribute +0)
     const unsigned long long pad_ent = (unsigned long long)0u | ((unsigned long long)((unsigned)ZERO | ((unsigned)ZERO << 8) | (1u << 16)) << 32);
     std::vector<unsigned long long> gtab(n_ent * DP, pad_ent);
     for (int j = 0; j < DP; ++j)

@@ -2204,7 +2204,7 @@ extern "C" int bfhip_sampler_run(bfhip_ctx *ctx, const bfhip_sampler_config *cfg
     const bool want_group = cfg->chain_layout == 1 || cfg->chain_layout == 3 || (cfg->chain_layout == 0 && !nuts);
     if (want_group && !(bf_tune().no_group != 0) && !(bf_tune().no_pipe != 0) && !(bf_tune().no_plain != 0) && !args.stamps && bf_group_supports(m, args)) {
         snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_group_kernel<%d, %s, %d>", W, nuts ? "true" : "false",
-                 1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0));
+                 m.pld.on ? (8 | (m.has_transform ? 4 : 0)) : (1 | (m.use_decay ? 2 : 0) | (m.has_transform ? 4 : 0)));
         return bf_launch_group(ctx, args);
     }
     {
