@@ -765,11 +765,22 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
             bf_sync();  // P0: the evaluation points of the 16 chains
-            for (int idx = tid; idx < pl.PP * 16; idx += 64 * W) {   // the monomials of every chain: B operand of GEMM1
-                const int pm = idx >> 4, cc = idx & 15;
-                const unsigned mo = PL.MONO[pm];
-                const double *xe2 = PL.XE + cc * (DP + 2);
-                PL.PHI[(pm >> 2) * PLD_XS + cc + 16 * (pm & 3)] = (xe2[mo & 255u] * xe2[(mo >> 8) & 255u]) * xe2[(mo >> 16) & 255u];
+            {   // the monomials of every chain, the B operand of GEMM1: lane (c, gq) of wave j takes monomials 4 j + gq, + 4 W, ... of
+                // chain c, four at a time (the table word and the three factors of a monomial are dependent LDS reads)
+                const double *xe2 = PL.XE + c * (DP + 2);
+                for (int p0 = 4 * j + gq; p0 < pl.PP; p0 += 16 * W) {
+                    unsigned mo[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) mo[u] = PL.MONO[p0 + 4 * W * u < pl.PP ? p0 + 4 * W * u : p0];
+                    double v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = (xe2[mo[u] & 255u] * xe2[(mo[u] >> 8) & 255u]) * xe2[(mo[u] >> 16) & 255u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int pm = p0 + 4 * W * u;
+                        if (pm < pl.PP) PL.PHI[(pm >> 2) * PLD_XS + c + 16 * (pm & 3)] = v[u];
+                    }
+                }
             }
             bf_sync();  // P1
             pld_gemm1(pl, PL, m.alpha, j, W, lane);
@@ -782,9 +793,29 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 s_rr += PL.RED[(w2 * 2 + 0) * 16 + c];
                 s_fr += PL.RED[(w2 * 2 + 1) * 16 + c];
             }
-            double gj0[4];
+            // (J_0^T r) of this lane's four dimensions: pld_grad's sum, entry by entry, the four dimensions side by side -- an entry is
+            // a chain of three dependent LDS reads, and four gathers one after the other were a third of the trip
+            double gj0[4] = {0., 0., 0., 0.};
+            {
+                const double *xe = PL.XE + c * (DP + 2);
+                for (int i = 0; i < pl.n_ent; ++i) {
+                    unsigned long long en[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gj0[r] = pld_grad(pl, PL, DP, c, dbase + 4 * r);   // (J_0^T r) of this lane's dimensions
+                    for (int r = 0; r < 4; ++r) en[r] = PL.GT[(size_t)i * DP + dbase + 4 * r];
+                    double wv[4], cf[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned eh = (unsigned)(en[r] >> 32);
+                        const int pm = (int)(unsigned)en[r], off = (pm >> 2) * PLD_XS + c + 16 * (pm & 3);
+                        wv[r] = PL.PHI[off];
+                        for (int kp = 1; kp < pl.KS2; ++kp) wv[r] += PL.WX[(size_t)(kp - 1) * pl.NS1 * PLD_XS + off];
+                        cf[r] = xe[eh & 255u] * xe[(eh >> 8) & 255u];
+                        wv[r] = (double)((eh >> 16) & 255u) * wv[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gj0[r] += wv[r] * cf[r];
+                }
+            }
             if (beta_o > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
                 const double b = (beta_o - m.alpha) / m.alpha;
                 s_rr += b * (b * pl.k_ff + 2. * pl.k_fy);
