@@ -139,10 +139,15 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     const double decay_thr = m.decay_alpha2 * (1. - 1e-9);
 #ifndef BF_HOST_EMU
     // pipeline density: its LDS block behind the group's own regions (sixteen-chain layout: the chains are the 16 columns)
+    // (its own K-split of the second contraction: 1 -- two or four waves share the jobs here, not sixteen -- and the A operands of
+    // both contractions from a row-major copy of C' in LDS, PldLds::CL: bf_group_supports has checked that it fits)
     PldLds PL;
+    PldDev plg = m.pld;
     if constexpr (PLDG) {
-        PL = pld_lds(lds + ((G::lds_doubles(NMAT) + 1) & ~(size_t)1), DP, m.pld, 16);
-        pld_stage(m.pld, PL, DP, tid, 64 * W);
+        plg.KS2 = 1;
+        plg.KPJ2 = plg.NS2;
+        PL = pld_lds(lds + ((G::lds_doubles(NMAT) + 1) & ~(size_t)1), DP, plg, 16, true);
+        pld_stage(plg, PL, DP, tid, 64 * W);
     }
 #endif
 
@@ -739,7 +744,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
 #ifndef BF_HOST_EMU
         if constexpr (PLDG) {
             // ================= the pipeline density (bfhip_pld.h; core/density.py:527-560, modules/poly.py:430-503) =================
-            const PldDev &pl = m.pld;
+            const PldDev &pl = plg;
             const double r_b2 = skipH ? 0. : rd(G::V_B2);
             const double r_pr = pl.has_prior ? rd(G::V_VAL) : 0.;
             double r_bd2 = 0.;
@@ -783,9 +788,9 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 }
             }
             bf_sync();  // P1
-            pld_gemm1(pl, PL, m.alpha, j, W, lane);
+            pld_gemm1_cl(pl, PL, m.alpha, j, W, lane);
             bf_sync();  // P2: residuals
-            pld_gemm2(pl, PL, j, W, lane);
+            pld_gemm2_cl(pl, PL, j, W, lane);
             bf_sync();  // P3: W = C'^T r
             double s_rr = 0., s_fr = 0.;
 #pragma unroll
@@ -807,8 +812,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     for (int r = 0; r < 4; ++r) {
                         const unsigned eh = (unsigned)(en[r] >> 32);
                         const int pm = (int)(unsigned)en[r], off = (pm >> 2) * PLD_XS + c + 16 * (pm & 3);
-                        wv[r] = PL.PHI[off];
-                        for (int kp = 1; kp < pl.KS2; ++kp) wv[r] += PL.WX[(size_t)(kp - 1) * pl.NS1 * PLD_XS + off];
+                        wv[r] = PL.PHI[off];   // (K-split 1: one slot)
                         cf[r] = xe[eh & 255u] * xe[(eh >> 8) & 255u];
                         wv[r] = (double)((eh >> 16) & 255u) * wv[r];
                     }

@@ -22,7 +22,8 @@ static int launch_t(bfhip_ctx *ctx, const SamplerArgs &args) {
     size_t lds = GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
     if (FS & 8) {   // the pipeline density's block behind the group's own regions (sixteen-chain layout)
         const PldDev &pl = ctx->model.pld;
-        lds = (((GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) + 1) & ~(size_t)1) + pld_lds_doubles(16 * W, pl.MP, pl.PP, pl.KS2, pl.n_ent, PLD_XS)) * sizeof(double);
+        lds = (((GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) + 1) & ~(size_t)1) + pld_lds_doubles(16 * W, pl.MP, pl.PP, 1, pl.n_ent, PLD_XS) +
+               pld_cl_doubles(pl.MP, pl.PP) + 2) * sizeof(double);
     }
     if (lds > 64 * 1024)
         BF_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -110,12 +111,13 @@ static size_t group_pld_lds_bytes(const DevModel &m) {
     if (!m.pld.on) return 0;
     const int W = m.DP / 16;
     const size_t own = W == 4 ? GroupGeo<4>::lds_doubles(2) : (W == 2 ? GroupGeo<2>::lds_doubles(2) : GroupGeo<1>::lds_doubles(2));
-    return (((own + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, m.pld.KS2, m.pld.n_ent, PLD_XS)) * sizeof(double);
+    // (K-split 1 of the second contraction and the row-major copy of C': bfhip_group.h)
+    return (((own + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, 1, m.pld.n_ent, PLD_XS) + pld_cl_doubles(m.pld.MP, m.pld.PP) + 2) * sizeof(double);
 }
 
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {
     if (m.pld.on)   // the pipeline density (round 6): NUTS, no decay term, the sixteen-chain LDS layout has to fit beside the tree vectors
-        return m.DP <= 64 && args.cfg.sampler == 0 && !m.use_decay && !args.mat && !m.pld.only8 && !(bf_tune().no_group_pld != 0) &&
+        return m.DP <= 64 && args.cfg.sampler == 0 && !m.use_decay && !args.mat && !(bf_tune().no_group_pld != 0) &&
                group_pld_lds_bytes(m) <= (size_t)160 * 1024;
     return m.DP <= 64 && m.has_quad && m.use_bound && !m.has_su && !m.has_cubic && !m.has_link && !args.mat;
 }
