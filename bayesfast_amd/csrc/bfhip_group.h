@@ -122,7 +122,9 @@ template <int W, bool NUTS, int FS>
 BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) {
     constexpr bool DEC = (FS & 2) != 0, TR = (FS & 4) != 0, PLDG = (FS & 8) != 0;
     using G = GroupGeo<W>;
-    constexpr int DP = G::DP, NS = G::NS, KS = G::KS, NMAT = DEC ? 3 : 2, LSS = G::LSS;
+    // (XO: the pipeline form has no S tiles and leaves the x region out: its first region is x - mu)
+    constexpr int XO = ((FS & 8) != 0) ? 1 : 0;
+    constexpr int DP = G::DP, NS = G::NS, KS = G::KS, NMAT = (DEC ? 3 : 2) - XO, LSS = G::LSS;
     double *XB = lds;                          // [NMAT][NS][64]  B operands: x | x - mu | x_orig - mu_decay
     double *RB = XB + NMAT * NS * 64;          // [NVAL][W][16]   per-wave partial sums
     double *TV = RB + G::NVAL * W * 16;        // [NTV][DP][16]   tree vectors
@@ -146,7 +148,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     if constexpr (PLDG) {
         plg.KS2 = 1;
         plg.KPJ2 = plg.NS2;
-        PL = pld_lds(lds + ((G::lds_doubles(NMAT) + 1) & ~(size_t)1), DP, plg, 16, true);
+        PL = pld_lds(lds + ((G::lds_doubles(NMAT) + 1) & ~(size_t)1), DP, plg, 16, true, W);
         pld_stage(plg, PL, DP, tid, 64 * W);
     }
 #endif
@@ -450,8 +452,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             if constexpr (PLDG) { if (m.has_su) xs[r] = (xs[r] - c_sulo[r]) / c_sudf[r]; }   // the surrogate's input (module.py:76-83)
             xev[r] = xs[r];
             if constexpr (!PLDG) XB[(0 * NS + 4 * j + r) * 64 + lane] = xev[r];
-            XB[(1 * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
-            if constexpr (DEC) XB[(2 * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
+            XB[((1 - XO) * NS + 4 * j + r) * 64 + lane] = xs[r] - c_mu[r];
+            if constexpr (DEC) XB[((2 - XO) * NS + 4 * j + r) * 64 + lane] = xo[r] - c_dmu[r];
         }
         // Bound proof.  (x - mu)^T H (x - mu) <= lam_max sum_j hd_j (x_j - mu_j)^2: when that is below alpha^2 for every chain of the
         // group the test of modules/poly.py:467-469 is decided (inside) without the H (x - mu) tiles -- half of the trip's
@@ -511,8 +513,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             if (!skipH) {
 #pragma unroll
                 for (int s = 0; s < KH; ++s) {
-                    aH0 = bf_mfma(afH[s], XB[(1 * NS + s) * 64 + lane], aH0);
-                    if constexpr (KS == 2) aH1 = bf_mfma(afH[KH + s], XB[(1 * NS + KH + s) * 64 + lane], aH1);
+                    aH0 = bf_mfma(afH[s], XB[((1 - XO) * NS + s) * 64 + lane], aH0);
+                    if constexpr (KS == 2) aH1 = bf_mfma(afH[KH + s], XB[((1 - XO) * NS + KH + s) * 64 + lane], aH1);
                 }
             }
             if constexpr (DEC) {
@@ -521,8 +523,8 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 if (ranD) {
 #pragma unroll
                     for (int s = 0; s < KH; ++s) {
-                        aD0 = bf_mfma(afD[s], XB[(2 * NS + s) * 64 + lane], aD0);
-                        if constexpr (KS == 2) aD1 = bf_mfma(afD[KH + s], XB[(2 * NS + KH + s) * 64 + lane], aD1);
+                        aD0 = bf_mfma(afD[s], XB[((2 - XO) * NS + s) * 64 + lane], aD0);
+                        if constexpr (KS == 2) aD1 = bf_mfma(afD[KH + s], XB[((2 - XO) * NS + KH + s) * 64 + lane], aD1);
                     }
                 }
             }

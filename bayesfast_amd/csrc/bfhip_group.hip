@@ -22,7 +22,7 @@ static int launch_t(bfhip_ctx *ctx, const SamplerArgs &args) {
     size_t lds = GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) * sizeof(double);
     if (FS & 8) {   // the pipeline density's block behind the group's own regions (sixteen-chain layout)
         const PldDev &pl = ctx->model.pld;
-        lds = (((GroupGeo<W>::lds_doubles((FS & 2) ? 3 : 2) + 1) & ~(size_t)1) + pld_lds_doubles(16 * W, pl.MP, pl.PP, 1, pl.n_ent, PLD_XS) +
+        lds = (((GroupGeo<W>::lds_doubles(((FS & 2) ? 3 : 2) - 1) + 1) & ~(size_t)1) + pld_lds_doubles(16 * W, pl.MP, pl.PP, 1, pl.n_ent, PLD_XS, W) +
                pld_cl_doubles(pl.MP, pl.PP) + 2) * sizeof(double);
     }
     if (lds > 64 * 1024)
@@ -110,9 +110,9 @@ int bf_launch_split(bfhip_ctx *ctx, const SamplerArgs &args_in) {
 static size_t group_pld_lds_bytes(const DevModel &m) {
     if (!m.pld.on) return 0;
     const int W = m.DP / 16;
-    const size_t own = W == 4 ? GroupGeo<4>::lds_doubles(2) : (W == 2 ? GroupGeo<2>::lds_doubles(2) : GroupGeo<1>::lds_doubles(2));
-    // (K-split 1 of the second contraction and the row-major copy of C': bfhip_group.h)
-    return (((own + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, 1, m.pld.n_ent, PLD_XS) + pld_cl_doubles(m.pld.MP, m.pld.PP) + 2) * sizeof(double);
+    const size_t own = W == 4 ? GroupGeo<4>::lds_doubles(1) : (W == 2 ? GroupGeo<2>::lds_doubles(1) : GroupGeo<1>::lds_doubles(1));
+    // (one operand region -- no decay term here --, K-split 1 of the second contraction and the row-major copy of C': bfhip_group.h)
+    return (((own + 1) & ~(size_t)1) + pld_lds_doubles(m.DP, m.pld.MP, m.pld.PP, 1, m.pld.n_ent, PLD_XS, W) + pld_cl_doubles(m.pld.MP, m.pld.PP) + 2) * sizeof(double);
 }
 
 bool bf_group_supports(const DevModel &m, const SamplerArgs &args) {

@@ -52,13 +52,14 @@ struct PldLds {
 
 __host__ __device__ inline size_t pld_cl_doubles(int MP, int PP) { return (size_t)MP * (PP + 1) + 1; }
 
-__host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent, int xs = PLD_XS) {
+// (n_red: waves that post partial sums into RED, 16 unless the caller has fewer -- the group kernel's two or four)
+__host__ __device__ inline size_t pld_lds_doubles(int DP, int MP, int PP, int KS2, int n_ent, int xs = PLD_XS, int n_red = 16) {
     const size_t ns1 = PP / 4, ns2 = MP / 4;
-    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + 512 + ns2 * xs + (size_t)KS2 * ns1 * xs + (size_t)n_ent * DP + PP / 2;
+    return (size_t)16 * (DP + 2) + 16 + (size_t)2 * MP + (size_t)32 * n_red + ns2 * xs + (size_t)KS2 * ns1 * xs + (size_t)n_ent * DP + PP / 2;
 }
 
 #ifndef BF_HOST_EMU
-__device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw = 16, bool with_cl = false) {
+__device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw = 16, bool with_cl = false, int n_red = 16) {
     PldLds L;
     L.CW = cw;
     L.XS = cw == 8 ? PLD_XS8 : PLD_XS;
@@ -66,7 +67,7 @@ __device__ inline PldLds pld_lds(double *base, int DP, const PldDev &pl, int cw 
     L.CH = L.XE + 16 * (DP + 2);
     L.YW = L.CH + 16;
     L.RED = L.YW + 2 * pl.MP;
-    L.RB = L.RED + 512;
+    L.RB = L.RED + 32 * n_red;
     L.PHI = L.RB + (size_t)pl.NS2 * L.XS;
     L.WX = L.PHI + (size_t)pl.NS1 * L.XS;
     double *gt = L.WX + (size_t)(pl.KS2 - 1) * pl.NS1 * L.XS;
