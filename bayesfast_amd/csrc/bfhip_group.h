@@ -64,6 +64,13 @@
 #define GTRACE2(k) do { } while (0)
 #endif
 
+// tuning builds of the pipeline form (-DBF_PTRACE=<n>): 16 stamp points per trip (tools/trace_group_pld.py)
+#if defined(BF_PTRACE) && !defined(BF_HOST_EMU)
+#define PTRACE(k) do { if (tid == 0 && bf_group() == 0 && a.stamps && trip_no < BF_PTRACE) a.stamps[trip_no * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PTRACE(k) do { } while (0)
+#endif
+
 // knock-out builds (tools/gvariant.sh -DBF_KO_...): WRONG results on purpose, to bound what a piece of the trip costs on the
 // critical path (the tree shapes do not depend on the pieces knocked out); never part of the library
 #if defined(BF_KO_EXP) && !defined(BF_HOST_EMU)
@@ -419,6 +426,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     for (;;) {
         ++trip_no;
         GTRACE(0);
+        PTRACE(0);
         if (!bf_any(mode != M_DONE)) break;  // (every wave holds all 16 chains' state: the same decision in all of them)
 
         // ================= phase A: first half of the leapfrog step, B operands =================
@@ -480,8 +488,10 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             }
         }
         GTRACE(1);
+        PTRACE(1);
         bf_sync();  // B1
         GTRACE(2);
+        PTRACE(2);
 
         // ================= phase B: row tile j of S x, H (x - mu) (, H_decay^T (x - mu_decay)) on MFMA =================
         double sx[4], hv[4], dgr[4];
@@ -537,6 +547,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
 
         GTRACE(3);
+        PTRACE(3);
         // ================= phase C: the evaluation's sums, and the U-turn sums of the leaf it completes =================
         double ge[4], pn[4];
         const double dt_c = 0.5 * eps_t;
@@ -554,11 +565,18 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             if (!skipH) post(G::V_B2, sum4(t_b2));
             if constexpr (DEC) post(G::V_BD2, sum4(t_bd2));
             if (m.pld.has_prior) post(G::V_VAL, sum4(t_pr));
-            if constexpr (TR) {
-                double l4[4];
+            if constexpr (TR) {   // sum_r log|J_r| as the logarithm of the lane's product (see the polynomial form below)
+                const double pj = (ldet[0] * ldet[1]) * (ldet[2] * ldet[3]);
+                double lsum;
+                if (bf_any(ev && !(pj > 1e-280 && pj < 1e280))) {
+                    double l4[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) l4[r] = ev ? bf_log(ldet[r]) : 0.;
-                post(G::V_LOGDET, sum4(l4));
+                    for (int r = 0; r < 4; ++r) l4[r] = ev ? bf_log(ldet[r]) : 0.;
+                    lsum = sum4(l4);
+                } else {
+                    lsum = ev ? bf_log(pj) : 0.;
+                }
+                post(G::V_LOGDET, lsum);
             }
             if (bf_any(need_E0)) post(G::V_KIN0, kin0_part);
 #pragma unroll
@@ -704,8 +722,10 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         GTRACE(4);
         if (NUTS && early) uturn_sums(spec1);
         GTRACE(5);
+        PTRACE(4);
         bf_sync();  // B2
         GTRACE(6);
+        PTRACE(5);
 
         // ================= the evaluation's scalars =================
         // this trip's sums, fetched together (one LDS round trip instead of one per value)
@@ -771,7 +791,9 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     PL.CH[c] = ev ? beta_o : 0.;
                 }
             }
+            PTRACE(6);
             bf_sync();  // P0: the evaluation points of the 16 chains
+            PTRACE(7);
             {   // the monomials of every chain, the B operand of GEMM1: lane (c, gq) of wave j takes monomials 4 j + gq, + 4 W, ... of
                 // chain c, four at a time (the table word and the three factors of a monomial are dependent LDS reads)
                 const double *xe2 = PL.XE + c * (DP + 2);
@@ -789,11 +811,17 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                     }
                 }
             }
+            PTRACE(8);
             bf_sync();  // P1
+            PTRACE(9);
             pld_gemm1_cl(pl, PL, m.alpha, j, W, lane);
+            PTRACE(10);
             bf_sync();  // P2: residuals
+            PTRACE(11);
             pld_gemm2_cl(pl, PL, j, W, lane);
+            PTRACE(12);
             bf_sync();  // P3: W = C'^T r
+            PTRACE(13);
             double s_rr = 0., s_fr = 0.;
 #pragma unroll
             for (int w2 = 0; w2 < W; ++w2) {
@@ -805,10 +833,14 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
             double gj0[4] = {0., 0., 0., 0.};
             {
                 const double *xe = PL.XE + c * (DP + 2);
-                for (int i = 0; i < pl.n_ent; ++i) {
-                    unsigned long long en[4];
+                unsigned long long en[4];   // (the table words of the NEXT entry are on their way while one is gathered)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) en[r] = PL.GT[(size_t)i * DP + dbase + 4 * r];
+                for (int r = 0; r < 4; ++r) en[r] = pl.n_ent > 0 ? PL.GT[dbase + 4 * r] : 0ull;
+                for (int i = 0; i < pl.n_ent; ++i) {
+                    unsigned long long nx[4];
+                    const int i1 = i + 1 < pl.n_ent ? i + 1 : i;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nx[r] = PL.GT[(size_t)i1 * DP + dbase + 4 * r];
                     double wv[4], cf[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -819,7 +851,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                         wv[r] = (double)((eh >> 16) & 255u) * wv[r];
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gj0[r] += wv[r] * cf[r];
+                    for (int r = 0; r < 4; ++r) { gj0[r] += wv[r] * cf[r]; en[r] = nx[r]; }
                 }
             }
             if (beta_o > 0.) {   // (compressed outputs: the tails of Q^T f_mu' and Q^T y' as scalars, bfhip_pipeline_upload)
@@ -859,6 +891,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                 pn[r] = bf_fma(dt_c, ge[r], p[r]);          // integration.py:90
             }
             late = ev;
+            PTRACE(14);
         }
 #endif
         // (the common trip -- every chain proven inside the bound, no decay term -- skips the rare branches as one: per-lane
@@ -1009,6 +1042,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         }
 
         GTRACE(7);
+        PTRACE(15);
         GTRACE2(1);
         // ================= per-chain state machine =================
         enum { S_NONE, S_MERGE, S_ABORT, S_DBL_END, S_END };

@@ -480,54 +480,75 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
 // hidden by other waves (15 k cycles per contraction at the DES shape); from LDS a k-step is two ~100-cycle reads.  Two row tiles
 // side by side per wave (two independent accumulation chains), four k-steps of operands fetched together.  K-split 1.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int ASTEP>
-__device__ inline void pld_tile2_cl(const double *ap0, const double *ap1, int a_step, const double *bp0, const double *bp1, int n_steps,
+// NT row tiles (1 or 2) against their B operands, chunks of four k-steps, the operands of the NEXT chunk on their way while one
+// runs on the matrix pipe (a chunk's 8 or 16 LDS reads would otherwise be waited for in front of every four k-steps: 11 k cycles
+// for the DES shape's first contraction against 5 k, profiles/r06c_trace_group_pld.log)
+template <int ASTEP, int NT>
+__device__ inline void pld_tiles_cl(const double *ap0, const double *ap1, int a_step, const double *bp0, const double *bp1, int n_steps,
                                     d4_t &acc0, d4_t &acc1) {
     acc0 = d4_t{0., 0., 0., 0.};
     acc1 = d4_t{0., 0., 0., 0.};
     const int st = ASTEP ? ASTEP : a_step;
-    for (int s = 0; s < n_steps; s += 4) {   // (n_steps is a multiple of 4)
-        double x[4], y[4], b[4], c2[4];
+    double x[4], y[4], b[4], c2[4];
+    auto fetch = [&](double (&xx)[4], double (&yy)[4], double (&bb)[4], double (&cc)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            x[q] = ap0[q * st];
-            y[q] = ap1[q * st];
-            b[q] = bp0[q * PLD_XS];
-            c2[q] = bp1[q * PLD_XS];
+            xx[q] = ap0[q * st];
+            bb[q] = bp0[q * PLD_XS];
+            if (NT == 2) { yy[q] = ap1[q * st]; cc[q] = bp1[q * PLD_XS]; }
         }
+        ap0 += 4 * st; bp0 += 4 * PLD_XS;
+        if (NT == 2) { ap1 += 4 * st; bp1 += 4 * PLD_XS; }
+    };
+    fetch(x, y, b, c2);
+    for (int s = 4; s < n_steps; s += 4) {   // (n_steps is a multiple of 4)
+        double x1[4], y1[4], b1[4], c1[4];
+        fetch(x1, y1, b1, c1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q], c2[q], acc1, 0, 0, 0);
+            if (NT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q], c2[q], acc1, 0, 0, 0);
         }
-        ap0 += 4 * st; ap1 += 4 * st; bp0 += 4 * PLD_XS; bp1 += 4 * PLD_XS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { x[q] = x1[q]; b[q] = b1[q]; if (NT == 2) { y[q] = y1[q]; c2[q] = c1[q]; } }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
+        if (NT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q], c2[q], acc1, 0, 0, 0);
     }
 }
 
 __device__ inline void pld_gemm1_cl(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
     const double beta = L.CH[lane & 15], inv_alpha = 1. / alpha;
     double s_rr = 0., s_fr = 0.;
+    auto a_of = [&](int t) { return L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4); };
     for (int t = w; t < pl.NT1; t += 2 * nwv) {
-        const int t2 = t + nwv < pl.NT1 ? t + nwv : t;   // (an odd tile out runs twice side by side: same result, same time)
+        const int t2 = t + nwv;
         d4_t a0, a1;
-        pld_tile2_cl<4>(L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4), L.CL + (size_t)(16 * t2 + (lane & 15)) * L.CLS + (lane >> 4), 0,
-                        L.PHI + lane, L.PHI + lane, pl.NS1, a0, a1);
-        pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
-        if (t2 != t) pld_epilogue1(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
+        if (t2 < pl.NT1) {
+            pld_tiles_cl<4, 2>(a_of(t), a_of(t2), 0, L.PHI + lane, L.PHI + lane, pl.NS1, a0, a1);
+            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
+            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
+        } else {
+            pld_tiles_cl<4, 1>(a_of(t), a_of(t), 0, L.PHI + lane, L.PHI + lane, pl.NS1, a0, a1);
+            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
+        }
     }
     pld_red_put(L, w, lane, s_rr, s_fr);
 }
 
 // W = C'^T R (K-split 1: every job is a whole row tile, its result lands in slot 0 = PHI)
 __device__ inline void pld_gemm2_cl(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
+    auto a_of = [&](int u) { return L.CL + (size_t)(lane >> 4) * L.CLS + 16 * u + (lane & 15); };
     for (int u = w; u < pl.NT2; u += 2 * nwv) {
-        const int u2 = u + nwv < pl.NT2 ? u + nwv : u;
+        const int u2 = u + nwv;
         d4_t a0, a1;
-        pld_tile2_cl<0>(L.CL + (size_t)(lane >> 4) * L.CLS + 16 * u + (lane & 15), L.CL + (size_t)(lane >> 4) * L.CLS + 16 * u2 + (lane & 15), 4 * L.CLS,
-                        L.RB + lane, L.RB + lane, pl.NS2, a0, a1);
+        if (u2 < pl.NT2) pld_tiles_cl<0, 2>(a_of(u), a_of(u2), 4 * L.CLS, L.RB + lane, L.RB + lane, pl.NS2, a0, a1);
+        else pld_tiles_cl<0, 1>(a_of(u), a_of(u), 4 * L.CLS, L.RB + lane, L.RB + lane, pl.NS2, a0, a1);
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) L.PHI[(size_t)(4 * u + r4) * PLD_XS + lane] = a0[r4];
-        if (u2 != u) {
+        if (u2 < pl.NT2) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) L.PHI[(size_t)(4 * u2 + r4) * PLD_XS + lane] = a1[r4];
         }
