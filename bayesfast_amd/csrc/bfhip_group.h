@@ -1014,7 +1014,7 @@ BF_DEV void bf_group_body(const DevModel &m, const SamplerArgs &a, double *lds) 
         const bool late_x = bf_any(ev && (late || !early));
         n_trip_late += late_x ? 1 : 0;
         n_trip_skip += early ? 0 : 1;
-        if (__builtin_expect(late_x, 0)) {
+        if (__builtin_expect(late_x, PLDG ? 1 : 0)) {   // (the pipeline form's evaluations are always late: not a cold path there)
             if (early && !late_sync_done) bf_sync();  // B2': the early exchange's sums have been read by every wave
             double t_kin[4];
 #pragma unroll

@@ -45,6 +45,8 @@ struct PldDev {
     int n_ent;              // entries per dimension of the gradient table
     int only8;              // the LDS block fits in the eight-chain forms' layout only (33 doubles per B-operand row): the launchers take them
     int has_prior;
+    int tri;                // C' is upper triangular (the R of the output compression, bfhip_pipeline_upload): row tile t of C' is zero left of
+                            // column 16 t, row tile u of C'^T right of column 16 u + 15 -- the group kernel's contractions leave those k-steps out
     const double *CF, *CTF; // A fragments (see above)
     const double *yw, *fmuw;    // (MP) whitened data vector and f_mu, zero padded
     const unsigned *mono;       // (PP) i1 | i2 << 8 | i3 << 16; index DP = 1, DP + 1 = 0 (padding monomials)

@@ -480,78 +480,79 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
 // hidden by other waves (15 k cycles per contraction at the DES shape); from LDS a k-step is two ~100-cycle reads.  Two row tiles
 // side by side per wave (two independent accumulation chains), four k-steps of operands fetched together.  K-split 1.
 // ---------------------------------------------------------------------------------------------------------------------
-// NT row tiles (1 or 2) against their B operands, chunks of four k-steps, the operands of the NEXT chunk on their way while one
-// runs on the matrix pipe (a chunk's 8 or 16 LDS reads would otherwise be waited for in front of every four k-steps: 11 k cycles
-// for the DES shape's first contraction against 5 k, profiles/r06c_trace_group_pld.log)
-template <int ASTEP, int NT>
-__device__ inline void pld_tiles_cl(const double *ap0, const double *ap1, int a_step, const double *bp0, const double *bp1, int n_steps,
-                                    d4_t &acc0, d4_t &acc1) {
-    acc0 = d4_t{0., 0., 0., 0.};
-    acc1 = d4_t{0., 0., 0., 0.};
+// One row tile against its B operand over k-steps [s0, s1) (multiples of 4), as TWO accumulation chains (even and odd chunks of
+// four k-steps) added at the end -- a tile's k-steps are one dependent chain of matrix instructions otherwise, ~100 cycles each
+// with one wave on the SIMD --, the operands of the next chunk on their way while one runs.
+template <int ASTEP>
+__device__ inline d4_t pld_tile_cl(const double *ap, int a_step, const double *bp, int s0, int s1) {
+    d4_t acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
     const int st = ASTEP ? ASTEP : a_step;
-    double x[4], y[4], b[4], c2[4];
-    auto fetch = [&](double (&xx)[4], double (&yy)[4], double (&bb)[4], double (&cc)[4]) {
+    if (s1 <= s0) return acc0;
+    ap += (size_t)s0 * st;
+    bp += (size_t)s0 * PLD_XS;
+    double x[4], b[4];
+    auto fetch = [&](double (&xx)[4], double (&bb)[4]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            xx[q] = ap0[q * st];
-            bb[q] = bp0[q * PLD_XS];
-            if (NT == 2) { yy[q] = ap1[q * st]; cc[q] = bp1[q * PLD_XS]; }
-        }
-        ap0 += 4 * st; bp0 += 4 * PLD_XS;
-        if (NT == 2) { ap1 += 4 * st; bp1 += 4 * PLD_XS; }
+        for (int q = 0; q < 4; ++q) { xx[q] = ap[q * st]; bb[q] = bp[q * PLD_XS]; }
+        ap += 4 * st;
+        bp += 4 * PLD_XS;
     };
-    fetch(x, y, b, c2);
-    for (int s = 4; s < n_steps; s += 4) {   // (n_steps is a multiple of 4)
-        double x1[4], y1[4], b1[4], c1[4];
-        fetch(x1, y1, b1, c1);
+    fetch(x, b);
+    bool odd = false;
+    for (int s = s0 + 4; s < s1; s += 4) {
+        double x1[4], b1[4];
+        fetch(x1, b1);
+        if (odd) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
-            if (NT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q], c2[q], acc1, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc1, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
         }
+        odd = !odd;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { x[q] = x1[q]; b[q] = b1[q]; if (NT == 2) { y[q] = y1[q]; c2[q] = c1[q]; } }
+        for (int q = 0; q < 4; ++q) { x[q] = x1[q]; b[q] = b1[q]; }
     }
+    if (odd) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
-        if (NT == 2) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[q], c2[q], acc1, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc1, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
     }
+    return acc0 + acc1;
+}
+
+// The row tiles of a contraction dealt over nwv waves so that their k-steps balance: with the triangular C' of a compressed
+// output space tile t of GEMM1 has NS1 - 4 t k-steps and tile u of GEMM2 4 u + 4 -- wave w takes tiles w, 2 nwv - 1 - w,
+// 2 nwv + w, ... (a boustrophedon over the tiles in order of their length).
+__device__ inline bool pld_tile_mine(int t, int w, int nwv) {
+    const int r = t % (2 * nwv);
+    return (r < nwv ? r : 2 * nwv - 1 - r) == w;
 }
 
 __device__ inline void pld_gemm1_cl(const PldDev &pl, const PldLds &L, double alpha, int w, int nwv, int lane) {
     const double beta = L.CH[lane & 15], inv_alpha = 1. / alpha;
     double s_rr = 0., s_fr = 0.;
-    auto a_of = [&](int t) { return L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4); };
-    for (int t = w; t < pl.NT1; t += 2 * nwv) {
-        const int t2 = t + nwv;
-        d4_t a0, a1;
-        if (t2 < pl.NT1) {
-            pld_tiles_cl<4, 2>(a_of(t), a_of(t2), 0, L.PHI + lane, L.PHI + lane, pl.NS1, a0, a1);
-            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
-            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t2, a1, lane, s_rr, s_fr);
-        } else {
-            pld_tiles_cl<4, 1>(a_of(t), a_of(t), 0, L.PHI + lane, L.PHI + lane, pl.NS1, a0, a1);
-            pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, a0, lane, s_rr, s_fr);
-        }
+    for (int t = 0; t < pl.NT1; ++t) {
+        if (!pld_tile_mine(t, w, nwv)) continue;
+        // (triangular C': columns left of 16 t are zero in rows 16 t .. 16 t + 15)
+        const int s0 = pl.tri ? (4 * t < pl.NS1 ? 4 * t : pl.NS1) : 0;
+        const d4_t acc = pld_tile_cl<4>(L.CL + (size_t)(16 * t + (lane & 15)) * L.CLS + (lane >> 4), 0, L.PHI + lane, s0, pl.NS1);
+        pld_epilogue1(pl, L, alpha, inv_alpha, beta, t, acc, lane, s_rr, s_fr);
     }
     pld_red_put(L, w, lane, s_rr, s_fr);
 }
 
 // W = C'^T R (K-split 1: every job is a whole row tile, its result lands in slot 0 = PHI)
 __device__ inline void pld_gemm2_cl(const PldDev &pl, const PldLds &L, int w, int nwv, int lane) {
-    auto a_of = [&](int u) { return L.CL + (size_t)(lane >> 4) * L.CLS + 16 * u + (lane & 15); };
-    for (int u = w; u < pl.NT2; u += 2 * nwv) {
-        const int u2 = u + nwv;
-        d4_t a0, a1;
-        if (u2 < pl.NT2) pld_tiles_cl<0, 2>(a_of(u), a_of(u2), 4 * L.CLS, L.RB + lane, L.RB + lane, pl.NS2, a0, a1);
-        else pld_tiles_cl<0, 1>(a_of(u), a_of(u), 4 * L.CLS, L.RB + lane, L.RB + lane, pl.NS2, a0, a1);
+    for (int u = 0; u < pl.NT2; ++u) {
+        if (!pld_tile_mine(pl.NT2 - 1 - u, w, nwv)) continue;   // (the long tiles are the last ones here)
+        // (triangular C': rows below 16 u + 15 are zero in columns 16 u .. 16 u + 15)
+        const int s1 = pl.tri ? (4 * u + 4 < pl.NS2 ? 4 * u + 4 : pl.NS2) : pl.NS2;
+        const d4_t acc = pld_tile_cl<0>(L.CL + (size_t)(lane >> 4) * L.CLS + 16 * u + (lane & 15), 4 * L.CLS, L.RB + lane, 0, s1);
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) L.PHI[(size_t)(4 * u + r4) * PLD_XS + lane] = a0[r4];
-        if (u2 < pl.NT2) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) L.PHI[(size_t)(4 * u2 + r4) * PLD_XS + lane] = a1[r4];
-        }
+        for (int r4 = 0; r4 < 4; ++r4) L.PHI[(size_t)(4 * u + r4) * PLD_XS + lane] = acc[r4];
     }
 }
 

@@ -291,6 +291,7 @@ extern "C" int bfhip_pipeline_upload(bfhip_ctx *ctx, const bfhip_pipeline_desc *
     pl.n_ent = (int)n_ent;
     pl.only8 = only8;
     pl.has_prior = ds->prior_mu != NULL;
+    pl.tri = compress ? 1 : 0;   // (the Householder factorisation left R: zero below the diagonal, exactly)
     pl.CF = dbase + o_cf; pl.CTF = dbase + o_ctf; pl.yw = dbase + o_y; pl.fmuw = dbase + o_f;
     pl.prior_mu = dbase + o_pr; pl.prior_prec = dbase + o_pr + DP;
     pl.gtab = (const unsigned long long *)(dbase + o_g);
