@@ -480,14 +480,17 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
 // hidden by other waves (15 k cycles per contraction at the DES shape); from LDS a k-step is two ~100-cycle reads.  Two row tiles
 // side by side per wave (two independent accumulation chains), four k-steps of operands fetched together.  K-split 1.
 // ---------------------------------------------------------------------------------------------------------------------
-// One row tile against its B operand over k-steps [s0, s1) (multiples of 4), as TWO accumulation chains (even and odd chunks of
-// four k-steps) added at the end -- a tile's k-steps are one dependent chain of matrix instructions otherwise, ~100 cycles each
-// with one wave on the SIMD --, the operands of the next chunk on their way while one runs.
+// One row tile against its B operand over k-steps [s0, s1) (multiples of 4), as FOUR accumulation chains (k-step q of every chunk
+// of four goes to chain q) added at the end -- a tile's k-steps are one dependent chain of matrix instructions otherwise, and a
+// dependent v_mfma_f64_16x16x4 issues every ~200 cycles with one wave on the SIMD (7.4 k cycles for 28 k-steps,
+// profiles/r06c_trace_group_pld.log) --, the operands of the next chunk on their way while one runs.
 template <int ASTEP>
 __device__ inline d4_t pld_tile_cl(const double *ap, int a_step, const double *bp, int s0, int s1) {
-    d4_t acc0 = {0., 0., 0., 0.}, acc1 = {0., 0., 0., 0.};
+    d4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = d4_t{0., 0., 0., 0.};
     const int st = ASTEP ? ASTEP : a_step;
-    if (s1 <= s0) return acc0;
+    if (s1 <= s0) return acc[0];
     ap += (size_t)s0 * st;
     bp += (size_t)s0 * PLD_XS;
     double x[4], b[4];
@@ -498,29 +501,17 @@ __device__ inline d4_t pld_tile_cl(const double *ap, int a_step, const double *b
         bp += 4 * PLD_XS;
     };
     fetch(x, b);
-    bool odd = false;
     for (int s = s0 + 4; s < s1; s += 4) {
         double x1[4], b1[4];
         fetch(x1, b1);
-        if (odd) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc1, 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
-        }
-        odd = !odd;
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc[q], 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { x[q] = x1[q]; b[q] = b1[q]; }
     }
-    if (odd) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc1, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc0, 0, 0, 0);
-    }
-    return acc0 + acc1;
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc[q], 0, 0, 0);
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // The row tiles of a contraction dealt over nwv waves so that their k-steps balance: with the triangular C' of a compressed
