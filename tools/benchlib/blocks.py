@@ -304,6 +304,10 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
         m_out = int(spec['poly']['output_size'])
         nf = (fl - (2 * d * d if spec['poly'].get('use_bound') else 0) - (2 * d * d if spec.get('use_decay') else 0)) // (4 * m_out)
         exec_share = (fl - 4 * m_out * nf + 4 * min(m_out, nf) * nf) / fl
+        if kname().startswith('bf_group_kernel') and m_out > nf:
+            # the group kernel leaves the zero tiles of the triangular C' = R out of both contractions: (NT + 1) / (2 NT) of the tile k-steps
+            nt = -(-nf // 16)
+            exec_share = (fl - 4 * m_out * nf + 4 * nf * nf * (nt + 1) / (2. * nt)) / fl
     out = {'workload': what, 'value': n_lf / (ms * 1e-3), 'unit': 'leapfrog steps/sec', 'chains': int(C), 'dim': int(d),
            'leapfrogs_timed': int(n_lf), 'wall_s_timed': t_wall, 'steps_timed': int(steps),
            'nuts_iterations_timed': steps * iters, 'nuts_adaptation_iterations': n_adapt, 'ms_per_launch': ms / steps,
