@@ -8,8 +8,10 @@ defaults algorithm='parallel', fun='logcosh' (alpha = 1), whiten='unit-variance'
 
 * centring, the Gram matrix of the whitening (``bfhip_gram``: the same MFMA kernel as the surrogate fit's normal equations)
   and the projections ``K X``, ``W X1``, ``g(W X1) X1^T`` as device products; tanh and its row means on the device;
-* the d x d pieces -- the symmetric eigen-decompositions of the whitening and of every ``_sym_decorrelation``, the
-  convergence test -- on the host in NumPy, as scikit-learn does them (32 KB across PCIe per iteration);
+* the fixed-point iteration is device-resident (round 6, ``_ica_par``): the symmetric decorrelation of every iteration is a
+  Newton-Schulz polar iteration of d x d device products, the iterations run ahead in chunks (a HIP graph on the GPU) and the
+  host reads the chunk's convergence measures once -- one synchronisation per ten iterations instead of one per iteration with
+  a host ``eigh`` each; only the eigen-decomposition of the whitening (once per fit) is NumPy's;
 * ``w_init`` from ``np.random.RandomState(random_state).normal(size=(d, d))``, exactly the draw ``FastICA`` makes, so the
   same ``random_state`` starts both from the same matrix.
 
@@ -59,6 +61,119 @@ def _tn_product(a, b, rows=400):
     return out
 
 
+# ---- the fixed-point iteration: host form (one round trip per iteration) and device-resident form -------------------------
+
+def _ica_step_host(ctx, x1, W):
+    """One iteration of scikit-learn's ``_ica_par`` with the d x d symmetric decorrelation on the host: (W1, lim)."""
+    import torch
+    d = W.shape[0]
+    p_ = float(x1.shape[0])
+    wt = ctx.tensor(W.T.copy())
+    gwtx = torch.tanh(x1 @ wt)                                   # (n, d) = g(W X1)^T, alpha = 1
+    g_wtx = (1. - gwtx * gwtx).mean(0)                           # (d,)   mean of g'(W X1) over the samples
+    both = torch.cat([_tn_product(gwtx, x1) / p_, g_wtx[None]], 0).cpu().numpy()   # one copy to the host
+    W1 = _sym_decorrelation(both[:d] - both[d][:, None] * W)
+    lim = np.max(np.abs(np.abs(np.einsum('ij,ij->i', W1, W)) - 1))
+    return W1, lim
+
+
+_NS_ITERS = 44      # Newton-Schulz steps of the polar factor (covers singular values down to ~1e-7 of the largest)
+_NS_RESID = 1e-11   # ... accepted when max |X X^T - I| ends below this; otherwise the chunk is redone with the host's eigh
+_CHUNK = 10         # iterations run ahead between two looks at the convergence test
+
+
+def _polar_newton_schulz(A, eye):
+    """(A A^T)^{-1/2} A -- scikit-learn's ``_sym_decorrelation``, the orthogonal polar factor of A -- by the Newton-Schulz iteration
+    X <- 1.5 X - 0.5 X X^T X from X_0 = A / sqrt(|A|_1 |A|_inf) (singular values in (0, 1]: monotone, finally quadratic
+    convergence to 1), all d x d device products: no eigen-decomposition, no host round trip.  Returns (X, max |X X^T - I|)."""
+    import torch
+    s = torch.sqrt(A.abs().sum(0).max() * A.abs().sum(1).max())
+    X = A / s
+    for _ in range(_NS_ITERS):
+        X = torch.addmm(X, X @ X.T, X, beta=1.5, alpha=-0.5)
+    return X, (X @ X.T - eye).abs().max()
+
+
+def _ica_par(ctx, x1, W, max_iter, tol):
+    """scikit-learn's ``_ica_par`` (W numpy (d, d), x1 (n, d) white data on the device): (W, n_iter, converged).
+
+    Device-resident (round 6): the iterations run ahead in chunks of ``_CHUNK`` -- products, tanh, the symmetric decorrelation
+    as a Newton-Schulz polar iteration, the convergence measure, every iterate kept -- and the host looks at the chunk's
+    convergence measures ONCE (one synchronisation per chunk instead of one per iteration plus a host eigh each: 612 of them were
+    0.57 s of a config-5 GBS run, profiles/r05b_evidence_profile.log); it stops at the FIRST iterate below ``tol`` exactly as
+    the sequential loop does, so the iteration count is scikit-learn's.  On a GPU the chunk is captured once as a HIP graph and
+    replayed (a chunk is ~1500 small launches).  A chunk whose polar iteration did not reach ``_NS_RESID`` is redone with the
+    host's eigen-decomposition (``_ica_step_host``)."""
+    import torch
+    from ..utils.threads import blas_single_thread
+    d = W.shape[0]
+    p_ = float(x1.shape[0])
+    dev = x1.device
+    Wd = torch.as_tensor(W, dtype=torch.float64, device=dev).clone()
+    eye = torch.eye(d, dtype=torch.float64, device=dev)
+    Wbuf = torch.empty((_CHUNK, d, d), dtype=torch.float64, device=dev)
+    meas = torch.zeros((2, _CHUNK), dtype=torch.float64, device=dev)   # convergence measure and polar residual of every iterate
+
+    def chunk(n_it=_CHUNK):
+        for k in range(n_it):
+            gwtx = torch.tanh(x1 @ Wd.T)
+            g_wtx = (1. - gwtx * gwtx).mean(0)
+            W1, res = _polar_newton_schulz(_tn_product(gwtx, x1) / p_ - g_wtx[:, None] * Wd, eye)
+            meas[0, k] = ((W1 * Wd).sum(1).abs() - 1.).abs().max()
+            meas[1, k] = res
+            Wbuf[k].copy_(W1)
+            Wd.copy_(W1)
+
+    graph = None
+    if dev.type == 'cuda' and max_iter >= _CHUNK:
+        try:   # (capture needs a side stream; the captured work is replayed on the current one)
+            torch.cuda.synchronize(dev)
+            w_keep = Wd.clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                chunk(1)   # one iteration outside the capture (lazy initialisations of the BLAS handle and its workspace)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            Wd.copy_(w_keep)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                chunk()
+            Wd.copy_(w_keep)
+            graph = g
+        except Exception:
+            graph = None
+            Wd.copy_(torch.as_tensor(W, dtype=torch.float64, device=dev))
+    n_iter = 0
+    with blas_single_thread():
+        while n_iter < max_iter:
+            start = Wd.clone()
+            if graph is not None:
+                graph.replay()
+            else:
+                chunk()
+            m = meas.cpu().numpy()
+            left = min(_CHUNK, max_iter - n_iter)
+            if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
+                # (rare) the polar iteration fell short somewhere in this chunk: the same iterations with the host's eigh
+                Wh = start.cpu().numpy()
+                for k in range(left):
+                    Wh, lim = _ica_step_host(ctx, x1, Wh)
+                    n_iter += 1
+                    if lim < tol:
+                        return Wh, n_iter, True
+                Wd.copy_(torch.as_tensor(Wh, dtype=torch.float64, device=dev))
+                continue
+            hit = np.flatnonzero(m[0, :left] < tol)
+            if hit.size:
+                k = int(hit[0])
+                return Wbuf[k].cpu().numpy(), n_iter + k + 1, True
+            if left < _CHUNK:   # max_iter fell inside the chunk: the iterate it ends on
+                return Wbuf[left - 1].cpu().numpy(), max_iter, False
+            n_iter += _CHUNK
+    return Wd.cpu().numpy(), n_iter, False
+
+
 def fastica_device(x, random_state=None, max_iter=200, tol=1e-4, w_init=None, ctx=None):
     """``FastICA(max_iter=..., tol=..., random_state=...).fit(x)`` for x (n, d) (array or device tensor).
 
@@ -93,25 +208,9 @@ def fastica_device(x, random_state=None, max_iter=200, tol=1e-4, w_init=None, ct
             raise ValueError('w_init has invalid shape -- should be {}'.format((d, d)))
     # _ica_par: parallel FastICA with the logcosh contrast
     W = _sym_decorrelation(w_init)
-    p_ = float(n)
-    n_iter, lim = 0, np.inf
-    # (the host's share of an iteration is one d x d eigh: with the BLAS pool's threads spinning on a GPU host whose cgroup gives
-    # the process a fraction of the cores it sees, 6.2 ms at d = 128 -- half of a config-5 GBS run -- against 1 ms on one thread)
-    from ..utils.threads import blas_single_thread
-    with blas_single_thread():
-        for ii in range(int(max_iter)):
-            wt = ctx.tensor(W.T.copy())
-            gwtx = torch.tanh(x1 @ wt)                                   # (n, d) = g(W X1)^T, alpha = 1
-            g_wtx = (1. - gwtx * gwtx).mean(0)                           # (d,)   mean of g'(W X1) over the samples
-            both = torch.cat([_tn_product(gwtx, x1) / p_, g_wtx[None]], 0).cpu().numpy()   # one copy to the host
-            W1 = _sym_decorrelation(both[:d] - both[d][:, None] * W)
-            lim = np.max(np.abs(np.abs(np.einsum('ij,ij->i', W1, W)) - 1))
-            W = W1
-            n_iter = ii + 1
-            if lim < tol:
-                break
-        else:
-            warnings.warn('FastICA did not converge. Consider increasing tolerance or the maximum number of iterations.')
+    W, n_iter, converged = _ica_par(ctx, x1, W, int(max_iter), float(tol))
+    if not converged:
+        warnings.warn('FastICA did not converge. Consider increasing tolerance or the maximum number of iterations.')
     # whiten='unit-variance': the sources get unit variance, the rows of W are scaled accordingly
     comp = W @ K
     s_std = ((xc @ ctx.tensor(comp.T.copy())).std(0, unbiased=False)).cpu().numpy()

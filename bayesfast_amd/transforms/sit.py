@@ -260,6 +260,10 @@ class SIT:
             assert n > 0
         except Exception:
             raise ValueError('n should be a positive int.')
-        y = self.mvn_generator(np.zeros(self.dim), np.eye(self.dim), n)
+        from ..utils import sobol
+        if self.mvn_generator is sobol.multivariate_normal:   # the default: Sobol points, the quantile function on the device
+            y = sobol.standard_normal_device(self.dim, n, self._ctx()).cpu().numpy()
+        else:
+            y = self.mvn_generator(np.zeros(self.dim), np.eye(self.dim), n)
         x, log_j = self.backward_transform(y)
         return x, log_j, y

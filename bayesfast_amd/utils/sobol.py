@@ -61,3 +61,12 @@ def multivariate_normal(mean, cov, size, skip=1):
     with blas_single_thread():  # (utils/threads.py)
         a, w = np.linalg.eigh(cov)
         return mean + (points * a**0.5) @ w.T
+
+
+def standard_normal_device(d, size, ctx, skip=1):
+    """``multivariate_normal(zeros(d), eye(d), size)`` as a device tensor: the Sobol points from the host generator, the normal
+    quantile function on the device (``torch.special.ndtri``: 112 k x 128 points were 0.14 s of a config-5 GBS run in SciPy's)."""
+    import torch
+    size, skip = _counts(size, skip)
+    u = ctx.tensor(_unit_points(d, size, skip), torch.float64)
+    return torch.special.ndtri(u)
