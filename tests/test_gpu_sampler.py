@@ -825,27 +825,31 @@ def test_tree_size_mode_share_flag_matches_numpy(ctx):
     ts_col = _lib.NSTATS.index('tree_size')
     seen = set()
     for p_mode, row0, n_rows, share, slow in ((1.0, 0, 40, 0.98, 0), (0.99, 8, 32, 0.98, 0), (0.9, 8, 32, 0.98, 0), (0.9, 0, 7, 0.85, 0),
-                                              (0.5, 39, 1, 0.5, 0), (1.0, 8, 32, 0.98, 31), (1.0, 8, 32, 0.98, 11), (1.0, 8, 32, 0.98, 15)):
+                                              (0.5, 39, 1, 0.5, 0), (1.0, 8, 32, 0.98, 63), (1.0, 8, 32, 0.98, 31), (1.0, 8, 32, 0.98, 15),
+                                              (0.5, 8, 32, 0.98, 4095)):
         st = np.zeros((n_chain, n_out, _lib.STAT_STRIDE))
         sizes = np.where(rng.uniform(size=(n_chain, n_out)) < p_mode, 7, rng.choice([1, 3, 15, 31, 5000], size=(n_chain, n_out)))
         if slow:
-            sizes[123] = slow   # (one chain whose trees are larger than everybody else's: 31 leaves make it a laggard; 15 -- 2.1 times the mean, under twice it by its size class's lower edge -- and 11 do not)
+            # (one chain whose trees are larger than everybody else's: 63 leaves make it a laggard -- nine times the mean --; 31 -- 4.4
+            # times the mean, but under four times it by its size class's lower edge -- and 15 do not; round 6: the threshold is
+            # four times the mean, and the bit is reported whether or not the trees are in step -- the last case)
+            sizes[123] = slow
         st[:, :, ts_col] = sizes
         blk = np.minimum(sizes[:, row0:row0 + n_rows], 4095).reshape(-1)
         cnt = np.bincount(blk)
         mode = max(1, int(cnt.argmax()))
-        sums = np.minimum(sizes[:, row0:row0 + n_rows], 4095).sum(1)   # per chain; the busiest one's size class against twice the mean
+        sums = np.minimum(sizes[:, row0:row0 + n_rows], 4095).sum(1)   # per chain; the busiest one's size class against four times the mean
         top = int(np.clip(np.searchsorted(np.array(_lib.LAG_EDGES), sums, side='right') - 1, 0, 63).max())
-        lag = _lib.LAG_EDGES[top] * n_chain >= 2 * int(blk.sum())
-        want = (mode + (4096 if lag else 0)) if cnt.max() >= share * blk.size else 0   # (0: not in step)
+        lag = _lib.LAG_EDGES[top] * n_chain >= 4 * int(blk.sum())
+        want = (mode if cnt.max() >= share * blk.size else 0) + (4096 if lag else 0)   # (size 0: not in step)
         t = ctx.tensor(st)
         _lib.check(ctx._lib.bfhip_tree_size_mode_share(ctx.handle, n_chain, n_out, _ptr(t), row0, n_rows, float(share), _ptr(work)))
         torch.cuda.synchronize()
         w = work.cpu().numpy()
-        assert int(w[0]) == want, (p_mode, row0, n_rows, slow)
+        assert int(w[0]) == want, (p_mode, row0, n_rows, slow, int(w[0]), want)
         assert not w[1:].any()  # histograms and arrival counter cleared for the next call
-        seen.add((want > 0, want >= 4096))
-    assert seen == {(False, False), (True, False), (True, True)}
+        seen.add(((want & 4095) > 0, want >= 4096))
+    assert seen == {(False, False), (True, False), (True, True), (False, True)}
 
 
 @pytest.mark.parametrize('case', ['inside', 'leaky'])
