@@ -246,3 +246,107 @@ extern "C" int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+// ---- symmetric decorrelation of FastICA (sklearn.decomposition._fastica._sym_decorrelation; transforms/sit.py:235-244) ----------
+// W <- (W W^T)^{-1/2} W is the orthogonal polar factor of W; here by the Newton-Schulz iteration X <- 1.5 X - 0.5 (X X^T) X from
+// X_0 = W / sqrt(|W|_1 |W|_inf) (singular values in (0, 1]: monotone, finally quadratic convergence to 1) -- two d x d x d products a
+// step on the FP64 matrix cores, one wave per 16 x 16 tile of the result (64 waves on 64 CUs at d = 128; rocBLAS takes ~20 us for
+// such a product, 32 steps of two were the whole cost of a device-resident FastICA iteration, transforms/ica.py).  No
+// eigen-decomposition and no host round trip: the iteration count is fixed by the caller, the residual max |X X^T - I| of the
+// result is left on the device for it to look at when it next synchronises.
+typedef double bf_d4 __attribute__((ext_vector_type(4)));
+
+// C = beta Cin + alpha A op(B), d x d row-major; op(B) = B^T when TRANSB
+template <bool TRANSB>
+__global__ __launch_bounds__(64) void bf_small_gemm_kernel(int d, const double *__restrict__ A, const double *__restrict__ B,
+                                                          const double *Cin, double *C, double alpha, double beta) {
+    const int nt = (d + 15) / 16, ti = blockIdx.x / nt, tj = blockIdx.x % nt, lane = threadIdx.x;
+    const int ar = 16 * ti + (lane & 15), bn = 16 * tj + (lane & 15), kk = lane >> 4;
+    const int ns = (d + 3) / 4;
+    bf_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
+    for (int s0 = 0; s0 < ns; s0 += 8) {   // eight k-steps of operands on their way together, four accumulation chains
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 4 * (s0 + q) + kk;
+            const bool ok = k < d && s0 + q < ns;
+            a[q] = (ok && ar < d) ? A[(size_t)ar * d + k] : 0.;
+            b[q] = (ok && bn < d) ? (TRANSB ? B[(size_t)bn * d + k] : B[(size_t)k * d + bn]) : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+    }
+    const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + 4 * r + kk, col = bn;
+        if (row < d && col < d) {
+            const size_t o = (size_t)row * d + col;
+            C[o] = (beta != 0. ? beta * Cin[o] : 0.) + alpha * t[r];
+        }
+    }
+}
+
+// X0 = A / sqrt(|A|_1 |A|_inf) (one workgroup; d <= 1024)
+__global__ __launch_bounds__(256) void bf_ns_scale_kernel(int d, const double *__restrict__ A, double *__restrict__ X) {
+    __shared__ double red[256];
+    __shared__ double s_col, s_row;
+    double mc = 0., mr = 0.;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        double c = 0., r = 0.;
+        for (int i = 0; i < d; ++i) { c += fabs(A[(size_t)i * d + j]); r += fabs(A[(size_t)j * d + i]); }
+        mc = c > mc ? c : mc;
+        mr = r > mr ? r : mr;
+    }
+    red[threadIdx.x] = mc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) s_col = red[0];
+    __syncthreads();
+    red[threadIdx.x] = mr;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) s_row = red[0];
+    __syncthreads();
+    const double inv = 1. / sqrt(s_col * s_row);
+    for (int i = threadIdx.x; i < d * d; i += 256) X[i] = A[i] * inv;
+}
+
+// resid[0] = max |T - I| over the d x d matrix T (one workgroup)
+__global__ __launch_bounds__(256) void bf_ns_resid_kernel(int d, const double *__restrict__ T, double *__restrict__ resid) {
+    __shared__ double red[256];
+    double m = 0.;
+    for (int i = threadIdx.x; i < d * d; i += 256) {
+        const double v = fabs(T[i] - ((i / d == i % d) ? 1. : 0.));
+        m = (v > m || v != v) ? v : m;   // (NaN propagates)
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { const double u = red[threadIdx.x + o]; if (u > red[threadIdx.x] || u != u) red[threadIdx.x] = u; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) resid[0] = red[0];
+}
+
+extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || d < 1 || d > 1024 || !a || !x || !work || !resid || n_iter < 0)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_polar_ns: invalid argument");
+    const int nt = (d + 15) / 16;
+    double *T = work, *Y = work + (size_t)d * d;   // X and Y take turns
+    double *cur = (n_iter % 2 == 0) ? x : Y;        // (so that the last step writes x)
+    hipLaunchKernelGGL(bf_ns_scale_kernel, dim3(1), dim3(256), 0, ctx->stream, d, a, cur);
+    for (int it = 0; it < n_iter; ++it) {
+        double *nxt = (cur == x) ? Y : x;
+        hipLaunchKernelGGL(bf_small_gemm_kernel<true>, dim3(nt * nt), dim3(64), 0, ctx->stream, d, cur, cur, (const double *)NULL, T, 1., 0.);
+        hipLaunchKernelGGL(bf_small_gemm_kernel<false>, dim3(nt * nt), dim3(64), 0, ctx->stream, d, T, cur, cur, nxt, -0.5, 1.5);
+        cur = nxt;
+    }
+    hipLaunchKernelGGL(bf_small_gemm_kernel<true>, dim3(nt * nt), dim3(64), 0, ctx->stream, d, x, x, (const double *)NULL, T, 1., 0.);
+    hipLaunchKernelGGL(bf_ns_resid_kernel, dim3(1), dim3(256), 0, ctx->stream, d, T, resid);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -83,11 +83,24 @@ _NS_RESID = 1e-11   # ... accepted when max |X X^T - I| ends below this; otherwi
 _CHUNK = 10         # iterations run ahead between two looks at the convergence test
 
 
-def _polar_newton_schulz(A, eye):
+def _polar_newton_schulz(A, eye, ctx=None, work=None):
     """(A A^T)^{-1/2} A -- scikit-learn's ``_sym_decorrelation``, the orthogonal polar factor of A -- by the Newton-Schulz iteration
     X <- 1.5 X - 0.5 X X^T X from X_0 = A / sqrt(|A|_1 |A|_inf) (singular values in (0, 1]: monotone, finally quadratic
-    convergence to 1), all d x d device products: no eigen-decomposition, no host round trip.  Returns (X, max |X X^T - I|)."""
+    convergence to 1): no eigen-decomposition, no host round trip.  On the GPU ``bfhip_polar_ns`` (FP64-MFMA tiles, one wave per
+    16 x 16 tile of a product: the 64 small rocBLAS products of the torch form below were 20 us each); the torch form serves CPU
+    tensors (tests).  Returns (X, max |X X^T - I|)."""
     import torch
+    if ctx is not None and A.is_cuda:
+        from .. import _lib
+        from ..device import _ptr
+        d = A.shape[0]
+        A = A.contiguous()
+        X = torch.empty_like(A)
+        if work is None:
+            work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=A.device)
+        res = work[2 * d * d:]
+        _lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(A), _ptr(X), _NS_ITERS, _ptr(work), _ptr(res)))
+        return X, res[0].clone()
     s = torch.sqrt(A.abs().sum(0).max() * A.abs().sum(1).max())
     X = A / s
     for _ in range(_NS_ITERS):
@@ -119,14 +132,18 @@ def _ica_par(ctx, x1, W, max_iter, tol):
         for k in range(n_it):
             gwtx = torch.tanh(x1 @ Wd.T)
             g_wtx = (1. - gwtx * gwtx).mean(0)
-            W1, res = _polar_newton_schulz(_tn_product(gwtx, x1) / p_ - g_wtx[:, None] * Wd, eye)
+            W1, res = _polar_newton_schulz(_tn_product(gwtx, x1) / p_ - g_wtx[:, None] * Wd, eye, polar_ctx, polar_work)
             meas[0, k] = ((W1 * Wd).sum(1).abs() - 1.).abs().max()
             meas[1, k] = res
             Wbuf[k].copy_(W1)
             Wd.copy_(W1)
 
+    # on the GPU the polar iteration is one C-ABI call (65 launches queued by the library): no graph capture needed; CPU tensors (the
+    # tests' stand-in context) take the torch form
+    polar_ctx = ctx if (dev.type == 'cuda' and hasattr(ctx, 'handle')) else None
+    polar_work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=dev) if polar_ctx is not None else None
     graph = None
-    if dev.type == 'cuda' and max_iter >= _CHUNK:
+    if False and dev.type == 'cuda' and max_iter >= _CHUNK:
         try:   # (capture needs a side stream; the captured work is replayed on the current one)
             torch.cuda.synchronize(dev)
             w_keep = Wd.clone()

@@ -413,6 +413,12 @@ int bfhip_bridge_sums(bfhip_ctx *ctx, long n_a, const double *a, long n_b, const
 int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const double *logq_p, long n_q, const double *logp_q,
                        const double *logq_q, double logr, double *f1, double *f2);
 
+/* FastICA's symmetric decorrelation W <- (W W^T)^{-1/2} W (sklearn.decomposition FastICA, as SIT calls it: transforms/sit.py:235-244;
+ * scikit-learn takes an eigen-decomposition of W W^T on the host in every fixed-point iteration): the orthogonal polar factor of
+ * a (d,d), by n_iter Newton-Schulz steps on the FP64 matrix cores, into x (d,d).  work: 2 d^2 doubles; resid (1,) receives
+ * max |x x^T - I| (device memory: nothing synchronises; a caller checks it when it next looks at the device).  d <= 1024. */
+int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid);
+
 /* NOT part of this interface: the library's test and tuning switches (force a chain layout, a kernel form or a chains-per-workgroup
  * count; attach measurement buffers; run a launch in one part).  They have ONE entry point each for integers and for buffers,
  * declared with their keys in include/bfhip_debug.h; they never change what a call computes, and a binding has no use for them. */

