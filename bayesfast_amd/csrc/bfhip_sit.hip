@@ -331,11 +331,110 @@ __global__ __launch_bounds__(256) void bf_ns_resid_kernel(int d, const double *_
     if (threadIdx.x == 0) resid[0] = red[0];
 }
 
+// The whole iteration as ONE launch: nt x nt single-wave workgroups (all resident: d <= 512), a grid barrier between the two
+// products of a step (an arrival counter in global memory, targets that only grow: nothing is reset inside the launch).  65 small
+// launches per decorrelation were 0.46 ms of host time each call, more than the device needed for them.
+__device__ inline void bf_grid_barrier(unsigned int *counter, unsigned int target) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(counter, 1u);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+// one 16 x 16 tile of C = beta Cin + alpha A op(B) (the body of bf_small_gemm_kernel)
+template <bool TRANSB>
+__device__ inline void bf_small_gemm_tile(int d, int ti, int tj, int lane, const double *A, const double *B, const double *Cin, double *C,
+                                          double alpha, double beta) {
+    const int ar = 16 * ti + (lane & 15), bn = 16 * tj + (lane & 15), kk = lane >> 4;
+    const int ns = (d + 3) / 4;
+    bf_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 4 * (s0 + q) + kk;
+            const bool ok = k < d && s0 + q < ns;
+            a[q] = (ok && ar < d) ? __builtin_nontemporal_load(&A[(size_t)ar * d + k]) : 0.;
+            b[q] = (ok && bn < d) ? __builtin_nontemporal_load(TRANSB ? &B[(size_t)bn * d + k] : &B[(size_t)k * d + bn]) : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+    }
+    const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + 4 * r + kk, col = bn;
+        if (row < d && col < d) {
+            const size_t o = (size_t)row * d + col;
+            C[o] = (beta != 0. ? beta * Cin[o] : 0.) + alpha * t[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bf_polar_ns_kernel(int d, const double *__restrict__ a, double *x, int n_iter, double *work, double *resid,
+                                                        unsigned int *counter) {
+    const int nt = (d + 15) / 16, ti = blockIdx.x / nt, tj = blockIdx.x % nt, lane = threadIdx.x;
+    const unsigned int nwg = gridDim.x;
+    double *T = work, *Y = work + (size_t)d * d;
+    double *cur = (n_iter % 2 == 0) ? x : Y;
+    unsigned int phase = 0;
+    // X_0 = A / sqrt(|A|_1 |A|_inf): every workgroup takes the two norms (d^2 reads from L2), then scales its own tile
+    {
+        double mc = 0., mr = 0.;
+        for (int j = lane; j < d; j += 64) {
+            double c = 0., r = 0.;
+            for (int i = 0; i < d; ++i) { c += fabs(a[(size_t)i * d + j]); r += fabs(a[(size_t)j * d + i]); }
+            mc = c > mc ? c : mc;
+            mr = r > mr ? r : mr;
+        }
+        for (int o = 32; o > 0; o >>= 1) { mc = fmax(mc, __shfl_xor(mc, o, 64)); mr = fmax(mr, __shfl_xor(mr, o, 64)); }
+        const double inv = 1. / sqrt(mc * mr);
+        for (int e = lane; e < 256; e += 64) {
+            const int row = 16 * ti + (e >> 4), col = 16 * tj + (e & 15);
+            if (row < d && col < d) cur[(size_t)row * d + col] = a[(size_t)row * d + col] * inv;
+        }
+    }
+    bf_grid_barrier(counter, ++phase * nwg);
+    for (int it = 0; it < n_iter; ++it) {
+        double *nxt = (cur == x) ? Y : x;
+        bf_small_gemm_tile<true>(d, ti, tj, lane, cur, cur, nullptr, T, 1., 0.);
+        bf_grid_barrier(counter, ++phase * nwg);
+        bf_small_gemm_tile<false>(d, ti, tj, lane, T, cur, cur, nxt, -0.5, 1.5);
+        bf_grid_barrier(counter, ++phase * nwg);
+        cur = nxt;
+    }
+    bf_small_gemm_tile<true>(d, ti, tj, lane, x, x, nullptr, T, 1., 0.);
+    bf_grid_barrier(counter, ++phase * nwg);
+    if (blockIdx.x == 0) {   // max |T - I|
+        double mx = 0.;
+        for (int i = lane; i < d * d; i += 64) {
+            const double v = fabs(__builtin_nontemporal_load(&T[i]) - ((i / d == i % d) ? 1. : 0.));
+            mx = (v > mx || v != v) ? v : mx;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(mx, o, 64); mx = (u > mx || u != u) ? u : mx; }
+        if (lane == 0) resid[0] = mx;
+    }
+}
+
 extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || d < 1 || d > 1024 || !a || !x || !work || !resid || n_iter < 0)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_polar_ns: invalid argument");
     const int nt = (d + 15) / 16;
+    if (d <= 512) {   // one launch, grid barriers between the products (every workgroup resident: at most 1024 single-wave workgroups)
+        if (int rc = ensure_ws(ctx, 256)) return rc;
+        unsigned int *counter = (unsigned int *)ctx->scratch;
+        BF_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
+        hipLaunchKernelGGL(bf_polar_ns_kernel, dim3(nt * nt), dim3(64), 0, ctx->stream, d, a, x, n_iter, work, resid, counter);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     double *T = work, *Y = work + (size_t)d * d;   // X and Y take turns
     double *cur = (n_iter % 2 == 0) ? x : Y;        // (so that the last step writes x)
     hipLaunchKernelGGL(bf_ns_scale_kernel, dim3(1), dim3(256), 0, ctx->stream, d, a, cur);
