@@ -354,17 +354,17 @@ __device__ inline void bf_small_gemm_tile(int d, int ti, int tj, int lane, const
     bf_d4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
-    for (int s0 = 0; s0 < ns; s0 += 8) {
-        double a[8], b[8];
+    for (int s0 = 0; s0 < ns; s0 += 32) {   // 32 k-steps (all of them at d <= 128) of operands on their way together: one L2 latency a product
+        double a[32], b[32];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 32; ++q) {
             const int k = 4 * (s0 + q) + kk;
             const bool ok = k < d && s0 + q < ns;
-            a[q] = (ok && ar < d) ? __builtin_nontemporal_load(&A[(size_t)ar * d + k]) : 0.;
-            b[q] = (ok && bn < d) ? __builtin_nontemporal_load(TRANSB ? &B[(size_t)bn * d + k] : &B[(size_t)k * d + bn]) : 0.;
+            a[q] = (ok && ar < d) ? A[(size_t)ar * d + k] : 0.;
+            b[q] = (ok && bn < d) ? (TRANSB ? B[(size_t)bn * d + k] : B[(size_t)k * d + bn]) : 0.;
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+        for (int q = 0; q < 32; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
     }
     const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
@@ -377,9 +377,12 @@ __device__ inline void bf_small_gemm_tile(int d, int ti, int tj, int lane, const
     }
 }
 
-__global__ __launch_bounds__(64) void bf_polar_ns_kernel(int d, const double *__restrict__ a, double *x, int n_iter, double *work, double *resid,
-                                                        unsigned int *counter) {
-    const int nt = (d + 15) / 16, ti = blockIdx.x / nt, tj = blockIdx.x % nt, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void bf_polar_ns_kernel(int d, const double *a, double *x, int n_iter, double *work, double *resid,
+                                                         unsigned int *counter) {
+    // four waves per workgroup, a 16 x 16 tile per wave (16 workgroups at d = 128: fewer arrivals per grid barrier than 64)
+    const int nt = (d + 15) / 16, tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool has = tile < nt * nt;
+    const int ti = has ? tile / nt : 0, tj = has ? tile % nt : 0;
     const unsigned int nwg = gridDim.x;
     double *T = work, *Y = work + (size_t)d * d;
     double *cur = (n_iter % 2 == 0) ? x : Y;
@@ -397,24 +400,24 @@ __global__ __launch_bounds__(64) void bf_polar_ns_kernel(int d, const double *__
         const double inv = 1. / sqrt(mc * mr);
         for (int e = lane; e < 256; e += 64) {
             const int row = 16 * ti + (e >> 4), col = 16 * tj + (e & 15);
-            if (row < d && col < d) cur[(size_t)row * d + col] = a[(size_t)row * d + col] * inv;
+            if (has && row < d && col < d) cur[(size_t)row * d + col] = a[(size_t)row * d + col] * inv;
         }
     }
     bf_grid_barrier(counter, ++phase * nwg);
     for (int it = 0; it < n_iter; ++it) {
         double *nxt = (cur == x) ? Y : x;
-        bf_small_gemm_tile<true>(d, ti, tj, lane, cur, cur, nullptr, T, 1., 0.);
+        if (has) bf_small_gemm_tile<true>(d, ti, tj, lane, cur, cur, nullptr, T, 1., 0.);
         bf_grid_barrier(counter, ++phase * nwg);
-        bf_small_gemm_tile<false>(d, ti, tj, lane, T, cur, cur, nxt, -0.5, 1.5);
+        if (has) bf_small_gemm_tile<false>(d, ti, tj, lane, T, cur, cur, nxt, -0.5, 1.5);
         bf_grid_barrier(counter, ++phase * nwg);
         cur = nxt;
     }
-    bf_small_gemm_tile<true>(d, ti, tj, lane, x, x, nullptr, T, 1., 0.);
+    if (has) bf_small_gemm_tile<true>(d, ti, tj, lane, x, x, nullptr, T, 1., 0.);
     bf_grid_barrier(counter, ++phase * nwg);
-    if (blockIdx.x == 0) {   // max |T - I|
+    if (tile == 0) {   // max |T - I|
         double mx = 0.;
         for (int i = lane; i < d * d; i += 64) {
-            const double v = fabs(__builtin_nontemporal_load(&T[i]) - ((i / d == i % d) ? 1. : 0.));
+            const double v = fabs(T[i] - ((i / d == i % d) ? 1. : 0.));
             mx = (v > mx || v != v) ? v : mx;
         }
         for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(mx, o, 64); mx = (u > mx || u != u) ? u : mx; }
@@ -431,7 +434,7 @@ extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x,
         if (int rc = ensure_ws(ctx, 256)) return rc;
         unsigned int *counter = (unsigned int *)ctx->scratch;
         BF_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(bf_polar_ns_kernel, dim3(nt * nt), dim3(64), 0, ctx->stream, d, a, x, n_iter, work, resid, counter);
+        hipLaunchKernelGGL(bf_polar_ns_kernel, dim3((nt * nt + 3) / 4), dim3(256), 0, ctx->stream, d, a, x, n_iter, work, resid, counter);
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }
