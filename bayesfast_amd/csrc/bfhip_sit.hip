@@ -377,22 +377,37 @@ __device__ inline void bf_small_gemm_tile(int d, int ti, int tj, int lane, const
     }
 }
 
+// wave maximum of a non-negative value (NaN wins)
+__device__ inline double bf_wave_max_nn(double v) {
+    for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(v, o, 64); v = (u > v || u != u) ? u : v; }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void bf_polar_ns_kernel(int d, const double *a, double *x, int n_iter, double *work, double *resid,
-                                                         unsigned int *counter) {
+                                                         unsigned int *counter, unsigned long long *dev_slots) {
     // four waves per workgroup, a 16 x 16 tile per wave (16 workgroups at d = 128: fewer arrivals per grid barrier than 64)
     const int nt = (d + 15) / 16, tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const bool has = tile < nt * nt;
     const int ti = has ? tile / nt : 0, tj = has ? tile % nt : 0;
     const unsigned int nwg = gridDim.x;
     double *T = work, *Y = work + (size_t)d * d;
-    double *cur = (n_iter % 2 == 0) ? x : Y;
+    double *cur = x;
     unsigned int phase = 0;
-    // X_0 = A / sqrt(|A|_1 |A|_inf): every workgroup takes the two norms (d^2 reads from L2), then scales its own tile
+    // X_0 = A / sqrt(|A|_1 |A|_inf): every workgroup takes the two norms (d^2 reads from L2, eight rows of loads in flight), then
+    // scales its own tile
     {
         double mc = 0., mr = 0.;
         for (int j = lane; j < d; j += 64) {
             double c = 0., r = 0.;
-            for (int i = 0; i < d; ++i) { c += fabs(a[(size_t)i * d + j]); r += fabs(a[(size_t)j * d + i]); }
+            int i = 0;
+            for (; i + 8 <= d; i += 8) {
+                double cv[8], rv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { cv[q] = a[(size_t)(i + q) * d + j]; rv[q] = a[(size_t)j * d + i + q]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c += fabs(cv[q]); r += fabs(rv[q]); }
+            }
+            for (; i < d; ++i) { c += fabs(a[(size_t)i * d + j]); r += fabs(a[(size_t)j * d + i]); }
             mc = c > mc ? c : mc;
             mr = r > mr ? r : mr;
         }
@@ -404,25 +419,43 @@ __global__ __launch_bounds__(256) void bf_polar_ns_kernel(int d, const double *a
         }
     }
     bf_grid_barrier(counter, ++phase * nwg);
-    for (int it = 0; it < n_iter; ++it) {
-        double *nxt = (cur == x) ? Y : x;
-        if (has) bf_small_gemm_tile<true>(d, ti, tj, lane, cur, cur, nullptr, T, 1., 0.);
+    // The steps.  T = X X^T of a step is also the measure of how far X is from orthogonal: every tile posts max |T - I| (an atomic
+    // maximum of the bit pattern of a non-negative double), and once the whole matrix is below 1e-13 the iteration STOPS -- the
+    // count follows the matrix (15-25 steps for the noise-dominated updates of a nearly Gaussian SIT iteration, fewer otherwise)
+    // instead of a worst-case constant; the same data give the same count.
+    double r_last = 1.;
+    for (int it = 0; it <= n_iter; ++it) {
+        double dv = 0.;
+        if (has) {
+            bf_small_gemm_tile<true>(d, ti, tj, lane, cur, cur, nullptr, T, 1., 0.);
+            // (this wave's own tile of T: the values it just stored)
+            const int kk = lane >> 4, col = 16 * tj + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * r + kk;
+                if (row < d && col < d) {
+                    const double v = fabs(T[(size_t)row * d + col] - (row == col ? 1. : 0.));
+                    dv = (v > dv || v != v) ? v : dv;
+                }
+            }
+            dv = bf_wave_max_nn(dv);
+            if (lane == 0) atomicMax(&dev_slots[it], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
+        }
         bf_grid_barrier(counter, ++phase * nwg);
+        r_last = __longlong_as_double((long long)__hip_atomic_load(&dev_slots[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (r_last < 1e-13 || it == n_iter) break;
+        double *nxt = (cur == x) ? Y : x;
         if (has) bf_small_gemm_tile<false>(d, ti, tj, lane, T, cur, cur, nxt, -0.5, 1.5);
         bf_grid_barrier(counter, ++phase * nwg);
         cur = nxt;
     }
-    if (has) bf_small_gemm_tile<true>(d, ti, tj, lane, x, x, nullptr, T, 1., 0.);
-    bf_grid_barrier(counter, ++phase * nwg);
-    if (tile == 0) {   // max |T - I|
-        double mx = 0.;
-        for (int i = lane; i < d * d; i += 64) {
-            const double v = fabs(T[i] - ((i / d == i % d) ? 1. : 0.));
-            mx = (v > mx || v != v) ? v : mx;
+    if (cur != x && has) {   // the result belongs in x: this wave's tile
+        for (int e = lane; e < 256; e += 64) {
+            const int row = 16 * ti + (e >> 4), col = 16 * tj + (e & 15);
+            if (row < d && col < d) x[(size_t)row * d + col] = cur[(size_t)row * d + col];
         }
-        for (int o = 32; o > 0; o >>= 1) { const double u = __shfl_xor(mx, o, 64); mx = (u > mx || u != u) ? u : mx; }
-        if (lane == 0) resid[0] = mx;
     }
+    if (tile == 0 && lane == 0) resid[0] = r_last;
 }
 
 extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid) {
@@ -431,10 +464,12 @@ extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x,
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_polar_ns: invalid argument");
     const int nt = (d + 15) / 16;
     if (d <= 512) {   // one launch, grid barriers between the products (every workgroup resident: at most 1024 single-wave workgroups)
-        if (int rc = ensure_ws(ctx, 256)) return rc;
+        const size_t ws = 64 + (size_t)(n_iter + 2) * sizeof(unsigned long long);
+        if (int rc = ensure_ws(ctx, ws)) return rc;
         unsigned int *counter = (unsigned int *)ctx->scratch;
-        BF_HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(bf_polar_ns_kernel, dim3((nt * nt + 3) / 4), dim3(256), 0, ctx->stream, d, a, x, n_iter, work, resid, counter);
+        BF_HIP_CHECK(hipMemsetAsync(counter, 0, ws, ctx->stream));   // (the arrival counter and one residual slot per step)
+        hipLaunchKernelGGL(bf_polar_ns_kernel, dim3((nt * nt + 3) / 4), dim3(256), 0, ctx->stream, d, a, x, n_iter, work, resid, counter,
+                           (unsigned long long *)((char *)ctx->scratch + 64));
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }

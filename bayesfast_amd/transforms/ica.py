@@ -77,7 +77,7 @@ def _ica_step_host(ctx, x1, W):
     return W1, lim
 
 
-_NS_ITERS = 40      # Newton-Schulz steps of the polar factor (covers singular values down to ~1e-5 of the largest; d^3 products of
+_NS_ITERS = 60      # Newton-Schulz steps of the polar factor (covers singular values down to ~1e-5 of the largest; d^3 products of
                     # 20 us each at d = 128: the iteration costs about what the host's eigh did -- the gain is the missing round trips)
 _NS_RESID = 1e-11   # ... accepted when max |X X^T - I| ends below this; otherwise the chunk is redone with the host's eigh
 _CHUNK = 10         # iterations run ahead between two looks at the convergence test

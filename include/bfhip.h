@@ -415,8 +415,9 @@ int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const dou
 
 /* FastICA's symmetric decorrelation W <- (W W^T)^{-1/2} W (sklearn.decomposition FastICA, as SIT calls it: transforms/sit.py:235-244;
  * scikit-learn takes an eigen-decomposition of W W^T on the host in every fixed-point iteration): the orthogonal polar factor of
- * a (d,d), by n_iter Newton-Schulz steps on the FP64 matrix cores, into x (d,d).  work: 2 d^2 doubles; resid (1,) receives
- * max |x x^T - I| (device memory: nothing synchronises; a caller checks it when it next looks at the device).  d <= 1024. */
+ * a (d,d), by AT MOST n_iter Newton-Schulz steps on the FP64 matrix cores (the iteration stops once max |x x^T - I| < 1e-13), into
+ * x (d,d).  work: 2 d^2 doubles; resid (1,) receives max |x x^T - I| (device memory: nothing synchronises; a caller checks it
+ * when it next looks at the device).  d <= 1024. */
 int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid);
 
 /* NOT part of this interface: the library's test and tuning switches (force a chain layout, a kernel form or a chains-per-workgroup
