@@ -143,7 +143,7 @@ def _ica_par(ctx, x1, W, max_iter, tol):
     polar_ctx = ctx if (dev.type == 'cuda' and hasattr(ctx, 'handle')) else None
     polar_work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=dev) if polar_ctx is not None else None
     graph = None
-    if False and dev.type == 'cuda' and max_iter >= _CHUNK:
+    if dev.type == 'cuda' and max_iter >= _CHUNK and not __import__('os').environ.get('BFHIP_ICA_NO_GRAPH'):
         try:   # (capture needs a side stream; the captured work is replayed on the current one)
             torch.cuda.synchronize(dev)
             w_keep = Wd.clone()
