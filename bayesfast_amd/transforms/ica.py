@@ -115,9 +115,9 @@ def _ica_par(ctx, x1, W, max_iter, tol):
     as a Newton-Schulz polar iteration, the convergence measure, every iterate kept -- and the host looks at the chunk's
     convergence measures ONCE (one synchronisation per chunk instead of one per iteration plus a host eigh each: 612 of them were
     0.57 s of a config-5 GBS run, profiles/r05b_evidence_profile.log); it stops at the FIRST iterate below ``tol`` exactly as
-    the sequential loop does, so the iteration count is scikit-learn's.  On a GPU the chunk is captured once as a HIP graph and
-    replayed (a chunk is ~1500 small launches).  A chunk whose polar iteration did not reach ``_NS_RESID`` is redone with the
-    host's eigen-decomposition (``_ica_step_host``)."""
+    the sequential loop does, so the iteration count is scikit-learn's.  A chunk whose polar iteration did not reach ``_NS_RESID`` is
+    redone with the host's eigen-decomposition (``_ica_step_host``).  (A HIP-graph capture of the chunk was tried and dropped: the
+    library's launches go to the context's stream, not to the capturing one.)"""
     import torch
     from ..utils.threads import blas_single_thread
     d = W.shape[0]
@@ -138,38 +138,15 @@ def _ica_par(ctx, x1, W, max_iter, tol):
             Wbuf[k].copy_(W1)
             Wd.copy_(W1)
 
-    # on the GPU the polar iteration is one C-ABI call (65 launches queued by the library): no graph capture needed; CPU tensors (the
+    # on the GPU the polar iteration is one C-ABI call (one persistent launch, bfhip_polar_ns); CPU tensors (the
     # tests' stand-in context) take the torch form
     polar_ctx = ctx if (dev.type == 'cuda' and hasattr(ctx, 'handle')) else None
     polar_work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=dev) if polar_ctx is not None else None
-    graph = None
-    if dev.type == 'cuda' and max_iter >= _CHUNK and not __import__('os').environ.get('BFHIP_ICA_NO_GRAPH'):
-        try:   # (capture needs a side stream; the captured work is replayed on the current one)
-            torch.cuda.synchronize(dev)
-            w_keep = Wd.clone()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                chunk(1)   # one iteration outside the capture (lazy initialisations of the BLAS handle and its workspace)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            Wd.copy_(w_keep)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                chunk()
-            Wd.copy_(w_keep)
-            graph = g
-        except Exception:
-            graph = None
-            Wd.copy_(torch.as_tensor(W, dtype=torch.float64, device=dev))
     n_iter = 0
     with blas_single_thread():
         while n_iter < max_iter:
             start = Wd.clone()
-            if graph is not None:
-                graph.replay()
-            else:
-                chunk()
+            chunk()
             m = meas.cpu().numpy()
             left = min(_CHUNK, max_iter - n_iter)
             if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
