@@ -26,7 +26,8 @@ b = line('bench_line.json')
 FULL = (b or {}).get('roofline', {}).get('kernel') or 'bf_group_kernel'
 KERNEL = FULL.split('<')[0]
 # kernel trace: durations of the sampler dispatches
-kt = [r for r in rows('trace/**/*kernel_trace.csv') if FULL in r.get('Kernel_Name', '')]   # the exact instantiation
+STEM = FULL.split("<")[0] + "<" + FULL.split("<")[1].split(",")[0].split(">")[0] if "<" in FULL else FULL   # (the library names the instantiation loosely: stem and first argument)
+kt = [r for r in rows("trace/**/*kernel_trace.csv") if STEM in r.get("Kernel_Name", "")]
 dur = np.array([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-6 for r in kt])
 if len(dur):
     res['kernel_trace'] = {'kernel': kt[0]['Kernel_Name'], 'calls': int(len(dur)), 'total_ms': float(dur.sum()), 'avg_ms': float(dur.mean()),
