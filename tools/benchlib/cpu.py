@@ -88,7 +88,9 @@ def fixed_rate_here(spec, x_start, step_size, var, seed, target_accept, target_s
     from oracle import oracle as orc
     host = host_facts()
     n_thr = max(1, min(host['usable_threads'], orc.max_threads()))
-    n_chain = min(n_thr, x_start.shape[0])
+    # (eight chains per thread, dealt dynamically: chains whose trees differ -- config 3's first round has chains at the depth limit
+    # beside 7-leaf ones -- would leave threads idle at one chain each, which the 4096-chain workload on the same cores would not)
+    n_chain = min(8 * n_thr, x_start.shape[0])
     cs = orc.ChainSet(spec, x_start[:n_chain], seed, tuned=True, step_size=step_size, metric=var, adapt_step_size=False,
                       adapt_metric=False, target_accept=target_accept)
     nl, dt, n_it, slice_it = 0, 0., 0, 2
@@ -107,8 +109,8 @@ def fixed_rate_here(spec, x_start, step_size, var, seed, target_accept, target_s
     return {'value': nl / dt, 'unit': 'leapfrog steps/sec', 'cores': host['usable_cores'], 'threads': n_thr, 'kind': 'port',
             'omp': _omp_env(), 'tuned_evaluation': bool(tuned), 'host': host,
             'sample': '%d chains x %d NUTS iterations (%d leapfrogs in %.1f s) of the same density from the device chains\' '
-                      'post-adaptation positions, with their adapted step size and diagonal metric (chain means) held fixed; one '
-                      'chain per OpenMP thread; %s density evaluation' % (
+                      'post-adaptation positions, with their adapted step size and diagonal metric (chain means) held fixed; chains '
+                      'dealt dynamically over the OpenMP threads; %s density evaluation' % (
                           n_chain, n_it, nl, dt, 'tuned (oracle/bf_cpu_tuned.c)' if tuned else 'statement-by-statement')}
 
 
