@@ -486,32 +486,36 @@ __device__ inline void pld_gemm2_q8(const PldDev &pl, const PldLds &L, int w, in
 // profiles/r06c_trace_group_pld.log) --, the operands of the next chunk on their way while one runs.
 template <int ASTEP>
 __device__ inline d4_t pld_tile_cl(const double *ap, int a_step, const double *bp, int s0, int s1) {
-    d4_t acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = d4_t{0., 0., 0., 0.};
+    d4_t c0 = {0., 0., 0., 0.}, c1 = {0., 0., 0., 0.}, c2 = {0., 0., 0., 0.}, c3 = {0., 0., 0., 0.};
     const int st = ASTEP ? ASTEP : a_step;
-    if (s1 <= s0) return acc[0];
+    if (s1 <= s0) return c0;
     ap += (size_t)s0 * st;
     bp += (size_t)s0 * PLD_XS;
-    double x[4], b[4];
-    auto fetch = [&](double (&xx)[4], double (&bb)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { xx[q] = ap[q * st]; bb[q] = bp[q * PLD_XS]; }
-        ap += 4 * st;
-        bp += 4 * PLD_XS;
-    };
-    fetch(x, b);
-    for (int s = s0 + 4; s < s1; s += 4) {
-        double x1[4], b1[4];
-        fetch(x1, b1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc[q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { x[q] = x1[q]; b[q] = b1[q]; }
+    // two operand buffers taken in turn (no register copies between chunks: the compiler turned those into accumulator shuffles)
+    double xa[4], ba[4], xb[4], bb[4];
+#define PLD_FETCH(xx, bq) do { _Pragma("unroll") for (int q = 0; q < 4; ++q) { xx[q] = ap[q * st]; bq[q] = bp[q * PLD_XS]; } ap += 4 * st; bp += 4 * PLD_XS; } while (0)
+#define PLD_RUN(xx, bq) do { \
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xx[0], bq[0], c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xx[1], bq[1], c1, 0, 0, 0); \
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xx[2], bq[2], c2, 0, 0, 0); \
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xx[3], bq[3], c3, 0, 0, 0); } while (0)
+    PLD_FETCH(xa, ba);
+    int s = s0;
+    for (;;) {
+        const bool more_b = s + 4 < s1;
+        if (more_b) PLD_FETCH(xb, bb);
+        PLD_RUN(xa, ba);
+        s += 4;
+        if (!more_b) break;
+        const bool more_a = s + 4 < s1;
+        if (more_a) PLD_FETCH(xa, ba);
+        PLD_RUN(xb, bb);
+        s += 4;
+        if (!more_a) break;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[q], b[q], acc[q], 0, 0, 0);
-    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#undef PLD_FETCH
+#undef PLD_RUN
+    return (c0 + c1) + (c2 + c3);
 }
 
 // The row tiles of a contraction dealt over nwv waves so that their k-steps balance: with the triangular C' of a compressed
