@@ -81,6 +81,7 @@ _NS_ITERS = 60      # Newton-Schulz steps of the polar factor (covers singular v
                     # 20 us each at d = 128: the iteration costs about what the host's eigh did -- the gain is the missing round trips)
 _NS_RESID = 1e-11   # ... accepted when max |X X^T - I| ends below this; otherwise the chunk is redone with the host's eigh
 _CHUNK = 10         # iterations run ahead between two looks at the convergence test
+GRAPH_STATS = {'captured': 0, 'failed': 0, 'replayed': 0}   # chunk graphs of this process (tests look at it)
 
 
 def _polar_newton_schulz(A, eye, ctx=None, work=None):
@@ -116,8 +117,9 @@ def _ica_par(ctx, x1, W, max_iter, tol):
     convergence measures ONCE (one synchronisation per chunk instead of one per iteration plus a host eigh each: 612 of them were
     0.57 s of a config-5 GBS run, profiles/r05b_evidence_profile.log); it stops at the FIRST iterate below ``tol`` exactly as
     the sequential loop does, so the iteration count is scikit-learn's.  A chunk whose polar iteration did not reach ``_NS_RESID`` is
-    redone with the host's eigen-decomposition (``_ica_step_host``).  (A HIP-graph capture of the chunk was tried and dropped: the
-    library's launches go to the context's stream, not to the capturing one.)"""
+    redone with the host's eigen-decomposition (``_ica_step_host``).  The first chunk runs eagerly; from the second on the chunk is
+    ONE HIP graph (captured with the library's context pointed at the capturing stream, so that the polar kernel is a node of it):
+    the ~25 launches of an iteration were 0.7 ms of host time against ~0.6 ms of device time."""
     import torch
     from ..utils.threads import blas_single_thread
     d = W.shape[0]
@@ -142,11 +144,39 @@ def _ica_par(ctx, x1, W, max_iter, tol):
     # tests' stand-in context) take the torch form
     polar_ctx = ctx if (dev.type == 'cuda' and hasattr(ctx, 'handle')) else None
     polar_work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=dev) if polar_ctx is not None else None
+    graph = None
+
+    def capture():
+        """The chunk as a HIP graph (None when the capture fails: the eager chunks go on)."""
+        if polar_ctx is None or GRAPH_STATS['failed'] > 2:
+            return None
+        keep = polar_ctx.stream
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                polar_ctx.set_stream(torch.cuda.current_stream(dev))
+                chunk()
+        except Exception:
+            g = None
+        finally:
+            polar_ctx.set_stream(keep)
+        GRAPH_STATS['captured' if g is not None else 'failed'] += 1
+        return g
+
     n_iter = 0
     with blas_single_thread():
         while n_iter < max_iter:
             start = Wd.clone()
-            chunk()
+            if n_iter == 0 or polar_ctx is None:
+                chunk()
+            else:
+                if graph is None and n_iter == _CHUNK:
+                    graph = capture()       # (capturing does not run anything)
+                if graph is not None:
+                    graph.replay()
+                    GRAPH_STATS['replayed'] += 1
+                else:
+                    chunk()
             m = meas.cpu().numpy()
             left = min(_CHUNK, max_iter - n_iter)
             if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):

@@ -65,8 +65,12 @@ def multivariate_normal(mean, cov, size, skip=1):
 
 def standard_normal_device(d, size, ctx, skip=1):
     """``multivariate_normal(zeros(d), eye(d), size)`` as a device tensor: the Sobol points from the host generator, the normal
-    quantile function on the device (``torch.special.ndtri``: 112 k x 128 points were 0.14 s of a config-5 GBS run in SciPy's)."""
+    quantile function on the device (``bfhip_ndtri``, Cephes' algorithm as SciPy's: 112 k x 128 points were 0.14 s of a config-5
+    GBS run in SciPy's, and 0.28 s of run-time compilation at the first call of ``torch.special.ndtri``)."""
     import torch
+    from .. import _lib
+    from ..device import _ptr
     size, skip = _counts(size, skip)
     u = ctx.tensor(_unit_points(d, size, skip), torch.float64)
-    return torch.special.ndtri(u)
+    _lib.check(ctx._lib.bfhip_ndtri(ctx.handle, u.numel(), _ptr(u), _ptr(u)))
+    return u

@@ -398,6 +398,11 @@ int bfhip_importance_weights(bfhip_ctx *ctx, long n, const double *logp, const d
 int bfhip_kde_cdf(bfhip_ctx *ctx, int d, long n, const double *data, const double *w, const double *h, int m, const double *pts,
                   double *out);
 
+/* The normal quantile function of n probabilities, out[i] = ndtri(p[i]) (scipy.special.ndtri, which scipy.stats.norm.ppf evaluates:
+ * utils/sobol.py:57 on the Sobol points of multivariate_normal, transforms/sit.py:225 on the KDE cdfs): Cephes' algorithm; -inf / +inf
+ * at 0 / 1, NaN outside [0, 1].  p and out may be the same array. */
+int bfhip_ndtri(bfhip_ctx *ctx, long n, const double *p, double *out);
+
 /* The per-dimension piecewise cubics of SIT for n points x (n,d) -> out (n,d): mode 0 evaluate, 1 derivative, 2 solve
  * (utils/_cubic.pyx:188-336, called per dimension by SIT.forward_transform / backward_transform, transforms/sit.py:372-451).
  * Dimension j owns knots[knot_off[j] .. knot_off[j+1]), values there, and m_j + 1 coefficient rows of 4 at

@@ -314,3 +314,57 @@ def test_sample_then_gbs_end_to_end_on_a_gaussian_surrogate():
     exact = c0 + 0.5 * d * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(cov)[1]
     assert 0. < err < 0.1
     assert abs(logz - exact) < 3. * err + 0.02, (logz, err, exact)
+
+
+@pytest.mark.gpu
+def test_device_ndtri_is_scipys():
+    """bfhip_ndtri (Cephes' algorithm, as scipy.special.ndtri -- what the reference's norm.ppf calls evaluate, utils/sobol.py:57,
+    transforms/sit.py:225) against SciPy's values over the middle, both tails, the far tails, the branch points and the edges."""
+    import torch
+    from scipy.special import ndtri
+    from bayesfast_amd import _lib
+    from bayesfast_amd.device import get_context, _ptr
+    ctx = get_context(0)
+    rng = np.random.default_rng(11)
+    e2 = np.exp(-2.)
+    p = np.concatenate([rng.uniform(size=20000), 10.**rng.uniform(-300, -1, 5000), 1. - 10.**rng.uniform(-16, -1, 5000),
+                        np.nextafter(e2, [0., 1.]), [e2, 1. - e2, 0.5, np.exp(-32.), 5e-324, 1. - 2.**-53],
+                        np.nextafter(1. - e2, [0., 1.])])
+    d = ctx.tensor(p)
+    out = torch.empty_like(d)
+    _lib.check(ctx._lib.bfhip_ndtri(ctx.handle, p.size, _ptr(d), _ptr(out)))
+    got, want = out.cpu().numpy(), ndtri(p)
+    # (the device's log and sqrt may round differently in the last place: a few ulp, 4e-16 relative + 1e-16 absolute at the centre)
+    np.testing.assert_allclose(got, want, rtol=2e-15, atol=2e-16)
+    edge = ctx.tensor(np.array([0., 1., -0.1, 1.1, np.nan]))
+    _lib.check(ctx._lib.bfhip_ndtri(ctx.handle, 5, _ptr(edge), _ptr(edge)))   # in place
+    e = edge.cpu().numpy()
+    assert e[0] == -np.inf and e[1] == np.inf and np.isnan(e[2:]).all()
+    # the Sobol-normal draws SIT.sample takes are the reference's (utils/sobol.py:40-57: norm.ppf of the scrambled points)
+    from bayesfast_amd.utils import sobol
+    dev = sobol.standard_normal_device(7, 1000, ctx).cpu().numpy()
+    host = sobol.multivariate_normal(np.zeros(7), np.eye(7), 1000)
+    np.testing.assert_allclose(dev, host, rtol=2e-15, atol=2e-16)
+
+
+@pytest.mark.gpu
+def test_fastica_chunk_graph_equals_the_eager_chunks(monkeypatch):
+    """The FastICA iteration's chunks replayed as ONE HIP graph (the polar kernel a node of it) find what the eager chunks find:
+    same iteration count, same components bit for bit (the same kernels on the same data in the same order)."""
+    from bayesfast_amd.transforms import ica
+    from bayesfast_amd.device import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(4)
+    x = rng.laplace(size=(20000, 48)) @ (np.eye(48) + 0.3 * rng.normal(size=(48, 48)))
+    before = dict(ica.GRAPH_STATS)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        comp_g, mean_g, n_g = ica.fastica_device(x, random_state=7, ctx=ctx)
+    assert ica.GRAPH_STATS['captured'] == before['captured'] + 1 and ica.GRAPH_STATS['failed'] == before['failed']
+    assert ica.GRAPH_STATS['replayed'] > before['replayed'] and n_g > ica._CHUNK
+    monkeypatch.setitem(ica.GRAPH_STATS, 'failed', 99)    # (no capture: eager chunks)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        comp_e, mean_e, n_e = ica.fastica_device(x, random_state=7, ctx=ctx)
+    assert n_e == n_g
+    np.testing.assert_array_equal(comp_g, comp_e)
