@@ -126,28 +126,97 @@ class SIT:
         mean = (yT * w).sum(1) / w.sum()
         var = (((yT - mean[:, None])**2) * w).sum(1) / w.sum() / (1. - float(np.sum(wn**2)))  # np.cov(aweights=w, bias=False)
         h = torch.sqrt(var) * (neff**(-1. / 5)) * self.bw_factor
-        # the sorted coordinates (percentiles of the knots and edge points): one device sort, one copy to the host
-        y_sorted = torch.sort(yT, dim=1).values.cpu().numpy()
+        y_sorted_dev = torch.sort(yT, dim=1).values    # (percentiles of the knots and edge points)
         hd = h.contiguous()
+        splines = self._build_on_device(ctx, y_sorted_dev, yT, w, hd)
+        if splines is not None:
+            return SplineTable(splines, ctx)
+        # host construction (options outside the device builder's range): one copy of the sorted coordinates to the host, the
+        # function values of every round of all d splines from ONE kde-cdf call
+        y_sorted = y_sorted_dev.cpu().numpy()
+        splines = GaussianizingSpline.build_many(y_sorted, self._batch_fun(ctx, yT, w, hd, y_sorted), presorted=True, **self.cubic_options)
+        return SplineTable(splines, ctx)
+
+    @staticmethod
+    def _batch_fun(ctx, yT, w, hd, y_sorted, rows=None):
+        """``batch_fun`` of ``GaussianizingSpline.build_many`` for the coordinates ``rows`` (default: all): norm.ppf(kde.cdf(.)) of
+        one round's requests in one device call (rows padded with their last point)."""
+        import torch
+        from scipy.special import ndtri
+        from .. import _lib
+        from ..device import _ptr
+        d, n = yT.shape
+        rows = list(range(d)) if rows is None else list(rows)
 
         def batch_fun(requests):
-            # the requests of one round of all d splines in ONE kde-cdf call (rows padded with their last point)
             m = max(r.size for r in requests if r is not None)
             pts = np.empty((d, m))
-            for j, r in enumerate(requests):
-                if r is None:
-                    pts[j] = y_sorted[j, 0]
-                else:
+            pts[:] = y_sorted[:, :1]
+            for j, r in zip(rows, requests):
+                if r is not None:
                     pts[j, :r.size] = r
                     pts[j, r.size:] = r[-1]
             p = ctx.tensor(pts)
             out = torch.empty_like(p)
             _lib.check(ctx._lib.bfhip_kde_cdf(ctx.handle, d, n, _ptr(yT), _ptr(w), _ptr(hd), m, _ptr(p), _ptr(out)))
             vals = ndtri(out.cpu().numpy())          # (scipy's norm.ppf is this function)
-            return [None if r is None else vals[j, :r.size] for j, r in enumerate(requests)]
+            return [None if r is None else vals[j, :r.size] for j, r in zip(rows, requests)]
+        return batch_fun
 
-        splines = GaussianizingSpline.build_many(y_sorted, batch_fun, presorted=True, **self.cubic_options)
-        return SplineTable(splines, ctx)
+    _BUILD_STRIDE = 512
+
+    def _build_on_device(self, ctx, y_sorted_dev, yT, w, hd):
+        """All d splines of the iteration in ONE launch (``bfhip_spline_build``: a workgroup per coordinate runs the whole construction,
+        cdf sums included) and one copy of the finished knots, values and coefficient rows to the host.  None when the options are
+        outside the kernel's range (then the host construction runs).  A coordinate the kernel gives up on (more than 512 knots, a
+        singular slope system) is built by the host construction; the reference's own failures are raised as it raises them."""
+        import torch
+        from .. import _lib
+        from ..device import _ptr
+        o = dict(bins=100, edge_bins=1, edge_points=10, max_width=5, split=4, max_add=5)
+        if not set(self.cubic_options) <= set(o) or not hasattr(ctx, 'handle'):
+            return None
+        o.update(self.cubic_options)
+        try:
+            bins, edge_points, split, max_add = int(o['bins']), int(o['edge_points']), int(o['split']), int(o['max_add'])
+            edge_bins = int(min(o['edge_bins'], bins // 4))
+            max_width = float(o['max_width'])
+        except Exception:
+            return None
+        if edge_bins < 1:
+            return None
+        grid = np.linspace(0, 100, bins + 1)[edge_bins:-edge_bins]
+        inner = np.linspace(0, 100, edge_points + 2)[1:-1]
+        stride = self._BUILD_STRIDE
+        if not (3 <= grid.size <= stride and 1 <= inner.size <= 128 and split >= 2 and max_add >= 0 and max_width > 0):
+            return None
+        d, n = yT.shape
+        ox, oy = ctx.empty((d, stride)), ctx.empty((d, stride))
+        oc = ctx.empty((d, 4 * (stride + 1)))
+        on = torch.zeros((d, 2), dtype=torch.int32, device=yT.device)
+        _lib.check(ctx._lib.bfhip_spline_build(ctx.handle, d, n, _ptr(y_sorted_dev), _ptr(yT), _ptr(w), _ptr(hd), grid.size,
+                                               _ptr(ctx.tensor(grid)), edge_bins, inner.size, _ptr(ctx.tensor(inner)), max_width, split,
+                                               max_add, stride, _ptr(ox), _ptr(oy), _ptr(oc), _ptr(on)))
+        cnt = on.cpu().numpy()
+        ox, oy, oc = ox.cpu().numpy(), oy.cpu().numpy(), oc.cpu().numpy()
+        if np.any(cnt[:, 1] & 4):
+            raise ValueError('the knots are too unevenly spaced.')
+        splines, redo = [], []
+        for j in range(d):
+            m, flag = int(cnt[j, 0]), int(cnt[j, 1])
+            if flag & (1 | 2 | 8) or m < 2:
+                redo.append(j)
+                splines.append(None)
+                continue
+            if flag & 16:
+                warnings.warn(RuntimeWarning('Not all the intervals are monotone.'))
+            splines.append(GaussianizingSpline.from_arrays(ox[j, :m].copy(), oy[j, :m].copy(), oc[j, :4 * (m + 1)].reshape(m + 1, 4).copy()))
+        if redo:
+            y_sorted = y_sorted_dev.cpu().numpy()
+            fun = self._batch_fun(ctx, yT, w, hd, y_sorted, rows=redo)
+            for j, sp in zip(redo, GaussianizingSpline.build_many(y_sorted[redo], fun, presorted=True, **self.cubic_options)):
+                splines[j] = sp
+        return splines
 
     def fit(self, data=None, weights=None, n_run=None):
         """transforms/sit.py:257-341 (without the plots)."""

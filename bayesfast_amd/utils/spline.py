@@ -78,6 +78,14 @@ class GaussianizingSpline:
             pass
 
     @classmethod
+    def from_arrays(cls, x, y, c):
+        """A finished spline from its knots, values and coefficient rows (the device builder's output)."""
+        out = cls.__new__(cls)
+        out.x, out.y, out.c = x, y, c
+        out._k_left, out._k_right = float(c[0, 2]), float(c[-1, 2])
+        return out
+
+    @classmethod
     def build_many(cls, rows, batch_fun, presorted=False, **options):
         """One spline per row of ``rows``, built side by side: every spline asks for function values at a few points
         several times on its way (knots, edge points, extra knots); ``batch_fun(requests)`` gets the requests of one round

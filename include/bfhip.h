@@ -403,6 +403,19 @@ int bfhip_kde_cdf(bfhip_ctx *ctx, int d, long n, const double *data, const doubl
  * at 0 / 1, NaN outside [0, 1].  p and out may be the same array. */
 int bfhip_ndtri(bfhip_ctx *ctx, long n, const double *p, double *out);
 
+/* The Gaussianizing splines of one SIT iteration, all d coordinates in one launch (SIT._gaussianize_1d, transforms/sit.py:223-227:
+ * cubic_spline(x, lambda xx: norm.ppf(kde.cdf(xx)), **cubic_options), utils/cubic.py:19-260).  sorted (d,n): every coordinate's
+ * samples in ascending order (the percentiles); data (d,n), w (n) normalised, h (d): the KDE as in bfhip_kde_cdf.  grid (n_grid):
+ * np.linspace(0, 100, bins + 1)[edge_bins:-edge_bins]; inner (n_inner): np.linspace(0, 100, edge_points + 2)[1:-1]; edge_bins,
+ * max_width, split, max_add: cubic_spline's options.  Output per coordinate j: out_n[2 j] knots (0 when the coordinate was given up),
+ * out_n[2 j + 1] flags (1 too few distinct knots / nothing beyond the edge knots, 2 singular slope system, 4 'the knots are too
+ * unevenly spaced' (the reference raises), 8 more than 512 knots, 16 'Not all the intervals are monotone' (the reference warns));
+ * knots out_x[j stride ..], values out_y[j stride ..], coefficient rows out_c[j 4 (stride + 1) ..] (m + 1 rows of 4, as
+ * bfhip_spline_apply takes them).  stride >= 512, n_grid <= 512, n_inner <= 128. */
+int bfhip_spline_build(bfhip_ctx *ctx, int d, long n, const double *sorted, const double *data, const double *w, const double *h,
+                       int n_grid, const double *grid, int edge_bins, int n_inner, const double *inner, double max_width, int split,
+                       int max_add, int stride, double *out_x, double *out_y, double *out_c, int *out_n);
+
 /* The per-dimension piecewise cubics of SIT for n points x (n,d) -> out (n,d): mode 0 evaluate, 1 derivative, 2 solve
  * (utils/_cubic.pyx:188-336, called per dimension by SIT.forward_transform / backward_transform, transforms/sit.py:372-451).
  * Dimension j owns knots[knot_off[j] .. knot_off[j+1]), values there, and m_j + 1 coefficient rows of 4 at
