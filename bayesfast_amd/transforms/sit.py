@@ -194,8 +194,9 @@ class SIT:
         ox, oy = ctx.empty((d, stride)), ctx.empty((d, stride))
         oc = ctx.empty((d, 4 * (stride + 1)))
         on = torch.zeros((d, 2), dtype=torch.int32, device=yT.device)
+        grid_d, inner_d = ctx.tensor(grid), ctx.tensor(inner)     # (named: they must outlive the launch's argument list)
         _lib.check(ctx._lib.bfhip_spline_build(ctx.handle, d, n, _ptr(y_sorted_dev), _ptr(yT), _ptr(w), _ptr(hd), grid.size,
-                                               _ptr(ctx.tensor(grid)), edge_bins, inner.size, _ptr(ctx.tensor(inner)), max_width, split,
+                                               _ptr(grid_d), edge_bins, inner.size, _ptr(inner_d), max_width, split,
                                                max_add, stride, _ptr(ox), _ptr(oy), _ptr(oc), _ptr(on)))
         cnt = on.cpu().numpy()
         ox, oy, oc = ox.cpu().numpy(), oy.cpu().numpy(), oc.cpu().numpy()
