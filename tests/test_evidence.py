@@ -412,12 +412,15 @@ def test_device_spline_build_is_the_host_construction(kind):
     for a, b in zip(dev, host):
         np.testing.assert_array_equal(a.x, b.x)
         np.testing.assert_allclose(a.y, b.y, rtol=0, atol=1e-11)
-        # (the cubic rows divide value differences of 1e-13 by knot spacings down to 1e-3, twice: compare them loosely and the
-        # cubics themselves, at the middle of every interval, tightly)
-        np.testing.assert_allclose(a.c, b.c, rtol=1e-4, atol=1e-5)
-        t = 0.5 * np.diff(a.x)
-        mid = lambda c: ((c[1:-1, 0] * t + c[1:-1, 1]) * t + c[1:-1, 2]) * t + c[1:-1, 3]
-        np.testing.assert_allclose(mid(a.c), mid(b.c), rtol=0, atol=1e-10)
+        # (the cubic rows divide value differences of 1e-14 by knot spacings down to 1e-5, up to three times: compare the cubics
+        # and their slopes inside every interval, not the leading coefficients)
+        np.testing.assert_allclose(a.c[:, 2:], b.c[:, 2:], rtol=1e-7, atol=1e-9)
+        for f in (0.25, 0.5, 0.9):
+            t = f * np.diff(a.x)
+            val = lambda c: ((c[1:-1, 0] * t + c[1:-1, 1]) * t + c[1:-1, 2]) * t + c[1:-1, 3]
+            der = lambda c: (3 * c[1:-1, 0] * t + 2 * c[1:-1, 1]) * t + c[1:-1, 2]
+            np.testing.assert_allclose(val(a.c), val(b.c), rtol=0, atol=1e-11)
+            np.testing.assert_allclose(der(a.c), der(b.c), rtol=1e-7, atol=1e-9)
         sizes.add(a.x.size)
     assert len(sizes) > 1 or kind == 'options'    # (knots were added somewhere: the rounds ran)
     print(kind, sorted(sizes))
