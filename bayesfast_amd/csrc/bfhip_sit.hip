@@ -482,11 +482,163 @@ __global__ __launch_bounds__(256) void bf_polar_ns_kernel(int d, const double *a
     if (tile == 0 && lane == 0) resid[0] = r_last;
 }
 
+// Round 6b: ONE grid barrier per step.  A workgroup owns a 16-row block of X (one wave per 16 x 16 tile of it, d <= 256): its waves
+// build the block's rows of T = X X^T side by side into LDS (they need all of X, which the barrier of the previous step made
+// visible), a workgroup barrier, and the update X' = 1.5 X - 0.5 T X of the block takes T from LDS: T never travels, and the step
+// ends in one arrival at the grid barrier (release fence before, acquire fence after: one cache write-back and one invalidate per
+// step where the first form paid two of each twice).  X_0 = A / sqrt(|A|_1 |A|_inf) is applied on load in the first step.  The
+// arithmetic per tile is the first form's (same operands, same four accumulation chains): the iterates are bit-identical.
+__device__ inline void bf_grid_barrier_ra(unsigned int *counter, unsigned int target) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// this wave's tile of T = (sc X)(sc X)^T into the workgroup's LDS rows; returns max |T - I| over the tile (NaN -> inf)
+__device__ inline double bf_polar_rows_t(int d, int ti, int tj, int lane, const double *X, double sc, double *Tl, int ld) {
+    const int ar = 16 * ti + (lane & 15), bn = 16 * tj + (lane & 15), kk = lane >> 4;
+    const int ns = (d + 3) / 4;
+    bf_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
+    for (int s0 = 0; s0 < ns; s0 += 32) {
+        double a[32], b[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int k = 4 * (s0 + q) + kk;
+            const bool ok = k < d && s0 + q < ns;
+            a[q] = (ok && ar < d) ? X[(size_t)ar * d + k] * sc : 0.;
+            b[q] = (ok && bn < d) ? X[(size_t)bn * d + k] * sc : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+    }
+    const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    double dv = 0.;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lr = 4 * r + kk, row = 16 * ti + lr, col = bn;
+        const bool in = row < d && col < d;
+        const double tv = in ? 0. + 1. * t[r] : 0.;     // (the first form stored 0 + 1 * t: the same value)
+        Tl[lr * ld + col] = tv;
+        if (in) {
+            const double v = fabs(tv - (row == col ? 1. : 0.));
+            dv = (v > dv || v != v) ? v : dv;
+        }
+    }
+    return dv;
+}
+
+// this wave's tile of X' = 1.5 (sc X) - 0.5 T (sc X), T's rows from LDS
+__device__ inline void bf_polar_rows_x(int d, int ti, int tj, int lane, const double *X, double sc, const double *Tl, int ld, double *out) {
+    const int bn = 16 * tj + (lane & 15), kk = lane >> 4;
+    const int ns = (d + 3) / 4;
+    bf_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
+    for (int s0 = 0; s0 < ns; s0 += 32) {
+        double a[32], b[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int k = 4 * (s0 + q) + kk;
+            const bool ok = k < d && s0 + q < ns;
+            a[q] = ok ? Tl[(lane & 15) * ld + k] : 0.;
+            b[q] = (ok && bn < d) ? X[(size_t)k * d + bn] * sc : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+    }
+    const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + 4 * r + kk, col = bn;
+        if (row < d && col < d) {
+            const size_t o = (size_t)row * d + col;
+            out[o] = 1.5 * (X[o] * sc) + -0.5 * t[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bf_polar_rows_kernel(int d, const double *a, double *x, int n_iter, double *work, double *resid,
+                                                            unsigned int *counter, unsigned long long *dev_slots) {
+    extern __shared__ double bf_polar_tl[];
+    const int nt = (d + 15) / 16, ti = blockIdx.x, tj = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = 16 * nt + 4;
+    const unsigned int nwg = gridDim.x;
+    double *Y = work;
+    // |A|_1 and |A|_inf: every wave for itself (d^2 reads from L2, eight rows of loads in flight)
+    double mc = 0., mr = 0.;
+    for (int j = lane; j < d; j += 64) {
+        double c = 0., r = 0.;
+        int i = 0;
+        for (; i + 8 <= d; i += 8) {
+            double cv[8], rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { cv[q] = a[(size_t)(i + q) * d + j]; rv[q] = a[(size_t)j * d + i + q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { c += fabs(cv[q]); r += fabs(rv[q]); }
+        }
+        for (; i < d; ++i) { c += fabs(a[(size_t)i * d + j]); r += fabs(a[(size_t)j * d + i]); }
+        mc = c > mc ? c : mc;
+        mr = r > mr ? r : mr;
+    }
+    for (int o = 32; o > 0; o >>= 1) { mc = fmax(mc, __shfl_xor(mc, o, 64)); mr = fmax(mr, __shfl_xor(mr, o, 64)); }
+    const double *src = a;
+    double sc = 1. / sqrt(mc * mr);
+    double *dst = x;
+    unsigned int phase = 0;
+    double r_last = 1.;
+    bool converged = false;
+    for (int it = 0; it < n_iter; ++it) {
+        double dv = bf_polar_rows_t(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
+        dv = bf_wave_max_nn(dv);
+        if (lane == 0) atomicMax(&dev_slots[it], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
+        __syncthreads();
+        bf_polar_rows_x(d, ti, tj, lane, src, sc, bf_polar_tl, ld, dst);
+        bf_grid_barrier_ra(counter, ++phase * nwg);
+        src = dst;
+        sc = 1.;
+        dst = (dst == x) ? Y : x;
+        // (the measure of the iterate this step STARTED from: below the threshold the step just taken only polished it)
+        r_last = __longlong_as_double((long long)__hip_atomic_load(&dev_slots[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (r_last < 1e-13) { converged = true; break; }
+    }
+    if (!converged) {   // the steps ran out (or there were none): the measure of the iterate they ended on
+        double dv = bf_polar_rows_t(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
+        dv = bf_wave_max_nn(dv);
+        if (lane == 0) atomicMax(&dev_slots[n_iter], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
+        bf_grid_barrier_ra(counter, ++phase * nwg);
+        r_last = __longlong_as_double((long long)__hip_atomic_load(&dev_slots[n_iter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (src != x) {   // the result belongs in x: this wave's tile
+        for (int e = lane; e < 256; e += 64) {
+            const int row = 16 * ti + (e >> 4), col = 16 * tj + (e & 15);
+            if (row < d && col < d) x[(size_t)row * d + col] = src[(size_t)row * d + col] * sc;
+        }
+    }
+    if (ti == 0 && tj == 0 && lane == 0) resid[0] = r_last;
+}
+
 extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || d < 1 || d > 1024 || !a || !x || !work || !resid || n_iter < 0)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_polar_ns: invalid argument");
     const int nt = (d + 15) / 16;
+    if (d <= 256 && !bf_tune().polar_tiles) {   // one launch, a workgroup per 16-row block, one grid barrier per step
+        const size_t ws = 64 + (size_t)(n_iter + 2) * sizeof(unsigned long long);
+        if (int rc = ensure_ws(ctx, ws)) return rc;
+        unsigned int *counter = (unsigned int *)ctx->scratch;
+        BF_HIP_CHECK(hipMemsetAsync(counter, 0, ws, ctx->stream));
+        hipLaunchKernelGGL(bf_polar_rows_kernel, dim3(nt), dim3(64 * nt), (size_t)16 * (16 * nt + 4) * sizeof(double), ctx->stream, d, a, x,
+                           n_iter, work, resid, counter, (unsigned long long *)((char *)ctx->scratch + 64));
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (d <= 512) {   // one launch, grid barriers between the products (every workgroup resident: at most 1024 single-wave workgroups)
         const size_t ws = 64 + (size_t)(n_iter + 2) * sizeof(unsigned long long);
         if (int rc = ensure_ws(ctx, ws)) return rc;

@@ -424,3 +424,44 @@ def test_device_spline_build_is_the_host_construction(kind):
         sizes.add(a.x.size)
     assert len(sizes) > 1 or kind == 'options'    # (knots were added somewhere: the rounds ran)
     print(kind, sorted(sizes))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('d', [5, 16, 48, 100, 128, 200, 256, 300])
+def test_polar_ns_is_the_orthogonal_polar_factor(d):
+    """bfhip_polar_ns (FastICA's symmetric decorrelation, scikit-learn's _sym_decorrelation as SIT calls it, transforms/sit.py:235-244)
+    against the SVD's polar factor; its two forms (a workgroup per row block with one grid barrier per step / a tile per wave with
+    two) take bit-identical steps; residual reported, early stop, n_iter = 0."""
+    import torch
+    from bayesfast_amd import _lib, debug_set
+    from bayesfast_amd.device import get_context, _ptr
+    ctx = get_context(0)
+    rng = np.random.default_rng(d)
+    A = rng.normal(size=(d, d)) * 0.03 + np.diag(rng.uniform(0.05, 2., size=d))
+    a = ctx.tensor(A)
+    work = torch.empty(2 * d * d + 1, dtype=torch.float64, device=a.device)
+
+    def run(n_iter, tiles=0):
+        debug_set('polar_tiles', tiles)
+        x = torch.empty_like(a)
+        _lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(a), _ptr(x), n_iter, _ptr(work), _ptr(work[2 * d * d:])))
+        return x.cpu().numpy(), float(work[2 * d * d])
+
+    u, s, vt = np.linalg.svd(A)
+    x, res = run(60)
+    assert res < 1e-13
+    np.testing.assert_allclose(x, u @ vt, rtol=0, atol=5e-13 * s.max() / s.min())
+    np.testing.assert_allclose(x @ x.T, np.eye(d), rtol=0, atol=1e-13)
+    x3, res3 = run(3)
+    assert res3 > 1e-13                                      # three steps are not enough for this matrix ...
+    np.testing.assert_allclose(np.abs(x3 @ x3.T - np.eye(d)).max(), res3, rtol=1e-9)   # ... and the residual says how far they got
+    if d <= 256:
+        x3t, res3t = run(3, tiles=1)
+        np.testing.assert_array_equal(x3, x3t)
+        assert res3 == res3t
+        xt, rest = run(60, tiles=1)
+        np.testing.assert_allclose(xt, x, rtol=0, atol=1e-14)
+    x0, res0 = run(0)
+    scale = np.sqrt(np.abs(A).sum(0).max() * np.abs(A).sum(1).max())
+    np.testing.assert_allclose(x0, A / scale, rtol=1e-15)
+    debug_set('polar_tiles', 0)
