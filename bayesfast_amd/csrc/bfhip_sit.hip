@@ -500,23 +500,27 @@ __device__ inline void bf_grid_barrier_ra(unsigned int *counter, unsigned int ta
 }
 
 // this wave's tile of T = (sc X)(sc X)^T into the workgroup's LDS rows; returns max |T - I| over the tile (NaN -> inf)
+template <int KB>
 __device__ inline double bf_polar_rows_t(int d, int ti, int tj, int lane, const double *X, double sc, double *Tl, int ld) {
     const int ar = 16 * ti + (lane & 15), bn = 16 * tj + (lane & 15), kk = lane >> 4;
     const int ns = (d + 3) / 4;
+    const int aoff = (ar < d ? ar : 0) * d + kk, boff = (bn < d ? bn : 0) * d + kk;
     bf_d4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
-    for (int s0 = 0; s0 < ns; s0 += 32) {
-        double a[32], b[32];
+    for (int s0 = 0; s0 < ns; s0 += KB) {
+        double a[KB], b[KB];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < KB; ++q) {
+            // (a uniform base per k-step plus one per-lane offset: an address register pair per operand stream, not per load)
             const int k = 4 * (s0 + q) + kk;
             const bool ok = k < d && s0 + q < ns;
-            a[q] = (ok && ar < d) ? X[(size_t)ar * d + k] * sc : 0.;
-            b[q] = (ok && bn < d) ? X[(size_t)bn * d + k] * sc : 0.;
+            const double *col = X + 4 * (s0 + q);
+            a[q] = (ok && ar < d) ? col[aoff] * sc : 0.;
+            b[q] = (ok && bn < d) ? col[boff] * sc : 0.;
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+        for (int q = 0; q < KB; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
     }
     const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     double dv = 0.;
@@ -535,23 +539,26 @@ __device__ inline double bf_polar_rows_t(int d, int ti, int tj, int lane, const 
 }
 
 // this wave's tile of X' = 1.5 (sc X) - 0.5 T (sc X), T's rows from LDS
+template <int KB>
 __device__ inline void bf_polar_rows_x(int d, int ti, int tj, int lane, const double *X, double sc, const double *Tl, int ld, double *out) {
     const int bn = 16 * tj + (lane & 15), kk = lane >> 4;
     const int ns = (d + 3) / 4;
+    const int boff = kk * d + (bn < d ? bn : 0);
     bf_d4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
-    for (int s0 = 0; s0 < ns; s0 += 32) {
-        double a[32], b[32];
+    for (int s0 = 0; s0 < ns; s0 += KB) {
+        double a[KB], b[KB];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < KB; ++q) {
             const int k = 4 * (s0 + q) + kk;
             const bool ok = k < d && s0 + q < ns;
+            const double *row = X + (size_t)(4 * (s0 + q)) * d;
             a[q] = ok ? Tl[(lane & 15) * ld + k] : 0.;
-            b[q] = (ok && bn < d) ? X[(size_t)k * d + bn] * sc : 0.;
+            b[q] = (ok && bn < d) ? row[boff] * sc : 0.;
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+        for (int q = 0; q < KB; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
     }
     const bf_d4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
@@ -564,7 +571,10 @@ __device__ inline void bf_polar_rows_x(int d, int ti, int tj, int lane, const do
     }
 }
 
-__global__ __launch_bounds__(1024) void bf_polar_rows_kernel(int d, const double *a, double *x, int n_iter, double *work, double *resid,
+// NW waves per workgroup (= tiles per row block); KB k-steps of operands on their way together: all of a product at d <= 128 with
+// the 256 registers eight waves leave a lane, a quarter of one with sixteen waves
+template <int NW, int KB>
+__global__ __launch_bounds__(64 * NW) void bf_polar_rows_kernel(int d, const double *a, double *x, int n_iter, double *work, double *resid,
                                                             unsigned int *counter, unsigned long long *dev_slots) {
     extern __shared__ double bf_polar_tl[];
     const int nt = (d + 15) / 16, ti = blockIdx.x, tj = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -595,11 +605,11 @@ __global__ __launch_bounds__(1024) void bf_polar_rows_kernel(int d, const double
     double r_last = 1.;
     bool converged = false;
     for (int it = 0; it < n_iter; ++it) {
-        double dv = bf_polar_rows_t(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
+        double dv = bf_polar_rows_t<KB>(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
         dv = bf_wave_max_nn(dv);
         if (lane == 0) atomicMax(&dev_slots[it], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
         __syncthreads();
-        bf_polar_rows_x(d, ti, tj, lane, src, sc, bf_polar_tl, ld, dst);
+        bf_polar_rows_x<KB>(d, ti, tj, lane, src, sc, bf_polar_tl, ld, dst);
         bf_grid_barrier_ra(counter, ++phase * nwg);
         src = dst;
         sc = 1.;
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(1024) void bf_polar_rows_kernel(int d, const double
         if (r_last < 1e-13) { converged = true; break; }
     }
     if (!converged) {   // the steps ran out (or there were none): the measure of the iterate they ended on
-        double dv = bf_polar_rows_t(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
+        double dv = bf_polar_rows_t<KB>(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
         dv = bf_wave_max_nn(dv);
         if (lane == 0) atomicMax(&dev_slots[n_iter], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
         bf_grid_barrier_ra(counter, ++phase * nwg);
@@ -634,8 +644,12 @@ extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x,
         if (int rc = ensure_ws(ctx, ws)) return rc;
         unsigned int *counter = (unsigned int *)ctx->scratch;
         BF_HIP_CHECK(hipMemsetAsync(counter, 0, ws, ctx->stream));
-        hipLaunchKernelGGL(bf_polar_rows_kernel, dim3(nt), dim3(64 * nt), (size_t)16 * (16 * nt + 4) * sizeof(double), ctx->stream, d, a, x,
-                           n_iter, work, resid, counter, (unsigned long long *)((char *)ctx->scratch + 64));
+        const size_t lds = (size_t)16 * (16 * nt + 4) * sizeof(double);
+        unsigned long long *slots = (unsigned long long *)((char *)ctx->scratch + 64);
+        if (nt <= 8)
+            hipLaunchKernelGGL((bf_polar_rows_kernel<8, 32>), dim3(nt), dim3(64 * nt), lds, ctx->stream, d, a, x, n_iter, work, resid, counter, slots);
+        else
+            hipLaunchKernelGGL((bf_polar_rows_kernel<16, 8>), dim3(nt), dim3(64 * nt), lds, ctx->stream, d, a, x, n_iter, work, resid, counter, slots);
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }

@@ -433,7 +433,8 @@ def test_polar_ns_is_the_orthogonal_polar_factor(d):
     against the SVD's polar factor; its two forms (a workgroup per row block with one grid barrier per step / a tile per wave with
     two) take bit-identical steps; residual reported, early stop, n_iter = 0."""
     import torch
-    from bayesfast_amd import _lib, debug_set
+    from bayesfast_amd import _lib
+    from bayesfast_amd._lib import debug_set
     from bayesfast_amd.device import get_context, _ptr
     ctx = get_context(0)
     rng = np.random.default_rng(d)
