@@ -575,8 +575,11 @@ __device__ inline void bf_polar_rows_x(int d, int ti, int tj, int lane, const do
 // the 256 registers eight waves leave a lane, a quarter of one with sixteen waves
 template <int NW, int KB>
 __global__ __launch_bounds__(64 * NW) void bf_polar_rows_kernel(int d, const double *a, double *x, int n_iter, double *work, double *resid,
-                                                            unsigned int *counter, unsigned long long *dev_slots) {
+                                                            unsigned int *counter, unsigned long long *dev_slots, unsigned long long *stamps) {
     extern __shared__ double bf_polar_tl[];
+    int n_stamp = 0;
+#define BF_POLAR_STAMP() do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0 && n_stamp < 60) stamps[n_stamp++] = wall_clock64(); } while (0)
+    BF_POLAR_STAMP();
     const int nt = (d + 15) / 16, ti = blockIdx.x, tj = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = 16 * nt + 4;
     const unsigned int nwg = gridDim.x;
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(64 * NW) void bf_polar_rows_kernel(int d, const dou
         mr = r > mr ? r : mr;
     }
     for (int o = 32; o > 0; o >>= 1) { mc = fmax(mc, __shfl_xor(mc, o, 64)); mr = fmax(mr, __shfl_xor(mr, o, 64)); }
+    BF_POLAR_STAMP();
     const double *src = a;
     double sc = 1. / sqrt(mc * mr);
     double *dst = x;
@@ -608,9 +612,13 @@ __global__ __launch_bounds__(64 * NW) void bf_polar_rows_kernel(int d, const dou
         double dv = bf_polar_rows_t<KB>(d, ti, tj, lane, src, sc, bf_polar_tl, ld);
         dv = bf_wave_max_nn(dv);
         if (lane == 0) atomicMax(&dev_slots[it], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
+        BF_POLAR_STAMP();
         __syncthreads();
+        BF_POLAR_STAMP();
         bf_polar_rows_x<KB>(d, ti, tj, lane, src, sc, bf_polar_tl, ld, dst);
+        BF_POLAR_STAMP();
         bf_grid_barrier_ra(counter, ++phase * nwg);
+        BF_POLAR_STAMP();
         src = dst;
         sc = 1.;
         dst = (dst == x) ? Y : x;
@@ -634,22 +642,188 @@ __global__ __launch_bounds__(64 * NW) void bf_polar_rows_kernel(int d, const dou
     if (ti == 0 && tj == 0 && lane == 0) resid[0] = r_last;
 }
 
+// Round 6c, d <= 128: the whole of X in LDS.  The stamps of the row-block form said where a step goes: 19 us in the T tiles and
+// 7 us in the update against 3 us in the grid barrier -- the operand loads, 16 (or 4) cache lines per instruction straight after the
+// barrier's invalidate.  Here every workgroup copies X (<= 128 KB) into its LDS with row-contiguous loads, all of them on their way
+// together, and both products take their operands from LDS (row stride 16 nt + 4 doubles: two lanes a bank, the minimum for 64
+// eight-byte reads).  |A|_1, |A|_inf and the scaling run on the LDS copy as well.  Same tiles, same accumulation chains: iterates
+// bit-identical to the other forms'.
+#define BF_POLAR_LDS_MAXT 8
+__device__ inline void bf_polar_lds_load(int d, int ld, const double *__restrict__ X, double *Xl, int nthr) {
+    // element e = tid + nthr p of the row-major d x d matrix: (row, col) advanced without a division per element
+    const int total = d * d, step_r = nthr / d, step_c = nthr % d;
+    int e = threadIdx.x, row = e / d, col = e % d;
+    for (; e < total;) {
+        double v[16];
+        int rr[16], cc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            rr[q] = row, cc[q] = col;
+            v[q] = (e < total) ? X[e] : 0.;
+            e += nthr;
+            row += step_r, col += step_c;
+            if (col >= d) { col -= d; ++row; }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (rr[q] < d) Xl[rr[q] * ld + cc[q]] = v[q];
+    }
+}
+
+template <bool TRANSB>
+__device__ inline bf_d4 bf_polar_lds_tile(int ns, const double *ap, const double *bp, int ld) {
+    // a[s] = ap[4 s] (row fixed per lane, k = 4 s + kk folded into ap); b[s] = TRANSB ? bp[4 s] : bp[4 s ld]
+    bf_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bf_d4{0., 0., 0., 0.};
+    for (int s0 = 0; s0 < ns; s0 += 16) {
+        double a[16], b[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const bool ok = s0 + q < ns;
+            a[q] = ok ? ap[4 * (s0 + q)] : 0.;
+            b[q] = ok ? (TRANSB ? bp[4 * (s0 + q)] : bp[(size_t)4 * (s0 + q) * ld]) : 0.;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc[q & 3], 0, 0, 0);
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__global__ __launch_bounds__(64 * BF_POLAR_LDS_MAXT) void bf_polar_lds_kernel(int d, const double *a, double *x, int n_iter, double *work,
+                                                                             double *resid, unsigned int *counter,
+                                                                             unsigned long long *dev_slots, unsigned long long *stamps) {
+    extern __shared__ double bf_polar_sm[];
+    int n_stamp = 0;
+    BF_POLAR_STAMP();
+    const int nt = (d + 15) / 16, ti = blockIdx.x, tj = threadIdx.x >> 6, lane = threadIdx.x & 63, nthr = blockDim.x;
+    const int ld = 16 * nt + 4, kk = lane >> 4;
+    const unsigned int nwg = gridDim.x;
+    double *Xl = bf_polar_sm, *Tl = bf_polar_sm + 16 * nt * ld, *red = Tl + 16 * ld;   // red: 2 * BF_POLAR_LDS_MAXT doubles
+    double *Y = work;
+    for (int e = threadIdx.x; e < 17 * nt * ld; e += nthr) bf_polar_sm[e] = 0.;   // (rows and columns past d stay zero: no guards in the products)
+    __syncthreads();
+    bf_polar_lds_load(d, ld, a, Xl, nthr);
+    __syncthreads();
+    // |A|_1 (column sums) and |A|_inf (row sums) on the LDS copy: wave w takes columns and rows w, w + nt, ...
+    {
+        double mc = 0., mr = 0.;
+        for (int j = tj; j < d; j += nt) {
+            double c = 0., r = 0.;
+            for (int i = lane; i < d; i += 64) { c += fabs(Xl[i * ld + j]); r += fabs(Xl[j * ld + i]); }
+            for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); }
+            mc = c > mc ? c : mc;
+            mr = r > mr ? r : mr;
+        }
+        if (lane == 0) { red[2 * tj] = mc; red[2 * tj + 1] = mr; }
+    }
+    __syncthreads();
+    double sc;
+    {
+        double mc = 0., mr = 0.;
+        for (int w = 0; w < nt; ++w) { mc = fmax(mc, red[2 * w]); mr = fmax(mr, red[2 * w + 1]); }
+        sc = 1. / sqrt(mc * mr);
+    }
+    for (int e = threadIdx.x; e < 16 * nt * ld; e += nthr) Xl[e] = Xl[e] * sc;     // X_0 = A / sqrt(|A|_1 |A|_inf)
+    __syncthreads();
+    BF_POLAR_STAMP();
+    const int ns = (d + 3) / 4;
+    const double *src = a;
+    double *dst = x;
+    unsigned int phase = 0;
+    double r_last = 1.;
+    bool converged = false, loaded = true;
+    const double *arow = Xl + (16 * ti + (lane & 15)) * ld + kk, *brow = Xl + (16 * tj + (lane & 15)) * ld + kk;
+    const double *trow = Tl + (lane & 15) * ld + kk, *xcol = Xl + kk * ld + 16 * tj + (lane & 15);
+    auto t_tile = [&]() -> double {     // this wave's tile of T = X X^T into Tl; max |T - I| over it
+        const bf_d4 t = bf_polar_lds_tile<true>(ns, arow, brow, ld);
+        double dv = 0.;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr = 4 * r + kk, row = 16 * ti + lr, col = 16 * tj + (lane & 15);
+            const bool in = row < d && col < d;
+            const double tv = in ? 0. + 1. * t[r] : 0.;
+            Tl[lr * ld + col] = tv;
+            if (in) {
+                const double v = fabs(tv - (row == col ? 1. : 0.));
+                dv = (v > dv || v != v) ? v : dv;
+            }
+        }
+        return bf_wave_max_nn(dv);
+    };
+    for (int it = 0; it < n_iter; ++it) {
+        if (!loaded) {
+            bf_polar_lds_load(d, ld, src, Xl, nthr);
+            __syncthreads();
+        }
+        loaded = false;
+        BF_POLAR_STAMP();
+        const double dv = t_tile();
+        if (lane == 0) atomicMax(&dev_slots[it], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
+        __syncthreads();
+        BF_POLAR_STAMP();
+        {
+            const bf_d4 t = bf_polar_lds_tile<false>(ns, trow, xcol, ld);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * r + kk, col = 16 * tj + (lane & 15);
+                if (row < d && col < d) dst[(size_t)row * d + col] = 1.5 * Xl[row * ld + col] + -0.5 * t[r];
+            }
+        }
+        BF_POLAR_STAMP();
+        bf_grid_barrier_ra(counter, ++phase * nwg);
+        BF_POLAR_STAMP();
+        src = dst;
+        dst = (dst == x) ? Y : x;
+        r_last = __longlong_as_double((long long)__hip_atomic_load(&dev_slots[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (r_last < 1e-13) { converged = true; break; }
+    }
+    if (!converged) {   // the steps ran out (or there were none): the measure of the iterate they ended on
+        if (!loaded) {
+            bf_polar_lds_load(d, ld, src, Xl, nthr);
+            __syncthreads();
+        }
+        const double dv = t_tile();
+        if (lane == 0) atomicMax(&dev_slots[n_iter], (unsigned long long)__double_as_longlong(dv != dv ? __builtin_inf() : dv));
+        bf_grid_barrier_ra(counter, ++phase * nwg);
+        r_last = __longlong_as_double((long long)__hip_atomic_load(&dev_slots[n_iter], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (src != x) {   // the result belongs in x: this wave's tile (from the LDS copy when no step was taken: X_0)
+        for (int e = lane; e < 256; e += 64) {
+            const int row = 16 * ti + (e >> 4), col = 16 * tj + (e & 15);
+            if (row < d && col < d) x[(size_t)row * d + col] = (src == a) ? Xl[row * ld + col] : src[(size_t)row * d + col];
+        }
+    }
+    if (ti == 0 && tj == 0 && lane == 0) resid[0] = r_last;
+}
+
 extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || d < 1 || d > 1024 || !a || !x || !work || !resid || n_iter < 0)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_polar_ns: invalid argument");
     const int nt = (d + 15) / 16;
-    if (d <= 256 && !bf_tune().polar_tiles) {   // one launch, a workgroup per 16-row block, one grid barrier per step
+    if (d <= 256 && bf_tune().polar_tiles != 1) {   // one launch, a workgroup per 16-row block, one grid barrier per step
         const size_t ws = 64 + (size_t)(n_iter + 2) * sizeof(unsigned long long);
         if (int rc = ensure_ws(ctx, ws)) return rc;
         unsigned int *counter = (unsigned int *)ctx->scratch;
         BF_HIP_CHECK(hipMemsetAsync(counter, 0, ws, ctx->stream));
         const size_t lds = (size_t)16 * (16 * nt + 4) * sizeof(double);
         unsigned long long *slots = (unsigned long long *)((char *)ctx->scratch + 64);
-        if (nt <= 8)
-            hipLaunchKernelGGL((bf_polar_rows_kernel<8, 32>), dim3(nt), dim3(64 * nt), lds, ctx->stream, d, a, x, n_iter, work, resid, counter, slots);
+        if (nt <= BF_POLAR_LDS_MAXT && bf_tune().polar_tiles != 2) {
+            const size_t lds_x = ((size_t)17 * nt * (16 * nt + 4) + 2 * BF_POLAR_LDS_MAXT) * sizeof(double);   // 152 KB at d = 128
+            static size_t lds_set = 0;
+            if (lds_x > lds_set) {
+                BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_polar_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+                lds_set = lds_x;
+            }
+            hipLaunchKernelGGL(bf_polar_lds_kernel, dim3(nt), dim3(64 * nt), lds_x, ctx->stream, d, a, x, n_iter, work, resid, counter, slots,
+                               bf_tune().gstamps);
+        }
+        else if (nt <= 8)
+            hipLaunchKernelGGL((bf_polar_rows_kernel<8, 32>), dim3(nt), dim3(64 * nt), lds, ctx->stream, d, a, x, n_iter, work, resid, counter, slots, bf_tune().gstamps);
         else
-            hipLaunchKernelGGL((bf_polar_rows_kernel<16, 8>), dim3(nt), dim3(64 * nt), lds, ctx->stream, d, a, x, n_iter, work, resid, counter, slots);
+            hipLaunchKernelGGL((bf_polar_rows_kernel<16, 8>), dim3(nt), dim3(64 * nt), lds, ctx->stream, d, a, x, n_iter, work, resid, counter, slots,
+                               bf_tune().gstamps);
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }

@@ -430,8 +430,8 @@ def test_device_spline_build_is_the_host_construction(kind):
 @pytest.mark.parametrize('d', [5, 16, 48, 100, 128, 200, 256, 300])
 def test_polar_ns_is_the_orthogonal_polar_factor(d):
     """bfhip_polar_ns (FastICA's symmetric decorrelation, scikit-learn's _sym_decorrelation as SIT calls it, transforms/sit.py:235-244)
-    against the SVD's polar factor; its two forms (a workgroup per row block with one grid barrier per step / a tile per wave with
-    two) take bit-identical steps; residual reported, early stop, n_iter = 0."""
+    against the SVD's polar factor; its forms (X in LDS, a workgroup per row block, one grid barrier per step / the same with operands from L2 / a tile per
+    wave with two barriers) take bit-identical steps; residual reported, early stop, n_iter = 0."""
     import torch
     from bayesfast_amd import _lib
     from bayesfast_amd._lib import debug_set
@@ -456,11 +456,11 @@ def test_polar_ns_is_the_orthogonal_polar_factor(d):
     x3, res3 = run(3)
     assert res3 > 1e-13                                      # three steps are not enough for this matrix ...
     np.testing.assert_allclose(np.abs(x3 @ x3.T - np.eye(d)).max(), res3, rtol=1e-9)   # ... and the residual says how far they got
-    if d <= 256:
-        x3t, res3t = run(3, tiles=1)
+    for form in ((1, 2) if d <= 128 else (1,) if d <= 256 else ()):    # 1: a tile per wave, 2: row blocks with operands from L2
+        x3t, res3t = run(3, tiles=form)
         np.testing.assert_array_equal(x3, x3t)
         assert res3 == res3t
-        xt, rest = run(60, tiles=1)
+        xt, rest = run(60, tiles=form)
         np.testing.assert_allclose(xt, x, rtol=0, atol=1e-14)
     x0, res0 = run(0)
     scale = np.sqrt(np.abs(A).sum(0).max() * np.abs(A).sum(1).max())

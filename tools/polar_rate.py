@@ -30,6 +30,15 @@ def timed(f, reps=20):
 for it in (0, 10, 40):
     t = timed(lambda: _lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(A), _ptr(X), it, _ptr(work), _ptr(work[2 * d * d:]))))
     print('bfhip_polar_ns d=%d n_iter=%d: %.1f us, resid %.2e' % (d, it, t, float(work[2 * d * d])))
+# phase stamps of workgroup 0 (100 MHz clock): start, norms, then per step: T tile, workgroup barrier, update, grid barrier
+st = torch.zeros(64, dtype=torch.int64, device=A.device)
+_lib.check(ctx._lib.bfhip_debug_buffer(b'gstamps', _ptr(st)))
+_lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(A), _ptr(X), 5, _ptr(work), _ptr(work[2 * d * d:])))
+torch.cuda.synchronize()
+_lib.check(ctx._lib.bfhip_debug_buffer(b'gstamps', None))
+t = st.cpu().numpy()
+t = t[t > 0]
+print('stamps (us since start):', np.round((t - t[0]) / 100., 2))
 u, s, vt = np.linalg.svd(A.cpu().numpy())
 print('error against the SVD polar factor: %.2e' % np.abs(X.cpu().numpy() - u @ vt).max())
 x1 = ctx.tensor(rng.normal(size=(n, d)))
