@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * BF_POLAR_LDS_MAXT) void bf_polar_lds_kernel(in
     const unsigned int nwg = gridDim.x;
     double *Xl = bf_polar_sm, *Tl = bf_polar_sm + 16 * nt * ld, *red = Tl + 16 * ld;   // red: 2 * BF_POLAR_LDS_MAXT doubles
     double *Y = work;
-    for (int e = threadIdx.x; e < 17 * nt * ld; e += nthr) bf_polar_sm[e] = 0.;   // (rows and columns past d stay zero: no guards in the products)
+    for (int e = threadIdx.x; e < (16 * nt + 16) * ld; e += nthr) bf_polar_sm[e] = 0.;   // (rows and columns past d stay zero: no guards in the products)
     __syncthreads();
     bf_polar_lds_load(d, ld, a, Xl, nthr);
     __syncthreads();
@@ -810,7 +810,7 @@ extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x,
         const size_t lds = (size_t)16 * (16 * nt + 4) * sizeof(double);
         unsigned long long *slots = (unsigned long long *)((char *)ctx->scratch + 64);
         if (nt <= BF_POLAR_LDS_MAXT && bf_tune().polar_tiles != 2) {
-            const size_t lds_x = ((size_t)17 * nt * (16 * nt + 4) + 2 * BF_POLAR_LDS_MAXT) * sizeof(double);   // 152 KB at d = 128
+            const size_t lds_x = ((size_t)(16 * nt + 16) * (16 * nt + 4) + 2 * BF_POLAR_LDS_MAXT) * sizeof(double);   // 152 KB at d = 128
             static size_t lds_set = 0;
             if (lds_x > lds_set) {
                 BF_HIP_CHECK(hipFuncSetAttribute((const void *)bf_polar_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
