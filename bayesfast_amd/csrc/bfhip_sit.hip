@@ -705,25 +705,25 @@ __global__ __launch_bounds__(64 * BF_POLAR_LDS_MAXT) void bf_polar_lds_kernel(in
     __syncthreads();
     bf_polar_lds_load(d, ld, a, Xl, nthr);
     __syncthreads();
-    // |A|_1 (column sums) and |A|_inf (row sums) on the LDS copy: wave w takes columns and rows w, w + nt, ...
+    // |A|_1 (column sums) and |A|_inf (row sums) on the LDS copy, each sum in index order by one thread (the other forms' order: the
+    // same scale to the last bit): threads 0 .. d-1 a column each, d .. 2d-1 a row each (the workgroup has >= 4 d threads)
     {
-        double mc = 0., mr = 0.;
-        for (int j = tj; j < d; j += nt) {
-            double c = 0., r = 0.;
-            for (int i = lane; i < d; i += 64) { c += fabs(Xl[i * ld + j]); r += fabs(Xl[j * ld + i]); }
-            for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); r += __shfl_xor(r, o, 64); }
-            mc = c > mc ? c : mc;
-            mr = r > mr ? r : mr;
+        const int t = threadIdx.x;
+        if (t < 2 * d) {
+            double sum = 0.;
+            if (t < d) for (int i = 0; i < d; ++i) sum += fabs(Xl[i * ld + t]);
+            else for (int i = 0; i < d; ++i) sum += fabs(Xl[(t - d) * ld + i]);
+            Tl[t] = sum;
         }
-        if (lane == 0) { red[2 * tj] = mc; red[2 * tj + 1] = mr; }
     }
     __syncthreads();
     double sc;
     {
         double mc = 0., mr = 0.;
-        for (int w = 0; w < nt; ++w) { mc = fmax(mc, red[2 * w]); mr = fmax(mr, red[2 * w + 1]); }
+        for (int j = 0; j < d; ++j) { mc = Tl[j] > mc ? Tl[j] : mc; mr = Tl[d + j] > mr ? Tl[d + j] : mr; }
         sc = 1. / sqrt(mc * mr);
     }
+    __syncthreads();
     for (int e = threadIdx.x; e < 16 * nt * ld; e += nthr) Xl[e] = Xl[e] * sc;     // X_0 = A / sqrt(|A|_1 |A|_inf)
     __syncthreads();
     BF_POLAR_STAMP();
