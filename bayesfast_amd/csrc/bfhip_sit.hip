@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64 * BF_POLAR_LDS_MAXT) void bf_polar_lds_kernel(in
     const int nt = (d + 15) / 16, ti = blockIdx.x, tj = threadIdx.x >> 6, lane = threadIdx.x & 63, nthr = blockDim.x;
     const int ld = 16 * nt + 4, kk = lane >> 4;
     const unsigned int nwg = gridDim.x;
-    double *Xl = bf_polar_sm, *Tl = bf_polar_sm + 16 * nt * ld, *red = Tl + 16 * ld;   // red: 2 * BF_POLAR_LDS_MAXT doubles
+    double *Xl = bf_polar_sm, *Tl = bf_polar_sm + 16 * nt * ld;
     double *Y = work;
     for (int e = threadIdx.x; e < (16 * nt + 16) * ld; e += nthr) bf_polar_sm[e] = 0.;   // (rows and columns past d stay zero: no guards in the products)
     __syncthreads();
