@@ -21,6 +21,7 @@ with ``sklearn.decomposition.FastICA`` on the same data and seed is tested to 1e
 (tests/test_evidence.py); the fixed point of a run that has not converged after ``max_iter`` iterations (the reference warns
 about those) is as sensitive to rounding here as it is there.
 """
+import time
 import warnings
 
 import numpy as np
@@ -81,7 +82,7 @@ _NS_ITERS = 60      # Newton-Schulz steps of the polar factor (covers singular v
                     # 20 us each at d = 128: the iteration costs about what the host's eigh did -- the gain is the missing round trips)
 _NS_RESID = 1e-11   # ... accepted when max |X X^T - I| ends below this; otherwise the chunk is redone with the host's eigh
 _CHUNK = 10         # iterations run ahead between two looks at the convergence test
-GRAPH_STATS = {'captured': 0, 'failed': 0, 'replayed': 0}   # chunk graphs of this process (tests look at it)
+GRAPH_STATS = {'captured': 0, 'failed': 0, 'replayed': 0, 'capture_s': 0., 'eager_s': 0., 'wait_s': 0.}   # chunk graphs of this process (tests and tools look at it)
 
 
 def _polar_newton_schulz(A, eye, ctx=None, work=None):
@@ -167,17 +168,22 @@ def _ica_par(ctx, x1, W, max_iter, tol):
     with blas_single_thread():
         while n_iter < max_iter:
             start = Wd.clone()
+            t_0 = time.perf_counter()
             if n_iter == 0 or polar_ctx is None:
                 chunk()
+                GRAPH_STATS['eager_s'] += time.perf_counter() - t_0
             else:
                 if graph is None and n_iter == _CHUNK:
                     graph = capture()       # (capturing does not run anything)
+                    GRAPH_STATS['capture_s'] += time.perf_counter() - t_0
                 if graph is not None:
                     graph.replay()
                     GRAPH_STATS['replayed'] += 1
                 else:
                     chunk()
+            t_0 = time.perf_counter()
             m = meas.cpu().numpy()
+            GRAPH_STATS['wait_s'] += time.perf_counter() - t_0
             left = min(_CHUNK, max_iter - n_iter)
             if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
                 # (rare) the polar iteration fell short somewhere in this chunk: the same iterations with the host's eigh

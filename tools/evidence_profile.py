@@ -32,4 +32,6 @@ with warnings.catch_warnings():
     pr.disable()
 print('gbs %.1f ms, logZ %.4f +- %.4f (exact %.4f)' % ((time.perf_counter() - t0) * 1e3, logz, err,
       0.5 * d * np.log(2. * np.pi) + float(np.sum(np.log(np.diag(chol))))), flush=True)
+from bayesfast_amd.transforms import ica
+print('FastICA chunks:', ica.GRAPH_STATS)
 pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
