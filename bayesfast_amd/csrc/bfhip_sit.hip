@@ -797,18 +797,134 @@ __global__ __launch_bounds__(64 * BF_POLAR_LDS_MAXT) void bf_polar_lds_kernel(in
     if (ti == 0 && tj == 0 && lane == 0) resid[0] = r_last;
 }
 
+// ---- the glue of a FastICA iteration (scikit-learn's _ica_par with the logcosh contrast, as SIT calls it: transforms/sit.py:235-244) ----
+// Between the two products of an iteration (Y = X1 W^T and G^T X1, library GEMMs) and the polar factor sat ~20 small framework
+// kernels and five device-to-device copies; as nodes of the chunk's HIP graph the copies alone cost more than the arithmetic.
+// Three kernels replace them.
+
+// G = tanh(Y) in place for Y (n_pad, d) and, per block of ICA_RB rows, the column sums of g'(y) = 1 - tanh(y)^2 over the rows < n
+// (rows n .. n_pad are zero padding: they stay zero and are not counted).  partial (n_blocks, d).
+#define ICA_RB 128
+__global__ __launch_bounds__(256) void bf_ica_tanh_kernel(long n, long n_pad, int d, double *__restrict__ Y, double *__restrict__ partial) {
+    __shared__ double red[256];
+    const int cw = d < 256 ? d : 256, ry = 256 / cw;          // cw columns side by side, ry row groups
+    const int c0 = threadIdx.x % cw, r0 = threadIdx.x / cw;
+    const long row0 = (long)blockIdx.x * ICA_RB;
+    for (int cb = 0; cb < d; cb += cw) {
+        const int c = cb + c0;
+        double sum = 0.;
+        if (r0 < ry && c < d)
+            for (long r = row0 + r0; r < row0 + ICA_RB && r < n_pad; r += ry) {
+                const double g = tanh(Y[r * d + c]);
+                Y[r * d + c] = g;
+                if (r < n) sum += 1. - g * g;
+            }
+        red[threadIdx.x] = (r0 < ry && c < d) ? sum : 0.;
+        __syncthreads();
+        if (r0 == 0 && c < d) {
+            double t = 0.;
+            for (int q = 0; q < ry; ++q) t += red[q * cw + c0];
+            partial[(size_t)blockIdx.x * d + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// A = (sum_b P[b]) / n - gmean[:, None] W with gmean[i] = (sum_blk partial[blk][i]) / n: one workgroup per row i.
+__global__ __launch_bounds__(256) void bf_ica_assemble_kernel(int d, int nb, const double *__restrict__ P, long n, int n_blk,
+                                                             const double *__restrict__ partial, const double *__restrict__ W,
+                                                             double *__restrict__ A) {
+    __shared__ double gsh[4];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double g = 0.;
+    for (int b = threadIdx.x; b < n_blk; b += 256) g += partial[(size_t)b * d + i];
+    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+    if (lane == 0) gsh[wave] = g;
+    __syncthreads();
+    const double gmean = (((gsh[0] + gsh[1]) + gsh[2]) + gsh[3]) / (double)n;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        double s = 0.;
+        for (int b = 0; b < nb; ++b) s += P[((size_t)b * d + i) * d + j];
+        A[(size_t)i * d + j] = s / (double)n - gmean * W[(size_t)i * d + j];
+    }
+}
+
+// after the polar factor W1 of A: lim = max_i | |sum_j W1[i][j] W[i][j]| - 1 | (scikit-learn's convergence measure) -> meas[k],
+// the polar iteration's residual -> meas[n_meas + k], W1 -> Wbuf[k] and -> W.  One workgroup.
+__global__ __launch_bounds__(256) void bf_ica_post_kernel(int d, const double *__restrict__ W1, double *__restrict__ W,
+                                                         const double *__restrict__ resid, int k, int n_meas, double *__restrict__ Wbuf,
+                                                         double *__restrict__ meas) {
+    __shared__ double msh[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double mx = 0.;
+    for (int i = wave; i < d; i += 4) {
+        double dot = 0.;
+        for (int j = lane; j < d; j += 64) dot += W1[(size_t)i * d + j] * W[(size_t)i * d + j];
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        const double v = fabs(fabs(dot) - 1.);
+        mx = (v > mx || v != v) ? v : mx;
+    }
+    if (lane == 0) msh[wave] = mx;
+    __syncthreads();     // (every row's dot product has read W: it may be overwritten now)
+    double *dst = Wbuf + (size_t)k * d * d;
+    for (int e = threadIdx.x; e < d * d; e += 256) {
+        const double v = W1[e];
+        dst[e] = v;
+        W[e] = v;
+    }
+    if (threadIdx.x == 0) {
+        double m = msh[0];
+        for (int q = 1; q < 4; ++q) m = (msh[q] > m || msh[q] != msh[q]) ? msh[q] : m;
+        meas[k] = m;
+        meas[n_meas + k] = resid[0];
+    }
+}
+
+extern "C" int bfhip_ica_tanh(bfhip_ctx *ctx, long n, long n_pad, int d, double *y, double *partial) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || n < 1 || n_pad < n || d < 1 || !y || !partial) return bf_set_error(BFHIP_ERR_ARG, "bfhip_ica_tanh: invalid argument");
+    hipLaunchKernelGGL(bf_ica_tanh_kernel, dim3((unsigned)((n_pad + ICA_RB - 1) / ICA_RB)), dim3(256), 0, ctx->stream, n, n_pad, d, y, partial);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bfhip_ica_assemble(bfhip_ctx *ctx, int d, int nb, const double *p, long n, long n_pad, const double *partial,
+                                  const double *w, double *a) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || d < 1 || nb < 1 || n < 1 || n_pad < n || !p || !partial || !w || !a)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_ica_assemble: invalid argument");
+    hipLaunchKernelGGL(bf_ica_assemble_kernel, dim3(d), dim3(256), 0, ctx->stream, d, nb, p, n, (int)((n_pad + ICA_RB - 1) / ICA_RB), partial, w, a);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bfhip_ica_post(bfhip_ctx *ctx, int d, const double *w1, double *w, const double *resid, int k, int n_meas, double *wbuf,
+                              double *meas) {
+    BfDeviceGuard dev_guard(ctx);
+    if (!ctx || d < 1 || k < 0 || k >= n_meas || !w1 || !w || !resid || !wbuf || !meas)
+        return bf_set_error(BFHIP_ERR_ARG, "bfhip_ica_post: invalid argument");
+    hipLaunchKernelGGL(bf_ica_post_kernel, dim3(1), dim3(256), 0, ctx->stream, d, w1, w, resid, k, n_meas, wbuf, meas);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void bf_zero_words_kernel(unsigned int *p, int n) {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) p[e] = 0u;
+}
+
 extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || d < 1 || d > 1024 || !a || !x || !work || !resid || n_iter < 0)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_polar_ns: invalid argument");
     const int nt = (d + 15) / 16;
     if (d <= 256 && bf_tune().polar_tiles != 1) {   // one launch, a workgroup per 16-row block, one grid barrier per step
+        // the arrival counter and one residual slot per step live at the end of the CALLER's work array (not in the context's scratch,
+        // which another call may reallocate: a HIP graph that holds this launch must stay valid)
         const size_t ws = 64 + (size_t)(n_iter + 2) * sizeof(unsigned long long);
-        if (int rc = ensure_ws(ctx, ws)) return rc;
-        unsigned int *counter = (unsigned int *)ctx->scratch;
-        BF_HIP_CHECK(hipMemsetAsync(counter, 0, ws, ctx->stream));
+        unsigned int *counter = (unsigned int *)(work + 2 * (size_t)d * d);
+        hipLaunchKernelGGL(bf_zero_words_kernel, dim3(1), dim3(256), 0, ctx->stream, counter, (int)(ws / 4));
         const size_t lds = (size_t)16 * (16 * nt + 4) * sizeof(double);
-        unsigned long long *slots = (unsigned long long *)((char *)ctx->scratch + 64);
+        unsigned long long *slots = (unsigned long long *)((char *)counter + 64);
         if (nt <= BF_POLAR_LDS_MAXT && bf_tune().polar_tiles != 2) {
             const size_t lds_x = ((size_t)(16 * nt + 16) * (16 * nt + 4) + 2 * BF_POLAR_LDS_MAXT) * sizeof(double);   // 152 KB at d = 128
             static size_t lds_set = 0;
@@ -829,11 +945,10 @@ extern "C" int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x,
     }
     if (d <= 512) {   // one launch, grid barriers between the products (every workgroup resident: at most 1024 single-wave workgroups)
         const size_t ws = 64 + (size_t)(n_iter + 2) * sizeof(unsigned long long);
-        if (int rc = ensure_ws(ctx, ws)) return rc;
-        unsigned int *counter = (unsigned int *)ctx->scratch;
-        BF_HIP_CHECK(hipMemsetAsync(counter, 0, ws, ctx->stream));   // (the arrival counter and one residual slot per step)
+        unsigned int *counter = (unsigned int *)(work + 2 * (size_t)d * d);
+        hipLaunchKernelGGL(bf_zero_words_kernel, dim3(1), dim3(256), 0, ctx->stream, counter, (int)(ws / 4));   // (a kernel: a memset node of a HIP graph costs far more)
         hipLaunchKernelGGL(bf_polar_ns_kernel, dim3((nt * nt + 3) / 4), dim3(256), 0, ctx->stream, d, a, x, n_iter, work, resid, counter,
-                           (unsigned long long *)((char *)ctx->scratch + 64));
+                           (unsigned long long *)((char *)counter + 64));
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }

@@ -99,8 +99,8 @@ def _polar_newton_schulz(A, eye, ctx=None, work=None):
         A = A.contiguous()
         X = torch.empty_like(A)
         if work is None:
-            work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=A.device)
-        res = work[2 * d * d:]
+            work = torch.empty((2 * d * d + _NS_ITERS + 11,), dtype=torch.float64, device=A.device)
+        res = work[-1:]
         _lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(A), _ptr(X), _NS_ITERS, _ptr(work), _ptr(res)))
         return X, res[0].clone()
     s = torch.sqrt(A.abs().sum(0).max() * A.abs().sum(1).max())
@@ -108,6 +108,120 @@ def _polar_newton_schulz(A, eye, ctx=None, work=None):
     for _ in range(_NS_ITERS):
         X = torch.addmm(X, X @ X.T, X, beta=1.5, alpha=-0.5)
     return X, (X @ X.T - eye).abs().max()
+
+
+_ROWS = 400         # rows per batch of the G^T X1 product (see _tn_product)
+_DEVICE_STATE = {}  # (device index, n, d) -> the chunk's buffers and its HIP graph (kept: a SIT fit calls FastICA once per iteration)
+
+
+class _ChunkState:
+    """Buffers of the device-resident iteration for one shape, and the chunk of ``_CHUNK`` iterations as a HIP graph."""
+
+    def __init__(self, ctx, n, d, dev):
+        import torch
+        self.ctx, self.n, self.d = ctx, n, d
+        self.n_pad = -(-n // _ROWS) * _ROWS                  # zero rows pad the last batch of the G^T X1 product
+        self.nb = self.n_pad // _ROWS
+        f = dict(dtype=torch.float64, device=dev)
+        self.x1 = torch.zeros((self.n_pad, d), **f)
+        self.Y = torch.empty((self.n_pad, d), **f)
+        self.P = torch.empty((self.nb, d, d), **f)
+        self.partial = torch.empty((-(-self.n_pad // 128), d), **f)
+        self.A, self.W1, self.W = (torch.empty((d, d), **f) for _ in range(3))
+        self.work = torch.empty((2 * d * d + _NS_ITERS + 11,), **f)    # bfhip_polar_ns: 2 d^2 + n_iter + 10, and the residual
+        self.Wbuf = torch.empty((_CHUNK, d, d), **f)
+        self.meas = torch.zeros((2, _CHUNK), **f)
+        self.graph = None
+        self.warm = False
+
+    def chunk(self):
+        """``_CHUNK`` iterations: two library products, three glue kernels and the polar kernel each -- no copies, no allocations."""
+        import torch
+        from .. import _lib
+        from ..device import _ptr
+        ctx, lib, d, h = self.ctx, self.ctx._lib, self.d, self.ctx.handle
+        Yb = self.Y.view(self.nb, _ROWS, d).transpose(1, 2)
+        Xb = self.x1.view(self.nb, _ROWS, d)
+        res = self.work[-1:]
+        for k in range(_CHUNK):
+            torch.mm(self.x1, self.W.T, out=self.Y)                                               # Y = X1 W^T
+            _lib.check(lib.bfhip_ica_tanh(h, self.n, self.n_pad, d, _ptr(self.Y), _ptr(self.partial)))   # G = tanh(Y), sums of g'
+            torch.bmm(Yb, Xb, out=self.P)                                                          # G^T X1 by row batches
+            _lib.check(lib.bfhip_ica_assemble(h, d, self.nb, _ptr(self.P), self.n, self.n_pad, _ptr(self.partial), _ptr(self.W),
+                                              _ptr(self.A)))
+            _lib.check(lib.bfhip_polar_ns(h, d, _ptr(self.A), _ptr(self.W1), _NS_ITERS, _ptr(self.work), _ptr(res)))
+            _lib.check(lib.bfhip_ica_post(h, d, _ptr(self.W1), _ptr(self.W), _ptr(res), k, _CHUNK, _ptr(self.Wbuf), _ptr(self.meas)))
+
+    def run_chunk(self):
+        import torch
+        t_0 = time.perf_counter()
+        if not self.warm:                       # the first chunk of a shape in this process: eager (the libraries' workspaces)
+            self.chunk()
+            self.warm = True
+            GRAPH_STATS['eager_s'] += time.perf_counter() - t_0
+            return
+        if self.graph is None and GRAPH_STATS['failed'] <= 2:
+            keep = self.ctx.stream
+            saved = self.W.clone()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    self.ctx.set_stream(torch.cuda.current_stream(self.x1.device))   # (the library's kernels: nodes of the graph)
+                    self.chunk()
+            except Exception:
+                g = None
+            finally:
+                self.ctx.set_stream(keep)
+            self.W.copy_(saved)
+            GRAPH_STATS['captured' if g is not None else 'failed'] += 1
+            GRAPH_STATS['capture_s'] += time.perf_counter() - t_0
+            self.graph = g
+        if self.graph is not None:
+            self.graph.replay()
+            GRAPH_STATS['replayed'] += 1
+        else:
+            self.chunk()
+
+
+def _ica_par_device(ctx, x1, W, max_iter, tol):
+    """``_ica_par`` on the GPU: see ``_ica_par``.  The chunk's buffers and graph live in ``_DEVICE_STATE`` per shape."""
+    import torch
+    n, d = x1.shape
+    key = (x1.device.index, n, d)
+    st = _DEVICE_STATE.get(key)
+    if st is None:
+        if len(_DEVICE_STATE) >= 4:             # (a handful of shapes at most: each holds ~3 copies of the data)
+            _DEVICE_STATE.pop(next(iter(_DEVICE_STATE)))
+        st = _DEVICE_STATE[key] = _ChunkState(ctx, n, d, x1.device)
+    st.ctx = ctx
+    st.x1[:n].copy_(x1)
+    st.W.copy_(torch.as_tensor(W, dtype=torch.float64, device=x1.device))
+    n_iter = 0
+    while n_iter < max_iter:
+        start = st.W.clone()
+        st.run_chunk()
+        t_0 = time.perf_counter()
+        m = st.meas.cpu().numpy()
+        GRAPH_STATS['wait_s'] += time.perf_counter() - t_0
+        left = min(_CHUNK, max_iter - n_iter)
+        if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
+            # (rare) the polar iteration fell short somewhere in this chunk: the same iterations with the host's eigh
+            Wh = start.cpu().numpy()
+            for k in range(left):
+                Wh, lim = _ica_step_host(ctx, x1, Wh)
+                n_iter += 1
+                if lim < tol:
+                    return Wh, n_iter, True
+            st.W.copy_(torch.as_tensor(Wh, dtype=torch.float64, device=x1.device))
+            continue
+        hit = np.flatnonzero(m[0, :left] < tol)
+        if hit.size:
+            k = int(hit[0])
+            return st.Wbuf[k].cpu().numpy(), n_iter + k + 1, True
+        if left < _CHUNK:   # max_iter fell inside the chunk: the iterate it ends on
+            return st.Wbuf[left - 1].cpu().numpy(), max_iter, False
+        n_iter += _CHUNK
+    return st.W.cpu().numpy(), n_iter, False
 
 
 def _ica_par(ctx, x1, W, max_iter, tol):
@@ -118,11 +232,15 @@ def _ica_par(ctx, x1, W, max_iter, tol):
     convergence measures ONCE (one synchronisation per chunk instead of one per iteration plus a host eigh each: 612 of them were
     0.57 s of a config-5 GBS run, profiles/r05b_evidence_profile.log); it stops at the FIRST iterate below ``tol`` exactly as
     the sequential loop does, so the iteration count is scikit-learn's.  A chunk whose polar iteration did not reach ``_NS_RESID`` is
-    redone with the host's eigen-decomposition (``_ica_step_host``).  The first chunk runs eagerly; from the second on the chunk is
-    ONE HIP graph (captured with the library's context pointed at the capturing stream, so that the polar kernel is a node of it):
-    the ~25 launches of an iteration were 0.7 ms of host time against ~0.6 ms of device time."""
+    redone with the host's eigen-decomposition (``_ica_step_host``).  On the GPU (``_ica_par_device``) an iteration is two library
+    products, three glue kernels (``bfhip_ica_tanh / _assemble / _post``) and ``bfhip_polar_ns``, and the chunk is ONE HIP graph
+    captured once per shape with the library's context pointed at the capturing stream (the ~25 framework launches of an iteration
+    were 0.7 ms of host time, and the device-to-device copies among them stalled the graph's replay).  CPU tensors (the tests'
+    stand-in context) take the framework form below."""
     import torch
     from ..utils.threads import blas_single_thread
+    if x1.device.type == 'cuda' and hasattr(ctx, 'handle'):
+        return _ica_par_device(ctx, x1, W, max_iter, tol)
     d = W.shape[0]
     p_ = float(x1.shape[0])
     dev = x1.device
@@ -135,58 +253,20 @@ def _ica_par(ctx, x1, W, max_iter, tol):
         for k in range(n_it):
             gwtx = torch.tanh(x1 @ Wd.T)
             g_wtx = (1. - gwtx * gwtx).mean(0)
-            W1, res = _polar_newton_schulz(_tn_product(gwtx, x1) / p_ - g_wtx[:, None] * Wd, eye, polar_ctx, polar_work)
+            W1, res = _polar_newton_schulz(_tn_product(gwtx, x1) / p_ - g_wtx[:, None] * Wd, eye)
             meas[0, k] = ((W1 * Wd).sum(1).abs() - 1.).abs().max()
             meas[1, k] = res
             Wbuf[k].copy_(W1)
             Wd.copy_(W1)
 
-    # on the GPU the polar iteration is one C-ABI call (one persistent launch, bfhip_polar_ns); CPU tensors (the
-    # tests' stand-in context) take the torch form
-    polar_ctx = ctx if (dev.type == 'cuda' and hasattr(ctx, 'handle')) else None
-    polar_work = torch.empty((2 * d * d + 1,), dtype=torch.float64, device=dev) if polar_ctx is not None else None
-    graph = None
-
-    def capture():
-        """The chunk as a HIP graph (None when the capture fails: the eager chunks go on)."""
-        if polar_ctx is None or GRAPH_STATS['failed'] > 2:
-            return None
-        keep = polar_ctx.stream
-        g = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(g):
-                polar_ctx.set_stream(torch.cuda.current_stream(dev))
-                chunk()
-        except Exception:
-            g = None
-        finally:
-            polar_ctx.set_stream(keep)
-        GRAPH_STATS['captured' if g is not None else 'failed'] += 1
-        return g
-
     n_iter = 0
     with blas_single_thread():
         while n_iter < max_iter:
             start = Wd.clone()
-            t_0 = time.perf_counter()
-            if n_iter == 0 or polar_ctx is None:
-                chunk()
-                GRAPH_STATS['eager_s'] += time.perf_counter() - t_0
-            else:
-                if graph is None and n_iter == _CHUNK:
-                    graph = capture()       # (capturing does not run anything)
-                    GRAPH_STATS['capture_s'] += time.perf_counter() - t_0
-                if graph is not None:
-                    graph.replay()
-                    GRAPH_STATS['replayed'] += 1
-                else:
-                    chunk()
-            t_0 = time.perf_counter()
+            chunk()
             m = meas.cpu().numpy()
-            GRAPH_STATS['wait_s'] += time.perf_counter() - t_0
             left = min(_CHUNK, max_iter - n_iter)
             if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
-                # (rare) the polar iteration fell short somewhere in this chunk: the same iterations with the host's eigh
                 Wh = start.cpu().numpy()
                 for k in range(left):
                     Wh, lim = _ica_step_host(ctx, x1, Wh)

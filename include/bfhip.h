@@ -431,11 +431,24 @@ int bfhip_bridge_sums(bfhip_ctx *ctx, long n_a, const double *a, long n_b, const
 int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const double *logq_p, long n_q, const double *logp_q,
                        const double *logq_q, double logr, double *f1, double *f2);
 
+/* The glue of one FastICA iteration (scikit-learn's _ica_par, logcosh contrast, as SIT calls it: transforms/sit.py:235-244) around
+ * the caller's two products Y = X1 W^T and P[b] = G_b^T X1_b (row batches b) and bfhip_polar_ns:
+ *   bfhip_ica_tanh      y (n_pad,d) <- tanh(y) in place; partial (ceil(n_pad / 128), d) <- column sums of 1 - tanh(y)^2 over the
+ *                       rows < n of every block of 128 rows (rows n .. n_pad: zero padding, not counted)
+ *   bfhip_ica_assemble  a (d,d) <- (sum_b p[b]) / n - gmean[:, None] w,  gmean = column sums of partial / n;  p (nb,d,d)
+ *   bfhip_ica_post      meas[k] <- max_i | |sum_j w1[i][j] w[i][j]| - 1 |, meas[n_meas + k] <- resid[0]; wbuf[k] <- w1; w <- w1 */
+int bfhip_ica_tanh(bfhip_ctx *ctx, long n, long n_pad, int d, double *y, double *partial);
+int bfhip_ica_assemble(bfhip_ctx *ctx, int d, int nb, const double *p, long n, long n_pad, const double *partial, const double *w,
+                       double *a);
+int bfhip_ica_post(bfhip_ctx *ctx, int d, const double *w1, double *w, const double *resid, int k, int n_meas, double *wbuf,
+                   double *meas);
+
 /* FastICA's symmetric decorrelation W <- (W W^T)^{-1/2} W (sklearn.decomposition FastICA, as SIT calls it: transforms/sit.py:235-244;
  * scikit-learn takes an eigen-decomposition of W W^T on the host in every fixed-point iteration): the orthogonal polar factor of
  * a (d,d), by AT MOST n_iter Newton-Schulz steps on the FP64 matrix cores (the iteration stops once max |x x^T - I| < 1e-13), into
- * x (d,d).  work: 2 d^2 doubles; resid (1,) receives max |x x^T - I| (device memory: nothing synchronises; a caller checks it
- * when it next looks at the device).  d <= 1024. */
+ * x (d,d).  work: 2 d^2 + n_iter + 10 doubles (the iterates' second buffer, the grid barrier's counter, a residual per step: all
+ * in the caller's memory, so that a HIP graph holding the launch stays valid); resid (1,) receives max |x x^T - I| (device memory:
+ * nothing synchronises; a caller checks it when it next looks at the device).  d <= 1024. */
 int bfhip_polar_ns(bfhip_ctx *ctx, int d, const double *a, double *x, int n_iter, double *work, double *resid);
 
 /* NOT part of this interface: the library's test and tuning switches (force a chain layout, a kernel form or a chains-per-workgroup

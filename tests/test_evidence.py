@@ -349,25 +349,40 @@ def test_device_ndtri_is_scipys():
 
 @pytest.mark.gpu
 def test_fastica_chunk_graph_equals_the_eager_chunks(monkeypatch):
-    """The FastICA iteration's chunks replayed as ONE HIP graph (the polar kernel a node of it) find what the eager chunks find:
-    same iteration count, same components bit for bit (the same kernels on the same data in the same order)."""
+    """The FastICA iteration's chunks replayed as ONE HIP graph (library products, the glue kernels and the polar kernel its nodes,
+    kept per shape) find what the eager chunks find: same iteration count, same components bit for bit (the same kernels on the same
+    data in the same order); a second fit of the same shape reuses the graph."""
     from bayesfast_amd.transforms import ica
     from bayesfast_amd.device import get_context
     ctx = get_context(0)
     rng = np.random.default_rng(4)
-    x = rng.laplace(size=(20000, 48)) @ (np.eye(48) + 0.3 * rng.normal(size=(48, 48)))
+    x = rng.laplace(size=(20100, 48)) @ (np.eye(48) + 0.3 * rng.normal(size=(48, 48)))    # (20100 rows: a padded last batch)
+    ica._DEVICE_STATE.clear()
     before = dict(ica.GRAPH_STATS)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         comp_g, mean_g, n_g = ica.fastica_device(x, random_state=7, tol=1e-9, ctx=ctx)
-    assert ica.GRAPH_STATS['captured'] == before['captured'] + 1 and ica.GRAPH_STATS['failed'] == before['failed']
-    assert ica.GRAPH_STATS['replayed'] > before['replayed'] and n_g > ica._CHUNK
+        assert ica.GRAPH_STATS['captured'] == before['captured'] + 1 and ica.GRAPH_STATS['failed'] == before['failed']
+        assert ica.GRAPH_STATS['replayed'] > before['replayed'] and n_g > ica._CHUNK
+        comp_2, _, n_2 = ica.fastica_device(x, random_state=7, tol=1e-9, ctx=ctx)
+    assert ica.GRAPH_STATS['captured'] == before['captured'] + 1 and n_2 == n_g
+    np.testing.assert_array_equal(comp_2, comp_g)
+    ica._DEVICE_STATE.clear()
     monkeypatch.setitem(ica.GRAPH_STATS, 'failed', 99)    # (no capture: eager chunks)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         comp_e, mean_e, n_e = ica.fastica_device(x, random_state=7, tol=1e-9, ctx=ctx)
     assert n_e == n_g
     np.testing.assert_array_equal(comp_g, comp_e)
+    ica._DEVICE_STATE.clear()
+    # ... and scikit-learn's own fit of the same data: the same components (to the fixed point's tolerance)
+    from sklearn.decomposition import FastICA
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        comp_d, _, n_d = ica.fastica_device(x, random_state=7, ctx=ctx)
+        sk = FastICA(random_state=7, whiten='unit-variance').fit(x)
+    assert n_d == sk.n_iter_
+    np.testing.assert_allclose(comp_d, sk.components_, rtol=1e-6, atol=1e-8)
 
 
 @pytest.mark.gpu
@@ -440,13 +455,13 @@ def test_polar_ns_is_the_orthogonal_polar_factor(d):
     rng = np.random.default_rng(d)
     A = rng.normal(size=(d, d)) * 0.03 + np.diag(rng.uniform(0.05, 2., size=d))
     a = ctx.tensor(A)
-    work = torch.empty(2 * d * d + 1, dtype=torch.float64, device=a.device)
+    work = torch.empty(2 * d * d + 80, dtype=torch.float64, device=a.device)
 
     def run(n_iter, tiles=0):
         debug_set('polar_tiles', tiles)
         x = torch.empty_like(a)
-        _lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(a), _ptr(x), n_iter, _ptr(work), _ptr(work[2 * d * d:])))
-        return x.cpu().numpy(), float(work[2 * d * d])
+        _lib.check(ctx._lib.bfhip_polar_ns(ctx.handle, d, _ptr(a), _ptr(x), n_iter, _ptr(work), _ptr(work[-1:])))
+        return x.cpu().numpy(), float(work[-1])
 
     u, s, vt = np.linalg.svd(A)
     x, res = run(60)
