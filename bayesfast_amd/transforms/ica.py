@@ -111,6 +111,8 @@ def _polar_newton_schulz(A, eye, ctx=None, work=None):
 
 
 _ROWS = 400         # rows per batch of the G^T X1 product (see _tn_product)
+_TIME_REPLAYS = False   # tools: HIP events around every replay
+_REPLAY_EVENTS = []
 _DEVICE_STATE = {}  # (device index, n, d) -> the chunk's buffers and its HIP graph (kept: a SIT fit calls FastICA once per iteration)
 
 
@@ -177,7 +179,14 @@ class _ChunkState:
             GRAPH_STATS['capture_s'] += time.perf_counter() - t_0
             self.graph = g
         if self.graph is not None:
-            self.graph.replay()
+            if _TIME_REPLAYS:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.graph.replay()
+                e1.record()
+                _REPLAY_EVENTS.append((e0, e1))
+            else:
+                self.graph.replay()
             GRAPH_STATS['replayed'] += 1
         else:
             self.chunk()

@@ -21,6 +21,8 @@ t0 = time.perf_counter()
 tt = bfa.sample(den, {'n_chain': chains, 'n_iter': n_iter, 'n_warmup': n_warmup, 'random_generator': 0}, verbose=False)
 torch.cuda.synchronize()
 print('sample %.1f ms' % ((time.perf_counter() - t0) * 1e3), flush=True)
+from bayesfast_amd.transforms import ica as _ica
+_ica._TIME_REPLAYS = True
 gbs = bfa.GBS(sit=dict(n_iter=sit_iter, random_generator=5), n_q=chains * (n_iter - n_warmup) // 2)
 pr = cProfile.Profile()
 with warnings.catch_warnings():
@@ -34,4 +36,6 @@ print('gbs %.1f ms, logZ %.4f +- %.4f (exact %.4f)' % ((time.perf_counter() - t0
       0.5 * d * np.log(2. * np.pi) + float(np.sum(np.log(np.diag(chol))))), flush=True)
 from bayesfast_amd.transforms import ica
 print('FastICA chunks:', ica.GRAPH_STATS)
+ts = [a.elapsed_time(b) for a, b in ica._REPLAY_EVENTS]
+print('replays: %d, device ms each: min %.2f median %.2f max %.2f, total %.1f ms' % (len(ts), min(ts), sorted(ts)[len(ts) // 2], max(ts), sum(ts)))
 pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
