@@ -111,6 +111,7 @@ def _polar_newton_schulz(A, eye, ctx=None, work=None):
 
 
 _ROWS = 400         # rows per batch of the G^T X1 product (see _tn_product)
+_SPIN_WAIT = bool(int(__import__('os').environ.get('BF_ICA_SPIN', '0')))
 _TIME_REPLAYS = False   # tools: HIP events around every replay
 _REPLAY_EVENTS = []
 _DEVICE_STATE = {}  # (device index, n, d) -> the chunk's buffers and its HIP graph (kept: a SIT fit calls FastICA once per iteration)
@@ -210,6 +211,12 @@ def _ica_par_device(ctx, x1, W, max_iter, tol):
         start = st.W.clone()
         st.run_chunk()
         t_0 = time.perf_counter()
+        if _SPIN_WAIT:
+            ev = torch.cuda.Event()
+            ev.record()
+            while not ev.query():
+                pass
+            GRAPH_STATS['spin_s'] = GRAPH_STATS.get('spin_s', 0.) + time.perf_counter() - t_0
         m = st.meas.cpu().numpy()
         GRAPH_STATS['wait_s'] += time.perf_counter() - t_0
         left = min(_CHUNK, max_iter - n_iter)

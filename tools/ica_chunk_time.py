@@ -44,3 +44,12 @@ pieces = [('mm', lambda: torch.mm(st.x1, st.W.T, out=st.Y)),
           ('post', lambda: _lib.check(lib.bfhip_ica_post(h, d, _ptr(st.W1), _ptr(st.W), _ptr(res), 0, ica._CHUNK, _ptr(st.Wbuf), _ptr(st.meas))))]
 for name, f in pieces:
     print('%-9s %.1f us' % (name, wall(f, 20) * 1e3))
+# replay + the host's look at the measures, as _ica_par_device alternates them
+for label, f in (('replay; meas.cpu()', lambda: (st.graph.replay(), st.meas.cpu())),
+                 ('W.clone(); replay; meas.cpu()', lambda: (st.W.clone(), st.graph.replay(), st.meas.cpu())),
+                 ('replay; synchronize', lambda: (st.graph.replay(), torch.cuda.synchronize())),
+                 ('eager chunk; meas.cpu()', lambda: (st.chunk(), st.meas.cpu()))):
+    t0 = time.perf_counter()
+    for _ in range(10):
+        f()
+    print('%-32s %.2f ms each' % (label, (time.perf_counter() - t0) / 10 * 1e3))
