@@ -183,7 +183,9 @@ class _ChunkState:
             if _TIME_REPLAYS:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+                t_1 = time.perf_counter()
                 self.graph.replay()
+                GRAPH_STATS['replay_call_s'] = GRAPH_STATS.get('replay_call_s', 0.) + time.perf_counter() - t_1
                 e1.record()
                 _REPLAY_EVENTS.append((e0, e1))
             else:
