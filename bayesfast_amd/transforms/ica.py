@@ -221,6 +221,7 @@ def _ica_par_device(ctx, x1, W, max_iter, tol):
             GRAPH_STATS['spin_s'] = GRAPH_STATS.get('spin_s', 0.) + time.perf_counter() - t_0
         m = st.meas.cpu().numpy()
         GRAPH_STATS['wait_s'] += time.perf_counter() - t_0
+        GRAPH_STATS.setdefault('waits', []).append(round((time.perf_counter() - t_0) * 1e3, 2))
         left = min(_CHUNK, max_iter - n_iter)
         if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
             # (rare) the polar iteration fell short somewhere in this chunk: the same iterations with the host's eigh
