@@ -67,9 +67,18 @@ class GBS:
     def run(self, x_p, logp, logp_p=None):
         """x_p: posterior samples (n, d), (chain, iteration, d) or a ``TraceTuple``; logp: the unnormalised log-posterior;
         logp_p: its values on x_p if already known.  Returns ``(logz, logz_err)``."""
-        from ..samplers.sample_trace import TraceTuple
+        from ..utils.threads import blas_single_thread
         if not callable(logp):
             raise ValueError('logp should be callable.')
+        # (host BLAS on one thread, as the reference runs it, core/sample.py:167: the d x d factorisations of a SIT fit gain nothing
+        # from threads, and OpenBLAS workers spinning after each call exhaust a container's CPU quota -- every thread of the process,
+        # the ROCm runtime's included, then stands still until the next 100 ms scheduling period: nine such stalls were 0.5 s of a
+        # config-5 GBS run)
+        with blas_single_thread():
+            return self._run(x_p, logp, logp_p)
+
+    def _run(self, x_p, logp, logp_p):
+        from ..samplers.sample_trace import TraceTuple
         n_call = None
         if isinstance(x_p, TraceTuple):
             n_call, x_p = x_p.n_call, x_p.get(flatten=False)

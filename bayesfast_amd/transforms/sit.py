@@ -221,6 +221,11 @@ class SIT:
 
     def fit(self, data=None, weights=None, n_run=None):
         """transforms/sit.py:257-341 (without the plots)."""
+        from ..utils.threads import blas_single_thread
+        with blas_single_thread():     # (see evidence/gbs.py: spinning BLAS workers stall the whole process in a CPU-quota container)
+            return self._fit(data, weights, n_run)
+
+    def _fit(self, data, weights, n_run):
         import torch
         ctx = self._ctx()
         if data is not None:

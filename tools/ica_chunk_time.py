@@ -53,3 +53,12 @@ for label, f in (('replay; meas.cpu()', lambda: (st.graph.replay(), st.meas.cpu(
     for _ in range(10):
         f()
     print('%-32s %.2f ms each' % (label, (time.perf_counter() - t0) / 10 * 1e3))
+# two seconds of replay + look: the individual times (stalls that end on a 100 ms grid were seen inside GBS runs)
+ts, t_end = [], time.perf_counter() + 2.
+while time.perf_counter() < t_end:
+    t0 = time.perf_counter()
+    st.graph.replay()
+    st.meas.cpu()
+    ts.append((time.perf_counter() - t0) * 1e3)
+ts = np.array(ts)
+print('%d replays in 2 s: median %.2f ms, %d above 8 ms: %s' % (ts.size, np.median(ts), (ts > 8).sum(), np.round(ts[ts > 8], 1)))
