@@ -32,6 +32,12 @@ def sample(density, sample_trace=None, sampler='NUTS', n_run=None, parallel_back
     is more than one rank, and the refit path (``bayesfast_amd.core.refit.select_fit_points``) exchanges only the
     selected rows.
     """
+    from ..utils.threads import blas_single_thread
+    with blas_single_thread():    # (core/sample.py:167: threadpool_limits(1) around the sampler; utils/threads.py says why it matters here)
+        return _sample(density, sample_trace, sampler, n_run, verbose, iters_per_launch, layout, gather)
+
+
+def _sample(density, sample_trace, sampler, n_run, verbose, iters_per_launch, layout, gather):
     import torch
     from ..chains import DeviceChains
     if not isinstance(density, SurrogateDensity):

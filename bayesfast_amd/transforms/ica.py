@@ -111,7 +111,6 @@ def _polar_newton_schulz(A, eye, ctx=None, work=None):
 
 
 _ROWS = 400         # rows per batch of the G^T X1 product (see _tn_product)
-_SPIN_WAIT = bool(int(__import__('os').environ.get('BF_ICA_SPIN', '0')))
 _TIME_REPLAYS = False   # tools: HIP events around every replay
 _REPLAY_EVENTS = []
 _DEVICE_STATE = {}  # (device index, n, d) -> the chunk's buffers and its HIP graph (kept: a SIT fit calls FastICA once per iteration)
@@ -183,9 +182,7 @@ class _ChunkState:
             if _TIME_REPLAYS:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                t_1 = time.perf_counter()
                 self.graph.replay()
-                GRAPH_STATS['replay_call_s'] = GRAPH_STATS.get('replay_call_s', 0.) + time.perf_counter() - t_1
                 e1.record()
                 _REPLAY_EVENTS.append((e0, e1))
             else:
@@ -213,15 +210,8 @@ def _ica_par_device(ctx, x1, W, max_iter, tol):
         start = st.W.clone()
         st.run_chunk()
         t_0 = time.perf_counter()
-        if _SPIN_WAIT:
-            ev = torch.cuda.Event()
-            ev.record()
-            while not ev.query():
-                pass
-            GRAPH_STATS['spin_s'] = GRAPH_STATS.get('spin_s', 0.) + time.perf_counter() - t_0
         m = st.meas.cpu().numpy()
         GRAPH_STATS['wait_s'] += time.perf_counter() - t_0
-        GRAPH_STATS.setdefault('waits', []).append(round((time.perf_counter() - t_0) * 1e3, 2))
         left = min(_CHUNK, max_iter - n_iter)
         if not np.all(m[1, :left] < _NS_RESID) or not np.all(np.isfinite(m[:, :left])):
             # (rare) the polar iteration fell short somewhere in this chunk: the same iterations with the host's eigh
