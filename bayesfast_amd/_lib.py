@@ -103,7 +103,7 @@ SYMBOLS = {
     'bfhip_polar_ns': (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     'bfhip_ndtri': (C.c_int, [_vp, C.c_long, _vp, _vp]),
     'bfhip_ica_tanh': (C.c_int, [_vp, C.c_long, C.c_long, C.c_int, _vp, _vp]),
-    'bfhip_ica_assemble': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_long, C.c_long, _vp, _vp, _vp]),
+    'bfhip_ica_assemble': (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_long, C.c_long, _vp, _vp, _vp, _vp]),
     'bfhip_ica_post': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     'bfhip_spline_build': (C.c_int, [_vp, C.c_int, C.c_long, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_double,
                                      C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

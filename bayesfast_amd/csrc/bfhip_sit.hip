@@ -804,7 +804,7 @@ __global__ __launch_bounds__(64 * BF_POLAR_LDS_MAXT) void bf_polar_lds_kernel(in
 
 // G = tanh(Y) in place for Y (n_pad, d) and, per block of ICA_RB rows, the column sums of g'(y) = 1 - tanh(y)^2 over the rows < n
 // (rows n .. n_pad are zero padding: they stay zero and are not counted).  partial (n_blocks, d).
-#define ICA_RB 128
+#define ICA_RB 32     // (625 workgroups at 20 000 rows: 128-row blocks left a third of the chip idle, 42 us against 15)
 __global__ __launch_bounds__(256) void bf_ica_tanh_kernel(long n, long n_pad, int d, double *__restrict__ Y, double *__restrict__ partial) {
     __shared__ double red[256];
     const int cw = d < 256 ? d : 256, ry = 256 / cw;          // cw columns side by side, ry row groups
@@ -833,8 +833,9 @@ __global__ __launch_bounds__(256) void bf_ica_tanh_kernel(long n, long n_pad, in
 // A = (sum_b P[b]) / n - gmean[:, None] W with gmean[i] = (sum_blk partial[blk][i]) / n: one workgroup per row i.
 __global__ __launch_bounds__(256) void bf_ica_assemble_kernel(int d, int nb, const double *__restrict__ P, long n, int n_blk,
                                                              const double *__restrict__ partial, const double *__restrict__ W,
-                                                             double *__restrict__ A) {
+                                                             double *__restrict__ A, double *__restrict__ meas_k) {
     __shared__ double gsh[4];
+    if (meas_k && blockIdx.x == 0 && threadIdx.x == 0) *meas_k = 0.;   // (the slot bf_ica_post_kernel takes its atomic maximum in)
     const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double g = 0.;
     for (int b = threadIdx.x; b < n_blk; b += 256) g += partial[(size_t)b * d + i];
@@ -849,34 +850,28 @@ __global__ __launch_bounds__(256) void bf_ica_assemble_kernel(int d, int nb, con
     }
 }
 
-// after the polar factor W1 of A: lim = max_i | |sum_j W1[i][j] W[i][j]| - 1 | (scikit-learn's convergence measure) -> meas[k],
-// the polar iteration's residual -> meas[n_meas + k], W1 -> Wbuf[k] and -> W.  One workgroup.
+// after the polar factor W1 of A: lim = max_i | |sum_j W1[i][j] W[i][j]| - 1 | (scikit-learn's convergence measure) -> meas[k]
+// (an atomic maximum of the bit patterns of non-negative doubles: order-independent; bf_ica_assemble_kernel zeroed the slot),
+// the polar iteration's residual -> meas[n_meas + k], W1 -> Wbuf[k] and -> W.  A row per wave (a row's dot product reads only that
+// row of W, which the wave then overwrites).
 __global__ __launch_bounds__(256) void bf_ica_post_kernel(int d, const double *__restrict__ W1, double *__restrict__ W,
                                                          const double *__restrict__ resid, int k, int n_meas, double *__restrict__ Wbuf,
                                                          double *__restrict__ meas) {
-    __shared__ double msh[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double mx = 0.;
-    for (int i = wave; i < d; i += 4) {
-        double dot = 0.;
-        for (int j = lane; j < d; j += 64) dot += W1[(size_t)i * d + j] * W[(size_t)i * d + j];
-        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        const double v = fabs(fabs(dot) - 1.);
-        mx = (v > mx || v != v) ? v : mx;
-    }
-    if (lane == 0) msh[wave] = mx;
-    __syncthreads();     // (every row's dot product has read W: it may be overwritten now)
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= d) return;
     double *dst = Wbuf + (size_t)k * d * d;
-    for (int e = threadIdx.x; e < d * d; e += 256) {
-        const double v = W1[e];
-        dst[e] = v;
-        W[e] = v;
+    double dot = 0.;
+    for (int j = lane; j < d; j += 64) {
+        const double v = W1[(size_t)i * d + j];
+        dot += v * W[(size_t)i * d + j];
+        dst[(size_t)i * d + j] = v;
     }
-    if (threadIdx.x == 0) {
-        double m = msh[0];
-        for (int q = 1; q < 4; ++q) m = (msh[q] > m || msh[q] != msh[q]) ? msh[q] : m;
-        meas[k] = m;
-        meas[n_meas + k] = resid[0];
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    for (int j = lane; j < d; j += 64) W[(size_t)i * d + j] = W1[(size_t)i * d + j];
+    if (lane == 0) {
+        const double v = fabs(fabs(dot) - 1.);
+        atomicMax((unsigned long long *)&meas[k], (unsigned long long)__double_as_longlong(v != v ? __builtin_inf() : v));
+        if (i == 0) meas[n_meas + k] = resid[0];
     }
 }
 
@@ -889,11 +884,11 @@ extern "C" int bfhip_ica_tanh(bfhip_ctx *ctx, long n, long n_pad, int d, double 
 }
 
 extern "C" int bfhip_ica_assemble(bfhip_ctx *ctx, int d, int nb, const double *p, long n, long n_pad, const double *partial,
-                                  const double *w, double *a) {
+                                  const double *w, double *a, double *meas_k) {
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || d < 1 || nb < 1 || n < 1 || n_pad < n || !p || !partial || !w || !a)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_ica_assemble: invalid argument");
-    hipLaunchKernelGGL(bf_ica_assemble_kernel, dim3(d), dim3(256), 0, ctx->stream, d, nb, p, n, (int)((n_pad + ICA_RB - 1) / ICA_RB), partial, w, a);
+    hipLaunchKernelGGL(bf_ica_assemble_kernel, dim3(d), dim3(256), 0, ctx->stream, d, nb, p, n, (int)((n_pad + ICA_RB - 1) / ICA_RB), partial, w, a, meas_k);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -903,7 +898,7 @@ extern "C" int bfhip_ica_post(bfhip_ctx *ctx, int d, const double *w1, double *w
     BfDeviceGuard dev_guard(ctx);
     if (!ctx || d < 1 || k < 0 || k >= n_meas || !w1 || !w || !resid || !wbuf || !meas)
         return bf_set_error(BFHIP_ERR_ARG, "bfhip_ica_post: invalid argument");
-    hipLaunchKernelGGL(bf_ica_post_kernel, dim3(1), dim3(256), 0, ctx->stream, d, w1, w, resid, k, n_meas, wbuf, meas);
+    hipLaunchKernelGGL(bf_ica_post_kernel, dim3((d + 3) / 4), dim3(256), 0, ctx->stream, d, w1, w, resid, k, n_meas, wbuf, meas);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -81,6 +81,9 @@ class GBS:
         from ..samplers.sample_trace import TraceTuple
         n_call = None
         if isinstance(x_p, TraceTuple):
+            dev = self._run_on_device(x_p, logp, logp_p)
+            if dev is not None:
+                return dev
             n_call, x_p = x_p.n_call, x_p.get(flatten=False)
         else:
             try:
@@ -110,5 +113,54 @@ class GBS:
         if known is None:
             known = _evaluate(logp, test)
         return bridge(known, _evaluate(logp, x_q), self.sit.logq(test), self.sit.logq(x_q))
+
+    def _run_on_device(self, trace, logp, logp_p):
+        """The same estimate with the samples where ``sample()`` left them: a TraceTuple of one rank whose arrays are device tensors,
+        a SIT with the default generator and ``logp`` the ``logp`` method of a ``SurrogateDensity`` (whose kernel takes device
+        tensors).  The halves, the SIT's draws and the four log-density vectors stay on the GPU; only the vectors (n,) visit the
+        host, for ``bridge``.  None when any of that does not hold (the host path runs)."""
+        import torch
+        from ..core.density import SurrogateDensity
+        from ..utils import sobol
+        from .. import parallel
+        if type(logp) is SurrogateDensity:
+            den = logp
+        else:
+            den = getattr(logp, '__self__', None)
+            if not (isinstance(den, SurrogateDensity) and getattr(logp, '__func__', None) in (SurrogateDensity.logp, SurrogateDensity.__call__)):
+                return None
+        if self.sit.mvn_generator is not sobol.multivariate_normal or parallel.world()[1] > 1:
+            return None
+        t = trace.device('samples_original')
+        if not isinstance(t, torch.Tensor) or t.dim() != 3:
+            return None
+        x_p = t[:, trace.n_warmup:]                       # TraceTuple.get(flatten=False): (chain, iteration, d) after the warm-up
+        if trace.n_warmup >= trace.i_iter - 1:
+            raise ValueError('since_iter is too large. Nothing to return.')
+        n_samples = int(x_p.shape[0] * x_p.shape[1])
+        if x_p.shape[-1] < 2 or n_samples < 2:
+            raise ValueError('invalid shape for x_p.')
+        n_q = self._draws_from_q(n_samples, trace.n_call)
+        if x_p.shape[0] == 1:
+            x_p = x_p[0]
+        cut = x_p.shape[0] // 2
+        d = x_p.shape[-1]
+        train, test = x_p[:cut].reshape(-1, d), x_p[cut:].reshape(-1, d).contiguous()
+        self.sit.fit(data=train)
+        x_q = self.sit._sample_device(n_q)
+        dd = den.device()
+        known = None
+        if logp_p is not None:
+            known = np.asarray(logp_p)
+            if known.shape == tuple(x_p.shape[:-1]):
+                known = known[cut:]
+            else:
+                warnings.warn('the logp_p you gave me seems not correct. Will recompute it from logp and x_p.', RuntimeWarning)
+                known = None
+        if known is None:
+            known = dd.logp_and_grad(test, True)[0].cpu().numpy().reshape(tuple(x_p.shape[:-1])[0] - cut, *x_p.shape[1:-1])
+        logp_q = dd.logp_and_grad(x_q, True)[0].cpu().numpy()
+        logq_p = self.sit._logq_device(test).cpu().numpy().reshape(np.shape(known))
+        return bridge(known, logp_q, logq_p, self.sit._logq_device(x_q).cpu().numpy())
 
     __call__ = run

@@ -128,7 +128,7 @@ class _ChunkState:
         self.x1 = torch.zeros((self.n_pad, d), **f)
         self.Y = torch.empty((self.n_pad, d), **f)
         self.P = torch.empty((self.nb, d, d), **f)
-        self.partial = torch.empty((-(-self.n_pad // 128), d), **f)
+        self.partial = torch.empty((-(-self.n_pad // 32), d), **f)
         self.A, self.W1, self.W = (torch.empty((d, d), **f) for _ in range(3))
         self.work = torch.empty((2 * d * d + _NS_ITERS + 11,), **f)    # bfhip_polar_ns: 2 d^2 + n_iter + 10, and the residual
         self.Wbuf = torch.empty((_CHUNK, d, d), **f)
@@ -150,7 +150,7 @@ class _ChunkState:
             _lib.check(lib.bfhip_ica_tanh(h, self.n, self.n_pad, d, _ptr(self.Y), _ptr(self.partial)))   # G = tanh(Y), sums of g'
             torch.bmm(Yb, Xb, out=self.P)                                                          # G^T X1 by row batches
             _lib.check(lib.bfhip_ica_assemble(h, d, self.nb, _ptr(self.P), self.n, self.n_pad, _ptr(self.partial), _ptr(self.W),
-                                              _ptr(self.A)))
+                                              _ptr(self.A), _ptr(self.meas[0, k:])))
             _lib.check(lib.bfhip_polar_ns(h, d, _ptr(self.A), _ptr(self.W1), _NS_ITERS, _ptr(self.work), _ptr(res)))
             _lib.check(lib.bfhip_ica_post(h, d, _ptr(self.W1), _ptr(self.W), _ptr(res), k, _CHUNK, _ptr(self.Wbuf), _ptr(self.meas)))
 

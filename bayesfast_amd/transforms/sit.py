@@ -228,7 +228,28 @@ class SIT:
     def _fit(self, data, weights, n_run):
         import torch
         ctx = self._ctx()
-        if data is not None:
+        if data is not None and isinstance(data, torch.Tensor):
+            # (device-resident callers, GBS on a TraceTuple: the samples never visit the host)
+            if data.numel() == 0 or data.dim() < 2:
+                raise ValueError('invalid value for data.')
+            data = data.to(torch.float64).reshape(-1, data.shape[-1])
+            if data.shape[-1] == 1:
+                raise ValueError('I cannot do rotations for only one variable.')
+            n = data.shape[0]
+            if weights is not None:
+                weights = np.asarray(weights, dtype=np.float64)
+                if weights.shape != (n,):
+                    raise ValueError('invalid value for weights.')
+                self._weights = weights
+            else:
+                self._weights = np.ones(n) / n
+            self._data = ctx.tensor(data).clone()
+            self._data_init = None
+            d = data.shape[-1]
+            self._tables = []
+            self._A, self._B = np.zeros((0, d, d)), np.zeros((0, d, d))
+            self._m, self._logdetA = np.zeros((0, d)), np.zeros(0)
+        elif data is not None:
             try:
                 data = np.array(data, dtype=np.float64)
                 assert data.size > 0
@@ -299,30 +320,61 @@ class SIT:
             raise ValueError('invalid shape for x.')
         return y.reshape((-1, y.shape[-1])), y.shape
 
-    def forward_transform(self, x, use_parallel=False):
-        import torch
+    def _rotations_on_device(self):
+        """The iterations' means and rotation matrices as device tensors (cached per fitted iteration count)."""
         ctx = self._ctx()
-        flat, shape = self._points(x)
-        y = ctx.tensor(flat)
+        c = getattr(self, '_dev_rot', None)
+        if c is None or c[0] != self.i_iter or c[1] is not ctx:
+            c = (self.i_iter, ctx, [ctx.tensor(self._m[i]) for i in range(self.i_iter)],
+                 [ctx.tensor(self._A[i].T.copy()) for i in range(self.i_iter)], [ctx.tensor(self._B[i].T.copy()) for i in range(self.i_iter)])
+            self._dev_rot = c
+        return c[2], c[3], c[4]
+
+    def _forward_device(self, y):
+        """``forward_transform`` of y (n, d) device tensor -> (y', log|J|) device tensors."""
+        import torch
+        m, At, _ = self._rotations_on_device()
         log_j = torch.zeros(y.shape[0], dtype=torch.float64, device=y.device)
         for i in range(self.i_iter):
-            y = (y - ctx.tensor(self._m[i])) @ ctx.tensor(self._A[i].T.copy())
+            y = (y - m[i]) @ At[i]
             log_j += torch.log(self._tables[i].apply('derivative', y)).sum(1)
             y = self._tables[i].apply('evaluate', y)
         log_j += float(np.sum(self._logdetA))
-        return y.cpu().numpy().reshape(shape), log_j.cpu().numpy().reshape(shape[:-1])
+        return y, log_j
 
-    def backward_transform(self, y, use_parallel=False):
+    def _backward_device(self, x):
+        """``backward_transform`` of x (n, d) device tensor -> (x', log|J|) device tensors."""
         import torch
-        ctx = self._ctx()
-        flat, shape = self._points(y)
-        x = ctx.tensor(flat)
+        m, _, Bt = self._rotations_on_device()
         log_j = torch.zeros(x.shape[0], dtype=torch.float64, device=x.device)
         for i in reversed(range(self.i_iter)):
             x = self._tables[i].apply('solve', x)
             log_j += torch.log(self._tables[i].apply('derivative', x)).sum(1)
-            x = x @ ctx.tensor(self._B[i].T.copy()) + ctx.tensor(self._m[i])
+            x = x @ Bt[i] + m[i]
         log_j += float(np.sum(self._logdetA))
+        return x, log_j
+
+    def _logq_device(self, x):
+        """``logq`` of x (n, d) device tensor -> (n,) device tensor (the standard normal's log-density summed on the device)."""
+        y, log_j = self._forward_device(x)
+        return (-0.5 * y * y - 0.9189385332046727).sum(1) + log_j
+
+    def _sample_device(self, n):
+        """``sample(n)[0]`` as a device tensor (the default Sobol-normal generator; None for a user's generator)."""
+        from ..utils import sobol
+        if self.mvn_generator is not sobol.multivariate_normal:
+            return None
+        y = sobol.standard_normal_device(self.dim, int(n), self._ctx())
+        return self._backward_device(y)[0]
+
+    def forward_transform(self, x, use_parallel=False):
+        flat, shape = self._points(x)
+        y, log_j = self._forward_device(self._ctx().tensor(flat))
+        return y.cpu().numpy().reshape(shape), log_j.cpu().numpy().reshape(shape[:-1])
+
+    def backward_transform(self, y, use_parallel=False):
+        flat, shape = self._points(y)
+        x, log_j = self._backward_device(self._ctx().tensor(flat))
         return x.cpu().numpy().reshape(shape), log_j.cpu().numpy().reshape(shape[:-1])
 
     def logq(self, x, use_parallel=False):

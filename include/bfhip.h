@@ -433,13 +433,15 @@ int bfhip_bridge_terms(bfhip_ctx *ctx, long n_p, const double *logp_p, const dou
 
 /* The glue of one FastICA iteration (scikit-learn's _ica_par, logcosh contrast, as SIT calls it: transforms/sit.py:235-244) around
  * the caller's two products Y = X1 W^T and P[b] = G_b^T X1_b (row batches b) and bfhip_polar_ns:
- *   bfhip_ica_tanh      y (n_pad,d) <- tanh(y) in place; partial (ceil(n_pad / 128), d) <- column sums of 1 - tanh(y)^2 over the
- *                       rows < n of every block of 128 rows (rows n .. n_pad: zero padding, not counted)
- *   bfhip_ica_assemble  a (d,d) <- (sum_b p[b]) / n - gmean[:, None] w,  gmean = column sums of partial / n;  p (nb,d,d)
- *   bfhip_ica_post      meas[k] <- max_i | |sum_j w1[i][j] w[i][j]| - 1 |, meas[n_meas + k] <- resid[0]; wbuf[k] <- w1; w <- w1 */
+ *   bfhip_ica_tanh      y (n_pad,d) <- tanh(y) in place; partial (ceil(n_pad / 32), d) <- column sums of 1 - tanh(y)^2 over the
+ *                       rows < n of every block of 32 rows (rows n .. n_pad: zero padding, not counted)
+ *   bfhip_ica_assemble  a (d,d) <- (sum_b p[b]) / n - gmean[:, None] w,  gmean = column sums of partial / n;  p (nb,d,d);
+ *                       *meas_k <- 0 (the slot bfhip_ica_post reduces into; may be NULL)
+ *   bfhip_ica_post      meas[k] <- max(meas[k], max_i | |sum_j w1[i][j] w[i][j]| - 1 |), meas[n_meas + k] <- resid[0];
+ *                       wbuf[k] <- w1; w <- w1 */
 int bfhip_ica_tanh(bfhip_ctx *ctx, long n, long n_pad, int d, double *y, double *partial);
 int bfhip_ica_assemble(bfhip_ctx *ctx, int d, int nb, const double *p, long n, long n_pad, const double *partial, const double *w,
-                       double *a);
+                       double *a, double *meas_k);
 int bfhip_ica_post(bfhip_ctx *ctx, int d, const double *w1, double *w, const double *resid, int k, int n_meas, double *wbuf,
                    double *meas);
 

@@ -314,6 +314,15 @@ def test_sample_then_gbs_end_to_end_on_a_gaussian_surrogate():
     exact = c0 + 0.5 * d * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(cov)[1]
     assert 0. < err < 0.1
     assert abs(logz - exact) < 3. * err + 0.02, (logz, err, exact)
+    # that call took GBS's device-resident route (a TraceTuple, the default generator, a SurrogateDensity's logp: halves, draws and
+    # log-densities stay on the GPU); the host route -- the same TraceTuple with logp wrapped so that it is just a callable -- is the
+    # same estimate: same SIT (same seeds), same draws, log-densities to summation order
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        logz_h, err_h = bfa.GBS(sit=dict(random_generator=5), n_q=12000)(tt, lambda x: den.logp(x))
+        logz_a, err_a = bfa.GBS(sit=dict(random_generator=5), n_q=12000)(tt.get(flatten=False), den.logp)
+    assert abs(logz - logz_h) < 1e-9 and abs(err - err_h) < 1e-9 * err
+    assert abs(logz_a - logz_h) < 1e-9
 
 
 @pytest.mark.gpu

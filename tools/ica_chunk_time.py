@@ -39,7 +39,7 @@ Xb = st.x1.view(st.nb, ica._ROWS, d)
 pieces = [('mm', lambda: torch.mm(st.x1, st.W.T, out=st.Y)),
           ('tanh', lambda: _lib.check(lib.bfhip_ica_tanh(h, st.n, st.n_pad, d, _ptr(st.Y), _ptr(st.partial)))),
           ('bmm', lambda: torch.bmm(Yb, Xb, out=st.P)),
-          ('assemble', lambda: _lib.check(lib.bfhip_ica_assemble(h, d, st.nb, _ptr(st.P), st.n, st.n_pad, _ptr(st.partial), _ptr(st.W), _ptr(st.A)))),
+          ('assemble', lambda: _lib.check(lib.bfhip_ica_assemble(h, d, st.nb, _ptr(st.P), st.n, st.n_pad, _ptr(st.partial), _ptr(st.W), _ptr(st.A), _ptr(st.meas[0, 0:])))),
           ('polar', lambda: _lib.check(lib.bfhip_polar_ns(h, d, _ptr(st.A), _ptr(st.W1), ica._NS_ITERS, _ptr(st.work), _ptr(res)))),
           ('post', lambda: _lib.check(lib.bfhip_ica_post(h, d, _ptr(st.W1), _ptr(st.W), _ptr(res), 0, ica._CHUNK, _ptr(st.Wbuf), _ptr(st.meas))))]
 for name, f in pieces:
