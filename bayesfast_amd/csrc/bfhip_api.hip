@@ -87,7 +87,7 @@ extern "C" int bfhip_debug_buffer(const char *key, void *device_ptr) {
 }
 extern "C" const char *bfhip_debug_last_kernel(void) { return bf_tune().last_kernel; }
 
-extern "C" int bfhip_version(void) { return 101; }   // 101: BFHIP_TREE_MODE_WORK 4162 (was 4098), work[0] = size | laggard << 12
+extern "C" int bfhip_version(void) { return 102; }   // 102: bfhip_polar_ns work = 2 d^2 + n_iter + 10 doubles; 101: BFHIP_TREE_MODE_WORK 4162 (was 4098), work[0] = size | laggard << 12
 extern "C" const char *bfhip_last_error(void) { return g_err; }
 
 extern "C" int bfhip_ctx_create(bfhip_ctx **out, int device, void *stream) {

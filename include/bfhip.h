@@ -37,7 +37,8 @@ typedef struct bfhip_ctx bfhip_ctx;
 #define BFHIP_MAX_DIM 128         /* input_size limit of the device path */
 #define BFHIP_MAX_TREEDEPTH 12
 
-/* 101 (round 6): BFHIP_TREE_MODE_WORK grew to 4162 and work[0] of bfhip_tree_size_mode_share carries the laggard bit; 100 before. */
+/* 102 (round 6): bfhip_polar_ns takes 2 d^2 + n_iter + 10 doubles of work.  101 (round 6): BFHIP_TREE_MODE_WORK grew to 4162 and
+ * work[0] of bfhip_tree_size_mode_share carries the laggard bit; 100 before. */
 int bfhip_version(void);
 const char *bfhip_last_error(void);
 

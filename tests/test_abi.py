@@ -58,7 +58,7 @@ def test_enums_match_header():
 
 
 def test_version_and_argument_errors(library):
-    assert library.bfhip_version() >= 101   # (101: BFHIP_TREE_MODE_WORK 4162)
+    assert library.bfhip_version() >= 102   # (101: BFHIP_TREE_MODE_WORK 4162; 102: bfhip_polar_ns work size)
     # NULL context is rejected with ValueError semantics before anything touches a GPU
     rc = library.bfhip_logp_grad(None, 1, None, 0, None, None)
     assert rc == -1
