@@ -48,6 +48,7 @@ BfTune &bf_tune() {
         u.no_proof_weights = env_int("BFHIP_NO_PROOF_WEIGHTS", 0);
         u.pld_no_compress = env_int("BFHIP_PLD_NO_COMPRESS", 0);
         u.pld_no_cl = env_int("BFHIP_PLD_NO_CL", 0);
+        u.no_decay_shared = env_int("BFHIP_NO_DECAY_SHARED", 0);
         u.polar_tiles = env_int("BFHIP_POLAR_TILES", 0);
         u.no_group_pld = env_int("BFHIP_NO_GROUP_PLD", 0);
         return u;
@@ -60,7 +61,7 @@ static int *tune_field(const char *key) {
         {"no_group", &t.no_group}, {"no_pipe", &t.no_pipe}, {"no_plain", &t.no_plain}, {"no_quad", &t.no_quad}, {"wave_cpg", &t.wave_cpg},
         {"tail_relaunch", &t.tail_relaunch}, {"tail_stop", &t.tail_stop}, {"tail_q", &t.tail_q}, {"tail_max", &t.tail_max}, {"lone", &t.lone}, {"lone_form", &t.lone_form},
         {"pld_waves", &t.pld_waves}, {"cubic_form", &t.cubic_form}, {"cubic_loops", &t.cubic_loops}, {"gram_one_wave", &t.gram_one_wave}, {"chol_one_panel", &t.chol_one_panel}, {"no_vel_ahead", &t.no_vel_ahead}, {"tnuts_wpb", &t.tnuts_wpb}, {"tnuts_generic", &t.tnuts_generic}, {"no_bound_proof", &t.no_bound_proof},
-        {"no_proof_weights", &t.no_proof_weights}, {"pld_no_compress", &t.pld_no_compress}, {"pld_no_cl", &t.pld_no_cl}, {"polar_tiles", &t.polar_tiles}, {"no_group_pld", &t.no_group_pld}};
+        {"no_proof_weights", &t.no_proof_weights}, {"pld_no_compress", &t.pld_no_compress}, {"pld_no_cl", &t.pld_no_cl}, {"no_decay_shared", &t.no_decay_shared}, {"polar_tiles", &t.polar_tiles}, {"no_group_pld", &t.no_group_pld}};
     for (auto &e : tab)
         if (key && !strcmp(key, e.k)) return e.p;
     return NULL;
@@ -165,6 +166,8 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     m.has_quad = ds->quad != NULL;
     m.use_bound = ds->use_bound != 0;
     m.use_decay = ds->use_decay != 0;
+    m.decay_shared = ds->use_bound && ds->use_decay && memcmp(ds->decay_hess, ds->hess, (size_t)d * d * sizeof(double)) == 0 &&
+                     memcmp(ds->decay_mu, ds->mu, (size_t)d * sizeof(double)) == 0;
     const double *base = (const double *)ctx->model_buf;
     m.pd = base;
     m.Sf = base + (size_t)PD_N * DP;

@@ -62,6 +62,7 @@ struct PldDev {
 struct DevModel {
     int d, DP;
     int has_transform, has_su, has_quad, use_bound, use_decay, has_cubic;
+    int decay_shared;   // the decay term's Hessian and centre are the bound's, bit for bit (the usual case: both are taken from the fit points)
     const double *pd;   // [PD_N][DP]
     const double *Sf;   // quadratic form, symmetrised: S = A + A^T (so grad = S x + lin, f = c0 + lin.x + x.Sx/2)
     const double *Hf;   // bound Hessian

@@ -37,11 +37,15 @@
 // (levels >= 1); they let an iteration start from its predecessor's proposal without evaluating it again
 enum { SL_PROPG = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH, SL_PG = SL_PROPG + 1, SL_PIPE_N = SL_PG + BFHIP_MAX_TREEDEPTH };
 
-// DEC: a third matrix, the decay term's (density.py:740-746).  The K-split is the sliced kernel's for the same model
+// DEC = 1: a third matrix, the decay term's (density.py:740-746).  DEC = 2 (round 6): the decay term's matrix and centre ARE the
+// bound's -- SurrogateDensity.fit takes both from the same points by the same statements (modules/poly.py:262-276 and
+// core/density.py:796-811: mean and inv(cov)), the upload compares the arrays bit for bit -- so H_d (x - mu_d) is the product the
+// bound already needs and the radius of the decay term is the bound's: two matrices, with DEC = 1's K-split, i.e. the same job
+// per (matrix, row tile): the numbers are DEC = 1's to the last bit.  The K-split is the sliced kernel's for the same model
 // (sampler_ksplit: at most 16 jobs), so that the sums associate the same way: at W = 4 twelve jobs of 16 k-steps.
-template <int W, bool DEC = false>
+template <int W, int DEC = 0>
 struct PipeGeo {
-    static constexpr int NMAT = DEC ? 3 : 2;
+    static constexpr int NMAT = DEC == 1 ? 3 : 2;
     static constexpr int KS = DEC ? (W == 2 ? 2 : 1) : ((W == 2 || W == 4) ? 2 : 1);  // K-split of the matvec jobs: every wave owns at most one job
     static constexpr int KPJ = (4 * W) / KS, NJOB = NMAT * W * KS, NTL = 12;
     static constexpr int MPS = KPJ > 8 ? 2 : 1;  // MFMAs at each of the eight points of phase B the chain is spread over
@@ -66,7 +70,7 @@ template <> struct PipeAcc<2> { typedef d2_t type; };
 __device__ inline d4_t bf_pipe_mfma(double a_, double b_, d4_t c_) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0); }
 __device__ inline double bf_pipe_mfma(double a_, double b_, double c_) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b_, c_, 0, 0, 0); }
 
-template <int W, bool TR, bool DEC = false, int QUAD = 0>
+template <int W, bool TR, int DEC = 0, int QUAD = 0>
 __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerArgs a) {
     using G = SamplerGeo<W>;
     using PG = PipeGeo<W, DEC>;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
     if (tid < 8) alive[tid] = 0;
     const double c_lin = lane_ok ? m.pd[PD_LIN * DP + lane] : 0.;
     const double c_mu = lane_ok ? m.pd[PD_MU * DP + lane] : 0.;
-    const double c_dmu = (DEC && lane_ok) ? m.pd[PD_DMU * DP + lane] : 0.;
+    const double c_dmu = (DEC == 1 && lane_ok) ? m.pd[PD_DMU * DP + lane] : 0.;
     const double c_smu = lane_ok ? m.pd[PD_SMU * DP + lane] : 0.;
     // constraint transform of this lane's dimension (TR) and what phase A leaves for phase C: x(q), dx/dq,
     // (d2x/dq2) / (dx/dq), log |dx/dq|
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
                 const int xi = (lane >> 2) * XS + w + 16 * (lane & 3);  // B[k = dim&3][n = chain] of k-step dim>>2
                 XB[xi] = xs;
                 XB[NS * XS + xi] = xs - c_mu;
-                if constexpr (DEC) XB[2 * NS * XS + xi] = xs - c_dmu;   // (the decay term lives in the original space)
+                if constexpr (DEC == 1) XB[2 * NS * XS + xi] = xs - c_dmu;   // (the decay term lives in the original space)
             }
         }
         if (lane == 0) {
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
         if (evaluating && !ended) {
             const double sx = lane_ok ? gb_read(0) : 0.;
             const double hv = lane_ok ? gb_read(1) : 0.;
-            const double dgr = (DEC && lane_ok) ? gb_read(2) : 0.;   // H_decay (x - mu_decay)
+            const double dgr = DEC == 2 ? hv : ((DEC == 1 && lane_ok) ? gb_read(2) : 0.);   // H_decay (x - mu_decay); DEC = 2: the bound's product
             double gn = sx + c_lin;
             const double xm = xs - c_mu;
             constexpr bool fast_kin = !DEC;   // (with the decay term the gradient is final only after its sum)
@@ -715,12 +719,19 @@ __global__ __launch_bounds__(1024) void bf_nuts_pipe_kernel(DevModel m, SamplerA
             const double sv = sx - c_smu, gmu = c_smu + c_lin;   // S (x - mu), the gradient at mu (bfhip_oob.h)
             double r_kin = 0., r_val, r_b2, r_bd2 = 0., r_a[2] = {0., 0.};
             TRACE(7);
-            if constexpr (DEC) {
+            if constexpr (DEC == 1) {
                 // (the densities that carry the decay term live outside the bound: its sum and the two sums of the extrapolation
                 // ride in the first reduction -- the same numbers as reductions of their own)
                 double r5[5] = {(xs - c_dmu) * dgr, __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv, xm * gmu, xm * sv};
                 wave_sum_n<5>(r5);
                 r_bd2 = r5[0]; r_val = r5[1]; r_b2 = r5[2]; r_a[0] = r5[3]; r_a[1] = r5[4];
+            } else if constexpr (DEC == 2) {
+                // (the decay term's radius IS the bound's: (x - mu_d) . H_d (x - mu_d) = (x - mu) . H (x - mu), the same products summed
+                // the same way)
+                double r4[4] = {__builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv, xm * gmu, xm * sv};
+                wave_sum_n<4>(r4);
+                r_val = r4[0]; r_b2 = r4[1]; r_a[0] = r4[2]; r_a[1] = r4[3];
+                r_bd2 = r_b2;
             } else {
                 double r3[3] = {0., __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv};
                 {  // in-bound gradient is already final: the kinetic energy rides along

@@ -1993,7 +1993,7 @@ static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks,
     return 1;
 }
 
-template <int W, bool TR = false, bool DEC = false>
+template <int W, bool TR = false, int DEC = 0>
 static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     SamplerArgs args = args_in;
     args.cpg = wave_layout_cpg(ctx, args.n_chain, 16);
@@ -2007,7 +2007,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = (CANQ && args.cpg <= 4 && !bf_tune().no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
              : ((CANQ && args.cpg <= 8 && !bf_tune().no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
     if ((args.cpg <= 4 && !bf_tune().no_quad && bf_tune().wave_cpg == 0) || bf_tune().lone == 2) {
-        const int r = launch_lone<W, TR, DEC>(ctx, args, args.n_chain, false);
+        const int r = launch_lone<W, TR, (DEC != 0)>(ctx, args, args.n_chain, false);
         if (r != 0) return r < 0 ? r : 0;
     }
     const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);
@@ -2046,7 +2046,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
         a2.cpg = 4;
         {   // the stragglers one per workgroup in the latency kernel (at most tail_stop chains of every first-part workgroup are listed)
             const int most = args.n_chain < args.tail_stop * groups ? args.n_chain : args.tail_stop * groups;
-            const int r = launch_lone<W, TR, DEC>(ctx, a2, most, true);
+            const int r = launch_lone<W, TR, (DEC != 0)>(ctx, a2, most, true);
             if (r != 0) return r < 0 ? r : 0;
         }
         // (at most four chains of every first-part workgroup are listed: groups workgroups of four chains, or one chain per CU)
@@ -2117,8 +2117,11 @@ static int launch_sampler(bfhip_ctx *ctx, const SamplerArgs &args) {
         return launch_nuts_pipe<(W <= 4 ? W : 1), (W <= 4)>(ctx, args);
     // ... and with the decay penalty (the GBS recipes' densities: configs 3 and 4)
     if (W <= 4 && NUTS && !(bf_tune().no_pipe != 0) && !(bf_tune().no_plain != 0) && !stamped && m.has_quad && m.use_bound && m.use_decay &&
-        !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link)
-        return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4)>(ctx, args);
+        !m.has_transform && !m.has_su && !m.has_cubic && !m.has_link) {
+        // (the decay term's matrix and centre are the bound's, bit for bit: two matrices do, bfhip_nuts_pipe.h)
+        if (m.decay_shared && !bf_tune().no_decay_shared) return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4 ? 2 : 0)>(ctx, args);
+        return launch_nuts_pipe<(W <= 4 ? W : 1), false, (W <= 4 ? 1 : 0)>(ctx, args);
+    }
 #ifndef BF_ONLY_HEADLINE
     // the common surrogate with the decay penalty and / or the constraint transform: compile-time feature sets at
     // 33 <= d <= 64 (the optional features' branches and register arrays of the run-time kernel disappear)

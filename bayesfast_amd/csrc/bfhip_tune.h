@@ -27,6 +27,7 @@ struct BfTune {
     int no_proof_weights;// BFHIP_NO_PROOF_WEIGHTS: the bound proof with the plain norm (read at upload)
     int no_group_pld;    // BFHIP_NO_GROUP_PLD: keep the pipeline density off the lane-per-chain group kernel (tests compare)
     int polar_tiles;     // BFHIP_POLAR_TILES: bfhip_polar_ns runs its first form (a tile per wave, two grid barriers per step) also at d <= 256 (tests compare)
+    int no_decay_shared; // BFHIP_NO_DECAY_SHARED: the pipelined kernel runs the decay term's third matrix also when it is the bound's (tests compare)
     int pld_no_cl;       // BFHIP_PLD_NO_CL: the pipeline density's contractions stream their A fragments from L2 also where the LDS copy fits (tests compare)
     int pld_no_compress; // BFHIP_PLD_NO_COMPRESS: the pipeline density without the output-space compression (read at upload)
     // --- measurement buffers (device pointers or NULL) ---

@@ -21,7 +21,7 @@ def golden_dir():
 # every integer switch of include/bfhip_debug.h
 DEBUG_SWITCHES = ('no_group', 'no_pipe', 'no_plain', 'no_quad', 'wave_cpg', 'tail_relaunch', 'tail_stop', 'tail_q', 'tail_max', 'lone',
                   'lone_form', 'pld_waves', 'cubic_form', 'cubic_loops', 'gram_one_wave', 'chol_one_panel', 'no_vel_ahead', 'tnuts_wpb', 'tnuts_generic',
-                  'no_bound_proof', 'no_proof_weights', 'pld_no_compress', 'pld_no_cl', 'polar_tiles', 'no_group_pld')
+                  'no_bound_proof', 'no_proof_weights', 'pld_no_compress', 'pld_no_cl', 'polar_tiles', 'no_decay_shared', 'no_group_pld')
 
 
 @pytest.fixture(autouse=True)

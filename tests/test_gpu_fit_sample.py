@@ -321,6 +321,42 @@ def test_config4_funnel_target_accept_095():
     assert acc > 0.85, acc
 
 
+@pytest.mark.parametrize('n_chain', [96, 4, 8, 600])
+def test_decay_term_on_the_bounds_matrix_is_bit_identical(n_chain):
+    """SurrogateDensity.fit takes the decay term's centre and Hessian from the same points, by the same statements, as the bound's
+    (core/density.py:796-811, modules/poly.py:262-276): the upload sees identical arrays and the pipelined kernel then runs TWO
+    matrices (H_d (x - mu_d) is the bound's product, the decay radius the bound's) -- the same numbers as the three-matrix form,
+    bit for bit, at every chains-per-workgroup form of the kernel (4 / 8 / 16 chains) and through the latency kernel's tail."""
+    from bayesfast_amd import PolyModel, SurrogateDensity
+    from bayesfast_amd._lib import debug_set
+    from bayesfast_amd.chains import DeviceChains
+    from bayesfast_amd.workloads import banana_logp
+    from bayesfast_amd.device import get_context
+    ctx = get_context(0)
+    D = 64
+    logp = banana_logp(D)
+    su = PolyModel('quadratic', input_size=D, output_size=1)
+    den = SurrogateDensity(su, decay_options=dict(use_decay=True))
+    rng = np.random.default_rng(3)
+    x_fit = rng.normal(size=(2 * su.n_param, D))
+    den.fit(x_fit, logp(x_fit))
+    assert np.array_equal(den._hess, su._hess) and np.array_equal(den._mu, su._mu)   # (what the upload compares)
+    x0 = rng.normal(size=(n_chain, D)) * 0.7
+    out = []
+    for off in (0, 1):
+        debug_set('no_decay_shared', off)
+        dc = DeviceChains(den.device(ctx), x0, seed=5)
+        s_a, st_a = dc.run(40, 'NUTS', n_warmup=30, layout='wave')
+        s_b, st_b = dc.run(25, 'NUTS', n_warmup=30, layout='wave')
+        out.append([t.cpu().numpy() for t in (s_a, st_a, s_b, st_b)] + [dc.total_leapfrog])
+    debug_set('no_decay_shared', 0)
+    for a, b in zip(out[0][:4], out[1][:4]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][4] == out[1][4] and out[0][4] > 65 * n_chain
+    from bayesfast_amd import _lib
+    assert (out[0][1][:, :, _lib.NSTATS.index('tree_size')] > 1).any()
+
+
 @pytest.mark.parametrize('ipl,pipeline,n_rank', [(0, False, 2), (7, False, 2), (0, True, 2), (7, False, 8)])
 def test_sample_two_ranks_equals_one_rank(tmp_path, ipl, pipeline, n_rank):
     """(ipl = 7: nine launches per round under layout 'auto' -- the layout of a launch is a pure function of the launches
