@@ -173,6 +173,10 @@ extern "C" int bfhip_density_upload(bfhip_ctx *ctx, const bfhip_density_desc *ds
     m.Sf = base + (size_t)PD_N * DP;
     m.Hf = m.Sf + MAT;
     m.Hdf = m.Hf + MAT;
+    // (decay_shared: EVERY kernel takes the decay term's product from the bound's fragments -- H (x - mu) where the reference writes
+    // (x - mu) H, core/density.py:745: the same numbers for a symmetric H, and inv(cov) is symmetric to rounding -- so that the
+    // two-matrix form of the pipelined kernel and the three-matrix forms of the others agree bit for bit)
+    if (m.decay_shared) m.Hdf = m.Hf;
     m.c0 = ds->c0;
     m.alpha = ds->alpha;
     m.lam_max = ds->use_bound ? bf_bound_lam_max_weighted(ds->hess, ds->d, h.data() + (size_t)PD_HD * DP) : 0.;

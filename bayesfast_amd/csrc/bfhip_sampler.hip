@@ -2031,6 +2031,8 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     }
     hipLaunchKernelGGL(k, dim3(groups), dim3(1024), lds, ctx->stream, ctx->model, args);
     BF_HIP_CHECK(hipGetLastError());
+    snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_nuts_pipe_kernel<%d, %s, %d, %d>", W, TR ? "true" : "false", DEC,
+             (args.cpg <= 4 && !bf_tune().no_quad) ? 1 : ((args.cpg <= 8 && !bf_tune().no_quad) ? 2 : 0));
     if (two_parts) {
         hipLaunchKernelGGL(bf_tail_list_kernel, dim3((args.n_chain + 255) / 256), dim3(256), 0, ctx->stream, args.n_chain, args.iter_end, args.sc,
                            ctx->tail_buf);

@@ -180,12 +180,24 @@ def random_pipeline_spec(m, d, nq, seed=0, bound=True, transform=True):
                 prior=dict(mu=np.zeros(d), prec_diag=np.where(np.arange(d) % 2, 4., 0.), c0=0.))
 
 
+def decay_shares_bound(spec):
+    """The decay term's Hessian and centre are the bound's arrays, bit for bit (what ``bfhip_density_upload`` compares)."""
+    poly = spec.get('poly') or {}
+    if not (spec.get('use_decay') and poly.get('use_bound')) or poly.get('hess') is None or spec.get('decay_hess') is None:
+        return False
+    return bool(np.array_equal(np.asarray(spec['decay_hess']), np.asarray(poly['hess'])) and
+                np.array_equal(np.asarray(spec['decay_mu']), np.asarray(poly['mu'])))
+
+
 def flops_per_leapfrog_spec(spec):
     """Algorithmic flops of one leapfrog step on a density spec: one d x d matvec (2 d^2) each for S x, the bound's
-    H (x - mu) and the decay term's H_d (x - mu_d), plus the cubic configs' contractions on their masked inputs
-    (cubic-2: two n2 x n2 matvecs; cubic-3: one n3^3 contraction); the O(d) tail is ignored."""
+    H (x - mu) and the decay term's H_d (x - mu_d) -- unless the decay term's matrix and centre ARE the bound's (``decay_shares_bound``:
+    the usual case, both come from the fit points; one product then serves both) -- plus the cubic configs' contractions on their
+    masked inputs (cubic-2: two n2 x n2 matvecs; cubic-3: one n3^3 contraction); the O(d) tail is ignored."""
     d = int(spec['d'])
     poly = spec['poly']
+    if decay_shares_bound(spec):
+        spec = dict(spec, use_decay=False)
     orders = {c['order']: np.asarray(c['input_mask']).size for c in poly['configs']}
     if spec.get('chi2') is not None:
         # pipeline density: f = C phi and C^T r, C (m, n_monomials) with the configs' masks (bfhip_pld.h), plus the matvecs of

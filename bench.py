@@ -62,10 +62,11 @@ def _dominant_roofline(rounds):
     rf = dict(r['roofline'])
     rf['round'] = rounds.index(r)
     rf['share_of_timed_region'] = r['wall_s_timed'] / sum(b['wall_s_timed'] for b in rounds)
-    rf['flops_note'] = ('achieved / frac count the flops the kernel EXECUTED per launch (S x, H (x - mu), H_decay (x - mu_d): 6 d^2 per '
-                        'leapfrog step on this density; the wave-layout kernel executes all three in every trip) over kernel_ms_per_launch, '
-                        'the HIP-event time of one launch of the dominant round averaged over its timed launches; *_algorithmic count them '
-                        'whether executed or proven away')
+    rf['flops_note'] = ('achieved / frac count the flops the kernel EXECUTED per launch -- S x and H (x - mu), 4 d^2 per leapfrog step: the decay '
+                        'term\'s matrix and centre are the bound\'s on this density (both come from the fit points), so its product '
+                        'H_d (x - mu_d) is the bound\'s and the pipelined kernel\'s two-matrix form runs it once; round 5 executed 6 d^2 -- over '
+                        'kernel_ms_per_launch, the HIP-event time of one launch of the dominant round averaged over its timed launches; '
+                        '*_algorithmic count the same 4 d^2 whether executed or proven away')
     return rf
 
 

@@ -258,7 +258,7 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
     launch stream).  Returns (block dict, samples (C, iters, d), stats) of the last launch."""
     import torch
     from bayesfast_amd.chains import DeviceChains
-    from bayesfast_amd.workloads import B_STEP_BYTES, flops_per_leapfrog_spec
+    from bayesfast_amd.workloads import B_STEP_BYTES, flops_per_leapfrog_spec, decay_shares_bound
     from bayesfast_amd import _lib
     dd = den.device(ctx)
     C, d = x0.shape
@@ -308,6 +308,10 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
             # the group kernel leaves the zero tiles of the triangular C' = R out of both contractions: (NT + 1) / (2 NT) of the tile k-steps
             nt = -(-nf // 16)
             exec_share = (fl - 4 * m_out * nf + 4 * nf * nf * (nt + 1) / (2. * nt)) / fl
+    if spec.get('chi2') is None and decay_shares_bound(spec) and not (kname().startswith('bf_nuts_pipe_kernel') and ', 2, ' in kname()):
+        # the decay term shares the bound's matrix: one product would do; every kernel but the pipelined kernel's two-matrix form still
+        # runs it a second time (the same numbers)
+        exec_share = (fl + 2 * d * d) / fl
     out = {'workload': what, 'value': n_lf / (ms * 1e-3), 'unit': 'leapfrog steps/sec', 'chains': int(C), 'dim': int(d),
            'leapfrogs_timed': int(n_lf), 'wall_s_timed': t_wall, 'steps_timed': int(steps),
            'nuts_iterations_timed': steps * iters, 'nuts_adaptation_iterations': n_adapt, 'ms_per_launch': ms / steps,
@@ -331,8 +335,8 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
         if spec.get('chi2') is None and spec['poly'].get('use_bound'):
             # the lane-per-chain kernels leave the bound's (and the decay term's) tiles out of a trip whose 16 chains are PROVEN
             # inside (identical results): those flops are decided, not executed
-            n_prov = 1 + (1 if spec.get('use_decay') else 0)
-            n_mat = 1 + n_prov
+            n_prov = 1 + (1 if spec.get('use_decay') else 0)                      # matrices a trip with bound tiles EXECUTES beside S
+            n_mat = 1 + n_prov - (1 if decay_shares_bound(spec) else 0)           # matrices the algorithm needs (fl)
             share = (1. + n_prov * gc[1] / gc[0]) / n_mat
             rf = out['roofline']
             rf.update({'achieved': ach * share, 'frac': ach * share / 78.6, 'executed_share_of_algorithmic_flops': share})
