@@ -59,7 +59,7 @@ enum { LF_NONE = 0, LF_LEAF = 1, LF_INIT = 2 };
 // direction (NEW: of the first doubling; closing: of the next one) | NEW: the evaluation that opens a launch (step of length 0)
 enum { LV_CMD = 0, LV_CLOSE, LV_EO, LV_EVAL, LV_DIR, LV_INIT, LV_N = 8 };
 
-template <int W, bool DEC>
+template <int W, int DEC>
 struct LoneGeo {
     using PG = PipeGeo<W, DEC>;
     static constexpr int DP = 16 * W, NS = 4 * W, NMAT = PG::NMAT, KS = PG::KS, KPJ = PG::KPJ;
@@ -90,7 +90,7 @@ struct LoneGeo {
 // fragment); B: the lane's k = lane >> 4, every column the chain's x (only column 0 is read back); D: lane 16 i + 4 b + j = row
 // 4 b + i, column j.  The NJT = NMAT x KS x W jobs are dealt over NT waves (wave r: jobs r, r + NT, ...), each wave running its
 // jobs as independent chains side by side, A fragments in registers for the whole launch.
-template <int W, bool DEC, int NT>
+template <int W, int DEC, int NT>
 struct LoneJobs {
     using LG = LoneGeo<W, DEC>;
     static constexpr int NJT = LG::NMAT * LG::KS * W, JPW = (NJT + NT - 1) / NT;
@@ -138,7 +138,7 @@ struct LoneJobs {
 // (The same with the decay term, whose jobs are twelve chains of sixteen k-steps: three job waves of four chains, 1.72 against 1.67 us.)
 // FORM 1 (d > 32 only): three job waves instead of four -- a workgroup of four waves, two of them a CU at 256 registers a wave, for
 // launches of up to two chains per CU (the jobs take 48 matrix instructions per wave instead of 32).
-template <int W, bool DEC, int FORM = 0> struct LoneWaves {
+template <int W, int DEC, int FORM = 0> struct LoneWaves {
     static constexpr bool ITILE = true;                   // the integrator runs jobs
     // waves that run jobs.  d <= 32: the integrator alone -- its 8 chains of 4 k-steps cost 250 cycles more than shared with a second
     // wave, but a workgroup is then two waves and four of them fit a CU at 256 registers a wave, without the bookkeeper's spills:
@@ -148,7 +148,7 @@ template <int W, bool DEC, int FORM = 0> struct LoneWaves {
     static constexpr int NW = KW + 1;
 };
 
-template <int W, bool TR, bool DEC, int MINW, int FORM = 0>
+template <int W, bool TR, int DEC, int MINW, int FORM = 0>   // DEC: 0 none, 1 the decay term's own matrix, 2 the bound's (bfhip_nuts_pipe.h)
 __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_lone_kernel(DevModel m, SamplerArgs a) {
     using LG = LoneGeo<W, DEC>;
     using LWV = LoneWaves<W, DEC, FORM>;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
         // ================================ integrator ================================
         const double c_lin = lane_ok ? m.pd[PD_LIN * DP + lane] : 0.;
         const double c_mu = lane_ok ? m.pd[PD_MU * DP + lane] : 0.;
-        const double c_dmu = (DEC && lane_ok) ? m.pd[PD_DMU * DP + lane] : 0.;
+        const double c_dmu = (DEC == 1 && lane_ok) ? m.pd[PD_DMU * DP + lane] : 0.;
         const double c_smu = lane_ok ? m.pd[PD_SMU * DP + lane] : 0.;
         const int c_kind = (TR && lane_ok) ? (int)m.pd[PD_KIND * DP + lane] : 0;
         const double c_lo = (TR && lane_ok) ? m.pd[PD_LO * DP + lane] : 0., c_rg = (TR && lane_ok) ? m.pd[PD_RG * DP + lane] : 1.;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
                 if (lane_ok) {
                     XT[xti] = xs;
                     XT[DP + xti] = xs - c_mu;
-                    if constexpr (DEC) XT[2 * DP + xti] = xs - c_dmu;
+                    if constexpr (DEC == 1) XT[2 * DP + xti] = xs - c_dmu;
                 }
             }
             LTRACE(0, 2);
@@ -292,16 +292,21 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
                 };
                 const double sx = lane_ok ? gb_read(0) : 0.;
                 const double hv = lane_ok ? gb_read(1) : 0.;
-                const double dgr = (DEC && lane_ok) ? gb_read(2) : 0.;   // H_decay (x - mu_decay)
+                const double dgr = DEC == 2 ? hv : ((DEC == 1 && lane_ok) ? gb_read(2) : 0.);   // H_decay (x - mu_decay); DEC = 2: the bound's product
                 double gn = sx + c_lin;
                 const double xm = xs - c_mu;
                 constexpr bool fast_kin = !DEC;
                 const double sv = sx - c_smu, gmu = c_smu + c_lin;
                 double r_kin = 0., r_val, r_b2, r_bd2 = 0., r_a[2] = {0., 0.};
-                if constexpr (DEC) {
+                if constexpr (DEC == 1) {
                     double r5[5] = {(xs - c_dmu) * dgr, __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv, xm * gmu, xm * sv};
                     wave_sum_n<5>(r5);
                     r_bd2 = r5[0]; r_val = r5[1]; r_b2 = r5[2]; r_a[0] = r5[3]; r_a[1] = r5[4];
+                } else if constexpr (DEC == 2) {   // (bf_nuts_pipe_kernel: the decay term's radius is the bound's)
+                    double r4[4] = {__builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv, xm * gmu, xm * sv};
+                    wave_sum_n<4>(r4);
+                    r_val = r4[0]; r_b2 = r4[1]; r_a[0] = r4[2]; r_a[1] = r4[3];
+                    r_bd2 = r_b2;
                 } else {
                     double r3[3] = {0., __builtin_fma(0.5 * xs, sx, c_lin * xs), xm * hv};
                     {

@@ -46,7 +46,7 @@ enum { SL_PROPG = SL_STACK + 4 * BFHIP_MAX_TREEDEPTH, SL_PG = SL_PROPG + 1, SL_P
 template <int W, int DEC = 0>
 struct PipeGeo {
     static constexpr int NMAT = DEC == 1 ? 3 : 2;
-    static constexpr int KS = DEC ? (W == 2 ? 2 : 1) : ((W == 2 || W == 4) ? 2 : 1);  // K-split of the matvec jobs: every wave owns at most one job
+    static constexpr int KS = DEC == 1 ? (W == 2 ? 2 : 1) : ((W == 2 || W == 4) ? 2 : 1);  // K-split of the matvec jobs: every wave owns at most one job
     static constexpr int KPJ = (4 * W) / KS, NJOB = NMAT * W * KS, NTL = 12;
     static constexpr int MPS = KPJ > 8 ? 2 : 1;  // MFMAs at each of the eight points of phase B the chain is spread over
     static_assert(NJOB <= 16 && KPJ <= 8 * MPS, "one job per wave, eight MFMA sites");

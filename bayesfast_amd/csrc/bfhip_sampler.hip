@@ -1936,15 +1936,15 @@ template <int W> struct LoneOcc { static constexpr int MINW = W == 1 ? 2 : 3; };
 
 // form 0: the roomy instantiation (W job waves at d > 32); form 1: three job waves (d > 32: two four-wave workgroups a CU at 256
 // registers); form 2: the tight instantiation (168 / 128 registers: the tail's stragglers when they outnumber the CUs' room)
-template <int W, bool TR, bool DEC, int FORM>
+template <int W, bool TR, int DEC, int FORM>
 static const void *lone_kernel_ptr() {
     if constexpr (FORM == 0) { auto k = bf_lone_kernel<W, TR, DEC, 1, 0>; return (const void *)k; }
     else if constexpr (FORM == 1) { auto k = bf_lone_kernel<W, TR, DEC, 1, (W == 4 ? 1 : 0)>; return (const void *)k; }
     else { auto k = bf_lone_kernel<W, TR, DEC, LoneOcc<W>::MINW, 0>; return (const void *)k; }
 }
-template <int W, bool DEC, int FORM> constexpr int lone_threads() { return LoneWaves<W, DEC, (FORM == 1 && W == 4) ? 1 : 0>::NW * 64; }
+template <int W, int DEC, int FORM> constexpr int lone_threads() { return LoneWaves<W, DEC, (FORM == 1 && W == 4) ? 1 : 0>::NW * 64; }
 
-template <int W, bool TR, bool DEC, int FORM>
+template <int W, bool TR, int DEC, int FORM>
 static int lone_blocks_per_cu(bfhip_ctx *ctx) {
     const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
     int nb = 0;
@@ -1954,7 +1954,7 @@ static int lone_blocks_per_cu(bfhip_ctx *ctx) {
     return nb;
 }
 
-template <int W, bool TR, bool DEC, int FORM>
+template <int W, bool TR, int DEC, int FORM>
 static void lone_launch_form(bfhip_ctx *ctx, const SamplerArgs &args, int n_blocks) {
     const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
     if constexpr (FORM == 0) hipLaunchKernelGGL((bf_lone_kernel<W, TR, DEC, 1, 0>), dim3(n_blocks), dim3(lone_threads<W, DEC, 0>()), lds, ctx->stream, ctx->model, args);
@@ -1963,7 +1963,7 @@ static void lone_launch_form(bfhip_ctx *ctx, const SamplerArgs &args, int n_bloc
 }
 
 // returns 1 when the launch was taken, 0 when the caller should use the pipelined kernel, < 0 on error
-template <int W, bool TR, bool DEC>
+template <int W, bool TR, int DEC>
 static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks, bool tail) {
     if (!bf_tune().lone || args_in.stamps) return 0;
     SamplerArgs args = args_in;
@@ -1989,7 +1989,7 @@ static int launch_lone(bfhip_ctx *ctx, const SamplerArgs &args_in, int n_blocks,
     else if (form == 1) lone_launch_form<W, TR, DEC, 1>(ctx, args, n_blocks);
     else lone_launch_form<W, TR, DEC, 2>(ctx, args, n_blocks);
     BF_HIP_CHECK(hipGetLastError());
-    if (!tail) snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_lone_kernel<%d, %s, %s, %d>", W, TR ? "true" : "false", DEC ? "true" : "false", form);
+    if (!tail) snprintf(bf_tune().last_kernel, sizeof(bf_tune().last_kernel), "bf_lone_kernel<%d, %s, %d, %d>", W, TR ? "true" : "false", DEC, form);
     return 1;
 }
 
@@ -2007,7 +2007,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
     auto k = (CANQ && args.cpg <= 4 && !bf_tune().no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 1 : 0>
              : ((CANQ && args.cpg <= 8 && !bf_tune().no_quad) ? bf_nuts_pipe_kernel<W, TR, DEC, CANQ ? 2 : 0> : bf_nuts_pipe_kernel<W, TR, DEC>);
     if ((args.cpg <= 4 && !bf_tune().no_quad && bf_tune().wave_cpg == 0) || bf_tune().lone == 2) {
-        const int r = launch_lone<W, TR, (DEC != 0)>(ctx, args, args.n_chain, false);
+        const int r = launch_lone<W, TR, DEC>(ctx, args, args.n_chain, false);
         if (r != 0) return r < 0 ? r : 0;
     }
     const size_t lds = PipeGeo<W, DEC>::lds_doubles() * sizeof(double);
@@ -2048,7 +2048,7 @@ static int launch_nuts_pipe(bfhip_ctx *ctx, const SamplerArgs &args_in) {
         a2.cpg = 4;
         {   // the stragglers one per workgroup in the latency kernel (at most tail_stop chains of every first-part workgroup are listed)
             const int most = args.n_chain < args.tail_stop * groups ? args.n_chain : args.tail_stop * groups;
-            const int r = launch_lone<W, TR, (DEC != 0)>(ctx, a2, most, true);
+            const int r = launch_lone<W, TR, DEC>(ctx, a2, most, true);
             if (r != 0) return r < 0 ? r : 0;
         }
         // (at most four chains of every first-part workgroup are listed: groups workgroups of four chains, or one chain per CU)
