@@ -31,7 +31,10 @@ def test_bench_single_gpu_line():
     assert rf['bound'] in ('hbm', 'mfma') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     assert 'workload' in j['config'] and 'model' not in j['config']
     assert 'extras_error' not in j, j.get('extras_error')
-    assert rf['frac'] <= rf['frac_algorithmic'] + 1e-12 and 'config 3' in j['config']['workload'] and 'banana' in j['config']['workload']
+    # (executed flops: never more than the algorithm's, except where a kernel runs the decay term's product although it is the bound's)
+    assert abs(rf['frac'] - rf['frac_algorithmic'] * rf['executed_share_of_algorithmic_flops']) < 1e-9 * rf['frac']
+    assert rf['executed_share_of_algorithmic_flops'] <= 1. + 1e-12 or not rf['kernel'].startswith(('bf_nuts_pipe_kernel', 'bf_lone_kernel'))
+    assert 'config 3' in j['config']['workload'] and 'banana' in j['config']['workload']
     # the line is SURVEY 8d's config 3: both rounds, the refit between them, and value = their leapfrogs over their sampling time
     r0, r1 = j['config3_round0'], j['config3_round1']
     assert j['config']['timed_launches_round0'] == 1 and j['config']['timed_launches_round1'] == 1

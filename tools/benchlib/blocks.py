@@ -308,9 +308,9 @@ def _sampler_block(ctx, den, x0, seed, target_accept, n_adapt, iters, steps, cpu
             # the group kernel leaves the zero tiles of the triangular C' = R out of both contractions: (NT + 1) / (2 NT) of the tile k-steps
             nt = -(-nf // 16)
             exec_share = (fl - 4 * m_out * nf + 4 * nf * nf * (nt + 1) / (2. * nt)) / fl
-    if spec.get('chi2') is None and decay_shares_bound(spec) and not (kname().startswith('bf_nuts_pipe_kernel') and ', 2, ' in kname()):
-        # the decay term shares the bound's matrix: one product would do; every kernel but the pipelined kernel's two-matrix form still
-        # runs it a second time (the same numbers)
+    if spec.get('chi2') is None and decay_shares_bound(spec) and not (kname().startswith(('bf_nuts_pipe_kernel', 'bf_lone_kernel')) and ', 2, ' in kname()):
+        # the decay term shares the bound's matrix: one product would do; every kernel but the two-matrix forms of the pipelined and the
+        # latency kernel still runs it a second time (the same numbers)
         exec_share = (fl + 2 * d * d) / fl
     out = {'workload': what, 'value': n_lf / (ms * 1e-3), 'unit': 'leapfrog steps/sec', 'chains': int(C), 'dim': int(d),
            'leapfrogs_timed': int(n_lf), 'wall_s_timed': t_wall, 'steps_timed': int(steps),
