@@ -60,6 +60,7 @@ typedef struct {
     double *C;          /* (m, nf) */
     double *Ct;         /* (nf, m) */
     double *Hs, *Hds;   /* symmetrised bound / decay Hessians */
+    int decay_shared;   /* the decay term's centre and Hessian are the bound's arrays (both come from the fit points): one product serves both */
 } tuned_t;
 
 static tuned_t g_tab[TUNED_MAX];
@@ -281,7 +282,12 @@ static int tuned_eval(const bfo_density *dn, const double *x, int original_space
         }
         f += dn->prior_c0 - 0.5 * pr;
     }
-    if (dn->use_decay) {
+    if (dn->use_decay && t->decay_shared) {
+        /* (x - mu_d) = xm and H_d xm = hv: the bound's product and radius (the device's two-matrix kernels do the same) */
+        const double b2 = beta * beta, ex = b2 - dn->decay_alpha2;
+        f -= dn->decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
+        if (b2 > dn->decay_alpha2) for (int i = 0; i < d; ++i) g[i] -= 2. * dn->decay_gamma * hv[i];
+    } else if (dn->use_decay) {
         double xd[TUNED_MAXD], hd[TUNED_MAXD];
         for (int i = 0; i < d; ++i) xd[i] = xo[i] - dn->decay_mu[i];
         matvec(t->Hds, xd, hd, d);
@@ -333,6 +339,9 @@ int bfo_tuned_prepare(const bfo_density *dn) {
     memset(t, 0, sizeof(*t));
     if (pm->use_bound && !(t->Hs = symmetrised(pm->hess, d))) return -1;
     if (dn->use_decay && !(t->Hds = symmetrised(dn->decay_hess, d))) { tuned_free(t); return -1; }
+    t->decay_shared = dn->use_decay && pm->use_bound && !dn->su_lo && pm->hess && pm->mu &&
+                      memcmp(dn->decay_hess, pm->hess, (size_t)d * d * sizeof(double)) == 0 &&
+                      memcmp(dn->decay_mu, pm->mu, (size_t)d * sizeof(double)) == 0;
     t->dn = dn;
     t->d = d;
     t->m = m;

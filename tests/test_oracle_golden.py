@@ -321,7 +321,10 @@ def _random_single_output_spec(d, rng, cubic, decay, transform, su, link):
     poly = dict(input_size=d, output_size=1, configs=cfgs, use_bound=False)
     poly.update(orc.set_bound(poly, xs, rng.normal(size=xs.shape[0]), dict(alpha_p=80.)))
     spec = dict(d=d, poly=poly)
-    if decay:
+    if decay == 2:   # the decay term on the bound's own points: its centre and Hessian ARE the bound's arrays (SurrogateDensity.fit's case)
+        spec.update(orc.set_decay(xs, alpha_p=90.))
+        assert np.array_equal(spec['decay_hess'], poly['hess']) and np.array_equal(spec['decay_mu'], poly['mu'])
+    elif decay:
         spec.update(orc.set_decay(xs * 0.7, alpha_p=90.))
     if transform:
         spec['ranges'] = np.stack((-4. - rng.uniform(size=d), 4. + rng.uniform(size=d)), axis=1)
@@ -336,7 +339,8 @@ def _random_single_output_spec(d, rng, cubic, decay, transform, su, link):
     return spec
 
 
-@pytest.mark.parametrize('cubic,decay,transform,su,link', [(0, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 1, 1, 0), (0, 0, 1, 0, 1), (0, 1, 0, 1, 0), (1, 0, 0, 0, 1)])
+@pytest.mark.parametrize('cubic,decay,transform,su,link', [(0, 1, 0, 0, 0), (1, 0, 0, 0, 0), (1, 1, 1, 1, 0), (0, 0, 1, 0, 1), (0, 1, 0, 1, 0), (1, 0, 0, 0, 1),
+                                                          (0, 2, 0, 0, 0), (1, 2, 1, 0, 0), (0, 2, 0, 1, 1)])
 def test_tuned_evaluation_of_every_single_output_feature_set(cubic, decay, transform, su, link):
     """Round 6: the tuned evaluation covers decay, points outside the bound (by linearity, or a second evaluation with cubic
     configs), cubic configs, transforms, input scaling and the Gaussian link -- the config blocks' CPU baselines all run it."""
