@@ -82,7 +82,9 @@ typedef struct {
     const double *hess;           /* (d,d) */
     double alpha;
     double f_mu;
-    /* Density decay, core/density.py:761-811 */
+    /* Density decay, core/density.py:761-811.  When decay_mu / decay_hess hold the same numbers as mu / hess bit for bit -- the
+     * reference takes both pairs from the fit points by the same statements (modules/poly.py:262-276, core/density.py:796-811) --
+     * the decay term's product H_d (x - mu_d) is the bound's H (x - mu) and the kernels run it once. */
     int use_decay;
     const double *decay_mu;       /* (d,) */
     const double *decay_hess;     /* (d,d) */

@@ -3,7 +3,8 @@ workload (target_accept 0.95): LAYOUT=auto|group|wave BFHIP_NUTS_KERNEL=pipe|sli
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-import bench
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from benchlib import blocks as bench   # (hetero_rate moved there in round 6)
 from bayesfast_amd.device import get_context
 ctx = get_context(0)
 lay = os.environ.get('LAYOUT', 'auto')
