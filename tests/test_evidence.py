@@ -490,3 +490,32 @@ def test_polar_ns_is_the_orthogonal_polar_factor(d):
     scale = np.sqrt(np.abs(A).sum(0).max() * np.abs(A).sum(1).max())
     np.testing.assert_allclose(x0, A / scale, rtol=1e-15)
     debug_set('polar_tiles', 0)
+
+
+@pytest.mark.gpu
+def test_device_spline_build_edge_columns_follow_the_host_construction(monkeypatch):
+    """Columns the construction struggles with -- five distinct values (too few distinct percentile knots: the kernel gives the
+    coordinate up and the host construction builds it, degenerate as in the reference), values rounded to one decimal (ties among the
+    percentiles), two far clusters (wide-gap knots) -- next to well-behaved ones: the device route returns what the host route returns."""
+    from bayesfast_amd.transforms import SIT
+    from bayesfast_amd.device import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(0)
+    n, d = 20000, 6
+    y = rng.normal(size=(n, d))
+    y[:, 1] = rng.integers(0, 5, size=n)
+    y[:, 2] = np.round(y[:, 2], 1)
+    y[:, 3] = np.where(rng.uniform(size=n) < 0.5, -50., 50.) + 0.01 * rng.normal(size=n)
+    sit = SIT(n_iter=1, random_generator=1)
+    sit._weights = np.ones(n) / n
+    yd = ctx.tensor(y)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dev = sit._gaussianize(yd).splines
+        monkeypatch.setattr(SIT, '_build_on_device', lambda self, *a: None)
+        host = sit._gaussianize(yd).splines
+    assert [s.x.size for s in dev] == [s.x.size for s in host]
+    assert dev[1].x.size > 512          # (the discrete column: built by the host construction on both routes)
+    for a, b in zip(dev, host):
+        np.testing.assert_array_equal(a.x, b.x)
+        np.testing.assert_allclose(a.y, b.y, rtol=0, atol=1e-10, equal_nan=True)
