@@ -72,8 +72,7 @@ bool bf_split_supports(const DevModel &m, const SamplerArgs &args) {
 #ifdef BF_ONLY_HEADLINE
     if (m.DP != 64) return false;
 #endif
-    // (the decay term only where its matrix and centre are the bound's: DevModel.decay_shared, bfhip_split.h)
-    return m.DP <= 64 && args.cfg.sampler == 0 && m.has_quad && m.use_bound && (!m.use_decay || (m.decay_shared && !bf_tune().no_decay_shared)) && !m.has_transform &&
+    return m.DP <= 64 && args.cfg.sampler == 0 && m.has_quad && m.use_bound && !m.use_decay && !m.has_transform &&
            !m.has_su && !m.has_cubic && !m.has_link && !args.mat &&
            args.nslot >= (m.DP == 64 ? SplitGeoT<4>::scratch_slots() : (m.DP == 32 ? SplitGeoT<2>::scratch_slots() : SplitGeoT<1>::scratch_slots()));
 }

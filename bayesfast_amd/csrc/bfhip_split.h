@@ -101,9 +101,7 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
     const int chain = bf_group() * 16 + c;
     const bool real = chain < a.n_chain;
     const int d = m.d, dbase = 16 * j + gq;
-    // (round 6: with the decay term on the bound's matrix -- DevModel.decay_shared, the only decay this kernel takes -- a point proven
-    // inside the SMALLER of the two ellipsoids needs neither the bound's sums nor the decay term)
-    const double bound_thr = ((m.use_decay && m.decay_alpha2 < m.alpha * m.alpha) ? m.decay_alpha2 : m.alpha * m.alpha) * (1. - 1e-9);
+    const double bound_thr = m.alpha * m.alpha * (1. - 1e-9);
     double *tvb = TV + dbase * 16 + c;
     double *vxb = VARX + dbase * 16 + c;
     double *sbase = a.scratch + ((size_t)(real ? chain : 0) * a.nslot) * DP + dbase;
@@ -403,21 +401,6 @@ BF_DEV void bf_split_body(const DevModel &m, const SamplerArgs &a, double *lds) 
                             t_kin[r] = pn[r] * (var[r] * pn[r]);
                         }
                         oob = true;
-                    }
-                    if (m.use_decay) {
-                        // the decay term on the bound's matrix (density.py:740-746 with H_d = H, mu_d = mu: bfhip_nuts_pipe.h, DEC = 2): its
-                        // radius is the bound's sum, its gradient the bound's product
-                        const double ex = r_b2 - m.decay_alpha2;
-                        f -= m.decay_gamma * (ex > 0. ? ex : (ex != ex ? ex : 0.));
-                        if (r_b2 > m.decay_alpha2) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                ge[r] -= 2. * m.decay_gamma * hv[r];
-                                pn[r] = bf_fma(dt_c, ge[r], p[r]);
-                                t_kin[r] = pn[r] * (var[r] * pn[r]);
-                            }
-                            oob = true;   // (the kinetic energy is posted again below)
-                        }
                     }
                     fin = true;
                     have_lp = true;
