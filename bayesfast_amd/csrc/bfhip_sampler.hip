@@ -1946,11 +1946,18 @@ template <int W, int DEC, int FORM> constexpr int lone_threads() { return LoneWa
 
 template <int W, bool TR, int DEC, int FORM>
 static int lone_blocks_per_cu(bfhip_ctx *ctx) {
+    // (asked once per instantiation and device, not at every launch: two runtime calls each)
+    static int cached[64];
+    static bool have[64];
+    const int dev = (ctx->device >= 0 && ctx->device < 64) ? ctx->device : 0;
+    if (have[dev]) return cached[dev];
     const size_t lds = LoneGeo<W, DEC>::n_doubles * sizeof(double);
     int nb = 0;
     const void *k = lone_kernel_ptr<W, TR, DEC, FORM>();
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, lone_threads<W, DEC, FORM>(), lds) != hipSuccess) return 0;
+    cached[dev] = nb;
+    have[dev] = true;
     return nb;
 }
 
