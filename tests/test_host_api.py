@@ -470,3 +470,26 @@ def test_input_scales_fold_into_a_quadratic_surrogate_and_its_bound():
     # ... and so does a range far from the origin in units of its width (cancellation in the folded form)
     ds4, keep4 = density_desc_from_spec(dict(spec, su_lo=lo + 1000.))
     assert bool(ds4.su_lo) and bool(ds4.su_diff)
+
+
+def test_decay_shares_bound_and_the_flop_count_follow_the_arrays():
+    """The decay term's statistics are the bound's when both come from the same points (core/density.py:796-811 and
+    modules/poly.py:262-276 are the same statements): `decay_shares_bound` is the comparison the upload makes, and the algorithmic
+    flops of a leapfrog step count the shared product once."""
+    from bayesfast_amd.workloads import decay_shares_bound, flops_per_leapfrog_spec
+    rng = np.random.default_rng(1)
+    d = 6
+    xs = rng.normal(size=(200, d))
+    cfgs = [dict(order='linear', input_mask=np.arange(d), output_mask=np.arange(1), coef=rng.normal(size=(1, d + 1))),
+            dict(order='quadratic', input_mask=np.arange(d), output_mask=np.arange(1), coef=np.triu(rng.normal(size=(d, d)))[None] * -0.3)]
+    poly = dict(input_size=d, output_size=1, configs=cfgs, use_bound=False)
+    poly.update(orc.set_bound(poly, xs, rng.normal(size=xs.shape[0]), dict(alpha_p=80.)))
+    spec = dict(d=d, poly=poly)
+    assert not decay_shares_bound(spec) and flops_per_leapfrog_spec(spec) == 4 * d * d
+    same = dict(spec, **orc.set_decay(xs, alpha_p=150.))
+    assert np.array_equal(same['decay_hess'], poly['hess']) and np.array_equal(same['decay_mu'], poly['mu'])
+    assert decay_shares_bound(same) and flops_per_leapfrog_spec(same) == 4 * d * d
+    other = dict(spec, **orc.set_decay(xs * 0.9, alpha_p=150.))
+    assert not decay_shares_bound(other) and flops_per_leapfrog_spec(other) == 6 * d * d
+    moved = dict(same, decay_mu=same['decay_mu'] + 1e-300)     # (bit for bit: the smallest change counts)
+    assert decay_shares_bound(moved) == bool(np.array_equal(moved['decay_mu'], poly['mu']))
