@@ -321,6 +321,41 @@ def test_config4_funnel_target_accept_095():
     assert acc > 0.85, acc
 
 
+@pytest.mark.parametrize('kernel', ['latency', 'pipelined'])
+def test_decay_term_on_the_bounds_matrix_against_the_oracle(kernel):
+    """The regime of config 3's second round at an oracle-affordable size: the banana's quadratic surrogate with the decay term (its
+    centre and Hessian the bound's), chains started outside the bound so that their leaves are extrapolated (modules/poly.py:480-503) and
+    the decay term is on -- the two-matrix forms of the latency kernel and of the pipelined kernel against the oracle's chains (which
+    evaluate the decay term with its own matrix, as the reference does): trees, divergences, positions."""
+    from bayesfast_amd import PolyModel, SurrogateDensity, sample, NTrace, _lib
+    from bayesfast_amd._lib import debug_set
+    from bayesfast_amd.workloads import banana_logp
+    D = 64
+    logp = banana_logp(D)
+    su = PolyModel('quadratic', input_size=D, output_size=1)
+    den = SurrogateDensity(su, decay_options=dict(use_decay=True))
+    rng = np.random.default_rng(8)
+    x_fit = rng.normal(size=(2 * su.n_param, D))
+    den.fit(x_fit, logp(x_fit))
+    assert np.array_equal(den._hess, su._hess)
+    x0 = x_fit[:64] * 1.8                                       # beyond the alpha-ellipsoid of the fit points
+    xm = x0 - su._mu
+    assert (np.sqrt(np.einsum('ij,jk,ik->i', xm, su._hess, xm)) > su._alpha).mean() > 0.9
+    try:
+        debug_set('no_group', 1)
+        if kernel == 'pipelined':
+            debug_set('lone', 0)
+            debug_set('wave_cpg', 16)
+        tt = sample(den, NTrace(n_chain=64, n_iter=14, n_warmup=8, x_0=x0, random_generator=21), verbose=False, layout='wave')
+        name = _lib.last_kernel()
+    finally:
+        for k, v in (('lone', 1), ('wave_cpg', 0), ('no_group', 0)):
+            debug_set(k, v)
+    assert name.startswith('bf_lone_kernel<4, false, 2,' if kernel == 'latency' else 'bf_nuts_pipe_kernel<4, false, 2,'), name
+    _compare_chains_with_oracle(tt, den, 21, (0, 31, 63), 14, 8)
+    assert tt.stat('tree_size').max() >= 15
+
+
 @pytest.mark.parametrize('n_chain', [70, 600])
 def test_decay_term_on_the_bounds_matrix(n_chain):
     """SurrogateDensity.fit takes the decay term's centre and Hessian from the same points, by the same statements, as the bound's
