@@ -323,6 +323,15 @@ def test_sample_then_gbs_end_to_end_on_a_gaussian_surrogate():
         logz_a, err_a = bfa.GBS(sit=dict(random_generator=5), n_q=12000)(tt.get(flatten=False), den.logp)
     assert abs(logz - logz_h) < 1e-9 and abs(err - err_h) < 1e-9 * err
     assert abs(logz_a - logz_h) < 1e-9
+    # logp_p given (evidence/gaussianized.py:203-211): used when its shape fits, recomputed (with the reference's warning) when not
+    lp = tt.get(return_type='logp', flatten=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        logz_k, _ = bfa.GBS(sit=dict(random_generator=5), n_q=12000)(tt, den.logp, logp_p=lp)
+    assert abs(logz_k - logz) < 1e-6
+    with pytest.warns(RuntimeWarning, match='seems not correct'):
+        logz_w, _ = bfa.GBS(sit=dict(random_generator=5), n_q=12000)(tt, den.logp, logp_p=lp[:, :-1])
+    assert abs(logz_w - logz) < 1e-9
 
 
 @pytest.mark.gpu
