@@ -528,3 +528,38 @@ def test_device_spline_build_edge_columns_follow_the_host_construction(monkeypat
     for a, b in zip(dev, host):
         np.testing.assert_array_equal(a.x, b.x)
         np.testing.assert_allclose(a.y, b.y, rtol=0, atol=1e-10, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_sit_fit_on_a_device_tensor_is_the_fit_on_the_array():
+    """SIT.fit takes the data as a device tensor too (GBS's device route hands it the samples where sample() left them): the same
+    model as from the host array -- rotations, log-determinants, logq -- and the same argument checks."""
+    import torch
+    from bayesfast_amd.transforms import SIT
+    from bayesfast_amd.device import get_context
+    ctx = get_context(0)
+    rng = np.random.default_rng(12)
+    x = rng.laplace(size=(6000, 5)) @ (np.eye(5) + 0.3 * rng.normal(size=(5, 5)))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a = SIT(n_iter=2, random_generator=4)
+        a.fit(x)
+        b = SIT(n_iter=2, random_generator=4)
+        b.fit(ctx.tensor(x).reshape(3, 2000, 5))          # (chain, iteration, d) as a TraceTuple holds it
+    np.testing.assert_array_equal(a._A, b._A)
+    np.testing.assert_array_equal(a._logdetA, b._logdetA)
+    pts = rng.normal(size=(50, 5))
+    np.testing.assert_allclose(a.logq(pts), b.logq(pts), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b._logq_device(ctx.tensor(pts)).cpu().numpy(), b.logq(pts), rtol=0, atol=1e-11)
+    xs = b._sample_device(300)
+    assert isinstance(xs, torch.Tensor) and xs.shape == (300, 5) and bool(torch.isfinite(xs).all())
+    np.testing.assert_allclose(xs.cpu().numpy(), b.sample(300)[0], rtol=0, atol=1e-12)     # (the same Sobol points)
+    with pytest.raises(ValueError):
+        SIT().fit(ctx.tensor(x[:, :1]))                   # one variable: nothing to rotate
+    with pytest.raises(ValueError):
+        SIT().fit(ctx.tensor(x[:0]))
+    c = SIT(n_iter=1, random_generator=4, mvn_generator=lambda m, c_, n: rng.normal(size=(n, m.size)))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        c.fit(x)
+    assert c._sample_device(10) is None                   # a user's generator: the host route draws
