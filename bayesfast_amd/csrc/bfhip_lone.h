@@ -355,18 +355,6 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
                 const double E_new = 0.5 * kin - logp_new;  // integration.py:92-93
                 if (lane_ok) { LF[lane] = q; LF[DP + lane] = p; LF[2 * DP + lane] = g; }
                 if (lane == 0) { LF[3 * DP] = E_new; LF[3 * DP + 1] = logp_new; }
-                // The exponential of this leaf's multinomial weight (nuts.py:126-127), for the bookkeeper: its longest chain of
-                // dependent instructions (~0.9 k cycles of its 4.3 k per trip, and the bookkeeper is what the trip waits for:
-                // profiles/r06d_lone_trace.log), taken here where this wave would otherwise wait at B0.  The same expression on the
-                // same numbers: the tree's start energy and the weights' offset are the bookkeeper's, published in VD[1] / LF[3 DP + 3]
-                // whenever it sets them (before a barrier that precedes this read).
-                {
-                    const double se_ = VD[1], wo_ = LF[3 * DP + 3];
-                    double dE_ = E_new - rfl(se_);
-                    if (dE_ != dE_) dE_ = INFINITY;
-                    const double e_aw_ = LN_EXPV(-dE_ - rfl(wo_));
-                    if (lane == 0) LF[3 * DP + 2] = e_aw_;
-                }
             }
             LTRACE(0, 6);
 #ifdef BF_LTRACE
@@ -393,7 +381,7 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
     double eps = 0.;
     int dir = 1, depth = 0, i_leaf = 0, n_prop = 0, diverged = 0;
     double start_energy = 0., acc_sum = 0., T_W = 0., T_acc = 0., max_de = 0., w_off = 0., L0_W = 0., L0_acc = 0.;
-    double E_pend = 0., lp_pend = 0., ew_pend = 0.;
+    double E_pend = 0., lp_pend = 0.;
     double log_step, log_bar, hbar, smu, count, step_now, step_bar;
     double prop_E = 0., prop_logp = 0., tree_W = 0., T_E = 0., T_logp = 0.;
     unsigned long long nlf = 0;
@@ -447,7 +435,6 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
             return false;
         }
         start_energy = E0;
-        if (lane == 0) { VD[1] = E0; LF[3 * DP + 3] = 0.; }   // (the weight's mailbox, for the integrator's exponential)
         stv(SL_LEFT_Q, q); stv(SL_LEFT_P, p); stv(SL_LEFT_G, g);
         stv(SL_RIGHT_Q, q); stv(SL_RIGHT_P, p); stv(SL_RIGHT_G, g);
         stv(SL_PROP_Q, q); stv(SL_PSUM, p);
@@ -486,7 +473,6 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
         }
         if (lane < 5) WF[4 * DP + lane] = scp[BFHIP_SC_FG_N + lane];   // fg_n, bg_n, n_samples, previous_update, adapt_window
     }
-    if (lane == 0) { VD[1] = 0.; LF[3 * DP + 2] = 0.; LF[3 * DP + 3] = 0.; }   // (the weight's mailbox: start energy, exp, offset)
     if (i_iter < a.iter_end && err == 0) {
         draw_momentum();
         eps = (i_iter < nw) ? step_now : step_bar;
@@ -509,17 +495,15 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
             // the evaluation that opened the launch: BaseHMC.astep start, base_hmc.py:70-76
             q = lfv(0); p = lfv(1); g = lfv(2);
             const double E0 = rfl(LF[3 * DP]), logp0 = rfl(LF[3 * DP + 1]);
-            if (lane == 0) { VD[1] = E0; LF[3 * DP + 3] = 0.; }   // (the integrator reads them behind B2, for the tree's first leaf)
             KBAR(); KBAR();   // (the integrator parks nothing this trip; the tree's slots are written behind its phase A anyway)
             if (!init_tree(E0, logp0)) { kdone = true; }
         } else if (prev == LF_LEAF) {
             {   // (one round of LDS reads)
                 const double lq_ = lfv(0), lp_ = lfv(1), lg_ = lfv(2);
-                const double le_ = LF[3 * DP], ll_ = LF[3 * DP + 1], lw_ = LF[3 * DP + 2];
+                const double le_ = LF[3 * DP], ll_ = LF[3 * DP + 1];
                 TPq = lq_; TRp = lp_; TPg = lg_;
                 E_pend = rfl(le_);
                 lp_pend = rfl(ll_);
-                ew_pend = rfl(lw_);   // exp(-(E - start_energy) - w_off), taken by the integrator
             }
             LTRACE(1, 4);
             int unit = U_EVAL, lev = 0;
@@ -539,11 +523,11 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
             LTRACE(1, 11);
             KBAR();
             LTRACE(1, 10);
-            // The exponential of the multinomial weight (a dependent chain of ~25 FP64 instructions, 32-40 cycles each) arrives with
-            // the leaf since round 6 (the integrator takes it while it would wait for this wave); the U-turn sums of the level-0
-            // merge (nuts.py:150-151: they need the momenta only) are taken whether or not they will be used.
+            // One block for the two long chains of a leaf, so that the scheduler runs them side by side: the exponential of the
+            // multinomial weight (a dependent chain of ~25 FP64 instructions, 32-40 cycles each) and the U-turn sums of the level-0
+            // merge (nuts.py:150-151: they need the momenta only).  Both are taken whether or not they will be used.
             double aw = -dE - w_off;
-            const double e_aw = ew_pend;   // (= exp(aw): the integrator's, same expression, same numbers)
+            const double e_aw = LN_EXPV(aw);
             const double ps0 = L0p + TRp;
             double r2[2] = {ps0 * (var * L0p), ps0 * (var * TRp)};
             wave_sum_n<2>(r2);
@@ -557,7 +541,6 @@ __global__ __launch_bounds__((LoneWaves<W, DEC, FORM>::NW * 64), MINW) void bf_l
                         for (int l2 = 0; l2 < depth; ++l2) LS[l2 * LS_N + LS_LS] *= sc_;
                     L0_W *= sc_;
                     w_off = w_off + aw;
-                    if (lane == 0) LF[3 * DP + 3] = w_off;   // (published before this trip's second barrier)
                     aw = 0.;
                     T_W = 1.;   // exp(0)
                 }
