@@ -161,7 +161,8 @@ class DeviceChains:
                 tree, laggard = ans & 4095, ans >= 4096
                 in_step = sampler == 'HMC' or tree > 0
                 lay = IN_STEP_LAYOUT if in_step else 'wave'
-                if sampler == 'NUTS' and tree >= 24 and self._deep_trees_prefer_waves():
+                deep = self._deep_trees_prefer_waves()
+                if sampler == 'NUTS' and deep and tree >= deep:
                     lay = 'wave'
                 if sampler == 'NUTS' and self._small_problem():
                     lay = 'wave'
@@ -252,10 +253,21 @@ class DeviceChains:
         6.2 x 10^8, 15: 7.7 against 6.6, 31: 6.3 against 7.0, 1022 (config 3's second round): 5.8 -- 3.7 with ONE such chain -- against
         7.4 (tools/layout_ab.py, bench.py --workload banana_decay; docs/EXPERIMENTS.md).  From 24 leaves up 'auto' takes the wave
         layout there.  Behind the constraint transform the group kernel stays ahead (31 leaves: 6.6 against 5.0), and the plain
-        surrogate's split kernel too (10.6 against 9.2).  A function of the shapes only."""
+        surrogate's split kernel too (10.6 against 9.2).  Round 6: where the decay term's matrix is the bound's the wave layout runs two
+        matrices (bfhip_nuts_pipe.h, DEC = 2) and wins earlier -- 4096 chains, 15-leaf trees: d = 64 8.1 against 7.8 x 10^8, d = 32 9.0
+        against 5.7; 7-leaf trees stay with the group kernel (9.8 against 7.8, 8.2 against 7.9): profiles/r06_dispatch_sweep.log.
+        Returns the tree size from which 'auto' takes the wave layout (0: never).  A function of the shapes and the uploaded arrays only."""
         plain, featured, n = self._shape_facts()
         sp = self.density.spec
-        return featured and bool(sp.get('use_decay')) and 32 < self.d <= 64
+        if not (featured and bool(sp.get('use_decay'))):
+            return 0
+        from .workloads import decay_shares_bound
+        shared = decay_shares_bound(sp)
+        if 32 < self.d <= 64:
+            return 12 if shared else 24
+        if 16 < self.d <= 32 and shared:
+            return 12
+        return 0
 
     def _two_groups_fit_a_cu(self):
         """Trees in step at 17 <= d <= 32 with at least two 16-chain groups per CU: the group kernel's two waves and 75 KB of LDS
