@@ -259,6 +259,10 @@ class DeviceChains:
         Returns the tree size from which 'auto' takes the wave layout (0: never).  A function of the shapes and the uploaded arrays only."""
         plain, featured, n = self._shape_facts()
         sp = self.density.spec
+        if plain and 32 < self.d <= 64 and 4 * self._n_cu < n <= 8 * self._n_cu:
+            # (round 6 sweep, the one cell under 0.9: plain surrogate, 64-d x 2048 chains -- eight chains per CU, where the pipelined
+            # kernel's jobs run on 4 x 4 x 4 tiles -- 15-leaf trees: wave 6.1 against split 5.3 x 10^8; 7-leaf trees: 5.9 against 6.1)
+            return 12
         if not (featured and bool(sp.get('use_decay'))):
             return 0
         from .workloads import decay_shares_bound
